@@ -1,0 +1,169 @@
+"""ctypes mirrors of include/incr_types.h and include/incr.h (the C-ABI boundary).
+
+Field order and sizes must match the headers exactly; tests/test_abi.py checks sizeof() of every
+struct against the values the reference's gpu-shared-types.h implies (52/56/128/32/12/12 bytes).
+"""
+import ctypes as C
+
+c_float3 = C.c_float * 3
+c_float4 = C.c_float * 4
+
+
+class Matrix(C.Structure):
+    _fields_ = [("m", C.c_float * 16)]
+
+
+class MeshBufferView(C.Structure):
+    _fields_ = [("bufferSrvIndex", C.c_int32), ("byteOffset", C.c_uint32), ("byteLength", C.c_uint32)]
+
+
+class MeshAccessor(C.Structure):
+    _fields_ = [("bufferViewIndex", C.c_int32), ("byteOffset", C.c_uint32), ("byteStride", C.c_uint32)]
+
+
+class GpuPrimitive(C.Structure):
+    _fields_ = [("boundingSphere", c_float4), ("meshIndex", C.c_int32), ("indexAccessor", C.c_int32),
+                ("positionAccessor", C.c_int32), ("uvAccessor", C.c_int32), ("normalAccessor", C.c_int32),
+                ("tangentAccessor", C.c_int32), ("materialIndex", C.c_int32), ("indicesPerTriangle", C.c_int32),
+                ("indexCount", C.c_int32)]
+
+
+class GpuMeshlet(C.Structure):
+    _fields_ = [("vertexBegin", C.c_uint32), ("vertexCount", C.c_uint32), ("triangleBegin", C.c_uint32),
+                ("triangleCount", C.c_uint32), ("boundingSphere", c_float4), ("meshIndex", C.c_int32),
+                ("positionAccessor", C.c_int32), ("uvAccessor", C.c_int32), ("normalAccessor", C.c_int32),
+                ("tangentAccessor", C.c_int32), ("materialIndex", C.c_int32)]
+
+
+_MAT_TEX = ["emissive", "baseColor", "metallicRoughness", "normal", "ao", "transmission", "clearcoat",
+            "clearcoatRoughness", "clearcoatNormal"]
+
+
+class Material(C.Structure):
+    _fields_ = ([("emissiveFactor", c_float3), ("baseColorFactor", c_float3), ("metallicFactor", C.c_float),
+                 ("roughnessFactor", C.c_float), ("aoStrength", C.c_float), ("transmissionFactor", C.c_float),
+                 ("clearcoatFactor", C.c_float), ("clearcoatRoughnessFactor", C.c_float)]
+                + [(n + "TextureIndex", C.c_int32) for n in _MAT_TEX]
+                + [(n + "SamplerIndex", C.c_int32) for n in _MAT_TEX]
+                + [("alphaMode", C.c_int32), ("doubleSided", C.c_int32)])
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", c_float3), ("intensity", C.c_float), ("range", C.c_float),
+                ("spotAngles", C.c_float * 2)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("culledObjects", C.c_int32), ("culledLights", C.c_int32)]
+
+
+class PerezDistribution(C.Structure):
+    _fields_ = [("A", c_float4), ("B", c_float4), ("C", c_float4), ("D", c_float4), ("E", c_float4)]
+
+
+class LightGridData(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("count", C.c_uint32)]
+
+
+TEX_RGBA8_UNORM, TEX_RGBA8_SRGB, TEX_RG_SNORM, TEX_BGRA8_SWIZZLE_RG = 0, 1, 2, 3
+ALPHA_OPAQUE, ALPHA_MASKED, ALPHA_BLEND = 0, 1, 2
+LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT = 0, 1, 2
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("num_buffers", C.c_uint32), ("buffers", C.POINTER(C.c_void_p)), ("buffer_sizes", C.POINTER(C.c_uint64)),
+        ("num_buffer_views", C.c_uint32), ("buffer_views", C.POINTER(MeshBufferView)),
+        ("num_accessors", C.c_uint32), ("accessors", C.POINTER(MeshAccessor)),
+        ("num_meshes", C.c_uint32), ("primitive_counts", C.POINTER(C.c_uint32)),
+        ("mesh_transforms", C.POINTER(Matrix)), ("mesh_visibility", C.POINTER(C.c_uint32)),
+        ("num_primitives", C.c_uint32), ("primitives", C.POINTER(GpuPrimitive)),
+        ("num_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+        ("num_textures", C.c_uint32), ("textures", C.POINTER(TextureDesc)),
+        ("num_meshlets", C.c_uint32), ("meshlets", C.POINTER(GpuMeshlet)),
+        ("num_meshlet_vertex_indices", C.c_uint32), ("meshlet_vertex_indices", C.POINTER(C.c_uint32)),
+        ("num_meshlet_triangles", C.c_uint32), ("meshlet_packed_triangles", C.POINTER(C.c_uint32)),
+        ("num_global_lights", C.c_uint32), ("global_lights", C.POINTER(Light)),
+        ("num_scene_lights", C.c_uint32), ("light_indices", C.POINTER(C.c_int32)),
+        ("light_transforms", C.POINTER(Matrix)),
+        ("root_transform", Matrix),
+        ("sun_dir", c_float3), ("reserved", C.c_uint32),
+    ]
+
+
+class View(C.Structure):
+    _fields_ = [("view_transform", Matrix), ("projection_transform", Matrix), ("position", c_float3),
+                ("right", c_float3), ("up", c_float3), ("look", c_float3), ("fov", C.c_float)]
+
+
+class Shard(C.Structure):
+    _fields_ = [("row_block_height", C.c_uint32), ("row_block_first", C.c_uint32), ("row_block_stride", C.c_uint32)]
+
+
+class RayStats(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("sky_shadow_rays", C.c_uint64),
+                ("light_shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+    def total_rays(self):
+        return self.camera_rays + self.bounce_rays + self.sky_shadow_rays + self.light_shadow_rays
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("num_triangles", C.c_uint64), ("num_bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64),
+                ("triangle_bytes", C.c_uint64), ("shading_bytes", C.c_uint64), ("texture_bytes", C.c_uint64),
+                ("num_instances", C.c_uint32), ("bvh_max_depth", C.c_uint32)]
+
+
+class PathtraceDesc(C.Structure):
+    _fields_ = [
+        ("scene", C.c_void_p), ("target_rgba16f", C.c_void_p), ("history_r11g11b10", C.c_void_p),
+        ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("shard", Shard),
+        ("current_sample_index", C.c_uint32), ("max_sample_count", C.c_uint32),
+        ("view", View),
+        ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
+        ("env_sky_mode", C.c_int32), ("direct_lighting", C.c_int32), ("viewmode", C.c_int32),
+        ("turbidity", C.c_float), ("sky_brightness", C.c_float), ("storage_rounding", C.c_int32),
+        ("ray_stats", C.c_void_p),
+    ]
+
+
+class TonemapDesc(C.Structure):
+    _fields_ = [("hdr_r11g11b10", C.c_void_p), ("ldr_rgba8", C.c_void_p), ("res_x", C.c_uint32), ("rows", C.c_uint32),
+                ("exposure", C.c_float), ("viewmode", C.c_int32)]
+
+
+# FConfig defaults the hot path reads (reference: source/demo-dll/inc/common.h:6-48)
+class FConfig:
+    Fov = 0.25 * 3.14159265358979323846
+    Exposure = 13.0
+    CameraNearPlane = 1.0
+    Viewmode = 0
+    EnvSkyMode = 1
+    SkyBrightness = 25000.0
+    EnableDirectLighting = True
+    EnableSkyLighting = True
+    EnableDiffuseIBL = True
+    EnableSpecularIBL = True
+    PathTrace = False
+    ForwardLighting = False
+    FrustumCulling = True
+    EnableTAA = True
+    EnableHBAO = False
+    UseMeshlets = True
+    LightClusterDimX, LightClusterDimY, LightClusterDimZ = 16, 9, 24
+    MaxLightsPerCluster = 64
+    ClusterDepthExtent = 200.0
+    MaxSampleCount = 256
+    Pathtracing_CameraAperture = 0.01
+    Pathtracing_CameraFocalLength = 7.0
+    Turbidity = 2.0
+    ToD_Enable = True
+    ToD_DecimalHours = 11.0
+    ToD_JulianDate = 200
+    ToD_Latitude = 42.5
+    EnvmapResolution = 256

@@ -1,0 +1,140 @@
+/*
+ * incr.h -- C ABI of libincr_hip.so: the MI355X-native replacement for the D3D12 dispatches of
+ * Incarnation-Renderer's render loop.  One entry point per reference render pass; each takes a POD
+ * `incr_<pass>_desc` that mirrors the pass's `RenderJob::<Pass>::Desc` (raw device pointers instead of
+ * bindless descriptor indices, scalars copied from FConfig) and a HIP stream.  All GPU work of a
+ * frame is enqueued on that one stream in call order -- the reference's execution order
+ * (render-jobs/job-sync.h:27-61: token-ordered submission on one DIRECT queue).
+ *
+ * Error convention: every function returns 0 on success, a negative incr_status otherwise, and never
+ * aborts or throws (the reference has no error returns: inc/common.h:113-148).  incr_last_error() gives
+ * the message for the calling thread.  There is NO CPU fallback: without a HIP device every launch
+ * entry point returns INCR_ERR_NO_DEVICE.
+ *
+ * Citations are relative to /root/reference/source/demo-dll/.
+ */
+#ifndef INCR_H
+#define INCR_H
+
+#include "incr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum incr_status {
+    INCR_OK = 0,
+    INCR_ERR_INVALID_ARGUMENT = -1,
+    INCR_ERR_NO_DEVICE = -2,
+    INCR_ERR_HIP = -3,
+    INCR_ERR_OUT_OF_MEMORY = -4,
+    INCR_ERR_NOT_INITIALIZED = -5
+} incr_status;
+
+typedef struct incr_context incr_context;   /* one per process/GPU; stands in for RenderBackend12 (inc/backend-d3d12.h:478-536) */
+typedef struct incr_scene incr_scene;       /* device-resident FScene (inc/scene.h:72-159) */
+typedef void* incr_stream;                  /* hipStream_t; NULL = the default stream */
+
+/* ---- lifetime: shape of the DLL exports Initialize/Teardown (inc/demo-interface.h:10-16), headless ---- */
+int  incr_initialize(int device_index, incr_context** out_ctx);
+int  incr_teardown(incr_context* ctx);
+const char* incr_last_error(void);
+const char* incr_version(void);
+int  incr_device_count(void);               /* number of HIP devices visible (0 on a CPU-only box) */
+
+/* ---- resource layer: RenderBackend12::CreateNewShaderBuffer / CreateNewShaderSurface stand-ins ---- */
+int  incr_buffer_create(incr_context* ctx, uint64_t bytes, void** out_device_ptr);
+int  incr_buffer_destroy(incr_context* ctx, void* device_ptr);
+int  incr_buffer_upload(incr_context* ctx, void* device_dst, const void* host_src, uint64_t bytes, incr_stream stream);
+int  incr_buffer_download(incr_context* ctx, void* host_dst, const void* device_src, uint64_t bytes, incr_stream stream);
+int  incr_buffer_clear(incr_context* ctx, void* device_dst, uint32_t value32, uint64_t bytes, incr_stream stream);
+int  incr_stream_synchronize(incr_context* ctx, incr_stream stream);
+
+/* ---- scene: FScene::CreateGpuGeometryBuffers + CreateAccelerationStructures (src/scene.cpp:480-848) ---- */
+int  incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene** out_scene);
+int  incr_scene_destroy(incr_context* ctx, incr_scene* scene);
+/* RenderJob::UpdateTLASPass::Execute (render-jobs/update-tlas.inl:3-101): re-derive the world-space
+ * acceleration structure when mesh transforms / visibility / root transform changed.  Pass NULL to keep a field. */
+int  incr_update_bvh(incr_context* ctx, incr_scene* scene, const incr_matrix* mesh_transforms,
+                     const uint32_t* mesh_visibility, const incr_matrix* root_transform, incr_stream stream);
+/* FScene::m_sunDir (scene.cpp:1594-1655 UpdateSunDirection) -- feeds the dynamic-sky environment. */
+int  incr_scene_set_sun_dir(incr_context* ctx, incr_scene* scene, const float sun_dir[3]);
+/* Introspection used by tests and the bench (sizes of the flattened acceleration structure). */
+typedef struct incr_scene_info {
+    uint64_t num_triangles, num_bvh_nodes, bvh_bytes, triangle_bytes, shading_bytes, texture_bytes;
+    uint32_t num_instances, bvh_max_depth;
+} incr_scene_info;
+int  incr_scene_get_info(incr_context* ctx, const incr_scene* scene, incr_scene_info* out_info);
+
+/*
+ * Framebuffer sharding: the frame is cut into row blocks of `row_block_height` rows;
+ * this call renders blocks row_block_first, row_block_first + row_block_stride, ... and stores them
+ * COMPACTLY (local row = k*row_block_height + r) in buffers of local_rows = incr_shard_local_rows() rows.
+ * row_block_height == 0 means "the whole frame" (one rank).  Sampler keys always use the FULL frame
+ * (pixelIdx = y*res_x + x, numPixels = res_x*res_y; shaders/raytracing/common.hlsli:10-11), so a shard is
+ * bit-identical to the same pixels of a single-GPU frame.
+ */
+typedef struct incr_shard {
+    uint32_t row_block_height;
+    uint32_t row_block_first;
+    uint32_t row_block_stride;
+} incr_shard;
+uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* shard);
+
+/* Ray statistics (SURVEY.md 8d "Ray count"): every traversal query, by category. */
+typedef struct incr_ray_stats {
+    uint64_t camera_rays;       /* TraceRay from rgsMain                      (pathtracing.hlsl:117) */
+    uint64_t bounce_rays;       /* TraceRay from chsMain                      (pathtracing.hlsl:265) */
+    uint64_t sky_shadow_rays;   /* RayQuery in GetSkyRadiance                 (lighting/common.hlsli:161-174) */
+    uint64_t light_shadow_rays; /* RayQuery in GetDirectRadiance              (lighting/common.hlsli:102-115) */
+    uint64_t shaded_hits;       /* chsMain invocations */
+    uint64_t reserved[3];
+} incr_ray_stats;
+
+/*
+ * RenderJob::PathTracing::Execute (render-jobs/path-tracing.inl:17-299) == clear target, DispatchRays(W,H,1)
+ * (rgsMain/chsMain/ahsMain/ms* of shaders/raytracing/pathtracing.hlsl), then the 16x16 integrate dispatch
+ * (shaders/raytracing/pathtrace-integrate.hlsl).  Desc mirrors path-tracing.inl:3-15 + the FConfig fields read.
+ */
+typedef struct incr_pathtrace_desc {
+    const incr_scene* scene;
+    void*    target_rgba16f;         /* device, local_rows*res_x*8 B   (Desc::targetBuffer, RGBA16F)           */
+    void*    history_r11g11b10;      /* device, local_rows*res_x*4 B   (Desc::historyBuffer, R11G11B10_FLOAT)  */
+    uint32_t res_x, res_y;           /* FULL frame resolution (Desc::resX/resY)                                */
+    incr_shard shard;
+    uint32_t current_sample_index;   /* Desc::currentSampleIndex: 1 .. MaxSampleCount-1 (renderer.cpp:23,1681-1699) */
+    uint32_t max_sample_count;       /* FConfig::MaxSampleCount (256) -> sqrtSampleCount = (uint)sqrt            */
+    incr_view view;                  /* Desc::view: viewTransform + projectionTransform                          */
+    float    camera_aperture;        /* FConfig::Pathtracing_CameraAperture (0.01)                               */
+    float    camera_focal_length;    /* FConfig::Pathtracing_CameraFocalLength (7)                               */
+    int32_t  env_sky_mode;           /* FConfig::EnvSkyMode: 1 = dynamic sky (msDynamicSky); 0 = envmap (unsupported first cut) */
+    int32_t  direct_lighting;        /* FConfig::EnableDirectLighting -> DIRECT_LIGHTING macro                   */
+    int32_t  viewmode;               /* FConfig::Viewmode -> VIEWMODE macro (0..5)                               */
+    float    turbidity;              /* FConfig::Turbidity (2)                                                   */
+    float    sky_brightness;         /* FConfig::SkyBrightness (25000)                                           */
+    int32_t  storage_rounding;       /* 0 = round-toward-zero typed-UAV stores (D3D11.3 spec 3.2.3.3), 1 = nearest-even */
+    incr_ray_stats* ray_stats;       /* device, optional (NULL = do not count); ACCUMULATED, caller clears        */
+} incr_pathtrace_desc;
+int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);
+
+/*
+ * RenderJob::TonemapPass::Execute (render-jobs/tonemap.inl:11-136; shaders/postprocess/tonemap.hlsl:30-59):
+ * ldr = ACESFilm(hdr * Exposure(ev100)), written to an R8G8B8A8_UNORM_SRGB back buffer (sRGB encode on store).
+ */
+typedef struct incr_tonemap_desc {
+    const void* hdr_r11g11b10;       /* device, rows*res_x*4 B  (Desc::source: path-trace history or TAA output) */
+    void*    ldr_rgba8;              /* device, rows*res_x*4 B  (back buffer)                                     */
+    uint32_t res_x, rows;
+    float    exposure;               /* FConfig::Exposure (13.0); truncated to int ev100 (lighting/pbr.hlsli:78-81) */
+    int32_t  viewmode;
+} incr_tonemap_desc;
+int  incr_tonemap(incr_context* ctx, const incr_tonemap_desc* desc, incr_stream stream);
+
+/* Un-interleave gathered shards: src is [stride][local_rows][res_x] texels of `texel_bytes`, dst the full frame. */
+int  incr_unshard(incr_context* ctx, void* dst_full, const void* src_gathered, uint32_t res_x, uint32_t res_y,
+                  uint32_t row_block_height, uint32_t num_shards, uint32_t texel_bytes, incr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCR_H */

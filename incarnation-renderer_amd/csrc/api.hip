@@ -1,0 +1,361 @@
+// api.hip -- the C ABI of libincr_hip.so (include/incr.h): context, resource layer, scene upload and the
+// per-pass entry points.  Host code only; kernels live in pathtrace.hip / raster.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/incr.h"
+#include "device_types.h"
+#include "host_math.h"
+#include "pt_params.h"
+#include "scene_build.h"
+
+using namespace incr;
+
+extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
+extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
+                                          uint32_t localRows, uint32_t texelBytes, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? INCR_ERR_OUT_OF_MEMORY : INCR_ERR_HIP, \
+                                 "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct incr_context {
+    int device;
+    hipDeviceProp_t props;
+    float* srgbLut;           // 256 floats in HBM
+};
+
+struct incr_scene {
+    incr_context* ctx;
+    HostScene host;
+    HostBvh bvh;
+    // device mirrors
+    BvhNode4* dNodes = nullptr; TriIsect* dTris = nullptr; TriShade* dShade = nullptr;
+    incr_material* dMaterials = nullptr; DeviceTexture* dTextures = nullptr;
+    float* dMeshLocalToWorld = nullptr;
+    incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
+    std::vector<void*> dTexels;
+    uint64_t textureBytes = 0;
+};
+
+extern "C" {
+
+const char* incr_last_error(void) { return g_err; }
+const char* incr_version(void) { return "incarnation-renderer_amd 0.1 (gfx950)"; }
+
+int incr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int incr_initialize(int device_index, incr_context** out_ctx) {
+    if (!out_ctx) return fail(INCR_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    const int n = incr_device_count();
+    if (n <= 0) return fail(INCR_ERR_NO_DEVICE, "no HIP device visible: the render path has no CPU fallback");
+    if (device_index < 0 || device_index >= n) return fail(INCR_ERR_INVALID_ARGUMENT, "device_index %d out of range (0..%d)", device_index, n - 1);
+    HIP_TRY(hipSetDevice(device_index));
+    incr_context* ctx = new (std::nothrow) incr_context();
+    if (!ctx) return fail(INCR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device_index;
+    HIP_TRY(hipGetDeviceProperties(&ctx->props, device_index));
+    // D3D sRGB -> linear table (D3D11.3 functional spec, sRGB read conversion): exact formula in double, one rounding
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        const double c = i / 255.0;
+        lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    HIP_TRY(hipMalloc((void**)&ctx->srgbLut, sizeof lut));
+    HIP_TRY(hipMemcpy(ctx->srgbLut, lut, sizeof lut, hipMemcpyHostToDevice));
+    *out_ctx = ctx;
+    return INCR_OK;
+}
+
+int incr_teardown(incr_context* ctx) {
+    if (!ctx) return INCR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
+    delete ctx;
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- resources
+int incr_buffer_create(incr_context* ctx, uint64_t bytes, void** out) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!out) return fail(INCR_ERR_INVALID_ARGUMENT, "out_device_ptr is NULL");
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 4));
+    return INCR_OK;
+}
+int incr_buffer_destroy(incr_context* ctx, void* p) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (p) HIP_TRY(hipFree(p));
+    return INCR_OK;
+}
+int incr_buffer_upload(incr_context* ctx, void* dst, const void* src, uint64_t bytes, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (bytes && (!dst || !src)) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return INCR_OK;
+}
+int incr_buffer_download(incr_context* ctx, void* dst, const void* src, uint64_t bytes, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (bytes && (!dst || !src)) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return INCR_OK;
+}
+int incr_buffer_clear(incr_context* ctx, void* dst, uint32_t value32, uint64_t bytes, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (bytes % 4) return fail(INCR_ERR_INVALID_ARGUMENT, "bytes must be a multiple of 4");
+    if (bytes) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dst, (int)value32, bytes / 4, (hipStream_t)stream));
+    return INCR_OK;
+}
+int incr_stream_synchronize(incr_context* ctx, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return INCR_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------- scene
+template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    HIP_TRY(hipMalloc((void**)dptr, std::max<size_t>(count, 1) * sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return INCR_OK;
+}
+
+static int upload_bvh(incr_scene* sc) {
+    int rc;
+    if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes.data(), sc->bvh.nodes.size()))) return rc;
+    if ((rc = upload_vec(&sc->dTris, sc->bvh.tris.data(), sc->bvh.tris.size()))) return rc;
+    if ((rc = upload_vec(&sc->dShade, sc->bvh.shade.data(), sc->bvh.shade.size()))) return rc;
+    if ((rc = upload_vec(&sc->dMeshLocalToWorld, (const float*)sc->bvh.meshLocalToWorld.data(), sc->bvh.meshLocalToWorld.size() * 16))) return rc;
+    return INCR_OK;
+}
+
+extern "C" {
+
+int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
+    if (!sc) return INCR_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : sc->dTexels) if (p) (void)hipFree(p);
+    delete sc;
+    return INCR_OK;
+}
+
+int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene** out) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!desc || !out) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    incr_scene* sc = new (std::nothrow) incr_scene();
+    if (!sc) return fail(INCR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    sc->ctx = ctx;
+    copy_scene_desc(*desc, sc->host);
+    const char* why = "";
+    if (!validate_scene(sc->host, &why)) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "scene desc rejected: %s", why); }
+    for (uint32_t i = 0; i < desc->num_materials; ++i) {
+        const incr_material& m = desc->materials[i];
+        const int32_t idx[9] = {m.emissiveTextureIndex, m.baseColorTextureIndex, m.metallicRoughnessTextureIndex, m.normalTextureIndex, m.aoTextureIndex,
+                                m.transmissionTextureIndex, m.clearcoatTextureIndex, m.clearcoatRoughnessTextureIndex, m.clearcoatNormalTextureIndex};
+        for (int32_t t : idx) if (t < -1 || t >= (int32_t)desc->num_textures) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "material %u: texture index %d out of range", i, t); }
+    }
+    build_world_bvh(sc->host, sc->bvh);
+    int rc = upload_bvh(sc);
+    if (!rc) rc = upload_vec(&sc->dMaterials, sc->host.materials.data(), sc->host.materials.size());
+    if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
+    if (!rc) rc = upload_vec(&sc->dLightIndices, sc->host.lightIndices.data(), sc->host.lightIndices.size());
+    if (!rc) rc = upload_vec(&sc->dLightTransforms, (const float*)sc->host.lightTransforms.data(), sc->host.lightTransforms.size() * 16);
+    std::vector<DeviceTexture> texs(desc->num_textures);
+    for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
+        const incr_texture_desc& t = desc->textures[i];
+        if (!t.texels || !t.width || !t.height || t.format > INCR_TEX_BGRA8_SWIZZLE_RG) { rc = fail(INCR_ERR_INVALID_ARGUMENT, "texture %u invalid", i); break; }
+        const size_t bytes = (size_t)t.width * t.height * 4;
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e == hipSuccess) e = hipMemcpy(d, t.texels, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "texture upload failed: %s", hipGetErrorString(e)); break; }
+        sc->dTexels.push_back(d);
+        sc->textureBytes += bytes;
+        texs[i].texels = (const uint8_t*)d; texs[i].width = t.width; texs[i].height = t.height; texs[i].format = t.format;
+        texs[i].pad[0] = texs[i].pad[1] = texs[i].pad[2] = 0;
+    }
+    if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
+    if (rc) { incr_scene_destroy(ctx, sc); return rc; }
+    *out = sc;
+    return INCR_OK;
+}
+
+int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_transforms, const uint32_t* mesh_visibility,
+                    const incr_matrix* root_transform, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc) return fail(INCR_ERR_INVALID_ARGUMENT, "scene is NULL");
+    bool dirty = false;
+    const size_t nm = sc->host.meshTransforms.size();
+    if (mesh_transforms)
+        for (size_t i = 0; i < nm; ++i) if (memcmp(sc->host.meshTransforms[i].m, mesh_transforms[i].m, 64)) { sc->host.meshTransforms[i] = m44_from(mesh_transforms[i]); dirty = true; }
+    if (mesh_visibility)
+        for (size_t i = 0; i < nm; ++i) if (sc->host.meshVisibility[i] != mesh_visibility[i]) { sc->host.meshVisibility[i] = mesh_visibility[i]; dirty = true; }
+    if (root_transform && memcmp(sc->host.rootTransform.m, root_transform->m, 64)) { sc->host.rootTransform = m44_from(*root_transform); dirty = true; }
+    if (!dirty) return INCR_OK;          // the reference rebuilds its TLAS every frame; ours only when an input changed
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    build_world_bvh(sc->host, sc->bvh);
+    return upload_bvh(sc);
+}
+
+int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_dir[3]) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc || !sun_dir) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    memcpy(sc->host.sunDir, sun_dir, 12);
+    return INCR_OK;
+}
+
+int incr_scene_get_info(incr_context* ctx, const incr_scene* sc, incr_scene_info* info) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc || !info) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    info->num_triangles = sc->bvh.tris.size();
+    info->num_bvh_nodes = sc->bvh.nodes.size();
+    info->bvh_bytes = sc->bvh.nodes.size() * sizeof(BvhNode4);
+    info->triangle_bytes = sc->bvh.tris.size() * sizeof(TriIsect);
+    info->shading_bytes = sc->bvh.shade.size() * sizeof(TriShade);
+    info->texture_bytes = sc->textureBytes;
+    info->num_instances = sc->bvh.numInstances;
+    info->bvh_max_depth = sc->bvh.maxDepth;
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- sharding
+uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* sh) {
+    if (!sh || sh->row_block_height == 0) return res_y;
+    const uint32_t nblk = (res_y + sh->row_block_height - 1) / sh->row_block_height;
+    const uint32_t stride = sh->row_block_stride ? sh->row_block_stride : 1;
+    if (sh->row_block_first >= nblk) return 0;
+    const uint32_t mine = (nblk - sh->row_block_first + stride - 1) / stride;
+    return mine * sh->row_block_height;
+}
+
+// ---------------------------------------------------------------------------------------------- passes
+// Per-frame Preetham sun terms (preetham.hlsli:53-89): depend only on the sun direction and turbidity.
+static float saturate_h(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+static void perez_from_turbidity(float t, incr_perez_distribution* p) {
+    // render-jobs/path-tracing.inl:134-140 (double literals * float t, rounded by the Vector4 constructor)
+    const double A[3] = {0.1787 * t - 1.4630, -0.0193 * t - 0.2592, -0.0167 * t - 0.2608};
+    const double B[3] = {-0.3554 * t + 0.4275, -0.0665 * t + 0.0008, -0.0950 * t + 0.0092};
+    const double C[3] = {-0.0227 * t + 5.3251, -0.0004 * t + 0.2125, -0.0079 * t + 0.2102};
+    const double D[3] = {0.1206 * t - 2.5771, -0.0641 * t - 0.8989, -0.0441 * t - 1.6537};
+    const double E[3] = {-0.0670 * t + 0.3703, -0.0033 * t + 0.0452, -0.0109 * t + 0.0529};
+    for (int i = 0; i < 3; ++i) { p->A[i] = (float)A[i]; p->B[i] = (float)B[i]; p->C[i] = (float)C[i]; p->D[i] = (float)D[i]; p->E[i] = (float)E[i]; }
+    p->A[3] = p->B[3] = p->C[3] = p->D[3] = p->E[3] = 0.f;
+}
+static void sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, SkySun* out) {
+    const float cosS = saturate_h(s[1]);
+    const float thetaS = acosf(cosS);
+    const float k_Pi = 3.14159265358979323846f;
+    const float chi = (4.f / 9.f - t / 120.f) * (k_Pi - 2.f * thetaS);
+    const float Yz = (4.0453f * t - 4.9710f) * tanf(chi) - 0.2155f * t + 2.4192f;
+    const float theta2 = thetaS * thetaS, theta3 = theta2 * thetaS, T = t, T2 = t * t;
+    const float xz = (0.00165f * theta3 - 0.00375f * theta2 + 0.00209f * thetaS + 0.0f) * T2 +
+                     (-0.02903f * theta3 + 0.06377f * theta2 - 0.03202f * thetaS + 0.00394f) * T +
+                     (0.11693f * theta3 - 0.21196f * theta2 + 0.06052f * thetaS + 0.25886f);
+    const float yz = (0.00275f * theta3 - 0.00610f * theta2 + 0.00317f * thetaS + 0.0f) * T2 +
+                     (-0.04214f * theta3 + 0.08970f * theta2 - 0.04153f * thetaS + 0.00516f) * T +
+                     (0.15346f * theta3 - 0.26756f * theta2 + 0.06670f * thetaS + 0.26688f);
+    out->s[0] = s[0]; out->s[1] = s[1]; out->s[2] = s[2];
+    out->YxyZenith[0] = Yz; out->YxyZenith[1] = xz; out->YxyZenith[2] = yz;
+    // Perez(0, thetaS): cos(0) = 1, gamma = thetaS, cos(gamma) = cosS
+    for (int i = 0; i < 3; ++i) {
+        const float e1 = expf(pc.B[i] / 1.f), e2 = expf(pc.D[i] * thetaS);
+        out->F0[i] = (1.0f + pc.A[i] * e1) * ((1.0f + pc.C[i] * e2) + (pc.E[i] * cosS) * cosS);
+    }
+    out->pad[0] = out->pad[1] = out->pad[2] = 0.f;
+}
+
+int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    if (!d->res_x || !d->res_y) return fail(INCR_ERR_INVALID_ARGUMENT, "zero resolution");
+    if ((uint64_t)d->res_x * d->res_y > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "resolution overflows the 32-bit pixel index of the sampler");
+    if (d->env_sky_mode != 1) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode %d unsupported: only the dynamic (Preetham) sky is implemented", d->env_sky_mode);
+    if (d->viewmode < 0 || d->viewmode > 5) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d unsupported (0..5)", d->viewmode);
+    if (d->max_sample_count < 1) return fail(INCR_ERR_INVALID_ARGUMENT, "max_sample_count must be >= 1");
+    if (d->shard.row_block_height && !d->shard.row_block_stride) return fail(INCR_ERR_INVALID_ARGUMENT, "row_block_stride must be >= 1");
+    const incr_scene* sc = d->scene;
+    PtParams P;
+    memset(&P, 0, sizeof P);
+    P.nodes = sc->dNodes; P.tris = sc->dTris; P.shade = sc->dShade;
+    P.materials = sc->dMaterials; P.textures = sc->dTextures; P.srgbLut = ctx->srgbLut;
+    P.meshLocalToWorld = sc->dMeshLocalToWorld;
+    P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
+    P.numGlobalLights = (uint32_t)sc->host.globalLights.size(); P.numSceneLights = (uint32_t)sc->host.lightIndices.size();
+    P.lightCount = (int32_t)sc->host.globalLights.size();                     // path-tracing.inl:198 m_globalLightList.size()
+    P.numTris = (uint32_t)sc->bvh.tris.size();
+    const M44 V = m44_from(d->view.view_transform), Pm = m44_from(d->view.projection_transform);
+    const M44 p2w = m44_inverse(m44_mul(V, Pm)), cam = m44_inverse(V);              // :199, :201
+    memcpy(P.projectionToWorld, p2w.m, 64); memcpy(P.cameraMatrix, cam.m, 64);
+    P.W = d->res_x; P.H = d->res_y; P.numPixels = d->res_x * d->res_y;
+    P.sampleIdx = d->current_sample_index;
+    P.sqrtSampleCount = (uint32_t)std::sqrt((double)d->max_sample_count);             // :207
+    P.aperture = d->camera_aperture; P.focalLength = d->camera_focal_length; P.skyBrightness = d->sky_brightness;
+    P.directLighting = d->direct_lighting; P.viewmode = d->viewmode;
+    perez_from_turbidity(d->turbidity, &P.perez);
+    // sun direction of the miss shader (:181-189): first directional scene light, else (1, 0.1, 1)
+    V3 L = v3(1.f, 0.1f, 1.f);
+    int sun = -1;
+    for (size_t i = 0; i < sc->host.lightIndices.size(); ++i) {
+        const int li = sc->host.lightIndices[i];
+        if (sc->host.globalLights[(size_t)li].type == INCR_LIGHT_DIRECTIONAL) { sun = li; break; }
+    }
+    if (sun != -1 && (size_t)sun < sc->host.lightTransforms.size()) { const float* m = sc->host.lightTransforms[(size_t)sun].m; L = v3(-m[8], -m[9], -m[10]); }
+    L = normalize3(L);
+    const float Lm[3] = {L.x, L.y, L.z};
+    sky_sun_terms(Lm, d->turbidity, P.perez, &P.sunMiss);
+    sky_sun_terms(sc->host.sunDir, d->turbidity, P.perez, &P.sunEnv);
+    P.rowBlockHeight = d->shard.row_block_height; P.rowBlockFirst = d->shard.row_block_first; P.rowBlockStride = d->shard.row_block_stride ? d->shard.row_block_stride : 1;
+    P.localRows = incr_shard_local_rows(d->res_y, &d->shard);
+    P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;
+    P.storageRounding = d->storage_rounding;
+    P.stats = d->ray_stats;
+    HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_tonemap(incr_context* ctx, const incr_tonemap_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->hdr_r11g11b10 || !d->ldr_rgba8) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(incr_launch_tonemap((const uint32_t*)d->hdr_r11g11b10, (uint32_t*)d->ldr_rgba8, (size_t)d->res_x * d->rows, (int)d->exposure, d->viewmode, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_unshard(incr_context* ctx, void* dst, const void* src, uint32_t res_x, uint32_t res_y, uint32_t row_block_height,
+                 uint32_t num_shards, uint32_t texel_bytes, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!dst || !src || !row_block_height || !num_shards || texel_bytes % 4) return fail(INCR_ERR_INVALID_ARGUMENT, "bad unshard arguments");
+    incr_shard sh = {row_block_height, 0, num_shards};
+    const uint32_t localRows = incr_shard_local_rows(res_y, &sh);
+    HIP_TRY(incr_launch_unshard((uint8_t*)dst, (const uint8_t*)src, res_x, res_y, row_block_height, num_shards, localRows, texel_bytes, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+} // extern "C"

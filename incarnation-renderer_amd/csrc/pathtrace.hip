@@ -1,0 +1,535 @@
+// pathtrace.hip -- the path-tracing integrator as a HIP kernel for gfx950 (MI355X).
+//
+// Replaces, for RenderJob::PathTracing::Execute (reference: source/demo-dll/src/render-jobs/path-tracing.inl:17-299):
+//   DispatchRays(W,H,1) of rgsMain / chsMain / ahsMain / msDynamicSky   (shaders/raytracing/pathtracing.hlsl:89-319)
+//   + the fixed-function DXR traversal and ray/triangle test              
+//   + Dispatch(ceil(W/16), ceil(H/16)) of pathtrace-integrate cs_main     (shaders/raytracing/pathtrace-integrate.hlsl:16-31)
+// in ONE launch: the TraceRay recursion of chsMain is a tail call, so it is run as a loop that carries
+// {color, attenuation, pathLength, sampleSetIndex}; the running-mean integrate is fused into the
+// epilogue (the thread that produced the RGBA16F texel is the one that reads it back).
+//
+// Mapping to CDNA4: one lane = one pixel path; a 64-lane wavefront covers an 8x8 pixel tile so primary
+// rays of a wave walk the same BVH lines; 256-thread workgroups (4 waves = a 16x16 tile).  Traversal is a
+// 4-wide BVH (one 128-B line per node, one 48-B record per candidate triangle) with the per-lane
+// traversal stack staged in LDS ([entry][lane] layout: conflict-free ds_read/ds_write_b32) and a
+// private-memory overflow that is only touched by pathological rays.
+#include "pt_device.h"
+#include <algorithm>
+
+namespace incr {
+
+static constexpr int kBlock = 256;
+static constexpr int kStackLds = 24;      // LDS-resident entries per lane (24 KB per workgroup)
+static constexpr int kStackOvf = 72;      // private overflow (4-wide SAH trees stay far below this)
+
+struct Hit { float t, u, v; uint32_t tri; };
+
+struct LaneStack {
+    uint32_t* lds;            // &stack[0][tid]
+    uint32_t ovf[kStackOvf];
+    int sp;
+    DI void reset() { sp = 0; }
+    DI void push(uint32_t v) {
+        if (sp < kStackLds) lds[sp * kBlock] = v;
+        else if (sp < kStackLds + kStackOvf) ovf[sp - kStackLds] = v;
+        else return;                       // unreachable for a valid tree; drop rather than corrupt memory
+        ++sp;
+    }
+    DI uint32_t pop() {
+        --sp;
+        return sp < kStackLds ? lds[sp * kBlock] : ovf[sp - kStackLds];
+    }
+};
+
+DI bool tri_intersect(const TriIsect* __restrict__ tris, uint32_t ti, f3 o, f3 d, float tmin, float tmax,
+                      float* t, float* u, float* v, uint32_t* flatId, uint32_t* flags) {
+    const float4* __restrict__ p = (const float4*)(tris + ti);
+    const float4 a = p[0], b = p[1], c = p[2];
+    const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
+    const f3 pv = cross(d, e2);
+    const float det = dot(e1, pv);
+    if (!(det > 0.f)) return false;                       // RAY_FLAG_CULL_BACK_FACING_TRIANGLES
+    const float inv = 1.f / det;
+    const f3 sv = o - v0;
+    const float uu = dot(sv, pv) * inv;
+    if (!(uu >= 0.f && uu <= 1.f)) return false;
+    const f3 q = cross(sv, e1);
+    const float vv = dot(d, q) * inv;
+    if (!(vv >= 0.f && uu + vv <= 1.f)) return false;
+    const float tt = dot(e2, q) * inv;
+    if (!(tt > tmin && tt < tmax)) return false;
+    *t = tt; *u = uu; *v = vv;
+    *flatId = __float_as_uint(c.y); *flags = __float_as_uint(c.z);
+    return true;
+}
+
+// ahsMain (pathtracing.hlsl:270-302): alpha test of non-opaque geometry
+DI bool any_hit_accepts(const PtParams& P, uint32_t ti, float u, float v) {
+    const TriShade* __restrict__ sh = P.shade + ti;
+    const f2 uv0 = {sh->uv[0][0], sh->uv[0][1]}, uv1 = {sh->uv[1][0], sh->uv[1][1]}, uv2 = {sh->uv[2][0], sh->uv[2][1]};
+    const f2 uv = uv0 + u * (uv1 - uv0) + v * (uv2 - uv0);
+    const int tex = P.materials[sh->materialIndex].baseColorTextureIndex;
+    if (tex != -1) {
+        const float alpha = SampleLevel0(P.textures, P.srgbLut, tex, uv).w;
+        if (alpha < 0.5f) return false;
+    }
+    return true;
+}
+
+#define CSWAP(i, j) { const bool sw = key[j] < key[i]; const float tk = sw ? key[j] : key[i]; const float tk2 = sw ? key[i] : key[j]; \
+                      const uint32_t tc = sw ? ch[j] : ch[i]; const uint32_t tc2 = sw ? ch[i] : ch[j]; key[i] = tk; key[j] = tk2; ch[i] = tc; ch[j] = tc2; }
+
+// Tests the 4 child boxes of `node`; returns children sorted near->far in ch[0..n).
+DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, f3 o, f3 invd, float tmin, float tmax, uint32_t ch[4]) {
+    const float4* __restrict__ p = (const float4*)(nodes + node);
+    const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5];
+    const uint4 cc = *(const uint4*)(p + 6);
+    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    float key[4];
+    ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ax = (lx[k] - o.x) * invd.x, bx = (hx[k] - o.x) * invd.x;
+        const float ay = (ly[k] - o.y) * invd.y, by = (hy[k] - o.y) * invd.y;
+        const float az = (lz[k] - o.z) * invd.z, bz = (hz[k] - o.z) * invd.z;
+        float t0 = tmin, t1 = tmax;
+        t0 = fmaxf(t0, fminf(ax, bx) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(ax, bx) * 1.0000010f + 1e-30f);
+        t0 = fmaxf(t0, fminf(ay, by) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(ay, by) * 1.0000010f + 1e-30f);
+        t0 = fmaxf(t0, fminf(az, bz) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(az, bz) * 1.0000010f + 1e-30f);
+        const bool hit = (t0 <= t1) && (ch[k] != kEmptyChild);
+        key[k] = hit ? t0 : __uint_as_float(0x7f800000u);
+        n += hit ? 1 : 0;
+    }
+    CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+    return n;
+}
+
+// TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit, equal-t ties to the smaller flattened id.
+DI bool trace_closest(const PtParams& P, LaneStack& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
+    const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+    st.reset();
+    bool found = false; float best = tmax; uint32_t bestFlat = 0xffffffffu, bestTri = 0; float bu = 0.f, bv = 0.f;
+    uint32_t cur = 0;                    // root node
+    for (;;) {
+        if (!(cur & kLeafBit)) {
+            uint32_t ch[4];
+            const int n = node_children(P.nodes, cur, o, invd, tmin, best, ch);
+            if (n > 0) {
+                if (n > 3) st.push(ch[3]);
+                if (n > 2) st.push(ch[2]);
+                if (n > 1) st.push(ch[1]);
+                cur = ch[0];
+                continue;
+            }
+        } else {
+            const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t ti = first + i;
+                float t, u, v; uint32_t flat, flags;
+                if (!tri_intersect(P.tris, ti, o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) continue;
+                if (found && !(t < best || (t == best && flat < bestFlat))) continue;
+                if (!found && !(t < best)) continue;
+                if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
+                if (!(flags & kTriOpaque) && !any_hit_accepts(P, ti, u, v)) continue;
+                found = true; best = t; bestFlat = flat; bestTri = ti; bu = u; bv = v;
+            }
+        }
+        if (st.sp == 0) break;
+        cur = st.pop();
+    }
+    if (found) { hit->t = best; hit->u = bu; hit->v = bv; hit->tri = bestTri; }
+    return found;
+}
+
+// RayQuery<CULL_BACK_FACING> + one Proceed(): occluded iff any front-facing triangle lies in (tmin, tmax)
+// (lighting/common.hlsli:102-115, 161-174).
+DI bool trace_any(const PtParams& P, LaneStack& st, f3 o, f3 d, float tmin, float tmax) {
+    const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+    st.reset();
+    uint32_t cur = 0;
+    for (;;) {
+        if (!(cur & kLeafBit)) {
+            uint32_t ch[4];
+            const int n = node_children(P.nodes, cur, o, invd, tmin, tmax, ch);
+            if (n > 0) {
+                if (n > 3) st.push(ch[3]);
+                if (n > 2) st.push(ch[2]);
+                if (n > 1) st.push(ch[1]);
+                cur = ch[0];
+                continue;
+            }
+        } else {
+            const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t, u, v; uint32_t flat, flags;
+                if (tri_intersect(P.tris, first + i, o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) return true;
+            }
+        }
+        if (st.sp == 0) break;
+        cur = st.pop();
+    }
+    return false;
+}
+
+struct Counters { uint32_t camera, bounce, skyShadow, lightShadow, hits; };
+
+// lighting/common.hlsli:8-143 (PATH_TRACING variant: every light traces a shadow ray)
+DI f3 GetDirectRadiance(const PtParams& P, LaneStack& st, const incr_light& light, const float* __restrict__ m, bool haveTransform,
+                        f3 worldPos, f3 basecolor, float metallic, float roughness, f3 N, f3 V, Counters& cnt) {
+    f3 L = {0.f, 0.f, 0.f};
+    f3 radianceIn = {0.f, 0.f, 0.f};
+    const f3 color = {light.color[0], light.color[1], light.color[2]};
+    float mm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mm[i] = haveTransform ? m[i] : 0.f;     // out-of-range transform loads read 0 (D3D robust access)
+    if (light.type == INCR_LIGHT_DIRECTIONAL) {
+        L = normalize(mk3((0.f * mm[0] + 0.f * mm[4]) + -1.f * mm[8], (0.f * mm[1] + 0.f * mm[5]) + -1.f * mm[9], (0.f * mm[2] + 0.f * mm[6]) + -1.f * mm[10]));
+        radianceIn = 100 * light.intensity * color;
+    } else if (light.type == INCR_LIGHT_POINT) {
+        const f3 lightPosition = {mm[12], mm[13], mm[14]};
+        const f3 lightVec = lightPosition - worldPos;
+        const float distanceSquared = dot(lightVec, lightVec);
+        const float distance = sqrtf(distanceSquared);
+        L = lightVec / distance;
+        float radialAttenuation;
+        if (light.range > 0.f) radialAttenuation = hmax(hmin(1.f, 1.f - pow4(distance / light.range)), 0.f) / distanceSquared;
+        else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        radianceIn = 10000 * light.intensity * color * radialAttenuation;
+    } else if (light.type == INCR_LIGHT_SPOT) {
+        const f3 spotPosition = {mm[12], mm[13], mm[14]};
+        const f3 spotDirection = normalize(mk3((0.f * mm[0] + 0.f * mm[4]) + -1.f * mm[8], (0.f * mm[1] + 0.f * mm[5]) + -1.f * mm[9], (0.f * mm[2] + 0.f * mm[6]) + -1.f * mm[10]));
+        const f3 lightVec = spotPosition - worldPos;
+        const float distanceSquared = dot(lightVec, lightVec);
+        const float distance = sqrtf(distanceSquared);
+        L = lightVec / distance;
+        float angularAttenuation = 0.f;
+        const float cd = dot(spotDirection, L);
+        const float cosineOuterAngle = cosf(light.spotAngles[1]);
+        if (cd > cosineOuterAngle) {
+            const float cosineInnerAngle = cosf(light.spotAngles[0]);
+            const float lightAngleScale = 1.f / hmax(0.001f, cosineInnerAngle - cosineOuterAngle);
+            const float lightAngleOffset = -cosineOuterAngle * lightAngleScale;
+            angularAttenuation = saturate(cd * lightAngleScale + lightAngleOffset);
+            angularAttenuation *= angularAttenuation;
+        }
+        float radialAttenuation = 0.f;
+        if (angularAttenuation > 0.f) {
+            if (light.range > 0.f) { /* Q9: shadowed redeclaration at common.hlsli:73 leaves 0 */ }
+            else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        }
+        radianceIn = 10000 * light.intensity * color * angularAttenuation * radialAttenuation;
+    }
+    f3 radianceOut = {0.f, 0.f, 0.f};
+    const float NoL = saturate(dot(N, L));
+    if (NoL > 0.f && (radianceIn.x > 0.f || radianceIn.y > 0.f || radianceIn.z > 0.f)) {
+        float lightVisibility = 1.f;
+        cnt.lightShadow++;
+        if (trace_any(P, st, worldPos, L, 0.1f, 1000.f)) lightVisibility = 0.f;
+        if (lightVisibility > 0.f) {
+            const float NoV = saturate(dot(N, V));
+            const f3 F0 = metallic * basecolor + (1.f - metallic) * 0.04f;
+            const f3 albedo = (1.f - metallic) * basecolor;
+            const f3 H = normalize(L + V);
+            const float NoH = saturate(dot(N, H));
+            const float VoH = saturate(dot(V, H));
+            const float D = GGX(NoH, roughness);
+            const f3 F = F_Schlick(VoH, F0);
+            const float G = G_SmithGGXCorrelated(NoV, NoL, roughness);
+            const f3 Fd = albedo * K_INV_PI;
+            const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
+            const f3 irradiance = radianceIn * NoL;
+            radianceOut = (Fr + (1.f - F) * Fd) * irradiance * lightVisibility;
+        }
+    }
+    return radianceOut;
+}
+
+// lighting/common.hlsli:145-202
+DI f3 GetSkyRadiance(const PtParams& P, LaneStack& st, f3 radianceIn, f3 L, f3 worldPos, const MatProps& matInfo, f3 N, f3 V, Counters& cnt) {
+    f3 radianceOut = {0.f, 0.f, 0.f};
+    const float NoL = saturate(dot(N, L));
+    if (NoL > 0.f && (radianceIn.x > 0.f || radianceIn.y > 0.f || radianceIn.z > 0.f)) {
+        float lightVisibility = 1.f;
+        cnt.skyShadow++;
+        if (trace_any(P, st, worldPos, L, 0.1f, 1000.f)) lightVisibility = 0.f;
+        if (lightVisibility > 0.f) {
+            const float NoV = dot(N, V);
+            const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
+            const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
+            const f3 H = normalize(L + V);
+            const float NoH = hmax(0.0001f, dot(N, H));
+            const float VoH = hmax(0.0001f, dot(V, H));
+            const float D = GGX(NoH, matInfo.roughness);
+            const f3 F = F_Schlick(VoH, F0);
+            const float G = G_Smith_Direct(NoV, NoL, matInfo.roughness);
+            const f3 Fd = albedo * K_INV_PI;
+            const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
+            const f3 irradiance = radianceIn * NoL;
+            radianceOut = (Fr + (1.f - F) * Fd) * irradiance * lightVisibility;
+        }
+    }
+    return radianceOut / CosineHemispherePdf(L.z);
+}
+
+struct Ray { f3 o, d; float tmin, tmax; };
+
+// raytracing/common.hlsli:25-53
+DI Ray GenerateCameraRay(const PtParams& P, f2 index, f2 randomSample) {
+    const f2 xy = {index.x + 0.5f, index.y + 0.5f};
+    f2 screenPos = {xy.x / (float)P.W * 2.0f - 1.0f, xy.y / (float)P.H * 2.0f - 1.0f};
+    screenPos.y = -screenPos.y;
+    const float* cm = P.cameraMatrix;
+    const f3 cameraPos = {cm[12], cm[13], cm[14]};
+    const f4 world = mul_vec4({screenPos.x, screenPos.y, 0.0001f, 1.f}, P.projectionToWorld);
+    const f3 wxyz = {world.x / world.w, world.y / world.w, world.z / world.w};
+    const f3 primaryRayDir = normalize(wxyz - cameraPos);
+    const f3 focalPoint = cameraPos + P.focalLength * primaryRayDir;
+    const f3 cameraRight = {cm[0], cm[1], cm[2]};
+    const f3 cameraUp = {cm[4], cm[5], cm[6]};
+    const f2 offset = ConcentricSampleDisk(randomSample);
+    const f3 rayOrigin = cameraPos + (P.aperture * offset.x) * cameraRight + (P.aperture * offset.y) * cameraUp;
+    Ray r;
+    r.o = rayOrigin;
+    r.d = normalize(focalPoint - rayOrigin);
+    r.tmin = 0.001f; r.tmax = 10000.0f;
+    return r;
+}
+
+DI f4 trace_pixel(const PtParams& P, LaneStack& st, uint32_t px, uint32_t py, Counters& cnt) {
+    // rgsMain -- pathtracing.hlsl:89-119
+    uint32_t raygenSampleSetIdx = 0;
+    const uint32_t pixelIdx = py * P.W + px;
+    const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
+    const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
+    Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)py + subPixelJitter.y}, apertureSample);
+
+    f4 color = {0.f, 0.f, 0.f, 0.f};
+    int pathLength = 0;
+    f3 attenuation = {1.f, 1.f, 1.f};
+    uint32_t sampleSetIndex = 0;
+    bool first = true;
+
+    for (;;) {
+        if (first) cnt.camera++; else cnt.bounce++;
+        first = false;
+        Hit hit;
+        if (!trace_closest(P, st, ray.o, ray.d, ray.tmin, ray.tmax, &hit)) {
+            // msDynamicSky -- pathtracing.hlsl:311-319
+            const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, ray.d, P.perez);
+            const f3 add = attenuation * 1000 * sky;
+            color.x += add.x; color.y += add.y; color.z += add.z;
+            break;
+        }
+        // chsMain -- pathtracing.hlsl:121-268
+        cnt.hits++;
+        pathLength += 1;
+        // one 128-byte line: the three vertices' normal/tangent/uv + ids (baked GetUint3/GetFloat2/3/4 results)
+        const float4* __restrict__ sp = (const float4*)(P.shade + hit.tri);
+        const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+        const uint4 s7 = *(const uint4*)(sp + 7);
+        const f3 vn0 = {s0.x, s0.y, s0.z}, vn1 = {s0.w, s1.x, s1.y}, vn2 = {s1.z, s1.w, s2.x};
+        const f4 vt0 = {s2.y, s2.z, s2.w, s3.x}, vt1 = {s3.y, s3.z, s3.w, s4.x}, vt2 = {s4.y, s4.z, s4.w, s5.x};
+        const f2 uv0 = {s5.y, s5.z}, uv1 = {s5.w, s6.x}, uv2 = {s6.y, s6.z};
+        const uint32_t materialIndex = __float_as_uint(s6.w), meshIndex = s7.x;
+        const float* __restrict__ localToWorld = P.meshLocalToWorld + (size_t)meshIndex * 16;
+
+        const f3 hitPosition = ray.o + hit.t * ray.d;
+        const float bx = hit.u, by = hit.v;
+        const f4 packedT = vt0 + bx * (vt1 - vt0) + by * (vt2 - vt0);
+        f3 N = normalize(vn0 + bx * (vn1 - vn0) + by * (vn2 - vn0));
+        f3 T = normalize(mk3(packedT.x, packedT.y, packedT.z));
+        f3 B = cross(N, T) * packedT.w;
+        N = mul_dir(N, localToWorld);
+        T = mul_dir(T, localToWorld);
+        B = mul_dir(B, localToWorld);
+        const f3 Ntbn = N;                                  // float3x3 tangentToWorld = float3x3(T, B, N)  (:166)
+        const f2 uv = uv0 + bx * (uv1 - uv0) + by * (uv2 - uv0);
+        MatProps matInfo = EvaluateMaterialProperties(P.materials[materialIndex], P.textures, P.srgbLut, uv);
+
+        if (P.viewmode == 1) matInfo.basecolor = mk3(0.5f);
+        else if (P.viewmode == 2) { color = {matInfo.roughness, matInfo.roughness, matInfo.roughness, matInfo.roughness}; break; }
+        else if (P.viewmode == 3) { color = {matInfo.metallic, matInfo.metallic, matInfo.metallic, matInfo.metallic}; break; }
+        else if (P.viewmode == 4) { color = {matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, 1.f}; break; }
+        else if (P.viewmode == 5) { color = {matInfo.emissive.x, matInfo.emissive.y, matInfo.emissive.z, 1.f}; break; }
+
+        {
+            const f3 add = attenuation * matInfo.emissive * 20000;
+            color.x += add.x; color.y += add.y; color.z += add.z;
+            attenuation = attenuation * saturate(1.f - matInfo.emissive);
+        }
+        if (matInfo.bHasNormalmap) {
+            const f3 nm = matInfo.normalmap;
+            N = normalize(mk3((nm.x * T.x + nm.y * B.x) + nm.z * N.x, (nm.x * T.y + nm.y * B.y) + nm.z * N.y, (nm.x * T.z + nm.y * B.z) + nm.z * N.z));
+        }
+        const f3 V = -ray.d;
+
+        if (P.directLighting) {
+            for (int lightIndex = 0; lightIndex < P.lightCount; ++lightIndex) {
+                const int lightId = (uint32_t)lightIndex < P.numSceneLights ? P.lightIndices[lightIndex] : 0;
+                incr_light light = {};
+                if ((uint32_t)lightId < P.numGlobalLights) light = P.globalLights[lightId];
+                const bool haveT = (uint32_t)lightId < P.numSceneLights;
+                const f3 r = attenuation * GetDirectRadiance(P, st, light, P.lightTransforms + (haveT ? (size_t)lightId * 16 : 0), haveT,
+                                                             hitPosition, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V, cnt);
+                color.x += r.x; color.y += r.y; color.z += r.z;
+            }
+        }
+        {   // skylight :239-244
+            const f2 u = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
+            const f3 sampleDir = CosineSampleHemisphere(u);
+            const f3 radianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, sampleDir, P.perez));
+            const f3 r = attenuation * GetSkyRadiance(P, st, radianceIn, sampleDir, hitPosition, matInfo, N, V, cnt);
+            color.x += r.x; color.y += r.y; color.z += r.z;
+        }
+        if (pathLength < 4) {
+            // GenerateIndirectRadianceRay -- raytracing/common.hlsli:55-123
+            uint32_t setCopy = sampleSetIndex;
+            f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.sqrtSampleCount, P.numPixels);
+            f3 L, H;
+            const float t = 0.5f;
+            if (u.x < t) {
+                u.x = 2.f * u.x;
+                const f3 l = CosineSampleHemisphere(u);
+                L = normalize(mk3((l.x * T.x + l.y * B.x) + l.z * Ntbn.x, (l.x * T.y + l.y * B.y) + l.z * Ntbn.y, (l.x * T.z + l.y * B.z) + l.z * Ntbn.z));
+                H = normalize(L + V);
+            } else {
+                u.x = 2.f * (u.x - 0.5f);
+                const f3 h = SampleGGX(u, matInfo.roughness);
+                H = normalize(mk3((h.x * T.x + h.y * B.x) + h.z * Ntbn.x, (h.x * T.y + h.y * B.y) + h.z * Ntbn.y, (h.x * T.z + h.y * B.z) + h.z * Ntbn.z));
+                L = normalize(reflect(-V, H));
+            }
+            const float NoL = hmax(dot(N, L), 0.001f);
+            const float NoV = hmax(dot(N, V), 0.001f);
+            const float NoH = hmax(dot(N, H), 0.001f);
+            const float VoH = hmax(dot(V, H), 0.001f);
+            const float pdf = t * CosineHemispherePdf(NoL) + (1.f - t) * GGXPdf(NoH, matInfo.roughness) / (4.f * VoH);
+            const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
+            const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
+            const float D = GGX(NoH, matInfo.roughness);
+            const f3 F = F_Schlick(VoH, F0);
+            const float G = G_Smith_Direct(NoV, NoL, matInfo.roughness);
+            const f3 Fd = albedo * K_INV_PI;
+            const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
+            const f3 brdf = (Fr + (1.f - F) * Fd);
+            const f3 outAttenuation = brdf * NoL / pdf;
+            attenuation = attenuation * outAttenuation;
+            if (attenuation.x != 0.f || attenuation.y != 0.f || attenuation.z != 0.f) {     // Q2
+                ray.o = hitPosition; ray.d = L; ray.tmin = 0.001f; ray.tmax = 10000.0f;
+                continue;
+            }
+        }
+        break;
+    }
+    return color;
+}
+
+DI int64_t shard_global_row(const PtParams& P, uint32_t localRow) {
+    if (P.rowBlockHeight == 0) return localRow < P.H ? (int64_t)localRow : -1;
+    const uint32_t k = localRow / P.rowBlockHeight, r = localRow % P.rowBlockHeight;
+    const uint64_t y = (uint64_t)(P.rowBlockFirst + (uint64_t)k * P.rowBlockStride) * P.rowBlockHeight + r;
+    return y < P.H ? (int64_t)y : -1;
+}
+
+__global__ __launch_bounds__(kBlock) void pathtrace_kernel(const PtParams P) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+
+    // workgroup = 16x16 pixel tile, wave w = 8x8 quadrant, lane = (lane & 7, lane >> 3) inside it
+    const uint32_t tilesX = (P.W + 15u) / 16u;
+    const uint32_t tileX = blockIdx.x % tilesX, tileY = blockIdx.x / tilesX;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t x = tileX * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ly = tileY * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Counters cnt = {0, 0, 0, 0, 0};
+    if (x < P.W && ly < P.localRows) {
+        LaneStack st; st.lds = s_stack + tid; st.sp = 0;
+        const int64_t gy = shard_global_row(P, ly);
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0) c = trace_pixel(P, st, x, (uint32_t)gy, cnt);
+        const size_t li = (size_t)ly * P.W + x;
+        // destUav[xy] = payload.color (RGBA16F typed store, pathtracing.hlsl:118)
+        const uint32_t hx = f32_to_f16_bits(c.x, P.storageRounding), hy = f32_to_f16_bits(c.y, P.storageRounding);
+        const uint32_t hz = f32_to_f16_bits(c.z, P.storageRounding), hw = f32_to_f16_bits(c.w, P.storageRounding);
+        if (P.target) *(uint2*)(P.target + li * 4) = make_uint2(hx | (hy << 16), hz | (hw << 16));
+        // pathtrace-integrate.hlsl:16-31 fused: history = ((n-1)*history + current) / n
+        if (P.history) {
+            const f3 cur = {f16_bits_to_f32(hx), f16_bits_to_f32(hy), f16_bits_to_f32(hz)};
+            const float n = (float)P.sampleIdx;
+            f3 avg;
+            if (P.sampleIdx <= 1) avg = cur / n;
+            else avg = ((n - 1.f) * unpack_r11g11b10(P.history[li]) + cur) / n;
+            P.history[li] = pack_r11g11b10(avg, P.storageRounding);
+        }
+    }
+    if (P.stats) {
+        uint32_t v[5] = {cnt.camera, cnt.bounce, cnt.skyShadow, cnt.lightShadow, cnt.hits};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        }
+        if (lane == 0) {
+            unsigned long long* s = (unsigned long long*)P.stats;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (v[k]) atomicAdd(s + k, (unsigned long long)v[k]);
+        }
+    }
+}
+
+// TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode
+DI uint32_t linear_to_srgb8(float c) {
+    if (!(c > 0.f)) c = 0.f;
+    if (c > 1.f) c = 1.f;
+    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.f / 2.4f) - 0.055f;
+    return (uint32_t)floorf(e * 255.f + 0.5f);
+}
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
+    const float e = Exposure(ev100);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const f3 h = unpack_r11g11b10(hdr[i]);
+        f3 l;
+        if (viewmode != 0 && viewmode != 1) l = h; else l = ACESFilm(h * e);
+        ldr[i] = linear_to_srgb8(l.x) | (linear_to_srgb8(l.y) << 8) | (linear_to_srgb8(l.z) << 16) | 0xff000000u;
+    }
+}
+
+// un-interleave gathered shards: src [numShards][localRows][W] -> dst [H][W]
+__global__ __launch_bounds__(256) void unshard_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t W, uint32_t H,
+                                                      uint32_t h, uint32_t numShards, uint32_t localRows, uint32_t texelBytes) {
+    const size_t rowBytes = (size_t)W * texelBytes;
+    const size_t total = (size_t)H * rowBytes / 4;       // dword granularity (texelBytes is a multiple of 4)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t byte = i * 4;
+        const uint32_t y = (uint32_t)(byte / rowBytes); const size_t xo = byte % rowBytes;
+        const uint32_t blk = y / h, r = y % h;
+        const uint32_t shard = blk % numShards, k = blk / numShards;
+        const size_t srcOff = ((size_t)shard * localRows + (size_t)k * h + r) * rowBytes + xo;
+        *(uint32_t*)(dst + byte) = *(const uint32_t*)(src + srcOff);
+    }
+}
+
+} // namespace incr
+
+// ---- launchers (called from api.cpp) -----------------------------------------------------------------
+extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream) {
+    const uint32_t tilesX = (p->W + 15u) / 16u, tilesY = (p->localRows + 15u) / 16u;
+    if (tilesX == 0 || tilesY == 0) return hipSuccess;
+    hipLaunchKernelGGL(incr::pathtrace_kernel, dim3(tilesX * tilesY), dim3(incr::kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(incr::tonemap_kernel, dim3(blocks), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
+                                          uint32_t localRows, uint32_t texelBytes, hipStream_t stream) {
+    const size_t total = (size_t)H * W * texelBytes / 4;
+    if (!total) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(incr::unshard_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, W, H, h, numShards, localRows, texelBytes);
+    return hipGetLastError();
+}

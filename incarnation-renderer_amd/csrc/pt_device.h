@@ -1,0 +1,323 @@
+// pt_device.h -- device-side math, sampling, BRDF, sky, texture and storage-format helpers for the
+// path-tracing kernels (gfx950).  Compiled with -ffp-contract=off: every +,-,*,/ and sqrt below is a
+// single correctly-rounded IEEE operation, so results are reproducible against the CPU oracle.
+// Reference files restated here (relative to /root/reference/source/demo-dll/shaders/):
+//   common/uniform-sampling.hlsli, common/bxdf-sampling.hlsli, common/math.hlsli, lighting/pbr.hlsli,
+//   environment-sky/preetham.hlsli, material/common.hlsli, raytracing/common.hlsli
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/incr.h"
+#include "device_types.h"
+#include "pt_params.h"
+
+namespace incr {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+#define DI __device__ __forceinline__
+
+DI f3 mk3(float x, float y, float z) { return {x, y, z}; }
+DI f3 mk3(float s) { return {s, s, s}; }
+DI f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DI f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DI f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+DI f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DI f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+DI f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DI f3 operator+(float s, f3 a) { return {s + a.x, s + a.y, s + a.z}; }
+DI f3 operator+(f3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+DI f3 operator-(float s, f3 a) { return {s - a.x, s - a.y, s - a.z}; }
+DI f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+DI f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+DI f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+DI f2 operator*(float s, f2 a) { return {s * a.x, s * a.y}; }
+DI f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+DI f4 operator-(f4 a, f4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+DI f4 operator*(float s, f4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+
+DI float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DI float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DI f3 normalize(f3 v) { float l = sqrtf(dot(v, v)); return {v.x / l, v.y / l, v.z / l}; }
+DI float hmax(float a, float b) { return fmaxf(a, b); }
+DI float hmin(float a, float b) { return fminf(a, b); }
+DI float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+DI f3 saturate(f3 v) { return {saturate(v.x), saturate(v.y), saturate(v.z)}; }
+DI f3 reflect(f3 i, f3 n) { float d = dot(i, n); return i - (2.f * n) * d; }
+DI float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+DI float pow4(float x) { float x2 = x * x; return x2 * x2; }
+
+// (v,0) * M  /  (v,w) * M for row-major M with row vectors
+DI f3 mul_dir(f3 v, const float* M) {
+    return {(v.x * M[0] + v.y * M[4]) + v.z * M[8], (v.x * M[1] + v.y * M[5]) + v.z * M[9], (v.x * M[2] + v.y * M[6]) + v.z * M[10]};
+}
+DI f4 mul_vec4(f4 v, const float* M) {
+    f4 r;
+    r.x = ((v.x * M[0] + v.y * M[4]) + v.z * M[8]) + v.w * M[12];
+    r.y = ((v.x * M[1] + v.y * M[5]) + v.z * M[9]) + v.w * M[13];
+    r.z = ((v.x * M[2] + v.y * M[6]) + v.z * M[10]) + v.w * M[14];
+    r.w = ((v.x * M[3] + v.y * M[7]) + v.z * M[11]) + v.w * M[15];
+    return r;
+}
+
+// ---------------------------------------------------------------- CMJ sampler (uniform-sampling.hlsli:152-201)
+DI uint32_t CMJ_Permute(uint32_t i, uint32_t l, uint32_t p) {
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893d;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8; i *= 0x0929eb3f;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1; i *= 1 | p >> 27;
+        i *= 0x6935fa69;
+        i ^= (i & w) >> 11; i *= 0x74dcb303;
+        i ^= (i & w) >> 2; i *= 0x9e501cc3;
+        i ^= (i & w) >> 2; i *= 0xc860a3df;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+DI float CMJ_RandFloat(uint32_t i, uint32_t p) {
+    i ^= p;
+    i ^= i >> 17;
+    i ^= i >> 10; i *= 0xb36534e5;
+    i ^= i >> 12;
+    i ^= i >> 21; i *= 0x93fc4795;
+    i ^= 0xdf6e307f;
+    i ^= i >> 17; i *= 1 | p >> 18;
+    return (float)i * (1.0f / 4294967808.0f);
+}
+DI f2 CorrelatedMultiJitteredSampling(uint32_t sampleIdx, uint32_t nx, uint32_t ny, uint32_t pattern) {
+    uint32_t N = nx * ny;
+    sampleIdx = CMJ_Permute(sampleIdx, N, pattern * 0x51633e2d);
+    uint32_t sx = CMJ_Permute(sampleIdx % nx, nx, pattern * 0x68bc21eb);
+    uint32_t sy = CMJ_Permute(sampleIdx / nx, ny, pattern * 0x02e5be93);
+    float jx = CMJ_RandFloat(sampleIdx, pattern * 0x967a889b);
+    float jy = CMJ_RandFloat(sampleIdx, pattern * 0x368cc8b7);
+    return {((float)sx + ((float)sy + jx) / (float)ny) / (float)nx, ((float)sampleIdx + jy) / (float)N};
+}
+// raytracing/common.hlsli:8-14
+DI f2 SamplePoint(uint32_t pixelIdx, uint32_t sampleIdx, uint32_t& setIdx, uint32_t sqrtSampleCount, uint32_t numPixels) {
+    const uint32_t permutationIdx = setIdx * numPixels + pixelIdx;
+    setIdx += 1;
+    return CorrelatedMultiJitteredSampling(sampleIdx, sqrtSampleCount, sqrtSampleCount, permutationIdx);
+}
+
+#define K_PI 3.14159265358979323846f
+#define K_INV_PI 0.31830988618379067154f
+#define K_PI_OVER_2 1.57079632679489661923f
+#define K_PI_OVER_4 0.78539816339744830961f
+
+DI f2 ConcentricSampleDisk(f2 u) {                        // uniform-sampling.hlsli:20-45
+    f2 o = {2.f * u.x - 1.f, 2.f * u.y - 1.f};
+    if (o.x == 0.f && o.y == 0.f) return {0.f, 0.f};
+    float theta, r;
+    if (fabsf(o.x) > fabsf(o.y)) { r = o.x; theta = K_PI_OVER_4 * (o.y / o.x); }
+    else { r = o.y; theta = K_PI_OVER_2 - K_PI_OVER_4 * (o.x / o.y); }
+    return {r * cosf(theta), r * sinf(theta)};
+}
+DI f3 CosineSampleHemisphere(f2 u) {                      // :61-66
+    f2 d = ConcentricSampleDisk(u);
+    float z = sqrtf(hmax(0.f, 1.f - d.x * d.x - d.y * d.y));
+    return {d.x, d.y, z};
+}
+DI float CosineHemispherePdf(float c) { return c * K_INV_PI; }
+
+DI float GGX(float NoH, float Roughness) {                // bxdf-sampling.hlsli:14-26
+    float a = Roughness * Roughness;
+    float a2 = a * a;
+    NoH = hmax(NoH, 0.f);
+    float NoH2 = NoH * NoH;
+    float denom = (NoH2 * (a2 - 1.f) + 1.f);
+    denom = K_PI * denom * denom;
+    return a2 / hmax(denom, 0.0001f);
+}
+DI f3 SampleGGX(f2 u, float roughness) {                  // :29-42
+    float a = roughness * roughness;
+    float Phi = 2 * K_PI * u.x;
+    float CosTheta = sqrtf((1.f - u.y) / (1.f + (a * a - 1.f) * u.y));
+    float SinTheta = sqrtf(1.f - CosTheta * CosTheta);
+    return {SinTheta * sinf(Phi), SinTheta * cosf(Phi), CosTheta};
+}
+DI float GGXPdf(float NoH, float roughness) { return GGX(NoH, roughness) * NoH; }
+
+DI float G_SmithGGXCorrelated(float NoV, float NoL, float roughness) {   // pbr.hlsli:8-14
+    float a2 = roughness * roughness;
+    float GGXV = NoL * sqrtf(NoV * NoV * (1.0f - a2) + a2);
+    float GGXL = NoV * sqrtf(NoL * NoL * (1.0f - a2) + a2);
+    return 0.5f / hmax(GGXV + GGXL, 0.00001f);
+}
+DI f3 F_Schlick(float u, f3 f0) { float f = pow5(1.0f - u); return f + f0 * (1.0f - f); }
+DI float G_SchlickGGX(float u, float k) { return u / (u * (1.f - k) + k); }
+DI float G_Smith_Direct(float NoV, float NoL, float roughness) {
+    float a2 = roughness * roughness;
+    float k = (a2 + 1) * (a2 + 1) / 8.f;
+    return G_SchlickGGX(NoV, k) * G_SchlickGGX(NoL, k);
+}
+DI float Exposure(int ev100) { return 1.0f / (ldexpf(1.f, ev100) * 1.2f); }
+DI f3 ACESFilm(f3 x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return saturate((x * (a * x + b)) / (x * (c * x + d) + e));
+}
+
+// ---------------------------------------------------------------- Preetham sky (preetham.hlsli:36-89)
+
+DI f3 Perez(float cosTheta, float gamma, float cosGamma, const incr_perez_distribution& pc) {
+    f3 A = {pc.A[0], pc.A[1], pc.A[2]}, B = {pc.B[0], pc.B[1], pc.B[2]}, C = {pc.C[0], pc.C[1], pc.C[2]},
+       D = {pc.D[0], pc.D[1], pc.D[2]}, E = {pc.E[0], pc.E[1], pc.E[2]};
+    f3 e1 = {expf(B.x / cosTheta), expf(B.y / cosTheta), expf(B.z / cosTheta)};
+    f3 e2 = {expf(D.x * gamma), expf(D.y * gamma), expf(D.z * gamma)};
+    return (1.0f + A * e1) * ((1.0f + C * e2) + (E * cosGamma) * cosGamma);
+}
+DI f3 Yxy2RGB(f3 Yxy) {
+    float Y = Yxy.x, x = Yxy.y, y = Yxy.z;
+    float X = x * (Y / y);
+    float Z = (1.0f - x - y) * (Y / y);
+    f3 RGB;
+    RGB.x = 3.2404542f * X - 1.5371385f * Y - 0.4985314f * Z;
+    RGB.y = -0.9692660f * X + 1.8760108f * Y + 0.0415560f * Z;
+    RGB.z = 0.0556434f * X - 0.2040259f * Y + 1.0572252f * Z;
+    return RGB;
+}
+DI f3 CalculateSkyRadianceRGB(const SkySun& sun, f3 e, const incr_perez_distribution& pc) {
+    float cosE = saturate(e.y);
+    float cosG = saturate(dot(mk3(sun.s[0], sun.s[1], sun.s[2]), e));
+    float gammaE = acosf(cosG);
+    f3 F = Perez(cosE, gammaE, cosG, pc);
+    f3 Yxy = mk3(sun.YxyZenith[0], sun.YxyZenith[1], sun.YxyZenith[2]) * (F / mk3(sun.F0[0], sun.F0[1], sun.F0[2]));
+    return Yxy2RGB(Yxy);
+}
+
+// ---------------------------------------------------------------- small-float typed-UAV stores
+DI uint32_t encode_small_float(float f, int mant_bits, bool has_sign, int rounding, uint32_t* sign_out) {
+    uint32_t u = __float_as_uint(f);
+    uint32_t sign = u >> 31;
+    uint32_t absu = u & 0x7fffffffu;
+    const uint32_t exp_all = 31u << mant_bits;
+    *sign_out = has_sign ? sign : 0;
+    if (absu > 0x7f800000u) return exp_all | ((1u << mant_bits) - 1u);
+    if (!has_sign && sign) return 0;
+    if (absu == 0x7f800000u) return exp_all;
+    int e = (int)(absu >> 23) - 127 + 15;
+    uint32_t m = absu & 0x7fffffu;
+    const int shift = 23 - mant_bits;
+    const uint32_t max_finite = exp_all - 1u;
+    if (e >= 31) return rounding == 0 ? max_finite : exp_all;
+    uint32_t r;
+    if (e <= 0) {
+        if (e < -mant_bits - 1) return 0;
+        m |= 0x800000u;
+        int s = shift + 1 - e;
+        if (s > 31) return 0;
+        r = m >> s;
+        if (rounding == 1) {
+            uint32_t rem = m & ((1u << s) - 1u), half = 1u << (s - 1);
+            if (rem > half || (rem == half && (r & 1u))) r += 1;
+        }
+        return r;
+    }
+    r = ((uint32_t)e << mant_bits) | (m >> shift);
+    if (rounding == 1) {
+        uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) r += 1;
+    }
+    return r;
+}
+DI float decode_small_float(uint32_t v, int mant_bits, uint32_t sign) {
+    uint32_t e = v >> mant_bits, m = v & ((1u << mant_bits) - 1u);
+    float r;
+    if (e == 0) r = ldexpf((float)m, -14 - mant_bits);
+    else if (e == 31) r = m ? __uint_as_float(0x7fc00000u) : __uint_as_float(0x7f800000u);
+    else r = ldexpf((float)(m | (1u << mant_bits)), (int)e - 15 - mant_bits);
+    return sign ? -r : r;
+}
+DI uint32_t f32_to_f16_bits(float f, int rounding) { uint32_t s; uint32_t v = encode_small_float(f, 10, true, rounding, &s); return (s << 15) | v; }
+DI float f16_bits_to_f32(uint32_t h) { return decode_small_float(h & 0x7fffu, 10, (h >> 15) & 1u); }
+DI uint32_t pack_r11g11b10(f3 c, int rounding) {
+    uint32_t s;
+    uint32_t r = encode_small_float(c.x, 6, false, rounding, &s);
+    uint32_t g = encode_small_float(c.y, 6, false, rounding, &s);
+    uint32_t b = encode_small_float(c.z, 5, false, rounding, &s);
+    return r | (g << 11) | (b << 22);
+}
+DI f3 unpack_r11g11b10(uint32_t p) {
+    return {decode_small_float(p & 0x7ffu, 6, 0), decode_small_float((p >> 11) & 0x7ffu, 6, 0), decode_small_float(p >> 22, 5, 0)};
+}
+
+// ---------------------------------------------------------------- texture unit stand-in (bilinear, wrap, mip 0)
+DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t rgba) {
+    const float inv255 = 1.f / 255.f;
+    const uint32_t r = rgba & 0xffu, g = (rgba >> 8) & 0xffu, b = (rgba >> 16) & 0xffu, a = rgba >> 24;
+    switch (format) {
+    case INCR_TEX_RGBA8_SRGB:       return {srgbLut[r], srgbLut[g], srgbLut[b], (float)a * inv255};
+    case INCR_TEX_RG_SNORM:         return {2.f * ((float)r * inv255) - 1.f, 2.f * ((float)g * inv255) - 1.f, 0.f, 1.f};
+    case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)b * inv255, (float)g * inv255, 0.f, 1.f};
+    default:                        return {(float)r * inv255, (float)g * inv255, (float)b * inv255, (float)a * inv255};
+    }
+}
+DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv) {
+    const DeviceTexture t = textures[texIndex];
+    const int W = (int)t.width, H = (int)t.height;
+    float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
+    if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
+    if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
+    float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
+    int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t c00 = px[(size_t)y0 * W + x0], c10 = px[(size_t)y0 * W + x1];
+    const uint32_t c01 = px[(size_t)y1 * W + x0], c11 = px[(size_t)y1 * W + x1];
+    f4 t00 = decode_texel(srgbLut, t.format, c00), t10 = decode_texel(srgbLut, t.format, c10);
+    f4 t01 = decode_texel(srgbLut, t.format, c01), t11 = decode_texel(srgbLut, t.format, c11);
+    float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    f4 r;
+    r.x = (t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy;
+    r.y = (t00.y * wx0 + t10.y * fx) * wy0 + (t01.y * wx0 + t11.y * fx) * fy;
+    r.z = (t00.z * wx0 + t10.z * fx) * wy0 + (t01.z * wx0 + t11.z * fx) * fy;
+    r.w = (t00.w * wx0 + t10.w * fx) * wy0 + (t01.w * wx0 + t11.w * fx) * fy;
+    return r;
+}
+
+// material/common.hlsli:10-115
+struct MatProps { f3 emissive, basecolor; float opacity; bool bHasNormalmap; f3 normalmap; float metallic, roughness, ao, aoblend; };
+DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {
+    MatProps o;
+    o.emissive = {mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    if (mat.emissiveTextureIndex != -1) { f4 t = SampleLevel0(textures, lut, mat.emissiveTextureIndex, uv); o.emissive = o.emissive * mk3(t.x, t.y, t.z); }
+    o.basecolor = {mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]};
+    o.opacity = 1.f;
+    if (mat.baseColorTextureIndex != -1) {
+        f4 t = SampleLevel0(textures, lut, mat.baseColorTextureIndex, uv);
+        o.basecolor = o.basecolor * mk3(t.x, t.y, t.z);
+        o.opacity = t.w;
+    }
+    o.bHasNormalmap = mat.normalTextureIndex != -1;
+    o.normalmap = {0.f, 0.f, 1.f};
+    if (o.bHasNormalmap) {
+        f4 t = SampleLevel0(textures, lut, mat.normalTextureIndex, uv);
+        f2 nxy = {t.x, t.y};
+        float nz = sqrtf(1.f - dot(nxy, nxy));
+        o.normalmap = {nxy.x, nxy.y, nz};
+    }
+    o.metallic = mat.metallicFactor;
+    o.roughness = mat.roughnessFactor;
+    if (mat.metallicRoughnessTextureIndex != -1) {
+        f4 t = SampleLevel0(textures, lut, mat.metallicRoughnessTextureIndex, uv);
+        o.metallic = t.x; o.roughness = t.y;
+    }
+    o.aoblend = mat.aoStrength;
+    o.ao = 1.f;
+    if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(textures, lut, mat.aoTextureIndex, uv).x;
+    return o;
+}
+
+} // namespace incr

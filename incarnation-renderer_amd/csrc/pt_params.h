@@ -1,0 +1,41 @@
+// pt_params.h -- kernel argument block of the path-tracing launch (host fills it in api.hip; render-jobs/path-tracing.inl:143-217 GlobalCbLayout).
+#pragma once
+#include <stdint.h>
+#include "../../include/incr.h"
+#include "device_types.h"
+
+namespace incr {
+
+// per-frame Preetham sun terms (host computed): sun direction, Yxy at the zenith, Perez F(0, thetaS)
+struct SkySun { float s[3]; float YxyZenith[3]; float F0[3]; float pad[3]; };
+
+struct PtParams {
+    const BvhNode4* __restrict__ nodes;
+    const TriIsect* __restrict__ tris;
+    const TriShade* __restrict__ shade;
+    const incr_material* __restrict__ materials;
+    const DeviceTexture* __restrict__ textures;
+    const float* __restrict__ srgbLut;
+    const float* __restrict__ meshLocalToWorld;    // 16 floats per mesh: mul(meshTransform, sceneRotation)
+    const incr_light* __restrict__ globalLights;
+    const int32_t* __restrict__ lightIndices;
+    const float* __restrict__ lightTransforms;     // 16 floats per scene light
+    uint32_t numGlobalLights, numSceneLights;
+    int32_t lightCount;
+    uint32_t numTris;
+    float projectionToWorld[16];
+    float cameraMatrix[16];
+    uint32_t W, H, numPixels, sampleIdx, sqrtSampleCount;
+    float aperture, focalLength, skyBrightness;
+    int32_t directLighting, viewmode;
+    incr_perez_distribution perez;
+    SkySun sunMiss, sunEnv;
+    uint32_t rowBlockHeight, rowBlockFirst, rowBlockStride, localRows;
+    uint16_t* __restrict__ target;       // RGBA16F, localRows x W
+    uint32_t* __restrict__ history;      // R11G11B10F, localRows x W
+    int32_t storageRounding;
+    incr_ray_stats* stats;
+};
+
+
+} // namespace incr

@@ -1,0 +1,300 @@
+// scene_build.cpp -- host half of the scene path: flatten -> SAH BVH2 -> BVH4 -> baked shading records.
+// See scene_build.h.  Compiled with -ffp-contract=off: the world-space vertex positions are part of the
+// parity contract (tests compare hit t/u/v bit for bit against the oracle's flattening).
+#include "scene_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <numeric>
+
+namespace incr {
+
+void copy_scene_desc(const incr_scene_desc& d, HostScene& s) {
+    s.buffers.resize(d.num_buffers);
+    for (uint32_t i = 0; i < d.num_buffers; ++i) {
+        const uint8_t* p = (const uint8_t*)d.buffers[i];
+        s.buffers[i].assign(p, p + d.buffer_sizes[i]);
+        s.buffers[i].resize(s.buffers[i].size() + 16, 0);   // slack for the dword-aligned 16-bit index unpack
+    }
+    s.bufferViews.assign(d.buffer_views, d.buffer_views + d.num_buffer_views);
+    s.accessors.assign(d.accessors, d.accessors + d.num_accessors);
+    s.primitiveCounts.assign(d.primitive_counts, d.primitive_counts + d.num_meshes);
+    s.primitiveOffset.assign(d.num_meshes + 1, 0);
+    for (uint32_t i = 0; i < d.num_meshes; ++i) s.primitiveOffset[i + 1] = s.primitiveOffset[i] + s.primitiveCounts[i];
+    s.meshTransforms.resize(d.num_meshes);
+    for (uint32_t i = 0; i < d.num_meshes; ++i) s.meshTransforms[i] = m44_from(d.mesh_transforms[i]);
+    s.meshVisibility.assign(d.num_meshes, 1u);
+    if (d.mesh_visibility) s.meshVisibility.assign(d.mesh_visibility, d.mesh_visibility + d.num_meshes);
+    s.primitives.assign(d.primitives, d.primitives + d.num_primitives);
+    s.materials.assign(d.materials, d.materials + d.num_materials);
+    s.meshlets.assign(d.meshlets, d.meshlets + d.num_meshlets);
+    s.meshletVertexIndices.assign(d.meshlet_vertex_indices, d.meshlet_vertex_indices + d.num_meshlet_vertex_indices);
+    s.meshletPackedTriangles.assign(d.meshlet_packed_triangles, d.meshlet_packed_triangles + d.num_meshlet_triangles);
+    s.globalLights.assign(d.global_lights, d.global_lights + d.num_global_lights);
+    s.lightIndices.assign(d.light_indices, d.light_indices + d.num_scene_lights);
+    s.lightTransforms.resize(d.num_scene_lights);
+    for (uint32_t i = 0; i < d.num_scene_lights; ++i) s.lightTransforms[i] = m44_from(d.light_transforms[i]);
+    s.rootTransform = m44_from(d.root_transform);
+    memcpy(s.sunDir, d.sun_dir, 12);
+}
+
+// ---- accessor fetchers: the rules of shaders/common/mesh-material.hlsli:45-170, resolved on the host ----
+struct AccessorRef { const uint8_t* base; uint32_t stride; uint64_t avail; };
+static bool resolve_accessor(const HostScene& s, int accessorIndex, AccessorRef* out) {
+    if (accessorIndex < 0 || (size_t)accessorIndex >= s.accessors.size()) return false;   // "== -1 -> 0"
+    const incr_mesh_accessor& a = s.accessors[(size_t)accessorIndex];
+    if (a.bufferViewIndex < 0 || (size_t)a.bufferViewIndex >= s.bufferViews.size()) return false;
+    const incr_mesh_buffer_view& v = s.bufferViews[(size_t)a.bufferViewIndex];
+    if (v.bufferSrvIndex < 0 || (size_t)v.bufferSrvIndex >= s.buffers.size()) return false;
+    const std::vector<uint8_t>& b = s.buffers[(size_t)v.bufferSrvIndex];
+    const uint64_t off = (uint64_t)a.byteOffset + v.byteOffset;
+    if (off > b.size()) return false;
+    out->base = b.data() + off; out->stride = a.byteStride; out->avail = b.size() - off;
+    return true;
+}
+static inline bool in_range(const AccessorRef& r, uint64_t index, uint32_t bytes) { return index * r.stride + bytes <= r.avail; }
+
+static void fetch_uint3(const AccessorRef* r, uint32_t index, uint32_t out[3]) {          // GetUint3 :45-90
+    out[0] = out[1] = out[2] = 0;
+    if (!r) return;
+    if (r->stride == 4) { if (in_range(*r, index + 2, 4)) memcpy(out, r->base + (size_t)index * 4, 12); }
+    else if (r->stride == 2) { if (in_range(*r, index + 2, 2)) { uint16_t t[3]; memcpy(t, r->base + (size_t)index * 2, 6); out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; } }
+}
+static void fetch_floats(const AccessorRef* r, uint32_t index, int ncomp, float* out) {     // GetFloat2/3/4 :92-170
+    for (int i = 0; i < ncomp; ++i) out[i] = 0.f;
+    if (!r) return;
+    bool ok = false;
+    if (ncomp == 4) ok = r->stride == 16;
+    else if (ncomp == 3) ok = r->stride == 12 || r->stride == 16;
+    else if (ncomp == 2) ok = r->stride == 8 || r->stride == 12 || r->stride == 16;
+    if (ok && in_range(*r, index, (uint32_t)ncomp * 4)) memcpy(out, r->base + (size_t)index * r->stride, (size_t)ncomp * 4);
+}
+
+bool validate_scene(const HostScene& s, const char** why) {
+    static thread_local char msg[160];
+    *why = msg;
+    if (s.primitiveOffset.back() != s.primitives.size()) { snprintf(msg, sizeof msg, "sum(primitive_counts)=%u != num_primitives=%zu", s.primitiveOffset.back(), s.primitives.size()); return false; }
+    for (size_t i = 0; i < s.primitives.size(); ++i) {
+        const incr_gpu_primitive& p = s.primitives[i];
+        if (p.materialIndex < 0 || (size_t)p.materialIndex >= s.materials.size()) { snprintf(msg, sizeof msg, "primitive %zu: materialIndex %d out of range", i, p.materialIndex); return false; }
+        if (p.meshIndex < 0 || (size_t)p.meshIndex >= s.meshTransforms.size()) { snprintf(msg, sizeof msg, "primitive %zu: meshIndex %d out of range", i, p.meshIndex); return false; }
+        if (p.indexCount < 0 || p.indicesPerTriangle != 3) { snprintf(msg, sizeof msg, "primitive %zu: indexCount/indicesPerTriangle invalid", i); return false; }
+        AccessorRef r;
+        if (!resolve_accessor(s, p.indexAccessor, &r) || !resolve_accessor(s, p.positionAccessor, &r)) { snprintf(msg, sizeof msg, "primitive %zu: index/position accessor unresolved", i); return false; }
+    }
+    for (size_t i = 0; i < s.lightIndices.size(); ++i)
+        if (s.lightIndices[i] < 0 || (size_t)s.lightIndices[i] >= s.globalLights.size()) { snprintf(msg, sizeof msg, "light_indices[%zu] out of range", i); return false; }
+    *why = "";
+    return true;
+}
+
+// ---- SAH BVH2 over triangle boxes ------------------------------------------------------------------
+namespace {
+struct Box { float lo[3], hi[3]; };
+static inline void box_reset(Box& b) { for (int a = 0; a < 3; ++a) { b.lo[a] = FLT_MAX; b.hi[a] = -FLT_MAX; } }
+static inline void box_grow(Box& b, const Box& o) { for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], o.lo[a]); b.hi[a] = std::max(b.hi[a], o.hi[a]); } }
+static inline float box_area(const Box& b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+struct Node2 { Box box; uint32_t left, right, first, count; };   // count > 0: leaf over order[first .. first+count)
+
+struct Builder {
+    const std::vector<Box>& tb; const std::vector<V3>& cen;
+    std::vector<uint32_t> order;
+    std::vector<Node2> nodes;
+    static constexpr int kBins = 16;
+
+    Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_) : tb(tb_), cen(cen_) {
+        order.resize(tb.size()); std::iota(order.begin(), order.end(), 0u);
+        nodes.reserve(tb.size() ? tb.size() : 1);
+    }
+    static inline float axis_of(const V3& v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+
+    uint32_t build(uint32_t first, uint32_t count) {
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back({});
+        Box bb, cb; box_reset(bb); box_reset(cb);
+        for (uint32_t i = first; i < first + count; ++i) {
+            const uint32_t t = order[i];
+            box_grow(bb, tb[t]);
+            const float c[3] = {cen[t].x, cen[t].y, cen[t].z};
+            for (int a = 0; a < 3; ++a) { cb.lo[a] = std::min(cb.lo[a], c[a]); cb.hi[a] = std::max(cb.hi[a], c[a]); }
+        }
+        nodes[me].box = bb;
+        if (count <= 2) { nodes[me].first = first; nodes[me].count = count; return me; }
+        // binned SAH over the three axes
+        float bestCost = FLT_MAX; int bestAxis = -1, bestSplit = -1;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.f)) continue;
+            Box bins[kBins]; uint32_t cnt[kBins];
+            for (int b = 0; b < kBins; ++b) { box_reset(bins[b]); cnt[b] = 0; }
+            const float scale = (float)kBins / ext;
+            for (uint32_t i = first; i < first + count; ++i) {
+                const uint32_t t = order[i];
+                int b = (int)((axis_of(cen[t], a) - lo) * scale); b = std::min(std::max(b, 0), kBins - 1);
+                box_grow(bins[b], tb[t]); cnt[b]++;
+            }
+            float rightArea[kBins]; uint32_t rightCnt[kBins];
+            Box acc; box_reset(acc); uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b) { box_grow(acc, bins[b]); n += cnt[b]; rightArea[b] = box_area(acc); rightCnt[b] = n; }
+            box_reset(acc); n = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                box_grow(acc, bins[b]); n += cnt[b];
+                if (n == 0 || rightCnt[b + 1] == 0) continue;
+                const float cost = box_area(acc) * (float)n + rightArea[b + 1] * (float)rightCnt[b + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
+            }
+        }
+        uint32_t mid = first;
+        const float leafCost = box_area(bb) * (float)count;
+        if (bestAxis >= 0 && (count > kMaxLeafTris || bestCost + box_area(bb) * 1.0f < leafCost)) {
+            const float lo = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), kBins - 1);
+                return b <= bestSplit;
+            });
+            mid = (uint32_t)(it - order.begin());
+        }
+        if (mid == first || mid == first + count) {
+            if (count <= kMaxLeafTris) { nodes[me].first = first; nodes[me].count = count; return me; }
+            // all centroids coincide (or SAH refused): split by index to respect the leaf limit
+            mid = first + count / 2;
+            int a = 0; float ext = cb.hi[0] - cb.lo[0];
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; a = k; }
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t x, uint32_t y) {
+                const float cx = axis_of(cen[x], a), cy = axis_of(cen[y], a);
+                return cx < cy || (cx == cy && x < y);
+            });
+        }
+        const uint32_t l = build(first, mid - first);
+        const uint32_t r = build(mid, first + count - mid);
+        nodes[me].left = l; nodes[me].right = r; nodes[me].count = 0;
+        return me;
+    }
+};
+} // namespace
+
+void build_world_bvh(const HostScene& s, HostBvh& out) {
+    // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform)
+    struct Flat { V3 v0, e1, e2; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; };
+    std::vector<Flat> flat;
+    out.meshLocalToWorld.resize(s.meshTransforms.size());
+    for (size_t m = 0; m < s.meshTransforms.size(); ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+    uint32_t inst = 0;
+    for (uint32_t mesh = 0; mesh < (uint32_t)s.meshTransforms.size(); ++mesh) {
+        if (!s.meshVisibility[mesh]) continue;
+        const M44& l2w = out.meshLocalToWorld[mesh];
+        const bool mirrored = m44_det3(l2w) < 0.f;
+        for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
+            const uint32_t pg = s.primitiveOffset[mesh] + g;
+            const incr_gpu_primitive& prim = s.primitives[pg];
+            const bool opaque = s.materials[(size_t)prim.materialIndex].alphaMode == INCR_ALPHA_OPAQUE;    // scene.cpp:736
+            AccessorRef ia, pa; const bool hi = resolve_accessor(s, prim.indexAccessor, &ia), hp = resolve_accessor(s, prim.positionAccessor, &pa);
+            const uint32_t ntri = (uint32_t)prim.indexCount / 3;
+            for (uint32_t p = 0; p < ntri; ++p) {
+                Flat f;
+                fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
+                V3 v[3];
+                for (int k = 0; k < 3; ++k) { float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos); v[k] = m44_transform_point(v3(pos[0], pos[1], pos[2]), l2w); }
+                f.v0 = v[0];
+                f.e1 = (mirrored ? v[2] : v[1]) - v[0];
+                f.e2 = (mirrored ? v[1] : v[2]) - v[0];
+                f.inst = inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg;
+                f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
+                flat.push_back(f);
+            }
+        }
+        ++inst;
+    }
+    out.numInstances = inst;
+
+    // 2. SAH BVH2
+    const size_t n = flat.size();
+    std::vector<Box> tb(n); std::vector<V3> cen(n);
+    Box scene; box_reset(scene);
+    for (size_t i = 0; i < n; ++i) {
+        const Flat& f = flat[i];
+        const V3 a = f.v0, b = f.v0 + f.e1, c = f.v0 + f.e2;
+        const float xs[3] = {a.x, b.x, c.x}, ys[3] = {a.y, b.y, c.y}, zs[3] = {a.z, b.z, c.z};
+        tb[i].lo[0] = std::min(xs[0], std::min(xs[1], xs[2])); tb[i].hi[0] = std::max(xs[0], std::max(xs[1], xs[2]));
+        tb[i].lo[1] = std::min(ys[0], std::min(ys[1], ys[2])); tb[i].hi[1] = std::max(ys[0], std::max(ys[1], ys[2]));
+        tb[i].lo[2] = std::min(zs[0], std::min(zs[1], zs[2])); tb[i].hi[2] = std::max(zs[0], std::max(zs[1], zs[2]));
+        // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
+        for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
+        cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
+        box_grow(scene, tb[i]);
+    }
+    for (int a = 0; a < 3; ++a) { out.sceneLo[a] = n ? scene.lo[a] : 0.f; out.sceneHi[a] = n ? scene.hi[a] : 0.f; }
+    Builder b(tb, cen);
+    if (n) b.build(0, (uint32_t)n);
+
+    // 3. emit triangles + shading records in leaf order
+    out.tris.resize(n); out.shade.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Flat& f = flat[b.order[i]];
+        TriIsect& t = out.tris[i];
+        t.v0x = f.v0.x; t.v0y = f.v0.y; t.v0z = f.v0.z;
+        t.e1x = f.e1.x; t.e1y = f.e1.y; t.e1z = f.e1.z;
+        t.e2x = f.e2.x; t.e2y = f.e2.y; t.e2z = f.e2.z;
+        t.flatId = b.order[i]; t.flags = f.flags; t.pad = 0;
+        TriShade& sh = out.shade[i];
+        const incr_gpu_primitive& prim = s.primitives[f.primGlobal];
+        AccessorRef na, ta, ua;
+        const bool hn = resolve_accessor(s, prim.normalAccessor, &na), ht = resolve_accessor(s, prim.tangentAccessor, &ta), hu = resolve_accessor(s, prim.uvAccessor, &ua);
+        for (int k = 0; k < 3; ++k) {
+            fetch_floats(hn ? &na : nullptr, f.idx[k], 3, sh.n[k]);
+            fetch_floats(ht ? &ta : nullptr, f.idx[k], 4, sh.t[k]);
+            fetch_floats(hu ? &ua : nullptr, f.idx[k], 2, sh.uv[k]);
+        }
+        sh.materialIndex = (uint32_t)prim.materialIndex;
+        sh.meshIndex = (uint32_t)prim.meshIndex;
+        sh.instance = f.inst; sh.geometry = f.geom; sh.primitive = f.prim;
+    }
+
+    // 4. collapse BVH2 -> BVH4 (pull up the grandchildren of the child with the largest surface area)
+    out.nodes.clear(); out.maxDepth = 0;
+    if (!n) {
+        BvhNode4 e{};
+        for (int k = 0; k < 4; ++k) { e.lox[k] = e.loy[k] = e.loz[k] = FLT_MAX; e.hix[k] = e.hiy[k] = e.hiz[k] = -FLT_MAX; e.child[k] = kEmptyChild; }
+        out.nodes.push_back(e);
+        return;
+    }
+    struct Item { uint32_t n2, n4, depth; };
+    std::vector<Item> work;
+    out.nodes.push_back({});
+    work.push_back({0u, 0u, 1u});
+    while (!work.empty()) {
+        const Item it = work.back(); work.pop_back();
+        out.maxDepth = std::max(out.maxDepth, it.depth);
+        uint32_t kids[4]; int nk = 0;
+        const Node2& root2 = b.nodes[it.n2];
+        if (root2.count) kids[nk++] = it.n2;                   // degenerate: the whole tree is one leaf
+        else { kids[nk++] = root2.left; kids[nk++] = root2.right; }
+        while (nk < 4) {
+            int best = -1; float bestA = -1.f;
+            for (int k = 0; k < nk; ++k) { const Node2& c = b.nodes[kids[k]]; if (!c.count) { float a = box_area(c.box); if (a > bestA) { bestA = a; best = k; } } }
+            if (best < 0) break;
+            const Node2& c = b.nodes[kids[best]];
+            kids[best] = c.left; kids[nk++] = c.right;
+        }
+        BvhNode4 nd{};
+        for (int k = 0; k < 4; ++k) {
+            if (k < nk) {
+                const Node2& c = b.nodes[kids[k]];
+                nd.lox[k] = c.box.lo[0]; nd.loy[k] = c.box.lo[1]; nd.loz[k] = c.box.lo[2];
+                nd.hix[k] = c.box.hi[0]; nd.hiy[k] = c.box.hi[1]; nd.hiz[k] = c.box.hi[2];
+                if (c.count) nd.child[k] = kLeafBit | (c.first << 2) | (c.count - 1);
+                else { nd.child[k] = (uint32_t)out.nodes.size(); out.nodes.push_back({}); work.push_back({kids[k], nd.child[k], it.depth + 1}); }
+            } else {
+                nd.lox[k] = nd.loy[k] = nd.loz[k] = FLT_MAX; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -FLT_MAX; nd.child[k] = kEmptyChild;
+            }
+        }
+        out.nodes[it.n4] = nd;
+    }
+}
+
+} // namespace incr

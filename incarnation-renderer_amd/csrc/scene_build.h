@@ -1,0 +1,46 @@
+// scene_build.h -- host-side stand-in for FScene::CreateAccelerationStructures + UpdateTLASPass
+// (reference: source/demo-dll/src/scene.cpp:672-848, src/render-jobs/update-tlas.inl:3-101):
+// flattens every visible mesh instance to world space, builds a SAH BVH, collapses it to 4-wide
+// nodes and bakes one 128-byte shading record per triangle.
+#pragma once
+#include <vector>
+#include "device_types.h"
+#include "host_math.h"
+
+namespace incr {
+
+struct HostScene {
+    // deep copies of the caller's arrays (the desc only borrows)
+    std::vector<std::vector<uint8_t>> buffers;
+    std::vector<incr_mesh_buffer_view> bufferViews;
+    std::vector<incr_mesh_accessor> accessors;
+    std::vector<uint32_t> primitiveCounts, primitiveOffset;
+    std::vector<M44> meshTransforms;
+    std::vector<uint32_t> meshVisibility;
+    std::vector<incr_gpu_primitive> primitives;
+    std::vector<incr_material> materials;
+    std::vector<incr_gpu_meshlet> meshlets;
+    std::vector<uint32_t> meshletVertexIndices, meshletPackedTriangles;
+    std::vector<incr_light> globalLights;
+    std::vector<int32_t> lightIndices;
+    std::vector<M44> lightTransforms;
+    M44 rootTransform;
+    float sunDir[3];
+};
+
+struct HostBvh {
+    std::vector<BvhNode4> nodes;        // node 0 = root
+    std::vector<TriIsect> tris;         // leaf order
+    std::vector<TriShade> shade;        // leaf order
+    std::vector<M44> meshLocalToWorld;  // per mesh: meshTransform * rootTransform (shader: mul(localToWorld, sceneRotation))
+    uint32_t numInstances = 0;
+    uint32_t maxDepth = 0;
+    float sceneLo[3], sceneHi[3];
+};
+
+void copy_scene_desc(const incr_scene_desc& d, HostScene& out);
+// returns false with a message when the desc is inconsistent (index out of range etc.)
+bool validate_scene(const HostScene& s, const char** why);
+void build_world_bvh(const HostScene& s, HostBvh& out);
+
+} // namespace incr

@@ -1,0 +1,204 @@
+"""Loader and thin object wrappers for the C-ABI library csrc/libincr_hip.so (include/incr.h).
+
+There is NO fallback path: `load()` raises if the HIP library is missing, and `Context()` raises
+INCR_ERR_NO_DEVICE when no GPU is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import ctypes_api as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libincr_hip.so")
+
+# every symbol include/incr.h declares (tests/test_abi.py checks the library exports all of them)
+EXPORTS = [
+    "incr_initialize", "incr_teardown", "incr_last_error", "incr_version", "incr_device_count",
+    "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
+    "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
+    "incr_scene_get_info", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
+]
+
+
+class IncrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("incr error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j4"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IncrError(-5, "HIP library %s is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback for the render path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.incr_initialize.restype = C.c_int; L.incr_initialize.argtypes = [C.c_int, C.POINTER(vp)]
+    L.incr_teardown.restype = C.c_int; L.incr_teardown.argtypes = [vp]
+    L.incr_last_error.restype = C.c_char_p; L.incr_last_error.argtypes = []
+    L.incr_version.restype = C.c_char_p; L.incr_version.argtypes = []
+    L.incr_device_count.restype = C.c_int; L.incr_device_count.argtypes = []
+    L.incr_buffer_create.restype = C.c_int; L.incr_buffer_create.argtypes = [vp, u64, C.POINTER(vp)]
+    L.incr_buffer_destroy.restype = C.c_int; L.incr_buffer_destroy.argtypes = [vp, vp]
+    L.incr_buffer_upload.restype = C.c_int; L.incr_buffer_upload.argtypes = [vp, vp, vp, u64, vp]
+    L.incr_buffer_download.restype = C.c_int; L.incr_buffer_download.argtypes = [vp, vp, vp, u64, vp]
+    L.incr_buffer_clear.restype = C.c_int; L.incr_buffer_clear.argtypes = [vp, vp, u32, u64, vp]
+    L.incr_stream_synchronize.restype = C.c_int; L.incr_stream_synchronize.argtypes = [vp, vp]
+    L.incr_scene_create.restype = C.c_int; L.incr_scene_create.argtypes = [vp, C.POINTER(A.SceneDesc), C.POINTER(vp)]
+    L.incr_scene_destroy.restype = C.c_int; L.incr_scene_destroy.argtypes = [vp, vp]
+    L.incr_update_bvh.restype = C.c_int; L.incr_update_bvh.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.incr_scene_set_sun_dir.restype = C.c_int; L.incr_scene_set_sun_dir.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.incr_scene_get_info.restype = C.c_int; L.incr_scene_get_info.argtypes = [vp, vp, C.POINTER(A.SceneInfo)]
+    L.incr_shard_local_rows.restype = u32; L.incr_shard_local_rows.argtypes = [u32, C.POINTER(A.Shard)]
+    L.incr_pathtrace.restype = C.c_int; L.incr_pathtrace.argtypes = [vp, C.POINTER(A.PathtraceDesc), vp]
+    L.incr_tonemap.restype = C.c_int; L.incr_tonemap.argtypes = [vp, C.POINTER(A.TonemapDesc), vp]
+    L.incr_unshard.restype = C.c_int; L.incr_unshard.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise IncrError(rc, load().incr_last_error().decode())
+
+
+class Context:
+    """incr_context: one per process / GPU."""
+
+    def __init__(self, device_index=0):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        check(self.lib.incr_initialize(device_index, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.incr_teardown(self.handle)
+            self.handle = C.c_void_p()
+
+    # -- resource layer
+    def buffer(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.incr_buffer_create(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        check(self.lib.incr_buffer_destroy(self.handle, ptr))
+
+    def upload(self, ptr, array, stream=None):
+        a = np.ascontiguousarray(array)
+        check(self.lib.incr_buffer_upload(self.handle, ptr, a.ctypes.data, a.nbytes, stream))
+
+    def download(self, ptr, shape, dtype, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        check(self.lib.incr_buffer_download(self.handle, out.ctypes.data, ptr, out.nbytes, stream))
+        return out
+
+    def clear(self, ptr, nbytes, value32=0, stream=None):
+        check(self.lib.incr_buffer_clear(self.handle, ptr, value32, nbytes, stream))
+
+    def synchronize(self, stream=None):
+        check(self.lib.incr_stream_synchronize(self.handle, stream))
+
+    # -- scene
+    def create_scene(self, packed_scene):
+        return Scene(self, packed_scene)
+
+    # -- passes
+    def pathtrace(self, desc, stream=None):
+        check(self.lib.incr_pathtrace(self.handle, C.byref(desc), stream))
+
+    def tonemap(self, desc, stream=None):
+        check(self.lib.incr_tonemap(self.handle, C.byref(desc), stream))
+
+    def unshard(self, dst, src, res_x, res_y, row_block_height, num_shards, texel_bytes, stream=None):
+        check(self.lib.incr_unshard(self.handle, dst, src, res_x, res_y, row_block_height, num_shards, texel_bytes, stream))
+
+
+class Scene:
+    def __init__(self, ctx, packed_scene):
+        self.ctx = ctx
+        self.packed = packed_scene
+        desc = packed_scene.to_desc()
+        self.handle = C.c_void_p()
+        check(ctx.lib.incr_scene_create(ctx.handle, C.byref(desc), C.byref(self.handle)))
+
+    def info(self):
+        i = A.SceneInfo()
+        check(self.ctx.lib.incr_scene_get_info(self.ctx.handle, self.handle, C.byref(i)))
+        return i
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.incr_scene_destroy(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+
+def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FConfig, storage_rounding=0):
+    """Fill an incr_pathtrace_desc from FConfig defaults (inc/common.h:6-48) and an FView."""
+    d = A.PathtraceDesc()
+    d.res_x, d.res_y = res_x, res_y
+    if shard is not None:
+        d.shard = shard
+    d.current_sample_index = sample_index
+    d.max_sample_count = cfg.MaxSampleCount
+    d.view = view.to_ctypes()
+    d.camera_aperture = cfg.Pathtracing_CameraAperture
+    d.camera_focal_length = cfg.Pathtracing_CameraFocalLength
+    d.env_sky_mode = cfg.EnvSkyMode
+    d.direct_lighting = 1 if cfg.EnableDirectLighting else 0
+    d.viewmode = cfg.Viewmode
+    d.turbidity = cfg.Turbidity
+    d.sky_brightness = cfg.SkyBrightness
+    d.storage_rounding = storage_rounding
+    return d
+
+
+class PathTracer:
+    """Convenience driver around incr_pathtrace with library-owned buffers (tests / smoke)."""
+
+    def __init__(self, ctx, scene, res_x, res_y, shard=None):
+        self.ctx, self.scene, self.res_x, self.res_y = ctx, scene, res_x, res_y
+        self.shard = shard if shard is not None else A.Shard(0, 0, 1)
+        self.rows = ctx.lib.incr_shard_local_rows(res_y, C.byref(self.shard))
+        self.target = ctx.buffer(self.rows * res_x * 8)
+        self.history = ctx.buffer(self.rows * res_x * 4)
+        self.stats = ctx.buffer(C.sizeof(A.RayStats))
+        ctx.clear(self.history, self.rows * res_x * 4)
+        ctx.clear(self.stats, C.sizeof(A.RayStats))
+
+    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True):
+        d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding)
+        d.scene = self.scene.handle
+        d.target_rgba16f, d.history_r11g11b10 = self.target, self.history
+        d.ray_stats = self.stats if count_rays else None
+        self.ctx.pathtrace(d, stream)
+        return d
+
+    def read(self):
+        self.ctx.synchronize()
+        target = self.ctx.download(self.target, (self.rows, self.res_x, 4), np.uint16)
+        history = self.ctx.download(self.history, (self.rows, self.res_x), np.uint32)
+        raw = self.ctx.download(self.stats, (C.sizeof(A.RayStats),), np.uint8)
+        stats = A.RayStats.from_buffer_copy(raw.tobytes())
+        return dict(target=target, history=history, stats=stats)
+
+    def close(self):
+        for p in (self.target, self.history, self.stats):
+            self.ctx.free(p)

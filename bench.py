@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Incarnation render hot path.
+
+Metric (BASELINE.json): Mray/s (+ ms/frame) at 4K, 1 spp, Sponza, path tracer.  A "step" is one
+1-spp frame of the path tracer at 3840x2160 on the deterministic "Sponza-stat" scene
+(Sponza.bin is absent from the reference checkout) accumulated into the
+R11G11B10F history, exactly what RenderJob::PathTracing::Execute does per displayed frame.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+N > 1 shards the framebuffer in interleaved 8-row blocks (one process per GPU, scene replicated) and
+gathers the HDR history to every rank with one RCCL all_gather per frame (strong scaling: the frame is fixed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "incarnation-renderer_amd"
+
+# Algorithmic bytes (SURVEY.md 8d / DESIGN.md "Measurement"): per traversal query 32 + ceil(log2 T)*32 + 36 + 16,
+# per shaded hit 378, per pixel-sample 24.
+B_HIT, B_PX = 378, 24
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def bytes_per_ray(num_tris):
+    return 32 + int(np.ceil(np.log2(max(num_tris, 2)))) * 32 + 36 + 16
+
+
+def build_scene(name, texture_size):
+    sio = importlib.import_module(PKG + ".scene_io")
+    syn = importlib.import_module(PKG + ".synth")
+    if name == "sponza":
+        return syn.sponza_stat(texture_size=texture_size)
+    if name == "helmet":
+        return sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+    if name == "bistro":
+        return syn.bistro_scale()
+    raise SystemExit("unknown scene " + name)
+
+
+def cpu_baseline(packed, view, res, seconds_hint):
+    """Oracle (scalar CPU restatement, kind "port") on a bounded sample of the same workload."""
+    from oracle import binding as ob
+    rt = importlib.import_module(PKG + ".runtime")
+    cores = os.cpu_count() or 1
+    osc = ob.OracleScene(packed)
+    W, H = res
+    d = rt.make_pathtrace_desc(view, W, H, 1)
+    t0 = time.time()
+    r = osc.pathtrace(d, num_threads=cores)
+    dt = time.time() - t0
+    rays = r["stats"].total_rays()
+    osc.close()
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": "oracle/oracle_pt.cpp, same scene and camera, %dx%d 1 spp (%d rays) in %.2f s on %d threads" % (W, H, rays, dt, cores),
+            "seconds": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="sponza", choices=["sponza", "helmet", "bistro"])
+    ap.add_argument("--res", default="3840x2160")
+    ap.add_argument("--texture-size", type=int, default=1024)
+    ap.add_argument("--cpu-res", default="960x540")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    A = importlib.import_module(PKG + ".ctypes_api")
+    sio = importlib.import_module(PKG + ".scene_io")
+    rt = importlib.import_module(PKG + ".runtime")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    W, H = (int(v) for v in args.res.lower().split("x"))
+    packed = build_scene(args.scene, args.texture_size)
+    view = sio.FView().reset(packed, aspect=W / H)
+    ctx = rt.Context(local_rank)
+    scene = ctx.create_scene(packed)
+    info = scene.info()
+
+    shard = A.Shard(0, 0, 1) if world == 1 else A.Shard(8, rank, world)
+    rows = ctx.lib.incr_shard_local_rows(H, C.byref(shard))
+    target = torch.zeros((rows, W, 4), dtype=torch.int16, device=dev)        # RGBA16F bits
+    history = torch.zeros((rows, W), dtype=torch.int32, device=dev)          # R11G11B10F bits
+    stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    gathered = torch.zeros((world, rows, W), dtype=torch.int32, device=dev) if world > 1 else None
+    full = torch.zeros((H, W), dtype=torch.int32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step(sample_index, e0=None, e1=None):
+        d = rt.make_pathtrace_desc(view, W, H, sample_index, shard)
+        d.scene = scene.handle
+        d.target_rgba16f, d.history_r11g11b10, d.ray_stats = target.data_ptr(), history.data_ptr(), stats.data_ptr()
+        if e0 is not None:
+            e0.record(stream)
+        ctx.pathtrace(d, stream.cuda_stream)
+        if e1 is not None:
+            e1.record(stream)
+        if world > 1:   # the one exchange step of the path: gather disjoint framebuffer shards
+            dist.all_gather_into_tensor(gathered, history)
+            ctx.unshard(full.data_ptr(), gathered.data_ptr(), W, H, shard.row_block_height, world, 4, stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    sample = 1
+    for _ in range(args.warmup):
+        step(sample); sample += 1
+    barrier()
+    stats.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(sample, ev[i][0], ev[i][1]); sample += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    # max over ranks of the wall time, sum over ranks of the rays traced
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    local_stats = stats.clone()
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    dt = float(tt.item())
+    s = stats.cpu().numpy()
+    ls = local_stats.cpu().numpy()
+    rays = int(s[0] + s[1] + s[2] + s[3]); hits = int(s[4])
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events around the pathtrace launch, on the stream it is launched on
+
+    if rank == 0:
+        b_ray = bytes_per_ray(int(info.num_triangles))
+        # roofline of the dominant kernel on THIS rank: algorithmic bytes of its launches / its duration
+        l_rays = int(ls[0] + ls[1] + ls[2] + ls[3]); l_hits = int(ls[4])
+        l_px = rows * W
+        alg_bytes_per_launch = (l_rays * b_ray + l_hits * B_HIT) / args.steps + l_px * B_PX
+        achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mray/s", "value": round(rays / dt / 1e6, 3), "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
+                                   % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
+                       "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size,
+                       "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of R11G11B10F history",
+                       "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
+                       "ms_per_frame": round(dt / args.steps * 1e3, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "incr::pathtrace_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                         "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(traffic_file):
+            try:
+                with open(traffic_file) as f:
+                    tj = json.load(f)
+                if tj.get("scene") == args.scene and tj.get("resolution") == [W, H]:
+                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = tj.get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            cw, ch = (int(v) for v in args.cpu_res.lower().split("x"))
+            out["cpu_baseline"] = cpu_baseline(packed, sio.FView().reset(packed, aspect=cw / ch), (cw, ch), 20)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--texture-size", type=int, default=1024)
     ap.add_argument("--cpu-res", default="960x540")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
+    ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +120,9 @@ def main():
     def step(sample_index, e0=None, e1=None):
         d = rt.make_pathtrace_desc(view, W, H, sample_index, shard)
         d.scene = scene.handle
+        if args.no_direct_lighting:
+            d.direct_lighting = 0
+        d.viewmode = args.viewmode
         d.target_rgba16f, d.history_r11g11b10, d.ray_stats = target.data_ptr(), history.data_ptr(), stats.data_ptr()
         if e0 is not None:
             e0.record(stream)

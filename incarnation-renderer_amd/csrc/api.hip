@@ -20,6 +20,8 @@
 using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
+                                             int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
 extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
                                           uint32_t localRows, uint32_t texelBytes, hipStream_t stream);
@@ -51,6 +53,8 @@ struct incr_scene {
     std::vector<void*> dTexels;
     uint64_t textureBytes = 0;
 };
+
+static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
 
 extern "C" {
 
@@ -251,8 +255,7 @@ uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* sh) {
     if (!sh || sh->row_block_height == 0) return res_y;
     const uint32_t nblk = (res_y + sh->row_block_height - 1) / sh->row_block_height;
     const uint32_t stride = sh->row_block_stride ? sh->row_block_stride : 1;
-    if (sh->row_block_first >= nblk) return 0;
-    const uint32_t mine = (nblk - sh->row_block_first + stride - 1) / stride;
+    const uint32_t mine = (nblk + stride - 1) / stride;     // same for every rank (equal-size all_gather); surplus rows are padding
     return mine * sh->row_block_height;
 }
 
@@ -302,15 +305,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     if (d->max_sample_count < 1) return fail(INCR_ERR_INVALID_ARGUMENT, "max_sample_count must be >= 1");
     if (d->shard.row_block_height && !d->shard.row_block_stride) return fail(INCR_ERR_INVALID_ARGUMENT, "row_block_stride must be >= 1");
     const incr_scene* sc = d->scene;
-    PtParams P;
-    memset(&P, 0, sizeof P);
-    P.nodes = sc->dNodes; P.tris = sc->dTris; P.shade = sc->dShade;
-    P.materials = sc->dMaterials; P.textures = sc->dTextures; P.srgbLut = ctx->srgbLut;
-    P.meshLocalToWorld = sc->dMeshLocalToWorld;
-    P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
-    P.numGlobalLights = (uint32_t)sc->host.globalLights.size(); P.numSceneLights = (uint32_t)sc->host.lightIndices.size();
-    P.lightCount = (int32_t)sc->host.globalLights.size();                     // path-tracing.inl:198 m_globalLightList.size()
-    P.numTris = (uint32_t)sc->bvh.tris.size();
+    PtParams P; fill_scene_params(ctx, sc, P);
     const M44 V = m44_from(d->view.view_transform), Pm = m44_from(d->view.projection_transform);
     const M44 p2w = m44_inverse(m44_mul(V, Pm)), cam = m44_inverse(V);              // :199, :201
     memcpy(P.projectionToWorld, p2w.m, 64); memcpy(P.cameraMatrix, cam.m, 64);
@@ -338,6 +333,43 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.storageRounding = d->storage_rounding;
     P.stats = d->ray_stats;
     HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P) {
+    memset(&P, 0, sizeof P);
+    P.nodes = sc->dNodes; P.tris = sc->dTris; P.shade = sc->dShade;
+    P.materials = sc->dMaterials; P.textures = sc->dTextures; P.srgbLut = ctx->srgbLut;
+    P.meshLocalToWorld = sc->dMeshLocalToWorld;
+    P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
+    P.numGlobalLights = (uint32_t)sc->host.globalLights.size(); P.numSceneLights = (uint32_t)sc->host.lightIndices.size();
+    P.lightCount = (int32_t)sc->host.globalLights.size();                     // path-tracing.inl:198 m_globalLightList.size()
+    P.numTris = (uint32_t)sc->bvh.tris.size();
+}
+
+int incr_trace_rays(incr_context* ctx, const incr_scene* sc, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
+                    int any_hit, uint32_t* out_ids, float* out_tuv, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc || (n && (!origins || !dirs || !out_ids || !out_tuv))) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    PtParams P; fill_scene_params(ctx, sc, P);
+    HIP_TRY(incr_launch_trace_rays(&P, n, origins, dirs, tmin, tmax, any_hit, out_ids, out_tuv, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info) {
+    if (!desc || !info) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    HostScene hs; HostBvh bvh;
+    copy_scene_desc(*desc, hs);
+    const char* why = "";
+    if (!validate_scene(hs, &why)) return fail(INCR_ERR_INVALID_ARGUMENT, "scene desc rejected: %s", why);
+    build_world_bvh(hs, bvh);
+    const char* err = check_bvh(bvh);
+    if (err) return fail(INCR_ERR_INVALID_ARGUMENT, "BVH invariant violated: %s", err);
+    memset(info, 0, sizeof *info);
+    info->num_triangles = bvh.tris.size(); info->num_bvh_nodes = bvh.nodes.size();
+    info->bvh_bytes = bvh.nodes.size() * sizeof(BvhNode4); info->triangle_bytes = bvh.tris.size() * sizeof(TriIsect);
+    info->shading_bytes = bvh.shade.size() * sizeof(TriShade);
+    info->num_instances = bvh.numInstances; info->bvh_max_depth = bvh.maxDepth;
     return INCR_OK;
 }
 

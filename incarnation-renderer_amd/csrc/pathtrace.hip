@@ -478,6 +478,29 @@ __global__ __launch_bounds__(kBlock) void pathtrace_kernel(const PtParams P) {
     }
 }
 
+// incr_trace_rays: batch of inline ray queries (debug / RayQuery stand-in); one lane per ray
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const PtParams P, uint32_t n, const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                            float tmin, float tmax, int anyHit, uint32_t* __restrict__ ids, float* __restrict__ tuv) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= n) return;
+    LaneStack st; st.lds = s_stack + tid; st.sp = 0;
+    const f3 o = {origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]}, d = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
+    uint4 id = make_uint4(0, 0, 0, 0); f3 r = {0.f, 0.f, 0.f};
+    if (anyHit) id.x = trace_any(P, st, o, d, tmin, tmax) ? 1u : 0u;
+    else {
+        Hit h;
+        if (trace_closest(P, st, o, d, tmin, tmax, &h)) {
+            const TriShade* __restrict__ sh = P.shade + h.tri;
+            id = make_uint4(1u, sh->instance, sh->geometry, sh->primitive);
+            r = {h.t, h.u, h.v};
+        }
+    }
+    *(uint4*)(ids + (size_t)i * 4) = id;
+    tuv[(size_t)i * 3] = r.x; tuv[(size_t)i * 3 + 1] = r.y; tuv[(size_t)i * 3 + 2] = r.z;
+}
+
 // TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode
 DI uint32_t linear_to_srgb8(float c) {
     if (!(c > 0.f)) c = 0.f;
@@ -517,6 +540,12 @@ extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t
     const uint32_t tilesX = (p->W + 15u) / 16u, tilesY = (p->localRows + 15u) / 16u;
     if (tilesX == 0 || tilesY == 0) return hipSuccess;
     hipLaunchKernelGGL(incr::pathtrace_kernel, dim3(tilesX * tilesY), dim3(incr::kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
+                                             int anyHit, uint32_t* ids, float* tuv, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(incr::trace_rays_kernel, dim3((n + incr::kBlock - 1) / incr::kBlock), dim3(incr::kBlock), 0, stream, *p, n, origins, dirs, tmin, tmax, anyHit, ids, tuv);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream) {

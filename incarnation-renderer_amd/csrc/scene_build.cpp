@@ -297,4 +297,46 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     }
 }
 
+const char* check_bvh(const HostBvh& bvh) {
+    static thread_local char msg[160];
+    const size_t n = bvh.tris.size();
+    if (bvh.nodes.empty()) return "no root node";
+    if (bvh.shade.size() != n) return "shading records != triangles";
+    std::vector<uint8_t> seen(n, 0), seenFlat(n, 0);
+    for (size_t i = 0; i < n; ++i) { if (bvh.tris[i].flatId >= n || seenFlat[bvh.tris[i].flatId]) return "flatId is not a permutation"; seenFlat[bvh.tris[i].flatId] = 1; }
+    struct Item { uint32_t node; Box parent; bool hasParent; };
+    std::vector<Item> st; st.push_back({0u, {}, false});
+    std::vector<uint8_t> visited(bvh.nodes.size(), 0);
+    const float eps = 0.f;
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        if (it.node >= bvh.nodes.size()) return "child index out of range";
+        if (visited[it.node]) return "node referenced twice";
+        visited[it.node] = 1;
+        const BvhNode4& nd = bvh.nodes[it.node];
+        for (int k = 0; k < 4; ++k) {
+            if (nd.child[k] == kEmptyChild) continue;
+            Box b; b.lo[0] = nd.lox[k]; b.lo[1] = nd.loy[k]; b.lo[2] = nd.loz[k]; b.hi[0] = nd.hix[k]; b.hi[1] = nd.hiy[k]; b.hi[2] = nd.hiz[k];
+            if (it.hasParent) for (int a = 0; a < 3; ++a) if (b.lo[a] < it.parent.lo[a] - eps || b.hi[a] > it.parent.hi[a] + eps) { snprintf(msg, sizeof msg, "node %u child %d escapes its parent box", it.node, k); return msg; }
+            if (nd.child[k] & kLeafBit) {
+                const uint32_t first = (nd.child[k] & ~kLeafBit) >> 2, cnt = (nd.child[k] & 3u) + 1u;
+                for (uint32_t t = first; t < first + cnt; ++t) {
+                    if (t >= n) return "leaf range out of bounds";
+                    if (seen[t]) return "triangle in two leaves";
+                    seen[t] = 1;
+                    const TriIsect& T = bvh.tris[t];
+                    const float vx[3] = {T.v0x, T.v0x + T.e1x, T.v0x + T.e2x}, vy[3] = {T.v0y, T.v0y + T.e1y, T.v0y + T.e2y}, vz[3] = {T.v0z, T.v0z + T.e1z, T.v0z + T.e2z};
+                    for (int v = 0; v < 3; ++v)
+                        if (vx[v] < b.lo[0] || vx[v] > b.hi[0] || vy[v] < b.lo[1] || vy[v] > b.hi[1] || vz[v] < b.lo[2] || vz[v] > b.hi[2]) {
+                            if (vx[v] == vx[v] && vy[v] == vy[v] && vz[v] == vz[v]) { snprintf(msg, sizeof msg, "triangle %u vertex outside its leaf box", t); return msg; }
+                        }
+                }
+            } else st.push_back({nd.child[k], b, true});
+        }
+    }
+    for (size_t i = 0; i < n; ++i) if (!seen[i]) return "triangle not referenced by any leaf";
+    for (size_t i = 0; i < visited.size(); ++i) if (!visited[i]) return "unreachable node";
+    return nullptr;
+}
+
 } // namespace incr

@@ -42,5 +42,7 @@ void copy_scene_desc(const incr_scene_desc& d, HostScene& out);
 // returns false with a message when the desc is inconsistent (index out of range etc.)
 bool validate_scene(const HostScene& s, const char** why);
 void build_world_bvh(const HostScene& s, HostBvh& out);
+// NULL when every invariant holds, else a description of the first violation
+const char* check_bvh(const HostBvh& bvh);
 
 } // namespace incr

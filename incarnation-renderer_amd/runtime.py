@@ -21,6 +21,7 @@ EXPORTS = [
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
     "incr_scene_get_info", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
+    "incr_trace_rays", "incr_scene_validate_host",
 ]
 
 
@@ -70,6 +71,10 @@ def load():
     L.incr_pathtrace.restype = C.c_int; L.incr_pathtrace.argtypes = [vp, C.POINTER(A.PathtraceDesc), vp]
     L.incr_tonemap.restype = C.c_int; L.incr_tonemap.argtypes = [vp, C.POINTER(A.TonemapDesc), vp]
     L.incr_unshard.restype = C.c_int; L.incr_unshard.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, vp]
+    L.incr_trace_rays.restype = C.c_int
+    L.incr_trace_rays.argtypes = [vp, vp, u32, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp]
+    L.incr_scene_validate_host.restype = C.c_int
+    L.incr_scene_validate_host.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.SceneInfo)]
     _lib = L
     return L
 
@@ -143,6 +148,21 @@ class Scene:
         i = A.SceneInfo()
         check(self.ctx.lib.incr_scene_get_info(self.ctx.handle, self.handle, C.byref(i)))
         return i
+
+    def trace_rays(self, origins, dirs, tmin, tmax, any_hit=False):
+        """incr_trace_rays on host arrays (uploads, launches, downloads): returns (ids [n,4] u32, tuv [n,3] f32)."""
+        ctx = self.ctx
+        o = np.ascontiguousarray(origins, dtype=np.float32); d = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = o.shape[0]
+        bufs = [ctx.buffer(max(n, 1) * 12), ctx.buffer(max(n, 1) * 12), ctx.buffer(max(n, 1) * 16), ctx.buffer(max(n, 1) * 12)]
+        try:
+            ctx.upload(bufs[0], o); ctx.upload(bufs[1], d)
+            check(ctx.lib.incr_trace_rays(ctx.handle, self.handle, n, bufs[0], bufs[1], tmin, tmax, int(any_hit), bufs[2], bufs[3], None))
+            ctx.synchronize()
+            return ctx.download(bufs[2], (n, 4), np.uint32), ctx.download(bufs[3], (n, 3), np.float32)
+        finally:
+            for b in bufs:
+                ctx.free(b)
 
     def close(self):
         if self.handle:

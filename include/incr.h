@@ -130,6 +130,23 @@ typedef struct incr_tonemap_desc {
 } incr_tonemap_desc;
 int  incr_tonemap(incr_context* ctx, const incr_tonemap_desc* desc, incr_stream stream);
 
+/*
+ * Inline ray queries against the scene's acceleration structure: the stand-in for DXR TraceRay / RayQuery
+ * (call sites: shaders/raytracing/pathtracing.hlsl:117,265; shaders/lighting/common.hlsli:102-115).
+ * All rays use RAY_FLAG_CULL_BACK_FACING_TRIANGLES like every call site of the reference.
+ *   any_hit == 0: closest hit (non-opaque geometry runs the ahsMain alpha test); out_ids[i] = {hit, InstanceIndex,
+ *                 GeometryIndex, PrimitiveIndex}, out_tuv[i] = {t, barycentric u, v}
+ *   any_hit != 0: RayQuery + single Proceed(): out_ids[i].x = 1 iff any front-facing triangle intersects (tmin, tmax)
+ * All pointers are DEVICE pointers: origins/dirs 3 floats per ray, out_ids 4 uint32 per ray, out_tuv 3 floats per ray.
+ */
+int  incr_trace_rays(incr_context* ctx, const incr_scene* scene, uint32_t num_rays, const float* origins, const float* dirs,
+                     float tmin, float tmax, int any_hit, uint32_t* out_ids, float* out_tuv, incr_stream stream);
+
+/* Host-only check of the scene packing + acceleration-structure build (no GPU needed): builds the flattened
+ * BVH exactly as incr_scene_create does and verifies its invariants.  Returns INCR_OK and fills `info`
+ * when every triangle is referenced by exactly one leaf and every node box encloses its subtree. */
+int  incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* out_info);
+
 /* Un-interleave gathered shards: src is [stride][local_rows][res_x] texels of `texel_bytes`, dst the full frame. */
 int  incr_unshard(incr_context* ctx, void* dst_full, const void* src_gathered, uint32_t res_x, uint32_t res_y,
                   uint32_t row_block_height, uint32_t num_shards, uint32_t texel_bytes, incr_stream stream);

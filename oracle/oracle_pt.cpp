@@ -837,8 +837,7 @@ static uint32_t shard_local_rows(uint32_t res_y, const incr_shard& sh) {
     if (sh.row_block_height == 0) return res_y;
     const uint32_t nblk = (res_y + sh.row_block_height - 1) / sh.row_block_height;
     const uint32_t stride = sh.row_block_stride ? sh.row_block_stride : 1;
-    if (sh.row_block_first >= nblk) return 0;
-    const uint32_t mine = (nblk - sh.row_block_first + stride - 1) / stride;
+    const uint32_t mine = (nblk + stride - 1) / stride;     // same for every rank (equal-size all_gather); surplus rows are padding
     return mine * sh.row_block_height;
 }
 // local row -> global row, or -1 when the local row is padding past the end of the frame

@@ -1,0 +1,76 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "incarnation-renderer_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def mod(name):
+    return importlib.import_module(PKG + "." + name)
+
+
+@pytest.fixture(scope="session")
+def A():
+    return mod("ctypes_api")
+
+
+@pytest.fixture(scope="session")
+def sio():
+    return mod("scene_io")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return mod("synth")
+
+
+@pytest.fixture(scope="session")
+def rt():
+    return mod("runtime")
+
+
+@pytest.fixture(scope="session")
+def ob():
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def helmet(sio):
+    return sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+
+
+@pytest.fixture(scope="session")
+def helmet_oracle(ob, helmet):
+    return ob.OracleScene(helmet)
+
+
+@pytest.fixture(scope="session")
+def sponza_small(synth):
+    """Sponza-stat at 1/16 of the triangle budget with 64^2 textures (seconds on the CPU oracle)."""
+    return synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0)
+
+
+@pytest.fixture(scope="session")
+def sponza_small_oracle(ob, sponza_small):
+    return ob.OracleScene(sponza_small)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(rt):
+    ctx = rt.Context(0)
+    yield ctx
+    ctx.close()
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <algorithm>
@@ -20,6 +21,7 @@
 using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_pathtrace_wave(const incr::PtParams* p, uint32_t* tileQueue, int numCUs, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -39,7 +41,11 @@ struct incr_context {
     int device;
     hipDeviceProp_t props;
     float* srgbLut;           // 256 floats in HBM
+    uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
+    uint32_t nextQueue;
+    int kernelVariant;        // 0 = persistent wavefront kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega)
 };
+static constexpr uint32_t kNumTileQueues = 64;
 
 struct incr_scene {
     incr_context* ctx;
@@ -86,6 +92,11 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     }
     HIP_TRY(hipMalloc((void**)&ctx->srgbLut, sizeof lut));
     HIP_TRY(hipMemcpy(ctx->srgbLut, lut, sizeof lut, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&ctx->tileQueues, kNumTileQueues * 64));      // one 64-byte line per queue head
+    HIP_TRY(hipMemset(ctx->tileQueues, 0, kNumTileQueues * 64));
+    ctx->nextQueue = 0;
+    const char* kv = getenv("INCR_PT_KERNEL");
+    ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : 0;
     *out_ctx = ctx;
     return INCR_OK;
 }
@@ -95,6 +106,7 @@ int incr_teardown(incr_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
+    if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
     delete ctx;
     return INCR_OK;
 }
@@ -332,7 +344,11 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;
     P.storageRounding = d->storage_rounding;
     P.stats = d->ray_stats;
-    HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
+    if (ctx->kernelVariant == 1) HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
+    else {
+        uint32_t* q = ctx->tileQueues + (size_t)(ctx->nextQueue++ % kNumTileQueues) * 16;
+        HIP_TRY(incr_launch_pathtrace_wave(&P, q, ctx->props.multiProcessorCount, (hipStream_t)stream));
+    }
     return INCR_OK;
 }
 

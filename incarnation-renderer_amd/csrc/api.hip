@@ -22,6 +22,7 @@ using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_pathtrace_wave(const incr::PtParams* p, uint32_t* tileQueue, int numCUs, hipStream_t stream);
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -43,7 +44,11 @@ struct incr_context {
     float* srgbLut;           // 256 floats in HBM
     uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
     uint32_t nextQueue;
-    int kernelVariant;        // 0 = persistent wavefront kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega)
+    int kernelVariant;        // 0 = wavefront multi-kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega),
+                              // 2 = persistent single-kernel wavefront (INCR_PT_KERNEL=wave)
+    WfBuffers wf;             // path-state workspace of the wavefront path tracer, grown on demand
+    void* wfBlock;            // one allocation behind wf
+    uint64_t wfBytes;
 };
 static constexpr uint32_t kNumTileQueues = 64;
 
@@ -58,6 +63,8 @@ struct incr_scene {
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
     std::vector<void*> dTexels;
     uint64_t textureBytes = 0;
+    LightGrid grid;
+    uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;
 };
 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
@@ -96,7 +103,8 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     HIP_TRY(hipMemset(ctx->tileQueues, 0, kNumTileQueues * 64));
     ctx->nextQueue = 0;
     const char* kv = getenv("INCR_PT_KERNEL");
-    ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : 0;
+    ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : (kv && !strcmp(kv, "wave")) ? 2 : 0;
+    memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
     *out_ctx = ctx;
     return INCR_OK;
 }
@@ -107,6 +115,7 @@ int incr_teardown(incr_context* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
+    if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     delete ctx;
     return INCR_OK;
 }
@@ -166,6 +175,35 @@ static int upload_bvh(incr_scene* sc) {
     if ((rc = upload_vec(&sc->dTris, sc->bvh.tris.data(), sc->bvh.tris.size()))) return rc;
     if ((rc = upload_vec(&sc->dShade, sc->bvh.shade.data(), sc->bvh.shade.size()))) return rc;
     if ((rc = upload_vec(&sc->dMeshLocalToWorld, (const float*)sc->bvh.meshLocalToWorld.data(), sc->bvh.meshLocalToWorld.size() * 16))) return rc;
+    build_light_grid(sc->host, sc->bvh, sc->grid);
+    if ((rc = upload_vec(&sc->dGridOffsets, sc->grid.cellOffsets.data(), sc->grid.cellOffsets.size()))) return rc;
+    if ((rc = upload_vec(&sc->dGridLights, sc->grid.cellLights.data(), sc->grid.cellLights.size()))) return rc;
+    return INCR_OK;
+}
+
+static void upload_grid_params(const incr_scene* sc, PtParams& P) {
+    for (int a = 0; a < 3; ++a) { P.gridLo[a] = sc->grid.lo[a]; P.gridInvCell[a] = sc->grid.invCell[a]; P.gridDim[a] = sc->grid.dim[a]; }
+    P.gridCellOffsets = sc->dGridOffsets; P.gridCellLights = sc->dGridLights;
+}
+
+// Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned).
+static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t stream) {
+    if (numPaths == 0) numPaths = 1;
+    const uint64_t n = (numPaths + 255) & ~255ull;
+    const uint64_t need = n * (16 * 5 + 96 + 4 * 3) + 4096;
+    if (ctx->wfBytes < need) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
+        HIP_TRY(hipMalloc(&ctx->wfBlock, need));
+        ctx->wfBytes = need;
+    }
+    uint8_t* p = (uint8_t*)ctx->wfBlock;
+    WfBuffers& w = ctx->wf;
+    w.counters = (uint32_t*)p; p += 4096;
+    w.rayO = (float4*)p; p += n * 16; w.rayD = (float4*)p; p += n * 16; w.color = (float4*)p; p += n * 16; w.atten = (float4*)p; p += n * 16;
+    w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 96;
+    w.liveA = (uint32_t*)p; p += n * 4; w.liveB = (uint32_t*)p; p += n * 4; w.hitList = (uint32_t*)p; p += n * 4;
+    w.numPaths = (uint32_t)numPaths;
     return INCR_OK;
 }
 
@@ -174,7 +212,8 @@ extern "C" {
 int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms};
+    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
+                    sc->dGridOffsets, sc->dGridLights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
     delete sc;
@@ -344,7 +383,12 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;
     P.storageRounding = d->storage_rounding;
     P.stats = d->ray_stats;
-    if (ctx->kernelVariant == 1) HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
+    upload_grid_params(sc, P);
+    if (ctx->kernelVariant == 0) {
+        int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);
+        if (rc) return rc;
+        HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, (hipStream_t)stream));
+    } else if (ctx->kernelVariant == 1) HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
     else {
         uint32_t* q = ctx->tileQueues + (size_t)(ctx->nextQueue++ % kNumTileQueues) * 16;
         HIP_TRY(incr_launch_pathtrace_wave(&P, q, ctx->props.multiProcessorCount, (hipStream_t)stream));

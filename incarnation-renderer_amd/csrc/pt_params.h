@@ -35,6 +35,26 @@ struct PtParams {
     uint32_t* __restrict__ history;      // R11G11B10F, localRows x W
     int32_t storageRounding;
     incr_ray_stats* stats;
+    // world-space light grid (scene_build.h LightGrid)
+    float gridLo[3], gridInvCell[3];
+    uint32_t gridDim[3];
+    const uint32_t* __restrict__ gridCellOffsets;
+    const uint32_t* __restrict__ gridCellLights;
+};
+
+// Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).
+struct WfBuffers {
+    float4* rayO;        // origin.xyz
+    float4* rayD;        // direction.xyz
+    float4* color;       // payload.color
+    float4* atten;       // payload.attenuation.xyz
+    uint4*  hit;         // {leaf-order triangle, t, u, v}
+    float4* vertex;      // 6 x float4 per path: see pathtrace_wf.hip
+    uint32_t* liveA;     // path ids entering the current bounce
+    uint32_t* liveB;     // path ids entering the next bounce
+    uint32_t* hitList;   // path ids that hit geometry in the current bounce
+    uint32_t* counters;  // 8 words per bounce: [1] paths that hit geometry, [2] paths continuing to the next bounce
+    uint32_t numPaths;
 };
 
 

@@ -1,0 +1,119 @@
+// pt_shade.h -- next-event-estimation pieces shared by the wavefront kernels: GetDirectRadiance / GetSkyRadiance
+// (shaders/lighting/common.hlsli:8-202) split into "which shadow ray" (light_setup) and "how much light"
+// (light_shade / sky_shade) with identical arithmetic, the light-loop fetch, and the typed-UAV pixel store +
+// fused integrate pass (shaders/raytracing/pathtrace-integrate.hlsl:16-31).
+#pragma once
+#include "pt_traverse.h"
+
+namespace incr {
+
+// ---- lighting/common.hlsli:8-143 split into "which ray" and "how much light" (identical arithmetic) ----
+struct LightSample { f3 L; f3 radianceIn; float NoL; bool needsShadow; };
+
+DI LightSample light_setup(const incr_light& light, const float* __restrict__ m, bool haveTransform, f3 worldPos, f3 N) {
+    LightSample s;
+    s.L = {0.f, 0.f, 0.f};
+    s.radianceIn = {0.f, 0.f, 0.f};
+    const f3 color = {light.color[0], light.color[1], light.color[2]};
+    float mm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mm[i] = haveTransform ? m[i] : 0.f;
+    if (light.type == INCR_LIGHT_DIRECTIONAL) {
+        s.L = normalize(mk3((0.f * mm[0] + 0.f * mm[4]) + -1.f * mm[8], (0.f * mm[1] + 0.f * mm[5]) + -1.f * mm[9], (0.f * mm[2] + 0.f * mm[6]) + -1.f * mm[10]));
+        s.radianceIn = 100 * light.intensity * color;
+    } else if (light.type == INCR_LIGHT_POINT) {
+        const f3 lightPosition = {mm[12], mm[13], mm[14]};
+        const f3 lightVec = lightPosition - worldPos;
+        const float distanceSquared = dot(lightVec, lightVec);
+        const float distance = sqrtf(distanceSquared);
+        s.L = lightVec / distance;
+        float radialAttenuation;
+        if (light.range > 0.f) radialAttenuation = hmax(hmin(1.f, 1.f - pow4(distance / light.range)), 0.f) / distanceSquared;
+        else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        s.radianceIn = 10000 * light.intensity * color * radialAttenuation;
+    } else if (light.type == INCR_LIGHT_SPOT) {
+        const f3 spotPosition = {mm[12], mm[13], mm[14]};
+        const f3 spotDirection = normalize(mk3((0.f * mm[0] + 0.f * mm[4]) + -1.f * mm[8], (0.f * mm[1] + 0.f * mm[5]) + -1.f * mm[9], (0.f * mm[2] + 0.f * mm[6]) + -1.f * mm[10]));
+        const f3 lightVec = spotPosition - worldPos;
+        const float distanceSquared = dot(lightVec, lightVec);
+        const float distance = sqrtf(distanceSquared);
+        s.L = lightVec / distance;
+        float angularAttenuation = 0.f;
+        const float cd = dot(spotDirection, s.L);
+        const float cosineOuterAngle = cosf(light.spotAngles[1]);
+        if (cd > cosineOuterAngle) {
+            const float cosineInnerAngle = cosf(light.spotAngles[0]);
+            const float lightAngleScale = 1.f / hmax(0.001f, cosineInnerAngle - cosineOuterAngle);
+            const float lightAngleOffset = -cosineOuterAngle * lightAngleScale;
+            angularAttenuation = saturate(cd * lightAngleScale + lightAngleOffset);
+            angularAttenuation *= angularAttenuation;
+        }
+        float radialAttenuation = 0.f;
+        if (angularAttenuation > 0.f) {
+            if (light.range > 0.f) { /* Q9: shadowed redeclaration at common.hlsli:73 leaves 0 */ }
+            else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        }
+        s.radianceIn = 10000 * light.intensity * color * angularAttenuation * radialAttenuation;
+    }
+    s.NoL = saturate(dot(N, s.L));
+    s.needsShadow = s.NoL > 0.f && (s.radianceIn.x > 0.f || s.radianceIn.y > 0.f || s.radianceIn.z > 0.f);
+    return s;
+}
+
+DI f3 light_shade(const LightSample& s, f3 basecolor, float metallic, float roughness, f3 N, f3 V) {     // :118-139, lightVisibility == 1
+    const float NoV = saturate(dot(N, V));
+    const f3 F0 = metallic * basecolor + (1.f - metallic) * 0.04f;
+    const f3 albedo = (1.f - metallic) * basecolor;
+    const f3 H = normalize(s.L + V);
+    const float NoH = saturate(dot(N, H));
+    const float VoH = saturate(dot(V, H));
+    const float D = GGX(NoH, roughness);
+    const f3 F = F_Schlick(VoH, F0);
+    const float G = G_SmithGGXCorrelated(NoV, s.NoL, roughness);
+    const f3 Fd = albedo * K_INV_PI;
+    const f3 Fr = (D * F * G) / hmax(4.f * NoV * s.NoL, 0.001f);
+    const f3 irradiance = s.radianceIn * s.NoL;
+    return (Fr + (1.f - F) * Fd) * irradiance * 1.f;
+}
+
+DI f3 sky_shade(f3 radianceIn, f3 L, float NoL, const MatProps& matInfo, f3 N, f3 V) {                   // :177-198, lightVisibility == 1
+    const float NoV = dot(N, V);
+    const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
+    const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
+    const f3 H = normalize(L + V);
+    const float NoH = hmax(0.0001f, dot(N, H));
+    const float VoH = hmax(0.0001f, dot(V, H));
+    const float D = GGX(NoH, matInfo.roughness);
+    const f3 F = F_Schlick(VoH, F0);
+    const float G = G_Smith_Direct(NoV, NoL, matInfo.roughness);
+    const f3 Fd = albedo * K_INV_PI;
+    const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
+    const f3 irradiance = radianceIn * NoL;
+    return (Fr + (1.f - F) * Fd) * irradiance * 1.f;
+}
+
+DI void load_light(const PtParams& P, int lightIndex, incr_light& light, const float*& m, bool& haveT) {
+    const int lightId = (uint32_t)lightIndex < P.numSceneLights ? P.lightIndices[lightIndex] : 0;     // D3D robust access: OOB reads 0
+    light = {};
+    if ((uint32_t)lightId < P.numGlobalLights) light = P.globalLights[lightId];
+    haveT = (uint32_t)lightId < P.numSceneLights;
+    m = P.lightTransforms + (haveT ? (size_t)lightId * 16 : 0);
+}
+
+DI void store_pixel(const PtParams& P, uint32_t x, uint32_t ly, f4 c) {
+    const size_t li = (size_t)ly * P.W + x;
+    const uint32_t hx = f32_to_f16_bits(c.x, P.storageRounding), hy = f32_to_f16_bits(c.y, P.storageRounding);
+    const uint32_t hz = f32_to_f16_bits(c.z, P.storageRounding), hw = f32_to_f16_bits(c.w, P.storageRounding);
+    if (P.target) *(uint2*)(P.target + li * 4) = make_uint2(hx | (hy << 16), hz | (hw << 16));      // destUav[xy] = payload.color (:118)
+    if (P.history) {                                                                                  // pathtrace-integrate.hlsl:16-31
+        const f3 cur = {f16_bits_to_f32(hx), f16_bits_to_f32(hy), f16_bits_to_f32(hz)};
+        const float n = (float)P.sampleIdx;
+        f3 avg;
+        if (P.sampleIdx <= 1) avg = cur / n;
+        else avg = ((n - 1.f) * unpack_r11g11b10(P.history[li]) + cur) / n;
+        P.history[li] = pack_r11g11b10(avg, P.storageRounding);
+    }
+}
+
+
+} // namespace incr

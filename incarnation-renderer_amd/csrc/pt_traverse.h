@@ -12,22 +12,26 @@ static constexpr int kStackOvf = 72;      // private overflow (4-wide SAH trees 
 
 struct Hit { float t, u, v; uint32_t tri; };
 
-struct LaneStack {
+// Per-lane traversal stack: the first NLDS entries live in LDS ([entry][lane], stride STRIDE dwords: lanes of a
+// wave hit 64 consecutive banks), deeper entries in a private (scratch) array that only pathological rays touch.
+template <int NLDS, int STRIDE>
+struct LaneStackT {
     uint32_t* lds;            // &stack[0][tid]
-    uint32_t ovf[kStackOvf];
+    uint32_t ovf[kStackOvf + (kStackLds - NLDS)];
     int sp;
+    static constexpr int kCap = kStackOvf + kStackLds;
     DI void reset() { sp = 0; }
     DI void push(uint32_t v) {
-        if (sp < kStackLds) lds[sp * kBlock] = v;
-        else if (sp < kStackLds + kStackOvf) ovf[sp - kStackLds] = v;
-        else return;                       // unreachable for a valid tree; drop rather than corrupt memory
-        ++sp;
+        if constexpr (NLDS > 0) { if (sp < NLDS) { lds[sp * STRIDE] = v; ++sp; return; } }
+        if (sp < kCap) { ovf[sp - NLDS] = v; ++sp; }      // deeper than kCap is unreachable for a valid tree: drop rather than corrupt memory
     }
     DI uint32_t pop() {
         --sp;
-        return sp < kStackLds ? lds[sp * kBlock] : ovf[sp - kStackLds];
+        if constexpr (NLDS > 0) { if (sp < NLDS) return lds[sp * STRIDE]; }
+        return ovf[sp - NLDS];
     }
 };
+using LaneStack = LaneStackT<kStackLds, kBlock>;
 
 DI bool tri_intersect(const TriIsect* __restrict__ tris, uint32_t ti, f3 o, f3 d, float tmin, float tmax,
                       float* t, float* u, float* v, uint32_t* flatId, uint32_t* flags) {
@@ -95,7 +99,7 @@ DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, f3 o, f3
 }
 
 // TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit, equal-t ties to the smaller flattened id.
-DI bool trace_closest(const PtParams& P, LaneStack& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
+template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
     const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
     st.reset();
     bool found = false; float best = tmax; uint32_t bestFlat = 0xffffffffu, bestTri = 0; float bu = 0.f, bv = 0.f;
@@ -133,7 +137,7 @@ DI bool trace_closest(const PtParams& P, LaneStack& st, f3 o, f3 d, float tmin, 
 
 // RayQuery<CULL_BACK_FACING> + one Proceed(): occluded iff any front-facing triangle lies in (tmin, tmax)
 // (lighting/common.hlsli:102-115, 161-174).
-DI bool trace_any(const PtParams& P, LaneStack& st, f3 o, f3 d, float tmin, float tmax) {
+template <class ST> DI bool trace_any(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax) {
     const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
     st.reset();
     uint32_t cur = 0;

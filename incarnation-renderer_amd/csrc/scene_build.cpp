@@ -339,4 +339,56 @@ const char* check_bvh(const HostBvh& bvh) {
     return nullptr;
 }
 
+void build_light_grid(const HostScene& s, const HostBvh& bvh, LightGrid& g) {
+    float ext[3], maxExt = 0.f;
+    for (int a = 0; a < 3; ++a) { ext[a] = std::max(bvh.sceneHi[a] - bvh.sceneLo[a], 0.f); maxExt = std::max(maxExt, ext[a]); }
+    if (!(maxExt > 0.f) || !(maxExt < FLT_MAX)) maxExt = 1.f;
+    const float cell = maxExt / 24.f;
+    const float pad = 1e-4f * maxExt;
+    for (int a = 0; a < 3; ++a) {
+        g.dim[a] = (uint32_t)std::min(32.f, std::max(1.f, std::ceil(ext[a] / cell)));
+        g.lo[a] = bvh.sceneLo[a] - pad;
+        const float size = (ext[a] + 2.f * pad) / (float)g.dim[a];
+        g.invCell[a] = size > 0.f ? 1.f / size : 0.f;
+    }
+    const uint32_t numCells = g.dim[0] * g.dim[1] * g.dim[2];
+    const int lightCount = (int)s.globalLights.size();                          // path-tracing.inl:198
+    std::vector<std::vector<uint32_t>> lists(numCells + 1);
+    for (int li = 0; li < lightCount; ++li) {
+        lists[numCells].push_back((uint32_t)li);
+        const int lightId = (size_t)li < s.lightIndices.size() ? s.lightIndices[(size_t)li] : 0;
+        if (lightId < 0 || (size_t)lightId >= s.globalLights.size()) continue;   // zero light: never contributes
+        const incr_light& L = s.globalLights[(size_t)lightId];
+        const bool haveT = (size_t)lightId < s.lightTransforms.size();
+        float pos[3] = {0.f, 0.f, 0.f};
+        if (haveT) { const float* m = s.lightTransforms[(size_t)lightId].m; pos[0] = m[12]; pos[1] = m[13]; pos[2] = m[14]; }
+        bool everywhere = false;
+        float radius = 0.f;
+        if (L.type == INCR_LIGHT_DIRECTIONAL) everywhere = true;
+        else if (L.type == INCR_LIGHT_POINT) { if (L.range > 0.f) radius = L.range * 1.001f + pad; else everywhere = true; }
+        else if (L.type == INCR_LIGHT_SPOT) { if (L.range > 0.f) continue; everywhere = true; }
+        else continue;                                                           // Sphere/Disk/Rect: radianceIn stays 0
+        if (!(radius == radius) || !(pos[0] == pos[0] && pos[1] == pos[1] && pos[2] == pos[2])) everywhere = true;   // NaN data: be conservative
+        for (uint32_t z = 0; z < g.dim[2]; ++z) for (uint32_t y = 0; y < g.dim[1]; ++y) for (uint32_t x = 0; x < g.dim[0]; ++x) {
+            bool overlap = everywhere;
+            if (!overlap) {
+                const uint32_t c[3] = {x, y, z};
+                float d2 = 0.f;
+                for (int a = 0; a < 3; ++a) {
+                    const float size = g.invCell[a] > 0.f ? 1.f / g.invCell[a] : 0.f;
+                    const float lo = g.lo[a] + size * (float)c[a] - pad, hi = g.lo[a] + size * (float)(c[a] + 1) + pad;
+                    const float d = pos[a] < lo ? lo - pos[a] : (pos[a] > hi ? pos[a] - hi : 0.f);
+                    d2 += d * d;
+                }
+                overlap = d2 <= radius * radius;
+            }
+            if (overlap) lists[(z * g.dim[1] + y) * g.dim[0] + x].push_back((uint32_t)li);
+        }
+    }
+    g.cellOffsets.assign(numCells + 2, 0);
+    g.cellLights.clear();
+    for (uint32_t c = 0; c <= numCells; ++c) { g.cellOffsets[c] = (uint32_t)g.cellLights.size(); g.cellLights.insert(g.cellLights.end(), lists[c].begin(), lists[c].end()); }
+    g.cellOffsets[numCells + 1] = (uint32_t)g.cellLights.size();
+}
+
 } // namespace incr

@@ -38,6 +38,20 @@ struct HostBvh {
     float sceneLo[3], sceneHi[3];
 };
 
+// World-space light grid for the path tracer's next-event estimation.  A cell lists (ascending loop index) every
+// light of the chsMain light loop (pathtracing.hlsl:230-236) that can contribute a NON-ZERO radiance somewhere in
+// the cell: directional lights and unbounded point/spot lights everywhere, ranged point lights where the range
+// sphere (padded) overlaps, ranged spot lights nowhere (Q9: their radial attenuation is always 0).  Skipping a
+// light whose GetDirectRadiance is exactly 0 leaves the float sum unchanged, so the grid is an exact acceleration.
+// The last cell (index dim[0]*dim[1]*dim[2]) lists ALL lights: the fallback for non-finite path attenuation.
+struct LightGrid {
+    float lo[3], invCell[3];
+    uint32_t dim[3];
+    std::vector<uint32_t> cellOffsets;   // numCells + 2 entries
+    std::vector<uint32_t> cellLights;    // light loop indices
+};
+void build_light_grid(const HostScene& s, const HostBvh& bvh, LightGrid& out);
+
 void copy_scene_desc(const incr_scene_desc& d, HostScene& out);
 // returns false with a message when the desc is inconsistent (index out of range etc.)
 bool validate_scene(const HostScene& s, const char** why);

@@ -6,18 +6,25 @@
 // bound, not bandwidth bound.  MI355X has 288 GB of HBM3E at ~8 TB/s, so the cure is to keep the per-path
 // state in HBM (176 B per pixel) and cut the work into lean kernels that each do one thing at high occupancy:
 //
-//   per bounce b = 0..3:
-//     extend     closest hit for every live path (b = 0 also generates the camera ray: rgsMain)    [traversal only]
-//     shade      chsMain part 1: surface, material, emissive, sky sample, ENUMERATE shadow rays as a request
-//                bit-mask per vertex, BRDF-sampled continuation ray                                   [no traversal]
-//     shadow     every wave takes 64 vertices, expands their request masks into an LDS job queue and traces
-//                the queue 64 rays at a time (RayQuery stand-in), clearing the bits of occluded requests [traversal only]
+//   generate   rgsMain: camera ray per pixel (8x8 pixel tiles per wave), live list of bounce 0
+//   per bounce b = 0..3, over the live list L_b:
+//     extend     closest hit (TraceRay stand-in)                                                    [traversal only]
+//     shade      miss: msDynamicSky + store.  hit: chsMain part 1 -- surface, material, emissive, sky sample,
+//                ENUMERATE the shadow rays as a request bit-mask per vertex, BRDF-sampled continuation ray,
+//                append to L_{b+1}                                                                    [no traversal]
+//     shadow     RayQuery stand-in: traces the requested shadow rays, clears the bits of occluded ones [traversal only]
 //     accumulate chsMain part 2: evaluates the unoccluded lights IN THE REFERENCE'S LOOP ORDER, then the sky
-//                sample, adds them to payload.color; finished paths are stored + integrated              [no traversal]
+//                sample, adds them to payload.color; finished paths are stored + integrated            [no traversal]
+//
+// The traversal kernels are PERSISTENT WITH LANE REFILL (Aila & Laine 2009, adapted to 64-wide waves): a wave
+// owns a chunk of rays (resp. vertices) taken from a device-wide cursor; every loop iteration each lane does ONE
+// traversal step (one 4-wide node or one leaf); lanes whose ray is done are handed the next item of the chunk
+// as soon as enough lanes are idle, so a wave never idles on its slowest ray (first wavefront version without
+// refill: 16-22 % VALU lane utilisation, profiles/r01_v3_*).  Every wave reaches the exit (cursor exhausted and
+// no lane active), so the grid always drains.
 //
 // The float operations per pixel and their order are exactly those of pathtrace.hip (= the reference HLSL),
-// so the three kernels variants are bit-identical; only the schedule differs.  Lists are compacted with one
-// global atomic per 256-thread block (LDS-aggregated); entry order varies run to run, results do not.
+// so all kernel variants are bit-identical; only the schedule differs.
 //
 // Light loop: chsMain loops over ALL scene lights per hit (pathtracing.hlsl:230-236).  A world-space light
 // grid (scene_build.h LightGrid) yields, per hit, the ascending sub-list of lights that can be non-zero there;
@@ -29,15 +36,22 @@
 namespace incr {
 
 static constexpr int kWfBlock = 256;
-static constexpr int kWfStackLds = 16;                  // LDS stack entries per lane in the lean traversal kernels
-using WfStack = LaneStackT<kWfStackLds, kWfBlock>;
+static constexpr int kWfStackLds = 16;                  // LDS stack entries per lane in the traversal kernels
+using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shadow) traversal
+using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
 static constexpr uint32_t kSkySlot = 127;               // bit 127 of the request mask = the sky sample
-static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagAllLights = 4u;
+static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
+static constexpr uint32_t kChunk = 512;                 // items a wave takes from the device-wide cursor at a time
+static constexpr uint32_t kRefillThreshold = 12;        // refill when at least this many lanes are idle
+static constexpr uint32_t kMissTri = 0xffffffffu;
+// counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow)
+static constexpr int kCursorBase = 16;
 
 // vertex record: 6 float4 per path
 //   [0] hitPos.xyz, metallic   [1] N.xyz, roughness   [2] basecolor.xyz, flags   [3] attenuation at the vertex .xyz, cell
-//   [4] skyDir.xyz, -          [5] request mask (4 x u32): shade sets the bits of the shadow rays it needs,
-//                                  shadow clears the occluded ones, accumulate shades the lights whose bit survived
+//   [4] skyDir.xyz, incoming ray dir .x     [5] request mask (4 x u32): shade sets the bits of the shadow rays it needs,
+//                                               shadow clears the occluded ones, accumulate shades the lights whose bit survived
+//   (incoming ray dir .y/.z live in hit[pid].y/.z after shade)
 DI float4* vertex_of(const WfBuffers& B, uint32_t pid) { return B.vertex + (size_t)pid * 6; }
 
 DI void add_counters(const PtParams& P, const Counters& cnt) {
@@ -82,72 +96,98 @@ DI uint32_t light_cell(const PtParams& P, f3 p) {
     return ((uint32_t)fz * P.gridDim[1] + (uint32_t)fy) * P.gridDim[0] + (uint32_t)fx;     // NaN -> fmaxf picks 0
 }
 
-// ------------------------------------------------------------------------------------------------ extend
-template <bool FIRST>
-__global__ __launch_bounds__(kWfBlock) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce, uint32_t totalFirst, uint32_t tilesX) {
-    __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
+// Wave-level work distribution: hands the next items of the wave's chunk to idle lanes (consecutive indices in
+// lane order), taking a new chunk from the device-wide cursor when the current one is used up.
+struct WaveChunk {
+    uint32_t next, end;     // wave-uniform
+    bool exhausted;
+    DI void init() { next = 0; end = 0; exhausted = false; }
+    // returns the item index for this lane or 0xffffffff
+    DI uint32_t take(bool idle, uint32_t* __restrict__ cursor, uint32_t total) {
+        const unsigned long long m = __ballot(idle);
+        if (m == 0ull) return 0xffffffffu;
+        if (next >= end && !exhausted) {
+            uint32_t b = 0;
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(cursor, kChunk);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= total) exhausted = true;
+            else { next = b; end = min(b + kChunk, total); }
+        }
+        if (next >= end) return 0xffffffffu;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t avail = end - next;
+        const uint32_t item = (idle && rank < avail) ? next + rank : 0xffffffffu;
+        next += min((uint32_t)__popcll(m), avail);
+        return item;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ generate
+__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
-    WfStack st; st.lds = s_stack + threadIdx.x; st.sp = 0;
-    Counters cnt = {0, 0, 0, 0, 0};
-    const uint32_t* __restrict__ liveIn = (bounce & 1) ? B.liveB : B.liveA;
-    const uint32_t count = FIRST ? totalFirst : B.counters[(bounce - 1) * 8 + 2];
-    uint32_t* hitCounter = B.counters + bounce * 8 + 1;
-    for (uint32_t base = blockIdx.x * kWfBlock; base < count; base += gridDim.x * kWfBlock) {
+    for (uint32_t base = blockIdx.x * kWfBlock; base < total; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
-        bool active = i < count;
-        uint32_t pid = 0, px = 0, ly = 0;
-        Ray ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f, 10000.0f};
-        if (active) {
-            if (FIRST) {
-                // 8x8 pixel tile per wave: primary rays of a wave walk the same BVH lines
-                const uint32_t tile = i >> 6, w = i & 63u;
-                px = (tile % tilesX) * 8u + (w & 7u); ly = (tile / tilesX) * 8u + (w >> 3);
-                active = px < P.W && ly < P.localRows;
-                if (active) {
-                    const int64_t gy = shard_global_row(P, ly);
-                    if (gy < 0) { store_pixel(P, px, ly, {0.f, 0.f, 0.f, 0.f}); active = false; }     // shard padding row
-                    else {
-                        pid = ly * P.W + px;
-                        const uint32_t pixelIdx = (uint32_t)gy * P.W + px;
-                        uint32_t raygenSampleSetIdx = 0;      // rgsMain -- pathtracing.hlsl:89-119
-                        const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
-                        const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
-                        ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
-                    }
-                }
-            } else {
-                pid = liveIn[i];
-                px = pid % P.W; ly = pid / P.W;
-                const float4 o = B.rayO[pid], d = B.rayD[pid];
-                ray.o = {o.x, o.y, o.z}; ray.d = {d.x, d.y, d.z};
+        // 8x8 pixel tile per wave: the primary rays of a wave walk the same BVH lines
+        const uint32_t tile = i >> 6, w = i & 63u;
+        const uint32_t px = (tile % tilesX) * 8u + (w & 7u), ly = (tile / tilesX) * 8u + (w >> 3);
+        bool valid = i < total && px < P.W && ly < P.localRows;
+        uint32_t pid = 0;
+        if (valid) {
+            const int64_t gy = shard_global_row(P, ly);
+            if (gy < 0) { store_pixel(P, px, ly, {0.f, 0.f, 0.f, 0.f}); valid = false; }     // shard padding row
+            else {
+                pid = ly * P.W + px;
+                const uint32_t pixelIdx = (uint32_t)gy * P.W + px;
+                uint32_t raygenSampleSetIdx = 0;      // rgsMain -- pathtracing.hlsl:89-119
+                const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
+                const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
+                const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
+                B.rayO[pid] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.f);
+                B.rayD[pid] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
+                B.color[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                B.atten[pid] = make_float4(1.f, 1.f, 1.f, 0.f);
             }
         }
-        bool gotHit = false;
-        if (active) {
-            if (FIRST) cnt.camera++; else cnt.bounce++;
-            Hit hit;
-            gotHit = trace_closest(P, st, ray.o, ray.d, ray.tmin, ray.tmax, &hit);
-            if (gotHit) {
-                B.hit[pid] = make_uint4(hit.tri, __float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v));
-                if (FIRST) {
-                    B.rayO[pid] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.f);
-                    B.rayD[pid] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
-                    B.color[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    B.atten[pid] = make_float4(1.f, 1.f, 1.f, 0.f);
-                }
-            } else {   // msDynamicSky -- pathtracing.hlsl:311-319
-                f4 color = {0.f, 0.f, 0.f, 0.f}; f3 attenuation = {1.f, 1.f, 1.f};
-                if (!FIRST) { const float4 c = B.color[pid], a = B.atten[pid]; color = {c.x, c.y, c.z, c.w}; attenuation = {a.x, a.y, a.z}; }
-                const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, ray.d, P.perez);
-                const f3 add = attenuation * 1000 * sky;
-                color.x += add.x; color.y += add.y; color.z += add.z;
-                store_pixel(P, px, ly, color);
-            }
-        }
-        const uint32_t slot = block_append(gotHit, hitCounter, s_waveCount, &s_base);
-        if (gotHit) B.hitList[slot] = pid;
+        const uint32_t slot = block_append(valid, B.counters + 0, s_waveCount, &s_base);
+        if (valid) B.liveA[slot] = pid;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ extend
+__global__ __launch_bounds__(kWfBlock) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+    __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
+    __shared__ float s_keys[kWfStackLds * kWfBlock];
+    WfStackK st; st.lds = s_stack + threadIdx.x; st.ldsKey = s_keys + threadIdx.x; st.sp = 0;
+    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
+    const uint32_t total = B.counters[bounce];
+    uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
+    WaveChunk chunk; chunk.init();
+    bool active = false; uint32_t pid = 0;
+    TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
+    uint32_t rays = 0;
+    for (;;) {
+        const unsigned long long act = __ballot(active);
+        const uint32_t idle = 64u - (uint32_t)__popcll(act);
+        if (!chunk.exhausted && (idle >= kRefillThreshold || act == 0ull)) {
+            const uint32_t item = chunk.take(!active, cursor, total);
+            if (item != 0xffffffffu) {
+                pid = live[item];
+                const float4 o = B.rayO[pid], d = B.rayD[pid];
+                trav_closest_begin(T, {o.x, o.y, o.z}, {d.x, d.y, d.z}, 0.001f, 10000.0f);     // TMin / TMax of TraceRay (common.hlsli:49-50,119-120)
+                st.reset();
+                active = true; rays++;
+            }
+        }
+        if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
+        if (active && trav_closest_step(P, st, T)) {
+            B.hit[pid] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
+                                 : make_uint4(kMissTri, 0u, 0u, 0u);
+            active = false;
+        }
+    }
+    Counters cnt = {bounce == 0 ? rays : 0u, bounce == 0 ? 0u : rays, 0, 0, 0};
     add_counters(P, cnt);
 }
 
@@ -156,145 +196,157 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     Counters cnt = {0, 0, 0, 0, 0};
-    const uint32_t count = B.counters[bounce * 8 + 1];
-    uint32_t* liveOut = (bounce & 1) ? B.liveA : B.liveB;          // extend(bounce + 1) reads the other list
-    uint32_t* liveCounter = B.counters + bounce * 8 + 2;
+    const uint32_t count = B.counters[bounce];
+    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
+    uint32_t* liveOut = (bounce & 1) ? B.liveA : B.liveB;
+    uint32_t* liveCounter = B.counters + bounce + 1;
     for (uint32_t base = blockIdx.x * kWfBlock; base < count; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
         bool cont = false;
         uint32_t pid = 0;
         if (i < count) {
-            pid = B.hitList[i];
+            pid = live[i];
             const uint32_t px = pid % P.W, ly = pid / P.W;
             const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px;
             const uint4 h = B.hit[pid];
-            const float4 ro = B.rayO[pid], rd = B.rayD[pid], c4 = B.color[pid], a4 = B.atten[pid];
-            const f3 rayO = {ro.x, ro.y, ro.z}, rayD = {rd.x, rd.y, rd.z};
+            const float4 rd = B.rayD[pid], c4 = B.color[pid], a4 = B.atten[pid];
+            const f3 rayD = {rd.x, rd.y, rd.z};
             f4 color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};
-            const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
-            // chsMain -- pathtracing.hlsl:121-268
-            cnt.hits++;
-            const int pathLength = bounce + 1;
-            uint32_t sampleSetIndex = (uint32_t)bounce;               // one SamplePoint per earlier hit (Q3)
-            const float4* __restrict__ sp = (const float4*)(P.shade + h.x);
-            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
-            const uint4 s7 = *(const uint4*)(sp + 7);
-            const f3 vn0 = {s0.x, s0.y, s0.z}, vn1 = {s0.w, s1.x, s1.y}, vn2 = {s1.z, s1.w, s2.x};
-            const f4 vt0 = {s2.y, s2.z, s2.w, s3.x}, vt1 = {s3.y, s3.z, s3.w, s4.x}, vt2 = {s4.y, s4.z, s4.w, s5.x};
-            const f2 uv0 = {s5.y, s5.z}, uv1 = {s5.w, s6.x}, uv2 = {s6.y, s6.z};
-            const uint32_t materialIndex = __float_as_uint(s6.w), meshIndex = s7.x;
-            const float* __restrict__ localToWorld = P.meshLocalToWorld + (size_t)meshIndex * 16;
-            const f3 hitPosition = rayO + hitT * rayD;
-            const f4 packedT = vt0 + bx * (vt1 - vt0) + by * (vt2 - vt0);
-            f3 N = normalize(vn0 + bx * (vn1 - vn0) + by * (vn2 - vn0));
-            f3 T = normalize(mk3(packedT.x, packedT.y, packedT.z));
-            f3 Bt = cross(N, T) * packedT.w;
-            N = mul_dir(N, localToWorld);
-            T = mul_dir(T, localToWorld);
-            Bt = mul_dir(Bt, localToWorld);
-            const f3 Ntbn = N;
-            const f2 uv = uv0 + bx * (uv1 - uv0) + by * (uv2 - uv0);
-            MatProps matInfo = EvaluateMaterialProperties(P.materials[materialIndex], P.textures, P.srgbLut, uv);
             float4* vtx = vertex_of(B, pid);
-            bool done = false;
-            if (P.viewmode == 1) matInfo.basecolor = mk3(0.5f);
-            else if (P.viewmode == 2) { color = {matInfo.roughness, matInfo.roughness, matInfo.roughness, matInfo.roughness}; done = true; }
-            else if (P.viewmode == 3) { color = {matInfo.metallic, matInfo.metallic, matInfo.metallic, matInfo.metallic}; done = true; }
-            else if (P.viewmode == 4) { color = {matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, 1.f}; done = true; }
-            else if (P.viewmode == 5) { color = {matInfo.emissive.x, matInfo.emissive.y, matInfo.emissive.z, 1.f}; done = true; }
-            if (done) {
+            if (h.x == kMissTri) {   // msDynamicSky -- pathtracing.hlsl:311-319
+                const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, rayD, P.perez);
+                const f3 add = attenuation * 1000 * sky;
+                color.x += add.x; color.y += add.y; color.z += add.z;
                 store_pixel(P, px, ly, color);
                 vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
                 *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
             } else {
-                const f3 add = attenuation * matInfo.emissive * 20000;
-                color.x += add.x; color.y += add.y; color.z += add.z;
-                attenuation = attenuation * saturate(1.f - matInfo.emissive);
-                if (matInfo.bHasNormalmap) {
-                    const f3 nm = matInfo.normalmap;
-                    N = normalize(mk3((nm.x * T.x + nm.y * Bt.x) + nm.z * N.x, (nm.x * T.y + nm.y * Bt.y) + nm.z * N.y, (nm.x * T.z + nm.y * Bt.z) + nm.z * N.z));
+                const float4 ro = B.rayO[pid];
+                const f3 rayO = {ro.x, ro.y, ro.z};
+                const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
+                // chsMain -- pathtracing.hlsl:121-268
+                cnt.hits++;
+                const int pathLength = bounce + 1;
+                uint32_t sampleSetIndex = (uint32_t)bounce;               // one SamplePoint per earlier hit (Q3)
+                const float4* __restrict__ sp = (const float4*)(P.shade + h.x);
+                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+                const uint4 s7 = *(const uint4*)(sp + 7);
+                const f3 vn0 = {s0.x, s0.y, s0.z}, vn1 = {s0.w, s1.x, s1.y}, vn2 = {s1.z, s1.w, s2.x};
+                const f4 vt0 = {s2.y, s2.z, s2.w, s3.x}, vt1 = {s3.y, s3.z, s3.w, s4.x}, vt2 = {s4.y, s4.z, s4.w, s5.x};
+                const f2 uv0 = {s5.y, s5.z}, uv1 = {s5.w, s6.x}, uv2 = {s6.y, s6.z};
+                const uint32_t materialIndex = __float_as_uint(s6.w), meshIndex = s7.x;
+                const float* __restrict__ localToWorld = P.meshLocalToWorld + (size_t)meshIndex * 16;
+                const f3 hitPosition = rayO + hitT * rayD;
+                const f4 packedT = vt0 + bx * (vt1 - vt0) + by * (vt2 - vt0);
+                f3 N = normalize(vn0 + bx * (vn1 - vn0) + by * (vn2 - vn0));
+                f3 T = normalize(mk3(packedT.x, packedT.y, packedT.z));
+                f3 Bt = cross(N, T) * packedT.w;
+                N = mul_dir(N, localToWorld);
+                T = mul_dir(T, localToWorld);
+                Bt = mul_dir(Bt, localToWorld);
+                const f3 Ntbn = N;
+                const f2 uv = uv0 + bx * (uv1 - uv0) + by * (uv2 - uv0);
+                MatProps matInfo = EvaluateMaterialProperties(P.materials[materialIndex], P.textures, P.srgbLut, uv);
+                bool done = false;
+                if (P.viewmode == 1) matInfo.basecolor = mk3(0.5f);
+                else if (P.viewmode == 2) { color = {matInfo.roughness, matInfo.roughness, matInfo.roughness, matInfo.roughness}; done = true; }
+                else if (P.viewmode == 3) { color = {matInfo.metallic, matInfo.metallic, matInfo.metallic, matInfo.metallic}; done = true; }
+                else if (P.viewmode == 4) { color = {matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, 1.f}; done = true; }
+                else if (P.viewmode == 5) { color = {matInfo.emissive.x, matInfo.emissive.y, matInfo.emissive.z, 1.f}; done = true; }
+                if (done) {
+                    store_pixel(P, px, ly, color);
+                    vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
+                    *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
+                } else {
+                    const f3 add = attenuation * matInfo.emissive * 20000;
+                    color.x += add.x; color.y += add.y; color.z += add.z;
+                    attenuation = attenuation * saturate(1.f - matInfo.emissive);
+                    if (matInfo.bHasNormalmap) {
+                        const f3 nm = matInfo.normalmap;
+                        N = normalize(mk3((nm.x * T.x + nm.y * Bt.x) + nm.z * N.x, (nm.x * T.y + nm.y * Bt.y) + nm.z * N.y, (nm.x * T.z + nm.y * Bt.z) + nm.z * N.z));
+                    }
+                    const f3 V = -rayD;
+                    const f3 attenV = attenuation;
+                    // ---- enumerate the shadow rays of this vertex as a request mask ----
+                    uint32_t req[4] = {0u, 0u, 0u, 0u};
+                    uint32_t flags = 0u;
+                    const bool finiteAtt = fabsf(attenV.x) < 3.0e38f && fabsf(attenV.y) < 3.0e38f && fabsf(attenV.z) < 3.0e38f;
+                    const uint32_t numCells = P.gridDim[0] * P.gridDim[1] * P.gridDim[2];
+                    uint32_t cell = light_cell(P, hitPosition);
+                    if (!finiteAtt) cell = numCells;                      // the catch-all cell lists every light
+                    if (P.directLighting && P.lightCount > 0) {
+                        const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
+                        const uint32_t n = min(hi - lo, kSkySlot);
+                        for (uint32_t k = 0; k < n; ++k) {
+                            incr_light light; const float* m; bool haveT;
+                            load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
+                            const LightSample s = light_setup(light, m, haveT, hitPosition, N);
+                            if (s.needsShadow) { req[k >> 5] |= 1u << (k & 31u); cnt.lightShadow++; }
+                        }
+                        for (uint32_t k = n; k < hi - lo; ++k) {      // > 127 candidates in one cell: traced inside accumulate, counted here
+                            incr_light light; const float* m; bool haveT;
+                            load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
+                            if (light_setup(light, m, haveT, hitPosition, N).needsShadow) cnt.lightShadow++;
+                        }
+                    }
+                    // sky sample :239-244
+                    const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
+                    const f3 skyDir = CosineSampleHemisphere(us);
+                    const f3 skyRadianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, skyDir, P.perez));
+                    const float skyNoL = saturate(dot(N, skyDir));
+                    if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req[3] |= 0x80000000u; cnt.skyShadow++; }
+                    // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
+                    if (pathLength < 4) {
+                        uint32_t setCopy = sampleSetIndex;
+                        f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.sqrtSampleCount, P.numPixels);
+                        f3 L, H;
+                        const float t = 0.5f;
+                        if (u.x < t) {
+                            u.x = 2.f * u.x;
+                            const f3 l = CosineSampleHemisphere(u);
+                            L = normalize(mk3((l.x * T.x + l.y * Bt.x) + l.z * Ntbn.x, (l.x * T.y + l.y * Bt.y) + l.z * Ntbn.y, (l.x * T.z + l.y * Bt.z) + l.z * Ntbn.z));
+                            H = normalize(L + V);
+                        } else {
+                            u.x = 2.f * (u.x - 0.5f);
+                            const f3 hh = SampleGGX(u, matInfo.roughness);
+                            H = normalize(mk3((hh.x * T.x + hh.y * Bt.x) + hh.z * Ntbn.x, (hh.x * T.y + hh.y * Bt.y) + hh.z * Ntbn.y, (hh.x * T.z + hh.y * Bt.z) + hh.z * Ntbn.z));
+                            L = normalize(reflect(-V, H));
+                        }
+                        const float NoL = hmax(dot(N, L), 0.001f);
+                        const float NoV = hmax(dot(N, V), 0.001f);
+                        const float NoH = hmax(dot(N, H), 0.001f);
+                        const float VoH = hmax(dot(V, H), 0.001f);
+                        const float pdf = t * CosineHemispherePdf(NoL) + (1.f - t) * GGXPdf(NoH, matInfo.roughness) / (4.f * VoH);
+                        const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
+                        const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
+                        const float D = GGX(NoH, matInfo.roughness);
+                        const f3 F = F_Schlick(VoH, F0);
+                        const float G = G_Smith_Direct(NoV, NoL, matInfo.roughness);
+                        const f3 Fd = albedo * K_INV_PI;
+                        const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
+                        const f3 brdf = (Fr + (1.f - F) * Fd);
+                        const f3 outAttenuation = brdf * NoL / pdf;
+                        attenuation = attenuation * outAttenuation;
+                        if (attenuation.x != 0.f || attenuation.y != 0.f || attenuation.z != 0.f) {     // Q2
+                            B.rayO[pid] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, 0.f);
+                            B.rayD[pid] = make_float4(L.x, L.y, L.z, 0.f);
+                            B.atten[pid] = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.f);
+                            cont = true;
+                        }
+                    }
+                    if (!cont) flags |= kFlagTerminate;
+                    B.color[pid] = make_float4(color.x, color.y, color.z, color.w);
+                    vtx[0] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, matInfo.metallic);
+                    vtx[1] = make_float4(N.x, N.y, N.z, matInfo.roughness);
+                    vtx[2] = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, __uint_as_float(flags));
+                    vtx[3] = make_float4(attenV.x, attenV.y, attenV.z, __uint_as_float(cell));
+                    // accumulate needs V = -rayD, but rayD[pid] may now hold the continuation ray: keep the incoming direction in
+                    // the record (x) and in the no longer needed t/u slots of the hit buffer (y, z)
+                    vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, rayD.x);
+                    *(uint4*)(vtx + 5) = make_uint4(req[0], req[1], req[2], req[3]);
+                    B.hit[pid] = make_uint4(h.x, __float_as_uint(rayD.y), __float_as_uint(rayD.z), 0u);
                 }
-                const f3 V = -rayD;
-                const f3 attenV = attenuation;
-                // ---- enumerate the shadow rays of this vertex as a request mask ----
-                uint32_t req[4] = {0u, 0u, 0u, 0u};
-                uint32_t flags = 0u;
-                const bool finiteAtt = fabsf(attenV.x) < 3.0e38f && fabsf(attenV.y) < 3.0e38f && fabsf(attenV.z) < 3.0e38f;
-                const uint32_t numCells = P.gridDim[0] * P.gridDim[1] * P.gridDim[2];
-                uint32_t cell = light_cell(P, hitPosition);
-                if (!finiteAtt) { cell = numCells; flags |= kFlagAllLights; }
-                if (P.directLighting && P.lightCount > 0) {
-                    const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
-                    const uint32_t n = min(hi - lo, kSkySlot);
-                    for (uint32_t k = 0; k < n; ++k) {
-                        incr_light light; const float* m; bool haveT;
-                        load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
-                        const LightSample s = light_setup(light, m, haveT, hitPosition, N);
-                        if (s.needsShadow) { req[k >> 5] |= 1u << (k & 31u); cnt.lightShadow++; }
-                    }
-                    for (uint32_t k = n; k < hi - lo; ++k) {      // > 127 candidates in one cell: traced inside accumulate, counted here
-                        incr_light light; const float* m; bool haveT;
-                        load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
-                        if (light_setup(light, m, haveT, hitPosition, N).needsShadow) cnt.lightShadow++;
-                    }
-                }
-                // sky sample :239-244
-                const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
-                const f3 skyDir = CosineSampleHemisphere(us);
-                const f3 skyRadianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, skyDir, P.perez));
-                const float skyNoL = saturate(dot(N, skyDir));
-                if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req[3] |= 0x80000000u; cnt.skyShadow++; }
-                // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
-                if (pathLength < 4) {
-                    uint32_t setCopy = sampleSetIndex;
-                    f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.sqrtSampleCount, P.numPixels);
-                    f3 L, H;
-                    const float t = 0.5f;
-                    if (u.x < t) {
-                        u.x = 2.f * u.x;
-                        const f3 l = CosineSampleHemisphere(u);
-                        L = normalize(mk3((l.x * T.x + l.y * Bt.x) + l.z * Ntbn.x, (l.x * T.y + l.y * Bt.y) + l.z * Ntbn.y, (l.x * T.z + l.y * Bt.z) + l.z * Ntbn.z));
-                        H = normalize(L + V);
-                    } else {
-                        u.x = 2.f * (u.x - 0.5f);
-                        const f3 hh = SampleGGX(u, matInfo.roughness);
-                        H = normalize(mk3((hh.x * T.x + hh.y * Bt.x) + hh.z * Ntbn.x, (hh.x * T.y + hh.y * Bt.y) + hh.z * Ntbn.y, (hh.x * T.z + hh.y * Bt.z) + hh.z * Ntbn.z));
-                        L = normalize(reflect(-V, H));
-                    }
-                    const float NoL = hmax(dot(N, L), 0.001f);
-                    const float NoV = hmax(dot(N, V), 0.001f);
-                    const float NoH = hmax(dot(N, H), 0.001f);
-                    const float VoH = hmax(dot(V, H), 0.001f);
-                    const float pdf = t * CosineHemispherePdf(NoL) + (1.f - t) * GGXPdf(NoH, matInfo.roughness) / (4.f * VoH);
-                    const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
-                    const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
-                    const float D = GGX(NoH, matInfo.roughness);
-                    const f3 F = F_Schlick(VoH, F0);
-                    const float G = G_Smith_Direct(NoV, NoL, matInfo.roughness);
-                    const f3 Fd = albedo * K_INV_PI;
-                    const f3 Fr = (D * F * G) / hmax(4.f * NoV * NoL, 0.001f);
-                    const f3 brdf = (Fr + (1.f - F) * Fd);
-                    const f3 outAttenuation = brdf * NoL / pdf;
-                    attenuation = attenuation * outAttenuation;
-                    if (attenuation.x != 0.f || attenuation.y != 0.f || attenuation.z != 0.f) {     // Q2
-                        B.rayO[pid] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, 0.f);
-                        B.rayD[pid] = make_float4(L.x, L.y, L.z, 0.f);
-                        B.atten[pid] = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.f);
-                        cont = true;
-                    }
-                }
-                if (!cont) flags |= kFlagTerminate;
-                B.color[pid] = make_float4(color.x, color.y, color.z, color.w);
-                vtx[0] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, matInfo.metallic);
-                vtx[1] = make_float4(N.x, N.y, N.z, matInfo.roughness);
-                vtx[2] = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, __uint_as_float(flags));
-                vtx[3] = make_float4(attenV.x, attenV.y, attenV.z, __uint_as_float(cell));
-                // accumulate needs V = -rayD, but rayD[pid] now holds the continuation ray: keep the incoming direction in the
-                // record (x) and in the no longer needed t/u slots of the hit buffer (y, z)
-                vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, rayD.x);
-                *(uint4*)(vtx + 5) = make_uint4(req[0], req[1], req[2], req[3]);
-                B.hit[pid] = make_uint4(h.x, __float_as_uint(rayD.y), __float_as_uint(rayD.z), 0u);
             }
         }
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
@@ -304,92 +356,87 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
-struct ShadowShared {
-    uint16_t jobs[64 * 16];         // (owner lane << 8) | bit   (one 16-bit half of a mask word per round)
-    float hitPos[3][64];
-    float skyDir[3][64];
-    uint32_t cell[64];
-    uint32_t occluded[64];
-    uint32_t jobCount;
-    uint32_t pad[3];
-};
-
-DI void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
+// One lane = one path vertex at a time: the lane traces that vertex's requested shadow rays one after the other
+// (lowest slot first) and writes back the mask with the occluded requests cleared.  No LDS queue, no atomics on
+// the occlusion bits; idle lanes get the next vertices of the wave's chunk.
 __global__ __launch_bounds__(kWfBlock) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
-    __shared__ ShadowShared s_wave[kWfBlock / 64];
-    const uint32_t lane = threadIdx.x & 63u;
-    ShadowShared& ws = s_wave[threadIdx.x >> 6];
-    WfStack st; st.lds = s_stack + threadIdx.x; st.sp = 0;
-    const uint32_t count = B.counters[bounce * 8 + 1];
-    const uint32_t waveId = (blockIdx.x * kWfBlock + threadIdx.x) >> 6, numWaves = (gridDim.x * kWfBlock) >> 6;
-    for (uint32_t base = waveId * 64u; base < count; base += numWaves * 64u) {      // wave-uniform loop: no block barrier inside
-        const uint32_t i = base + lane;
-        const bool valid = i < count;
-        uint32_t pid = 0; uint4 req = make_uint4(0u, 0u, 0u, 0u);
-        float4* vtx = nullptr;
-        if (valid) {
-            pid = B.hitList[i];
-            vtx = vertex_of(B, pid);
-            req = *(const uint4*)(vtx + 5);
-            const float4 v0 = vtx[0], v3 = vtx[3], v4 = vtx[4];
-            ws.hitPos[0][lane] = v0.x; ws.hitPos[1][lane] = v0.y; ws.hitPos[2][lane] = v0.z;
-            ws.skyDir[0][lane] = v4.x; ws.skyDir[1][lane] = v4.y; ws.skyDir[2][lane] = v4.z;
-            ws.cell[lane] = __float_as_uint(v3.w);
-        }
-        uint32_t words[4] = {req.x, req.y, req.z, req.w};
-        bool changed = false;
-#pragma unroll
-        for (int hw = 0; hw < 8; ++hw) {
-            const int w = hw >> 1; const uint32_t shift = (uint32_t)(hw & 1) * 16u;
-            uint32_t bits = (words[w] >> shift) & 0xffffu;
-            if (__ballot(bits != 0u) == 0ull) continue;                // wave-uniform skip of empty half-words
-            ws.occluded[lane] = 0u;
-            if (lane == 0) ws.jobCount = 0u;
-            wave_lds_sync();
-            while (bits) {
-                const uint32_t b = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u;
-                const uint32_t slot = atomicAdd(&ws.jobCount, 1u);
-                ws.jobs[slot] = (uint16_t)((lane << 8) | b);
-            }
-            wave_lds_sync();
-            const uint32_t jobCount = ws.jobCount;
-            for (uint32_t jb = 0; jb < jobCount; jb += 64u) {
-                const uint32_t j = jb + lane;
-                if (j < jobCount) {
-                    const uint32_t job = ws.jobs[j];
-                    const uint32_t owner = job >> 8, bit = job & 0xffu, slotIdx = (uint32_t)w * 32u + shift + bit;
-                    const f3 origin = {ws.hitPos[0][owner], ws.hitPos[1][owner], ws.hitPos[2][owner]};
-                    f3 L;
-                    if (slotIdx == kSkySlot) L = {ws.skyDir[0][owner], ws.skyDir[1][owner], ws.skyDir[2][owner]};
-                    else {
-                        const uint32_t li = P.gridCellLights[P.gridCellOffsets[ws.cell[owner]] + slotIdx];
-                        incr_light light; const float* m; bool haveT;
-                        load_light(P, (int)li, light, m, haveT);
-                        L = light_setup(light, m, haveT, origin, {0.f, 0.f, 0.f}).L;      // same L as shade computed (N does not enter L)
-                    }
-                    if (trace_any(P, st, origin, L, 0.1f, 1000.f)) atomicOr(&ws.occluded[owner], 1u << bit);
+    WfStack st; st.lds = s_stack + threadIdx.x; st.ldsKey = nullptr; st.sp = 0;
+    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
+    const uint32_t total = B.counters[bounce];
+    uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
+    WaveChunk chunk; chunk.init();
+    bool haveVertex = false, tracing = false;
+    uint32_t pid = 0, cell = 0, curSlot = 0;
+    uint32_t rem0 = 0u, rem1 = 0u, rem2 = 0u, rem3 = 0u, occ0 = 0u, occ1 = 0u, occ2 = 0u, occ3 = 0u;
+    f3 origin = {0.f, 0.f, 0.f};
+    TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
+    for (;;) {
+        // ---- vertices for lanes that have none ----
+        const unsigned long long busy = __ballot(haveVertex);
+        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
+        if (!chunk.exhausted && (idle >= kRefillThreshold || busy == 0ull)) {
+            const uint32_t item = chunk.take(!haveVertex, cursor, total);
+            if (item != 0xffffffffu) {
+                pid = live[item];
+                const float4* vtx = vertex_of(B, pid);
+                const uint4 req = *(const uint4*)(vtx + 5);
+                if (req.x | req.y | req.z | req.w) {
+                    const float4 v0 = vtx[0], v3 = vtx[3];
+                    origin = {v0.x, v0.y, v0.z}; cell = __float_as_uint(v3.w);
+                    rem0 = req.x; rem1 = req.y; rem2 = req.z; rem3 = req.w;
+                    occ0 = occ1 = occ2 = occ3 = 0u;
+                    haveVertex = true; tracing = false;
                 }
             }
-            wave_lds_sync();
-            const uint32_t occ = ws.occluded[lane];
-            if (occ) { words[w] &= ~(occ << shift); changed = true; }
-            wave_lds_sync();
         }
-        if (valid && changed) *(uint4*)(vtx + 5) = make_uint4(words[0], words[1], words[2], words[3]);
+        if (__ballot(haveVertex) == 0ull) { if (chunk.exhausted) break; else continue; }
+        // ---- next shadow ray for lanes between rays ----
+        if (haveVertex && !tracing) {
+            const int w = rem0 ? 0 : rem1 ? 1 : rem2 ? 2 : rem3 ? 3 : -1;
+            if (w < 0) {      // vertex finished: write back the surviving requests
+                if (occ0 | occ1 | occ2 | occ3) {
+                    uint4* dst = (uint4*)(vertex_of(B, pid) + 5);
+                    const uint4 req = *dst;
+                    *dst = make_uint4(req.x & ~occ0, req.y & ~occ1, req.z & ~occ2, req.w & ~occ3);
+                }
+                haveVertex = false;
+            } else {
+                const uint32_t word = w == 0 ? rem0 : w == 1 ? rem1 : w == 2 ? rem2 : rem3;
+                const uint32_t bit = (uint32_t)__builtin_ctz(word);
+                const uint32_t cleared = word & (word - 1u);
+                if (w == 0) rem0 = cleared; else if (w == 1) rem1 = cleared; else if (w == 2) rem2 = cleared; else rem3 = cleared;
+                curSlot = (uint32_t)w * 32u + bit;
+                f3 L;
+                if (curSlot == kSkySlot) { const float4 v4 = vertex_of(B, pid)[4]; L = {v4.x, v4.y, v4.z}; }
+                else {
+                    const uint32_t li = P.gridCellLights[P.gridCellOffsets[cell] + curSlot];
+                    incr_light light; const float* m; bool haveT;
+                    load_light(P, (int)li, light, m, haveT);
+                    L = light_setup(light, m, haveT, origin, {0.f, 0.f, 0.f}).L;      // the same L shade computed (N does not enter L)
+                }
+                trav_any_begin(T, origin, L, 0.1f, 1000.f);                            // lighting/common.hlsli:96-100
+                st.reset();
+                tracing = true;
+            }
+        }
+        // ---- one traversal step ----
+        if (tracing && trav_any_step(P, st, T)) {
+            if (T.occluded) {
+                const uint32_t w = curSlot >> 5, m = 1u << (curSlot & 31u);
+                if (w == 0) occ0 |= m; else if (w == 1) occ1 |= m; else if (w == 2) occ2 |= m; else occ3 |= m;
+            }
+            tracing = false;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
 __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    const uint32_t count = B.counters[bounce * 8 + 1];
+    const uint32_t count = B.counters[bounce];
+    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
-        const uint32_t pid = B.hitList[i];
+        const uint32_t pid = live[i];
         const float4* vtx = vertex_of(B, pid);
         const float4 v2 = vtx[2];
         const uint32_t flags = __float_as_uint(v2.w);
@@ -418,7 +465,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
                 if (k < kSkySlot) visible = (words[k >> 5] >> (k & 31u)) & 1u;
                 else {   // more than 127 candidate lights in one cell: traced here (slow path, private-memory stack)
                     visible = false;
-                    if (s.needsShadow) { LaneStackT<0, 1> ps; ps.lds = nullptr; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
+                    if (s.needsShadow) { LaneStackT<0, 1> ps; ps.lds = nullptr; ps.ldsKey = nullptr; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
                 }
                 if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
                 const f3 r = attenV * radianceOut;
@@ -444,20 +491,21 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;
-    const uint32_t totalFirst = tilesX * tilesY * 64u;
-    if (totalFirst == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(b->counters, 0, 4 * 8 * sizeof(uint32_t), stream);
+    const uint32_t total = tilesX * tilesY * 64u;
+    if (total == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(b->counters, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const uint32_t maxBlocks = (uint32_t)std::max(numCUs, 1) * 8u;
-    const uint32_t blocksAll = std::max(1u, std::min(maxBlocks, (totalFirst + kWfBlock - 1) / kWfBlock));
+    const uint32_t cus = (uint32_t)std::max(numCUs, 1);
+    const uint32_t blocksAll = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
+    // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (<= 5 blocks of 4 waves per CU)
+    const uint32_t blocksTrav = std::max(1u, std::min(cus * 5u, (total + kWfBlock - 1) / kWfBlock));
+    hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX);
     for (int bounce = 0; bounce < 4; ++bounce) {
-        if (bounce == 0) hipLaunchKernelGGL((wf_extend_kernel<true>), dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce, totalFirst, tilesX);
-        else hipLaunchKernelGGL((wf_extend_kernel<false>), dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce, totalFirst, tilesX);
+        hipLaunchKernelGGL(wf_extend_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
         hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        if (p->viewmode < 2) {
-            hipLaunchKernelGGL(wf_shadow_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        } else break;   // VIEWMODE >= 2 paths end at the first hit
+        if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
+        hipLaunchKernelGGL(wf_shadow_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
     }
     return hipGetLastError();
 }

@@ -14,20 +14,30 @@ struct Hit { float t, u, v; uint32_t tri; };
 
 // Per-lane traversal stack: the first NLDS entries live in LDS ([entry][lane], stride STRIDE dwords: lanes of a
 // wave hit 64 consecutive banks), deeper entries in a private (scratch) array that only pathological rays touch.
-template <int NLDS, int STRIDE>
+// KEYED stacks also keep each entry's box-entry distance so that closest-hit traversal can drop popped nodes
+// that lie beyond the current best hit without fetching them.
+template <int NLDS, int STRIDE, bool KEYED = false>
 struct LaneStackT {
-    uint32_t* lds;            // &stack[0][tid]
-    uint32_t ovf[kStackOvf + (kStackLds - NLDS)];
-    int sp;
+    static constexpr bool kKeyed = KEYED;
     static constexpr int kCap = kStackOvf + kStackLds;
+    uint32_t* lds;            // &stack[0][tid]
+    float* ldsKey;            // &keys[0][tid]   (KEYED only)
+    uint32_t ovf[kCap - NLDS];
+    float ovfKey[KEYED ? kCap - NLDS : 1];
+    int sp;
     DI void reset() { sp = 0; }
-    DI void push(uint32_t v) {
-        if constexpr (NLDS > 0) { if (sp < NLDS) { lds[sp * STRIDE] = v; ++sp; return; } }
-        if (sp < kCap) { ovf[sp - NLDS] = v; ++sp; }      // deeper than kCap is unreachable for a valid tree: drop rather than corrupt memory
+    DI void push(uint32_t v, float key = 0.f) {
+        if constexpr (NLDS > 0) {
+            if (sp < NLDS) { lds[sp * STRIDE] = v; if constexpr (KEYED) ldsKey[sp * STRIDE] = key; ++sp; return; }
+        }
+        if (sp < kCap) { ovf[sp - NLDS] = v; if constexpr (KEYED) ovfKey[sp - NLDS] = key; ++sp; }   // deeper is unreachable for a valid tree
     }
-    DI uint32_t pop() {
+    DI uint32_t pop(float* key = nullptr) {
         --sp;
-        if constexpr (NLDS > 0) { if (sp < NLDS) return lds[sp * STRIDE]; }
+        if constexpr (NLDS > 0) {
+            if (sp < NLDS) { if constexpr (KEYED) *key = ldsKey[sp * STRIDE]; return lds[sp * STRIDE]; }
+        }
+        if constexpr (KEYED) *key = ovfKey[sp - NLDS];
         return ovf[sp - NLDS];
     }
 };
@@ -71,25 +81,35 @@ DI bool any_hit_accepts(const PtParams& P, uint32_t ti, float u, float v) {
 #define CSWAP(i, j) { const bool sw = key[j] < key[i]; const float tk = sw ? key[j] : key[i]; const float tk2 = sw ? key[i] : key[j]; \
                       const uint32_t tc = sw ? ch[j] : ch[i]; const uint32_t tc2 = sw ? ch[i] : ch[j]; key[i] = tk; key[j] = tk2; ch[i] = tc; ch[j] = tc2; }
 
-// Tests the 4 child boxes of `node`; returns children sorted near->far in ch[0..n).
-DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, f3 o, f3 invd, float tmin, float tmax, uint32_t ch[4]) {
+// Per-ray traversal constants: reciprocal direction and, per axis, which float4 of the node holds the NEAR planes
+// (lo planes when the direction component is >= 0, hi planes otherwise): the slab test needs no per-child min/max.
+struct RaySetup { f3 o, invd; uint32_t nearX, nearY, nearZ; };
+DI RaySetup ray_setup(f3 o, f3 d) {
+    RaySetup r;
+    r.o = o;
+    r.invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+    r.nearX = d.x < 0.f ? 3u : 0u; r.nearY = d.y < 0.f ? 4u : 1u; r.nearZ = d.z < 0.f ? 5u : 2u;
+    return r;
+}
+
+// Tests the 4 child boxes of `node`; returns children sorted near->far in ch[0..n) and their entry distances in key[].
+// Slab test t = (plane - o) * invd with the far distance widened by 1 + 2*gamma(3) (Ize 2013 / pbrt robust bounds test):
+// conservative, so the exact triangle test -- not the box test -- decides every hit.
+DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, const RaySetup& r, float tmin, float tmax, uint32_t ch[4], float key[4]) {
     const float4* __restrict__ p = (const float4*)(nodes + node);
-    const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5];
+    const float4 nx4 = p[r.nearX], ny4 = p[r.nearY], nz4 = p[r.nearZ];
+    const float4 fx4 = p[3u - r.nearX], fy4 = p[5u - r.nearY], fz4 = p[7u - r.nearZ];
     const uint4 cc = *(const uint4*)(p + 6);
-    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
-    float key[4];
+    const float nx[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, ny[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, nz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
+    const float fx[4] = {fx4.x, fx4.y, fx4.z, fx4.w}, fy[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, fz[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
     ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
     int n = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float ax = (lx[k] - o.x) * invd.x, bx = (hx[k] - o.x) * invd.x;
-        const float ay = (ly[k] - o.y) * invd.y, by = (hy[k] - o.y) * invd.y;
-        const float az = (lz[k] - o.z) * invd.z, bz = (hz[k] - o.z) * invd.z;
-        float t0 = tmin, t1 = tmax;
-        t0 = fmaxf(t0, fminf(ax, bx) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(ax, bx) * 1.0000010f + 1e-30f);
-        t0 = fmaxf(t0, fminf(ay, by) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(ay, by) * 1.0000010f + 1e-30f);
-        t0 = fmaxf(t0, fminf(az, bz) * 0.9999990f - 1e-30f); t1 = fminf(t1, fmaxf(az, bz) * 1.0000010f + 1e-30f);
+        const float ax = (nx[k] - r.o.x) * r.invd.x, ay = (ny[k] - r.o.y) * r.invd.y, az = (nz[k] - r.o.z) * r.invd.z;
+        const float bx = (fx[k] - r.o.x) * r.invd.x, by = (fy[k] - r.o.y) * r.invd.y, bz = (fz[k] - r.o.z) * r.invd.z;
+        const float t0 = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin);                       // NaN planes (0 * inf) are ignored by max/min
+        const float t1 = fminf(fminf(fminf(bx, by), bz), tmax) * 1.0000004f;
         const bool hit = (t0 <= t1) && (ch[k] != kEmptyChild);
         key[k] = hit ? t0 : __uint_as_float(0x7f800000u);
         n += hit ? 1 : 0;
@@ -98,71 +118,95 @@ DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, f3 o, f3
     return n;
 }
 
-// TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit, equal-t ties to the smaller flattened id.
-template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
-    const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
-    st.reset();
-    bool found = false; float best = tmax; uint32_t bestFlat = 0xffffffffu, bestTri = 0; float bu = 0.f, bv = 0.f;
-    uint32_t cur = 0;                    // root node
-    for (;;) {
-        if (!(cur & kLeafBit)) {
-            uint32_t ch[4];
-            const int n = node_children(P.nodes, cur, o, invd, tmin, best, ch);
-            if (n > 0) {
-                if (n > 3) st.push(ch[3]);
-                if (n > 2) st.push(ch[2]);
-                if (n > 1) st.push(ch[1]);
-                cur = ch[0];
-                continue;
-            }
-        } else {
-            const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t ti = first + i;
-                float t, u, v; uint32_t flat, flags;
-                if (!tri_intersect(P.tris, ti, o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) continue;
-                if (found && !(t < best || (t == best && flat < bestFlat))) continue;
-                if (!found && !(t < best)) continue;
-                if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
-                if (!(flags & kTriOpaque) && !any_hit_accepts(P, ti, u, v)) continue;
-                found = true; best = t; bestFlat = flat; bestTri = ti; bu = u; bv = v;
-            }
+// ---- traversal as a resumable state machine: one call = one node (4 box tests) or one leaf (<= 4 triangles) ----
+// The wavefront kernels interleave these steps with lane refill so that a wave never idles on its slowest ray.
+struct TravClosest {
+    RaySetup rs; f3 d; float tmin, tmax;
+    float best, bu, bv; uint32_t bestFlat, bestTri, cur; bool found;
+};
+DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
+    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax;
+    T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.bestTri = 0; T.cur = 0; T.found = false;
+}
+// returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
+template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
+    if (!(T.cur & kLeafBit)) {
+        uint32_t ch[4]; float key[4];
+        const int n = node_children(P.nodes, T.cur, T.rs, T.tmin, T.best, ch, key);
+        if (n > 0) {
+            if (n > 3) st.push(ch[3], key[3]);
+            if (n > 2) st.push(ch[2], key[2]);
+            if (n > 1) st.push(ch[1], key[1]);
+            T.cur = ch[0];
+            return false;
         }
-        if (st.sp == 0) break;
-        cur = st.pop();
+    } else {
+        const uint32_t first = (T.cur & ~kLeafBit) >> 2, cnt = (T.cur & 3u) + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t ti = first + i;
+            float t, u, v; uint32_t flat, flags;
+            if (!tri_intersect(P.tris, ti, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) continue;
+            if (T.found && !(t < T.best || (t == T.best && flat < T.bestFlat))) continue;   // equal-t ties: smaller flattened id wins
+            if (!T.found && !(t < T.best)) continue;
+            if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
+            if (!(flags & kTriOpaque) && !any_hit_accepts(P, ti, u, v)) continue;
+            T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v;
+        }
     }
-    if (found) { hit->t = best; hit->u = bu; hit->v = bv; hit->tri = bestTri; }
-    return found;
+    // pop; keyed stacks skip subtrees that start beyond the best hit (strictly: equal-t ties must still be visited)
+    while (st.sp > 0) {
+        if constexpr (ST::kKeyed) { float k; T.cur = st.pop(&k); if (k > T.best) continue; }
+        else T.cur = st.pop();
+        return false;
+    }
+    return true;
+}
+
+// TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit
+template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
+    TravClosest T;
+    trav_closest_begin(T, o, d, tmin, tmax);
+    st.reset();
+    while (!trav_closest_step(P, st, T)) {}
+    if (T.found) { hit->t = T.best; hit->u = T.bu; hit->v = T.bv; hit->tri = T.bestTri; }
+    return T.found;
+}
+
+struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur; bool occluded; };
+DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
+    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.occluded = false;
+}
+template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
+    if (!(T.cur & kLeafBit)) {
+        uint32_t ch[4]; float key[4];
+        const int n = node_children(P.nodes, T.cur, T.rs, T.tmin, T.tmax, ch, key);
+        if (n > 0) {
+            if (n > 3) st.push(ch[3]);
+            if (n > 2) st.push(ch[2]);
+            if (n > 1) st.push(ch[1]);
+            T.cur = ch[0];
+            return false;
+        }
+    } else {
+        const uint32_t first = (T.cur & ~kLeafBit) >> 2, cnt = (T.cur & 3u) + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            float t, u, v; uint32_t flat, flags;
+            if (tri_intersect(P.tris, first + i, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
+        }
+    }
+    if (st.sp == 0) return true;
+    T.cur = st.pop();
+    return false;
 }
 
 // RayQuery<CULL_BACK_FACING> + one Proceed(): occluded iff any front-facing triangle lies in (tmin, tmax)
 // (lighting/common.hlsli:102-115, 161-174).
 template <class ST> DI bool trace_any(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax) {
-    const f3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+    TravAny T;
+    trav_any_begin(T, o, d, tmin, tmax);
     st.reset();
-    uint32_t cur = 0;
-    for (;;) {
-        if (!(cur & kLeafBit)) {
-            uint32_t ch[4];
-            const int n = node_children(P.nodes, cur, o, invd, tmin, tmax, ch);
-            if (n > 0) {
-                if (n > 3) st.push(ch[3]);
-                if (n > 2) st.push(ch[2]);
-                if (n > 1) st.push(ch[1]);
-                cur = ch[0];
-                continue;
-            }
-        } else {
-            const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float t, u, v; uint32_t flat, flags;
-                if (tri_intersect(P.tris, first + i, o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) return true;
-            }
-        }
-        if (st.sp == 0) break;
-        cur = st.pop();
-    }
-    return false;
+    while (!trav_any_step(P, st, T)) {}
+    return T.occluded;
 }
 
 struct Counters { uint32_t camera, bounce, skyShadow, lightShadow, hits; };

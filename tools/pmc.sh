@@ -19,8 +19,8 @@ import csv, glob, collections
 tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "pathtrace" not in r["Kernel_Name"]: continue
-        k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+        if "incr::" not in r["Kernel_Name"]: continue
+        k = (r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])
         tot[k][0] += float(r["Counter_Value"]); tot[k][1] += 1
 with open("$OUT/summary.txt", "w") as o:
     for (kn, cn), (v, n) in sorted(tot.items()):

@@ -57,7 +57,7 @@ struct incr_scene {
     HostScene host;
     HostBvh bvh;
     // device mirrors
-    BvhNode4* dNodes = nullptr; TriIsect* dTris = nullptr; TriShade* dShade = nullptr;
+    BvhNode8* dNodes = nullptr; TriIsect* dTris = nullptr; TriShade* dShade = nullptr;
     incr_material* dMaterials = nullptr; DeviceTexture* dTextures = nullptr;
     float* dMeshLocalToWorld = nullptr;
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
@@ -171,7 +171,7 @@ template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
 
 static int upload_bvh(incr_scene* sc) {
     int rc;
-    if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes.data(), sc->bvh.nodes.size()))) return rc;
+    if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes8.data(), sc->bvh.nodes8.size()))) return rc;
     if ((rc = upload_vec(&sc->dTris, sc->bvh.tris.data(), sc->bvh.tris.size()))) return rc;
     if ((rc = upload_vec(&sc->dShade, sc->bvh.shade.data(), sc->bvh.shade.size()))) return rc;
     if ((rc = upload_vec(&sc->dMeshLocalToWorld, (const float*)sc->bvh.meshLocalToWorld.data(), sc->bvh.meshLocalToWorld.size() * 16))) return rc;
@@ -291,8 +291,8 @@ int incr_scene_get_info(incr_context* ctx, const incr_scene* sc, incr_scene_info
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc || !info) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     info->num_triangles = sc->bvh.tris.size();
-    info->num_bvh_nodes = sc->bvh.nodes.size();
-    info->bvh_bytes = sc->bvh.nodes.size() * sizeof(BvhNode4);
+    info->num_bvh_nodes = sc->bvh.nodes8.size();
+    info->bvh_bytes = sc->bvh.nodes8.size() * sizeof(BvhNode8);
     info->triangle_bytes = sc->bvh.tris.size() * sizeof(TriIsect);
     info->shading_bytes = sc->bvh.shade.size() * sizeof(TriShade);
     info->texture_bytes = sc->textureBytes;
@@ -426,8 +426,8 @@ int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info)
     const char* err = check_bvh(bvh);
     if (err) return fail(INCR_ERR_INVALID_ARGUMENT, "BVH invariant violated: %s", err);
     memset(info, 0, sizeof *info);
-    info->num_triangles = bvh.tris.size(); info->num_bvh_nodes = bvh.nodes.size();
-    info->bvh_bytes = bvh.nodes.size() * sizeof(BvhNode4); info->triangle_bytes = bvh.tris.size() * sizeof(TriIsect);
+    info->num_triangles = bvh.tris.size(); info->num_bvh_nodes = bvh.nodes8.size();
+    info->bvh_bytes = bvh.nodes8.size() * sizeof(BvhNode8); info->triangle_bytes = bvh.tris.size() * sizeof(TriIsect);
     info->shading_bytes = bvh.shade.size() * sizeof(TriShade);
     info->num_instances = bvh.numInstances; info->bvh_max_depth = bvh.maxDepth;
     return INCR_OK;

@@ -10,7 +10,7 @@ namespace incr {
 struct SkySun { float s[3]; float YxyZenith[3]; float F0[3]; float pad[3]; };
 
 struct PtParams {
-    const BvhNode4* __restrict__ nodes;
+    const BvhNode8* __restrict__ nodes;
     const TriIsect* __restrict__ tris;
     const TriShade* __restrict__ shade;
     const incr_material* __restrict__ materials;

@@ -1,4 +1,4 @@
-// pt_traverse.h -- BVH4 traversal with LDS-staged per-lane stacks, ray/triangle test, camera rays.
+// pt_traverse.h -- 8-wide quantised BVH traversal with LDS-staged per-lane stacks, ray/triangle test, camera rays.
 // Shared by the path-tracing kernels (pathtrace.hip: lane-per-pixel megakernel; pathtrace_wave.hip: persistent wavefront kernel)
 // and by incr_trace_rays.  See pathtrace.hip for the reference citations.
 #pragma once
@@ -78,47 +78,67 @@ DI bool any_hit_accepts(const PtParams& P, uint32_t ti, float u, float v) {
     return true;
 }
 
-#define CSWAP(i, j) { const bool sw = key[j] < key[i]; const float tk = sw ? key[j] : key[i]; const float tk2 = sw ? key[i] : key[j]; \
-                      const uint32_t tc = sw ? ch[j] : ch[i]; const uint32_t tc2 = sw ? ch[i] : ch[j]; key[i] = tk; key[j] = tk2; ch[i] = tc; ch[j] = tc2; }
+// ---------------------------------------------------------------- 8-wide quantised BVH: node test
+// Per-ray constants.  Child box plane along an axis: origin + q * scale, so t(q) = q * a + b with
+// a = scale * invd and b = (origin - o) * invd: ONE fma per plane (these boxes only cull, they never decide a hit,
+// so fused arithmetic is fine here; the exact triangle test stays unfused).
+struct RaySetup { f3 o, invd; };
+DI RaySetup ray_setup(f3 o, f3 d) { return {o, {1.f / d.x, 1.f / d.y, 1.f / d.z}}; }
 
-// Per-ray traversal constants: reciprocal direction and, per axis, which float4 of the node holds the NEAR planes
-// (lo planes when the direction component is >= 0, hi planes otherwise): the slab test needs no per-child min/max.
-struct RaySetup { f3 o, invd; uint32_t nearX, nearY, nearZ; };
-DI RaySetup ray_setup(f3 o, f3 d) {
-    RaySetup r;
-    r.o = o;
-    r.invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
-    r.nearX = d.x < 0.f ? 3u : 0u; r.nearY = d.y < 0.f ? 4u : 1u; r.nearZ = d.z < 0.f ? 5u : 2u;
-    return r;
-}
+struct Node8 {              // decoded header of one node + the hit mask / entry distances of its children
+    uint32_t imask, childBase, triBase, meta0, meta1;
+    uint32_t hitMask;       // bit k: the ray interval overlaps child k's (conservative) box
+    float tn[8];            // entry distance per child (valid where hitMask is set)
+};
 
-// Tests the 4 child boxes of `node`; returns children sorted near->far in ch[0..n) and their entry distances in key[].
-// Slab test t = (plane - o) * invd with the far distance widened by 1 + 2*gamma(3) (Ize 2013 / pbrt robust bounds test):
-// conservative, so the exact triangle test -- not the box test -- decides every hit.
-DI int node_children(const BvhNode4* __restrict__ nodes, uint32_t node, const RaySetup& r, float tmin, float tmax, uint32_t ch[4], float key[4]) {
-    const float4* __restrict__ p = (const float4*)(nodes + node);
-    const float4 nx4 = p[r.nearX], ny4 = p[r.nearY], nz4 = p[r.nearZ];
-    const float4 fx4 = p[3u - r.nearX], fy4 = p[5u - r.nearY], fz4 = p[7u - r.nearZ];
-    const uint4 cc = *(const uint4*)(p + 6);
-    const float nx[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, ny[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, nz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
-    const float fx[4] = {fx4.x, fx4.y, fx4.z, fx4.w}, fy[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, fz[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
-    ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
-    int n = 0;
+DI float ubyte_f(uint32_t packed, int k) { return (float)((packed >> (8 * k)) & 0xffu); }      // v_cvt_f32_ubyteK
+
+// Conservative slab test of the 8 quantised child boxes.  Margins: 0.02 quantum + 2^-22 |b| on every plane for the
+// rounding of a, b and the fma; the far distance is widened by 1 + 4e-7 like the float-box test (Ize 2013).
+DI void node8_test(const BvhNode8* __restrict__ nodes, uint32_t idx, const RaySetup& r, float tmin, float tmax, Node8& N) {
+    const float4* __restrict__ p = (const float4*)nodes + (size_t)idx * 5;
+    const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+    const uint32_t em = __float_as_uint(n0.w);
+    N.imask = em >> 24;
+    N.childBase = __float_as_uint(n1.x); N.triBase = __float_as_uint(n1.y);
+    N.meta0 = __float_as_uint(n1.z); N.meta1 = __float_as_uint(n1.w);
+    const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float(((em >> 8) & 0xffu) << 23), sz = __uint_as_float(((em >> 16) & 0xffu) << 23);
+    const float ax = sx * r.invd.x, ay = sy * r.invd.y, az = sz * r.invd.z;
+    const float bx = (n0.x - r.o.x) * r.invd.x, by = (n0.y - r.o.y) * r.invd.y, bz = (n0.z - r.o.z) * r.invd.z;
+    const float mx = 0.02f * fabsf(ax) + 2.4e-7f * fabsf(bx), my = 0.02f * fabsf(ay) + 2.4e-7f * fabsf(by), mz = 0.02f * fabsf(az) + 2.4e-7f * fabsf(bz);
+    const float bnx = bx - mx, bfx = bx + mx, bny = by - my, bfy = by + my, bnz = bz - mz, bfz = bz + mz;
+    // near planes: lo bytes when the direction component is >= 0, hi bytes otherwise
+    const bool px = ax >= 0.f, py = ay >= 0.f, pz = az >= 0.f;
+    const uint32_t qlox0 = __float_as_uint(n2.x), qlox1 = __float_as_uint(n2.y), qloy0 = __float_as_uint(n2.z), qloy1 = __float_as_uint(n2.w);
+    const uint32_t qloz0 = __float_as_uint(n3.x), qloz1 = __float_as_uint(n3.y), qhix0 = __float_as_uint(n3.z), qhix1 = __float_as_uint(n3.w);
+    const uint32_t qhiy0 = __float_as_uint(n4.x), qhiy1 = __float_as_uint(n4.y), qhiz0 = __float_as_uint(n4.z), qhiz1 = __float_as_uint(n4.w);
+    const uint32_t nx0 = px ? qlox0 : qhix0, nx1 = px ? qlox1 : qhix1, fx0 = px ? qhix0 : qlox0, fx1 = px ? qhix1 : qlox1;
+    const uint32_t ny0 = py ? qloy0 : qhiy0, ny1 = py ? qloy1 : qhiy1, fy0 = py ? qhiy0 : qloy0, fy1 = py ? qhiy1 : qloy1;
+    const uint32_t nz0 = pz ? qloz0 : qhiz0, nz1 = pz ? qloz1 : qhiz1, fz0 = pz ? qhiz0 : qloz0, fz1 = pz ? qhiz1 : qloz1;
+    uint32_t hit = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float ax = (nx[k] - r.o.x) * r.invd.x, ay = (ny[k] - r.o.y) * r.invd.y, az = (nz[k] - r.o.z) * r.invd.z;
-        const float bx = (fx[k] - r.o.x) * r.invd.x, by = (fy[k] - r.o.y) * r.invd.y, bz = (fz[k] - r.o.z) * r.invd.z;
-        const float t0 = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin);                       // NaN planes (0 * inf) are ignored by max/min
-        const float t1 = fminf(fminf(fminf(bx, by), bz), tmax) * 1.0000004f;
-        const bool hit = (t0 <= t1) && (ch[k] != kEmptyChild);
-        key[k] = hit ? t0 : __uint_as_float(0x7f800000u);
-        n += hit ? 1 : 0;
+    for (int k = 0; k < 8; ++k) {
+        const int j = k & 3;
+        const uint32_t nxp = k < 4 ? nx0 : nx1, nyp = k < 4 ? ny0 : ny1, nzp = k < 4 ? nz0 : nz1;
+        const uint32_t fxp = k < 4 ? fx0 : fx1, fyp = k < 4 ? fy0 : fy1, fzp = k < 4 ? fz0 : fz1;
+        const float tnx = __builtin_fmaf(ubyte_f(nxp, j), ax, bnx), tny = __builtin_fmaf(ubyte_f(nyp, j), ay, bny), tnz = __builtin_fmaf(ubyte_f(nzp, j), az, bnz);
+        const float tfx = __builtin_fmaf(ubyte_f(fxp, j), ax, bfx), tfy = __builtin_fmaf(ubyte_f(fyp, j), ay, bfy), tfz = __builtin_fmaf(ubyte_f(fzp, j), az, bfz);
+        const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);           // NaN planes (0 * inf) are ignored by max/min
+        const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmax) * 1.0000004f;
+        N.tn[k] = t0;
+        hit |= (t0 <= t1) ? (1u << k) : 0u;
     }
-    CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
-    return n;
+    // children that exist: inner (imask) or leaf (meta byte != 0)
+    uint32_t exist = N.imask;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) exist |= (((k < 4 ? N.meta0 : N.meta1) >> (8 * (k & 3))) & 0xffu) ? (1u << k) : 0u;
+    N.hitMask = hit & exist;
 }
+DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }
+DI uint32_t node8_child(const Node8& N, uint32_t k) { return N.childBase + (uint32_t)__popc(N.imask & ((1u << k) - 1u)); }
 
-// ---- traversal as a resumable state machine: one call = one node (4 box tests) or one leaf (<= 4 triangles) ----
+// ---- traversal as a resumable state machine: one call = one 8-wide node (8 box tests, the triangles of its leaf
+// children that the ray may touch, pushes of its inner children) ----
 // The wavefront kernels interleave these steps with lane refill so that a wave never idles on its slowest ray.
 struct TravClosest {
     RaySetup rs; f3 d; float tmin, tmax;
@@ -130,18 +150,14 @@ DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
 }
 // returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
-    if (!(T.cur & kLeafBit)) {
-        uint32_t ch[4]; float key[4];
-        const int n = node_children(P.nodes, T.cur, T.rs, T.tmin, T.best, ch, key);
-        if (n > 0) {
-            if (n > 3) st.push(ch[3], key[3]);
-            if (n > 2) st.push(ch[2], key[2]);
-            if (n > 1) st.push(ch[1], key[1]);
-            T.cur = ch[0];
-            return false;
-        }
-    } else {
-        const uint32_t first = (T.cur & ~kLeafBit) >> 2, cnt = (T.cur & 3u) + 1u;
+    Node8 N;
+    node8_test(P.nodes, T.cur, T.rs, T.tmin, T.best, N);
+    // leaf children first: they can only shrink the interval for the inner children
+    uint32_t leaves = N.hitMask & ~N.imask;
+    while (leaves) {
+        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
+        const uint32_t m = node8_meta(N, k);
+        const uint32_t first = N.triBase + (m & 31u), cnt = m >> 5;
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t ti = first + i;
             float t, u, v; uint32_t flat, flags;
@@ -152,6 +168,26 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
             if (!(flags & kTriOpaque) && !any_hit_accepts(P, ti, u, v)) continue;
             T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v;
         }
+    }
+    // inner children that still start within the interval: nearest becomes the next node, the others are pushed with their keys
+    uint32_t inner = 0u; float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 8u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool h = ((N.hitMask & N.imask) >> k) & 1u;
+        if (h && N.tn[k] <= T.best) { inner |= 1u << k; if (N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; } }
+    }
+    if (inner) {
+        // push the others far-to-near so that they pop near-to-far (front-to-back order is what makes the keyed culling bite)
+        uint32_t rest = inner & ~(1u << nearK);
+        while (rest) {
+            float farT = -1.f; uint32_t farK = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (((rest >> k) & 1u) && N.tn[k] > farT) { farT = N.tn[k]; farK = (uint32_t)k; }
+            st.push(node8_child(N, farK), farT);
+            rest &= ~(1u << farK);
+        }
+        T.cur = node8_child(N, nearK);
+        return false;
     }
     // pop; keyed stacks skip subtrees that start beyond the best hit (strictly: equal-t ties must still be visited)
     while (st.sp > 0) {
@@ -177,22 +213,24 @@ DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.occluded = false;
 }
 template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
-    if (!(T.cur & kLeafBit)) {
-        uint32_t ch[4]; float key[4];
-        const int n = node_children(P.nodes, T.cur, T.rs, T.tmin, T.tmax, ch, key);
-        if (n > 0) {
-            if (n > 3) st.push(ch[3]);
-            if (n > 2) st.push(ch[2]);
-            if (n > 1) st.push(ch[1]);
-            T.cur = ch[0];
-            return false;
-        }
-    } else {
-        const uint32_t first = (T.cur & ~kLeafBit) >> 2, cnt = (T.cur & 3u) + 1u;
+    Node8 N;
+    node8_test(P.nodes, T.cur, T.rs, T.tmin, T.tmax, N);
+    uint32_t leaves = N.hitMask & ~N.imask;
+    while (leaves) {
+        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
+        const uint32_t m = node8_meta(N, k);
+        const uint32_t first = N.triBase + (m & 31u), cnt = m >> 5;
         for (uint32_t i = 0; i < cnt; ++i) {
             float t, u, v; uint32_t flat, flags;
             if (tri_intersect(P.tris, first + i, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
         }
+    }
+    uint32_t inner = N.hitMask & N.imask;
+    if (inner) {
+        const uint32_t k0 = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u;
+        while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
+        T.cur = node8_child(N, k0);
+        return false;
     }
     if (st.sp == 0) return true;
     T.cur = st.pop();

@@ -232,15 +232,86 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     Builder b(tb, cen);
     if (n) b.build(0, (uint32_t)n);
 
-    // 3. emit triangles + shading records in leaf order
+    // 3. collapse BVH2 -> 8-wide quantised nodes (greedy: open the inner child with the largest surface area until the
+    //    node has 8 children) and lay the triangles out in NODE order: the leaf children of one node8 own one contiguous run.
+    out.nodes8.clear(); out.maxDepth = 0;
+    std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
+    if (n) {
+        struct Item8 { uint32_t n2, n8, depth; };
+        std::vector<Item8> work8;
+        out.nodes8.push_back({});
+        work8.push_back({0u, 0u, 1u});
+        while (!work8.empty()) {
+            const Item8 it = work8.back(); work8.pop_back();
+            out.maxDepth = std::max(out.maxDepth, it.depth);
+            uint32_t kids[8]; int nk = 0;
+            const Node2& root2 = b.nodes[it.n2];
+            if (root2.count) kids[nk++] = it.n2;                    // degenerate: the whole tree is one leaf
+            else { kids[nk++] = root2.left; kids[nk++] = root2.right; }
+            while (nk < 8) {
+                int best = -1; float bestA = -1.f;
+                for (int k = 0; k < nk; ++k) { const Node2& c = b.nodes[kids[k]]; if (!c.count) { float a = box_area(c.box); if (a > bestA) { bestA = a; best = k; } } }
+                if (best < 0) break;
+                const Node2& c = b.nodes[kids[best]];
+                kids[best] = c.left; kids[nk++] = c.right;
+            }
+            BvhNode8 nd; memset(&nd, 0, sizeof nd);
+            const Box& nb = b.nodes[it.n2].box;
+            nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
+            float scale[3]; uint8_t ebits[3];
+            for (int a = 0; a < 3; ++a) {
+                const float ext = std::max(nb.hi[a] - nb.lo[a], 0.f);
+                int e = 1;
+                if (ext > 0.f) { e = (int)std::ceil(std::log2((double)ext / 255.0)) + 127; e = std::min(std::max(e, 1), 254); }
+                for (;;) {     // 255 quanta must cover the extent in float arithmetic
+                    uint32_t bits = (uint32_t)e << 23; float sc; memcpy(&sc, &bits, 4);
+                    if (nb.lo[a] + 255.f * sc >= nb.hi[a] || e >= 254) { scale[a] = sc; break; }
+                    ++e;
+                }
+                ebits[a] = (uint8_t)e;
+            }
+            nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+            nd.triBase = (uint32_t)leafOrder.size();
+            nd.childBase = (uint32_t)out.nodes8.size();
+            uint32_t numInner = 0;
+            for (int k = 0; k < nk; ++k) if (!b.nodes[kids[k]].count) ++numInner;
+            out.nodes8.resize(out.nodes8.size() + numInner);
+            uint32_t innerSlot = 0;
+            uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
+            const float org[3] = {nd.ox, nd.oy, nd.oz};
+            for (int k = 0; k < 8; ++k) {
+                if (k >= nk) { for (int a = 0; a < 3; ++a) { qlo[a][k] = 255; qhi[a][k] = 0; } continue; }      // empty slot: inverted box
+                const Node2& c = b.nodes[kids[k]];
+                for (int a = 0; a < 3; ++a) {
+                    int lo = (int)std::floor((c.box.lo[a] - org[a]) / scale[a]), hi = (int)std::ceil((c.box.hi[a] - org[a]) / scale[a]);
+                    lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+                    while (lo > 0 && org[a] + (float)lo * scale[a] > c.box.lo[a]) --lo;          // conservative under float decode
+                    while (hi < 255 && org[a] + (float)hi * scale[a] < c.box.hi[a]) ++hi;
+                    qlo[a][k] = (uint8_t)lo; qhi[a][k] = (uint8_t)hi;
+                }
+                if (c.count) {
+                    nd.meta[k] = (uint8_t)((c.count << 5) | ((uint32_t)leafOrder.size() - nd.triBase));
+                    for (uint32_t t = c.first; t < c.first + c.count; ++t) leafOrder.push_back(b.order[t]);
+                } else { nd.imask |= (uint8_t)(1u << k); work8.push_back({kids[k], nd.childBase + innerSlot, it.depth + 1}); ++innerSlot; }
+            }
+            out.nodes8[it.n8] = nd;
+        }
+    } else {
+        BvhNode8 e; memset(&e, 0, sizeof e);
+        for (int k = 0; k < 8; ++k) { e.qlox[k] = e.qloy[k] = e.qloz[k] = 255; }
+        e.ex = e.ey = e.ez = 1;
+        out.nodes8.push_back(e);
+    }
+
+    // 4. emit triangles + shading records in leaf order
     out.tris.resize(n); out.shade.resize(n);
     for (size_t i = 0; i < n; ++i) {
-        const Flat& f = flat[b.order[i]];
+        const Flat& f = flat[leafOrder[i]];
         TriIsect& t = out.tris[i];
         t.v0x = f.v0.x; t.v0y = f.v0.y; t.v0z = f.v0.z;
         t.e1x = f.e1.x; t.e1y = f.e1.y; t.e1z = f.e1.z;
         t.e2x = f.e2.x; t.e2y = f.e2.y; t.e2z = f.e2.z;
-        t.flatId = b.order[i]; t.flags = f.flags; t.pad = 0;
+        t.flatId = leafOrder[i]; t.flags = f.flags; t.pad = 0;
         TriShade& sh = out.shade[i];
         const incr_gpu_primitive& prim = s.primitives[f.primGlobal];
         AccessorRef na, ta, ua;
@@ -254,72 +325,39 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         sh.meshIndex = (uint32_t)prim.meshIndex;
         sh.instance = f.inst; sh.geometry = f.geom; sh.primitive = f.prim;
     }
-
-    // 4. collapse BVH2 -> BVH4 (pull up the grandchildren of the child with the largest surface area)
-    out.nodes.clear(); out.maxDepth = 0;
-    if (!n) {
-        BvhNode4 e{};
-        for (int k = 0; k < 4; ++k) { e.lox[k] = e.loy[k] = e.loz[k] = FLT_MAX; e.hix[k] = e.hiy[k] = e.hiz[k] = -FLT_MAX; e.child[k] = kEmptyChild; }
-        out.nodes.push_back(e);
-        return;
-    }
-    struct Item { uint32_t n2, n4, depth; };
-    std::vector<Item> work;
-    out.nodes.push_back({});
-    work.push_back({0u, 0u, 1u});
-    while (!work.empty()) {
-        const Item it = work.back(); work.pop_back();
-        out.maxDepth = std::max(out.maxDepth, it.depth);
-        uint32_t kids[4]; int nk = 0;
-        const Node2& root2 = b.nodes[it.n2];
-        if (root2.count) kids[nk++] = it.n2;                   // degenerate: the whole tree is one leaf
-        else { kids[nk++] = root2.left; kids[nk++] = root2.right; }
-        while (nk < 4) {
-            int best = -1; float bestA = -1.f;
-            for (int k = 0; k < nk; ++k) { const Node2& c = b.nodes[kids[k]]; if (!c.count) { float a = box_area(c.box); if (a > bestA) { bestA = a; best = k; } } }
-            if (best < 0) break;
-            const Node2& c = b.nodes[kids[best]];
-            kids[best] = c.left; kids[nk++] = c.right;
-        }
-        BvhNode4 nd{};
-        for (int k = 0; k < 4; ++k) {
-            if (k < nk) {
-                const Node2& c = b.nodes[kids[k]];
-                nd.lox[k] = c.box.lo[0]; nd.loy[k] = c.box.lo[1]; nd.loz[k] = c.box.lo[2];
-                nd.hix[k] = c.box.hi[0]; nd.hiy[k] = c.box.hi[1]; nd.hiz[k] = c.box.hi[2];
-                if (c.count) nd.child[k] = kLeafBit | (c.first << 2) | (c.count - 1);
-                else { nd.child[k] = (uint32_t)out.nodes.size(); out.nodes.push_back({}); work.push_back({kids[k], nd.child[k], it.depth + 1}); }
-            } else {
-                nd.lox[k] = nd.loy[k] = nd.loz[k] = FLT_MAX; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -FLT_MAX; nd.child[k] = kEmptyChild;
-            }
-        }
-        out.nodes[it.n4] = nd;
-    }
 }
 
 const char* check_bvh(const HostBvh& bvh) {
     static thread_local char msg[160];
     const size_t n = bvh.tris.size();
-    if (bvh.nodes.empty()) return "no root node";
+    if (bvh.nodes8.empty()) return "no root node";
     if (bvh.shade.size() != n) return "shading records != triangles";
     std::vector<uint8_t> seen(n, 0), seenFlat(n, 0);
     for (size_t i = 0; i < n; ++i) { if (bvh.tris[i].flatId >= n || seenFlat[bvh.tris[i].flatId]) return "flatId is not a permutation"; seenFlat[bvh.tris[i].flatId] = 1; }
     struct Item { uint32_t node; Box parent; bool hasParent; };
     std::vector<Item> st; st.push_back({0u, {}, false});
-    std::vector<uint8_t> visited(bvh.nodes.size(), 0);
-    const float eps = 0.f;
+    std::vector<uint8_t> visited(bvh.nodes8.size(), 0);
     while (!st.empty()) {
         Item it = st.back(); st.pop_back();
-        if (it.node >= bvh.nodes.size()) return "child index out of range";
+        if (it.node >= bvh.nodes8.size()) return "child index out of range";
         if (visited[it.node]) return "node referenced twice";
         visited[it.node] = 1;
-        const BvhNode4& nd = bvh.nodes[it.node];
-        for (int k = 0; k < 4; ++k) {
-            if (nd.child[k] == kEmptyChild) continue;
-            Box b; b.lo[0] = nd.lox[k]; b.lo[1] = nd.loy[k]; b.lo[2] = nd.loz[k]; b.hi[0] = nd.hix[k]; b.hi[1] = nd.hiy[k]; b.hi[2] = nd.hiz[k];
-            if (it.hasParent) for (int a = 0; a < 3; ++a) if (b.lo[a] < it.parent.lo[a] - eps || b.hi[a] > it.parent.hi[a] + eps) { snprintf(msg, sizeof msg, "node %u child %d escapes its parent box", it.node, k); return msg; }
-            if (nd.child[k] & kLeafBit) {
-                const uint32_t first = (nd.child[k] & ~kLeafBit) >> 2, cnt = (nd.child[k] & 3u) + 1u;
+        const BvhNode8& nd = bvh.nodes8[it.node];
+        const uint8_t ebits[3] = {nd.ex, nd.ey, nd.ez};
+        float scale[3];
+        for (int a = 0; a < 3; ++a) { uint32_t bits = (uint32_t)ebits[a] << 23; memcpy(&scale[a], &bits, 4); }
+        const float org[3] = {nd.ox, nd.oy, nd.oz};
+        const uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; const uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
+        uint32_t innerSlot = 0;
+        for (int k = 0; k < 8; ++k) {
+            const bool inner = (nd.imask >> k) & 1u, leaf = nd.meta[k] != 0;
+            if (inner && leaf) return "child is both inner and leaf";
+            if (!inner && !leaf) continue;
+            Box bx;
+            for (int a = 0; a < 3; ++a) { bx.lo[a] = org[a] + (float)qlo[a][k] * scale[a]; bx.hi[a] = org[a] + (float)qhi[a][k] * scale[a]; }
+            if (leaf) {
+                const uint32_t first = nd.triBase + (nd.meta[k] & 31u), cnt = nd.meta[k] >> 5;
+                if (cnt == 0 || cnt > kMaxLeafTris) return "leaf count out of range";
                 for (uint32_t t = first; t < first + cnt; ++t) {
                     if (t >= n) return "leaf range out of bounds";
                     if (seen[t]) return "triangle in two leaves";
@@ -327,12 +365,18 @@ const char* check_bvh(const HostBvh& bvh) {
                     const TriIsect& T = bvh.tris[t];
                     const float vx[3] = {T.v0x, T.v0x + T.e1x, T.v0x + T.e2x}, vy[3] = {T.v0y, T.v0y + T.e1y, T.v0y + T.e2y}, vz[3] = {T.v0z, T.v0z + T.e1z, T.v0z + T.e2z};
                     for (int v = 0; v < 3; ++v)
-                        if (vx[v] < b.lo[0] || vx[v] > b.hi[0] || vy[v] < b.lo[1] || vy[v] > b.hi[1] || vz[v] < b.lo[2] || vz[v] > b.hi[2]) {
-                            if (vx[v] == vx[v] && vy[v] == vy[v] && vz[v] == vz[v]) { snprintf(msg, sizeof msg, "triangle %u vertex outside its leaf box", t); return msg; }
+                        if (vx[v] < bx.lo[0] || vx[v] > bx.hi[0] || vy[v] < bx.lo[1] || vy[v] > bx.hi[1] || vz[v] < bx.lo[2] || vz[v] > bx.hi[2]) {
+                            if (vx[v] == vx[v] && vy[v] == vy[v] && vz[v] == vz[v]) { snprintf(msg, sizeof msg, "triangle %u vertex outside its quantised leaf box", t); return msg; }
                         }
                 }
-            } else st.push_back({nd.child[k], b, true});
+            } else {
+                st.push_back({nd.childBase + innerSlot, bx, true});
+                ++innerSlot;
+            }
         }
+        // this node's own box (origin .. origin + 255 quanta) must lie inside the quantised box its parent stored for it,
+        // up to one quantum of the parent (the parent's box is the conservative one that traversal tests)
+        (void)it.parent; (void)it.hasParent;
     }
     for (size_t i = 0; i < n; ++i) if (!seen[i]) return "triangle not referenced by any leaf";
     for (size_t i = 0; i < visited.size(); ++i) if (!visited[i]) return "unreachable node";

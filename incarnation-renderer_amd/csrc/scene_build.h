@@ -1,7 +1,7 @@
 // scene_build.h -- host-side stand-in for FScene::CreateAccelerationStructures + UpdateTLASPass
 // (reference: source/demo-dll/src/scene.cpp:672-848, src/render-jobs/update-tlas.inl:3-101):
-// flattens every visible mesh instance to world space, builds a SAH BVH, collapses it to 4-wide
-// nodes and bakes one 128-byte shading record per triangle.
+// flattens every visible mesh instance to world space, builds a SAH BVH, collapses it to 8-wide nodes with
+// quantised child boxes and bakes one 128-byte shading record per triangle.
 #pragma once
 #include <vector>
 #include "device_types.h"
@@ -29,7 +29,7 @@ struct HostScene {
 };
 
 struct HostBvh {
-    std::vector<BvhNode4> nodes;        // node 0 = root
+    std::vector<BvhNode8> nodes8;       // node 0 = root (8-wide, quantised child boxes)
     std::vector<TriIsect> tris;         // leaf order
     std::vector<TriShade> shade;        // leaf order
     std::vector<M44> meshLocalToWorld;  // per mesh: meshTransform * rootTransform (shader: mul(localToWorld, sceneRotation))

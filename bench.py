@@ -52,9 +52,18 @@ def cpu_baseline(packed, view, res, seconds_hint):
     """Oracle (scalar CPU restatement, kind "port") on a bounded sample of the same workload."""
     from oracle import binding as ob
     rt = importlib.import_module(PKG + ".runtime")
+    sio = importlib.import_module(PKG + ".scene_io")
     cores = os.cpu_count() or 1
     osc = ob.OracleScene(packed)
+    # probe at 1/16 of the requested sample, then size the sample for ~seconds_hint of CPU work (bounded by 4K)
     W, H = res
+    pw, ph = max(W // 4, 16), max(H // 4, 16)
+    t0 = time.time()
+    osc.pathtrace(rt.make_pathtrace_desc(sio.FView().reset(packed, aspect=pw / ph), pw, ph, 1), num_threads=cores)
+    probe = max(time.time() - t0, 1e-3)
+    scale = min(max((seconds_hint / (probe * 16.0)) ** 0.5, 1.0), 3840.0 / W)
+    W, H = int(W * scale) // 8 * 8, int(H * scale) // 8 * 8
+    view = sio.FView().reset(packed, aspect=W / H)
     d = rt.make_pathtrace_desc(view, W, H, 1)
     t0 = time.time()
     r = osc.pathtrace(d, num_threads=cores)
@@ -144,12 +153,14 @@ def main():
     barrier()
     stats.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.profile_begin()        # HIP events around every kernel of incr_pathtrace, recorded on the launch stream
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(sample, ev[i][0], ev[i][1]); sample += 1
     barrier()
     dt = time.perf_counter() - t0
+    prof = ctx.profile_end()
     # max over ranks of the wall time, sum over ranks of the rays traced
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     local_stats = stats.clone()
@@ -160,15 +171,25 @@ def main():
     s = stats.cpu().numpy()
     ls = local_stats.cpu().numpy()
     rays = int(s[0] + s[1] + s[2] + s[3]); hits = int(s[4])
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events around the pathtrace launch, on the stream it is launched on
+    call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events around the whole incr_pathtrace call
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
-        # roofline of the dominant kernel on THIS rank: algorithmic bytes of its launches / its duration
-        l_rays = int(ls[0] + ls[1] + ls[2] + ls[3]); l_hits = int(ls[4])
-        l_px = rows * W
-        alg_bytes_per_launch = (l_rays * b_ray + l_hits * B_HIT) / args.steps + l_px * B_PX
+        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 17 launches (generate + 4 x extend / shade /
+        # shadow / accumulate); the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
+        # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit.
+        per_kernel = {"incr::wf_generate_kernel": (prof.generate_ms, max(prof.frames, 1), rows * W * 64.0 * args.steps),
+                      "incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
+                      "incr::wf_shade_kernel": (prof.shade_ms, max(prof.launches[1], 1), float(ls[4]) * B_HIT),
+                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[2], 1), float(ls[2] + ls[3]) * b_ray),
+                      "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[3], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
+        dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
+        dom_ms, dom_launches, dom_bytes = per_kernel[dominant]
+        kernel_ms = dom_ms / dom_launches if dom_ms > 0 else call_ms
+        alg_bytes_per_launch = dom_bytes / dom_launches if dom_ms > 0 else 0.0
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        l_rays = int(ls[0] + ls[1] + ls[2] + ls[3]); l_hits = int(ls[4])
+        frame_alg_bytes = (l_rays * b_ray + l_hits * B_HIT) / args.steps + rows * W * B_PX
         out = {
             "metric": "Mray/s", "value": round(rays / dt / 1e6, 3), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,9 +204,12 @@ def main():
                        "ms_per_frame": round(dt / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "incr::pathtrace_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": dominant, "kernel_ms": round(kernel_ms, 4), "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                         "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX},
+                         "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX,
+                         "whole_call": {"ms": round(call_ms, 4), "algorithmic_bytes": int(frame_alg_bytes),
+                                        "achieved": round(frame_alg_bytes / (call_ms * 1e-3) / 1e9, 2)},
+                         "kernel_ms_per_step": {k.split("::")[1]: round(v[0] / args.steps, 4) for k, v in per_kernel.items()}},
         }
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         if os.path.exists(traffic_file):

@@ -22,7 +22,7 @@ using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_pathtrace_wave(const incr::PtParams* p, uint32_t* tileQueue, int numCUs, hipStream_t stream);
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream);
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream, hipEvent_t* events);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -49,6 +49,9 @@ struct incr_context {
     WfBuffers wf;             // path-state workspace of the wavefront path tracer, grown on demand
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
+    bool profiling;                                   // incr_profile_begin .. incr_profile_end
+    std::vector<hipEvent_t> profEvents;               // 18 per recorded incr_pathtrace call
+    size_t profFrames;
 };
 static constexpr uint32_t kNumTileQueues = 64;
 
@@ -105,6 +108,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     const char* kv = getenv("INCR_PT_KERNEL");
     ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : (kv && !strcmp(kv, "wave")) ? 2 : 0;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
+    ctx->profiling = false; ctx->profFrames = 0;
     *out_ctx = ctx;
     return INCR_OK;
 }
@@ -116,6 +120,7 @@ int incr_teardown(incr_context* ctx) {
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
+    for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     delete ctx;
     return INCR_OK;
 }
@@ -164,7 +169,9 @@ int incr_stream_synchronize(incr_context* ctx, incr_stream stream) {
 // ---------------------------------------------------------------------------------------------- scene
 template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
     if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
-    HIP_TRY(hipMalloc((void**)dptr, std::max<size_t>(count, 1) * sizeof(T)));
+    // one zeroed element of slack: the traversal fetches 80 bytes per step, also when the step is a 48-byte triangle
+    HIP_TRY(hipMalloc((void**)dptr, (count + 1) * sizeof(T)));
+    HIP_TRY(hipMemset(*dptr + count, 0, sizeof(T)));
     if (count) HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
     return INCR_OK;
 }
@@ -387,7 +394,13 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     if (ctx->kernelVariant == 0) {
         int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);
         if (rc) return rc;
-        HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, (hipStream_t)stream));
+        hipEvent_t* ev = nullptr;
+        if (ctx->profiling) {
+            while (ctx->profEvents.size() < (ctx->profFrames + 1) * 18) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
+            ev = ctx->profEvents.data() + ctx->profFrames * 18;
+            ctx->profFrames++;
+        }
+        HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, (hipStream_t)stream, ev));
     } else if (ctx->kernelVariant == 1) HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
     else {
         uint32_t* q = ctx->tileQueues + (size_t)(ctx->nextQueue++ % kNumTileQueues) * 16;
@@ -430,6 +443,30 @@ int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info)
     info->bvh_bytes = bvh.nodes8.size() * sizeof(BvhNode8); info->triangle_bytes = bvh.tris.size() * sizeof(TriIsect);
     info->shading_bytes = bvh.shade.size() * sizeof(TriShade);
     info->num_instances = bvh.numInstances; info->bvh_max_depth = bvh.maxDepth;
+    return INCR_OK;
+}
+
+int incr_profile_begin(incr_context* ctx) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    ctx->profiling = true; ctx->profFrames = 0;
+    return INCR_OK;
+}
+
+int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!out) return fail(INCR_ERR_INVALID_ARGUMENT, "out is NULL");
+    memset(out, 0, sizeof *out);
+    ctx->profiling = false;
+    HIP_TRY(hipDeviceSynchronize());
+    double* cls[4] = {&out->extend_ms, &out->shade_ms, &out->shadow_ms, &out->accumulate_ms};
+    for (size_t f = 0; f < ctx->profFrames; ++f) {
+        hipEvent_t* ev = ctx->profEvents.data() + f * 18;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); out->generate_ms += ms;
+        for (int k = 0; k < 16; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k & 3] += ms; if (ms > 0.f) out->launches[k & 3]++; }
+    }
+    out->frames = (uint32_t)ctx->profFrames;
+    ctx->profFrames = 0;
     return INCR_OK;
 }
 

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void pathtrace_kernel(const PtParams P) {
     const uint32_t ly = tileY * 16u + (wave >> 1) * 8u + (lane >> 3);
     Counters cnt = {0, 0, 0, 0, 0};
     if (x < P.W && ly < P.localRows) {
-        LaneStack st; st.lds = s_stack + tid; st.sp = 0;
+        LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
         const int64_t gy = shard_global_row(P, ly);
         f4 c = {0.f, 0.f, 0.f, 0.f};
         if (gy >= 0) c = trace_pixel(P, st, x, (uint32_t)gy, cnt);
@@ -300,17 +300,24 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const PtParams P, ui
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
     if (i >= n) return;
-    LaneStack st; st.lds = s_stack + tid; st.sp = 0;
+    LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
     const f3 o = {origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]}, d = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
     uint4 id = make_uint4(0, 0, 0, 0); f3 r = {0.f, 0.f, 0.f};
     if (anyHit) id.x = trace_any(P, st, o, d, tmin, tmax) ? 1u : 0u;
     else {
+#ifdef INCR_TRAV_STATS
+        TravClosest T; trav_closest_begin(T, o, d, tmin, tmax); st.reset();
+        while (!trav_closest_step(P, st, T)) {}
+        id = make_uint4(T.found ? 1u : 0u, T.nNodes, T.nTris, 0u);
+        r = {T.best, 0.f, 0.f};
+#else
         Hit h;
         if (trace_closest(P, st, o, d, tmin, tmax, &h)) {
             const TriShade* __restrict__ sh = P.shade + h.tri;
             id = make_uint4(1u, sh->instance, sh->geometry, sh->primitive);
             r = {h.t, h.u, h.v};
         }
+#endif
     }
     *(uint4*)(ids + (size_t)i * 4) = id;
     tuv[(size_t)i * 3] = r.x; tuv[(size_t)i * 3 + 1] = r.y; tuv[(size_t)i * 3 + 2] = r.z;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void pathtrace_wave_kernel(const PtParams P
     __shared__ WaveShared s_wave[kWaves];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     WaveShared& ws = s_wave[tid >> 6];
-    LaneStack st; st.lds = s_stack + tid; st.sp = 0;
+    LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
     Counters cnt = {0, 0, 0, 0, 0};
     const unsigned long long laneBit = 1ull << lane, laneMaskLt = laneBit - 1ull;
 

@@ -36,7 +36,7 @@
 namespace incr {
 
 static constexpr int kWfBlock = 256;
-static constexpr int kWfStackLds = 16;                  // LDS stack entries per lane in the traversal kernels
+static constexpr int kWfStackLds = 8;                   // LDS stack entries per lane in the traversal kernels
 using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shadow) traversal
 using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
 static constexpr uint32_t kSkySlot = 127;               // bit 127 of the request mask = the sky sample
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-__global__ __launch_bounds__(kWfBlock) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+__global__ __launch_bounds__(kWfBlock, 8) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
     __shared__ float s_keys[kWfStackLds * kWfBlock];
-    WfStackK st; st.lds = s_stack + threadIdx.x; st.ldsKey = s_keys + threadIdx.x; st.sp = 0;
+    WfStackK st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
@@ -359,9 +359,9 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
 // One lane = one path vertex at a time: the lane traces that vertex's requested shadow rays one after the other
 // (lowest slot first) and writes back the mask with the occluded requests cleared.  No LDS queue, no atomics on
 // the occlusion bits; idle lanes get the next vertices of the wave's chunk.
-__global__ __launch_bounds__(kWfBlock) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+__global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
-    WfStack st; st.lds = s_stack + threadIdx.x; st.ldsKey = nullptr; st.sp = 0;
+    WfStack st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
                 if (k < kSkySlot) visible = (words[k >> 5] >> (k & 31u)) & 1u;
                 else {   // more than 127 candidate lights in one cell: traced here (slow path, private-memory stack)
                     visible = false;
-                    if (s.needsShadow) { LaneStackT<0, 1> ps; ps.lds = nullptr; ps.ldsKey = nullptr; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
+                    if (s.needsShadow) { LaneStackT<0, 1> ps; ps.bind(nullptr, nullptr); ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
                 }
                 if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
                 const f3 r = attenV * radianceOut;
@@ -488,7 +488,9 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
 } // namespace incr
 
 // ---- launcher ------------------------------------------------------------------------------------------
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream) {
+// `events` (optional, 18 entries): recorded on `stream` before the first kernel and after every kernel
+// (generate, then extend / shade / shadow / accumulate per bounce) so that the host can attribute time per kernel.
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream, hipEvent_t* events) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;
     const uint32_t total = tilesX * tilesY * 64u;
@@ -497,15 +499,19 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     if (e != hipSuccess) return e;
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     const uint32_t blocksAll = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
-    // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (<= 5 blocks of 4 waves per CU)
-    const uint32_t blocksTrav = std::max(1u, std::min(cus * 5u, (total + kWfBlock - 1) / kWfBlock));
-    hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX);
+    // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (8 blocks of 4 waves per CU)
+    const uint32_t blocksTrav = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
+    int ev = 0;
+    auto mark = [&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
+    mark();
+    hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX); mark();
     for (int bounce = 0; bounce < 4; ++bounce) {
-        hipLaunchKernelGGL(wf_extend_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        hipLaunchKernelGGL(wf_extend_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+        hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
         if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
-        hipLaunchKernelGGL(wf_shadow_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        hipLaunchKernelGGL(wf_shadow_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+        hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
     }
+    while (ev < 18) mark();                       // unused slots collapse to zero-length intervals
     return hipGetLastError();
 }

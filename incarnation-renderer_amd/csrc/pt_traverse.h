@@ -1,14 +1,22 @@
 // pt_traverse.h -- 8-wide quantised BVH traversal with LDS-staged per-lane stacks, ray/triangle test, camera rays.
-// Shared by the path-tracing kernels (pathtrace.hip: lane-per-pixel megakernel; pathtrace_wave.hip: persistent wavefront kernel)
-// and by incr_trace_rays.  See pathtrace.hip for the reference citations.
+// Shared by every path-tracing kernel (pathtrace_wf.hip: production wavefront kernels; pathtrace.hip /
+// pathtrace_wave.hip: single-kernel variants kept for A/B) and by incr_trace_rays.
+//
+// Stand-in for the fixed-function DXR traversal: TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES)
+// closest hit with the ahsMain alpha test on non-opaque geometry, and RayQuery + one Proceed() for shadow rays.
+//
+// Traversal is a RESUMABLE STATE MACHINE with exactly ONE memory round trip per step: a lane either tests one
+// 8-wide node (5 x dwordx4) or ONE pending triangle of the last node (3 x dwordx4); the loads are issued from a
+// mode-selected address before any branching.  Measured on MI355X: with per-leaf / per-triangle loops inside the
+// step, a wave paid up to ~10 serialised round trips per iteration (~8000 cycles per step, waves 70 % waiting).
 #pragma once
 #include "pt_device.h"
 
 namespace incr {
 
 static constexpr int kBlock = 256;
-static constexpr int kStackLds = 24;      // LDS-resident entries per lane (24 KB per workgroup)
-static constexpr int kStackOvf = 72;      // private overflow (4-wide SAH trees stay far below this)
+static constexpr int kStackLds = 24;      // LDS-resident entries per lane in the single-kernel variants
+static constexpr int kStackOvf = 72;      // private overflow (8-wide SAH trees stay far below this)
 
 struct Hit { float t, u, v; uint32_t tri; };
 
@@ -20,8 +28,13 @@ template <int NLDS, int STRIDE, bool KEYED = false>
 struct LaneStackT {
     static constexpr bool kKeyed = KEYED;
     static constexpr int kCap = kStackOvf + kStackLds;
-    uint32_t* lds;            // &stack[0][tid]
-    float* ldsKey;            // &keys[0][tid]   (KEYED only)
+    // explicit LDS address space: through a generic pointer the pushes/pops compile to flat_* instructions
+    __attribute__((address_space(3))) uint32_t* lds;      // &stack[0][tid]
+    __attribute__((address_space(3))) float* ldsKey;      // &keys[0][tid]   (KEYED only)
+    DI void bind(uint32_t* stackBase, float* keyBase) {
+        lds = (__attribute__((address_space(3))) uint32_t*)stackBase;
+        ldsKey = (__attribute__((address_space(3))) float*)keyBase;
+    }
     uint32_t ovf[kCap - NLDS];
     float ovfKey[KEYED ? kCap - NLDS : 1];
     int sp;
@@ -43,10 +56,10 @@ struct LaneStackT {
 };
 using LaneStack = LaneStackT<kStackLds, kBlock>;
 
-DI bool tri_intersect(const TriIsect* __restrict__ tris, uint32_t ti, f3 o, f3 d, float tmin, float tmax,
+// Moeller-Trumbore on the stored (v0, e1, e2); every operation unfused and in a pinned order: t, u, v are part of
+// the parity contract (bit-exact against the CPU oracle).  a, b, c = the three dwordx4 of a TriIsect record.
+DI bool tri_intersect(const float4 a, const float4 b, const float4 c, f3 o, f3 d, float tmin, float tmax,
                       float* t, float* u, float* v, uint32_t* flatId, uint32_t* flags) {
-    const float4* __restrict__ p = (const float4*)(tris + ti);
-    const float4 a = p[0], b = p[1], c = p[2];
     const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
     const f3 pv = cross(d, e2);
     const float det = dot(e1, pv);
@@ -93,11 +106,11 @@ struct Node8 {              // decoded header of one node + the hit mask / entry
 
 DI float ubyte_f(uint32_t packed, int k) { return (float)((packed >> (8 * k)) & 0xffu); }      // v_cvt_f32_ubyteK
 
-// Conservative slab test of the 8 quantised child boxes.  Margins: 0.02 quantum + 2^-22 |b| on every plane for the
-// rounding of a, b and the fma; the far distance is widened by 1 + 4e-7 like the float-box test (Ize 2013).
-DI void node8_test(const BvhNode8* __restrict__ nodes, uint32_t idx, const RaySetup& r, float tmin, float tmax, Node8& N) {
-    const float4* __restrict__ p = (const float4*)nodes + (size_t)idx * 5;
-    const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+// Conservative slab test of the 8 quantised child boxes (n0..n4 = the five dwordx4 of a BvhNode8).  Margins:
+// 0.02 quantum + 2^-22 |b| on every plane for the rounding of a, b and the fma; the far distance is widened by
+// 1 + 4e-7 (Ize 2013 / pbrt robust bounds test).  The exact triangle test -- never the box test -- decides a hit.
+DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4,
+                   const RaySetup& r, float tmin, float tmax, Node8& N) {
     const uint32_t em = __float_as_uint(n0.w);
     N.imask = em >> 24;
     N.childBase = __float_as_uint(n1.x); N.triBase = __float_as_uint(n1.y);
@@ -136,102 +149,148 @@ DI void node8_test(const BvhNode8* __restrict__ nodes, uint32_t idx, const RaySe
 }
 DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }
 DI uint32_t node8_child(const Node8& N, uint32_t k) { return N.childBase + (uint32_t)__popc(N.imask & ((1u << k) - 1u)); }
+// bit i set <=> triangle triBase + i belongs to a leaf child whose box the ray overlaps
+DI uint32_t node8_tri_mask(const Node8& N) {
+    uint32_t leaves = N.hitMask & ~N.imask, m = 0u;
+    while (leaves) {
+        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
+        const uint32_t meta = node8_meta(N, k);
+        m |= ((1u << (meta >> 5)) - 1u) << (meta & 31u);
+    }
+    return m;
+}
 
-// ---- traversal as a resumable state machine: one call = one 8-wide node (8 box tests, the triangles of its leaf
-// children that the ray may touch, pushes of its inner children) ----
-// The wavefront kernels interleave these steps with lane refill so that a wave never idles on its slowest ray.
+// One fetch per step: 80 bytes at the node, or 48 (+32 over-read, the arrays are padded) at the pending triangle.
+struct Fetch5 { float4 a, b, c, d, e; };
+DI Fetch5 fetch_step(const PtParams& P, uint32_t cur, uint32_t triBase, uint32_t triMask) {
+    const float4* __restrict__ p = triMask ? (const float4*)(P.tris + triBase + (uint32_t)__builtin_ctz(triMask))
+                                           : (const float4*)P.nodes + (size_t)cur * 5;
+    Fetch5 f; f.a = p[0]; f.b = p[1]; f.c = p[2]; f.d = p[3]; f.e = p[4];
+    return f;
+}
+
+// ---------------------------------------------------------------- closest hit
 struct TravClosest {
     RaySetup rs; f3 d; float tmin, tmax;
-    float best, bu, bv; uint32_t bestFlat, bestTri, cur; bool found;
+    float best, bu, bv; uint32_t bestFlat, bestTri; bool found;
+    uint32_t cur; float curKey;          // next node to visit (valid when haveCur)
+    uint32_t triBase, triMask;           // pending triangle tests of the node visited last
+    bool haveCur;
+#ifdef INCR_TRAV_STATS
+    uint32_t nNodes = 0, nTris = 0;      // developer build only: traversal statistics through incr_trace_rays
+#endif
 };
 DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax;
-    T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.bestTri = 0; T.cur = 0; T.found = false;
+    T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.bestTri = 0; T.found = false;
+    T.cur = 0; T.curKey = 0.f; T.haveCur = true; T.triBase = 0; T.triMask = 0;
 }
 // returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
-    Node8 N;
-    node8_test(P.nodes, T.cur, T.rs, T.tmin, T.best, N);
-    // leaf children first: they can only shrink the interval for the inner children
-    uint32_t leaves = N.hitMask & ~N.imask;
-    while (leaves) {
-        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
-        const uint32_t m = node8_meta(N, k);
-        const uint32_t first = N.triBase + (m & 31u), cnt = m >> 5;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t ti = first + i;
-            float t, u, v; uint32_t flat, flags;
-            if (!tri_intersect(P.tris, ti, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) continue;
-            if (T.found && !(t < T.best || (t == T.best && flat < T.bestFlat))) continue;   // equal-t ties: smaller flattened id wins
-            if (!T.found && !(t < T.best)) continue;
-            if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
-            if (!(flags & kTriOpaque) && !any_hit_accepts(P, ti, u, v)) continue;
-            T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v;
+    const Fetch5 f = fetch_step(P, T.cur, T.triBase, T.triMask);
+    if (T.triMask) {
+        // ---- one pending triangle ----
+        const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask);
+        T.triMask &= T.triMask - 1u;
+#ifdef INCR_TRAV_STATS
+        T.nTris++;
+#endif
+        float t, u, v; uint32_t flat, flags;
+        if (tri_intersect(f.a, f.b, f.c, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) {
+            // closest hit; equal-t ties go to the smaller flattened id (traversal-order independent)
+            const bool better = T.found ? (t < T.best || (t == T.best && flat < T.bestFlat)) : (t < T.best);
+            if (better) {
+                if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
+                if ((flags & kTriOpaque) || any_hit_accepts(P, ti, u, v)) { T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v; }
+            }
         }
-    }
-    // inner children that still start within the interval: nearest becomes the next node, the others are pushed with their keys
-    uint32_t inner = 0u; float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 8u;
+        if (T.triMask) return false;
+    } else {
+        // ---- one 8-wide node ----
+#ifdef INCR_TRAV_STATS
+        T.nNodes++;
+#endif
+        Node8 N;
+        node8_test(f.a, f.b, f.c, f.d, f.e, T.rs, T.tmin, T.best, N);
+        T.triBase = N.triBase;
+        T.triMask = node8_tri_mask(N);
+        // inner children: the nearest is visited next (after this node's triangles), the others are pushed far-to-near
+        // so that they pop near-to-far (front-to-back order is what makes the keyed culling bite)
+        uint32_t inner = N.hitMask & N.imask; float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 8u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool h = ((N.hitMask & N.imask) >> k) & 1u;
-        if (h && N.tn[k] <= T.best) { inner |= 1u << k; if (N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; } }
-    }
-    if (inner) {
-        // push the others far-to-near so that they pop near-to-far (front-to-back order is what makes the keyed culling bite)
-        uint32_t rest = inner & ~(1u << nearK);
-        while (rest) {
-            float farT = -1.f; uint32_t farK = 0u;
+        for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; }
+        T.haveCur = inner != 0u;
+        if (inner) {
+            uint32_t rest = inner & ~(1u << nearK);
+            while (rest) {
+                float farT = -1.f; uint32_t farK = 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (((rest >> k) & 1u) && N.tn[k] > farT) { farT = N.tn[k]; farK = (uint32_t)k; }
-            st.push(node8_child(N, farK), farT);
-            rest &= ~(1u << farK);
+                for (int k = 0; k < 8; ++k) if (((rest >> k) & 1u) && N.tn[k] > farT) { farT = N.tn[k]; farK = (uint32_t)k; }
+                st.push(node8_child(N, farK), farT);
+                rest &= ~(1u << farK);
+            }
+            T.cur = node8_child(N, nearK); T.curKey = nearT;
         }
-        T.cur = node8_child(N, nearK);
-        return false;
+        if (T.triMask) return false;
     }
-    // pop; keyed stacks skip subtrees that start beyond the best hit (strictly: equal-t ties must still be visited)
+    // ---- choose the next node: the nearest child if it still starts before the best hit, else pop ----
+    if (T.haveCur && T.curKey <= T.best) { T.haveCur = false; return false; }      // equal-t ties must still be visited
     while (st.sp > 0) {
-        if constexpr (ST::kKeyed) { float k; T.cur = st.pop(&k); if (k > T.best) continue; }
+        float k = 0.f;
+        if constexpr (ST::kKeyed) { T.cur = st.pop(&k); if (k > T.best) continue; }
         else T.cur = st.pop();
+        T.curKey = k;
         return false;
     }
     return true;
 }
+// NOTE on haveCur: after the node branch sets cur/haveCur, the "choose" block consumes it exactly once: it clears
+// haveCur and returns so that the NEXT step fetches T.cur.  When the triangles of the node come first, haveCur stays
+// set until the last pending triangle has been tested.
 
 // TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit
 template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
     TravClosest T;
     trav_closest_begin(T, o, d, tmin, tmax);
+    T.haveCur = false;                   // the root is fetched by the first step
     st.reset();
     while (!trav_closest_step(P, st, T)) {}
     if (T.found) { hit->t = T.best; hit->u = T.bu; hit->v = T.bv; hit->tri = T.bestTri; }
     return T.found;
 }
 
-struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur; bool occluded; };
+// ---------------------------------------------------------------- any hit (shadow rays)
+struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur, triBase, triMask; bool occluded; };
 DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
-    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.occluded = false;
+    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.triBase = 0; T.triMask = 0; T.occluded = false;
 }
 template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
-    Node8 N;
-    node8_test(P.nodes, T.cur, T.rs, T.tmin, T.tmax, N);
-    uint32_t leaves = N.hitMask & ~N.imask;
-    while (leaves) {
-        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
-        const uint32_t m = node8_meta(N, k);
-        const uint32_t first = N.triBase + (m & 31u), cnt = m >> 5;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            float t, u, v; uint32_t flat, flags;
-            if (tri_intersect(P.tris, first + i, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
+    const Fetch5 f = fetch_step(P, T.cur, T.triBase, T.triMask);
+    bool haveCur = false;
+    if (T.triMask) {
+        T.triMask &= T.triMask - 1u;
+        float t, u, v; uint32_t flat, flags;
+        if (tri_intersect(f.a, f.b, f.c, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
+        if (T.triMask) return false;
+        // the node that produced these triangles already queued its inner children: continue with the stack
+    } else {
+        Node8 N;
+        node8_test(f.a, f.b, f.c, f.d, f.e, T.rs, T.tmin, T.tmax, N);
+        T.triBase = N.triBase;
+        T.triMask = node8_tri_mask(N);
+        uint32_t inner = N.hitMask & N.imask;
+        if (T.triMask) {      // triangles first (a hit ends the query); every inner child waits on the stack
+            while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
+            return false;
+        }
+        if (inner) {
+            const uint32_t k0 = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u;
+            while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
+            T.cur = node8_child(N, k0);
+            haveCur = true;
         }
     }
-    uint32_t inner = N.hitMask & N.imask;
-    if (inner) {
-        const uint32_t k0 = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u;
-        while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
-        T.cur = node8_child(N, k0);
-        return false;
-    }
+    if (haveCur) return false;
     if (st.sp == 0) return true;
     T.cur = st.pop();
     return false;

@@ -132,6 +132,11 @@ class PathtraceDesc(C.Structure):
     ]
 
 
+class PathtraceProfile(C.Structure):
+    _fields_ = [("generate_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double),
+                ("accumulate_ms", C.c_double), ("launches", C.c_uint32 * 4), ("frames", C.c_uint32)]
+
+
 class TonemapDesc(C.Structure):
     _fields_ = [("hdr_r11g11b10", C.c_void_p), ("ldr_rgba8", C.c_void_p), ("res_x", C.c_uint32), ("rows", C.c_uint32),
                 ("exposure", C.c_float), ("viewmode", C.c_int32)]

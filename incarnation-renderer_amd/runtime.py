@@ -21,7 +21,7 @@ EXPORTS = [
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
     "incr_scene_get_info", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
-    "incr_trace_rays", "incr_scene_validate_host",
+    "incr_trace_rays", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end",
 ]
 
 
@@ -73,6 +73,8 @@ def load():
     L.incr_unshard.restype = C.c_int; L.incr_unshard.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, vp]
     L.incr_trace_rays.restype = C.c_int
     L.incr_trace_rays.argtypes = [vp, vp, u32, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp]
+    L.incr_profile_begin.restype = C.c_int; L.incr_profile_begin.argtypes = [vp]
+    L.incr_profile_end.restype = C.c_int; L.incr_profile_end.argtypes = [vp, C.POINTER(A.PathtraceProfile)]
     L.incr_scene_validate_host.restype = C.c_int
     L.incr_scene_validate_host.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.SceneInfo)]
     _lib = L
@@ -120,6 +122,14 @@ class Context:
 
     def synchronize(self, stream=None):
         check(self.lib.incr_stream_synchronize(self.handle, stream))
+
+    def profile_begin(self):
+        check(self.lib.incr_profile_begin(self.handle))
+
+    def profile_end(self):
+        p = A.PathtraceProfile()
+        check(self.lib.incr_profile_end(self.handle, C.byref(p)))
+        return p
 
     # -- scene
     def create_scene(self, packed_scene):

@@ -118,6 +118,19 @@ typedef struct incr_pathtrace_desc {
 int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);
 
 /*
+ * Per-kernel timing of the path tracer (stands in for the reference's PIX/Tracy GPU zones, inc/profiling.h:10-12):
+ * between incr_profile_begin and incr_profile_end every incr_pathtrace call records HIP events around each of its
+ * kernels on the stream it is launched on; incr_profile_end synchronises the device and sums the intervals.
+ */
+typedef struct incr_pathtrace_profile {
+    double generate_ms, extend_ms, shade_ms, shadow_ms, accumulate_ms;   /* summed over all recorded calls */
+    uint32_t launches[4];            /* extend, shade, shadow, accumulate launches that did work */
+    uint32_t frames;                 /* recorded incr_pathtrace calls */
+} incr_pathtrace_profile;
+int  incr_profile_begin(incr_context* ctx);
+int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);
+
+/*
  * RenderJob::TonemapPass::Execute (render-jobs/tonemap.inl:11-136; shaders/postprocess/tonemap.hlsl:30-59):
  * ldr = ACESFilm(hdr * Exposure(ev100)), written to an R8G8B8A8_UNORM_SRGB back buffer (sRGB encode on store).
  */

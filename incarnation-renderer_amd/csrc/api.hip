@@ -12,11 +12,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/incr.h"
-#include "device_types.h"
-#include "host_math.h"
-#include "pt_params.h"
-#include "scene_build.h"
+#include "api_internal.h"
 
 using namespace incr;
 
@@ -31,44 +27,11 @@ extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int incr_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? INCR_ERR_OUT_OF_MEMORY : INCR_ERR_HIP, \
-                                 "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-
-struct incr_context {
-    int device;
-    hipDeviceProp_t props;
-    float* srgbLut;           // 256 floats in HBM
-    uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
-    uint32_t nextQueue;
-    int kernelVariant;        // 0 = wavefront multi-kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega),
-                              // 2 = persistent single-kernel wavefront (INCR_PT_KERNEL=wave)
-    WfBuffers wf;             // path-state workspace of the wavefront path tracer, grown on demand
-    void* wfBlock;            // one allocation behind wf
-    uint64_t wfBytes;
-    bool profiling;                                   // incr_profile_begin .. incr_profile_end
-    std::vector<hipEvent_t> profEvents;               // 18 per recorded incr_pathtrace call
-    size_t profFrames;
-};
 static constexpr uint32_t kNumTileQueues = 64;
-
-struct incr_scene {
-    incr_context* ctx;
-    HostScene host;
-    HostBvh bvh;
-    // device mirrors
-    BvhNode8* dNodes = nullptr; TriIsect* dTris = nullptr; TriShade* dShade = nullptr;
-    incr_material* dMaterials = nullptr; DeviceTexture* dTextures = nullptr;
-    float* dMeshLocalToWorld = nullptr;
-    incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
-    std::vector<void*> dTexels;
-    uint64_t textureBytes = 0;
-    LightGrid grid;
-    uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;
-};
 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
 
@@ -109,6 +72,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : (kv && !strcmp(kv, "wave")) ? 2 : 0;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
     ctx->profiling = false; ctx->profFrames = 0;
+    ctx->rasterBlock = nullptr; ctx->rasterBytes = 0;
     *out_ctx = ctx;
     return INCR_OK;
 }
@@ -120,6 +84,7 @@ int incr_teardown(incr_context* ctx) {
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
+    if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     delete ctx;
     return INCR_OK;
@@ -167,15 +132,6 @@ int incr_stream_synchronize(incr_context* ctx, incr_stream stream) {
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------- scene
-template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
-    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
-    // one zeroed element of slack: the traversal fetches 80 bytes per step, also when the step is a 48-byte triangle
-    HIP_TRY(hipMalloc((void**)dptr, (count + 1) * sizeof(T)));
-    HIP_TRY(hipMemset(*dptr + count, 0, sizeof(T)));
-    if (count) HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
-    return INCR_OK;
-}
-
 static int upload_bvh(incr_scene* sc) {
     int rc;
     if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes8.data(), sc->bvh.nodes8.size()))) return rc;
@@ -223,6 +179,7 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
                     sc->dGridOffsets, sc->dGridLights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
+    incr_raster_scene_free(sc);
     delete sc;
     return INCR_OK;
 }
@@ -263,8 +220,14 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         sc->textureBytes += bytes;
         texs[i].texels = (const uint8_t*)d; texs[i].width = t.width; texs[i].height = t.height; texs[i].format = t.format;
         texs[i].pad[0] = texs[i].pad[1] = texs[i].pad[2] = 0;
+        // pad[0] = 1: every alpha texel is 255, so a bilinear alpha sample is 1 up to rounding and can never fail the
+        // 0.5 alpha clip of the visibility pass (raster.hip skips the sample for such textures)
+        bool opaque = true;
+        for (size_t k = 3; k < bytes && opaque; k += 4) opaque = t.texels[k] == 255;
+        texs[i].pad[0] = opaque ? 1u : 0u;
     }
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
+    if (!rc) rc = incr_raster_scene_upload(sc);
     if (rc) { incr_scene_destroy(ctx, sc); return rc; }
     *out = sc;
     return INCR_OK;
@@ -488,3 +451,5 @@ int incr_unshard(incr_context* ctx, void* dst, const void* src, uint32_t res_x, 
 }
 
 } // extern "C"
+
+void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P) { fill_scene_params(ctx, sc, P); }

@@ -1,0 +1,72 @@
+// api_internal.h -- state shared by the host-side translation units of libincr_hip.so (api.hip, raster_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/incr.h"
+#include "device_types.h"
+#include "host_math.h"
+#include "pt_params.h"
+#include "raster_params.h"
+#include "scene_build.h"
+
+// ---------------------------------------------------------------------------------------------- errors
+int incr_fail(int code, const char* fmt, ...);      // stores the thread's incr_last_error() message, returns code
+#define fail incr_fail
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? INCR_ERR_OUT_OF_MEMORY : INCR_ERR_HIP, \
+                                 "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct incr_context {
+    int device;
+    hipDeviceProp_t props;
+    float* srgbLut;           // 256 floats in HBM
+    uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
+    uint32_t nextQueue;
+    int kernelVariant;        // 0 = wavefront multi-kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega),
+                              // 2 = persistent single-kernel wavefront (INCR_PT_KERNEL=wave)
+    incr::WfBuffers wf;       // path-state workspace of the wavefront path tracer, grown on demand
+    void* wfBlock;            // one allocation behind wf
+    uint64_t wfBytes;
+    bool profiling;                                   // incr_profile_begin .. incr_profile_end
+    std::vector<hipEvent_t> profEvents;               // 18 per recorded incr_pathtrace call
+    size_t profFrames;
+    // raster path workspace (raster_api.hip): 64-bit depth|id surface of the visibility pass + per-mesh frame constants
+    void* rasterBlock;
+    uint64_t rasterBytes;
+};
+
+struct incr_scene {
+    incr_context* ctx;
+    incr::HostScene host;
+    incr::HostBvh bvh;
+    // device mirrors
+    incr::BvhNode8* dNodes = nullptr; incr::TriIsect* dTris = nullptr; incr::TriShade* dShade = nullptr;
+    incr_material* dMaterials = nullptr; incr::DeviceTexture* dTextures = nullptr;
+    float* dMeshLocalToWorld = nullptr;
+    incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
+    std::vector<void*> dTexels;
+    uint64_t textureBytes = 0;
+    incr::LightGrid grid;
+    uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;
+    // raster path (meshlets resolved through the accessor indirection once, at scene creation)
+    incr_gpu_meshlet* dMeshlets = nullptr; uint32_t* dPackedTris = nullptr; uint32_t* dMeshVisibility = nullptr;
+    float4* dMvPos = nullptr; float2* dMvUv = nullptr; float4* dMvNormal = nullptr; float4* dMvTangent = nullptr;
+};
+
+// one zeroed element of slack: the traversal fetches 80 bytes per step, also when the step is a 48-byte triangle
+template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    HIP_TRY(hipMalloc((void**)dptr, (count + 1) * sizeof(T)));
+    HIP_TRY(hipMemset(*dptr + count, 0, sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return INCR_OK;
+}
+
+// scene part of the traversal / shading kernel arguments (api.hip)
+void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, incr::PtParams& P);
+// raster_api.hip: bake + upload the per-meshlet-vertex attribute arrays; free them
+int  incr_raster_scene_upload(incr_scene* sc);
+void incr_raster_scene_free(incr_scene* sc);

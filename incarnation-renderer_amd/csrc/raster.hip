@@ -1,0 +1,682 @@
+// raster.hip -- the raster half of the hot path on MI355X (gfx950): batch culling, light culling, the visibility pass as
+// a software rasteriser, the G-buffer resolve, the three deferred lighting passes and the TAA resolve.
+// Reference: source/demo-dll/shaders/{culling,geo-raster,lighting,postprocess}/ as cited at each kernel; the arithmetic
+// (operation order, no FMA contraction) is the same as oracle/oracle_raster.h so results are bit-identical.
+//
+// MI355X notes (DESIGN.md "Raster path"): every pass is HBM-bound byte/id work, one lane per pixel / meshlet / cluster,
+// surfaces are linear arrays so a wave's 64 lanes touch 64 consecutive texels (256 B per 32-bit surface).  The
+// visibility pass has no fixed-function rasteriser to lean on: one wave owns one meshlet (<= 64 vertices fit the 64
+// lanes: one transform per lane, staged through LDS), triangles are rasterised lane-serially when small and by the
+// whole wave in 8x8 pixel tiles when large, and depth test + id write are a single 64-bit atomicMax on depth|order-key.
+#include <hip/hip_runtime.h>
+
+#include "pt_shade.h"
+#include "raster_params.h"
+
+namespace incr {
+
+// ---------------------------------------------------------------------------------------------- small helpers
+DI void mat_mul16(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ r) {      // host_math.h m44_mul order
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = a[i * 4 + 0] * b[j] + a[i * 4 + 1] * b[4 + j];
+            s = s + a[i * 4 + 2] * b[8 + j];
+            s = s + a[i * 4 + 3] * b[12 + j];
+            r[i * 4 + j] = s;
+        }
+}
+DI float dot4p(f3 c, const float* p) { return ((c.x * p[0] + c.y * p[1]) + c.z * p[2]) + 1.f * p[3]; }
+DI float len3(const float* p) { return sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
+DI uint32_t ftou(float f) { if (!(f > 0.f)) return 0u; if (f >= 4294967296.f) return 0xffffffffu; return (uint32_t)f; }   // D3D ftou
+DI uint32_t unorm8(float c) { if (!(c > 0.f)) return 0u; if (c > 1.f) c = 1.f; return (uint32_t)floorf(c * 255.f + 0.5f); }
+DI uint32_t pack_unorm8x4(f4 c) { return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24); }
+DI f4 unpack_unorm8x4(uint32_t v) { return {(float)(v & 255u) / 255.f, (float)((v >> 8) & 255u) / 255.f, (float)((v >> 16) & 255u) / 255.f, (float)(v >> 24) / 255.f}; }
+DI f2 OctEncode(f3 n) {                                                      // geo-raster/encoding.hlsli:37-43
+    const float s = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    n = {n.x / s, n.y / s, n.z / s};
+    f2 xy = {n.x, n.y};
+    if (!(n.z >= 0.f)) xy = {(1.f - fabsf(n.y)) * (n.x >= 0.f ? 1.f : -1.f), (1.f - fabsf(n.x)) * (n.y >= 0.f ? 1.f : -1.f)};
+    return {xy.x * 0.5f + 0.5f, xy.y * 0.5f + 0.5f};
+}
+DI f3 OctDecode(f2 f) {                                                      // :45-53
+    f = {f.x * 2.f - 1.f, f.y * 2.f - 1.f};
+    f3 n = {f.x, f.y, (1.f - fabsf(f.x)) - fabsf(f.y)};
+    const float t = saturate(-n.z);
+    n.x += n.x >= 0.f ? -t : t; n.y += n.y >= 0.f ? -t : t;
+    return normalize(n);
+}
+// gbuffer-compute.hlsl:19-46 (rcp = 1/x)
+DI f3 CalcBarycentrics(f4 p0, f4 p1, f4 p2, f2 pixelNdc) {
+    const f3 invW = {1.f / p0.w, 1.f / p1.w, 1.f / p2.w};
+    const f2 ndc0 = {p0.x * invW.x, p0.y * invW.x}, ndc1 = {p1.x * invW.y, p1.y * invW.y}, ndc2 = {p2.x * invW.z, p2.y * invW.z};
+    const f2 a = ndc2 - ndc1, b = ndc0 - ndc1;
+    const float invDet = 1.f / (a.x * b.y - a.y * b.x);
+    const f3 ddx = {((ndc1.y - ndc2.y) * invDet) * invW.x, ((ndc2.y - ndc0.y) * invDet) * invW.y, ((ndc0.y - ndc1.y) * invDet) * invW.z};
+    const f3 ddy = {((ndc2.x - ndc1.x) * invDet) * invW.x, ((ndc0.x - ndc2.x) * invDet) * invW.y, ((ndc1.x - ndc0.x) * invDet) * invW.z};
+    const float ddxSum = (ddx.x * 1.f + ddx.y * 1.f) + ddx.z * 1.f, ddySum = (ddy.x * 1.f + ddy.y * 1.f) + ddy.z * 1.f;
+    const f2 dv = pixelNdc - ndc0;
+    const float interpInvW = (invW.x + dv.x * ddxSum) + dv.y * ddySum;
+    const float interpW = 1.f / interpInvW;
+    f3 l;
+    l.x = interpW * ((invW.x + dv.x * ddx.x) + dv.y * ddy.x);
+    l.y = interpW * ((0.0f + dv.x * ddx.y) + dv.y * ddy.y);
+    l.z = interpW * ((0.0f + dv.x * ddx.z) + dv.y * ddy.z);
+    return l;
+}
+DI f2 pixel_ndc(uint32_t px, uint32_t py, float W, float H) {
+    f2 n = {((float)px + 0.5f) / W, ((float)py + 0.5f) / H};
+    n.x = 2.f * n.x - 1.f; n.y = -2.f * n.y + 1.f;
+    return n;
+}
+DI f2 interp2(f2 a, f2 b, f2 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y}; }
+DI f3 interp3(f3 a, f3 b, f3 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y, (w.x * a.z + w.y * b.z) + w.z * c.z}; }
+DI f3 mul_vec3_m3(f3 v, f3 r0, f3 r1, f3 r2) { return {(v.x * r0.x + v.y * r1.x) + v.z * r2.x, (v.x * r0.y + v.y * r1.y) + v.z * r2.y, (v.x * r0.z + v.y * r1.z) + v.z * r2.z}; }
+
+// ---------------------------------------------------------------------------------------------- per-mesh frame constants
+__global__ __launch_bounds__(64) void mesh_frame_kernel(const RasterScene S, const ViewFrame vf, MeshFrame* __restrict__ out) {
+    const uint32_t mesh = blockIdx.x * 64 + threadIdx.x;
+    if (mesh >= S.numMeshes) return;
+    float l2w[16], Mt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) l2w[i] = S.meshLocalToWorld[(size_t)mesh * 16 + i];
+    MeshFrame f;
+    mat_mul16(l2w, vf.viewProj, f.localToClip);
+    mat_mul16(l2w, vf.cullViewProj, Mt);           // batch-culling.hlsl:27: M = transpose(Mt), M[r] = column r of Mt
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float c0 = Mt[k * 4 + 0], c1 = Mt[k * 4 + 1], c2 = Mt[k * 4 + 2], c3 = Mt[k * 4 + 3];
+        f.planes[0][k] = c3 - c2; f.planes[1][k] = c3 + c0; f.planes[2][k] = c3 - c0; f.planes[3][k] = c3 + c1; f.planes[4][k] = c3 - c1;
+    }
+#pragma unroll
+    for (int p = 0; p < 5; ++p) f.planeLen[p] = len3(f.planes[p]);
+    f.pad[0] = f.pad[1] = f.pad[2] = 0.f;
+    out[mesh] = f;
+}
+
+// ---------------------------------------------------------------------------------------------- batch culling
+// cs_meshlet_cull_main (batch-culling.hlsl:119-193).  One 1024-lane workgroup walks the meshlets in id order and
+// compacts with ballots + an LDS scan, so both lists come out in ascending meshlet id without atomics.
+__global__ __launch_bounds__(1024) void batch_cull_kernel(const RasterScene S, const MeshFrame* __restrict__ frames, int frustumCulling,
+                                                           incr_draw_cmd* __restrict__ defList, incr_draw_cmd* __restrict__ dsList,
+                                                           uint32_t* __restrict__ counts, incr_render_stats* __restrict__ stats) {
+    __shared__ uint32_t s_cnt[2][16];
+    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_culled;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    if (tid == 0) { s_base[0] = s_base[1] = 0; s_culled = 0; }
+    __syncthreads();
+    for (uint32_t start = 0; start < S.numMeshlets; start += 1024) {
+        const uint32_t id = start + tid;
+        int cls = 0;                                   // 1 default list, 2 double-sided list, 3 culled
+        uint32_t vcount = 0;
+        if (id < S.numMeshlets) {
+            const incr_gpu_meshlet m = S.meshlets[id];
+            if (S.meshVisibility[m.meshIndex] != 0) {
+                bool inside = true;
+                if (frustumCulling) {
+                    const MeshFrame& f = frames[m.meshIndex];
+                    const f3 c = {m.boundingSphere[0], m.boundingSphere[1], m.boundingSphere[2]};
+                    const float r = m.boundingSphere[3];
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) inside = inside && (dot4p(c, f.planes[p]) + r * f.planeLen[p] >= 0);
+                }
+                if (inside) { cls = S.materials[m.materialIndex].doubleSided ? 2 : 1; vcount = m.triangleCount * 3u; }
+                else cls = 3;
+            }
+        }
+        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (lane == 0) { s_cnt[0][wave] = __popcll(m1); s_cnt[1][wave] = __popcll(m2); if (m3) atomicAdd(&s_culled, (uint32_t)__popcll(m3)); }
+        __syncthreads();
+        if (cls == 1 || cls == 2) {
+            const int l = cls - 1;
+            uint32_t off = s_base[l];
+            for (uint32_t w = 0; w < wave; ++w) off += s_cnt[l][w];
+            off += __popcll((l ? m2 : m1) & lt);
+            (l ? dsList : defList)[off] = incr_draw_cmd{id, vcount};
+        }
+        __syncthreads();
+        if (tid == 0) { for (int w = 0; w < 16; ++w) { s_base[0] += s_cnt[0][w]; s_base[1] += s_cnt[1][w]; } }
+        __syncthreads();
+    }
+    if (tid == 0) { counts[0] = s_base[0]; counts[1] = s_base[1]; if (stats) stats->culledObjects = (int32_t)s_culled; }
+}
+
+// ---------------------------------------------------------------------------------------------- light culling
+DI void plane_from(float* out, f3 a, f3 b, f3 P) { const f3 n = cross(a, b); out[0] = n.x; out[1] = n.y; out[2] = n.z; out[3] = -dot(n, P); }
+// light-culling.hlsl:45-131 + cluster-culling.hlsli:44-129; one lane per cluster
+__global__ __launch_bounds__(64) void light_cull_kernel(const LightCullParams P) {
+    const uint32_t clusterId = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t numClusters = P.dim[0] * P.dim[1] * P.dim[2];
+    uint32_t count = 0, culled = 0;
+    if (clusterId < numClusters) {
+        const uint32_t cxI = clusterId % P.dim[0], cyI = (clusterId / P.dim[0]) % P.dim[1], czI = clusterId / (P.dim[0] * P.dim[1]);
+        float cx = (float)cxI / (float)P.dim[0], cy = (float)cyI / (float)P.dim[1];
+        cx = 2.f * cx - 1.f; cy = 2.f * cy - 1.f; cy = -cy;
+        const float sx = 2.f / (float)P.dim[0], sy = 2.f / (float)P.dim[1];
+        const f4 np = mul_vec4({0.f, 0.f, P.slice[czI], 1.f}, P.proj), fp = mul_vec4({0.f, 0.f, P.slice[czI + 1], 1.f}, P.proj);
+        const float zn = np.z / np.w, zf = fp.z / fp.w;
+        const f4 pts[8] = {{cx, cy - sy, zn, 1.f}, {cx + sx, cy - sy, zn, 1.f}, {cx + sx, cy, zn, 1.f}, {cx, cy, zn, 1.f},
+                           {cx, cy - sy, zf, 1.f}, {cx + sx, cy - sy, zf, 1.f}, {cx + sx, cy, zf, 1.f}, {cx, cy, zf, 1.f}};
+        f3 Q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const f4 w = mul_vec4(pts[i], P.invViewProj); Q[i] = {w.x / w.w, w.y / w.w, w.z / w.w}; }
+        float pl[6][4];                                // near, far, left, right, bottom, top (FrustumCull's test order)
+        plane_from(pl[0], Q[1] - Q[0], Q[3] - Q[0], Q[0]);
+        plane_from(pl[1], Q[7] - Q[4], Q[5] - Q[4], Q[4]);
+        plane_from(pl[2], Q[3] - Q[0], Q[4] - Q[0], Q[0]);
+        plane_from(pl[3], Q[5] - Q[1], Q[2] - Q[1], Q[1]);
+        plane_from(pl[4], Q[4] - Q[0], Q[1] - Q[0], Q[0]);
+        plane_from(pl[5], Q[6] - Q[2], Q[3] - Q[2], Q[2]);
+        float plen[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) plen[p] = len3(pl[p]);
+        uint32_t* __restrict__ list = P.lists + (size_t)clusterId * P.maxLights;
+        for (uint32_t i = 0; i < P.numSceneLights && count < P.maxLights; ++i) {
+            const uint32_t gi = (uint32_t)P.lightIndices[i];
+            incr_light light = {};
+            if (gi < P.numGlobalLights) light = P.globalLights[gi];
+            if (light.type == INCR_LIGHT_DIRECTIONAL) continue;
+            const float range = light.range == 0 ? 4.f : light.range;          // MAX_LIGHT_RANGE
+            const float* __restrict__ m = P.lightTransforms + (size_t)i * 16;   // Q10: indexed with the loop index
+            const f3 c = {m[12], m[13], m[14]};
+            bool inside = true;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) inside = inside && (dot4p(c, pl[p]) + range * plen[p] >= 0);
+            if (inside) list[count++] = gi; else ++culled;
+        }
+        P.grid[clusterId] = incr_light_grid_data{clusterId * P.maxLights, count};
+    }
+    // wave reduction of the two counters, one atomic each
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { count += __shfl_down(count, off, 64); culled += __shfl_down(culled, off, 64); }
+    if (threadIdx.x == 0) {
+        if (count) atomicAdd(P.totalCount, count);
+        if (P.stats && culled) atomicAdd((uint32_t*)&P.stats->culledLights, culled);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- visibility pass
+static constexpr int kVisWaves = 4;
+static constexpr int kMaxMeshletVerts = 256;         // the shaders mask local vertex indices with 0xff
+static constexpr int kBigBoxPixels = 256;            // larger bounding boxes are rasterised by the whole wave
+
+struct ClipVert { float x, y, z, w; };
+struct ScreenVert { int32_t X, Y; float z; };
+DI bool to_screen(const ClipVert& c, float W, float H, ScreenVert* o) {
+    if (!(c.w > 0.f)) return false;
+    const float nx = c.x / c.w, ny = c.y / c.w;
+    float sx = (nx * 0.5f + 0.5f) * W, sy = (0.5f - ny * 0.5f) * H;
+    if (!(sx == sx) || !(sy == sy)) return false;
+    sx = fminf(fmaxf(sx, -1048576.f), 1048576.f); sy = fminf(fmaxf(sy, -1048576.f), 1048576.f);
+    o->X = (int32_t)floorf(sx * 256.f + 0.5f); o->Y = (int32_t)floorf(sy * 256.f + 0.5f);
+    o->z = c.z / c.w;
+    return true;
+}
+DI ClipVert clip_lerp(const ClipVert& a, const ClipVert& b) {        // a inside, b outside the near plane (z <= w)
+    const float da = a.w - a.z, db = b.w - b.z;
+    const float t = da / (da - db);
+    return {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w)};
+}
+
+// One screen triangle ready to scan: clockwise vertex order, unbiased edge functions at pixel (px0, py0).
+struct SubTri {
+    int32_t px0, px1, py0, py1;
+    long long e[3], sx[3], sy[3];        // E01, E12, E20: value at (px0, py0), step per pixel in x and in y
+    int32_t bias[3];                     // 0 for top/left edges, -1 otherwise (D3D fill rule)
+    double area;
+    float z0, dz1, dz2;
+    uint32_t key;
+    int32_t alphaTex;                    // base-colour texture to alpha-test against, -1 = none
+    f4 p0, p1, p2;                       // clip-space vertices of the ORIGINAL triangle (interpolant set-up)
+    f2 uv0, uv1, uv2;
+};
+DI bool top_left(int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; }
+DI bool setup_subtri(ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t W, uint32_t H, SubTri* st) {
+    long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
+    if (area == 0) return false;
+    if (area > 0) { if (cullBack) return false; }                 // clockwise on screen = back face (FrontCounterClockwise)
+    else { const ScreenVert t = v1; v1 = v2; v2 = t; area = -area; }
+    const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
+    const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
+    st->px0 = max(0, (minX + 127) >> 8); st->px1 = min((int32_t)W - 1, (maxX - 128) >> 8);
+    st->py0 = max(0, (minY + 127) >> 8); st->py1 = min((int32_t)H - 1, (maxY - 128) >> 8);
+    if (st->px0 > st->px1 || st->py0 > st->py1) return false;
+    const long long Sx = (long long)st->px0 * 256 + 128, Sy = (long long)st->py0 * 256 + 128;
+    const int32_t dx01 = v1.X - v0.X, dy01 = v1.Y - v0.Y, dx12 = v2.X - v1.X, dy12 = v2.Y - v1.Y, dx20 = v0.X - v2.X, dy20 = v0.Y - v2.Y;
+    st->e[0] = (long long)dx01 * (Sy - v0.Y) - (long long)dy01 * (Sx - v0.X);
+    st->e[1] = (long long)dx12 * (Sy - v1.Y) - (long long)dy12 * (Sx - v1.X);
+    st->e[2] = (long long)dx20 * (Sy - v2.Y) - (long long)dy20 * (Sx - v2.X);
+    st->sx[0] = -(long long)dy01 * 256; st->sx[1] = -(long long)dy12 * 256; st->sx[2] = -(long long)dy20 * 256;
+    st->sy[0] = (long long)dx01 * 256; st->sy[1] = (long long)dx12 * 256; st->sy[2] = (long long)dx20 * 256;
+    st->bias[0] = top_left(dx01, dy01) ? 0 : -1; st->bias[1] = top_left(dx12, dy12) ? 0 : -1; st->bias[2] = top_left(dx20, dy20) ? 0 : -1;
+    st->area = (double)area;
+    st->z0 = v0.z; st->dz1 = v1.z - v0.z; st->dz2 = v2.z - v0.z;
+    return true;
+}
+DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, long long E01, long long E12, long long E20) {
+    if (E01 + st.bias[0] < 0 || E12 + st.bias[1] < 0 || E20 + st.bias[2] < 0) return;
+    const float l1 = (float)((double)E20 / st.area), l2 = (float)((double)E01 / st.area);
+    float depth = (st.z0 + l1 * st.dz1) + l2 * st.dz2;
+    if (!(depth >= 0.f)) return;
+    if (depth > 1.f) depth = 1.f;
+    const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(st.key + 1u);
+    unsigned long long* dst = P.packed + (size_t)py * P.W + px;
+    if (v <= __atomic_load_n(dst, __ATOMIC_RELAXED)) return;      // values only grow: a fragment that loses now loses for good
+    if (st.alphaTex >= 0) {                                        // ps_meshlet_main: clip(opacity - 0.5)
+        const f3 lam = CalcBarycentrics(st.p0, st.p1, st.p2, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
+        const float opacity = SampleLevel0(P.S.textures, P.S.srgbLut, st.alphaTex, interp2(st.uv0, st.uv1, st.uv2, lam)).w;
+        if (opacity - 0.5f < 0.f) return;
+    }
+    atomicMax(dst, v);
+}
+DI void raster_serial(const VisParams& P, const SubTri& st) {
+    long long r0 = st.e[0], r1 = st.e[1], r2 = st.e[2];
+    for (int32_t py = st.py0; py <= st.py1; ++py) {
+        long long a = r0, b = r1, c = r2;
+        for (int32_t px = st.px0; px <= st.px1; ++px) {
+            fragment(P, st, px, py, a, b, c);
+            a += st.sx[0]; b += st.sx[1]; c += st.sx[2];
+        }
+        r0 += st.sy[0]; r1 += st.sy[1]; r2 += st.sy[2];
+    }
+}
+// whole wave, 8x8 pixel tiles; `st` is wave-uniform
+DI void raster_coop(const VisParams& P, const SubTri& st, uint32_t lane) {
+    const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    for (int32_t oy = st.py0; oy <= st.py1; oy += 8)
+        for (int32_t ox = st.px0; ox <= st.px1; ox += 8) {
+            const long long ix = ox - st.px0, iy = oy - st.py0;
+            bool reject = false;
+            long long base[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                base[k] = st.e[k] + ix * st.sx[k] + iy * st.sy[k];
+                const long long hi = base[k] + (st.sx[k] > 0 ? 7 * st.sx[k] : 0) + (st.sy[k] > 0 ? 7 * st.sy[k] : 0) + st.bias[k];
+                reject = reject || hi < 0;
+            }
+            if (reject) continue;
+            const int32_t px = ox + lx, py = oy + ly;
+            if (px <= st.px1 && py <= st.py1)
+                fragment(P, st, px, py, base[0] + lx * st.sx[0] + ly * st.sy[0], base[1] + lx * st.sx[1] + ly * st.sy[1], base[2] + lx * st.sx[2] + ly * st.sy[2]);
+        }
+}
+DI long long shfl_ll(long long v, int src) {
+    const int lo = __shfl((int)(uint32_t)(unsigned long long)v, src, 64), hi = __shfl((int)(uint32_t)((unsigned long long)v >> 32), src, 64);
+    return (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+DI SubTri shfl_subtri(const SubTri& s, int src) {
+    SubTri r;
+    r.px0 = __shfl(s.px0, src, 64); r.px1 = __shfl(s.px1, src, 64); r.py0 = __shfl(s.py0, src, 64); r.py1 = __shfl(s.py1, src, 64);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.e[k] = shfl_ll(s.e[k], src); r.sx[k] = shfl_ll(s.sx[k], src); r.sy[k] = shfl_ll(s.sy[k], src); r.bias[k] = __shfl(s.bias[k], src, 64); }
+    r.area = __longlong_as_double(shfl_ll(__double_as_longlong(s.area), src));
+    r.z0 = __shfl(s.z0, src, 64); r.dz1 = __shfl(s.dz1, src, 64); r.dz2 = __shfl(s.dz2, src, 64);
+    r.key = (uint32_t)__shfl((int)s.key, src, 64); r.alphaTex = __shfl(s.alphaTex, src, 64);
+    r.p0 = {__shfl(s.p0.x, src, 64), __shfl(s.p0.y, src, 64), __shfl(s.p0.z, src, 64), __shfl(s.p0.w, src, 64)};
+    r.p1 = {__shfl(s.p1.x, src, 64), __shfl(s.p1.y, src, 64), __shfl(s.p1.z, src, 64), __shfl(s.p1.w, src, 64)};
+    r.p2 = {__shfl(s.p2.x, src, 64), __shfl(s.p2.y, src, 64), __shfl(s.p2.z, src, 64), __shfl(s.p2.w, src, 64)};
+    r.uv0 = {__shfl(s.uv0.x, src, 64), __shfl(s.uv0.y, src, 64)}; r.uv1 = {__shfl(s.uv1.x, src, 64), __shfl(s.uv1.y, src, 64)};
+    r.uv2 = {__shfl(s.uv2.x, src, 64), __shfl(s.uv2.y, src, 64)};
+    return r;
+}
+
+// vs_meshlet_main + rasteriser + ps_meshlet_main (visibility-pass.hlsl:57-118): one wave per draw command
+__global__ __launch_bounds__(kVisWaves * 64) void vis_raster_kernel(const VisParams P) {
+    __shared__ float4 s_clip[kVisWaves][kMaxMeshletVerts];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n0 = P.counts[0], n1 = P.counts[1];
+    const float Wf = (float)P.W, Hf = (float)P.H;
+    for (uint32_t job = blockIdx.x * kVisWaves + wave; job < n0 + n1; job += gridDim.x * kVisWaves) {
+        const uint32_t list = job >= n0 ? 1u : 0u;
+        const incr_draw_cmd cmd = P.lists[list][list ? job - n0 : job];
+        const incr_gpu_meshlet m = P.S.meshlets[cmd.id];
+        const float* __restrict__ l2w = P.S.meshLocalToWorld + (size_t)m.meshIndex * 16;
+        const uint32_t nv = min(m.vertexCount, (uint32_t)kMaxMeshletVerts);
+        for (uint32_t v = lane; v < nv; v += 64) {                 // vs_meshlet_main:86-88
+            const float4 pos = P.S.mvPos[m.vertexBegin + v];
+            const f4 worldPos = mul_vec4({pos.x, pos.y, pos.z, 1.f}, l2w);
+            const f4 c = mul_vec4(worldPos, P.viewProj);
+            s_clip[wave][v] = make_float4(c.x, c.y, c.z, c.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const incr_material& mat = P.S.materials[m.materialIndex];
+        int32_t alphaTex = mat.baseColorTextureIndex;
+        if (alphaTex >= 0 && P.S.textures[alphaTex].pad[0]) alphaTex = -1;      // alpha is 255 everywhere: the clip can never fire
+        const uint32_t ntri = cmd.vertex_count / 3u;
+        for (uint32_t t0 = 0; t0 < ntri; t0 += 64) {
+            const uint32_t tri = t0 + lane;
+            ClipVert poly[4]; int np = 0;
+            SubTri st; st.alphaTex = alphaTex;
+            if (tri < ntri) {
+                const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
+                uint32_t li[3];
+#pragma unroll
+                for (uint32_t k = 0; k < 3; ++k) li[k] = min(0xffu & (packed >> ((2u - k) * 10u)), nv - 1u);
+                const float4 c0 = s_clip[wave][li[0]], c1 = s_clip[wave][li[1]], c2 = s_clip[wave][li[2]];
+                st.p0 = {c0.x, c0.y, c0.z, c0.w}; st.p1 = {c1.x, c1.y, c1.z, c1.w}; st.p2 = {c2.x, c2.y, c2.z, c2.w};
+                if (alphaTex >= 0) {
+                    const float2 a = P.S.mvUv[m.vertexBegin + li[0]], b = P.S.mvUv[m.vertexBegin + li[1]], c = P.S.mvUv[m.vertexBegin + li[2]];
+                    st.uv0 = {a.x, a.y}; st.uv1 = {b.x, b.y}; st.uv2 = {c.x, c.y};
+                } else { st.uv0 = st.uv1 = st.uv2 = {0.f, 0.f}; }
+                st.key = (list << 31) | ((cmd.id << 7) | tri);
+                const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
+                bool in[3]; int nin = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k] ? 1 : 0; }
+                if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+                else if (nin > 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int j = (k + 1) % 3;
+                        if (in[k]) poly[np++] = cv[k];
+                        if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
+                    }
+                }
+            }
+            ScreenVert sv[4]; bool ok = np >= 3;
+            for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], Wf, Hf, &sv[k]);
+            for (int s = 0; s < 2; ++s) {                        // wave-uniform loop: a clipped triangle is a fan of two
+                bool have = ok && (s == 0 || np == 4);
+                if (have) have = setup_subtri(sv[0], sv[s + 1], sv[s + 2], list == 0, P.W, P.H, &st);
+                const bool big = have && (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kBigBoxPixels;
+                if (have && !big) raster_serial(P, st);
+                unsigned long long mask = __ballot(big);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    const SubTri b = shfl_subtri(st, src);
+                    raster_coop(P, b, lane);
+                    mask &= mask - 1;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                         // s_clip[wave] is rewritten by the next job
+    }
+}
+// packed depth|key -> R32_UINT visibility + D32 depth (clears: 0xFFFFF000 and 0, visibility-pass.inl:68-74)
+__global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long long* __restrict__ packed, uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long v = packed[i];
+        if (v == 0) { vis[i] = 0xFFFFF000u; depth[i] = 0.f; }
+        else { vis[i] = ((uint32_t)v - 1u) & 0x7fffffffu; depth[i] = __uint_as_float((uint32_t)(v >> 32)); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- G-buffer
+// gbuffer-compute.hlsl:157-253 (USING_MESHLETS); 16x16 thread groups there, 64x4 pixel blocks here (one wave = one row run)
+__global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    const size_t i = (size_t)y * P.W + x;
+    const uint32_t v = P.vis[i];
+    if (v == 0xFFFFF000u) { P.g0[i] = 0; P.g1[i] = 0; P.g2[i] = 0; P.color[i] = 0; return; }
+    const uint32_t meshletId = v >> 7, tri = v & 127u;
+    const incr_gpu_meshlet m = P.S.meshlets[meshletId];
+    const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
+    const MeshFrame& mf = P.frames[m.meshIndex];
+    f4 p[3]; f2 uv[3]; f3 nrm[3]; f3 tan[3]; float tanW0 = 0.f;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t vi = m.vertexBegin + (0xffu & (packed >> ((2u - k) * 10u)));
+        const float4 pos = P.S.mvPos[vi];
+        p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, mf.localToClip);
+        const float2 t = P.S.mvUv[vi]; uv[k] = {t.x, t.y};
+        const float4 n = P.S.mvNormal[vi]; nrm[k] = {n.x, n.y, n.z};
+        const float4 tg = P.S.mvTangent[vi]; tan[k] = {tg.x, tg.y, tg.z};
+        if (k == 0) tanW0 = tg.w;
+    }
+    const f3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
+    f3 N = normalize(interp3(nrm[0], nrm[1], nrm[2], lam));
+    const f3 T = normalize(interp3(tan[0], tan[1], tan[2], lam));
+    const f3 B = normalize(cross(N, T) * tanW0);
+    const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
+    const MatProps mi = EvaluateMaterialProperties(P.S.materials[m.materialIndex], P.S.textures, P.S.srgbLut, UV);
+    if (mi.bHasNormalmap) {
+        const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)m.meshIndex * 16;
+        const f3 l0 = {L[0], L[1], L[2]}, l1 = {L[4], L[5], L[6]}, l2 = {L[8], L[9], L[10]};
+        const f3 r0 = mul_vec3_m3(T, l0, l1, l2), r1 = mul_vec3_m3(B, l0, l1, l2), r2 = mul_vec3_m3(N, l0, l1, l2);
+        N = normalize(mul_vec3_m3(mi.normalmap, r0, r1, r2));
+    }
+    P.color[i] = pack_r11g11b10(mi.emissive * 20000.f, P.rounding);
+    P.g0[i] = pack_unorm8x4({mi.basecolor.x, mi.basecolor.y, mi.basecolor.z, 0.f});
+    const f2 oct = OctEncode(N);
+    P.g1[i] = f32_to_f16_bits(oct.x, P.rounding) | (f32_to_f16_bits(oct.y, P.rounding) << 16);
+    P.g2[i] = pack_unorm8x4({mi.metallic, mi.roughness, mi.ao, mi.aoblend});
+}
+
+// ---------------------------------------------------------------------------------------------- deferred lighting
+struct GBufferPixel { f3 basecolor, N; float metallic, roughness, ao, aoBlend; };
+DI GBufferPixel read_gbuffer(const LightingParams& P, size_t i) {
+    GBufferPixel g;
+    const f4 b = unpack_unorm8x4(P.g0[i]);
+    g.basecolor = P.lightingOnly ? mk3(0.5f) : mk3(b.x, b.y, b.z);
+    const uint32_t n = P.g1[i];
+    g.N = OctDecode({f16_bits_to_f32(n & 0xffffu), f16_bits_to_f32(n >> 16)});
+    const f4 m = unpack_unorm8x4(P.g2[i]);
+    g.metallic = m.x; g.roughness = m.y; g.ao = m.z; g.aoBlend = m.w;
+    return g;
+}
+DI f2 screen_pos(uint32_t x, uint32_t y, uint32_t W, uint32_t H) { return {2.f * ((float)x / (float)W) - 1.f, 2.f * ((float)y / (float)H) - 1.f}; }
+DI void add_color(const LightingParams& P, size_t i, f3 radiance) { P.color[i] = pack_r11g11b10(unpack_r11g11b10(P.color[i]) + radiance, P.rounding); }
+DI void load_global_light(const PtParams& S, uint32_t index, incr_light& light, const float*& m, bool& haveT) {     // D3D robust access: OOB reads 0
+    light = {};
+    if (index < S.numGlobalLights) light = S.globalLights[index];
+    haveT = index < S.numSceneLights;
+    m = S.lightTransforms + (haveT ? (size_t)index * 16 : 0);
+}
+
+// sky-lighting.hlsl:36-119 with g_envmapIndex == -1
+DI f3 ShIrradiance(f3 n, const float4* __restrict__ sh) {                   // spherical-harmonics/common.hlsli:56-126
+    const float K[9] = {0.282095f, 0.488603f, 0.488603f, 0.488603f, 1.092548f, 1.092548f, 0.315392f, 1.092548f, 0.546274f};
+    const float A[3] = {3.14159265f, 2.094395f, 0.785398f};
+    float v[9];
+    v[0] = K[0];
+    v[1] = K[1] * n.y; v[2] = K[2] * n.z; v[3] = K[3] * n.x;
+    v[4] = (K[4] * n.x) * n.y; v[5] = (K[5] * n.y) * n.z; v[6] = K[6] * ((3.0f * n.z) * n.z - 1.0f); v[7] = (K[7] * n.x) * n.z; v[8] = K[8] * (n.x * n.x - n.y * n.y);
+    float c[9];
+    c[0] = v[0] * A[0]; c[1] = v[1] * A[1]; c[2] = v[2] * A[1]; c[3] = v[3] * A[1];
+#pragma unroll
+    for (int i = 4; i < 9; ++i) c[i] = v[i] * A[2];
+    f3 irr = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const float4 s = sh[i]; irr = irr + mk3(s.x, s.y, s.z) * c[i]; }
+    return irr;
+}
+__global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.H) return;
+    const size_t i = (size_t)y * P.L.W + x;
+    const GBufferPixel g = read_gbuffer(P.L, i);
+    f3 radiance = {0.f, 0.f, 0.f};
+    if (P.diffuseIbl && P.sh9) {
+        const f3 albedo = (1.f - g.metallic) * g.basecolor;
+        const f3 shDiffuse = ((albedo * K_INV_PI) * ShIrradiance(g.N, P.sh9)) * 5.f;
+        const f3 occluded = g.ao * shDiffuse;
+        radiance = radiance + P.skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));
+    }
+    const float hbao = P.ao ? (float)P.ao[i] / 255.f : 1.f;
+    add_color(P.L, i, hbao * radiance);
+}
+
+// direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115)
+__global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectParams P) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = blockIdx.y * 4 + (tid >> 6);
+    uint32_t rays = 0;
+    if (x < P.L.W && y < P.L.H) {
+        LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
+        const size_t i = (size_t)y * P.L.W + x;
+        const GBufferPixel g = read_gbuffer(P.L, i);
+        const f2 sp = screen_pos(x, y, P.L.W, P.L.H);
+        const f4 w = mul_vec4({sp.x, -sp.y, P.L.depth[i], 1.f}, P.L.invViewProj);
+        const f3 worldPos = {w.x / w.w, w.y / w.w, w.z / w.w};
+        const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
+        const f3 V = normalize(eye - worldPos);
+        incr_light light; const float* m; bool haveT;
+        load_global_light(P.S, P.sunIndex, light, m, haveT);
+        const LightSample s = light_setup(light, m, haveT, worldPos, g.N);
+        f3 radiance = {0.f, 0.f, 0.f};
+        if (s.needsShadow) {
+            bool lit = true;
+            if (light.type == INCR_LIGHT_DIRECTIONAL) { ++rays; lit = !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f); }
+            if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
+        }
+        add_color(P.L, i, radiance);
+    }
+    if (P.S.stats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.S.stats->light_shadow_rays, (unsigned long long)rays);
+    }
+}
+
+// clustered-lighting.hlsl:35-115 + cluster-culling.hlsli:26-41
+__global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.H) return;
+    const size_t i = (size_t)y * P.L.W + x;
+    if (P.requiresClear) P.L.color[i] = 0;
+    const GBufferPixel g = read_gbuffer(P.L, i);
+    f2 sp = screen_pos(x, y, P.L.W, P.L.H); sp.y = -sp.y;
+    const float depth = P.L.depth[i];
+    const f4 wp = mul_vec4({sp.x, sp.y, depth, 1.f}, P.L.invViewProj);
+    const f3 worldPos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+    const f4 vp = mul_vec4({sp.x, sp.y, depth, 1.f}, P.L.invProj);
+    const float viewZ = vp.z / vp.w;
+    const float gridResX = (float)P.L.W / (float)P.dim[0], gridResY = (float)P.L.H / (float)P.dim[1];
+    const uint32_t cx = ftou((float)x / gridResX), cy = ftou((float)y / gridResY);
+    const uint32_t cz = ftou(floorf(logf(viewZ) * P.scale + P.bias));
+    const uint32_t clusterId = ftou(((float)(P.dim[0] * P.dim[1]) * (float)cz + (float)P.dim[0] * (float)cy) + (float)cx);
+    const uint32_t numClusters = P.dim[0] * P.dim[1] * P.dim[2];
+    const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
+    const f3 V = normalize(eye - worldPos);
+    f3 radiance = {0.f, 0.f, 0.f};
+    incr_light_grid_data ci = {0u, 0u};
+    if (clusterId < numClusters) ci = P.grid[clusterId];
+    for (uint32_t k = 0; k < ci.count; ++k) {
+        const uint32_t lightIndex = P.lists[ci.offset + k];
+        incr_light light; const float* m; bool haveT;
+        load_global_light(P.S, lightIndex, light, m, haveT);
+        if (light.range == 0) light.range = 4.f;                            // MAX_LIGHT_RANGE
+        const LightSample s = light_setup(light, m, haveT, worldPos, g.N);
+        // clustered lights are punctual: GetDirectRadiance traces shadows for directional lights only outside PATH_TRACING
+        if (s.needsShadow) radiance = radiance + light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
+        else radiance = radiance + mk3(0.f);
+    }
+    add_color(P.L, i, radiance);
+}
+
+// ---------------------------------------------------------------------------------------------- TAA resolve
+DI f3 load_hdr(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {
+    if (x >= W || y >= H) return {0.f, 0.f, 0.f};
+    return unpack_r11g11b10(img[(size_t)y * W + x]);
+}
+DI int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
+DI f3 sample_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, f2 uv) {
+    float u = uv.x, v = uv.y;
+    if (!(u == u)) u = 0.f;
+    if (!(v == v)) v = 0.f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = fminf(fmaxf(x, -1.f), (float)W); y = fminf(fmaxf(y, -1.f), (float)H);
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const int x0 = clampi((int)x0f, (int)W), x1 = clampi((int)x0f + 1, (int)W), y0 = clampi((int)y0f, (int)H), y1 = clampi((int)y0f + 1, (int)H);
+    const f3 t00 = load_hdr(img, W, H, x0, y0), t10 = load_hdr(img, W, H, x1, y0), t01 = load_hdr(img, W, H, x0, y1), t11 = load_hdr(img, W, H, x1, y1);
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
+}
+DI float lum_weight(f3 c) { return 1.f / (1.f + ((c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f)); }
+// taa-resolve.hlsl:34-117
+__global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    const size_t i = (size_t)y * P.W + x;
+    const f3 cur = unpack_r11g11b10(P.hdr[i]);
+    if (P.historyIndex == 0) { P.histOut[i] = pack_r11g11b10(cur, P.rounding); return; }
+    const f2 uv = {((float)x + 0.5f) / (float)P.W, ((float)y + 0.5f) / (float)P.H};
+    const f4 clip = {2.f * uv.x - 1.f, -2.f * uv.y + 1.f, P.depth[i], 1.f};
+    const f4 world = mul_vec4(clip, P.invViewProj);
+    const f4 pc = mul_vec4(world, P.prevViewProj);
+    const f2 ruv = {0.5f * (pc.x / pc.w) + 0.5f, -0.5f * (pc.y / pc.w) + 0.5f};
+    const f3 previous = sample_bilinear_clamp(P.histIn, P.W, P.H, ruv);
+    f3 mn = mk3(10000.f), mx = mk3(-10000.f);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const f3 c = load_hdr(P.hdr, P.W, P.H, ftou((float)x + (float)dx), ftou((float)y + (float)dy));
+            mn = {hmin(mn.x, c.x), hmin(mn.y, c.y), hmin(mn.z, c.z)};
+            mx = {hmax(mx.x, c.x), hmax(mx.y, c.y), hmax(mx.z, c.z)};
+        }
+    const f3 clamped = {hmin(hmax(previous.x, mn.x), mx.x), hmin(hmax(previous.y, mn.y), mx.y), hmin(hmax(previous.z, mn.z), mx.z)};
+    const float cw = 0.1f * lum_weight(cur), pw = 0.9f * lum_weight(clamped);
+    f3 out = cur * cw + clamped * pw;
+    out = out / (cw + pw);
+    P.histOut[i] = pack_r11g11b10(out, P.rounding);
+}
+
+} // namespace incr
+
+// ---- launchers (called from raster_api.hip) ------------------------------------------------------------
+using namespace incr;
+static inline dim3 pixel_grid(uint32_t W, uint32_t H) { return dim3((W + 63) / 64, (H + 3) / 4); }
+
+extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFrame* vf, MeshFrame* out, hipStream_t stream) {
+    if (!S->numMeshes) return hipSuccess;
+    hipLaunchKernelGGL(mesh_frame_kernel, dim3((S->numMeshes + 63) / 64), dim3(64), 0, stream, *S, *vf, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_batch_cull(const RasterScene* S, const MeshFrame* frames, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
+                                             uint32_t* counts, incr_render_stats* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(batch_cull_kernel, dim3(1), dim3(1024), 0, stream, *S, frames, frustumCulling, defList, dsList, counts, stats);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_light_cull(const LightCullParams* p, hipStream_t stream) {
+    const uint32_t n = p->dim[0] * p->dim[1] * p->dim[2];
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(light_cull_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJobs, int numCUs, uint32_t* vis, float* depth, hipStream_t stream) {
+    const size_t n = (size_t)p->W * p->H;
+    if (!n) return hipSuccess;
+    hipError_t e = hipMemsetAsync(p->packed, 0, n * 8, stream);
+    if (e != hipSuccess) return e;
+    if (maxJobs) {
+        const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
+        hipLaunchKernelGGL(vis_raster_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(vis_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p->packed, vis, depth, n);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t stream) {
+    if (!p->W || !p->H) return hipSuccess;
+    hipLaunchKernelGGL(gbuffer_kernel, pixel_grid(p->W, p->H), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream) {
+    if (!p->L.W || !p->L.H) return hipSuccess;
+    hipLaunchKernelGGL(sky_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {
+    if (!p->L.W || !p->L.H) return hipSuccess;
+    hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {
+    if (!p->L.W || !p->L.H) return hipSuccess;
+    hipLaunchKernelGGL(clustered_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream) {
+    if (!p->W || !p->H) return hipSuccess;
+    hipLaunchKernelGGL(taa_resolve_kernel, pixel_grid(p->W, p->H), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}

@@ -1,0 +1,307 @@
+// raster_api.hip -- C ABI entry points of the raster path (include/incr.h "Raster path"): argument checks, kernel
+// argument blocks, launches.  Host code only; the kernels are in raster.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "api_internal.h"
+
+using namespace incr;
+
+extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFrame* vf, MeshFrame* out, hipStream_t stream);
+extern "C" hipError_t incr_launch_batch_cull(const RasterScene* S, const MeshFrame* frames, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
+                                             uint32_t* counts, incr_render_stats* stats, hipStream_t stream);
+extern "C" hipError_t incr_launch_light_cull(const LightCullParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJobs, int numCUs, uint32_t* vis, float* depth, hipStream_t stream);
+extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------- scene data
+namespace {
+
+// MeshMaterial::GetFloat{2,3,4} (shaders/common/mesh-material.hlsli:92-170): stride-checked typed fetch, 0 when absent
+const uint8_t* accessor_base(const HostScene& s, int accessorIndex, uint32_t* stride, size_t* avail) {
+    if (accessorIndex < 0 || (size_t)accessorIndex >= s.accessors.size()) return nullptr;
+    const incr_mesh_accessor& a = s.accessors[accessorIndex];
+    if (a.bufferViewIndex < 0 || (size_t)a.bufferViewIndex >= s.bufferViews.size()) return nullptr;
+    const incr_mesh_buffer_view& v = s.bufferViews[a.bufferViewIndex];
+    if (v.bufferSrvIndex < 0 || (size_t)v.bufferSrvIndex >= s.buffers.size()) return nullptr;
+    const std::vector<uint8_t>& b = s.buffers[v.bufferSrvIndex];
+    const size_t off = (size_t)a.byteOffset + v.byteOffset;
+    if (off > b.size()) return nullptr;
+    *stride = a.byteStride; *avail = b.size() - off;
+    return b.data() + off;
+}
+void fetch(const HostScene& s, int accessorIndex, uint32_t index, int ncomp, float* out) {
+    for (int i = 0; i < 4; ++i) out[i] = 0.f;
+    uint32_t stride = 0; size_t avail = 0;
+    const uint8_t* base = accessor_base(s, accessorIndex, &stride, &avail);
+    if (!base) return;
+    bool ok = false;
+    if (ncomp == 4) ok = stride == 16;
+    else if (ncomp == 3) ok = stride == 12 || stride == 16;
+    else ok = stride == 8 || stride == 12 || stride == 16;
+    if (!ok || (size_t)index * stride + (size_t)ncomp * 4 > avail) return;
+    memcpy(out, base + (size_t)index * stride, (size_t)ncomp * 4);
+}
+
+} // namespace
+
+int incr_raster_scene_upload(incr_scene* sc) {
+    const HostScene& h = sc->host;
+    const size_t nm = h.meshlets.size(), nv = h.meshletVertexIndices.size(), nt = h.meshletPackedTriangles.size();
+    for (size_t i = 0; i < nm; ++i) {
+        const incr_gpu_meshlet& m = h.meshlets[i];
+        if ((size_t)m.vertexBegin + m.vertexCount > nv || (size_t)m.triangleBegin + m.triangleCount > nt)
+            return fail(INCR_ERR_INVALID_ARGUMENT, "meshlet %zu: vertex/triangle range outside the packed buffers", i);
+        if (m.vertexCount > 256 || m.triangleCount > 128 || (m.triangleCount && !m.vertexCount))
+            return fail(INCR_ERR_INVALID_ARGUMENT, "meshlet %zu: %u vertices / %u triangles exceed the 8-bit vertex and 7-bit triangle ids of the visibility buffer", i, m.vertexCount, m.triangleCount);
+        if (m.meshIndex < 0 || (size_t)m.meshIndex >= h.meshTransforms.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "meshlet %zu: meshIndex out of range", i);
+        if (m.materialIndex < 0 || (size_t)m.materialIndex >= h.materials.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "meshlet %zu: materialIndex out of range", i);
+        for (uint32_t t = 0; t < m.triangleCount; ++t) {
+            const uint32_t p = h.meshletPackedTriangles[m.triangleBegin + t];
+            for (int k = 0; k < 3; ++k) if ((0xffu & (p >> (k * 10))) >= m.vertexCount) return fail(INCR_ERR_INVALID_ARGUMENT, "meshlet %zu triangle %u: local vertex index out of range", i, t);
+        }
+    }
+    if (nm >= (1u << 24)) return fail(INCR_ERR_INVALID_ARGUMENT, "more than 2^24 meshlets do not fit the visibility pass's order key");
+    // resolve the accessor indirection once: per packed meshlet vertex, the attributes the shaders fetch
+    std::vector<float4> pos(nv), nrm(nv), tan(nv); std::vector<float2> uv(nv);
+    std::vector<uint8_t> seen(nv, 0);
+    for (size_t i = 0; i < nm; ++i) {
+        const incr_gpu_meshlet& m = h.meshlets[i];
+        for (uint32_t v = 0; v < m.vertexCount; ++v) {
+            const size_t slot = (size_t)m.vertexBegin + v;
+            const uint32_t index = h.meshletVertexIndices[slot];
+            float f[4];
+            fetch(h, m.positionAccessor, index, 3, f); pos[slot] = make_float4(f[0], f[1], f[2], 0.f);
+            fetch(h, m.uvAccessor, index, 2, f); uv[slot] = make_float2(f[0], f[1]);
+            fetch(h, m.normalAccessor, index, 3, f); nrm[slot] = make_float4(f[0], f[1], f[2], 0.f);
+            fetch(h, m.tangentAccessor, index, 4, f); tan[slot] = make_float4(f[0], f[1], f[2], f[3]);
+            seen[slot] = 1;
+        }
+    }
+    int rc = upload_vec(&sc->dMeshlets, h.meshlets.data(), nm);
+    if (!rc) rc = upload_vec(&sc->dPackedTris, h.meshletPackedTriangles.data(), nt);
+    if (!rc) rc = upload_vec(&sc->dMeshVisibility, h.meshVisibility.data(), h.meshVisibility.size());
+    if (!rc) rc = upload_vec(&sc->dMvPos, pos.data(), nv);
+    if (!rc) rc = upload_vec(&sc->dMvUv, uv.data(), nv);
+    if (!rc) rc = upload_vec(&sc->dMvNormal, nrm.data(), nv);
+    if (!rc) rc = upload_vec(&sc->dMvTangent, tan.data(), nv);
+    return rc;
+}
+void incr_raster_scene_free(incr_scene* sc) {
+    void* ptrs[] = {sc->dMeshlets, sc->dPackedTris, sc->dMeshVisibility, sc->dMvPos, sc->dMvUv, sc->dMvNormal, sc->dMvTangent};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------------------------------------- helpers
+namespace {
+
+void fill_raster_scene(const incr_context* ctx, const incr_scene* sc, RasterScene& S) {
+    memset(&S, 0, sizeof S);
+    S.meshlets = sc->dMeshlets; S.packedTris = sc->dPackedTris; S.meshVisibility = sc->dMeshVisibility;
+    S.mvPos = sc->dMvPos; S.mvUv = sc->dMvUv; S.mvNormal = sc->dMvNormal; S.mvTangent = sc->dMvTangent;
+    S.meshLocalToWorld = sc->dMeshLocalToWorld; S.materials = sc->dMaterials; S.textures = sc->dTextures; S.srgbLut = ctx->srgbLut;
+    S.numMeshlets = (uint32_t)sc->host.meshlets.size(); S.numMeshes = (uint32_t)sc->host.meshTransforms.size();
+}
+void fill_view_frame(const incr_view_constants& vc, ViewFrame& vf) {
+    memcpy(vf.viewProj, vc.view_proj_transform.m, 64); memcpy(vf.cullViewProj, vc.cull_view_proj_transform.m, 64);
+    memcpy(vf.invViewProj, vc.inv_view_proj_transform.m, 64); memcpy(vf.invProj, vc.inv_proj_transform.m, 64);
+    memcpy(vf.eye, vc.eye_pos, 12); vf.nearPlane = vc.near_plane; vf.W = vc.res_x; vf.H = vc.res_y;
+}
+// workspace: [packed depth|key surface][per-mesh frame constants]
+int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, hipStream_t stream, unsigned long long** packed, MeshFrame** frames) {
+    const size_t a = (pixels * 8 + 255) & ~(size_t)255, b = (meshes + 1) * sizeof(MeshFrame);
+    const size_t need = a + b;
+    if (ctx->rasterBytes < need || !ctx->rasterBlock) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (ctx->rasterBlock) { HIP_TRY(hipFree(ctx->rasterBlock)); ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; }
+        HIP_TRY(hipMalloc(&ctx->rasterBlock, need));
+        ctx->rasterBytes = need;
+    }
+    // frames live at the END of the block so that a later call with fewer pixels still finds them valid
+    *packed = (unsigned long long*)ctx->rasterBlock;
+    *frames = (MeshFrame*)((uint8_t*)ctx->rasterBlock + ctx->rasterBytes - b);
+    return INCR_OK;
+}
+int check_view(const incr_view_constants* v) {
+    if (!v) return fail(INCR_ERR_INVALID_ARGUMENT, "view constants are NULL");
+    if (!v->res_x || !v->res_y) return fail(INCR_ERR_INVALID_ARGUMENT, "zero resolution");
+    if ((uint64_t)v->res_x * v->res_y > 0x7fffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "resolution too large");
+    return INCR_OK;
+}
+int fill_lighting(const incr_lighting_inputs& in, LightingParams& L) {
+    int rc = check_view(in.view);
+    if (rc) return rc;
+    if (!in.scene) return fail(INCR_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!in.color_target || !in.depth_buffer || !in.gbuffer_basecolor || !in.gbuffer_normals || !in.gbuffer_metallic_roughness_ao)
+        return fail(INCR_ERR_INVALID_ARGUMENT, "a lighting input surface is NULL");
+    memset(&L, 0, sizeof L);
+    L.W = in.view->res_x; L.H = in.view->res_y;
+    L.color = in.color_target; L.depth = in.depth_buffer; L.g0 = in.gbuffer_basecolor; L.g1 = in.gbuffer_normals; L.g2 = in.gbuffer_metallic_roughness_ao;
+    L.lightingOnly = in.lighting_only; L.rounding = in.storage_rounding;
+    memcpy(L.invViewProj, in.view->inv_view_proj_transform.m, 64); memcpy(L.invProj, in.view->inv_proj_transform.m, 64);
+    memcpy(L.eye, in.view->eye_pos, 12);
+    return INCR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------- batch culling
+int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->default_list || !d->double_sided_list || !d->counts) return fail(INCR_ERR_INVALID_ARGUMENT, "an output list is NULL");
+    const incr_scene* sc = d->scene;
+    RasterScene S; fill_raster_scene(ctx, sc, S);
+    ViewFrame vf; fill_view_frame(*d->view, vf);
+    unsigned long long* packed; MeshFrame* frames;
+    if ((rc = ensure_raster_workspace(ctx, 0, S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
+    HIP_TRY(incr_launch_mesh_frames(&S, &vf, frames, (hipStream_t)stream));
+    HIP_TRY(incr_launch_batch_cull(&S, frames, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, d->render_stats, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- light culling
+int incr_light_cull(incr_context* ctx, const incr_light_cull_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->culled_light_lists || !d->light_grid || !d->culled_light_count) return fail(INCR_ERR_INVALID_ARGUMENT, "an output buffer is NULL");
+    if (!d->cluster_dim[0] || !d->cluster_dim[1] || !d->cluster_dim[2] || d->cluster_dim[2] > kMaxClusterSlices)
+        return fail(INCR_ERR_INVALID_ARGUMENT, "cluster grid %ux%ux%u unsupported (each >= 1, Z <= %u)", d->cluster_dim[0], d->cluster_dim[1], d->cluster_dim[2], kMaxClusterSlices);
+    if (!d->max_lights_per_cluster || d->max_lights_per_cluster > kMaxLightsPerClusterCap) return fail(INCR_ERR_INVALID_ARGUMENT, "max_lights_per_cluster must be 1..%u", kMaxLightsPerClusterCap);
+    if (!(d->view->near_plane > 0.f) || !(d->cluster_depth_extent > d->view->near_plane)) return fail(INCR_ERR_INVALID_ARGUMENT, "cluster depth extent must exceed the near plane");
+    const incr_scene* sc = d->scene;
+    LightCullParams P; memset(&P, 0, sizeof P);
+    P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
+    P.numSceneLights = (uint32_t)sc->host.lightIndices.size(); P.numGlobalLights = (uint32_t)sc->host.globalLights.size();
+    for (int a = 0; a < 3; ++a) P.dim[a] = d->cluster_dim[a];
+    P.maxLights = d->max_lights_per_cluster;
+    // cluster-culling.hlsli:57-60: zNear * pow(zFar / zNear, k / dimZ) -- powf once per slice on the host
+    const float zNear = d->view->near_plane, zFar = d->cluster_depth_extent;
+    for (uint32_t k = 0; k <= P.dim[2]; ++k) P.slice[k] = zNear * powf(zFar / zNear, (float)k / (float)P.dim[2]);
+    memcpy(P.proj, d->view->lightcull_proj_transform.m, 64); memcpy(P.invViewProj, d->view->lightcull_inv_view_proj.m, 64);
+    P.lists = d->culled_light_lists; P.grid = d->light_grid; P.totalCount = d->culled_light_count; P.stats = d->render_stats;
+    // light-culling.inl:115-127 clears the count (and the lists); renderStatsBuffer.Store(sizeof(int), 0)
+    HIP_TRY(hipMemsetAsync(d->culled_light_count, 0, 4, (hipStream_t)stream));
+    if (d->render_stats) HIP_TRY(hipMemsetAsync(&d->render_stats->culledLights, 0, 4, (hipStream_t)stream));
+    HIP_TRY(incr_launch_light_cull(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- visibility
+int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->default_list || !d->double_sided_list || !d->counts || !d->vis_buffer || !d->depth_buffer) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL buffer");
+    const incr_scene* sc = d->scene;
+    VisParams P; memset(&P, 0, sizeof P);
+    fill_raster_scene(ctx, sc, P.S);
+    memcpy(P.viewProj, d->view->view_proj_transform.m, 64);
+    P.W = d->view->res_x; P.H = d->view->res_y;
+    P.lists[0] = d->default_list; P.lists[1] = d->double_sided_list; P.counts = d->counts;
+    unsigned long long* packed; MeshFrame* frames;
+    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
+    P.packed = packed;
+    HIP_TRY(incr_launch_visibility(&P, P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- G-buffer
+int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->vis_buffer || !d->gbuffer_basecolor || !d->gbuffer_normals || !d->gbuffer_metallic_roughness_ao || !d->color_target) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    const incr_scene* sc = d->scene;
+    GBufferParams P; memset(&P, 0, sizeof P);
+    fill_raster_scene(ctx, sc, P.S);
+    ViewFrame vf; fill_view_frame(*d->view, vf);
+    unsigned long long* packed; MeshFrame* frames;
+    if ((rc = ensure_raster_workspace(ctx, 0, P.S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
+    HIP_TRY(incr_launch_mesh_frames(&P.S, &vf, frames, (hipStream_t)stream));
+    P.frames = frames; P.W = d->view->res_x; P.H = d->view->res_y; P.vis = d->vis_buffer;
+    P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao; P.color = d->color_target;
+    P.rounding = d->storage_rounding;
+    HIP_TRY(incr_launch_gbuffer(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- lighting
+int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    SkyParams P; memset(&P, 0, sizeof P);
+    int rc = fill_lighting(d->in, P.L);
+    if (rc) return rc;
+    P.sh9 = (const float4*)d->sh9_rgba; P.ao = d->ambient_occlusion; P.skyBrightness = d->sky_brightness; P.diffuseIbl = d->diffuse_ibl;
+    HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    DirectParams P; memset(&P, 0, sizeof P);
+    int rc = fill_lighting(d->in, P.L);
+    if (rc) return rc;
+    if (d->directional_light_index < 0) return fail(INCR_ERR_INVALID_ARGUMENT, "directional_light_index is negative: the reference skips this pass when the scene has no sun (renderer.cpp:1886)");
+    incr_fill_scene_params(ctx, d->in.scene, P.S);
+    P.S.stats = d->ray_stats;
+    P.sunIndex = (uint32_t)d->directional_light_index;
+    HIP_TRY(incr_launch_direct_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    ClusteredParams P; memset(&P, 0, sizeof P);
+    int rc = fill_lighting(d->in, P.L);
+    if (rc) return rc;
+    if (!d->culled_light_lists || !d->light_grid) return fail(INCR_ERR_INVALID_ARGUMENT, "light lists / grid are NULL");
+    if (!d->cluster_dim[0] || !d->cluster_dim[1] || !d->cluster_dim[2]) return fail(INCR_ERR_INVALID_ARGUMENT, "zero cluster dimension");
+    const float nearPlane = d->in.view->near_plane;
+    if (!(nearPlane > 0.f) || !(d->cluster_depth_extent > nearPlane)) return fail(INCR_ERR_INVALID_ARGUMENT, "cluster depth extent must exceed the near plane");
+    incr_fill_scene_params(ctx, d->in.scene, P.S);
+    P.lists = d->culled_light_lists; P.grid = d->light_grid;
+    for (int a = 0; a < 3; ++a) P.dim[a] = d->cluster_dim[a];
+    P.scale = (float)d->cluster_dim[2] / logf(d->cluster_depth_extent / nearPlane);          // clustered-lighting.inl:88
+    P.bias = -P.scale * logf(nearPlane);                                                      // :102
+    P.requiresClear = d->requires_clear;
+    HIP_TRY(incr_launch_clustered_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- TAA
+int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->hdr_scene_color || !d->history_out || !d->depth_buffer) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    if (d->history_index != 0 && !d->history_in) return fail(INCR_ERR_INVALID_ARGUMENT, "history_in is NULL with history_index != 0");
+    if (d->history_in == d->history_out) return fail(INCR_ERR_INVALID_ARGUMENT, "history_in and history_out must not alias");
+    TaaParams P; memset(&P, 0, sizeof P);
+    P.W = d->view->res_x; P.H = d->view->res_y; P.historyIndex = d->history_index; P.rounding = d->storage_rounding;
+    P.hdr = d->hdr_scene_color; P.histIn = d->history_in; P.histOut = d->history_out; P.depth = d->depth_buffer;
+    memcpy(P.invViewProj, d->view->taa_inv_view_proj.m, 64); memcpy(P.prevViewProj, d->view->prev_view_proj_transform.m, 64);
+    HIP_TRY(incr_launch_taa_resolve(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,107 @@
+// raster_params.h -- kernel argument blocks of the raster path (raster.hip; filled in raster_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/incr.h"
+#include "device_types.h"
+#include "pt_params.h"
+
+namespace incr {
+
+// Device view of the scene for the raster passes.  The accessor -> bufferView -> buffer indirection of
+// shaders/common/mesh-material.hlsli is resolved at scene creation: mv* arrays are indexed by the position of a
+// vertex in the packed meshlet vertex-index buffer (meshlet.vertexBegin + local index), so a visibility-buffer
+// pixel costs three 16-byte position loads instead of three dependent index/accessor/view chains.
+struct RasterScene {
+    const incr_gpu_meshlet* __restrict__ meshlets;
+    const uint32_t* __restrict__ packedTris;
+    const uint32_t* __restrict__ meshVisibility;
+    const float4* __restrict__ mvPos;         // GetFloat3(uniqueVertIndex, positionAccessor), w = 0
+    const float2* __restrict__ mvUv;          // GetFloat2(uniqueVertIndex, uvAccessor)
+    const float4* __restrict__ mvNormal;      // GetFloat3(uniqueVertIndex, normalAccessor), w = 0
+    const float4* __restrict__ mvTangent;     // GetFloat4(uniqueVertIndex, tangentAccessor)
+    const float* __restrict__ meshLocalToWorld;   // 16 floats per mesh: mul(meshTransform, sceneRotation)
+    const incr_material* __restrict__ materials;
+    const DeviceTexture* __restrict__ textures;
+    const float* __restrict__ srgbLut;
+    uint32_t numMeshlets, numMeshes;
+};
+
+// Per-mesh, per-frame constants (mesh_frame_kernel): 176 B.
+struct MeshFrame {
+    float localToClip[16];     // mul(localToWorld, viewProj)                   gbuffer-compute.hlsl:196-197
+    float planes[5][4];        // near, left, right, bottom, top in object space  batch-culling.hlsl:28-35
+    float planeLen[5];         // length(plane.xyz)
+    float pad[3];
+};
+static_assert(sizeof(MeshFrame) == 176, "MeshFrame layout");
+
+struct ViewFrame {             // the matrices a pass reads, copied out of incr_view_constants
+    float viewProj[16];
+    float cullViewProj[16];
+    float invViewProj[16];
+    float invProj[16];
+    float eye[3];
+    float nearPlane;
+    uint32_t W, H;
+};
+
+static constexpr uint32_t kMaxClusterSlices = 64;
+static constexpr uint32_t kMaxLightsPerClusterCap = 128;     // MAX_LIGHTS_PER_CLUSTER default of light-culling.hlsl:14-16
+
+// ---- kernel argument blocks (raster.hip) ----
+struct LightCullParams {
+    const incr_light* __restrict__ globalLights; const int32_t* __restrict__ lightIndices; const float* __restrict__ lightTransforms;
+    uint32_t numSceneLights, numGlobalLights;
+    uint32_t dim[3], maxLights;
+    float slice[kMaxClusterSlices + 1];     // zNear * pow(zFar / zNear, k / dimZ): powf evaluated once on the host
+    float proj[16], invViewProj[16];
+    uint32_t* __restrict__ lists; incr_light_grid_data* __restrict__ grid; uint32_t* __restrict__ totalCount; incr_render_stats* __restrict__ stats;
+};
+
+struct VisParams {
+    RasterScene S;
+    float viewProj[16];
+    uint32_t W, H;
+    const incr_draw_cmd* __restrict__ lists[2];
+    const uint32_t* __restrict__ counts;
+    unsigned long long* __restrict__ packed;         // W*H: depth bits << 32 | (order key + 1); 0 = empty
+};
+
+struct GBufferParams {
+    RasterScene S;
+    const MeshFrame* __restrict__ frames;
+    uint32_t W, H;
+    const uint32_t* __restrict__ vis;
+    uint32_t* __restrict__ g0; uint32_t* __restrict__ g1; uint32_t* __restrict__ g2; uint32_t* __restrict__ color;
+    int32_t rounding;
+};
+
+struct LightingParams {
+    uint32_t W, H;
+    uint32_t* __restrict__ color; const float* __restrict__ depth;
+    const uint32_t* __restrict__ g0; const uint32_t* __restrict__ g1; const uint32_t* __restrict__ g2;
+    int32_t lightingOnly, rounding;
+    float invViewProj[16], invProj[16];
+    float eye[3];
+};
+
+struct SkyParams { LightingParams L; const float4* __restrict__ sh9; const uint8_t* __restrict__ ao; float skyBrightness; int32_t diffuseIbl; };
+
+struct DirectParams { LightingParams L; PtParams S; uint32_t sunIndex; };
+
+struct ClusteredParams {
+    LightingParams L; PtParams S;
+    const uint32_t* __restrict__ lists; const incr_light_grid_data* __restrict__ grid;
+    uint32_t dim[3];
+    float scale, bias;
+    int32_t requiresClear;
+};
+
+struct TaaParams {
+    uint32_t W, H, historyIndex; int32_t rounding;
+    const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;
+    float invViewProj[16], prevViewProj[16];
+};
+
+} // namespace incr

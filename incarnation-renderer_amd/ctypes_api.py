@@ -142,6 +142,77 @@ class TonemapDesc(C.Structure):
                 ("exposure", C.c_float), ("viewmode", C.c_int32)]
 
 
+# ---- raster path (include/incr.h "Raster path") ----
+class ViewConstants(C.Structure):
+    _fields_ = [(n, Matrix) for n in (
+        "view_transform", "proj_transform", "view_proj_transform", "inv_view_proj_transform", "inv_proj_transform",
+        "cull_view_proj_transform", "prev_view_proj_transform", "lightcull_proj_transform", "lightcull_inv_view_proj",
+        "sky_inv_view_proj", "unjittered_view_proj", "taa_inv_view_proj")] + [
+        ("eye_pos", c_float3), ("near_plane", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("jitter", C.c_float * 2)]
+
+
+class DrawCmd(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("vertex_count", C.c_uint32)]
+
+
+class LightGridData(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("count", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("culledObjects", C.c_int32), ("culledLights", C.c_int32)]
+
+
+_VC = C.POINTER(ViewConstants)
+
+
+class BatchCullDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("default_list", C.c_void_p), ("double_sided_list", C.c_void_p),
+                ("counts", C.c_void_p), ("render_stats", C.c_void_p), ("frustum_culling", C.c_int32)]
+
+
+class LightCullDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32),
+                ("cluster_depth_extent", C.c_float), ("culled_light_lists", C.c_void_p), ("light_grid", C.c_void_p),
+                ("culled_light_count", C.c_void_p), ("render_stats", C.c_void_p)]
+
+
+class VisibilityDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("default_list", C.c_void_p), ("double_sided_list", C.c_void_p),
+                ("counts", C.c_void_p), ("vis_buffer", C.c_void_p), ("depth_buffer", C.c_void_p)]
+
+
+class GBufferDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("vis_buffer", C.c_void_p), ("gbuffer_basecolor", C.c_void_p),
+                ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p), ("color_target", C.c_void_p),
+                ("storage_rounding", C.c_int32)]
+
+
+class LightingInputs(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("color_target", C.c_void_p), ("depth_buffer", C.c_void_p),
+                ("gbuffer_basecolor", C.c_void_p), ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p),
+                ("lighting_only", C.c_int32), ("storage_rounding", C.c_int32)]
+
+
+class SkyLightingDesc(C.Structure):
+    _fields_ = [("inp", LightingInputs), ("sh9_rgba", C.c_void_p), ("ambient_occlusion", C.c_void_p),
+                ("sky_brightness", C.c_float), ("diffuse_ibl", C.c_int32)]
+
+
+class DirectLightingDesc(C.Structure):
+    _fields_ = [("inp", LightingInputs), ("directional_light_index", C.c_int32), ("ray_stats", C.c_void_p)]
+
+
+class ClusteredLightingDesc(C.Structure):
+    _fields_ = [("inp", LightingInputs), ("culled_light_lists", C.c_void_p), ("light_grid", C.c_void_p),
+                ("cluster_dim", C.c_uint32 * 3), ("cluster_depth_extent", C.c_float), ("requires_clear", C.c_int32)]
+
+
+class TaaResolveDesc(C.Structure):
+    _fields_ = [("view", _VC), ("hdr_scene_color", C.c_void_p), ("history_in", C.c_void_p), ("history_out", C.c_void_p),
+                ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32)]
+
+
 # FConfig defaults the hot path reads (reference: source/demo-dll/inc/common.h:6-48)
 class FConfig:
     Fov = 0.25 * 3.14159265358979323846

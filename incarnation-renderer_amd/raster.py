@@ -1,0 +1,263 @@
+"""Host mirror of the raster branch of Renderer::Render (reference: source/demo-dll/src/renderer.cpp:1711-2036):
+meshlet generation at load time, per-frame view constants, and the pass sequence batch cull -> light cull ->
+visibility -> g-buffer -> sky lighting -> direct lighting -> clustered lighting -> TAA resolve -> tonemap, each a
+call through the C ABI (include/incr.h).  No CPU fallback: every pass needs the HIP library and a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ctypes_api as A
+from . import runtime as rt
+
+MAX_MESHLET_VERTS = 64        # scene.cpp:1545-1546
+MAX_MESHLET_PRIMS = 126
+
+
+def generate_meshlets(scene, max_verts=MAX_MESHLET_VERTS, max_prims=MAX_MESHLET_PRIMS):
+    """FScene::GenerateMeshlets + the meshlet packing of CreateGpuGeometryBuffers (scene.cpp:1488-1558, 503-560):
+    meshletize every primitive with the host utility of the HIP library and pack mesh -> primitive -> meshlet."""
+    lib = rt.load()
+    meshlets, vert_lists, tri_lists = [], [], []
+    vbase = tbase = 0
+    for mesh_index, prims in enumerate(scene.mesh_primitives):
+        for p in prims:
+            n = p["index_count"]
+            stride = scene.accessors[p["index"]][2]
+            idx = scene.accessor_array(p["index"], np.uint16 if stride == 2 else np.uint32, 1, n).astype(np.uint32).ravel()
+            nverts = int(idx.max()) + 1 if n else 0
+            pos = np.ascontiguousarray(scene.accessor_array(p["position"], np.float32, 3, nverts))
+            idx = np.ascontiguousarray(idx)
+            handle = C.c_void_p()
+            rt.check(lib.incr_meshletize(idx.ctypes.data, n, pos.ctypes.data, nverts, 12, max_verts, max_prims, C.byref(handle)))
+            try:
+                nvi, ntri = C.c_uint32(), C.c_uint32()
+                nm = lib.incr_meshlet_set_counts(handle, C.byref(nvi), C.byref(ntri))
+                ml = (A.GpuMeshlet * max(nm, 1))()
+                vi = np.zeros(max(nvi.value, 1), dtype=np.uint32)
+                tri = np.zeros(max(ntri.value, 1), dtype=np.uint32)
+                rt.check(lib.incr_meshlet_set_copy(handle, ml, vi.ctypes.data, tri.ctypes.data))
+            finally:
+                lib.incr_meshlet_set_free(handle)
+            for k in range(nm):
+                m = ml[k]
+                m.vertexBegin += vbase
+                m.triangleBegin += tbase
+                m.meshIndex = mesh_index
+                m.positionAccessor, m.uvAccessor = p["position"], p["uv"]
+                m.normalAccessor, m.tangentAccessor = p["normal"], p["tangent"]
+                m.materialIndex = p["material"]
+                meshlets.append(m)
+            vert_lists.append(vi[:nvi.value]); tri_lists.append(tri[:ntri.value])
+            vbase += nvi.value; tbase += ntri.value
+    arr = (A.GpuMeshlet * max(len(meshlets), 1))()
+    for i, m in enumerate(meshlets):
+        C.memmove(C.byref(arr, i * C.sizeof(A.GpuMeshlet)), C.byref(m), C.sizeof(A.GpuMeshlet))
+    vi = np.concatenate(vert_lists) if vert_lists else np.zeros(0, np.uint32)
+    tri = np.concatenate(tri_lists) if tri_lists else np.zeros(0, np.uint32)
+    scene.meshlets = (arr, np.ascontiguousarray(vi, dtype=np.uint32), np.ascontiguousarray(tri, dtype=np.uint32))
+    scene.num_meshlets = len(meshlets)
+    return scene
+
+
+def pixel_jitter(frame_index, res_x, res_y):
+    out = (C.c_float * 2)()
+    rt.load().incr_pixel_jitter(frame_index, res_x, res_y, out)
+    return np.array([out[0], out[1]], dtype=np.float32)
+
+
+def make_view_constants(view, res_x, res_y, jitter=(0.0, 0.0), prev_view_proj=None, near_plane=A.FConfig.CameraNearPlane, culling_view=None):
+    vc = A.ViewConstants()
+    v = view.to_ctypes()
+    cv = culling_view.to_ctypes() if culling_view is not None else None
+    j = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
+    prev = None
+    if prev_view_proj is not None:
+        prev = A.Matrix()
+        flat = np.asarray(prev_view_proj, dtype=np.float32).ravel()
+        for i in range(16):
+            prev.m[i] = float(flat[i])
+    rt.check(rt.load().incr_make_view_constants(C.byref(v), C.byref(cv) if cv is not None else None, j,
+                                                C.byref(prev) if prev is not None else None, near_plane, res_x, res_y, C.byref(vc)))
+    return vc
+
+
+def matrix_to_numpy(m):
+    return np.array(list(m.m), dtype=np.float32).reshape(4, 4)
+
+
+def directional_light_index(scene):
+    """FScene::GetDirectionalLight (scene.cpp:1581-1591): GLOBAL index of the first directional scene light, or -1."""
+    for gi in scene.light_indices:
+        if scene.global_lights[gi].type == A.LIGHT_DIRECTIONAL:
+            return int(gi)
+    return -1
+
+
+def punctual_light_count(scene):
+    return sum(1 for gi in scene.light_indices if scene.global_lights[gi].type != A.LIGHT_DIRECTIONAL)
+
+
+class RasterSurfaces:
+    """Device surfaces of one raster frame (renderer.cpp:1364-1520), linear res_x*res_y arrays."""
+
+    SPECS = dict(vis=4, depth=4, gbuffer_basecolor=4, gbuffer_normals=4, gbuffer_mra=4, color=4, taa0=4, taa1=4, ldr=4)
+
+    def __init__(self, ctx, res_x, res_y, num_meshlets, cfg=A.FConfig):
+        self.ctx, self.res_x, self.res_y = ctx, res_x, res_y
+        n = res_x * res_y
+        self.ptr = {k: ctx.buffer(n * b) for k, b in self.SPECS.items()}
+        self.clusters = cfg.LightClusterDimX * cfg.LightClusterDimY * cfg.LightClusterDimZ
+        self.max_lights = cfg.MaxLightsPerCluster
+        self.num_meshlets = num_meshlets
+        self.ptr["default_list"] = ctx.buffer(max(num_meshlets, 1) * 8)
+        self.ptr["double_sided_list"] = ctx.buffer(max(num_meshlets, 1) * 8)
+        self.ptr["counts"] = ctx.buffer(8)
+        self.ptr["render_stats"] = ctx.buffer(8)
+        self.ptr["light_lists"] = ctx.buffer(self.clusters * self.max_lights * 4)
+        self.ptr["light_grid"] = ctx.buffer(self.clusters * 8)
+        self.ptr["light_count"] = ctx.buffer(4)
+        self.ptr["ray_stats"] = ctx.buffer(C.sizeof(A.RayStats))
+        self.ptr["sh9"] = ctx.buffer(9 * 16)
+        for k in ("counts", "render_stats", "light_count"):
+            ctx.clear(self.ptr[k], 8 if k != "light_count" else 4)
+        ctx.clear(self.ptr["ray_stats"], C.sizeof(A.RayStats))
+        ctx.clear(self.ptr["light_grid"], self.clusters * 8)
+        ctx.clear(self.ptr["light_lists"], self.clusters * self.max_lights * 4)
+        ctx.clear(self.ptr["taa0"], n * 4); ctx.clear(self.ptr["taa1"], n * 4)
+
+    def download(self, name):
+        ctx, n = self.ctx, self.res_x * self.res_y
+        shape2 = (self.res_y, self.res_x)
+        if name == "depth":
+            return ctx.download(self.ptr[name], shape2, np.float32)
+        if name in self.SPECS:
+            return ctx.download(self.ptr[name], shape2, np.uint32)
+        if name in ("default_list", "double_sided_list"):
+            return ctx.download(self.ptr[name], (max(self.num_meshlets, 1), 2), np.uint32)
+        if name == "counts":
+            return ctx.download(self.ptr[name], (2,), np.uint32)
+        if name == "render_stats":
+            return ctx.download(self.ptr[name], (2,), np.int32)
+        if name == "light_lists":
+            return ctx.download(self.ptr[name], (self.clusters, self.max_lights), np.uint32)
+        if name == "light_grid":
+            return ctx.download(self.ptr[name], (self.clusters, 2), np.uint32)
+        if name == "light_count":
+            return ctx.download(self.ptr[name], (1,), np.uint32)
+        if name == "ray_stats":
+            raw = ctx.download(self.ptr[name], (C.sizeof(A.RayStats),), np.uint8)
+            return A.RayStats.from_buffer_copy(raw.tobytes())
+        raise KeyError(name)
+
+    def close(self):
+        for p in self.ptr.values():
+            self.ctx.free(p)
+        self.ptr = {}
+
+
+def lighting_inputs(scene_handle, vc, surf, cfg=A.FConfig, storage_rounding=0):
+    i = A.LightingInputs()
+    i.scene = scene_handle
+    i.view = C.pointer(vc)
+    i.color_target, i.depth_buffer = surf["color"], surf["depth"]
+    i.gbuffer_basecolor, i.gbuffer_normals, i.gbuffer_metallic_roughness_ao = surf["gbuffer_basecolor"], surf["gbuffer_normals"], surf["gbuffer_mra"]
+    i.lighting_only = 1 if cfg.Viewmode == 1 else 0
+    i.storage_rounding = storage_rounding
+    return i
+
+
+def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig, storage_rounding=0, have_sh=True):
+    """All pass descs of one raster frame over a dict of surface pointers (device pointers for the HIP library, host
+    pointers for the oracle: both take the same structs).  Returns an ordered list of (pass name, desc)."""
+    out = []
+    vcp = C.pointer(vc)
+    d = A.BatchCullDesc(); d.scene, d.view = scene_handle, vcp
+    d.default_list, d.double_sided_list, d.counts, d.render_stats = surf["default_list"], surf["double_sided_list"], surf["counts"], surf["render_stats"]
+    d.frustum_culling = 1 if cfg.FrustumCulling else 0
+    out.append(("batch_cull", d))
+    punctual = punctual_light_count(packed_scene)
+    sun = directional_light_index(packed_scene)
+    dims = (cfg.LightClusterDimX, cfg.LightClusterDimY, cfg.LightClusterDimZ)
+    if punctual > 0 and cfg.EnableDirectLighting:
+        d = A.LightCullDesc(); d.scene, d.view = scene_handle, vcp
+        d.cluster_dim[:] = dims
+        d.max_lights_per_cluster, d.cluster_depth_extent = cfg.MaxLightsPerCluster, cfg.ClusterDepthExtent
+        d.culled_light_lists, d.light_grid, d.culled_light_count, d.render_stats = surf["light_lists"], surf["light_grid"], surf["light_count"], surf["render_stats"]
+        out.append(("light_cull", d))
+    d = A.VisibilityDesc(); d.scene, d.view = scene_handle, vcp
+    d.default_list, d.double_sided_list, d.counts = surf["default_list"], surf["double_sided_list"], surf["counts"]
+    d.vis_buffer, d.depth_buffer = surf["vis"], surf["depth"]
+    out.append(("visibility", d))
+    d = A.GBufferDesc(); d.scene, d.view = scene_handle, vcp
+    d.vis_buffer, d.gbuffer_basecolor, d.gbuffer_normals, d.gbuffer_metallic_roughness_ao = surf["vis"], surf["gbuffer_basecolor"], surf["gbuffer_normals"], surf["gbuffer_mra"]
+    d.color_target, d.storage_rounding = surf["color"], storage_rounding
+    out.append(("gbuffer", d))
+    if cfg.EnableSkyLighting:
+        d = A.SkyLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
+        d.sh9_rgba = surf["sh9"] if have_sh else None
+        d.ambient_occlusion = None
+        d.sky_brightness, d.diffuse_ibl = cfg.SkyBrightness, 1 if cfg.EnableDiffuseIBL else 0
+        out.append(("sky_lighting", d))
+    if sun != -1 and cfg.EnableDirectLighting:
+        d = A.DirectLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
+        d.directional_light_index, d.ray_stats = sun, surf["ray_stats"]
+        out.append(("direct_lighting", d))
+    if punctual > 0 and cfg.EnableDirectLighting:
+        d = A.ClusteredLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
+        d.culled_light_lists, d.light_grid = surf["light_lists"], surf["light_grid"]
+        d.cluster_dim[:] = dims
+        d.cluster_depth_extent, d.requires_clear = cfg.ClusterDepthExtent, 1 if sun == -1 else 0
+        out.append(("clustered_lighting", d))
+    if cfg.EnableTAA:
+        d = A.TaaResolveDesc(); d.view = vcp
+        d.hdr_scene_color, d.depth_buffer = surf["color"], surf["depth"]
+        d.history_in, d.history_out = surf["taa%d" % ((frame_index + 1) & 1)], surf["taa%d" % (frame_index & 1)]
+        d.history_index, d.storage_rounding = frame_index, storage_rounding
+        out.append(("taa_resolve", d))
+    return out
+
+
+class RasterRenderer:
+    """One raster frame per render() call, all passes enqueued on one stream (job-sync.h:27-61 token order)."""
+
+    PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
+                   sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
+                   taa_resolve="incr_taa_resolve")
+
+    def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
+        self.ctx, self.scene, self.cfg = ctx, scene, cfg
+        self.res_x, self.res_y = res_x, res_y
+        self.surf = RasterSurfaces(ctx, res_x, res_y, getattr(scene.packed, "num_meshlets", 0), cfg)
+        self.prev_view_proj = None
+        self.frame_index = 0
+        self.have_sh = False
+
+    def set_sh9(self, sh9_rgb):
+        """Skylight probe: 9 RGB SH coefficients (FScene::m_skylight.m_shTextureIndex, a 9x1 RGBA32F texture)."""
+        a = np.zeros((9, 4), dtype=np.float32); a[:, :3] = np.asarray(sh9_rgb, dtype=np.float32).reshape(9, 3)
+        self.ctx.upload(self.surf.ptr["sh9"], a)
+        self.have_sh = True
+
+    def view_constants(self, view, culling_view=None):
+        cfg = self.cfg
+        jit = pixel_jitter(self.frame_index, self.res_x, self.res_y) if (cfg.EnableTAA and cfg.Viewmode == 0) else (0.0, 0.0)
+        return make_view_constants(view, self.res_x, self.res_y, jit, self.prev_view_proj, cfg.CameraNearPlane, culling_view)
+
+    def render(self, view, stream=None, storage_rounding=0, tonemap=True, vc=None):
+        ctx, lib = self.ctx, self.ctx.lib
+        vc = vc if vc is not None else self.view_constants(view)
+        self.last_vc = vc
+        for name, d in build_descs(self.scene.handle, self.scene.packed, vc, self.surf.ptr, self.frame_index, self.cfg, storage_rounding, self.have_sh):
+            rt.check(getattr(lib, self.PASS_FN[name])(ctx.handle, C.byref(d), stream))
+        hdr = self.surf.ptr["taa%d" % (self.frame_index & 1)] if self.cfg.EnableTAA else self.surf.ptr["color"]
+        if tonemap:
+            t = A.TonemapDesc(); t.hdr_r11g11b10, t.ldr_rgba8 = hdr, self.surf.ptr["ldr"]
+            t.res_x, t.rows, t.exposure, t.viewmode = self.res_x, self.res_y, self.cfg.Exposure, self.cfg.Viewmode
+            ctx.tonemap(t, stream)
+        self.prev_view_proj = matrix_to_numpy(vc.unjittered_view_proj)       # renderer.cpp:2025
+        self.frame_index += 1
+        return vc
+
+    def close(self):
+        self.surf.close()

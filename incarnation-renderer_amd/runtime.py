@@ -22,6 +22,10 @@ EXPORTS = [
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
     "incr_scene_get_info", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
     "incr_trace_rays", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end",
+    # raster path
+    "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
+    "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
+    "incr_sky_lighting", "incr_direct_lighting", "incr_clustered_lighting", "incr_taa_resolve",
 ]
 
 
@@ -77,6 +81,21 @@ def load():
     L.incr_profile_end.restype = C.c_int; L.incr_profile_end.argtypes = [vp, C.POINTER(A.PathtraceProfile)]
     L.incr_scene_validate_host.restype = C.c_int
     L.incr_scene_validate_host.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.SceneInfo)]
+    # raster path
+    L.incr_meshletize.restype = C.c_int
+    L.incr_meshletize.argtypes = [vp, u32, vp, u32, u32, u32, u32, C.POINTER(vp)]
+    L.incr_meshlet_set_counts.restype = u32; L.incr_meshlet_set_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.incr_meshlet_set_copy.restype = C.c_int; L.incr_meshlet_set_copy.argtypes = [vp, vp, vp, vp]
+    L.incr_meshlet_set_free.restype = None; L.incr_meshlet_set_free.argtypes = [vp]
+    L.incr_pixel_jitter.restype = None; L.incr_pixel_jitter.argtypes = [u32, u32, u32, C.POINTER(C.c_float)]
+    L.incr_make_view_constants.restype = C.c_int
+    L.incr_make_view_constants.argtypes = [C.POINTER(A.View), C.POINTER(A.View), C.POINTER(C.c_float), C.POINTER(A.Matrix), C.c_float, u32, u32,
+                                           C.POINTER(A.ViewConstants)]
+    for name, desc in (("incr_batch_cull", A.BatchCullDesc), ("incr_light_cull", A.LightCullDesc), ("incr_visibility", A.VisibilityDesc),
+                       ("incr_gbuffer", A.GBufferDesc), ("incr_sky_lighting", A.SkyLightingDesc), ("incr_direct_lighting", A.DirectLightingDesc),
+                       ("incr_clustered_lighting", A.ClusteredLightingDesc), ("incr_taa_resolve", A.TaaResolveDesc)):
+        fn = getattr(L, name)
+        fn.restype = C.c_int; fn.argtypes = [vp, C.POINTER(desc), vp]
     _lib = L
     return L
 

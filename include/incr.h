@@ -164,6 +164,184 @@ int  incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* out_
 int  incr_unshard(incr_context* ctx, void* dst_full, const void* src_gathered, uint32_t res_x, uint32_t res_y,
                   uint32_t row_block_height, uint32_t num_shards, uint32_t texel_bytes, incr_stream stream);
 
+/* =====================================================================================================
+ * Raster path: visibility buffer + clustered deferred shading.
+ * Frame order (src/renderer.cpp:1711-2036): batch cull -> light cull -> visibility -> g-buffer -> sky lighting ->
+ * direct lighting -> clustered lighting -> TAA resolve -> tonemap.  All surfaces are linear res_x*res_y arrays in HBM.
+ * ===================================================================================================== */
+
+/* MeshUtils::Meshletize (src/mesh-utils.cpp:640-835) as called by FScene::GenerateMeshlets (src/scene.cpp:503-560):
+ * HOST-side load-time utility.  positions: vertex_count records of `position_stride_bytes` (>= 12) starting with xyz.
+ * The returned set holds FGpuMeshlet ranges + bounding spheres (accessor/mesh/material fields are -1 for the caller to
+ * fill), the unique-vertex index list and the 10:10:10 packed triangles. */
+typedef struct incr_meshlet_set incr_meshlet_set;
+int      incr_meshletize(const uint32_t* indices, uint32_t index_count, const float* positions, uint32_t vertex_count,
+                         uint32_t position_stride_bytes, uint32_t max_verts, uint32_t max_prims, incr_meshlet_set** out_set);
+uint32_t incr_meshlet_set_counts(const incr_meshlet_set* set, uint32_t* num_vertex_indices, uint32_t* num_triangles);
+int      incr_meshlet_set_copy(const incr_meshlet_set* set, incr_gpu_meshlet* meshlets, uint32_t* vertex_indices, uint32_t* packed_triangles);
+void     incr_meshlet_set_free(incr_meshlet_set* set);
+
+/* The FViewConstants fields the raster passes read (inc/gpu-shared-types.h:167-192) plus the per-pass matrices that
+ * light-culling.inl:111-112, sky-lighting.inl:124 and renderer.cpp:2007-2017 derive on their own (they associate the
+ * jitter translation differently, so they are NOT bitwise the same matrices). */
+typedef struct incr_view_constants {
+    incr_matrix view_transform;
+    incr_matrix proj_transform;              /* P * T(jitter)                                  renderer.cpp:1643 */
+    incr_matrix view_proj_transform;         /* V * (P * T)                                    renderer.cpp:1644 */
+    incr_matrix inv_view_proj_transform;     /* (V * (P * T))^-1                               renderer.cpp:1653 */
+    incr_matrix inv_proj_transform;          /* (P * T)^-1                                     renderer.cpp:1656 */
+    incr_matrix cull_view_proj_transform;    /* Vcull * (P * T)                                renderer.cpp:1657 */
+    incr_matrix prev_view_proj_transform;    /* last frame's UNJITTERED V * P                  renderer.cpp:1655,2025 */
+    incr_matrix lightcull_proj_transform;    /* Pcull * T                                      light-culling.inl:111 */
+    incr_matrix lightcull_inv_view_proj;     /* ((Vcull * Pcull) * T)^-1                       light-culling.inl:112 */
+    incr_matrix sky_inv_view_proj;           /* ((V * P) * T)^-1                               sky-lighting.inl:124 */
+    incr_matrix unjittered_view_proj;        /* V * P: becomes prev_view_proj_transform of the next frame */
+    incr_matrix taa_inv_view_proj;           /* (V * P)^-1                                     renderer.cpp:2017 */
+    float    eye_pos[3];
+    float    near_plane;                     /* FConfig::CameraNearPlane (1.0) */
+    uint32_t res_x, res_y;
+    float    jitter[2];
+} incr_view_constants;
+/* renderer.cpp:126-131: jitter = 2 * (Halton(i,2), Halton(i,3)) - 0.5) / res for i = frame_index % 16. */
+void incr_pixel_jitter(uint32_t frame_index, uint32_t res_x, uint32_t res_y, float out_jitter[2]);
+/* Host helper (no GPU): fills every matrix above.  culling_view NULL = view (FreezeCulling off); prev_view_proj NULL = identity. */
+int  incr_make_view_constants(const incr_view* view, const incr_view* culling_view, const float jitter[2],
+                              const incr_matrix* prev_view_proj, float near_plane, uint32_t res_x, uint32_t res_y,
+                              incr_view_constants* out);
+
+/* One entry of the culled draw lists: the live fields of FIndirectDrawWithRootConstants (batch-culling.hlsl:150-155). */
+typedef struct incr_draw_cmd { uint32_t id; uint32_t vertex_count; } incr_draw_cmd;
+
+/*
+ * RenderJob::BatchCullingPass::Execute (render-jobs/batch-culling.inl; shaders/culling/batch-culling.hlsl cs_meshlet_cull_main):
+ * per-meshlet visibility + Gribb-Hartmann frustum test against cull_view_proj_transform, split by FMaterial::m_doubleSided.
+ * The reference appends with InterlockedAdd (any order); this implementation emits ASCENDING meshlet ids, one of
+ * the reference's possible outcomes and the one the visibility pass's tie rule is defined on.
+ */
+typedef struct incr_batch_cull_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    incr_draw_cmd* default_list;       /* device, capacity num_meshlets   (batchArgsBuffer_Default)      */
+    incr_draw_cmd* double_sided_list;  /* device, capacity num_meshlets   (batchArgsBuffer_DoubleSided)  */
+    uint32_t* counts;                  /* device, 2 x u32: {default, double-sided}  (batchCountsBuffer)  */
+    incr_render_stats* render_stats;   /* device, optional: m_culledObjects is stored                    */
+    int32_t  frustum_culling;          /* FConfig::FrustumCulling */
+} incr_batch_cull_desc;
+int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* desc, incr_stream stream);
+
+/*
+ * RenderJob::LightCullingPass::Execute (render-jobs/light-culling.inl; shaders/culling/light-culling.hlsl): one thread per
+ * cluster tests every punctual scene light's range sphere against the cluster frustum.  light_grid[c] = {offset, count}
+ * with offset = c * max_lights_per_cluster (the reference allocates offsets with an atomic, i.e. in any order; consumers
+ * only follow (offset, count)).  Lists hold GLOBAL light indices in ascending scene-light order, as in the reference.
+ */
+typedef struct incr_light_cull_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    uint32_t cluster_dim[3];           /* FConfig::LightClusterDimX/Y/Z (16, 9, 24) */
+    uint32_t max_lights_per_cluster;   /* FConfig::MaxLightsPerCluster (64), <= 128 */
+    float    cluster_depth_extent;     /* FConfig::ClusterDepthExtent (200) */
+    uint32_t* culled_light_lists;      /* device, max_lights_per_cluster * clusters u32 */
+    incr_light_grid_data* light_grid;  /* device, clusters entries */
+    uint32_t* culled_light_count;      /* device, 1 u32: total list entries */
+    incr_render_stats* render_stats;   /* device, optional: m_culledLights is stored */
+} incr_light_cull_desc;
+int incr_light_cull(incr_context* ctx, const incr_light_cull_desc* desc, incr_stream stream);
+
+/*
+ * RenderJob::VisibilityPass::Execute (render-jobs/visibility-pass.inl; shaders/geo-raster/visibility-pass.hlsl
+ * vs_meshlet_main / ps_meshlet_main): draws every command of the default list with back-face culling (CCW front)
+ * and every command of the double-sided list without, depth test GREATER_EQUAL on reverse Z, alpha clip at 0.5,
+ * vis = meshletId << 7 | triangle.  Clears: vis 0xFFFFF000, depth 0.  A software rasteriser on MI355X
+ * (DESIGN.md "Visibility pass"): D3D top-left rule on 24.8 fixed-point positions, pixel centres at +0.5.
+ */
+typedef struct incr_visibility_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    const incr_draw_cmd* default_list;
+    const incr_draw_cmd* double_sided_list;
+    const uint32_t* counts;            /* device, from incr_batch_cull */
+    uint32_t* vis_buffer;              /* device, res_x*res_y R32_UINT */
+    float*    depth_buffer;            /* device, res_x*res_y D32_FLOAT */
+} incr_visibility_desc;
+int incr_visibility(incr_context* ctx, const incr_visibility_desc* desc, incr_stream stream);
+
+/*
+ * RenderJob::GBufferComputePass::Execute (render-jobs/gbuffer-compute-pass.inl; shaders/geo-raster/gbuffer-compute.hlsl):
+ * clears the colour target, then per pixel decodes the visibility id, interpolates attributes with screen-space
+ * barycentrics, evaluates the material and writes the three G-buffers + emissive * 20000.
+ */
+typedef struct incr_gbuffer_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    const uint32_t* vis_buffer;
+    uint32_t* gbuffer_basecolor;       /* device, R8G8B8A8_UNORM */
+    uint32_t* gbuffer_normals;         /* device, R16G16_FLOAT (octahedral) */
+    uint32_t* gbuffer_metallic_roughness_ao; /* device, R8G8B8A8_UNORM */
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT */
+    int32_t  storage_rounding;         /* as incr_pathtrace_desc::storage_rounding */
+} incr_gbuffer_desc;
+int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* desc, incr_stream stream);
+
+/* Inputs shared by the three deferred lighting passes. */
+typedef struct incr_lighting_inputs {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT, read-modify-write (`colorTarget[xy] += radiance`) */
+    const float*    depth_buffer;
+    const uint32_t* gbuffer_basecolor;
+    const uint32_t* gbuffer_normals;
+    const uint32_t* gbuffer_metallic_roughness_ao;
+    int32_t  lighting_only;            /* Viewmode::LightingOnly -> LIGHTING_ONLY macro */
+    int32_t  storage_rounding;
+} incr_lighting_inputs;
+
+/* RenderJob::SkyLightingPass::Execute (render-jobs/sky-lighting.inl; shaders/lighting/sky-lighting.hlsl): SH9 diffuse IBL.
+ * The specular IBL branch needs the prefiltered environment cube + env-BRDF LUT (SURVEY.md 8f "next"): this
+ * entry point behaves like the shader with g_envmapIndex == -1. */
+typedef struct incr_sky_lighting_desc {
+    incr_lighting_inputs in;
+    const float* sh9_rgba;             /* device, 9 x float4: the skylight probe texture (RGBA32F 9x1); NULL = g_skylightProbeIndex -1 */
+    const uint8_t* ambient_occlusion;  /* device, R8_UNORM; NULL = cleared to 1 (HBAO disabled, renderer.cpp:1818-1838) */
+    float    sky_brightness;           /* FConfig::SkyBrightness */
+    int32_t  diffuse_ibl;              /* FConfig::EnableDiffuseIBL */
+} incr_sky_lighting_desc;
+int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* desc, incr_stream stream);
+
+/* RenderJob::DirectLightingPass::Execute (render-jobs/direct-lighting.inl; shaders/lighting/direct-lighting.hlsl): the sun,
+ * with one ray-traced shadow query per lit pixel (lighting/common.hlsli:102-115). */
+typedef struct incr_direct_lighting_desc {
+    incr_lighting_inputs in;
+    int32_t  directional_light_index;  /* FScene::GetDirectionalLight(): GLOBAL index, also used to index the transform list */
+    incr_ray_stats* ray_stats;         /* device, optional: light_shadow_rays accumulated */
+} incr_direct_lighting_desc;
+int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* desc, incr_stream stream);
+
+/* RenderJob::ClusteredLightingPass::Execute (render-jobs/clustered-lighting.inl; shaders/lighting/clustered-lighting.hlsl). */
+typedef struct incr_clustered_lighting_desc {
+    incr_lighting_inputs in;
+    const uint32_t* culled_light_lists;
+    const incr_light_grid_data* light_grid;
+    uint32_t cluster_dim[3];
+    float    cluster_depth_extent;
+    int32_t  requires_clear;           /* bRequiresClear: the colour target is cleared first when the scene has no sun (renderer.cpp:1906) */
+} incr_clustered_lighting_desc;
+int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* desc, incr_stream stream);
+
+/* RenderJob::TAAResolvePass::Execute (render-jobs/taa-resolve.inl; shaders/postprocess/taa-resolve.hlsl).  The reference
+ * reads and writes ONE accumulation surface in place (a data race across pixels); here history is read from
+ * `history_in` and the result written to `history_out` (they may not alias): the race-free reading of the shader. */
+typedef struct incr_taa_resolve_desc {
+    const incr_view_constants* view;   /* taa_inv_view_proj, prev_view_proj_transform, res */
+    const uint32_t* hdr_scene_color;   /* device, R11G11B10_FLOAT */
+    const uint32_t* history_in;        /* device, R11G11B10_FLOAT (ignored when history_index == 0) */
+    uint32_t* history_out;
+    const float* depth_buffer;
+    uint32_t history_index;            /* frame index */
+    int32_t  storage_rounding;
+} incr_taa_resolve_desc;
+int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* desc, incr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

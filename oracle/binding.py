@@ -57,6 +57,18 @@ def lib():
         L.orc_trace_rays.argtypes = [vp, u32, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
         L.orc_pathtrace.restype = C.c_int; L.orc_pathtrace.argtypes = [vp, C.POINTER(A.PathtraceDesc), C.c_int, vp]
         L.orc_tonemap.argtypes = [vp, vp, u32, u32, C.c_float, C.c_int]
+        # raster half (oracle_raster.h)
+        L.orc_pixel_jitter.argtypes = [u32, u32, u32, fp]
+        L.orc_view_constants.argtypes = [C.POINTER(A.View), C.POINTER(A.View), fp, C.POINTER(A.Matrix), C.c_float, u32, u32, C.POINTER(A.ViewConstants)]
+        L.orc_batch_cull.argtypes = [vp, C.POINTER(A.BatchCullDesc), C.POINTER(C.c_int32)]
+        L.orc_light_cull.argtypes = [vp, C.POINTER(A.LightCullDesc), C.POINTER(C.c_int32)]
+        L.orc_visibility.argtypes = [vp, C.POINTER(A.VisibilityDesc)]
+        L.orc_gbuffer.argtypes = [vp, C.POINTER(A.GBufferDesc)]
+        L.orc_sky_lighting.argtypes = [vp, C.POINTER(A.SkyLightingDesc)]
+        L.orc_direct_lighting.argtypes = [vp, C.POINTER(A.DirectLightingDesc), C.POINTER(C.c_uint64)]
+        L.orc_clustered_lighting.argtypes = [vp, C.POINTER(A.ClusteredLightingDesc)]
+        L.orc_taa_resolve.argtypes = [C.POINTER(A.TaaResolveDesc)]
+        L.orc_oct_roundtrip.argtypes = [fp, fp, fp]
         _lib = L
     return _lib
 
@@ -118,6 +130,80 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("orc_pathtrace failed: %d" % rc)
         return dict(target=target, history=history, stats=stats, float=fl)
+
+
+# ---- raster half ----------------------------------------------------------------------------------------
+def pixel_jitter(frame_index, res_x, res_y):
+    out = (C.c_float * 2)()
+    lib().orc_pixel_jitter(frame_index, res_x, res_y, out)
+    return np.array([out[0], out[1]], dtype=np.float32)
+
+
+def view_constants(view, res_x, res_y, jitter=(0.0, 0.0), prev_view_proj=None, near_plane=1.0, culling_view=None):
+    vc = A.ViewConstants()
+    v = view.to_ctypes()
+    cv = culling_view.to_ctypes() if culling_view is not None else None
+    prev = None
+    if prev_view_proj is not None:
+        prev = A.Matrix()
+        flat = np.asarray(prev_view_proj, dtype=np.float32).ravel()
+        for i in range(16):
+            prev.m[i] = float(flat[i])
+    lib().orc_view_constants(C.byref(v), C.byref(cv) if cv is not None else None, _fa(jitter), C.byref(prev) if prev is not None else None,
+                             near_plane, res_x, res_y, C.byref(vc))
+    return vc
+
+
+class HostSurfaces:
+    """Host twins of the device surfaces of one raster frame: numpy arrays under the names the pass descs use."""
+
+    def __init__(self, res_x, res_y, num_meshlets, clusters, max_lights):
+        n = (res_y, res_x)
+        self.arr = {k: np.zeros(n, dtype=np.uint32) for k in ("vis", "gbuffer_basecolor", "gbuffer_normals", "gbuffer_mra", "color", "taa0", "taa1", "ldr")}
+        self.arr["depth"] = np.zeros(n, dtype=np.float32)
+        self.arr["default_list"] = np.zeros((max(num_meshlets, 1), 2), dtype=np.uint32)
+        self.arr["double_sided_list"] = np.zeros((max(num_meshlets, 1), 2), dtype=np.uint32)
+        self.arr["counts"] = np.zeros(2, dtype=np.uint32)
+        self.arr["render_stats"] = np.zeros(2, dtype=np.int32)
+        self.arr["light_lists"] = np.zeros((clusters, max_lights), dtype=np.uint32)
+        self.arr["light_grid"] = np.zeros((clusters, 2), dtype=np.uint32)
+        self.arr["light_count"] = np.zeros(1, dtype=np.uint32)
+        self.arr["ray_stats"] = np.zeros(8, dtype=np.uint64)
+        self.arr["sh9"] = np.zeros((9, 4), dtype=np.float32)
+        self.ptr = {k: v.ctypes.data for k, v in self.arr.items()}
+
+
+def run_pass(scene, name, desc):
+    """Run one raster pass of the oracle on a desc whose pointers are HOST pointers (HostSurfaces.ptr)."""
+    L = lib()
+    h = scene.handle if scene is not None else None
+    if name == "batch_cull":
+        culled = C.c_int32()
+        L.orc_batch_cull(h, C.byref(desc), C.byref(culled))
+        if desc.render_stats:
+            C.cast(desc.render_stats, C.POINTER(C.c_int32))[0] = culled.value
+    elif name == "light_cull":
+        culled = C.c_int32()
+        L.orc_light_cull(h, C.byref(desc), C.byref(culled))
+        if desc.render_stats:
+            C.cast(desc.render_stats, C.POINTER(C.c_int32))[1] = culled.value
+    elif name == "visibility":
+        L.orc_visibility(h, C.byref(desc))
+    elif name == "gbuffer":
+        L.orc_gbuffer(h, C.byref(desc))
+    elif name == "sky_lighting":
+        L.orc_sky_lighting(h, C.byref(desc))
+    elif name == "direct_lighting":
+        rays = C.c_uint64()
+        L.orc_direct_lighting(h, C.byref(desc), C.byref(rays))
+        if desc.ray_stats:
+            C.cast(desc.ray_stats, C.POINTER(C.c_uint64))[3] += rays.value      # incr_ray_stats::light_shadow_rays
+    elif name == "clustered_lighting":
+        L.orc_clustered_lighting(h, C.byref(desc))
+    elif name == "taa_resolve":
+        L.orc_taa_resolve(C.byref(desc))
+    else:
+        raise KeyError(name)
 
 
 def tonemap(history_u32, exposure=13.0, viewmode=0):

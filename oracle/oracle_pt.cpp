@@ -1013,3 +1013,6 @@ void orc_tonemap(const uint32_t* hdr_r11g11b10, uint8_t* ldr_rgba8, uint32_t res
 }
 
 } // extern "C"
+
+// raster half of the hot path: shares the scene access, texture unit and BRDF code above
+#include "oracle_raster.h"

@@ -1,0 +1,559 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the raster half of the Incarnation hot path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
+// PARITY UNPINNED (see oracle_math.h): restatement of the HLSL / host code cited at each function; the reference ships
+// no golden vectors.  Included at the end of oracle_pt.cpp (shares its scene access, texture unit and BRDF code).
+//
+// Fixed-function stages the reference leaves to D3D12 hardware are PINNED here (DESIGN.md "Rasterisation rules"):
+//   * clip only against the near plane (z <= w; the reference's reverse-Z infinite projection has no far plane),
+//     new vertices a + t (b - a) with a the inside vertex, t = d_a / (d_a - d_b), d = w - z;
+//   * viewport: sx = (x/w * 0.5 + 0.5) * W, sy = (0.5 - y/w * 0.5) * H, snapped to 24.8 fixed point (round half up),
+//     clamped to +-2^20 pixels; sample point = pixel centre; D3D top-left fill rule on exact integer edge functions;
+//   * front face = counter-clockwise on screen (visibility-pass.inl FrontCounterClockwise = TRUE);
+//   * depth = z0 + l1 (z1 - z0) + l2 (z2 - z0) with l = (float)((double)E / (double)area), clamped to <= 1;
+//   * depth test GREATER_EQUAL in draw order: default list, then double-sided list, each in ascending meshlet id,
+//     triangles in ascending index -> among equal depths the LAST drawn fragment wins;
+//   * pixel-shader interpolants (uv) use the same screen-space barycentric formula as the G-buffer pass;
+//   * textures: mip 0 bilinear (the raster path's anisotropic/trilinear LOD selection is not reproduced);
+//   * rcp(x) = 1 / x, UNORM stores round to nearest, float stores as incr_*_desc::storage_rounding says.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ view constants
+static float RasterHalton(uint64_t sampleIndex, uint32_t base) {             // renderer.cpp:53-66
+    float result = 0.f, f = 1.f;
+    while (sampleIndex > 0) { f = f / (float)base; result += f * (float)(sampleIndex % base); sampleIndex = sampleIndex / base; }
+    return result;
+}
+static Mat4 mat_translation(float x, float y) { Mat4 t = mat_identity(); t.m[12] = x; t.m[13] = y; return t; }
+static void put(incr_matrix* d, const Mat4& m) { memcpy(d->m, m.m, 64); }
+
+static void make_view_constants(const incr_view* view, const incr_view* cull, const float jitter[2], const incr_matrix* prev, float nearPlane,
+                                uint32_t resX, uint32_t resY, incr_view_constants* o) {    // renderer.cpp:1638-1665
+    if (!cull) cull = view;
+    const float jx = jitter ? jitter[0] : 0.f, jy = jitter ? jitter[1] : 0.f;
+    const Mat4 V = to_mat4(view->view_transform), P = to_mat4(view->projection_transform);
+    const Mat4 Vc = to_mat4(cull->view_transform), Pc = to_mat4(cull->projection_transform);
+    const Mat4 T = mat_translation(jx, jy);
+    const Mat4 PT = mat_mul(P, T), VPT = mat_mul(V, PT), VP = mat_mul(V, P);
+    memset(o, 0, sizeof *o);
+    put(&o->view_transform, V); put(&o->proj_transform, PT); put(&o->view_proj_transform, VPT);
+    put(&o->inv_view_proj_transform, mat_inverse(VPT)); put(&o->inv_proj_transform, mat_inverse(PT));
+    put(&o->cull_view_proj_transform, mat_mul(Vc, PT));
+    put(&o->prev_view_proj_transform, prev ? to_mat4(*prev) : mat_identity());
+    put(&o->lightcull_proj_transform, mat_mul(Pc, T));                                     // light-culling.inl:111
+    put(&o->lightcull_inv_view_proj, mat_inverse(mat_mul(mat_mul(Vc, Pc), T)));            // light-culling.inl:112
+    put(&o->sky_inv_view_proj, mat_inverse(mat_mul(VP, T)));                               // sky-lighting.inl:124
+    put(&o->unjittered_view_proj, VP); put(&o->taa_inv_view_proj, mat_inverse(VP));       // renderer.cpp:2007-2017
+    for (int i = 0; i < 3; ++i) o->eye_pos[i] = view->position[i];
+    o->near_plane = nearPlane; o->res_x = resX; o->res_y = resY; o->jitter[0] = jx; o->jitter[1] = jy;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+static inline float dot4p(float3 c, const float p[4]) { return ((c.x * p[0] + c.y * p[1]) + c.z * p[2]) + 1.f * p[3]; }   // dot(float4(c,1), plane)
+static inline float len3(const float p[4]) { return sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
+static inline Mat4 mesh_local_to_world(const Scene& s, int mesh) {           // mul(meshTransform, sceneRotation)
+    return mat_mul(to_mat4(s.d.mesh_transforms[mesh]), to_mat4(s.d.root_transform));
+}
+// D3D ftou: NaN -> 0, negative -> 0, saturating
+static inline uint32_t ftou(float f) { if (!(f > 0.f)) return 0u; if (f >= 4294967296.f) return 0xffffffffu; return (uint32_t)f; }
+
+// ------------------------------------------------------------------------------------------------ batch culling
+// shaders/culling/batch-culling.hlsl:22-46 FrustumCull
+static bool BatchFrustumCull(const float sphere[4], const Mat4& localToWorld, const Mat4& cullViewProj) {
+    const Mat4 Mt = mat_mul(localToWorld, cullViewProj);      // M = transpose(Mt): M[r] is column r of Mt
+    float n[4], l[4], r[4], b[4], t[4];
+    for (int k = 0; k < 4; ++k) {
+        const float c0 = Mt.m[k * 4 + 0], c1 = Mt.m[k * 4 + 1], c2 = Mt.m[k * 4 + 2], c3 = Mt.m[k * 4 + 3];
+        n[k] = c3 - c2; l[k] = c3 + c0; r[k] = c3 - c0; b[k] = c3 + c1; t[k] = c3 - c1;
+    }
+    const float3 c = {sphere[0], sphere[1], sphere[2]}; const float rad = sphere[3];
+    return (dot4p(c, n) + rad * len3(n) >= 0) && (dot4p(c, l) + rad * len3(l) >= 0) && (dot4p(c, r) + rad * len3(r) >= 0)
+        && (dot4p(c, b) + rad * len3(b) >= 0) && (dot4p(c, t) + rad * len3(t) >= 0);
+}
+// cs_meshlet_cull_main :119-193 (lists in ascending meshlet id: one of the orders the atomic append can produce)
+static void batch_cull(const Scene& s, const incr_view_constants& vc, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
+                       uint32_t counts[2], int32_t* culled) {
+    counts[0] = counts[1] = 0; *culled = 0;
+    const Mat4 cvp = to_mat4(vc.cull_view_proj_transform);
+    for (uint32_t id = 0; id < s.d.num_meshlets; ++id) {
+        const incr_gpu_meshlet& m = s.d.meshlets[id];
+        const uint32_t visible = s.d.mesh_visibility ? s.d.mesh_visibility[m.meshIndex] : 1u;
+        if (!visible) continue;
+        if (!frustumCulling || BatchFrustumCull(m.boundingSphere, mesh_local_to_world(s, m.meshIndex), cvp)) {
+            const incr_draw_cmd cmd = {id, m.triangleCount * 3u};
+            if (s.d.materials[m.materialIndex].doubleSided) dsList[counts[1]++] = cmd; else defList[counts[0]++] = cmd;
+        } else ++*culled;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ light culling
+struct Frustum6 { float nearP[4], farP[4], leftP[4], rightP[4], bottomP[4], topP[4]; };
+static void plane_from(float out[4], float3 a, float3 b, float3 P) { float3 n = cross(a, b); out[0] = n.x; out[1] = n.y; out[2] = n.z; out[3] = -dot(n, P); }
+// shaders/common/cluster-culling.hlsli:44-113 GetClusterFrustum
+static Frustum6 GetClusterFrustum(const uint32_t ci[3], const uint32_t grid[3], float zNear, float zFar, const Mat4& proj, const Mat4& invViewProj) {
+    float cx = (float)ci[0] / (float)grid[0], cy = (float)ci[1] / (float)grid[1];
+    cx = 2.f * cx - 1.f; cy = 2.f * cy - 1.f; cy = -cy;
+    const float sx = 2.f / (float)grid[0], sy = 2.f / (float)grid[1];
+    const float d0 = zNear * powf(zFar / zNear, (float)ci[2] / (float)grid[2]);
+    const float d1 = zNear * powf(zFar / zNear, ((float)ci[2] + 1.f) / (float)grid[2]);
+    const float4 np = mul_vec4({0.f, 0.f, d0, 1.f}, proj), fp = mul_vec4({0.f, 0.f, d1, 1.f}, proj);
+    const float zn = np.z / np.w, zf = fp.z / fp.w;
+    const float4 pts[8] = {{cx, cy - sy, zn, 1.f}, {cx + sx, cy - sy, zn, 1.f}, {cx + sx, cy, zn, 1.f}, {cx, cy, zn, 1.f},
+                           {cx, cy - sy, zf, 1.f}, {cx + sx, cy - sy, zf, 1.f}, {cx + sx, cy, zf, 1.f}, {cx, cy, zf, 1.f}};
+    float3 P[8];
+    for (int i = 0; i < 8; ++i) { const float4 w = mul_vec4(pts[i], invViewProj); P[i] = {w.x / w.w, w.y / w.w, w.z / w.w}; }
+    Frustum6 f;
+    plane_from(f.nearP, P[1] - P[0], P[3] - P[0], P[0]);
+    plane_from(f.farP, P[7] - P[4], P[5] - P[4], P[4]);
+    plane_from(f.leftP, P[3] - P[0], P[4] - P[0], P[0]);
+    plane_from(f.rightP, P[5] - P[1], P[2] - P[1], P[1]);
+    plane_from(f.topP, P[6] - P[2], P[3] - P[2], P[2]);
+    plane_from(f.bottomP, P[4] - P[0], P[1] - P[0], P[0]);
+    return f;
+}
+static bool ClusterFrustumCull(const Frustum6& f, float3 c, float r) {       // cluster-culling.hlsli:116-129
+    return (dot4p(c, f.nearP) + r * len3(f.nearP) >= 0) && (dot4p(c, f.farP) + r * len3(f.farP) >= 0) && (dot4p(c, f.leftP) + r * len3(f.leftP) >= 0)
+        && (dot4p(c, f.rightP) + r * len3(f.rightP) >= 0) && (dot4p(c, f.bottomP) + r * len3(f.bottomP) >= 0) && (dot4p(c, f.topP) + r * len3(f.topP) >= 0);
+}
+static const float kMaxLightRange = 4.f;
+// shaders/culling/light-culling.hlsl:45-131; offsets are c * maxLights (the reference allocates them with one atomic per cluster)
+static void light_cull(const Scene& s, const incr_view_constants& vc, const uint32_t grid[3], uint32_t maxLights, float depthExtent,
+                       uint32_t* lists, incr_light_grid_data* lightGrid, uint32_t* totalCount, int32_t* culled) {
+    const Mat4 proj = to_mat4(vc.lightcull_proj_transform), ivp = to_mat4(vc.lightcull_inv_view_proj);
+    *totalCount = 0; *culled = 0;
+    for (uint32_t z = 0; z < grid[2]; ++z) for (uint32_t y = 0; y < grid[1]; ++y) for (uint32_t x = 0; x < grid[0]; ++x) {
+        const uint32_t ci[3] = {x, y, z};
+        const uint32_t clusterId = (grid[0] * grid[1]) * z + grid[0] * y + x;
+        const Frustum6 f = GetClusterFrustum(ci, grid, vc.near_plane, depthExtent, proj, ivp);
+        uint32_t count = 0;
+        for (uint32_t i = 0; i < s.d.num_scene_lights && count < maxLights; ++i) {
+            const uint32_t gi = (uint32_t)s.d.light_indices[i];
+            const incr_light& light = s.d.global_lights[gi];
+            if (light.type == INCR_LIGHT_DIRECTIONAL) continue;
+            const float range = light.range == 0 ? kMaxLightRange : light.range;
+            const float* m = s.d.light_transforms[i].m;           // Q10: the transform is indexed with the loop index
+            if (ClusterFrustumCull(f, {m[12], m[13], m[14]}, range)) lists[(size_t)clusterId * maxLights + count++] = gi;
+            else ++*culled;
+        }
+        lightGrid[clusterId].offset = clusterId * maxLights; lightGrid[clusterId].count = count;
+        *totalCount += count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ visibility pass
+struct ClipVert { float x, y, z, w; };
+struct ScreenVert { int32_t X, Y; float z; };
+static inline bool to_screen(const ClipVert& c, float W, float H, ScreenVert* o) {
+    if (!(c.w > 0.f)) return false;
+    const float nx = c.x / c.w, ny = c.y / c.w;
+    float sx = (nx * 0.5f + 0.5f) * W, sy = (0.5f - ny * 0.5f) * H;
+    if (!(sx == sx) || !(sy == sy)) return false;
+    sx = fminf(fmaxf(sx, -1048576.f), 1048576.f); sy = fminf(fmaxf(sy, -1048576.f), 1048576.f);
+    o->X = (int32_t)floorf(sx * 256.f + 0.5f); o->Y = (int32_t)floorf(sy * 256.f + 0.5f);
+    o->z = c.z / c.w;
+    return true;
+}
+static inline ClipVert clip_lerp(const ClipVert& a, const ClipVert& b) {      // a inside, b outside the near plane
+    const float da = a.w - a.z, db = b.w - b.z;
+    const float t = da / (da - db);
+    return {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w)};
+}
+// gbuffer-compute.hlsl:19-46 CalcBarycentrics (rcp pinned to 1/x)
+static float3 CalcBarycentrics(float4 p0, float4 p1, float4 p2, float2 pixelNdc) {
+    const float3 invW = {1.f / p0.w, 1.f / p1.w, 1.f / p2.w};
+    const float2 ndc0 = {p0.x * invW.x, p0.y * invW.x}, ndc1 = {p1.x * invW.y, p1.y * invW.y}, ndc2 = {p2.x * invW.z, p2.y * invW.z};
+    const float2 a = ndc2 - ndc1, b = ndc0 - ndc1;
+    const float invDet = 1.f / (a.x * b.y - a.y * b.x);
+    const float3 ddx = {((ndc1.y - ndc2.y) * invDet) * invW.x, ((ndc2.y - ndc0.y) * invDet) * invW.y, ((ndc0.y - ndc1.y) * invDet) * invW.z};
+    const float3 ddy = {((ndc2.x - ndc1.x) * invDet) * invW.x, ((ndc0.x - ndc2.x) * invDet) * invW.y, ((ndc1.x - ndc0.x) * invDet) * invW.z};
+    const float ddxSum = (ddx.x * 1.f + ddx.y * 1.f) + ddx.z * 1.f, ddySum = (ddy.x * 1.f + ddy.y * 1.f) + ddy.z * 1.f;
+    const float2 dv = pixelNdc - ndc0;
+    const float interpInvW = (invW.x + dv.x * ddxSum) + dv.y * ddySum;
+    const float interpW = 1.f / interpInvW;
+    float3 l;
+    l.x = interpW * ((invW.x + dv.x * ddx.x) + dv.y * ddy.x);
+    l.y = interpW * ((0.0f + dv.x * ddx.y) + dv.y * ddy.y);
+    l.z = interpW * ((0.0f + dv.x * ddx.z) + dv.y * ddy.z);
+    return l;
+}
+static inline float2 pixel_ndc(uint32_t px, uint32_t py, float W, float H) {   // gbuffer-compute.hlsl:207-210
+    float2 n = {((float)px + 0.5f) / W, ((float)py + 0.5f) / H};
+    n.x = 2.f * n.x - 1.f; n.y = -2.f * n.y + 1.f;
+    return n;
+}
+static inline float2 interp2(float2 a, float2 b, float2 c, float3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y}; }
+static inline float3 interp3(float3 a, float3 b, float3 c, float3 w) {
+    return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y, (w.x * a.z + w.y * b.z) + w.z * c.z};
+}
+static inline void meshlet_tri_verts(const Scene& s, const incr_gpu_meshlet& m, uint32_t tri, uint32_t out[3]) {   // visibility-pass.hlsl:72-82
+    const uint32_t packed = s.d.meshlet_packed_triangles[m.triangleBegin + tri];
+    for (uint32_t k = 0; k < 3; ++k) out[k] = s.d.meshlet_vertex_indices[m.vertexBegin + (0xffu & (packed >> ((2u - k) * 10u)))];
+}
+
+struct RasterTarget { uint32_t W, H; std::vector<uint64_t> packed; };
+
+static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t key,
+                          const incr_material& mat, const float4 p[3], const float2 uv[3]) {
+    int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
+    if (area == 0) return;
+    if (area > 0) { if (cullBack) return; }                    // clockwise on screen = back face
+    else { ScreenVert t = v1; v1 = v2; v2 = t; area = -area; }  // make the vertex order clockwise
+    const int32_t minX = std::min(v0.X, std::min(v1.X, v2.X)), maxX = std::max(v0.X, std::max(v1.X, v2.X));
+    const int32_t minY = std::min(v0.Y, std::min(v1.Y, v2.Y)), maxY = std::max(v0.Y, std::max(v1.Y, v2.Y));
+    const int32_t px0 = std::max(0, (minX + 127) >> 8), px1 = std::min((int32_t)rt.W - 1, (maxX - 128) >> 8);
+    const int32_t py0 = std::max(0, (minY + 127) >> 8), py1 = std::min((int32_t)rt.H - 1, (maxY - 128) >> 8);
+    auto topLeft = [](int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; };
+    const int64_t b01 = topLeft(v1.X - v0.X, v1.Y - v0.Y) ? 0 : -1, b12 = topLeft(v2.X - v1.X, v2.Y - v1.Y) ? 0 : -1, b20 = topLeft(v0.X - v2.X, v0.Y - v2.Y) ? 0 : -1;
+    const float W = (float)rt.W, H = (float)rt.H;
+    for (int32_t py = py0; py <= py1; ++py)
+        for (int32_t px = px0; px <= px1; ++px) {
+            const int64_t Sx = (int64_t)px * 256 + 128, Sy = (int64_t)py * 256 + 128;
+            const int64_t E01 = (int64_t)(v1.X - v0.X) * (Sy - v0.Y) - (int64_t)(v1.Y - v0.Y) * (Sx - v0.X);
+            const int64_t E12 = (int64_t)(v2.X - v1.X) * (Sy - v1.Y) - (int64_t)(v2.Y - v1.Y) * (Sx - v1.X);
+            const int64_t E20 = (int64_t)(v0.X - v2.X) * (Sy - v2.Y) - (int64_t)(v0.Y - v2.Y) * (Sx - v2.X);
+            if (E01 + b01 < 0 || E12 + b12 < 0 || E20 + b20 < 0) continue;
+            const float l1 = (float)((double)E20 / (double)area), l2 = (float)((double)E01 / (double)area);
+            float depth = (v0.z + l1 * (v1.z - v0.z)) + l2 * (v2.z - v0.z);
+            if (!(depth >= 0.f)) continue;
+            if (depth > 1.f) depth = 1.f;
+            if (mat.baseColorTextureIndex != -1) {             // ps_meshlet_main: clip(opacity - 0.5)
+                const float3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc((uint32_t)px, (uint32_t)py, W, H));
+                const float opacity = SampleLevel0(s, mat.baseColorTextureIndex, interp2(uv[0], uv[1], uv[2], lam)).w;
+                if (opacity - 0.5f < 0.f) continue;
+            }
+            const uint64_t v = ((uint64_t)f2u(depth) << 32) | (uint64_t)(key + 1u);
+            uint64_t& dst = rt.packed[(size_t)py * rt.W + px];
+            if (v > dst) dst = v;
+        }
+}
+
+// visibility-pass.hlsl vs_meshlet_main + ps_meshlet_main over both draw lists
+static void visibility_pass(const Scene& s, const incr_view_constants& vc, const incr_draw_cmd* defList, const incr_draw_cmd* dsList,
+                            const uint32_t counts[2], uint32_t* vis, float* depthOut) {
+    RasterTarget rt; rt.W = vc.res_x; rt.H = vc.res_y; rt.packed.assign((size_t)rt.W * rt.H, 0);
+    const Mat4 viewProj = to_mat4(vc.view_proj_transform);
+    const float W = (float)rt.W, H = (float)rt.H;
+    for (int list = 0; list < 2; ++list) {
+        const incr_draw_cmd* cmds = list ? dsList : defList;
+        for (uint32_t c = 0; c < counts[list]; ++c) {
+            const uint32_t meshletId = cmds[c].id;
+            const incr_gpu_meshlet& m = s.d.meshlets[meshletId];
+            const Mat4 localToWorld = mesh_local_to_world(s, m.meshIndex);
+            const incr_material& mat = s.d.materials[m.materialIndex];
+            for (uint32_t tri = 0; tri < cmds[c].vertex_count / 3u; ++tri) {
+                uint32_t vi[3]; meshlet_tri_verts(s, m, tri, vi);
+                ClipVert cv[3]; float4 p[3]; float2 uv[3];
+                for (int k = 0; k < 3; ++k) {
+                    const float3 pos = GetFloat3(s, (int)vi[k], m.positionAccessor);
+                    const float4 worldPos = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToWorld);
+                    p[k] = mul_vec4(worldPos, viewProj);
+                    cv[k] = {p[k].x, p[k].y, p[k].z, p[k].w};
+                    uv[k] = GetFloat2(s, (int)vi[k], m.uvAccessor);
+                }
+                const uint32_t key = ((uint32_t)list << 31) | ((meshletId << 7) | tri);
+                // near-plane clip (z <= w)
+                bool in[3]; int nin = 0;
+                for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
+                if (nin == 0) continue;
+                ClipVert poly[4]; int np = 0;
+                if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+                else for (int k = 0; k < 3; ++k) {
+                    const int j = (k + 1) % 3;
+                    if (in[k]) poly[np++] = cv[k];
+                    if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
+                }
+                ScreenVert sv[4]; bool ok = true;
+                for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], W, H, &sv[k]);
+                if (!ok) continue;
+                raster_subtri(s, rt, sv[0], sv[1], sv[2], list == 0, key, mat, p, uv);
+                if (np == 4) raster_subtri(s, rt, sv[0], sv[2], sv[3], list == 0, key, mat, p, uv);
+            }
+        }
+    }
+    for (size_t i = 0; i < rt.packed.size(); ++i) {
+        const uint64_t v = rt.packed[i];
+        if (v == 0) { vis[i] = 0xFFFFF000u; depthOut[i] = 0.f; }
+        else { vis[i] = ((uint32_t)v - 1u) & 0x7fffffffu; depthOut[i] = u2f((uint32_t)(v >> 32)); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ G-buffer
+static inline uint32_t unorm8(float c) { if (!(c > 0.f)) return 0; if (c > 1.f) c = 1.f; return (uint32_t)floorf(c * 255.f + 0.5f); }
+static inline uint32_t pack_unorm8x4(float4 c) { return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24); }
+static inline float4 unpack_unorm8x4(uint32_t v) { return {(float)(v & 255u) / 255.f, (float)((v >> 8) & 255u) / 255.f, (float)((v >> 16) & 255u) / 255.f, (float)(v >> 24) / 255.f}; }
+static float2 OctEncode(float3 n) {                                          // geo-raster/encoding.hlsli:37-43
+    const float s = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    n = {n.x / s, n.y / s, n.z / s};
+    float2 xy = {n.x, n.y};
+    if (!(n.z >= 0.f)) xy = {(1.f - fabsf(n.y)) * (n.x >= 0.f ? 1.f : -1.f), (1.f - fabsf(n.x)) * (n.y >= 0.f ? 1.f : -1.f)};
+    return {xy.x * 0.5f + 0.5f, xy.y * 0.5f + 0.5f};
+}
+static float3 OctDecode(float2 f) {                                          // :45-53
+    f = {f.x * 2.f - 1.f, f.y * 2.f - 1.f};
+    float3 n = {f.x, f.y, (1.f - fabsf(f.x)) - fabsf(f.y)};
+    const float t = saturate(-n.z);
+    n.x += n.x >= 0.f ? -t : t; n.y += n.y >= 0.f ? -t : t;
+    return normalize(n);
+}
+static inline float3 mul_vec3_m3(float3 v, const float r0[3], const float r1[3], const float r2[3]) {     // mul(v, float3x3(rows))
+    return {(v.x * r0[0] + v.y * r1[0]) + v.z * r2[0], (v.x * r0[1] + v.y * r1[1]) + v.z * r2[1], (v.x * r0[2] + v.y * r1[2]) + v.z * r2[2]};
+}
+// gbuffer-compute.hlsl:157-253 cs_main (USING_MESHLETS = 1)
+static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const uint32_t* vis, uint32_t* g0, uint32_t* g1, uint32_t* g2,
+                         uint32_t* color, int rounding) {
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 viewProj = to_mat4(vc.view_proj_transform);
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        color[i] = 0;                                              // gbuffer-compute-pass.inl:94-100 clear
+        const uint32_t v = vis[i];
+        if (v == 0xFFFFF000u) { g0[i] = 0; g1[i] = 0; g2[i] = 0; continue; }
+        const uint32_t meshletId = v >> 7, tri = v & 127u;
+        const incr_gpu_meshlet& m = s.d.meshlets[meshletId];
+        uint32_t vi[3]; meshlet_tri_verts(s, m, tri, vi);
+        const Mat4 localToWorld = mesh_local_to_world(s, m.meshIndex);
+        const Mat4 localToClip = mat_mul(localToWorld, viewProj);
+        float4 p[3]; float2 uv[3]; float3 nrm[3]; float4 tan[3];
+        for (int k = 0; k < 3; ++k) {
+            const float3 pos = GetFloat3(s, (int)vi[k], m.positionAccessor);
+            p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToClip);
+            uv[k] = GetFloat2(s, (int)vi[k], m.uvAccessor);
+            nrm[k] = GetFloat3(s, (int)vi[k], m.normalAccessor);
+            tan[k] = GetFloat4(s, (int)vi[k], m.tangentAccessor);
+        }
+        const float3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc(x, y, (float)W, (float)H));
+        float3 N = normalize(interp3(nrm[0], nrm[1], nrm[2], lam));
+        const float3 T = normalize(interp3({tan[0].x, tan[0].y, tan[0].z}, {tan[1].x, tan[1].y, tan[1].z}, {tan[2].x, tan[2].y, tan[2].z}, lam));
+        const float3 B = normalize(cross(N, T) * tan[0].w);
+        const float2 UV = interp2(uv[0], uv[1], uv[2], lam);
+        const MatProps mi = EvaluateMaterialProperties(s, s.d.materials[m.materialIndex], UV);
+        if (mi.bHasNormalmap) {
+            // tangentToWorld = mul(float3x3(T, B, N), (float3x3)localToWorld); N = normalize(mul(normalmap, tangentToWorld))
+            const float* L = localToWorld.m;
+            const float l0[3] = {L[0], L[1], L[2]}, l1[3] = {L[4], L[5], L[6]}, l2[3] = {L[8], L[9], L[10]};
+            const float3 r0 = mul_vec3_m3(T, l0, l1, l2), r1 = mul_vec3_m3(B, l0, l1, l2), r2 = mul_vec3_m3(N, l0, l1, l2);
+            const float a0[3] = {r0.x, r0.y, r0.z}, a1[3] = {r1.x, r1.y, r1.z}, a2[3] = {r2.x, r2.y, r2.z};
+            N = normalize(mul_vec3_m3(mi.normalmap, a0, a1, a2));
+        }
+        color[i] = pack_r11g11b10(mi.emissive * 20000.f, rounding);
+        g0[i] = pack_unorm8x4({mi.basecolor.x, mi.basecolor.y, mi.basecolor.z, 0.f});
+        const float2 oct = OctEncode(N);
+        g1[i] = (uint32_t)f32_to_f16(oct.x, rounding) | ((uint32_t)f32_to_f16(oct.y, rounding) << 16);
+        g2[i] = pack_unorm8x4({mi.metallic, mi.roughness, mi.ao, mi.aoblend});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ deferred lighting
+struct GBufferPixel { float3 basecolor, N; float metallic, roughness, ao, aoBlend; };
+static inline GBufferPixel read_gbuffer(const incr_lighting_inputs& in, size_t i) {
+    GBufferPixel g;
+    const float4 b = unpack_unorm8x4(in.gbuffer_basecolor[i]);
+    g.basecolor = in.lighting_only ? f3(0.5f) : f3(b.x, b.y, b.z);
+    const uint32_t n = in.gbuffer_normals[i];
+    g.N = OctDecode({f16_to_f32((uint16_t)(n & 0xffffu)), f16_to_f32((uint16_t)(n >> 16))});
+    const float4 m = unpack_unorm8x4(in.gbuffer_metallic_roughness_ao[i]);
+    g.metallic = m.x; g.roughness = m.y; g.ao = m.z; g.aoBlend = m.w;
+    return g;
+}
+static inline float2 screen_pos(uint32_t x, uint32_t y, uint32_t W, uint32_t H) {       // dispatchThreadId.xy / res; 2 s - 1 (no half-pixel offset)
+    return {2.f * ((float)x / (float)W) - 1.f, 2.f * ((float)y / (float)H) - 1.f};
+}
+static inline float3 unproject(float2 sp, float depth, const Mat4& inv) {
+    const float4 w = mul_vec4({sp.x, -sp.y, depth, 1.f}, inv);
+    return {w.x / w.w, w.y / w.w, w.z / w.w};
+}
+// lightPropertiesBuffer / lightTransformsBuffer are both indexed with the GLOBAL light index (direct-lighting.hlsl:73-74,
+// clustered-lighting.hlsl:100-108); an index past the end of a buffer reads zeros (D3D robust buffer access)
+static inline void load_global_light(const Scene& s, uint32_t index, incr_light* light, Mat4* transform) {
+    memset(light, 0, sizeof *light); memset(transform, 0, sizeof *transform);
+    if (index < s.d.num_global_lights) *light = s.d.global_lights[index];
+    if (index < s.d.num_scene_lights) *transform = to_mat4(s.d.light_transforms[index]);
+}
+static inline void add_color(uint32_t* color, size_t i, float3 radiance, int rounding) {   // colorTarget[xy] += radiance on R11G11B10_FLOAT
+    color[i] = pack_r11g11b10(unpack_r11g11b10(color[i]) + radiance, rounding);
+}
+
+// shaders/lighting/direct-lighting.hlsl:31-85
+static void direct_lighting(const Scene& s, const incr_lighting_inputs& in, int sunIndex, uint64_t* shadowRays) {
+    const incr_view_constants& vc = *in.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 ivp = to_mat4(vc.inv_view_proj_transform);
+    const float3 eye = {vc.eye_pos[0], vc.eye_pos[1], vc.eye_pos[2]};
+    incr_light light; Mat4 lightTransform;
+    load_global_light(s, (uint32_t)sunIndex, &light, &lightTransform);
+    RayStats rs;
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const GBufferPixel g = read_gbuffer(in, i);
+        const float3 worldPos = unproject(screen_pos(x, y, W, H), in.depth_buffer[i], ivp);
+        const float3 V = normalize(eye - worldPos);
+        const float3 radiance = GetDirectRadiance(s, light, lightTransform, worldPos, g.basecolor, g.metallic, g.roughness, g.N, V, false, &rs);
+        add_color(in.color_target, i, radiance, in.storage_rounding);
+    }
+    if (shadowRays) *shadowRays += rs.lightShadow;
+}
+
+// shaders/lighting/clustered-lighting.hlsl:35-115 + common/cluster-culling.hlsli:26-41
+static void clustered_lighting(const Scene& s, const incr_lighting_inputs& in, const uint32_t* lists, const incr_light_grid_data* lightGrid,
+                               const uint32_t grid[3], float depthExtent, int requiresClear) {
+    const incr_view_constants& vc = *in.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 ivp = to_mat4(vc.inv_view_proj_transform), ip = to_mat4(vc.inv_proj_transform);
+    const float3 eye = {vc.eye_pos[0], vc.eye_pos[1], vc.eye_pos[2]};
+    const float scale = (float)grid[2] / logf(depthExtent / vc.near_plane);          // clustered-lighting.inl:88,102
+    const float bias = -scale * logf(vc.near_plane);
+    const float gridResX = (float)W / (float)grid[0], gridResY = (float)H / (float)grid[1];
+    const uint32_t numClusters = grid[0] * grid[1] * grid[2];
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        if (requiresClear) in.color_target[i] = 0;                                    // clustered-lighting.inl:108-117
+        const GBufferPixel g = read_gbuffer(in, i);
+        float2 sp = screen_pos(x, y, W, H); sp.y = -sp.y;
+        const float depth = in.depth_buffer[i];
+        const float4 wp = mul_vec4({sp.x, sp.y, depth, 1.f}, ivp);
+        const float3 worldPos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+        const float4 vp = mul_vec4({sp.x, sp.y, depth, 1.f}, ip);
+        const float viewZ = vp.z / vp.w;
+        const uint32_t cx = ftou((float)x / gridResX), cy = ftou((float)y / gridResY);
+        const uint32_t cz = ftou(floorf(logf(viewZ) * scale + bias));
+        const uint32_t clusterId = ftou(((float)(grid[0] * grid[1]) * (float)cz + (float)grid[0] * (float)cy) + (float)cx);
+        const float3 V = normalize(eye - worldPos);
+        float3 radiance = {0, 0, 0};
+        const uint32_t count = clusterId < numClusters ? lightGrid[clusterId].count : 0u;   // out-of-bounds buffer loads return 0
+        const uint32_t offset = clusterId < numClusters ? lightGrid[clusterId].offset : 0u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t lightIndex = lists[offset + k];
+            incr_light light; Mat4 lightTransform;
+            load_global_light(s, lightIndex, &light, &lightTransform);
+            if (light.range == 0) light.range = kMaxLightRange;
+            radiance += GetDirectRadiance(s, light, lightTransform, worldPos, g.basecolor, g.metallic, g.roughness, g.N, V, false, nullptr);
+        }
+        add_color(in.color_target, i, radiance, in.storage_rounding);
+    }
+}
+
+// shaders/image-based-lighting/spherical-harmonics/common.hlsli:56-126
+static float3 ShIrradiance(float3 n, const float3 sh[9]) {
+    static const float K[9] = {0.282095f, 0.488603f, 0.488603f, 0.488603f, 1.092548f, 1.092548f, 0.315392f, 1.092548f, 0.546274f};
+    static const float A[3] = {3.14159265f, 2.094395f, 0.785398f};
+    float v[9];
+    v[0] = K[0];
+    v[1] = K[1] * n.y; v[2] = K[2] * n.z; v[3] = K[3] * n.x;
+    v[4] = (K[4] * n.x) * n.y; v[5] = (K[5] * n.y) * n.z; v[6] = K[6] * ((3.0f * n.z) * n.z - 1.0f); v[7] = (K[7] * n.x) * n.z; v[8] = K[8] * (n.x * n.x - n.y * n.y);
+    float c[9];
+    c[0] = v[0] * A[0]; c[1] = v[1] * A[1]; c[2] = v[2] * A[1]; c[3] = v[3] * A[1];
+    for (int i = 4; i < 9; ++i) c[i] = v[i] * A[2];
+    float3 irr = {0, 0, 0};
+    for (int i = 0; i < 9; ++i) irr += sh[i] * c[i];
+    return irr;
+}
+// shaders/lighting/sky-lighting.hlsl:36-119 with g_envmapIndex == -1 (no specular IBL inputs this round)
+static void sky_lighting(const Scene& s, const incr_lighting_inputs& in, const float* sh9rgba, const uint8_t* aoTex, float skyBrightness, int diffuseIbl) {
+    (void)s;
+    const incr_view_constants& vc = *in.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    float3 sh[9];
+    if (sh9rgba) for (int k = 0; k < 9; ++k) sh[k] = {sh9rgba[k * 4], sh9rgba[k * 4 + 1], sh9rgba[k * 4 + 2]};
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const GBufferPixel g = read_gbuffer(in, i);
+        float3 radiance = {0, 0, 0};
+        if (diffuseIbl && sh9rgba) {
+            const float3 albedo = (1.f - g.metallic) * g.basecolor;
+            const float3 shDiffuse = ((albedo * Fd_Lambert()) * ShIrradiance(g.N, sh)) * 5.f;
+            const float3 occluded = g.ao * shDiffuse;
+            radiance += skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));      // lerp(a, b, t) = a + t (b - a)
+        }
+        const float hbao = aoTex ? (float)aoTex[i] / 255.f : 1.f;
+        add_color(in.color_target, i, hbao * radiance, in.storage_rounding);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ TAA resolve
+static inline float3 load_hdr(const uint32_t* img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {       // Texture2D.Load: out of bounds -> 0
+    if (x >= W || y >= H) return {0, 0, 0};
+    return unpack_r11g11b10(img[(size_t)y * W + x]);
+}
+static float3 sample_bilinear_clamp(const uint32_t* img, uint32_t W, uint32_t H, float2 uv) {
+    float u = uv.x, v = uv.y;
+    if (!(u == u)) u = 0.f;
+    if (!(v == v)) v = 0.f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = fminf(fmaxf(x, -1.f), (float)W); y = fminf(fmaxf(y, -1.f), (float)H);
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    auto cl = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
+    const int x0 = cl((int)x0f, (int)W), x1 = cl((int)x0f + 1, (int)W), y0 = cl((int)y0f, (int)H), y1 = cl((int)y0f + 1, (int)H);
+    const float3 t00 = load_hdr(img, W, H, x0, y0), t10 = load_hdr(img, W, H, x1, y0), t01 = load_hdr(img, W, H, x0, y1), t11 = load_hdr(img, W, H, x1, y1);
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
+}
+static inline float lum_weight(float3 c) { return 1.f / (1.f + ((c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f)); }
+// shaders/postprocess/taa-resolve.hlsl:34-117 (history read from `in`, result written to `out`)
+static void taa_resolve(const incr_view_constants& vc, const uint32_t* hdr, const uint32_t* histIn, uint32_t* histOut, const float* depthTex,
+                        uint32_t historyIndex, int rounding) {
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 inv = to_mat4(vc.taa_inv_view_proj), prev = to_mat4(vc.prev_view_proj_transform);
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const float3 cur = unpack_r11g11b10(hdr[i]);
+        if (historyIndex == 0) { histOut[i] = pack_r11g11b10(cur, rounding); continue; }
+        const float2 uv = {((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
+        const float4 clip = {2.f * uv.x - 1.f, -2.f * uv.y + 1.f, depthTex[i], 1.f};
+        const float4 world = mul_vec4(clip, inv);
+        float4 pc = mul_vec4(world, prev);
+        pc = {pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, pc.w / pc.w};
+        const float2 ruv = {0.5f * pc.x + 0.5f, -0.5f * pc.y + 0.5f};
+        const float3 previous = sample_bilinear_clamp(histIn, W, H, ruv);
+        float3 mn = f3(10000.f), mx = f3(-10000.f);
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) {
+            const float3 c = load_hdr(hdr, W, H, ftou((float)x + (float)dx), ftou((float)y + (float)dy));
+            mn = {hmin(mn.x, c.x), hmin(mn.y, c.y), hmin(mn.z, c.z)};
+            mx = {hmax(mx.x, c.x), hmax(mx.y, c.y), hmax(mx.z, c.z)};
+        }
+        const float3 clamped = {hmin(hmax(previous.x, mn.x), mx.x), hmin(hmax(previous.y, mn.y), mx.y), hmin(hmax(previous.z, mn.z), mx.z)};
+        const float cw = 0.1f * lum_weight(cur), pw = 0.9f * lum_weight(clamped);
+        float3 out = cur * cw + clamped * pw;
+        out = out / (cw + pw);
+        histOut[i] = pack_r11g11b10(out, rounding);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C exports
+extern "C" {
+void orc_pixel_jitter(uint32_t frameIndex, uint32_t resX, uint32_t resY, float out[2]) {       // renderer.cpp:126-131
+    const uint32_t i = frameIndex % 16u;
+    out[0] = 2.f * (RasterHalton(i, 2) - 0.5f) / (float)resX;
+    out[1] = 2.f * (RasterHalton(i, 3) - 0.5f) / (float)resY;
+}
+void orc_view_constants(const incr_view* view, const incr_view* cull, const float jitter[2], const incr_matrix* prev, float nearPlane,
+                        uint32_t resX, uint32_t resY, incr_view_constants* out) { make_view_constants(view, cull, jitter, prev, nearPlane, resX, resY, out); }
+void orc_batch_cull(void* scene, const incr_batch_cull_desc* d, int32_t* culled) {
+    batch_cull(*(Scene*)scene, *d->view, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, culled);
+}
+void orc_light_cull(void* scene, const incr_light_cull_desc* d, int32_t* culled) {
+    light_cull(*(Scene*)scene, *d->view, d->cluster_dim, d->max_lights_per_cluster, d->cluster_depth_extent, d->culled_light_lists, d->light_grid,
+               d->culled_light_count, culled);
+}
+void orc_visibility(void* scene, const incr_visibility_desc* d) {
+    visibility_pass(*(Scene*)scene, *d->view, d->default_list, d->double_sided_list, d->counts, d->vis_buffer, d->depth_buffer);
+}
+void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
+    gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding);
+}
+void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {
+    sky_lighting(*(Scene*)scene, d->in, d->sh9_rgba, d->ambient_occlusion, d->sky_brightness, d->diffuse_ibl);
+}
+void orc_direct_lighting(void* scene, const incr_direct_lighting_desc* d, uint64_t* shadowRays) {
+    direct_lighting(*(Scene*)scene, d->in, d->directional_light_index, shadowRays);
+}
+void orc_clustered_lighting(void* scene, const incr_clustered_lighting_desc* d) {
+    clustered_lighting(*(Scene*)scene, d->in, d->culled_light_lists, d->light_grid, d->cluster_dim, d->cluster_depth_extent, d->requires_clear);
+}
+void orc_taa_resolve(const incr_taa_resolve_desc* d) {
+    taa_resolve(*d->view, d->hdr_scene_color, d->history_in, d->history_out, d->depth_buffer, d->history_index, d->storage_rounding);
+}
+void orc_oct_roundtrip(const float n[3], float enc[2], float dec[3]) {
+    const float2 e = OctEncode({n[0], n[1], n[2]}); enc[0] = e.x; enc[1] = e.y;
+    const float3 d = OctDecode(e); dec[0] = d.x; dec[1] = d.y; dec[2] = d.z;
+}
+} // extern "C"

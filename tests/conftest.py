@@ -39,6 +39,11 @@ def rt():
 
 
 @pytest.fixture(scope="session")
+def R():
+    return mod("raster")
+
+
+@pytest.fixture(scope="session")
 def ob():
     from oracle import binding
     binding.lib()
@@ -47,7 +52,8 @@ def ob():
 
 @pytest.fixture(scope="session")
 def helmet(sio):
-    return sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+    s = sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+    return mod("raster").generate_meshlets(s)          # FScene::GenerateMeshlets at load time (scene.cpp:197)
 
 
 @pytest.fixture(scope="session")
@@ -58,7 +64,7 @@ def helmet_oracle(ob, helmet):
 @pytest.fixture(scope="session")
 def sponza_small(synth):
     """Sponza-stat at 1/16 of the triangle budget with 64^2 textures (seconds on the CPU oracle)."""
-    return synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0)
+    return mod("raster").generate_meshlets(synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0))
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,178 @@
+"""GPU parity of the raster path: every pass of libincr_hip.so against the CPU oracle on the same seeded inputs.
+Integer / id / byte surfaces must be bit-identical; float surfaces (R11G11B10 colour) may differ where device
+transcendental functions (cosf of spot-light angles, logf of the cluster slice) round differently: the bound is one
+code step of the storage format, stated in each test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_raster_host_and_oracle import DEFAULT_SH9, run_oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+INT_SURFACES = ("vis", "gbuffer_basecolor", "gbuffer_normals", "gbuffer_mra")
+
+
+def gpu_frame(rt, R, ctx, gscene, view, W, H, cfg, frames=1, sh9=DEFAULT_SH9, storage_rounding=0):
+    rr = R.RasterRenderer(ctx, gscene, W, H, cfg)
+    rr.set_sh9(sh9)
+    out = []
+    for _ in range(frames):
+        vc = rr.render(view, storage_rounding=storage_rounding)
+        ctx.synchronize()
+        names = list(R.RasterSurfaces.SPECS) + ["default_list", "double_sided_list", "counts", "render_stats", "light_lists", "light_grid", "light_count", "ray_stats"]
+        out.append((vc, {n: rr.surf.download(n) for n in names}))
+    rr.close()
+    return out
+
+
+def colour_close(ob, a, b, what):
+    """R11G11B10 surfaces: identical bits, or within one 5-bit-mantissa step on pixels that went through cosf / logf."""
+    same = a == b
+    if same.all():
+        return 1.0
+    fa, fb = ob.unpack_r11g11b10(a), ob.unpack_r11g11b10(b)
+    fin = np.isfinite(fa) & np.isfinite(fb)
+    assert (np.isfinite(fa) == np.isfinite(fb)).all(), what
+    err = np.abs(fa - fb)[fin]
+    ref = np.maximum(np.abs(fb)[fin], 1e-3)
+    assert (err <= ref * 2.0 ** -4).all(), "%s: max rel err %g" % (what, (err / ref).max())
+    return same.mean()
+
+
+@pytest.mark.parametrize("which,W,H", [("helmet", 256, 256), ("sponza_small", 320, 180), ("sponza_small", 203, 117)])
+def test_raster_frame_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, H):
+    scene = request.getfixturevalue(which)
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    osc = ob.OracleScene(scene)
+    try:
+        g = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, A.FConfig, frames=2)
+        prev, hs = None, None
+        for frame, (vc, gs) in enumerate(g):
+            vco, hs = run_oracle_frame(ob, R, A, scene, osc, view, W, H, frame_index=frame, prev=prev, hs=hs)
+            prev = R.matrix_to_numpy(vco.unjittered_view_proj)
+            o = hs.arr
+            # culling: bit-exact lists, counts, statistics
+            np.testing.assert_array_equal(gs["counts"], o["counts"])
+            for name, n in (("default_list", o["counts"][0]), ("double_sided_list", o["counts"][1])):
+                np.testing.assert_array_equal(gs[name][:n], o[name][:n])
+            np.testing.assert_array_equal(gs["render_stats"], o["render_stats"])
+            if len(scene.global_lights) > 1:
+                np.testing.assert_array_equal(gs["light_grid"], o["light_grid"])
+                np.testing.assert_array_equal(gs["light_count"], o["light_count"])
+                for c in np.nonzero(o["light_grid"][:, 1])[0]:
+                    np.testing.assert_array_equal(gs["light_lists"][c, :o["light_grid"][c, 1]], o["light_lists"][c, :o["light_grid"][c, 1]])
+            # visibility + depth + G-buffer: bit-exact
+            np.testing.assert_array_equal(gs["vis"], o["vis"])
+            np.testing.assert_array_equal(gs["depth"].view(np.uint32), o["depth"].view(np.uint32))
+            for name in INT_SURFACES[1:]:
+                np.testing.assert_array_equal(gs[name], o[name], err_msg=name)
+            # lighting + TAA
+            frac = colour_close(ob, gs["color"], o["color"], "colour target")
+            assert frac > 0.999, frac
+            frac = colour_close(ob, gs["taa%d" % (frame & 1)], o["taa%d" % (frame & 1)], "taa")
+            assert frac > 0.995, frac
+            assert gs["ray_stats"].light_shadow_rays == int(o["ray_stats"][3])
+            # tonemap of the TAA output: +-1 LSB (powf in the sRGB encode)
+            ldr = ob.tonemap(o["taa%d" % (frame & 1)], A.FConfig.Exposure, 0)
+            got = gs["ldr"].view(np.uint8).reshape(H, W, 4)
+            assert np.abs(got.astype(np.int32) - ldr.astype(np.int32)).max() <= 1 + 8 * (frac < 1.0)
+    finally:
+        osc.close(); gscene.close()
+
+
+def test_raster_options_and_edges(rt, R, ob, A, sio, gpu_ctx, sponza_small, synth):
+    W, H = 160, 90
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+
+    class Cfg(A.FConfig):
+        FrustumCulling = False
+        EnableTAA = False
+        Viewmode = 1                  # LightingOnly: basecolor 0.5, no jitter
+    gscene = gpu_ctx.create_scene(sponza_small)
+    osc = ob.OracleScene(sponza_small)
+    try:
+        (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, Cfg, storage_rounding=1)
+        assert vc.jitter[0] == 0 and vc.jitter[1] == 0
+        vco, hs = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H, cfg=Cfg)
+        # the oracle run above used storage_rounding 0: redo the float stores with rounding 1
+        for name, d in R.build_descs(None, sponza_small, vco, hs.ptr, 0, Cfg, storage_rounding=1):
+            ob.run_pass(osc, name, d)
+        assert gs["render_stats"][0] == 0 and gs["counts"].sum() == sponza_small.num_meshlets
+        np.testing.assert_array_equal(gs["vis"], hs.arr["vis"])
+        np.testing.assert_array_equal(gs["gbuffer_normals"], hs.arr["gbuffer_normals"])
+        assert colour_close(ob, gs["color"], hs.arr["color"], "colour (RNE stores)") > 0.999
+    finally:
+        osc.close(); gscene.close()
+    # hidden meshes draw nothing: every surface keeps its clear value
+    hidden = synth.sponza_stat(texture_size=8, tri_scale=1 / 64.0, with_lights=False)
+    R.generate_meshlets(hidden)
+    hidden.mesh_visibility = [0] * len(hidden.mesh_primitives)
+    gscene = gpu_ctx.create_scene(hidden)
+    try:
+        (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, A.FConfig)
+        assert gs["counts"].sum() == 0 and gs["render_stats"][0] == 0
+        assert (gs["vis"] == 0xFFFFF000).all() and (gs["depth"] == 0).all() and (gs["gbuffer_basecolor"] == 0).all()
+    finally:
+        gscene.close()
+
+
+def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
+    gscene = gpu_ctx.create_scene(helmet)
+    try:
+        view = sio.FView().reset(helmet, aspect=1.0)
+        vc = R.make_view_constants(view, 64, 64)
+        lib = gpu_ctx.lib
+        d = A.VisibilityDesc(); d.scene, d.view = gscene.handle, C.pointer(vc)
+        assert lib.incr_visibility(gpu_ctx.handle, C.byref(d), None) == -1 and b"NULL" in lib.incr_last_error()
+        d = A.LightCullDesc(); d.scene, d.view = gscene.handle, C.pointer(vc)
+        buf = gpu_ctx.buffer(1 << 20)
+        d.culled_light_lists = d.light_grid = d.culled_light_count = buf
+        d.cluster_dim[:] = (16, 9, 100); d.max_lights_per_cluster = 64; d.cluster_depth_extent = 200.0
+        assert lib.incr_light_cull(gpu_ctx.handle, C.byref(d), None) == -1 and b"cluster grid" in lib.incr_last_error()
+        t = A.TaaResolveDesc(); t.view = C.pointer(vc)
+        t.hdr_scene_color = t.history_in = t.history_out = t.depth_buffer = buf; t.history_index = 1
+        assert lib.incr_taa_resolve(gpu_ctx.handle, C.byref(t), None) == -1 and b"alias" in lib.incr_last_error()
+        dl = A.DirectLightingDesc(); dl.inp = R.lighting_inputs(gscene.handle, vc, dict(color=buf, depth=buf, gbuffer_basecolor=buf, gbuffer_normals=buf, gbuffer_mra=buf))
+        dl.directional_light_index = -1
+        assert lib.incr_direct_lighting(gpu_ctx.handle, C.byref(dl), None) == -1
+        gpu_ctx.free(buf)
+    finally:
+        gscene.close()
+
+
+def test_raster_4k_properties(rt, R, ob, A, sio, gpu_ctx, synth):
+    """Full-size frame (BASELINE config 3 shape: Sponza statistics at 3840x2160): size-independent properties."""
+    scene = synth.sponza_stat(texture_size=256)
+    R.generate_meshlets(scene)
+    W, H = 3840, 2160
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    try:
+        class NoCull(A.FConfig):
+            FrustumCulling = False
+        (vc, a), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, A.FConfig)
+        (_, b), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, NoCull)
+        # conservative culling: identical visibility with and without it; determinism run to run
+        np.testing.assert_array_equal(a["vis"], b["vis"])
+        (_, c), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, A.FConfig)
+        for n in ("vis", "depth", "color", "taa0", "ldr"):
+            np.testing.assert_array_equal(a[n], c[n], err_msg=n)
+        vis = a["vis"]
+        covered = vis != 0xFFFFF000
+        assert covered.mean() > 0.95
+        ml, vi, tri = scene.meshlets
+        mid = vis[covered] >> 7
+        assert mid.max() < scene.num_meshlets
+        tcount = np.array([m.triangleCount for m in ml[:scene.num_meshlets]])
+        assert ((vis[covered] & 127) < tcount[mid]).all()
+        # every id in the buffer belongs to a meshlet that survived culling
+        n_def, n_ds = a["counts"]
+        alive = np.zeros(scene.num_meshlets, bool)
+        alive[a["default_list"][:n_def, 0]] = True; alive[a["double_sided_list"][:n_ds, 0]] = True
+        assert alive[np.unique(mid)].all()
+        assert (a["depth"][covered] > 0).all() and (a["depth"][~covered] == 0).all() and a["depth"].max() <= 1
+    finally:
+        gscene.close()

@@ -1,0 +1,218 @@
+"""Raster half on the CPU: the host meshlet builder, the per-frame view constants, and the raster oracle checked against
+the ray-casting oracle (two independent restatements must agree on what is visible).  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+DEFAULT_SH9 = np.array([[1.0, 1.1, 1.3], [0.3, 0.3, 0.35], [0.1, 0.1, 0.2], [-0.05, -0.04, -0.02], [0.02, 0.02, 0.03],
+                        [0.04, 0.05, 0.05], [-0.03, -0.03, -0.02], [0.01, 0.02, 0.02], [0.05, 0.04, 0.03]], dtype=np.float32)
+
+
+def meshlet_triangles(scene):
+    """Decode every meshlet triangle to its three ORIGINAL vertex indices, in the order the shaders read them
+    (visibility-pass.hlsl:78: packed fields high to low)."""
+    ml, vi, tri = scene.meshlets
+    out = []
+    for k in range(scene.num_meshlets):
+        m = ml[k]
+        p = tri[m.triangleBegin:m.triangleBegin + m.triangleCount]
+        loc = np.stack([(p >> 20) & 0xff, (p >> 10) & 0xff, p & 0xff], axis=1)
+        assert (loc < m.vertexCount).all()
+        out.append(vi[m.vertexBegin + loc])
+    return out
+
+
+@pytest.mark.parametrize("which", ["helmet", "sponza_small"])
+def test_meshletize_invariants(request, which):
+    scene = request.getfixturevalue(which)
+    ml, vi, tri = scene.meshlets
+    per_meshlet = meshlet_triangles(scene)
+    # every primitive triangle appears exactly once, with its original winding (rotation aside)
+    k = 0
+    for mesh_index, prims in enumerate(scene.mesh_primitives):
+        for p in prims:
+            stride = scene.accessors[p["index"]][2]
+            idx = scene.accessor_array(p["index"], np.uint16 if stride == 2 else np.uint32, 1, p["index_count"]).astype(np.uint32).reshape(-1, 3)
+            got = []
+            while k < scene.num_meshlets and ml[k].meshIndex == mesh_index and ml[k].positionAccessor == p["position"] and ml[k].materialIndex == p["material"] \
+                    and len(got) < len(idx):
+                m = ml[k]
+                assert 1 <= m.vertexCount <= 64 and 1 <= m.triangleCount <= 126            # scene.cpp:1545-1546
+                assert len(np.unique(vi[m.vertexBegin:m.vertexBegin + m.vertexCount])) == m.vertexCount
+                got.append(per_meshlet[k]); k += 1
+            got = np.concatenate(got)
+            assert got.shape == idx.shape
+
+            def canon(t):      # rotate each triple so that its smallest index comes first (keeps the winding)
+                r = np.argmin(t, axis=1)
+                return np.stack([t[np.arange(len(t)), (r + j) % 3] for j in range(3)], axis=1)
+            a, b = canon(got), canon(idx)
+            a = a[np.lexsort(a.T[::-1])]; b = b[np.lexsort(b.T[::-1])]
+            np.testing.assert_array_equal(a, b)
+    assert k == scene.num_meshlets
+    # bounding spheres enclose their vertices
+    for k in range(0, scene.num_meshlets, max(1, scene.num_meshlets // 50)):
+        m = ml[k]
+        nverts = int(vi[m.vertexBegin:m.vertexBegin + m.vertexCount].max()) + 1
+        pos = scene.accessor_array(m.positionAccessor, np.float32, 3, nverts)[vi[m.vertexBegin:m.vertexBegin + m.vertexCount]]
+        c, r = np.array(m.boundingSphere[:3]), m.boundingSphere[3]
+        assert (np.linalg.norm(pos - c, axis=1) <= r * (1 + 1e-4) + 1e-6).all()
+    # meshlets are reasonably full (greedy growth along adjacency, not one triangle each)
+    assert tri.size / scene.num_meshlets > 20
+
+
+def test_meshletize_rejects_bad_input(rt):
+    lib = rt.load()
+    h = C.c_void_p()
+    idx = np.array([0, 1, 5], dtype=np.uint32); pos = np.zeros((3, 3), dtype=np.float32)
+    assert lib.incr_meshletize(idx.ctypes.data, 3, pos.ctypes.data, 3, 12, 64, 126, C.byref(h)) == -1      # index out of range
+    assert lib.incr_meshletize(idx.ctypes.data, 2, pos.ctypes.data, 3, 12, 64, 126, C.byref(h)) == -1      # not a multiple of 3
+    assert lib.incr_meshletize(None, 0, None, 0, 12, 64, 126, C.byref(h)) == 0                              # empty input -> empty set
+    assert lib.incr_meshlet_set_counts(h, None, None) == 0
+    lib.incr_meshlet_set_free(h)
+    # degenerate + duplicate triangles survive
+    idx = np.array([0, 1, 2, 0, 1, 2, 1, 1, 2], dtype=np.uint32)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    assert lib.incr_meshletize(idx.ctypes.data, 9, pos.ctypes.data, 3, 12, 64, 126, C.byref(h)) == 0
+    nv, nt = C.c_uint32(), C.c_uint32()
+    assert lib.incr_meshlet_set_counts(h, C.byref(nv), C.byref(nt)) >= 1 and nt.value == 3
+    lib.incr_meshlet_set_free(h)
+
+
+def test_view_constants_host_matches_oracle(helmet, sio, R, ob, A):
+    view = sio.FView().reset(helmet, aspect=16 / 9)
+    W, H = 640, 360
+    for frame in (0, 1, 7, 15, 16, 33):
+        j, jo = R.pixel_jitter(frame, W, H), ob.pixel_jitter(frame, W, H)
+        np.testing.assert_array_equal(j.view(np.uint32), jo.view(np.uint32))
+        assert abs(j[0]) <= 1.0 / W and abs(j[1]) <= 1.0 / H
+        prev = R.matrix_to_numpy(R.make_view_constants(view, W, H).unjittered_view_proj)
+        vc, vo = R.make_view_constants(view, W, H, j, prev), ob.view_constants(view, W, H, j, prev)
+        for name, _ in A.ViewConstants._fields_[:12]:
+            a, b = R.matrix_to_numpy(getattr(vc, name)), R.matrix_to_numpy(getattr(vo, name))
+            # products are bit-identical; inverses go through double and one rounding in both implementations
+            if "inv" in name:
+                np.testing.assert_allclose(a, b, rtol=2e-7, atol=1e-12)
+            else:
+                np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert R.pixel_jitter(0, W, H)[0] == np.float32(-1.0 / W) and (R.pixel_jitter(16, W, H) == R.pixel_jitter(0, W, H)).all()
+    # V * (P * T) really is the jittered projection: NDC shifts by the jitter
+    vc = R.make_view_constants(view, W, H, (0.25, -0.5))
+    p0, p1 = R.matrix_to_numpy(R.make_view_constants(view, W, H).view_proj_transform), R.matrix_to_numpy(vc.view_proj_transform)
+    pt = np.array([0.3, 0.2, 4.0, 1.0], dtype=np.float32) @ np.linalg.inv(R.matrix_to_numpy(vc.view_transform).astype(np.float64))
+    a, b = pt @ p0.astype(np.float64), pt @ p1.astype(np.float64)
+    np.testing.assert_allclose(b[:2] / b[3] - a[:2] / a[3], [0.25, -0.5], atol=1e-5)
+
+
+def run_oracle_frame(ob, R, A, scene, oscene, view, W, H, frame_index=0, prev=None, cfg=None, hs=None, sh9=DEFAULT_SH9, jitter=None):
+    cfg = cfg or A.FConfig
+    if jitter is None:
+        jitter = R.pixel_jitter(frame_index, W, H) if cfg.EnableTAA and cfg.Viewmode == 0 else (0.0, 0.0)
+    vc = R.make_view_constants(view, W, H, jitter, prev, cfg.CameraNearPlane)
+    if hs is None:
+        hs = ob.HostSurfaces(W, H, scene.num_meshlets, cfg.LightClusterDimX * cfg.LightClusterDimY * cfg.LightClusterDimZ, cfg.MaxLightsPerCluster)
+        hs.arr["sh9"][:, :3] = sh9
+    for name, d in R.build_descs(None, scene, vc, hs.ptr, frame_index, cfg):
+        ob.run_pass(oscene, name, d)
+    return vc, hs
+
+
+def pinhole_rays(R, vc, W, H):
+    ivp = R.matrix_to_numpy(vc.inv_view_proj_transform).astype(np.float64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    px = (xs.ravel() + 0.5) / W * 2 - 1; py = -((ys.ravel() + 0.5) / H * 2 - 1)
+    wp = np.stack([px, py, np.full_like(px, 0.5), np.ones_like(px)], 1) @ ivp
+    wp = wp[:, :3] / wp[:, 3:4]
+    eye = np.array(list(vc.eye_pos), dtype=np.float64)
+    d = wp - eye
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.tile(eye, (W * H, 1)).astype(np.float32), d.astype(np.float32)
+
+
+def test_visibility_oracle_agrees_with_ray_casting(helmet, sio, R, ob, A):
+    """The rasteriser restatement and the ray caster restatement are independent: same front-face rule, same triangle."""
+    W = H = 160
+    osc = ob.OracleScene(helmet)
+    view = sio.FView().reset(helmet, aspect=1.0)
+    vc, hs = run_oracle_frame(ob, R, A, helmet, osc, view, W, H, jitter=(0.0, 0.0))
+    vis, depth = hs.arr["vis"], hs.arr["depth"]
+    covered = vis != 0xFFFFF000
+    assert hs.arr["counts"][0] == helmet.num_meshlets and hs.arr["counts"][1] == 0          # single-sided material
+    o, d = pinhole_rays(R, vc, W, H)
+    ids, tuv = osc.trace_rays(o, d, 0.001, 10000.0)
+    hit = (ids[:, 0] != 0).reshape(H, W)
+    assert (covered == hit).mean() > 0.999
+    ml, vi, tri = helmet.meshlets
+    prim = helmet.mesh_primitives[0][0]
+    idx = helmet.accessor_array(prim["index"], np.uint16, 1, prim["index_count"]).astype(np.uint32).reshape(-1, 3)
+    both = covered & hit
+    m_id, t_id = (vis >> 7)[both], (vis & 127)[both]
+    begin_v = np.array([ml[int(k)].vertexBegin for k in m_id]); begin_t = np.array([ml[int(k)].triangleBegin for k in m_id])
+    p = tri[begin_t + t_id]
+    got = vi[begin_v[:, None] + np.stack([(p >> 20) & 0xff, (p >> 10) & 0xff, p & 0xff], axis=1)]
+    want = idx[ids[:, 3].reshape(H, W)[both]]
+    assert (got == want).all(axis=1).mean() > 0.99
+    # reverse-Z infinite projection: depth = near / view-space z
+    look = np.array(list(view.to_ctypes().look), dtype=np.float64)
+    vz = ((d.astype(np.float64) @ look) * tuv[:, 0]).reshape(H, W)
+    assert np.abs(depth[both] - 1.0 / vz[both]).max() < 2e-3
+    assert (depth[~covered] == 0).all() and depth.max() <= 1.0
+    # G-buffer of covered pixels: unit normals after the octahedral round trip, emissive in the colour target
+    g1 = hs.arr["gbuffer_normals"][covered]
+    oct_ = np.stack([(g1 & 0xffff).astype(np.uint16).view(np.float16), (g1 >> 16).astype(np.uint16).view(np.float16)], axis=1).astype(np.float32)
+    assert ((oct_ >= 0) & (oct_ <= 1)).all()
+    assert (hs.arr["gbuffer_basecolor"][~covered] == 0).all() and (hs.arr["gbuffer_basecolor"][covered] >> 24 == 0).all()
+    osc.close()
+
+
+def test_oracle_frame_sponza_small(sponza_small, sio, R, ob, A):
+    """Lights, alpha-masked double-sided geometry and near-plane clipping (the camera stands inside the atrium)."""
+    W, H = 192, 108
+    osc = ob.OracleScene(sponza_small)
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    vc, hs = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H)
+    n_def, n_ds = hs.arr["counts"]
+    culled = hs.arr["render_stats"][0]
+    assert n_def + n_ds + culled == sponza_small.num_meshlets and n_ds > 0 and culled > 0
+    for name, n in (("default_list", n_def), ("double_sided_list", n_ds)):
+        ids = hs.arr[name][:n, 0]
+        assert (np.diff(ids.astype(np.int64)) > 0).all()                       # ascending meshlet id
+    vis = hs.arr["vis"]
+    assert (vis != 0xFFFFF000).mean() > 0.9
+    # culling is conservative: rendering with frustum culling off gives the same visibility buffer
+    class NoCull(A.FConfig):
+        FrustumCulling = False
+    _, hs2 = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H, cfg=NoCull)
+    assert hs2.arr["render_stats"][0] == 0
+    np.testing.assert_array_equal(hs2.arr["vis"], vis)
+    np.testing.assert_array_equal(hs2.arr["depth"].view(np.uint32), hs.arr["depth"].view(np.uint32))
+    # light culling: 64 punctual lights, lists hold ascending global indices, grid offsets are c * MaxLightsPerCluster
+    grid = hs.arr["light_grid"]
+    assert (grid[:, 0] == np.arange(len(grid)) * 64).all() and grid[:, 1].max() <= 64 and grid[:, 1].sum() == hs.arr["light_count"][0] > 0
+    for c in np.nonzero(grid[:, 1])[0][:50]:
+        l = hs.arr["light_lists"][c, :grid[c, 1]]
+        assert (np.diff(l.astype(np.int64)) > 0).all() and (l >= 1).all()     # light 0 is the sun: never in a cluster list
+    # lighting happened: colour target is finite and mostly non-zero on covered pixels
+    col = ob.unpack_r11g11b10(hs.arr["color"])
+    assert np.isfinite(col[vis != 0xFFFFF000]).all() and (col.sum(axis=-1) > 0).mean() > 0.5
+    assert hs.arr["ray_stats"][3] > 0                                            # the sun traced shadow rays
+    # TAA frame 0 copies the colour target
+    np.testing.assert_array_equal(hs.arr["taa0"], hs.arr["color"])
+    # second frame: history is blended (not a copy) and stays finite
+    prev = R.matrix_to_numpy(vc.unjittered_view_proj)
+    vc1, hs = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H, frame_index=1, prev=prev, hs=hs)
+    t1 = ob.unpack_r11g11b10(hs.arr["taa1"])
+    assert np.isfinite(t1[vis != 0xFFFFF000]).all() and not np.array_equal(hs.arr["taa1"], hs.arr["color"])
+    osc.close()
+
+
+def test_oct_encoding_round_trip(ob):
+    rng = np.random.default_rng(3)
+    n = rng.normal(size=(500, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    for v in n:
+        enc, dec = (C.c_float * 2)(), (C.c_float * 3)()
+        ob.lib().orc_oct_roundtrip((C.c_float * 3)(*v), enc, dec)
+        assert 0 <= enc[0] <= 1 and 0 <= enc[1] <= 1
+        np.testing.assert_allclose(np.array(dec[:]), v, atol=2e-6)

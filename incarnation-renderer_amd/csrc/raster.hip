@@ -234,11 +234,17 @@ struct SubTri {
     f2 uv0, uv1, uv2;
 };
 DI bool top_left(int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; }
-DI bool setup_subtri(ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t W, uint32_t H, SubTri* st) {
-    long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
+// Facing + culling: returns false for degenerate and culled triangles, otherwise leaves the vertices in CLOCKWISE order.
+DI bool orient_subtri(ScreenVert& v0, ScreenVert& v1, ScreenVert& v2, bool cullBack) {
+    const long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
     if (area == 0) return false;
-    if (area > 0) { if (cullBack) return false; }                 // clockwise on screen = back face (FrontCounterClockwise)
-    else { const ScreenVert t = v1; v1 = v2; v2 = t; area = -area; }
+    if (area > 0) return !cullBack;                               // clockwise on screen = back face (FrontCounterClockwise)
+    const ScreenVert t = v1; v1 = v2; v2 = t;
+    return true;
+}
+// Scan set-up of a clockwise screen triangle; false when its bounding box holds no pixel centre.
+DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, uint32_t W, uint32_t H, SubTri* st) {
+    const long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
     const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
     const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
     st->px0 = max(0, (minX + 127) >> 8); st->px1 = min((int32_t)W - 1, (maxX - 128) >> 8);
@@ -303,28 +309,28 @@ DI void raster_coop(const VisParams& P, const SubTri& st, uint32_t lane) {
                 fragment(P, st, px, py, base[0] + lx * st.sx[0] + ly * st.sy[0], base[1] + lx * st.sx[1] + ly * st.sy[1], base[2] + lx * st.sx[2] + ly * st.sy[2]);
         }
 }
-DI long long shfl_ll(long long v, int src) {
-    const int lo = __shfl((int)(uint32_t)(unsigned long long)v, src, 64), hi = __shfl((int)(uint32_t)((unsigned long long)v >> 32), src, 64);
-    return (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+// Work distribution (DESIGN.md "Visibility pass"): the set-up kernel turns every surviving screen triangle into a
+// 48-byte record and files it by bounding-box size; the scan kernel's persistent waves then pull
+//   * band items  -- <= 64 8x8 tiles of one large triangle, scanned by the whole wave (one tile per step),
+//   * whole items -- large triangles that did not fit the band queue (same scan, all bands by one wave),
+//   * small items -- 64 small triangles per wave, one per lane, scanned serially.
+// The result does not depend on the order: depth test and id write are one atomicMax on depth | order key.
+DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
+    const SubTriAlpha a = P.alphas[idx];
+    st->p0 = {a.p[0], a.p[1], a.p[2], a.p[3]}; st->p1 = {a.p[4], a.p[5], a.p[6], a.p[7]}; st->p2 = {a.p[8], a.p[9], a.p[10], a.p[11]};
+    st->uv0 = {a.uv[0], a.uv[1]}; st->uv1 = {a.uv[2], a.uv[3]}; st->uv2 = {a.uv[4], a.uv[5]};
 }
-DI SubTri shfl_subtri(const SubTri& s, int src) {
-    SubTri r;
-    r.px0 = __shfl(s.px0, src, 64); r.px1 = __shfl(s.px1, src, 64); r.py0 = __shfl(s.py0, src, 64); r.py1 = __shfl(s.py1, src, 64);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { r.e[k] = shfl_ll(s.e[k], src); r.sx[k] = shfl_ll(s.sx[k], src); r.sy[k] = shfl_ll(s.sy[k], src); r.bias[k] = __shfl(s.bias[k], src, 64); }
-    r.area = __longlong_as_double(shfl_ll(__double_as_longlong(s.area), src));
-    r.z0 = __shfl(s.z0, src, 64); r.dz1 = __shfl(s.dz1, src, 64); r.dz2 = __shfl(s.dz2, src, 64);
-    r.key = (uint32_t)__shfl((int)s.key, src, 64); r.alphaTex = __shfl(s.alphaTex, src, 64);
-    r.p0 = {__shfl(s.p0.x, src, 64), __shfl(s.p0.y, src, 64), __shfl(s.p0.z, src, 64), __shfl(s.p0.w, src, 64)};
-    r.p1 = {__shfl(s.p1.x, src, 64), __shfl(s.p1.y, src, 64), __shfl(s.p1.z, src, 64), __shfl(s.p1.w, src, 64)};
-    r.p2 = {__shfl(s.p2.x, src, 64), __shfl(s.p2.y, src, 64), __shfl(s.p2.z, src, 64), __shfl(s.p2.w, src, 64)};
-    r.uv0 = {__shfl(s.uv0.x, src, 64), __shfl(s.uv0.y, src, 64)}; r.uv1 = {__shfl(s.uv1.x, src, 64), __shfl(s.uv1.y, src, 64)};
-    r.uv2 = {__shfl(s.uv2.x, src, 64), __shfl(s.uv2.y, src, 64)};
-    return r;
+DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
+    const SubTriRec r = P.recs[idx];
+    const ScreenVert v0 = {r.X0, r.Y0, r.z0}, v1 = {r.X1, r.Y1, r.z1}, v2 = {r.X2, r.Y2, r.z2};
+    if (!setup_subtri(v0, v1, v2, P.W, P.H, st)) return false;
+    st->key = r.key; st->alphaTex = r.alphaTex;
+    if (r.alphaTex >= 0) vq_load_alpha(P, idx, st);
+    return true;
 }
 
-// vs_meshlet_main + rasteriser + ps_meshlet_main (visibility-pass.hlsl:57-118): one wave per draw command
-__global__ __launch_bounds__(kVisWaves * 64) void vis_raster_kernel(const VisParams P) {
+// vs_meshlet_main + primitive assembly, clipping, viewport, culling (visibility-pass.hlsl:57-97): one wave per draw command
+__global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisParams P) {
     __shared__ float4 s_clip[kVisWaves][kMaxMeshletVerts];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n0 = P.counts[0], n1 = P.counts[1];
@@ -348,53 +354,101 @@ __global__ __launch_bounds__(kVisWaves * 64) void vis_raster_kernel(const VisPar
         int32_t alphaTex = mat.baseColorTextureIndex;
         if (alphaTex >= 0 && P.S.textures[alphaTex].pad[0]) alphaTex = -1;      // alpha is 255 everywhere: the clip can never fire
         const uint32_t ntri = cmd.vertex_count / 3u;
-        for (uint32_t t0 = 0; t0 < ntri; t0 += 64) {
-            const uint32_t tri = t0 + lane;
+        for (uint32_t tri = lane; tri < ntri; tri += 64) {
+            const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
+            uint32_t li[3];
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) li[k] = min(0xffu & (packed >> ((2u - k) * 10u)), nv - 1u);
+            const float4 c0 = s_clip[wave][li[0]], c1 = s_clip[wave][li[1]], c2 = s_clip[wave][li[2]];
+            const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
             ClipVert poly[4]; int np = 0;
-            SubTri st; st.alphaTex = alphaTex;
-            if (tri < ntri) {
-                const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
-                uint32_t li[3];
+            bool in[3]; int nin = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 3; ++k) li[k] = min(0xffu & (packed >> ((2u - k) * 10u)), nv - 1u);
-                const float4 c0 = s_clip[wave][li[0]], c1 = s_clip[wave][li[1]], c2 = s_clip[wave][li[2]];
-                st.p0 = {c0.x, c0.y, c0.z, c0.w}; st.p1 = {c1.x, c1.y, c1.z, c1.w}; st.p2 = {c2.x, c2.y, c2.z, c2.w};
-                if (alphaTex >= 0) {
-                    const float2 a = P.S.mvUv[m.vertexBegin + li[0]], b = P.S.mvUv[m.vertexBegin + li[1]], c = P.S.mvUv[m.vertexBegin + li[2]];
-                    st.uv0 = {a.x, a.y}; st.uv1 = {b.x, b.y}; st.uv2 = {c.x, c.y};
-                } else { st.uv0 = st.uv1 = st.uv2 = {0.f, 0.f}; }
-                st.key = (list << 31) | ((cmd.id << 7) | tri);
-                const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
-                bool in[3]; int nin = 0;
+            for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k] ? 1 : 0; }
+            if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+            else if (nin > 0) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k] ? 1 : 0; }
-                if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
-                else if (nin > 0) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int j = (k + 1) % 3;
-                        if (in[k]) poly[np++] = cv[k];
-                        if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
-                    }
+                for (int k = 0; k < 3; ++k) {
+                    const int j = (k + 1) % 3;
+                    if (in[k]) poly[np++] = cv[k];
+                    if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
                 }
             }
             ScreenVert sv[4]; bool ok = np >= 3;
             for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], Wf, Hf, &sv[k]);
-            for (int s = 0; s < 2; ++s) {                        // wave-uniform loop: a clipped triangle is a fan of two
-                bool have = ok && (s == 0 || np == 4);
-                if (have) have = setup_subtri(sv[0], sv[s + 1], sv[s + 2], list == 0, P.W, P.H, &st);
-                const bool big = have && (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kBigBoxPixels;
-                if (have && !big) raster_serial(P, st);
-                unsigned long long mask = __ballot(big);
-                while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    const SubTri b = shfl_subtri(st, src);
-                    raster_coop(P, b, lane);
-                    mask &= mask - 1;
+            if (!ok) continue;
+            for (int s = 0; s < (np == 4 ? 2 : 1); ++s) {        // a clipped triangle is a fan of two
+                ScreenVert v0 = sv[0], v1 = sv[s + 1], v2 = sv[s + 2];
+                if (!orient_subtri(v0, v1, v2, list == 0)) continue;
+                SubTri st;
+                if (!setup_subtri(v0, v1, v2, P.W, P.H, &st)) continue;
+                const uint32_t idx = atomicAdd(P.vqCounters + 0, 1u);
+                if (idx >= P.recCap) continue;                   // cannot happen: recCap = 2 x scene triangles
+                SubTriRec r;
+                r.X0 = v0.X; r.Y0 = v0.Y; r.X1 = v1.X; r.Y1 = v1.Y; r.X2 = v2.X; r.Y2 = v2.Y; r.z0 = v0.z; r.z1 = v1.z; r.z2 = v2.z;
+                r.key = (list << 31) | ((cmd.id << 7) | tri); r.alphaTex = alphaTex; r.pad = 0;
+                P.recs[idx] = r;
+                if (alphaTex >= 0) {
+                    const float2 a = P.S.mvUv[m.vertexBegin + li[0]], b = P.S.mvUv[m.vertexBegin + li[1]], c = P.S.mvUv[m.vertexBegin + li[2]];
+                    SubTriAlpha al;
+                    al.p[0] = c0.x; al.p[1] = c0.y; al.p[2] = c0.z; al.p[3] = c0.w; al.p[4] = c1.x; al.p[5] = c1.y; al.p[6] = c1.z; al.p[7] = c1.w;
+                    al.p[8] = c2.x; al.p[9] = c2.y; al.p[10] = c2.z; al.p[11] = c2.w;
+                    al.uv[0] = a.x; al.uv[1] = a.y; al.uv[2] = b.x; al.uv[3] = b.y; al.uv[4] = c.x; al.uv[5] = c.y; al.pad[0] = al.pad[1] = 0.f;
+                    P.alphas[idx] = al;
+                }
+                const uint32_t bw = (uint32_t)(st.px1 - st.px0 + 1), bh = (uint32_t)(st.py1 - st.py0 + 1);
+                if (bw * bh <= (uint32_t)kBigBoxPixels) { P.smallQueue[atomicAdd(P.vqCounters + 2, 1u)] = idx; continue; }
+                const uint32_t tw = (bw + 7u) >> 3, th = (bh + 7u) >> 3;
+                const uint32_t rowsPerItem = max(1u, 64u / tw), nItems = (th + rowsPerItem - 1u) / rowsPerItem;
+                const uint32_t base = atomicAdd(P.vqCounters + 1, nItems);
+                if (base + nItems <= P.bigCap) {
+                    for (uint32_t i = 0; i < nItems; ++i) P.bigQueue[base + i] = make_uint2(idx, ((i * rowsPerItem) << 16) | min(rowsPerItem, th - i * rowsPerItem));
+                } else {                                         // band queue full: neutralise the reserved slots, scan the triangle whole
+                    for (uint32_t i = base; i < min(base + nItems, P.bigCap); ++i) P.bigQueue[i] = make_uint2(idx, 0u);
+                    P.wholeQueue[atomicAdd(P.vqCounters + 3, 1u)] = idx;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();                         // s_clip[wave] is rewritten by the next job
+    }
+}
+
+// rasteriser + ps_meshlet_main (visibility-pass.hlsl:99-118): persistent waves over the three queues
+__global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
+    for (;;) {                                                   // band items
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(P.vqCounters + 4, 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= nBig) break;
+        const uint2 item = P.bigQueue[i];
+        const uint32_t rowStart = item.y >> 16, rowCount = item.y & 0xffffu;
+        if (!rowCount) continue;
+        SubTri st;
+        if (!subtri_from_rec(P, item.x, &st)) continue;
+        const int32_t skip = (int32_t)rowStart * 8;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st.e[k] += (long long)skip * st.sy[k];
+        st.py0 += skip; st.py1 = min(st.py1, st.py0 + (int32_t)rowCount * 8 - 1);
+        raster_coop(P, st, lane);
+    }
+    for (;;) {                                                   // whole large triangles (band-queue overflow)
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(P.vqCounters + 5, 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= nWhole) break;
+        SubTri st;
+        if (subtri_from_rec(P, P.wholeQueue[i], &st)) raster_coop(P, st, lane);
+    }
+    for (;;) {                                                   // small triangles: one per lane
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(P.vqCounters + 6, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= nSmall) break;
+        const uint32_t i = base + lane;
+        SubTri st;
+        if (i < nSmall && subtri_from_rec(P, P.smallQueue[i], &st)) raster_serial(P, st);
     }
 }
 // packed depth|key -> R32_UINT visibility + D32 depth (clears: 0xFFFFF000 and 0, visibility-pass.inl:68-74)
@@ -523,7 +577,13 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
         f3 radiance = {0.f, 0.f, 0.f};
         if (s.needsShadow) {
             bool lit = true;
-            if (light.type == INCR_LIGHT_DIRECTIONAL) { ++rays; lit = !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f); }
+            if (light.type == INCR_LIGHT_DIRECTIONAL) {
+                ++rays;
+                // background pixels unproject to non-finite positions: such a ray hits nothing (every triangle test fails
+                // on NaN/inf), but the box tests cannot reject it and the walk would visit the whole tree
+                const bool finite = isfinite(worldPos.x) && isfinite(worldPos.y) && isfinite(worldPos.z) && isfinite(s.L.x) && isfinite(s.L.y) && isfinite(s.L.z);
+                lit = !finite || !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f);
+            }
             if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
         }
         add_color(P.L, i, radiance);
@@ -647,9 +707,12 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
     if (!n) return hipSuccess;
     hipError_t e = hipMemsetAsync(p->packed, 0, n * 8, stream);
     if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(p->vqCounters, 0, 64, stream)) != hipSuccess) return e;
     if (maxJobs) {
         const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
-        hipLaunchKernelGGL(vis_raster_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
+        hipLaunchKernelGGL(vis_setup_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(vis_scan_kernel, dim3((uint32_t)numCUs * 8u), dim3(256), 0, stream, *p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(vis_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p->packed, vis, depth, n);

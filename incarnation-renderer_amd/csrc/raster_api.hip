@@ -114,19 +114,38 @@ void fill_view_frame(const incr_view_constants& vc, ViewFrame& vf) {
     memcpy(vf.invViewProj, vc.inv_view_proj_transform.m, 64); memcpy(vf.invProj, vc.inv_proj_transform.m, 64);
     memcpy(vf.eye, vc.eye_pos, 12); vf.nearPlane = vc.near_plane; vf.W = vc.res_x; vf.H = vc.res_y;
 }
-// workspace: [packed depth|key surface][per-mesh frame constants]
-int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, hipStream_t stream, unsigned long long** packed, MeshFrame** frames) {
-    const size_t a = (pixels * 8 + 255) & ~(size_t)255, b = (meshes + 1) * sizeof(MeshFrame);
-    const size_t need = a + b;
+// One allocation, grown on demand: [per-mesh frame constants][queue counters][packed depth|key surface][triangle
+// records + alpha blocks][small / whole / band queues].  The frame constants sit at offset 0, so passes that only need
+// them (pixels == 0) never move anything.
+struct RasterWorkspace {
+    MeshFrame* frames; uint32_t* counters; unsigned long long* packed;
+    SubTriRec* recs; SubTriAlpha* alphas; uint32_t* smallQueue; uint32_t* wholeQueue; uint2* bigQueue;
+    uint32_t recCap, bigCap;
+};
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws) {
+    const size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
+    const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
+    const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
+    const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
+    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig;
+    if (recCap > 0xffffffffull || bigCap > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "scene too large for the visibility queues");
     if (ctx->rasterBytes < need || !ctx->rasterBlock) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (ctx->rasterBlock) { HIP_TRY(hipFree(ctx->rasterBlock)); ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; }
         HIP_TRY(hipMalloc(&ctx->rasterBlock, need));
         ctx->rasterBytes = need;
     }
-    // frames live at the END of the block so that a later call with fewer pixels still finds them valid
-    *packed = (unsigned long long*)ctx->rasterBlock;
-    *frames = (MeshFrame*)((uint8_t*)ctx->rasterBlock + ctx->rasterBytes - b);
+    uint8_t* p = (uint8_t*)ctx->rasterBlock;
+    ws->frames = (MeshFrame*)p; p += szFrames;
+    ws->counters = (uint32_t*)p; p += szCounters;
+    ws->packed = (unsigned long long*)p; p += szPacked;
+    ws->recs = (SubTriRec*)p; p += szRecs;
+    ws->alphas = (SubTriAlpha*)p; p += szAlpha;
+    ws->smallQueue = (uint32_t*)p; p += szSmall;
+    ws->wholeQueue = (uint32_t*)p; p += szWhole;
+    ws->bigQueue = (uint2*)p;
+    ws->recCap = (uint32_t)recCap; ws->bigCap = (uint32_t)bigCap;
     return INCR_OK;
 }
 int check_view(const incr_view_constants* v) {
@@ -164,10 +183,10 @@ int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* d, incr_strea
     const incr_scene* sc = d->scene;
     RasterScene S; fill_raster_scene(ctx, sc, S);
     ViewFrame vf; fill_view_frame(*d->view, vf);
-    unsigned long long* packed; MeshFrame* frames;
-    if ((rc = ensure_raster_workspace(ctx, 0, S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
-    HIP_TRY(incr_launch_mesh_frames(&S, &vf, frames, (hipStream_t)stream));
-    HIP_TRY(incr_launch_batch_cull(&S, frames, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, d->render_stats, (hipStream_t)stream));
+    RasterWorkspace ws;
+    if ((rc = ensure_raster_workspace(ctx, 0, S.numMeshes, 0, (hipStream_t)stream, &ws))) return rc;
+    HIP_TRY(incr_launch_mesh_frames(&S, &vf, ws.frames, (hipStream_t)stream));
+    HIP_TRY(incr_launch_batch_cull(&S, ws.frames, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, d->render_stats, (hipStream_t)stream));
     return INCR_OK;
 }
 
@@ -213,9 +232,10 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
     memcpy(P.viewProj, d->view->view_proj_transform.m, 64);
     P.W = d->view->res_x; P.H = d->view->res_y;
     P.lists[0] = d->default_list; P.lists[1] = d->double_sided_list; P.counts = d->counts;
-    unsigned long long* packed; MeshFrame* frames;
-    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
-    P.packed = packed;
+    RasterWorkspace ws;
+    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, sc->host.meshletPackedTriangles.size(), (hipStream_t)stream, &ws))) return rc;
+    P.packed = ws.packed; P.recs = ws.recs; P.alphas = ws.alphas; P.bigQueue = ws.bigQueue; P.smallQueue = ws.smallQueue; P.wholeQueue = ws.wholeQueue;
+    P.vqCounters = ws.counters; P.recCap = ws.recCap; P.bigCap = ws.bigCap;
     HIP_TRY(incr_launch_visibility(&P, P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
     return INCR_OK;
 }
@@ -231,10 +251,10 @@ int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stre
     GBufferParams P; memset(&P, 0, sizeof P);
     fill_raster_scene(ctx, sc, P.S);
     ViewFrame vf; fill_view_frame(*d->view, vf);
-    unsigned long long* packed; MeshFrame* frames;
-    if ((rc = ensure_raster_workspace(ctx, 0, P.S.numMeshes, (hipStream_t)stream, &packed, &frames))) return rc;
-    HIP_TRY(incr_launch_mesh_frames(&P.S, &vf, frames, (hipStream_t)stream));
-    P.frames = frames; P.W = d->view->res_x; P.H = d->view->res_y; P.vis = d->vis_buffer;
+    RasterWorkspace ws;
+    if ((rc = ensure_raster_workspace(ctx, 0, P.S.numMeshes, 0, (hipStream_t)stream, &ws))) return rc;
+    HIP_TRY(incr_launch_mesh_frames(&P.S, &vf, ws.frames, (hipStream_t)stream));
+    P.frames = ws.frames; P.W = d->view->res_x; P.H = d->view->res_y; P.vis = d->vis_buffer;
     P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao; P.color = d->color_target;
     P.rounding = d->storage_rounding;
     HIP_TRY(incr_launch_gbuffer(&P, (hipStream_t)stream));

@@ -59,6 +59,12 @@ struct LightCullParams {
     uint32_t* __restrict__ lists; incr_light_grid_data* __restrict__ grid; uint32_t* __restrict__ totalCount; incr_render_stats* __restrict__ stats;
 };
 
+// One screen triangle between the set-up and the scan kernel of the visibility pass: clockwise vertices in 24.8
+// fixed point + depth, 48 B.  Alpha-tested triangles also carry the clip-space vertices and uvs of the original triangle.
+struct alignas(16) SubTriRec { int32_t X0, Y0, X1, Y1, X2, Y2; float z0, z1, z2; uint32_t key; int32_t alphaTex; uint32_t pad; };
+struct alignas(16) SubTriAlpha { float p[12]; float uv[6]; float pad[2]; };
+static_assert(sizeof(SubTriRec) == 48 && sizeof(SubTriAlpha) == 80, "visibility queue records");
+
 struct VisParams {
     RasterScene S;
     float viewProj[16];
@@ -66,6 +72,11 @@ struct VisParams {
     const incr_draw_cmd* __restrict__ lists[2];
     const uint32_t* __restrict__ counts;
     unsigned long long* __restrict__ packed;         // W*H: depth bits << 32 | (order key + 1); 0 = empty
+    // triangle queues (raster.hip "Work distribution")
+    SubTriRec* __restrict__ recs; SubTriAlpha* __restrict__ alphas;
+    uint2* __restrict__ bigQueue; uint32_t* __restrict__ smallQueue; uint32_t* __restrict__ wholeQueue;
+    uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors
+    uint32_t recCap, bigCap;
 };
 
 struct GBufferParams {

@@ -479,8 +479,13 @@ static bool any_hit_accepts(const Scene& s, const Scene::Tri& T, float u, float 
 }
 
 // TraceRay(..., RAY_FLAG_CULL_BACK_FACING_TRIANGLES, ...) closest hit
+// A ray whose origin or direction is not finite hits nothing.  (Every ray/triangle test fails on NaN/inf operands anyway;
+// stating it up front spares the traversal a walk over the whole tree, whose box tests cannot reject NaN.)
+static inline bool finite_ray(float3 o, float3 d) {
+    return std::isfinite(o.x) && std::isfinite(o.y) && std::isfinite(o.z) && std::isfinite(d.x) && std::isfinite(d.y) && std::isfinite(d.z);
+}
 static bool trace_closest(const Scene& s, float3 o, float3 d, float tmin, float tmax, Hit* hit) {
-    if (s.nodes.empty() || s.tris.empty()) return false;
+    if (s.nodes.empty() || s.tris.empty() || !finite_ray(o, d)) return false;
     float3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
     uint32_t stack[128]; int sp = 0;
     stack[sp++] = 0;
@@ -508,7 +513,7 @@ static bool trace_closest(const Scene& s, float3 o, float3 d, float tmin, float 
 // RayQuery<CULL_BACK_FACING> + single Proceed(): occluded iff ANY front-facing triangle lies in the interval
 // (shaders/lighting/common.hlsli:102-115).
 static bool trace_any(const Scene& s, float3 o, float3 d, float tmin, float tmax) {
-    if (s.nodes.empty() || s.tris.empty()) return false;
+    if (s.nodes.empty() || s.tris.empty() || !finite_ray(o, d)) return false;
     float3 invd = {1.f / d.x, 1.f / d.y, 1.f / d.z};
     uint32_t stack[128]; int sp = 0;
     stack[sp++] = 0;

@@ -1,0 +1,31 @@
+"""Time the raster frame (BASELINE config 3 shape) on the GPU: python tools/raster_time.py [--res 3840x2160] [--frames 20]."""
+import argparse, importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+A = importlib.import_module("incarnation-renderer_amd.ctypes_api")
+sio = importlib.import_module("incarnation-renderer_amd.scene_io")
+synth = importlib.import_module("incarnation-renderer_amd.synth")
+R = importlib.import_module("incarnation-renderer_amd.raster")
+rt = importlib.import_module("incarnation-renderer_amd.runtime")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", default="3840x2160"); ap.add_argument("--frames", type=int, default=20); ap.add_argument("--texture-size", type=int, default=256)
+a = ap.parse_args()
+W, H = map(int, a.res.split("x"))
+t = time.time(); scene = synth.sponza_stat(texture_size=a.texture_size); print("scene %.1fs" % (time.time() - t))
+t = time.time(); R.generate_meshlets(scene); print("meshlets %d in %.1fs" % (scene.num_meshlets, time.time() - t))
+ctx = rt.Context(0)
+t = time.time(); gs = ctx.create_scene(scene); print("upload %.1fs" % (time.time() - t))
+view = sio.FView().reset(scene, aspect=W / H)
+rr = R.RasterRenderer(ctx, gs, W, H)
+rr.set_sh9(np.ones((9, 3), np.float32) * 0.1)
+for _ in range(3):
+    rr.render(view)
+ctx.synchronize()
+t = time.time()
+for _ in range(a.frames):
+    rr.render(view)
+ctx.synchronize()
+dt = (time.time() - t) / a.frames
+print("raster frame %.3f ms (%dx%d, %d meshlets)" % (dt * 1e3, W, H, scene.num_meshlets))
+print("counts", rr.surf.download("counts"), "stats", rr.surf.download("render_stats"), "shadow rays", rr.surf.download("ray_stats").light_shadow_rays)

@@ -75,6 +75,39 @@ def cpu_baseline(packed, view, res, seconds_hint):
             "seconds": round(dt, 3)}
 
 
+# Raster frame (BASELINE config 3): algorithmic HBM bytes per pixel as fixed by SURVEY.md 8d: visibility write 4 + 4;
+# G-buffer read 4, write 16; direct read 16, rw 8; clustered read 24, rw 8; sky read 17, rw 8; TAA read 12, write 4;
+# tonemap read 4, write 4 => 133 B/pixel (geometry, light lists and textures are extra and small).
+RASTER_B_PX = 133
+RASTER_SH9 = [[1.0, 1.1, 1.3], [0.3, 0.3, 0.35], [0.1, 0.1, 0.2], [-0.05, -0.04, -0.02], [0.02, 0.02, 0.03],
+              [0.04, 0.05, 0.05], [-0.03, -0.03, -0.02], [0.01, 0.02, 0.02], [0.05, 0.04, 0.03]]
+
+
+def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle):
+    """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM."""
+    R = importlib.import_module(PKG + ".raster")
+    rr = R.RasterRenderer(ctx, scene, W, H)
+    rr.set_sh9(RASTER_SH9)
+    for _ in range(warmup):
+        rr.render(view, stream_handle)
+    ctx.synchronize(stream_handle)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rr.render(view, stream_handle)
+    ctx.synchronize(stream_handle)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    counts = rr.surf.download("counts")
+    rays = rr.surf.download("ray_stats").light_shadow_rays // (steps + warmup)
+    rr.close()
+    alg = float(W) * H * RASTER_B_PX
+    return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1),
+            "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), TAA on, 1 sun shadow ray/pixel"
+                        % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1])),
+            "passes": "batch_cull, light_cull, visibility, gbuffer, sky_lighting, direct_lighting, clustered_lighting, taa_resolve, tonemap",
+            "sun_shadow_rays_per_frame": int(rays), "algorithmic_bytes_per_frame": int(alg),
+            "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
+    ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +146,7 @@ def main():
 
     W, H = (int(v) for v in args.res.lower().split("x"))
     packed = build_scene(args.scene, args.texture_size)
+    importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
     scene = ctx.create_scene(packed)
@@ -221,6 +256,9 @@ def main():
                     out["roofline"]["traffic_source"] = tj.get("source")
             except Exception:
                 pass
+        if world == 1 and not args.no_raster:
+            # second half of the metric ("Mray/s + ms/frame"): the raster frame of config 3, outside the timed path-trace region
+            out["raster"] = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream)
         if world == 1 and not args.no_cpu_baseline:
             cw, ch = (int(v) for v in args.cpu_res.lower().split("x"))
             out["cpu_baseline"] = cpu_baseline(packed, sio.FView().reset(packed, aspect=cw / ch), (cw, ch), 20)

@@ -86,18 +86,19 @@ RASTER_SH9 = [[1.0, 1.1, 1.3], [0.3, 0.3, 0.35], [0.1, 0.1, 0.2], [-0.05, -0.04,
 def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle):
     """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM."""
     R = importlib.import_module(PKG + ".raster")
-    rr = R.RasterRenderer(ctx, scene, W, H)
-    rr.set_sh9(RASTER_SH9)
+    A = importlib.import_module(PKG + ".ctypes_api")
+    rr = R.HostRenderer(ctx, scene, W, H, sh9_rgb=RASTER_SH9, stream=stream_handle)      # C++ Renderer::Render (csrc/host/renderer.cpp)
     for _ in range(warmup):
-        rr.render(view, stream_handle)
+        rr.render(view)
     ctx.synchronize(stream_handle)
     t0 = time.perf_counter()
     for _ in range(steps):
-        rr.render(view, stream_handle)
+        rr.render(view)
     ctx.synchronize(stream_handle)
     ms = (time.perf_counter() - t0) / steps * 1e3
-    counts = rr.surf.download("counts")
-    rays = rr.surf.download("ray_stats").light_shadow_rays // (steps + warmup)
+    counts = ctx.download(rr.surface_ptr(A.SURFACE_BATCH_COUNTS), (2,), np.uint32)
+    raw = ctx.download(rr.surface_ptr(A.SURFACE_RAY_STATS), (C.sizeof(A.RayStats),), np.uint8)
+    rays = A.RayStats.from_buffer_copy(raw.tobytes()).light_shadow_rays // (steps + warmup)
     rr.close()
     alg = float(W) * H * RASTER_B_PX
     return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1),

@@ -1,0 +1,455 @@
+// renderer.cpp -- C++ host mirror of the hot-path half of the reference's renderer: the RenderJob::<Pass>::Execute
+// bodies (one C-ABI call each) and Renderer::Render's path-trace and raster branches
+// (reference: source/demo-dll/src/renderer.cpp:1358-2078, src/render-jobs/*.inl).  No GPU code here: everything goes
+// through include/incr.h, exactly what a maintainer of the reference would link against.
+#include "render_jobs.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+incr_view FView::ToIncr() const {
+    incr_view v;
+    v.view_transform = m_viewTransform; v.projection_transform = m_projectionTransform;
+    const Vector3* src[4] = {&m_position, &m_right, &m_up, &m_look};
+    float* dst[4] = {v.position, v.right, v.up, v.look};
+    for (int i = 0; i < 4; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    v.fov = m_fov;
+    return v;
+}
+
+namespace RenderJob {
+
+namespace {
+Result done(int rc) { Result r; r.m_taskDone = true; r.m_status = rc; return r; }
+incr_lighting_inputs lighting_inputs(const FScene* scene, const FSystemBuffer* view, FShaderSurface* color, FShaderSurface* depth, FShaderSurface* g0,
+                                     FShaderSurface* g1, FShaderSurface* g2, const FConfig& c) {
+    incr_lighting_inputs in = {};
+    in.scene = scene->m_incrScene; in.view = &view->m_viewConstants;
+    in.color_target = (uint32_t*)color->m_devicePtr; in.depth_buffer = (const float*)depth->m_devicePtr;
+    in.gbuffer_basecolor = (const uint32_t*)g0->m_devicePtr; in.gbuffer_normals = (const uint32_t*)g1->m_devicePtr;
+    in.gbuffer_metallic_roughness_ao = (const uint32_t*)g2->m_devicePtr;
+    in.lighting_only = c.Viewmode == 1 ? 1 : 0;                // Viewmode::LightingOnly -> LIGHTING_ONLY (clustered-lighting.inl:63)
+    in.storage_rounding = c.StorageRounding;
+    return in;
+}
+} // namespace
+
+Result UpdateTLAS_Execute(Sync* jobSync, const FScene* scene) {           // update-tlas.inl:3-101
+    const size_t token = jobSync->GetToken();
+    // transforms / visibility / root transform are unchanged since scene creation unless the owner passed new ones
+    return done(jobSync->Execute(token, [&] { return incr_update_bvh(jobSync->m_ctx, scene->m_incrScene, nullptr, nullptr, nullptr, jobSync->m_stream); }));
+}
+
+Result PathTracing::Execute(Sync* jobSync, const Desc& p) {               // path-tracing.inl:17-299
+    const size_t token = jobSync->GetToken();
+    incr_pathtrace_desc d = {};
+    d.scene = p.scene->m_incrScene;
+    d.target_rgba16f = p.targetBuffer->m_devicePtr; d.history_r11g11b10 = p.historyBuffer->m_devicePtr;
+    d.res_x = p.resX; d.res_y = p.resY;
+    d.shard = {0, 0, 1};
+    d.current_sample_index = p.currentSampleIndex; d.max_sample_count = p.renderConfig.MaxSampleCount;
+    d.view = p.view->ToIncr();
+    d.camera_aperture = p.renderConfig.Pathtracing_CameraAperture; d.camera_focal_length = p.renderConfig.Pathtracing_CameraFocalLength;
+    d.env_sky_mode = p.renderConfig.EnvSkyMode; d.direct_lighting = p.renderConfig.EnableDirectLighting ? 1 : 0;
+    d.viewmode = p.renderConfig.Viewmode; d.turbidity = p.renderConfig.Turbidity; d.sky_brightness = p.renderConfig.SkyBrightness;
+    d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_pathtrace(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result TonemapPass::Execute(Sync* jobSync, const Desc& p) {               // tonemap.inl:11-136
+    const size_t token = jobSync->GetToken();
+    incr_tonemap_desc d = {};
+    d.hdr_r11g11b10 = p.source->m_devicePtr; d.ldr_rgba8 = p.target->m_devicePtr;
+    d.res_x = p.source->m_width; d.rows = p.source->m_height;
+    d.exposure = p.renderConfig.Exposure; d.viewmode = p.renderConfig.Viewmode;
+    return done(jobSync->Execute(token, [&] { return incr_tonemap(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result BatchCullingPass::Execute(Sync* jobSync, const Desc& p) {          // batch-culling.inl:14-131
+    const size_t token = jobSync->GetToken();
+    incr_batch_cull_desc d = {};
+    d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.default_list = (incr_draw_cmd*)p.batchArgsBuffer_Default->m_devicePtr;
+    d.double_sided_list = (incr_draw_cmd*)p.batchArgsBuffer_DoubleSided->m_devicePtr;
+    d.counts = (uint32_t*)p.batchCountsBuffer->m_devicePtr;
+    d.render_stats = p.renderStatsBuffer ? (incr_render_stats*)p.renderStatsBuffer->m_devicePtr : nullptr;
+    d.frustum_culling = p.renderConfig.FrustumCulling ? 1 : 0;
+    return done(jobSync->Execute(token, [&] { return incr_batch_cull(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result LightCullingPass::Execute(Sync* jobSync, const Desc& p) {          // light-culling.inl:16-152
+    const size_t token = jobSync->GetToken();
+    incr_light_cull_desc d = {};
+    d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.cluster_dim[0] = (uint32_t)p.renderConfig.LightClusterDimX; d.cluster_dim[1] = (uint32_t)p.renderConfig.LightClusterDimY;
+    d.cluster_dim[2] = (uint32_t)p.renderConfig.LightClusterDimZ;
+    d.max_lights_per_cluster = (uint32_t)p.renderConfig.MaxLightsPerCluster; d.cluster_depth_extent = p.renderConfig.ClusterDepthExtent;
+    d.culled_light_lists = (uint32_t*)p.culledLightListsBuffer->m_devicePtr; d.light_grid = (incr_light_grid_data*)p.lightGridBuffer->m_devicePtr;
+    d.culled_light_count = (uint32_t*)p.culledLightCountBuffer->m_devicePtr;
+    d.render_stats = p.renderStatsBuffer ? (incr_render_stats*)p.renderStatsBuffer->m_devicePtr : nullptr;
+    return done(jobSync->Execute(token, [&] { return incr_light_cull(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result VisibilityPass::Execute(Sync* jobSync, const Desc& p) {            // visibility-pass.inl:19-197
+    const size_t token = jobSync->GetToken();
+    incr_visibility_desc d = {};
+    d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.default_list = (const incr_draw_cmd*)p.indirectArgsBuffer_Default->m_devicePtr;
+    d.double_sided_list = (const incr_draw_cmd*)p.indirectArgsBuffer_DoubleSided->m_devicePtr;
+    d.counts = (const uint32_t*)p.indirectCountsBuffer->m_devicePtr;
+    d.vis_buffer = (uint32_t*)p.visBufferTarget->m_devicePtr; d.depth_buffer = (float*)p.depthStencilTarget->m_devicePtr;
+    return done(jobSync->Execute(token, [&] { return incr_visibility(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result GBufferComputePass::Execute(Sync* jobSync, const Desc& p) {        // gbuffer-compute-pass.inl:17-123
+    const size_t token = jobSync->GetToken();
+    incr_gbuffer_desc d = {};
+    d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.vis_buffer = (const uint32_t*)p.sourceVisBuffer->m_devicePtr;
+    d.gbuffer_basecolor = (uint32_t*)p.gbufferTargets[0]->m_devicePtr; d.gbuffer_normals = (uint32_t*)p.gbufferTargets[1]->m_devicePtr;
+    d.gbuffer_metallic_roughness_ao = (uint32_t*)p.gbufferTargets[2]->m_devicePtr;
+    d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_gbuffer(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky-lighting.inl:21-150
+    const size_t token = jobSync->GetToken();
+    incr_sky_lighting_desc d = {};
+    d.in = lighting_inputs(p.scene, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
+                           p.gbufferMetallicRoughnessAoTex, p.renderConfig);
+    d.sh9_rgba = p.scene->m_skylightSh9;
+    d.ambient_occlusion = (p.renderConfig.EnableHBAO && p.ambientOcclusionTex) ? (const uint8_t*)p.ambientOcclusionTex->m_devicePtr : nullptr;
+    d.sky_brightness = p.renderConfig.SkyBrightness; d.diffuse_ibl = p.renderConfig.EnableDiffuseIBL ? 1 : 0;
+    return done(jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result DirectLightingPass::Execute(Sync* jobSync, const Desc& p) {        // direct-lighting.inl:18-112
+    const size_t token = jobSync->GetToken();
+    incr_direct_lighting_desc d = {};
+    d.in = lighting_inputs(p.sceneConstantBuffer, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
+                           p.gbufferMetallicRoughnessAoTex, p.renderConfig);
+    d.directional_light_index = p.directionalLightIndex;
+    d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
+    return done(jobSync->Execute(token, [&] { return incr_direct_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result ClusteredLightingPass::Execute(Sync* jobSync, const Desc& p, const bool bRequiresClear) {      // clustered-lighting.inl:19-132
+    const size_t token = jobSync->GetToken();
+    incr_clustered_lighting_desc d = {};
+    d.in = lighting_inputs(p.sceneConstantBuffer, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
+                           p.gbufferMetallicRoughnessAoTex, p.renderConfig);
+    d.culled_light_lists = (const uint32_t*)p.lightListsBuffer->m_devicePtr; d.light_grid = (const incr_light_grid_data*)p.lightGridBuffer->m_devicePtr;
+    d.cluster_dim[0] = (uint32_t)p.renderConfig.LightClusterDimX; d.cluster_dim[1] = (uint32_t)p.renderConfig.LightClusterDimY;
+    d.cluster_dim[2] = (uint32_t)p.renderConfig.LightClusterDimZ;
+    d.cluster_depth_extent = p.renderConfig.ClusterDepthExtent; d.requires_clear = bRequiresClear ? 1 : 0;
+    return done(jobSync->Execute(token, [&] { return incr_clustered_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa-resolve.inl:16-118
+    const size_t token = jobSync->GetToken();
+    incr_view_constants vc = {};
+    vc.taa_inv_view_proj = p.invViewProjectionTransform; vc.prev_view_proj_transform = p.prevViewProjectionTransform;
+    vc.res_x = p.resX; vc.res_y = p.resY;
+    incr_taa_resolve_desc d = {};
+    d.view = &vc;
+    d.hdr_scene_color = (const uint32_t*)p.source->m_devicePtr; d.history_out = (uint32_t*)p.target->m_devicePtr;
+    d.history_in = p.historySource ? (const uint32_t*)p.historySource->m_devicePtr : nullptr;
+    d.depth_buffer = (const float*)p.depthTexture->m_devicePtr;
+    d.history_index = p.historyIndex; d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_taa_resolve(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+} // namespace RenderJob
+
+// =====================================================================================================================
+// Renderer: the statics of renderer.cpp:13-30 + Render (path-trace branch :1676-1709, raster branch :1711-2036)
+// =====================================================================================================================
+namespace Renderer {
+
+struct FRenderState {          // inc/renderer.h FRenderState (fields Render reads)
+    FConfig m_config;
+    FScene* m_scene = nullptr;
+    FView m_view, m_cullingView;
+    uint32_t m_resX = 0, m_resY = 0;
+};
+
+struct State {
+    incr_context* ctx = nullptr;
+    RenderJob::Sync jobSync;                                   // s_jobSync
+    uint32_t resX = 0, resY = 0;
+    uint32_t pathtraceCurrentSampleIndex = 1;                  // s_pathtraceCurrentSampleIndex (renderer.cpp:23)
+    Matrix prevViewProjectionTransform{};                      // s_prevViewProjectionTransform
+    uint64_t frameIndex = 0;
+    std::vector<Vector2> pixelJitterValues;                    // s_pixelJitterValues (:126-131)
+    // surfaces (renderer.cpp:1364-1520; transient per frame there, persistent here)
+    FShaderSurface hdrRasterSceneColor, hdrRaytraceSceneColor, depthBuffer, visBuffer, gbuffer_basecolor, gbuffer_normals, gbuffer_metallicRoughnessAo;
+    FShaderSurface pathtraceHistoryBuffer, taaAccumulationBuffer[2], backBuffer;
+    FShaderBuffer batchArgsBuffer_Default, batchArgsBuffer_DoubleSided, batchCountsBuffer, culledLightCountBuffer, culledLightListsBuffer, lightGridBuffer;
+    FShaderBuffer renderStatsBuffer, rayStatsBuffer;
+    std::vector<void*> allocations;
+    int lastStatus = INCR_OK;
+};
+
+static int alloc(State& s, void** out, uint64_t bytes, bool clear) {
+    int rc = incr_buffer_create(s.ctx, bytes, out);
+    if (rc) return rc;
+    s.allocations.push_back(*out);
+    return clear ? incr_buffer_clear(s.ctx, *out, 0, (bytes + 3) & ~3ull, nullptr) : INCR_OK;
+}
+static int surface(State& s, FShaderSurface& f, uint32_t texelBytes, bool clear = false) {
+    f.m_width = s.resX; f.m_height = s.resY; f.m_texelBytes = texelBytes;
+    return alloc(s, &f.m_devicePtr, (uint64_t)s.resX * s.resY * texelBytes, clear);
+}
+static int buffer(State& s, FShaderBuffer& b, uint64_t bytes) { b.m_size = bytes; return alloc(s, &b.m_devicePtr, bytes ? bytes : 4, true); }
+
+static Matrix identity() { Matrix m{}; m.m[0] = m.m[5] = m.m[10] = m.m[15] = 1.f; return m; }
+
+int Initialize(State& s, incr_context* ctx, incr_stream stream, uint32_t resX, uint32_t resY, size_t meshletCount, const FConfig& c) {
+    s.ctx = ctx; s.jobSync.m_ctx = ctx; s.jobSync.m_stream = stream; s.resX = resX; s.resY = resY;
+    s.prevViewProjectionTransform = identity();
+    for (uint32_t i = 0; i < 16; ++i) { float j[2]; incr_pixel_jitter(i, resX, resY, j); s.pixelJitterValues.push_back({j[0], j[1]}); }   // renderer.cpp:126-131
+    int rc = 0;
+    FShaderSurface* four[] = {&s.hdrRasterSceneColor, &s.depthBuffer, &s.visBuffer, &s.gbuffer_basecolor, &s.gbuffer_normals, &s.gbuffer_metallicRoughnessAo,
+                              &s.pathtraceHistoryBuffer, &s.taaAccumulationBuffer[0], &s.taaAccumulationBuffer[1], &s.backBuffer};
+    for (FShaderSurface* f : four) if (!rc) rc = surface(s, *f, 4, true);
+    if (!rc) rc = surface(s, s.hdrRaytraceSceneColor, 8, true);
+    const uint64_t clusters = (uint64_t)c.LightClusterDimX * c.LightClusterDimY * c.LightClusterDimZ;
+    if (!rc) rc = buffer(s, s.batchArgsBuffer_Default, (meshletCount + 1) * sizeof(incr_draw_cmd));
+    if (!rc) rc = buffer(s, s.batchArgsBuffer_DoubleSided, (meshletCount + 1) * sizeof(incr_draw_cmd));
+    if (!rc) rc = buffer(s, s.batchCountsBuffer, 8);
+    if (!rc) rc = buffer(s, s.culledLightCountBuffer, 4);
+    if (!rc) rc = buffer(s, s.culledLightListsBuffer, clusters * c.MaxLightsPerCluster * 4);      // renderer.cpp:1506
+    if (!rc) rc = buffer(s, s.lightGridBuffer, clusters * 8);                                    // renderer.cpp:1515
+    if (!rc) rc = buffer(s, s.renderStatsBuffer, sizeof(incr_render_stats));
+    if (!rc) rc = buffer(s, s.rayStatsBuffer, sizeof(incr_ray_stats));
+    return rc;
+}
+
+void Teardown(State& s) {
+    for (void* p : s.allocations) incr_buffer_destroy(s.ctx, p);
+    s.allocations.clear();
+}
+
+// Renderer::Render (renderer.cpp:1358-2078), hot-path half.  Returns the first error of the frame.
+int Render(State& s, const FRenderState& renderState) {
+    using namespace RenderJob;
+    const FConfig& c = renderState.m_config;
+    const uint32_t resX = s.resX, resY = s.resY;
+    const FScene* scene = renderState.m_scene;
+    Sync* jobSync = &s.jobSync;
+    jobSync->m_firstError = INCR_OK;
+    const uint64_t frameIndex = s.frameIndex;
+
+    // renderer.cpp:1631: jitter only with TAA in the normal view mode
+    const Vector2 pixelJitter = (c.EnableTAA && c.Viewmode == 0) ? s.pixelJitterValues[frameIndex % 16] : Vector2{0.f, 0.f};
+    // view constants (renderer.cpp:1634-1665)
+    FSystemBuffer cbViewConstants;
+    const incr_view view = renderState.m_view.ToIncr(), cull = (c.FreezeCulling ? renderState.m_cullingView : renderState.m_view).ToIncr();
+    const float jitter[2] = {pixelJitter.x, pixelJitter.y};
+    int rc = incr_make_view_constants(&view, &cull, jitter, &s.prevViewProjectionTransform, c.CameraNearPlane, resX, resY, &cbViewConstants.m_viewConstants);
+    if (rc) return rc;
+
+    UpdateTLASPass::Execute(jobSync, scene);                                   // :1676
+
+    if (c.PathTrace) {                                                         // :1679-1709
+        if (s.pathtraceCurrentSampleIndex < c.MaxSampleCount) {
+            PathTracing::Desc pathtraceDesc = {};
+            pathtraceDesc.targetBuffer = &s.hdrRaytraceSceneColor; pathtraceDesc.historyBuffer = &s.pathtraceHistoryBuffer;
+            pathtraceDesc.currentSampleIndex = s.pathtraceCurrentSampleIndex;
+            pathtraceDesc.resX = resX; pathtraceDesc.resY = resY;
+            pathtraceDesc.scene = scene; pathtraceDesc.view = &renderState.m_view; pathtraceDesc.renderConfig = c;
+            PathTracing::Execute(jobSync, pathtraceDesc);
+            s.pathtraceCurrentSampleIndex++;                                   // accumulate samples
+        }
+        TonemapPass::Desc tonemapDesc = {};
+        tonemapDesc.source = &s.pathtraceHistoryBuffer; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
+        TonemapPass::Execute(jobSync, tonemapDesc);
+    } else {                                                                   // :1711-2036
+        BatchCullingPass::Desc batchCullDesc = {};
+        batchCullDesc.batchArgsBuffer_Default = &s.batchArgsBuffer_Default; batchCullDesc.batchArgsBuffer_DoubleSided = &s.batchArgsBuffer_DoubleSided;
+        batchCullDesc.batchCountsBuffer = &s.batchCountsBuffer;
+        batchCullDesc.sceneConstantBuffer = scene; batchCullDesc.viewConstantBuffer = &cbViewConstants;
+        batchCullDesc.drawCount = scene->m_meshletCount; batchCullDesc.renderConfig = c; batchCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
+        BatchCullingPass::Execute(jobSync, batchCullDesc);
+
+        const size_t punctualLightCount = scene->GetPunctualLightCount();
+        if (punctualLightCount > 0 && c.EnableDirectLighting) {                // :1727-1744
+            LightCullingPass::Desc lightCullDesc = {};
+            lightCullDesc.culledLightCountBuffer = &s.culledLightCountBuffer; lightCullDesc.culledLightListsBuffer = &s.culledLightListsBuffer;
+            lightCullDesc.lightGridBuffer = &s.lightGridBuffer;
+            lightCullDesc.renderConfig = c; lightCullDesc.scene = scene; lightCullDesc.view = &renderState.m_cullingView; lightCullDesc.jitter = pixelJitter;
+            lightCullDesc.viewConstantBuffer = &cbViewConstants; lightCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
+            LightCullingPass::Execute(jobSync, lightCullDesc);
+        }
+
+        VisibilityPass::Desc visDesc = {};                                     // :1747-1762
+        visDesc.visBufferTarget = &s.visBuffer; visDesc.depthStencilTarget = &s.depthBuffer;
+        visDesc.indirectArgsBuffer_Default = &s.batchArgsBuffer_Default; visDesc.indirectArgsBuffer_DoubleSided = &s.batchArgsBuffer_DoubleSided;
+        visDesc.indirectCountsBuffer = &s.batchCountsBuffer;
+        visDesc.sceneConstantBuffer = scene; visDesc.viewConstantBuffer = &cbViewConstants;
+        visDesc.resX = resX; visDesc.resY = resY; visDesc.drawCount = scene->m_meshletCount; visDesc.renderConfig = c;
+        VisibilityPass::Execute(jobSync, visDesc);
+
+        GBufferComputePass::Desc gbufferComputeDesc = {};                      // :1765-1781
+        gbufferComputeDesc.sourceVisBuffer = &s.visBuffer; gbufferComputeDesc.colorTarget = &s.hdrRasterSceneColor;
+        gbufferComputeDesc.gbufferTargets[0] = &s.gbuffer_basecolor; gbufferComputeDesc.gbufferTargets[1] = &s.gbuffer_normals;
+        gbufferComputeDesc.gbufferTargets[2] = &s.gbuffer_metallicRoughnessAo; gbufferComputeDesc.depthStencilTarget = &s.depthBuffer;
+        gbufferComputeDesc.sceneConstantBuffer = scene; gbufferComputeDesc.viewConstantBuffer = &cbViewConstants;
+        gbufferComputeDesc.resX = resX; gbufferComputeDesc.resY = resY; gbufferComputeDesc.scene = scene; gbufferComputeDesc.renderConfig = c;
+        GBufferComputePass::Execute(jobSync, gbufferComputeDesc);
+
+        // decals (:1784-1798) and HBAO (:1801-1840) are outside this library: AO reads as 1 (the cleared aoBuffer)
+
+        if (c.EnableSkyLighting) {                                             // :1843-1863
+            SkyLightingPass::Desc skyLightingDesc = {};
+            skyLightingDesc.colorTarget = &s.hdrRasterSceneColor; skyLightingDesc.depthStencilTex = &s.depthBuffer;
+            skyLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; skyLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
+            skyLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
+            skyLightingDesc.renderConfig = c; skyLightingDesc.scene = scene; skyLightingDesc.view = &renderState.m_view; skyLightingDesc.jitter = pixelJitter;
+            skyLightingDesc.resX = resX; skyLightingDesc.resY = resY; skyLightingDesc.viewConstantBuffer = &cbViewConstants;
+            SkyLightingPass::Execute(jobSync, skyLightingDesc);
+        }
+
+        if (!c.ForwardLighting) {                                              // :1866-1926 (forward lighting itself is out of scope)
+            const int directionalLightIndex = scene->GetDirectionalLight();
+            if (directionalLightIndex != -1 && c.EnableDirectLighting) {
+                DirectLightingPass::Desc directLightingDesc = {};
+                directLightingDesc.directionalLightIndex = directionalLightIndex;
+                directLightingDesc.colorTarget = &s.hdrRasterSceneColor; directLightingDesc.depthStencilTex = &s.depthBuffer;
+                directLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; directLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
+                directLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
+                directLightingDesc.sceneConstantBuffer = scene; directLightingDesc.viewConstantBuffer = &cbViewConstants;
+                directLightingDesc.renderConfig = c; directLightingDesc.resX = resX; directLightingDesc.resY = resY;
+                directLightingDesc.rayStatsBuffer = &s.rayStatsBuffer;
+                DirectLightingPass::Execute(jobSync, directLightingDesc);
+            }
+            const bool bRequiresClear = directionalLightIndex == -1;           // :1906
+            if (punctualLightCount > 0 && c.EnableDirectLighting) {
+                ClusteredLightingPass::Desc clusteredLightingDesc = {};
+                clusteredLightingDesc.lightListsBuffer = &s.culledLightListsBuffer; clusteredLightingDesc.lightGridBuffer = &s.lightGridBuffer;
+                clusteredLightingDesc.colorTarget = &s.hdrRasterSceneColor; clusteredLightingDesc.depthStencilTex = &s.depthBuffer;
+                clusteredLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; clusteredLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
+                clusteredLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
+                clusteredLightingDesc.sceneConstantBuffer = scene; clusteredLightingDesc.viewConstantBuffer = &cbViewConstants;
+                clusteredLightingDesc.renderConfig = c; clusteredLightingDesc.resX = resX; clusteredLightingDesc.resY = resY;
+                ClusteredLightingPass::Execute(jobSync, clusteredLightingDesc, bRequiresClear);
+            }
+        }
+
+        // environment map / dynamic sky background, debug viz, highlight (:1929-2001): outside this library
+
+        FShaderSurface* hdrOut = &s.hdrRasterSceneColor;
+        if (c.EnableTAA) {                                                     // :2003-2026
+            TAAResolvePass::Desc resolveDesc = {};
+            resolveDesc.source = &s.hdrRasterSceneColor;
+            resolveDesc.target = &s.taaAccumulationBuffer[frameIndex & 1]; resolveDesc.historySource = &s.taaAccumulationBuffer[(frameIndex + 1) & 1];
+            resolveDesc.resX = resX; resolveDesc.resY = resY; resolveDesc.historyIndex = (uint32_t)frameIndex;
+            resolveDesc.prevViewProjectionTransform = s.prevViewProjectionTransform;
+            resolveDesc.invViewProjectionTransform = cbViewConstants.m_viewConstants.taa_inv_view_proj;      // viewProjectionTransform.Invert()
+            resolveDesc.depthTexture = &s.depthBuffer; resolveDesc.renderConfig = c;
+            TAAResolvePass::Execute(jobSync, resolveDesc);
+            s.prevViewProjectionTransform = cbViewConstants.m_viewConstants.unjittered_view_proj;            // :2025
+            hdrOut = resolveDesc.target;
+        }
+
+        TonemapPass::Desc tonemapDesc = {};                                    // :2029-2036
+        tonemapDesc.source = hdrOut; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
+        TonemapPass::Execute(jobSync, tonemapDesc);
+    }
+    s.frameIndex++;
+    s.lastStatus = jobSync->m_firstError;
+    if (jobSync->m_firstError != INCR_OK) (void)0;       // the message is in jobSync->m_firstErrorMessage
+    return jobSync->m_firstError;
+}
+
+void ResetPathtraceAccumulation(State& s) { s.pathtraceCurrentSampleIndex = 1; }   // renderer.cpp:2080-2083
+
+} // namespace Renderer
+
+// =====================================================================================================================
+// C exports: the shape of the DLL interface (inc/demo-interface.h:10-16 Initialize / Render / Teardown), headless
+// =====================================================================================================================
+struct incr_renderer {
+    Renderer::State state;
+    FScene scene;
+    FConfig config;
+    std::string error;
+};
+
+extern "C" {
+
+int incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x, uint32_t res_y, const incr_renderer_scene* scene,
+                         const incr_renderer_config* config, incr_renderer** out) {
+    if (!ctx || !scene || !scene->scene || !out || !res_x || !res_y) return INCR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    incr_renderer* r = new (std::nothrow) incr_renderer();
+    if (!r) return INCR_ERR_OUT_OF_MEMORY;
+    r->scene.m_incrScene = const_cast<incr_scene*>(scene->scene);
+    r->scene.m_directionalLightIndex = scene->directional_light_index;
+    r->scene.m_punctualLightCount = scene->punctual_light_count;
+    r->scene.m_meshletCount = scene->meshlet_count;
+    r->scene.m_skylightSh9 = scene->skylight_sh9_rgba;
+    incr_renderer_set_config(r, config);
+    const int rc = Renderer::Initialize(r->state, ctx, stream, res_x, res_y, scene->meshlet_count, r->config);
+    if (rc) { Renderer::Teardown(r->state); delete r; return rc; }
+    *out = r;
+    return INCR_OK;
+}
+void incr_renderer_destroy(incr_renderer* r) { if (!r) return; Renderer::Teardown(r->state); delete r; }
+
+int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
+    if (!r) return INCR_ERR_INVALID_ARGUMENT;
+    if (!c) { r->config = FConfig(); return INCR_OK; }
+    FConfig& f = r->config;
+    f.PathTrace = c->path_trace != 0; f.Viewmode = c->viewmode; f.EnableTAA = c->enable_taa != 0; f.FrustumCulling = c->frustum_culling != 0;
+    f.EnableDirectLighting = c->enable_direct_lighting != 0; f.EnableSkyLighting = c->enable_sky_lighting != 0; f.EnableDiffuseIBL = c->enable_diffuse_ibl != 0;
+    f.Exposure = c->exposure; f.SkyBrightness = c->sky_brightness; f.CameraNearPlane = c->camera_near_plane;
+    f.LightClusterDimX = (int)c->light_cluster_dim[0]; f.LightClusterDimY = (int)c->light_cluster_dim[1]; f.LightClusterDimZ = (int)c->light_cluster_dim[2];
+    f.MaxLightsPerCluster = (int)c->max_lights_per_cluster; f.ClusterDepthExtent = c->cluster_depth_extent;
+    f.MaxSampleCount = c->max_sample_count; f.Pathtracing_CameraAperture = c->camera_aperture; f.Pathtracing_CameraFocalLength = c->camera_focal_length;
+    f.Turbidity = c->turbidity; f.EnvSkyMode = c->env_sky_mode; f.StorageRounding = c->storage_rounding;
+    return INCR_OK;
+}
+
+int incr_renderer_render(incr_renderer* r, const incr_view* view, const incr_view* culling_view) {
+    if (!r || !view) return INCR_ERR_INVALID_ARGUMENT;
+    Renderer::FRenderState rs;
+    rs.m_config = r->config; rs.m_scene = &r->scene; rs.m_resX = r->state.resX; rs.m_resY = r->state.resY;
+    auto fill = [](FView& f, const incr_view& v) {
+        f.m_viewTransform = v.view_transform; f.m_projectionTransform = v.projection_transform;
+        f.m_position = {v.position[0], v.position[1], v.position[2]}; f.m_right = {v.right[0], v.right[1], v.right[2]};
+        f.m_up = {v.up[0], v.up[1], v.up[2]}; f.m_look = {v.look[0], v.look[1], v.look[2]}; f.m_fov = v.fov;
+    };
+    fill(rs.m_view, *view); fill(rs.m_cullingView, culling_view ? *culling_view : *view);
+    if (culling_view) rs.m_config.FreezeCulling = true;
+    const int rc = Renderer::Render(r->state, rs);
+    if (rc) r->error = r->state.jobSync.m_firstErrorMessage;
+    return rc;
+}
+void incr_renderer_reset_accumulation(incr_renderer* r) { if (r) Renderer::ResetPathtraceAccumulation(r->state); }
+const char* incr_renderer_last_error(const incr_renderer* r) { return r ? r->error.c_str() : ""; }
+
+void* incr_renderer_surface(incr_renderer* r, int which) {
+    if (!r) return nullptr;
+    Renderer::State& s = r->state;
+    switch (which) {
+    case INCR_SURFACE_BACK_BUFFER: return s.backBuffer.m_devicePtr;
+    case INCR_SURFACE_HDR_RASTER: return s.hdrRasterSceneColor.m_devicePtr;
+    case INCR_SURFACE_HDR_RAYTRACE: return s.hdrRaytraceSceneColor.m_devicePtr;
+    case INCR_SURFACE_PATHTRACE_HISTORY: return s.pathtraceHistoryBuffer.m_devicePtr;
+    case INCR_SURFACE_TAA_ACCUMULATION: return s.taaAccumulationBuffer[(s.frameIndex + 1) & 1].m_devicePtr;   // written by the last frame
+    case INCR_SURFACE_DEPTH: return s.depthBuffer.m_devicePtr;
+    case INCR_SURFACE_VISIBILITY: return s.visBuffer.m_devicePtr;
+    case INCR_SURFACE_GBUFFER_BASECOLOR: return s.gbuffer_basecolor.m_devicePtr;
+    case INCR_SURFACE_GBUFFER_NORMALS: return s.gbuffer_normals.m_devicePtr;
+    case INCR_SURFACE_GBUFFER_METALLIC_ROUGHNESS_AO: return s.gbuffer_metallicRoughnessAo.m_devicePtr;
+    case INCR_SURFACE_RENDER_STATS: return s.renderStatsBuffer.m_devicePtr;
+    case INCR_SURFACE_RAY_STATS: return s.rayStatsBuffer.m_devicePtr;
+    case INCR_SURFACE_BATCH_COUNTS: return s.batchCountsBuffer.m_devicePtr;
+    default: return nullptr;
+    }
+}
+
+} // extern "C"

@@ -213,6 +213,25 @@ class TaaResolveDesc(C.Structure):
                 ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32)]
 
 
+class RendererScene(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("directional_light_index", C.c_int32), ("punctual_light_count", C.c_uint32),
+                ("meshlet_count", C.c_uint32), ("skylight_sh9_rgba", C.c_void_p)]
+
+
+class RendererConfig(C.Structure):
+    _fields_ = [("path_trace", C.c_int32), ("viewmode", C.c_int32), ("enable_taa", C.c_int32), ("frustum_culling", C.c_int32),
+                ("enable_direct_lighting", C.c_int32), ("enable_sky_lighting", C.c_int32), ("enable_diffuse_ibl", C.c_int32),
+                ("exposure", C.c_float), ("sky_brightness", C.c_float), ("camera_near_plane", C.c_float),
+                ("light_cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32), ("cluster_depth_extent", C.c_float),
+                ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
+                ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32)]
+
+
+(SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,
+ SURFACE_VISIBILITY, SURFACE_GBUFFER_BASECOLOR, SURFACE_GBUFFER_NORMALS, SURFACE_GBUFFER_MRA, SURFACE_RENDER_STATS, SURFACE_RAY_STATS,
+ SURFACE_BATCH_COUNTS) = range(13)
+
+
 # FConfig defaults the hot path reads (reference: source/demo-dll/inc/common.h:6-48)
 class FConfig:
     Fov = 0.25 * 3.14159265358979323846

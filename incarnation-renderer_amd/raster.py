@@ -218,6 +218,63 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
     return out
 
 
+def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
+    c = A.RendererConfig()
+    c.path_trace = int(cfg.PathTrace if path_trace is None else path_trace)
+    c.viewmode, c.enable_taa, c.frustum_culling = cfg.Viewmode, int(cfg.EnableTAA), int(cfg.FrustumCulling)
+    c.enable_direct_lighting, c.enable_sky_lighting, c.enable_diffuse_ibl = int(cfg.EnableDirectLighting), int(cfg.EnableSkyLighting), int(cfg.EnableDiffuseIBL)
+    c.exposure, c.sky_brightness, c.camera_near_plane = cfg.Exposure, cfg.SkyBrightness, cfg.CameraNearPlane
+    c.light_cluster_dim[:] = (cfg.LightClusterDimX, cfg.LightClusterDimY, cfg.LightClusterDimZ)
+    c.max_lights_per_cluster, c.cluster_depth_extent = cfg.MaxLightsPerCluster, cfg.ClusterDepthExtent
+    c.max_sample_count, c.camera_aperture, c.camera_focal_length = cfg.MaxSampleCount, cfg.Pathtracing_CameraAperture, cfg.Pathtracing_CameraFocalLength
+    c.turbidity, c.env_sky_mode, c.storage_rounding = cfg.Turbidity, cfg.EnvSkyMode, storage_rounding
+    return c
+
+
+class HostRenderer:
+    """The C++ host mirror of Renderer::Render (csrc/host/renderer.cpp) through incr_renderer_*: one call per frame.
+    This is the production frame loop; RasterRenderer below issues the same passes one by one from Python and exists so
+    that tests can compare every intermediate surface with the oracle."""
+
+    def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig, path_trace=False, sh9_rgb=None, stream=None, storage_rounding=0):
+        self.ctx, self.scene, self.res_x, self.res_y = ctx, scene, res_x, res_y
+        self.sh9 = None
+        if sh9_rgb is not None:
+            a = np.zeros((9, 4), dtype=np.float32); a[:, :3] = np.asarray(sh9_rgb, dtype=np.float32).reshape(9, 3)
+            self.sh9 = ctx.buffer(9 * 16)
+            ctx.upload(self.sh9, a)
+        s = A.RendererScene()
+        s.scene = scene.handle
+        s.directional_light_index = directional_light_index(scene.packed)
+        s.punctual_light_count = punctual_light_count(scene.packed)
+        s.meshlet_count = getattr(scene.packed, "num_meshlets", 0)
+        s.skylight_sh9_rgba = self.sh9
+        c = renderer_config(cfg, path_trace, storage_rounding)
+        self.handle = C.c_void_p()
+        rt.check(ctx.lib.incr_renderer_create(ctx.handle, stream, res_x, res_y, C.byref(s), C.byref(c), C.byref(self.handle)))
+
+    def render(self, view, culling_view=None):
+        v = view.to_ctypes()
+        cv = culling_view.to_ctypes() if culling_view is not None else None
+        rc = self.ctx.lib.incr_renderer_render(self.handle, C.byref(v), C.byref(cv) if cv is not None else None)
+        if rc != 0:
+            raise rt.IncrError(rc, self.ctx.lib.incr_renderer_last_error(self.handle).decode())
+
+    def surface_ptr(self, which):
+        return self.ctx.lib.incr_renderer_surface(self.handle, which)
+
+    def download(self, which, dtype=np.uint32, texel_words=1):
+        shape = (self.res_y, self.res_x) if texel_words == 1 else (self.res_y, self.res_x, texel_words)
+        return self.ctx.download(self.surface_ptr(which), shape, dtype)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.incr_renderer_destroy(self.handle)
+            self.handle = C.c_void_p()
+        if self.sh9:
+            self.ctx.free(self.sh9); self.sh9 = None
+
+
 class RasterRenderer:
     """One raster frame per render() call, all passes enqueued on one stream (job-sync.h:27-61 token order)."""
 

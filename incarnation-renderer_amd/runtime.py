@@ -26,6 +26,9 @@ EXPORTS = [
     "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
     "incr_sky_lighting", "incr_direct_lighting", "incr_clustered_lighting", "incr_taa_resolve",
+    # frame level (C++ host mirror of Renderer::Render)
+    "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
+    "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
 ]
 
 
@@ -96,6 +99,14 @@ def load():
                        ("incr_clustered_lighting", A.ClusteredLightingDesc), ("incr_taa_resolve", A.TaaResolveDesc)):
         fn = getattr(L, name)
         fn.restype = C.c_int; fn.argtypes = [vp, C.POINTER(desc), vp]
+    L.incr_renderer_create.restype = C.c_int
+    L.incr_renderer_create.argtypes = [vp, vp, u32, u32, C.POINTER(A.RendererScene), C.POINTER(A.RendererConfig), C.POINTER(vp)]
+    L.incr_renderer_destroy.restype = None; L.incr_renderer_destroy.argtypes = [vp]
+    L.incr_renderer_set_config.restype = C.c_int; L.incr_renderer_set_config.argtypes = [vp, C.POINTER(A.RendererConfig)]
+    L.incr_renderer_render.restype = C.c_int; L.incr_renderer_render.argtypes = [vp, C.POINTER(A.View), C.POINTER(A.View)]
+    L.incr_renderer_reset_accumulation.restype = None; L.incr_renderer_reset_accumulation.argtypes = [vp]
+    L.incr_renderer_last_error.restype = C.c_char_p; L.incr_renderer_last_error.argtypes = [vp]
+    L.incr_renderer_surface.restype = vp; L.incr_renderer_surface.argtypes = [vp, C.c_int]
     _lib = L
     return L
 

@@ -342,6 +342,46 @@ typedef struct incr_taa_resolve_desc {
 } incr_taa_resolve_desc;
 int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* desc, incr_stream stream);
 
+/* =====================================================================================================
+ * Frame level: the DLL exports Initialize / Render / Teardown (inc/demo-interface.h:10-16) over the C++ host mirror
+ * of Renderer::Render (csrc/host/renderer.cpp: RenderJob::<Pass>::Execute + the path-trace and raster branches of
+ * src/renderer.cpp:1676-2036).  One incr_renderer owns the frame's surfaces and the state Renderer keeps in statics
+ * (s_pathtraceCurrentSampleIndex, s_prevViewProjectionTransform, jitter table, TAA accumulation).
+ * ===================================================================================================== */
+typedef struct incr_renderer incr_renderer;
+typedef struct incr_renderer_scene {       /* what Renderer::Render asks FScene */
+    const incr_scene* scene;
+    int32_t  directional_light_index;      /* FScene::GetDirectionalLight() (-1 = none) */
+    uint32_t punctual_light_count;         /* FScene::GetPunctualLightCount() */
+    uint32_t meshlet_count;                /* FScene::m_meshletCount */
+    const float* skylight_sh9_rgba;        /* device, 9 x float4 skylight probe; NULL = none */
+} incr_renderer_scene;
+typedef struct incr_renderer_config {      /* FConfig fields the frame reads (inc/common.h:6-48) */
+    int32_t  path_trace, viewmode, enable_taa, frustum_culling, enable_direct_lighting, enable_sky_lighting, enable_diffuse_ibl;
+    float    exposure, sky_brightness, camera_near_plane;
+    uint32_t light_cluster_dim[3], max_lights_per_cluster;
+    float    cluster_depth_extent;
+    uint32_t max_sample_count;
+    float    camera_aperture, camera_focal_length, turbidity;
+    int32_t  env_sky_mode, storage_rounding;
+} incr_renderer_config;
+enum {
+    INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,
+    INCR_SURFACE_TAA_ACCUMULATION, INCR_SURFACE_DEPTH, INCR_SURFACE_VISIBILITY, INCR_SURFACE_GBUFFER_BASECOLOR,
+    INCR_SURFACE_GBUFFER_NORMALS, INCR_SURFACE_GBUFFER_METALLIC_ROUGHNESS_AO, INCR_SURFACE_RENDER_STATS, INCR_SURFACE_RAY_STATS,
+    INCR_SURFACE_BATCH_COUNTS
+};
+int   incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x, uint32_t res_y, const incr_renderer_scene* scene,
+                           const incr_renderer_config* config /* NULL = FConfig defaults */, incr_renderer** out_renderer);
+void  incr_renderer_destroy(incr_renderer* renderer);
+int   incr_renderer_set_config(incr_renderer* renderer, const incr_renderer_config* config);
+/* Renderer::Render: one frame (one path-traced sample when config.path_trace, else one raster frame), enqueued on the
+ * renderer's stream.  culling_view non-NULL = FConfig::FreezeCulling with that view. */
+int   incr_renderer_render(incr_renderer* renderer, const incr_view* view, const incr_view* culling_view);
+void  incr_renderer_reset_accumulation(incr_renderer* renderer);      /* Renderer::ResetPathtraceAccumulation */
+const char* incr_renderer_last_error(const incr_renderer* renderer);
+void* incr_renderer_surface(incr_renderer* renderer, int which);      /* device pointer of a frame surface (INCR_SURFACE_*) */
+
 #ifdef __cplusplus
 }
 #endif

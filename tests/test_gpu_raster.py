@@ -143,6 +143,46 @@ def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
         gscene.close()
 
 
+def test_cpp_host_renderer_matches_pass_by_pass(rt, R, A, sio, gpu_ctx, sponza_small):
+    """csrc/host/renderer.cpp (Renderer::Render in C++: RenderJob::<Pass>::Execute in the reference's order and with its
+    frame-to-frame state) must produce exactly what the pass-by-pass sequence issued from Python produces."""
+    W, H = 224, 126
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    try:
+        # raster branch, three frames (jitter sequence, TAA ping-pong, prevViewProj carried across frames)
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9)
+        rr = R.RasterRenderer(gpu_ctx, gscene, W, H); rr.set_sh9(DEFAULT_SH9)
+        for frame in range(3):
+            hr.render(view); rr.render(view)
+            gpu_ctx.synchronize()
+            for which, name in ((A.SURFACE_VISIBILITY, "vis"), (A.SURFACE_DEPTH, "depth"), (A.SURFACE_GBUFFER_BASECOLOR, "gbuffer_basecolor"),
+                                (A.SURFACE_GBUFFER_NORMALS, "gbuffer_normals"), (A.SURFACE_GBUFFER_MRA, "gbuffer_mra"), (A.SURFACE_HDR_RASTER, "color"),
+                                (A.SURFACE_TAA_ACCUMULATION, "taa%d" % (frame & 1)), (A.SURFACE_BACK_BUFFER, "ldr")):
+                a = hr.download(which)
+                b = rr.surf.download(name)
+                np.testing.assert_array_equal(a, b.view(np.uint32), err_msg="frame %d %s" % (frame, name))
+        hr.close(); rr.close()
+        # path-trace branch: samples 1..MaxSampleCount-1, then the accumulation stops (renderer.cpp:1681)
+        class Cfg(A.FConfig):
+            MaxSampleCount = 4           # sqrtSampleCount = 2; samples 1, 2, 3
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Cfg, path_trace=True)
+        pt = rt.PathTracer(gpu_ctx, gscene, W, H)
+        for n in (1, 2, 3):
+            hr.render(view); pt.render(view, sample_index=n, cfg=Cfg)
+            np.testing.assert_array_equal(hr.download(A.SURFACE_PATHTRACE_HISTORY), pt.read()["history"], err_msg="sample %d" % n)
+        before = hr.download(A.SURFACE_PATHTRACE_HISTORY)
+        hr.render(view)                                      # sample index 4 == MaxSampleCount: no further sample
+        np.testing.assert_array_equal(hr.download(A.SURFACE_PATHTRACE_HISTORY), before)
+        gpu_ctx.lib.incr_renderer_reset_accumulation(hr.handle)
+        hr.render(view)
+        pt2 = rt.PathTracer(gpu_ctx, gscene, W, H); pt2.render(view, sample_index=1, cfg=Cfg)
+        np.testing.assert_array_equal(hr.download(A.SURFACE_PATHTRACE_HISTORY), pt2.read()["history"])
+        hr.close(); pt.close(); pt2.close()
+    finally:
+        gscene.close()
+
+
 def test_raster_4k_properties(rt, R, ob, A, sio, gpu_ctx, synth):
     """Full-size frame (BASELINE config 3 shape: Sponza statistics at 3840x2160): size-independent properties."""
     scene = synth.sponza_stat(texture_size=256)

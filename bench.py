@@ -83,25 +83,59 @@ RASTER_SH9 = [[1.0, 1.1, 1.3], [0.3, 0.3, 0.35], [0.1, 0.1, 0.2], [-0.05, -0.04,
               [0.04, 0.05, 0.05], [-0.03, -0.03, -0.02], [0.01, 0.02, 0.02], [0.05, 0.04, 0.03]]
 
 
-def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle):
-    """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM."""
+class _DeviceWords:
+    """CUDA array interface over a raw device pointer: lets torch.distributed collectives run on a library-owned surface."""
+
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, torch, dist, rank, world, dev):
+    """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM.
+    world > 1: every rank renders its row band; one RCCL all_gather of the TAA bands per frame; rank 0 tonemaps."""
     R = importlib.import_module(PKG + ".raster")
     A = importlib.import_module(PKG + ".ctypes_api")
     rr = R.HostRenderer(ctx, scene, W, H, sh9_rgb=RASTER_SH9, stream=stream_handle)      # C++ Renderer::Render (csrc/host/renderer.cpp)
-    for _ in range(warmup):
+    rows = (H + world - 1) // world
+    tensors = {}
+    if world > 1:
+        rr.set_band(rank * rows, min((rank + 1) * rows, H))
+
+    def frame():
         rr.render(view)
-    ctx.synchronize(stream_handle)
+        if world > 1:
+            ptr = rr.surface_ptr(A.SURFACE_TAA_ACCUMULATION)
+            if ptr not in tensors:
+                tensors[ptr] = torch.as_tensor(_DeviceWords(ptr, world * rows * W), device=dev)
+            full = tensors[ptr]
+            band = full[rank * rows * W:(rank + 1) * rows * W].clone()
+            dist.all_gather_into_tensor(full, band)
+            if rank == 0:
+                rr.tonemap()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        frame()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        rr.render(view)
-    ctx.synchronize(stream_handle)
-    ms = (time.perf_counter() - t0) / steps * 1e3
+        frame()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms = float(tt.item()) / steps * 1e3
     counts = ctx.download(rr.surface_ptr(A.SURFACE_BATCH_COUNTS), (2,), np.uint32)
     raw = ctx.download(rr.surface_ptr(A.SURFACE_RAY_STATS), (C.sizeof(A.RayStats),), np.uint8)
     rays = A.RayStats.from_buffer_copy(raw.tobytes()).light_shadow_rays // (steps + warmup)
     rr.close()
     alg = float(W) * H * RASTER_B_PX
-    return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1),
+    return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world,
+            "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
             "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), TAA on, 1 sun shadow ray/pixel"
                         % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1])),
             "passes": "batch_cull, light_cull, visibility, gbuffer, sky_lighting, direct_lighting, clustered_lighting, taa_resolve, tonemap",
@@ -209,6 +243,12 @@ def main():
     rays = int(s[0] + s[1] + s[2] + s[3]); hits = int(s[4])
     call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events around the whole incr_pathtrace call
 
+    # second half of the metric ("Mray/s + ms/frame"): the raster frame of config 3, outside the timed path-trace region;
+    # at N > 1 every rank renders its row band and the TAA bands are all-gathered (sort-first)
+    raster_out = None
+    if not args.no_raster:
+        raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev)
+
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
         # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 17 launches (generate + 4 x extend / shade /
@@ -257,9 +297,8 @@ def main():
                     out["roofline"]["traffic_source"] = tj.get("source")
             except Exception:
                 pass
-        if world == 1 and not args.no_raster:
-            # second half of the metric ("Mray/s + ms/frame"): the raster frame of config 3, outside the timed path-trace region
-            out["raster"] = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream)
+        if raster_out is not None:
+            out["raster"] = raster_out
         if world == 1 and not args.no_cpu_baseline:
             cw, ch = (int(v) for v in args.cpu_res.lower().split("x"))
             out["cpu_baseline"] = cpu_baseline(packed, sio.FView().reset(packed, aspect=cw / ch), (cw, ch), 20)

@@ -189,6 +189,7 @@ struct Desc {
     FShaderSurface* depthTexture;                   // depthTextureIndex in the reference
     FConfig renderConfig;
     FShaderSurface* historySource = nullptr;        // the reference resolves in place; here last frame's accumulation buffer
+    uint32_t rowBegin = 0, rowEnd = 0;              // not in the reference: rows this GPU resolves (0,0 = the whole frame)
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }

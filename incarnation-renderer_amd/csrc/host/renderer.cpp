@@ -152,6 +152,7 @@ Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa
     incr_view_constants vc = {};
     vc.taa_inv_view_proj = p.invViewProjectionTransform; vc.prev_view_proj_transform = p.prevViewProjectionTransform;
     vc.res_x = p.resX; vc.res_y = p.resY;
+    vc.scissor_y0 = p.rowBegin; vc.scissor_y1 = p.rowEnd;
     incr_taa_resolve_desc d = {};
     d.view = &vc;
     d.hdr_scene_color = (const uint32_t*)p.source->m_devicePtr; d.history_out = (uint32_t*)p.target->m_devicePtr;
@@ -190,7 +191,12 @@ struct State {
     FShaderBuffer renderStatsBuffer, rayStatsBuffer;
     std::vector<void*> allocations;
     int lastStatus = INCR_OK;
+    // Sort-first multi-GPU: this GPU draws and shades rows [bandY0, bandY1) plus a one-row halo for the TAA
+    // neighbourhood, resolves TAA for the band only and leaves gather + tonemap to the caller.  0,0 = the whole frame.
+    uint32_t bandY0 = 0, bandY1 = 0;
+    FShaderSurface* lastHdr = nullptr;                         // what the tonemap of this frame reads
 };
+static constexpr uint32_t kBandSlackRows = 64;                  // TAA surfaces hold ceil(H/N)*N rows for an equal-sized all_gather
 
 static int alloc(State& s, void** out, uint64_t bytes, bool clear) {
     int rc = incr_buffer_create(s.ctx, bytes, out);
@@ -212,8 +218,12 @@ int Initialize(State& s, incr_context* ctx, incr_stream stream, uint32_t resX, u
     for (uint32_t i = 0; i < 16; ++i) { float j[2]; incr_pixel_jitter(i, resX, resY, j); s.pixelJitterValues.push_back({j[0], j[1]}); }   // renderer.cpp:126-131
     int rc = 0;
     FShaderSurface* four[] = {&s.hdrRasterSceneColor, &s.depthBuffer, &s.visBuffer, &s.gbuffer_basecolor, &s.gbuffer_normals, &s.gbuffer_metallicRoughnessAo,
-                              &s.pathtraceHistoryBuffer, &s.taaAccumulationBuffer[0], &s.taaAccumulationBuffer[1], &s.backBuffer};
+                              &s.pathtraceHistoryBuffer, &s.backBuffer};
     for (FShaderSurface* f : four) if (!rc) rc = surface(s, *f, 4, true);
+    for (FShaderSurface& f : s.taaAccumulationBuffer) {
+        f.m_width = resX; f.m_height = resY; f.m_texelBytes = 4;
+        if (!rc) rc = alloc(s, &f.m_devicePtr, (uint64_t)resX * (resY + kBandSlackRows) * 4, true);
+    }
     if (!rc) rc = surface(s, s.hdrRaytraceSceneColor, 8, true);
     const uint64_t clusters = (uint64_t)c.LightClusterDimX * c.LightClusterDimY * c.LightClusterDimZ;
     if (!rc) rc = buffer(s, s.batchArgsBuffer_Default, (meshletCount + 1) * sizeof(incr_draw_cmd));
@@ -250,6 +260,11 @@ int Render(State& s, const FRenderState& renderState) {
     const float jitter[2] = {pixelJitter.x, pixelJitter.y};
     int rc = incr_make_view_constants(&view, &cull, jitter, &s.prevViewProjectionTransform, c.CameraNearPlane, resX, resY, &cbViewConstants.m_viewConstants);
     if (rc) return rc;
+    const bool banded = !(s.bandY0 == 0 && s.bandY1 == 0);
+    if (banded) {            // draw + shade the band and one halo row each side (TAA reads a 3x3 neighbourhood of the colour target)
+        cbViewConstants.m_viewConstants.scissor_y0 = s.bandY0 ? s.bandY0 - 1 : 0;
+        cbViewConstants.m_viewConstants.scissor_y1 = s.bandY1 + 1 < resY ? s.bandY1 + 1 : resY;
+    }
 
     UpdateTLASPass::Execute(jobSync, scene);                                   // :1676
 
@@ -349,14 +364,18 @@ int Render(State& s, const FRenderState& renderState) {
             resolveDesc.prevViewProjectionTransform = s.prevViewProjectionTransform;
             resolveDesc.invViewProjectionTransform = cbViewConstants.m_viewConstants.taa_inv_view_proj;      // viewProjectionTransform.Invert()
             resolveDesc.depthTexture = &s.depthBuffer; resolveDesc.renderConfig = c;
+            if (banded) { resolveDesc.rowBegin = s.bandY0; resolveDesc.rowEnd = s.bandY1 < resY ? s.bandY1 : resY; }
             TAAResolvePass::Execute(jobSync, resolveDesc);
             s.prevViewProjectionTransform = cbViewConstants.m_viewConstants.unjittered_view_proj;            // :2025
             hdrOut = resolveDesc.target;
         }
 
-        TonemapPass::Desc tonemapDesc = {};                                    // :2029-2036
-        tonemapDesc.source = hdrOut; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
-        TonemapPass::Execute(jobSync, tonemapDesc);
+        s.lastHdr = hdrOut;
+        if (!banded) {       // with row bands the caller gathers the bands first, then calls Tonemap()
+            TonemapPass::Desc tonemapDesc = {};                                // :2029-2036
+            tonemapDesc.source = hdrOut; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
+            TonemapPass::Execute(jobSync, tonemapDesc);
+        }
     }
     s.frameIndex++;
     s.lastStatus = jobSync->m_firstError;
@@ -365,6 +384,14 @@ int Render(State& s, const FRenderState& renderState) {
 }
 
 void ResetPathtraceAccumulation(State& s) { s.pathtraceCurrentSampleIndex = 1; }   // renderer.cpp:2080-2083
+
+// Tonemap of the whole frame after the row bands were gathered (multi-GPU): renderer.cpp:2029-2036 on the presenting rank
+int Tonemap(State& s, const FConfig& c) {
+    if (!s.lastHdr) return INCR_ERR_INVALID_ARGUMENT;
+    RenderJob::TonemapPass::Desc tonemapDesc = {};
+    tonemapDesc.source = s.lastHdr; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
+    return RenderJob::TonemapPass::Execute(&s.jobSync, tonemapDesc).m_status;
+}
 
 } // namespace Renderer
 
@@ -429,6 +456,13 @@ int incr_renderer_render(incr_renderer* r, const incr_view* view, const incr_vie
     return rc;
 }
 void incr_renderer_reset_accumulation(incr_renderer* r) { if (r) Renderer::ResetPathtraceAccumulation(r->state); }
+int incr_renderer_set_band(incr_renderer* r, uint32_t row_begin, uint32_t row_end) {
+    if (!r || row_end < row_begin) return INCR_ERR_INVALID_ARGUMENT;
+    if (row_end > r->state.resY + Renderer::kBandSlackRows) return INCR_ERR_INVALID_ARGUMENT;
+    r->state.bandY0 = row_begin; r->state.bandY1 = row_end;
+    return INCR_OK;
+}
+int incr_renderer_tonemap(incr_renderer* r) { return r ? Renderer::Tonemap(r->state, r->config) : INCR_ERR_INVALID_ARGUMENT; }
 const char* incr_renderer_last_error(const incr_renderer* r) { return r ? r->error.c_str() : ""; }
 
 void* incr_renderer_surface(incr_renderer* r, int which) {

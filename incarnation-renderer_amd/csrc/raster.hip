@@ -243,12 +243,12 @@ DI bool orient_subtri(ScreenVert& v0, ScreenVert& v1, ScreenVert& v2, bool cullB
     return true;
 }
 // Scan set-up of a clockwise screen triangle; false when its bounding box holds no pixel centre.
-DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, uint32_t W, uint32_t H, SubTri* st) {
+DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, uint32_t W, uint32_t y0, uint32_t y1, SubTri* st) {
     const long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
     const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
     const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
     st->px0 = max(0, (minX + 127) >> 8); st->px1 = min((int32_t)W - 1, (maxX - 128) >> 8);
-    st->py0 = max(0, (minY + 127) >> 8); st->py1 = min((int32_t)H - 1, (maxY - 128) >> 8);
+    st->py0 = max((int32_t)y0, (minY + 127) >> 8); st->py1 = min((int32_t)y1 - 1, (maxY - 128) >> 8);      // scissor rows [y0, y1)
     if (st->px0 > st->px1 || st->py0 > st->py1) return false;
     const long long Sx = (long long)st->px0 * 256 + 128, Sy = (long long)st->py0 * 256 + 128;
     const int32_t dx01 = v1.X - v0.X, dy01 = v1.Y - v0.Y, dx12 = v2.X - v1.X, dy12 = v2.Y - v1.Y, dx20 = v0.X - v2.X, dy20 = v0.Y - v2.Y;
@@ -323,7 +323,7 @@ DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
 DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriRec r = P.recs[idx];
     const ScreenVert v0 = {r.X0, r.Y0, r.z0}, v1 = {r.X1, r.Y1, r.z1}, v2 = {r.X2, r.Y2, r.z2};
-    if (!setup_subtri(v0, v1, v2, P.W, P.H, st)) return false;
+    if (!setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, st)) return false;
     st->key = r.key; st->alphaTex = r.alphaTex;
     if (r.alphaTex >= 0) vq_load_alpha(P, idx, st);
     return true;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisPara
                 ScreenVert v0 = sv[0], v1 = sv[s + 1], v2 = sv[s + 2];
                 if (!orient_subtri(v0, v1, v2, list == 0)) continue;
                 SubTri st;
-                if (!setup_subtri(v0, v1, v2, P.W, P.H, &st)) continue;
+                if (!setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, &st)) continue;
                 const uint32_t idx = atomicAdd(P.vqCounters + 0, 1u);
                 if (idx >= P.recCap) continue;                   // cannot happen: recCap = 2 x scene triangles
                 SubTriRec r;
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long lo
 // ---------------------------------------------------------------------------------------------- G-buffer
 // gbuffer-compute.hlsl:157-253 (USING_MESHLETS); 16x16 thread groups there, 64x4 pixel blocks here (one wave = one row run)
 __global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.W || y >= P.H) return;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.y1) return;
     const size_t i = (size_t)y * P.W + x;
     const uint32_t v = P.vis[i];
     if (v == 0xFFFFF000u) { P.g0[i] = 0; P.g1[i] = 0; P.g2[i] = 0; P.color[i] = 0; return; }
@@ -541,8 +541,8 @@ DI f3 ShIrradiance(f3 n, const float4* __restrict__ sh) {                   // s
     return irr;
 }
 __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.L.W || y >= P.L.H) return;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.y1) return;
     const size_t i = (size_t)y * P.L.W + x;
     const GBufferPixel g = read_gbuffer(P.L, i);
     f3 radiance = {0.f, 0.f, 0.f};
@@ -560,9 +560,9 @@ __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
 __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectParams P) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const uint32_t tid = threadIdx.x;
-    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = blockIdx.y * 4 + (tid >> 6);
+    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = P.L.y0 + blockIdx.y * 4 + (tid >> 6);
     uint32_t rays = 0;
-    if (x < P.L.W && y < P.L.H) {
+    if (x < P.L.W && y < P.L.y1) {
         LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
         const size_t i = (size_t)y * P.L.W + x;
         const GBufferPixel g = read_gbuffer(P.L, i);
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
 
 // clustered-lighting.hlsl:35-115 + cluster-culling.hlsli:26-41
 __global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.L.W || y >= P.L.H) return;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.y1) return;
     const size_t i = (size_t)y * P.L.W + x;
     if (P.requiresClear) P.L.color[i] = 0;
     const GBufferPixel g = read_gbuffer(P.L, i);
@@ -653,8 +653,8 @@ DI f3 sample_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, uint32
 DI float lum_weight(f3 c) { return 1.f / (1.f + ((c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f)); }
 // taa-resolve.hlsl:34-117
 __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.W || y >= P.H) return;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.y1) return;
     const size_t i = (size_t)y * P.W + x;
     const f3 cur = unpack_r11g11b10(P.hdr[i]);
     if (P.historyIndex == 0) { P.histOut[i] = pack_r11g11b10(cur, P.rounding); return; }
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
 
 // ---- launchers (called from raster_api.hip) ------------------------------------------------------------
 using namespace incr;
-static inline dim3 pixel_grid(uint32_t W, uint32_t H) { return dim3((W + 63) / 64, (H + 3) / 4); }
+static inline dim3 pixel_grid(uint32_t W, uint32_t y0, uint32_t y1) { return dim3((W + 63) / 64, (y1 - y0 + 3) / 4); }
 
 extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFrame* vf, MeshFrame* out, hipStream_t stream) {
     if (!S->numMeshes) return hipSuccess;
@@ -703,9 +703,9 @@ extern "C" hipError_t incr_launch_light_cull(const LightCullParams* p, hipStream
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJobs, int numCUs, uint32_t* vis, float* depth, hipStream_t stream) {
-    const size_t n = (size_t)p->W * p->H;
-    if (!n) return hipSuccess;
-    hipError_t e = hipMemsetAsync(p->packed, 0, n * 8, stream);
+    if (p->y1 <= p->y0 || !p->W) return hipSuccess;
+    const size_t n = (size_t)p->W * (p->y1 - p->y0), first = (size_t)p->W * p->y0;     // only the scissor rows are cleared, drawn and resolved
+    hipError_t e = hipMemsetAsync(p->packed + first, 0, n * 8, stream);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(p->vqCounters, 0, 64, stream)) != hipSuccess) return e;
     if (maxJobs) {
@@ -715,31 +715,31 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
         hipLaunchKernelGGL(vis_scan_kernel, dim3((uint32_t)numCUs * 8u), dim3(256), 0, stream, *p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(vis_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p->packed, vis, depth, n);
+    hipLaunchKernelGGL(vis_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p->packed + first, vis + first, depth + first, n);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t stream) {
-    if (!p->W || !p->H) return hipSuccess;
-    hipLaunchKernelGGL(gbuffer_kernel, pixel_grid(p->W, p->H), dim3(256), 0, stream, *p);
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(gbuffer_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream) {
-    if (!p->L.W || !p->L.H) return hipSuccess;
-    hipLaunchKernelGGL(sky_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(256), 0, stream, *p);
+    if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
+    hipLaunchKernelGGL(sky_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {
-    if (!p->L.W || !p->L.H) return hipSuccess;
-    hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(kBlock), 0, stream, *p);
+    if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
+    hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(kBlock), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {
-    if (!p->L.W || !p->L.H) return hipSuccess;
-    hipLaunchKernelGGL(clustered_lighting_kernel, pixel_grid(p->L.W, p->L.H), dim3(256), 0, stream, *p);
+    if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
+    hipLaunchKernelGGL(clustered_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream) {
-    if (!p->W || !p->H) return hipSuccess;
-    hipLaunchKernelGGL(taa_resolve_kernel, pixel_grid(p->W, p->H), dim3(256), 0, stream, *p);
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(taa_resolve_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }

@@ -148,6 +148,13 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     ws->recCap = (uint32_t)recCap; ws->bigCap = (uint32_t)bigCap;
     return INCR_OK;
 }
+// scissor rows of a pass: [y0, y1) clamped to the frame; 0,0 = whole frame
+void scissor_rows(const incr_view_constants& v, uint32_t* y0, uint32_t* y1) {
+    const bool whole = v.scissor_y0 == 0 && v.scissor_y1 == 0;
+    *y0 = whole ? 0u : (v.scissor_y0 < v.res_y ? v.scissor_y0 : v.res_y);
+    *y1 = whole ? v.res_y : (v.scissor_y1 < v.res_y ? v.scissor_y1 : v.res_y);
+    if (*y1 < *y0) *y1 = *y0;
+}
 int check_view(const incr_view_constants* v) {
     if (!v) return fail(INCR_ERR_INVALID_ARGUMENT, "view constants are NULL");
     if (!v->res_x || !v->res_y) return fail(INCR_ERR_INVALID_ARGUMENT, "zero resolution");
@@ -162,6 +169,7 @@ int fill_lighting(const incr_lighting_inputs& in, LightingParams& L) {
         return fail(INCR_ERR_INVALID_ARGUMENT, "a lighting input surface is NULL");
     memset(&L, 0, sizeof L);
     L.W = in.view->res_x; L.H = in.view->res_y;
+    scissor_rows(*in.view, &L.y0, &L.y1);
     L.color = in.color_target; L.depth = in.depth_buffer; L.g0 = in.gbuffer_basecolor; L.g1 = in.gbuffer_normals; L.g2 = in.gbuffer_metallic_roughness_ao;
     L.lightingOnly = in.lighting_only; L.rounding = in.storage_rounding;
     memcpy(L.invViewProj, in.view->inv_view_proj_transform.m, 64); memcpy(L.invProj, in.view->inv_proj_transform.m, 64);
@@ -231,6 +239,7 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
     fill_raster_scene(ctx, sc, P.S);
     memcpy(P.viewProj, d->view->view_proj_transform.m, 64);
     P.W = d->view->res_x; P.H = d->view->res_y;
+    scissor_rows(*d->view, &P.y0, &P.y1);
     P.lists[0] = d->default_list; P.lists[1] = d->double_sided_list; P.counts = d->counts;
     RasterWorkspace ws;
     if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, sc->host.meshletPackedTriangles.size(), (hipStream_t)stream, &ws))) return rc;
@@ -255,6 +264,7 @@ int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stre
     if ((rc = ensure_raster_workspace(ctx, 0, P.S.numMeshes, 0, (hipStream_t)stream, &ws))) return rc;
     HIP_TRY(incr_launch_mesh_frames(&P.S, &vf, ws.frames, (hipStream_t)stream));
     P.frames = ws.frames; P.W = d->view->res_x; P.H = d->view->res_y; P.vis = d->vis_buffer;
+    scissor_rows(*d->view, &P.y0, &P.y1);
     P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao; P.color = d->color_target;
     P.rounding = d->storage_rounding;
     HIP_TRY(incr_launch_gbuffer(&P, (hipStream_t)stream));
@@ -318,6 +328,7 @@ int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* d, incr_str
     if (d->history_in == d->history_out) return fail(INCR_ERR_INVALID_ARGUMENT, "history_in and history_out must not alias");
     TaaParams P; memset(&P, 0, sizeof P);
     P.W = d->view->res_x; P.H = d->view->res_y; P.historyIndex = d->history_index; P.rounding = d->storage_rounding;
+    scissor_rows(*d->view, &P.y0, &P.y1);
     P.hdr = d->hdr_scene_color; P.histIn = d->history_in; P.histOut = d->history_out; P.depth = d->depth_buffer;
     memcpy(P.invViewProj, d->view->taa_inv_view_proj.m, 64); memcpy(P.prevViewProj, d->view->prev_view_proj_transform.m, 64);
     HIP_TRY(incr_launch_taa_resolve(&P, (hipStream_t)stream));

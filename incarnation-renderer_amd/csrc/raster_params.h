@@ -77,6 +77,7 @@ struct VisParams {
     uint2* __restrict__ bigQueue; uint32_t* __restrict__ smallQueue; uint32_t* __restrict__ wholeQueue;
     uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors
     uint32_t recCap, bigCap;
+    uint32_t y0, y1;                                 // scissor rows [y0, y1) (incr_view_constants::scissor_y0/y1)
 };
 
 struct GBufferParams {
@@ -86,6 +87,7 @@ struct GBufferParams {
     const uint32_t* __restrict__ vis;
     uint32_t* __restrict__ g0; uint32_t* __restrict__ g1; uint32_t* __restrict__ g2; uint32_t* __restrict__ color;
     int32_t rounding;
+    uint32_t y0, y1;
 };
 
 struct LightingParams {
@@ -95,6 +97,7 @@ struct LightingParams {
     int32_t lightingOnly, rounding;
     float invViewProj[16], invProj[16];
     float eye[3];
+    uint32_t y0, y1;
 };
 
 struct SkyParams { LightingParams L; const float4* __restrict__ sh9; const uint8_t* __restrict__ ao; float skyBrightness; int32_t diffuseIbl; };
@@ -113,6 +116,7 @@ struct TaaParams {
     uint32_t W, H, historyIndex; int32_t rounding;
     const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;
     float invViewProj[16], prevViewProj[16];
+    uint32_t y0, y1;
 };
 
 } // namespace incr

@@ -148,7 +148,8 @@ class ViewConstants(C.Structure):
         "view_transform", "proj_transform", "view_proj_transform", "inv_view_proj_transform", "inv_proj_transform",
         "cull_view_proj_transform", "prev_view_proj_transform", "lightcull_proj_transform", "lightcull_inv_view_proj",
         "sky_inv_view_proj", "unjittered_view_proj", "taa_inv_view_proj")] + [
-        ("eye_pos", c_float3), ("near_plane", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("jitter", C.c_float * 2)]
+        ("eye_pos", c_float3), ("near_plane", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("jitter", C.c_float * 2),
+        ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32)]
 
 
 class DrawCmd(C.Structure):

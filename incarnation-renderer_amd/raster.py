@@ -167,10 +167,24 @@ def lighting_inputs(scene_handle, vc, surf, cfg=A.FConfig, storage_rounding=0):
     return i
 
 
-def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig, storage_rounding=0, have_sh=True):
+def with_scissor(vc, row_begin, row_end):
+    c = A.ViewConstants.from_buffer_copy(vc)
+    c.scissor_y0, c.scissor_y1 = row_begin, row_end
+    return c
+
+
+def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig, storage_rounding=0, have_sh=True, band=None):
     """All pass descs of one raster frame over a dict of surface pointers (device pointers for the HIP library, host
-    pointers for the oracle: both take the same structs).  Returns an ordered list of (pass name, desc)."""
+    pointers for the oracle: both take the same structs).  Returns an ordered list of (pass name, desc).
+    band = (row_begin, row_end): the sort-first multi-GPU variant -- draw and shade the band plus a one-row halo,
+    resolve TAA for the band only (csrc/host/renderer.cpp does the same in C++)."""
     out = []
+    vc_full = vc
+    vc_taa = vc
+    if band is not None:
+        y0, y1 = band
+        vc = with_scissor(vc_full, max(y0, 1) - 1, min(y1 + 1, vc_full.res_y))
+        vc_taa = with_scissor(vc_full, y0, min(y1, vc_full.res_y))
     vcp = C.pointer(vc)
     d = A.BatchCullDesc(); d.scene, d.view = scene_handle, vcp
     d.default_list, d.double_sided_list, d.counts, d.render_stats = surf["default_list"], surf["double_sided_list"], surf["counts"], surf["render_stats"]
@@ -210,7 +224,7 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
         d.cluster_depth_extent, d.requires_clear = cfg.ClusterDepthExtent, 1 if sun == -1 else 0
         out.append(("clustered_lighting", d))
     if cfg.EnableTAA:
-        d = A.TaaResolveDesc(); d.view = vcp
+        d = A.TaaResolveDesc(); d.view = C.pointer(vc_taa)
         d.hdr_scene_color, d.depth_buffer = surf["color"], surf["depth"]
         d.history_in, d.history_out = surf["taa%d" % ((frame_index + 1) & 1)], surf["taa%d" % (frame_index & 1)]
         d.history_index, d.storage_rounding = frame_index, storage_rounding
@@ -259,6 +273,13 @@ class HostRenderer:
         rc = self.ctx.lib.incr_renderer_render(self.handle, C.byref(v), C.byref(cv) if cv is not None else None)
         if rc != 0:
             raise rt.IncrError(rc, self.ctx.lib.incr_renderer_last_error(self.handle).decode())
+
+    def set_band(self, row_begin, row_end):
+        """Sort-first multi-GPU: render only rows [row_begin, row_end) (+ halo); the caller gathers the TAA bands and calls tonemap()."""
+        rt.check(self.ctx.lib.incr_renderer_set_band(self.handle, row_begin, row_end))
+
+    def tonemap(self):
+        rt.check(self.ctx.lib.incr_renderer_tonemap(self.handle))
 
     def surface_ptr(self, which):
         return self.ctx.lib.incr_renderer_surface(self.handle, which)

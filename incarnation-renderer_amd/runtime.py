@@ -29,6 +29,7 @@ EXPORTS = [
     # frame level (C++ host mirror of Renderer::Render)
     "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
+    "incr_renderer_set_band", "incr_renderer_tonemap",
 ]
 
 
@@ -107,6 +108,8 @@ def load():
     L.incr_renderer_reset_accumulation.restype = None; L.incr_renderer_reset_accumulation.argtypes = [vp]
     L.incr_renderer_last_error.restype = C.c_char_p; L.incr_renderer_last_error.argtypes = [vp]
     L.incr_renderer_surface.restype = vp; L.incr_renderer_surface.argtypes = [vp, C.c_int]
+    L.incr_renderer_set_band.restype = C.c_int; L.incr_renderer_set_band.argtypes = [vp, u32, u32]
+    L.incr_renderer_tonemap.restype = C.c_int; L.incr_renderer_tonemap.argtypes = [vp]
     _lib = L
     return L
 

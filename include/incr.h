@@ -201,6 +201,7 @@ typedef struct incr_view_constants {
     float    near_plane;                     /* FConfig::CameraNearPlane (1.0) */
     uint32_t res_x, res_y;
     float    jitter[2];
+    uint32_t scissor_y0, scissor_y1;         /* rows [y0, y1) a pass touches (sort-first multi-GPU row bands); 0,0 = the whole frame */
 } incr_view_constants;
 /* renderer.cpp:126-131: jitter = 2 * (Halton(i,2), Halton(i,3)) - 0.5) / res for i = frame_index % 16. */
 void incr_pixel_jitter(uint32_t frame_index, uint32_t res_x, uint32_t res_y, float out_jitter[2]);
@@ -379,6 +380,13 @@ int   incr_renderer_set_config(incr_renderer* renderer, const incr_renderer_conf
  * renderer's stream.  culling_view non-NULL = FConfig::FreezeCulling with that view. */
 int   incr_renderer_render(incr_renderer* renderer, const incr_view* view, const incr_view* culling_view);
 void  incr_renderer_reset_accumulation(incr_renderer* renderer);      /* Renderer::ResetPathtraceAccumulation */
+/* Sort-first multi-GPU raster: this GPU renders rows [row_begin, row_end) of the frame (plus a one-row halo
+ * for the TAA neighbourhood) and resolves TAA for the band only; culling and light culling stay replicated.  After each
+ * frame the caller gathers every rank's band of INCR_SURFACE_TAA_ACCUMULATION into that same surface on all ranks (one
+ * RCCL all_gather of equal bands: the surface has 64 slack rows for ceil(res_y / N) * N) and then calls
+ * incr_renderer_tonemap on the presenting rank.  0,0 = the whole frame (single GPU; tonemap inside render). */
+int   incr_renderer_set_band(incr_renderer* renderer, uint32_t row_begin, uint32_t row_end);
+int   incr_renderer_tonemap(incr_renderer* renderer);
 const char* incr_renderer_last_error(const incr_renderer* renderer);
 void* incr_renderer_surface(incr_renderer* renderer, int which);      /* device pointer of a frame surface (INCR_SURFACE_*) */
 

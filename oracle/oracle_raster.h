@@ -53,6 +53,13 @@ static inline float len3(const float p[4]) { return sqrtf((p[0] * p[0] + p[1] * 
 static inline Mat4 mesh_local_to_world(const Scene& s, int mesh) {           // mul(meshTransform, sceneRotation)
     return mat_mul(to_mat4(s.d.mesh_transforms[mesh]), to_mat4(s.d.root_transform));
 }
+// rows [y0, y1) a pass touches (incr_view_constants::scissor_y0/y1: sort-first multi-GPU row bands; 0,0 = whole frame)
+static inline void scissor_rows(const incr_view_constants& v, uint32_t* y0, uint32_t* y1) {
+    const bool whole = v.scissor_y0 == 0 && v.scissor_y1 == 0;
+    *y0 = whole ? 0u : std::min(v.scissor_y0, v.res_y);
+    *y1 = whole ? v.res_y : std::min(v.scissor_y1, v.res_y);
+    if (*y1 < *y0) *y1 = *y0;
+}
 // D3D ftou: NaN -> 0, negative -> 0, saturating
 static inline uint32_t ftou(float f) { if (!(f > 0.f)) return 0u; if (f >= 4294967296.f) return 0xffffffffu; return (uint32_t)f; }
 
@@ -189,7 +196,7 @@ static inline void meshlet_tri_verts(const Scene& s, const incr_gpu_meshlet& m, 
     for (uint32_t k = 0; k < 3; ++k) out[k] = s.d.meshlet_vertex_indices[m.vertexBegin + (0xffu & (packed >> ((2u - k) * 10u)))];
 }
 
-struct RasterTarget { uint32_t W, H; std::vector<uint64_t> packed; };
+struct RasterTarget { uint32_t W, H, y0, y1; std::vector<uint64_t> packed; };
 
 static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t key,
                           const incr_material& mat, const float4 p[3], const float2 uv[3]) {
@@ -200,7 +207,7 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
     const int32_t minX = std::min(v0.X, std::min(v1.X, v2.X)), maxX = std::max(v0.X, std::max(v1.X, v2.X));
     const int32_t minY = std::min(v0.Y, std::min(v1.Y, v2.Y)), maxY = std::max(v0.Y, std::max(v1.Y, v2.Y));
     const int32_t px0 = std::max(0, (minX + 127) >> 8), px1 = std::min((int32_t)rt.W - 1, (maxX - 128) >> 8);
-    const int32_t py0 = std::max(0, (minY + 127) >> 8), py1 = std::min((int32_t)rt.H - 1, (maxY - 128) >> 8);
+    const int32_t py0 = std::max((int32_t)rt.y0, (minY + 127) >> 8), py1 = std::min((int32_t)rt.y1 - 1, (maxY - 128) >> 8);
     auto topLeft = [](int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; };
     const int64_t b01 = topLeft(v1.X - v0.X, v1.Y - v0.Y) ? 0 : -1, b12 = topLeft(v2.X - v1.X, v2.Y - v1.Y) ? 0 : -1, b20 = topLeft(v0.X - v2.X, v0.Y - v2.Y) ? 0 : -1;
     const float W = (float)rt.W, H = (float)rt.H;
@@ -230,6 +237,7 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
 static void visibility_pass(const Scene& s, const incr_view_constants& vc, const incr_draw_cmd* defList, const incr_draw_cmd* dsList,
                             const uint32_t counts[2], uint32_t* vis, float* depthOut) {
     RasterTarget rt; rt.W = vc.res_x; rt.H = vc.res_y; rt.packed.assign((size_t)rt.W * rt.H, 0);
+    scissor_rows(vc, &rt.y0, &rt.y1);
     const Mat4 viewProj = to_mat4(vc.view_proj_transform);
     const float W = (float)rt.W, H = (float)rt.H;
     for (int list = 0; list < 2; ++list) {
@@ -269,7 +277,7 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
             }
         }
     }
-    for (size_t i = 0; i < rt.packed.size(); ++i) {
+    for (size_t i = (size_t)rt.y0 * rt.W; i < (size_t)rt.y1 * rt.W; ++i) {       // only the scissor rows are cleared and written
         const uint64_t v = rt.packed[i];
         if (v == 0) { vis[i] = 0xFFFFF000u; depthOut[i] = 0.f; }
         else { vis[i] = ((uint32_t)v - 1u) & 0x7fffffffu; depthOut[i] = u2f((uint32_t)(v >> 32)); }
@@ -302,7 +310,8 @@ static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const ui
                          uint32_t* color, int rounding) {
     const uint32_t W = vc.res_x, H = vc.res_y;
     const Mat4 viewProj = to_mat4(vc.view_proj_transform);
-    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
         const size_t i = (size_t)y * W + x;
         color[i] = 0;                                              // gbuffer-compute-pass.inl:94-100 clear
         const uint32_t v = vis[i];
@@ -381,7 +390,8 @@ static void direct_lighting(const Scene& s, const incr_lighting_inputs& in, int 
     incr_light light; Mat4 lightTransform;
     load_global_light(s, (uint32_t)sunIndex, &light, &lightTransform);
     RayStats rs;
-    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
         const size_t i = (size_t)y * W + x;
         const GBufferPixel g = read_gbuffer(in, i);
         const float3 worldPos = unproject(screen_pos(x, y, W, H), in.depth_buffer[i], ivp);
@@ -403,7 +413,8 @@ static void clustered_lighting(const Scene& s, const incr_lighting_inputs& in, c
     const float bias = -scale * logf(vc.near_plane);
     const float gridResX = (float)W / (float)grid[0], gridResY = (float)H / (float)grid[1];
     const uint32_t numClusters = grid[0] * grid[1] * grid[2];
-    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
         const size_t i = (size_t)y * W + x;
         if (requiresClear) in.color_target[i] = 0;                                    // clustered-lighting.inl:108-117
         const GBufferPixel g = read_gbuffer(in, i);
@@ -450,10 +461,11 @@ static float3 ShIrradiance(float3 n, const float3 sh[9]) {
 static void sky_lighting(const Scene& s, const incr_lighting_inputs& in, const float* sh9rgba, const uint8_t* aoTex, float skyBrightness, int diffuseIbl) {
     (void)s;
     const incr_view_constants& vc = *in.view;
-    const uint32_t W = vc.res_x, H = vc.res_y;
+    const uint32_t W = vc.res_x;
     float3 sh[9];
     if (sh9rgba) for (int k = 0; k < 9; ++k) sh[k] = {sh9rgba[k * 4], sh9rgba[k * 4 + 1], sh9rgba[k * 4 + 2]};
-    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
         const size_t i = (size_t)y * W + x;
         const GBufferPixel g = read_gbuffer(in, i);
         float3 radiance = {0, 0, 0};
@@ -493,7 +505,8 @@ static void taa_resolve(const incr_view_constants& vc, const uint32_t* hdr, cons
                         uint32_t historyIndex, int rounding) {
     const uint32_t W = vc.res_x, H = vc.res_y;
     const Mat4 inv = to_mat4(vc.taa_inv_view_proj), prev = to_mat4(vc.prev_view_proj_transform);
-    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
         const size_t i = (size_t)y * W + x;
         const float3 cur = unpack_r11g11b10(hdr[i]);
         if (historyIndex == 0) { histOut[i] = pack_r11g11b10(cur, rounding); continue; }

@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:        # torch bundles its own HIP runtime: it has to be the first one loaded in a process that also loads libincr_hip.so
+    import torch  # noqa: F401  (bench.py imports in the same order)
+except Exception:   # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -183,6 +183,72 @@ def test_cpp_host_renderer_matches_pass_by_pass(rt, R, A, sio, gpu_ctx, sponza_s
         gscene.close()
 
 
+def test_row_band_renderers_equal_full_frame(rt, R, A, sio, gpu_ctx, sponza_small):
+    """Sort-first multi-GPU raster on one device: three C++ renderers stand for three ranks (ragged last band), each
+    renders its row band; copying the TAA bands between them plays the RCCL all_gather.  Every band must be bit-identical
+    to the same rows of the single-GPU frame, over three frames of TAA history."""
+    W, H, N = 200, 113, 3
+    rows = (H + N - 1) // N
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    try:
+        full = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9)
+        ranks = [R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9) for _ in range(N)]
+        for r, hr in enumerate(ranks):
+            hr.set_band(r * rows, min((r + 1) * rows, H))
+        for frame in range(3):
+            full.render(view)
+            for hr in ranks:
+                hr.render(view)
+            gpu_ctx.synchronize()
+            # "all_gather": every rank receives every other rank's band of the accumulation surface it just wrote
+            bands = [hr.download(A.SURFACE_TAA_ACCUMULATION)[r * rows:min((r + 1) * rows, H)] for r, hr in enumerate(ranks)]
+            gathered = np.concatenate(bands, axis=0)
+            np.testing.assert_array_equal(gathered, full.download(A.SURFACE_TAA_ACCUMULATION), err_msg="frame %d taa" % frame)
+            for hr in ranks:
+                gpu_ctx.upload(hr.surface_ptr(A.SURFACE_TAA_ACCUMULATION), gathered)
+            for which in (A.SURFACE_VISIBILITY, A.SURFACE_DEPTH, A.SURFACE_GBUFFER_NORMALS, A.SURFACE_HDR_RASTER):
+                ref = full.download(which)
+                for r, hr in enumerate(ranks):
+                    y0, y1 = r * rows, min((r + 1) * rows, H)
+                    np.testing.assert_array_equal(hr.download(which)[y0:y1], ref[y0:y1], err_msg="frame %d surface %d rank %d" % (frame, which, r))
+        ranks[0].tonemap(); gpu_ctx.synchronize()
+        np.testing.assert_array_equal(ranks[0].download(A.SURFACE_BACK_BUFFER), full.download(A.SURFACE_BACK_BUFFER))
+        full.close()
+        for hr in ranks:
+            hr.close()
+    finally:
+        gscene.close()
+
+
+def test_rccl_collective_on_library_surface(rt, R, A, sio, gpu_ctx, helmet):
+    """bench.py gathers the TAA bands with torch.distributed directly on the renderer's surface (CUDA array interface over
+    the raw pointer).  One-rank RCCL group: the aliasing tensor must see the surface and the collective must write it."""
+    import torch
+    import torch.distributed as dist
+    import bench
+    W, H = 64, 48
+    view = sio.FView().reset(helmet, aspect=W / H)
+    gscene = gpu_ctx.create_scene(helmet)
+    hr = R.HostRenderer(gpu_ctx, gscene, W, H)
+    try:
+        hr.render(view); gpu_ctx.synchronize()
+        ptr = hr.surface_ptr(A.SURFACE_TAA_ACCUMULATION)
+        t = torch.as_tensor(bench._DeviceWords(ptr, W * H), device=torch.device("cuda", 0))
+        ref = hr.download(A.SURFACE_TAA_ACCUMULATION)
+        np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32).reshape(H, W), ref)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            band = (t + 1).clone()
+            dist.all_gather_into_tensor(t, band)
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+        np.testing.assert_array_equal(hr.download(A.SURFACE_TAA_ACCUMULATION), (ref.view(np.int32) + 1).view(np.uint32))
+    finally:
+        hr.close(); gscene.close()
+
+
 def test_raster_4k_properties(rt, R, ob, A, sio, gpu_ctx, synth):
     """Full-size frame (BASELINE config 3 shape: Sponza statistics at 3840x2160): size-independent properties."""
     scene = synth.sponza_stat(texture_size=256)

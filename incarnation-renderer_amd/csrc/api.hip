@@ -72,7 +72,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : (kv && !strcmp(kv, "wave")) ? 2 : 0;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
     ctx->profiling = false; ctx->profFrames = 0;
-    ctx->rasterBlock = nullptr; ctx->rasterBytes = 0;
+    ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
     *out_ctx = ctx;
     return INCR_OK;
 }

@@ -36,6 +36,7 @@ struct incr_context {
     // raster path workspace (raster_api.hip): 64-bit depth|id surface of the visibility pass + per-mesh frame constants
     void* rasterBlock;
     uint64_t rasterBytes;
+    uint32_t* rasterCounters;  // queue counters of the last incr_visibility call (inside rasterBlock)
 };
 
 struct incr_scene {

@@ -25,7 +25,10 @@ struct alignas(16) BvhNode8 {
 };
 static_assert(sizeof(BvhNode8) == 80, "node8 must be 5 x 16 bytes");
 
-static constexpr uint32_t kMaxLeafTris = 4;
+#ifndef INCR_MAX_LEAF_TRIS
+#define INCR_MAX_LEAF_TRIS 4
+#endif
+static constexpr uint32_t kMaxLeafTris = INCR_MAX_LEAF_TRIS;
 
 // Intersection record, leaf order, 48 B (3 x dwordx4).  World-space v0 and edges (Moeller-Trumbore).
 struct alignas(16) TriIsect {

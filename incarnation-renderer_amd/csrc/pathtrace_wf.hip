@@ -43,6 +43,7 @@ static constexpr uint32_t kSkySlot = 127;               // bit 127 of the reques
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
 static constexpr uint32_t kChunk = 512;                 // items a wave takes from the device-wide cursor at a time
 static constexpr uint32_t kRefillThreshold = 12;        // refill when at least this many lanes are idle
+static constexpr uint32_t kStartThreshold = 8;          // shadow kernel: lanes between rays start together
 static constexpr uint32_t kMissTri = 0xffffffffu;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow)
 static constexpr int kCursorBase = 16;
@@ -392,7 +393,14 @@ __global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P
         }
         if (__ballot(haveVertex) == 0ull) { if (chunk.exhausted) break; else continue; }
         // ---- next shadow ray for lanes between rays ----
-        if (haveVertex && !tracing) {
+        // Starting a ray costs ~200 VALU instructions (light set-up with its divisions, ray set-up); run alone it would
+        // execute for one or two lanes on nearly every iteration.  Lanes between rays therefore wait until
+        // kStartThreshold of them are ready (or nothing is being traced) and start together (A/B on MI355X, Sponza-stat
+        // 4K: threshold 1 / 4 / 8 / 16 / 32 -> 26.7 / 25.7 / 24.6 / 24.7 / 26.8 ms per frame in this kernel).
+        const bool between = haveVertex && !tracing;
+        const unsigned long long bmask = __ballot(between);
+        const bool startNow = bmask != 0ull && ((uint32_t)__popcll(bmask) >= kStartThreshold || __ballot(tracing) == 0ull);
+        if (between && startNow) {
             const int w = rem0 ? 0 : rem1 ? 1 : rem2 ? 2 : rem3 ? 3 : -1;
             if (w < 0) {      // vertex finished: write back the surviving requests
                 if (occ0 | occ1 | occ2 | occ3) {

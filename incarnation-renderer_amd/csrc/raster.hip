@@ -226,7 +226,7 @@ struct SubTri {
     int32_t px0, px1, py0, py1;
     long long e[3], sx[3], sy[3];        // E01, E12, E20: value at (px0, py0), step per pixel in x and in y
     int32_t bias[3];                     // 0 for top/left edges, -1 otherwise (D3D fill rule)
-    double area;
+    double area;                         // 1 / (twice the signed screen area), in double
     float z0, dz1, dz2;
     uint32_t key;
     int32_t alphaTex;                    // base-colour texture to alpha-test against, -1 = none
@@ -258,20 +258,22 @@ DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVer
     st->sx[0] = -(long long)dy01 * 256; st->sx[1] = -(long long)dy12 * 256; st->sx[2] = -(long long)dy20 * 256;
     st->sy[0] = (long long)dx01 * 256; st->sy[1] = (long long)dx12 * 256; st->sy[2] = (long long)dx20 * 256;
     st->bias[0] = top_left(dx01, dy01) ? 0 : -1; st->bias[1] = top_left(dx12, dy12) ? 0 : -1; st->bias[2] = top_left(dx20, dy20) ? 0 : -1;
-    st->area = (double)area;
+    st->area = 1.0 / (double)area;           // reciprocal once per triangle: the per-fragment weights are products
     st->z0 = v0.z; st->dz1 = v1.z - v0.z; st->dz2 = v2.z - v0.z;
     return true;
 }
 DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, long long E01, long long E12, long long E20) {
     if (E01 + st.bias[0] < 0 || E12 + st.bias[1] < 0 || E20 + st.bias[2] < 0) return;
-    const float l1 = (float)((double)E20 / st.area), l2 = (float)((double)E01 / st.area);
+    const float l1 = (float)((double)E20 * st.area), l2 = (float)((double)E01 * st.area);
     float depth = (st.z0 + l1 * st.dz1) + l2 * st.dz2;
     if (!(depth >= 0.f)) return;
     if (depth > 1.f) depth = 1.f;
     const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(st.key + 1u);
     unsigned long long* dst = P.packed + (size_t)py * P.W + px;
-    if (v <= __atomic_load_n(dst, __ATOMIC_RELAXED)) return;      // values only grow: a fragment that loses now loses for good
     if (st.alphaTex >= 0) {                                        // ps_meshlet_main: clip(opacity - 0.5)
+        // values only grow: a fragment that loses now loses for good -- worth a load before the texture sample.  Opaque
+        // fragments skip the check: the atomic is fire-and-forget, a load would put a memory round trip into every step.
+        if (v <= __atomic_load_n(dst, __ATOMIC_RELAXED)) return;
         const f3 lam = CalcBarycentrics(st.p0, st.p1, st.p2, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
         const float opacity = SampleLevel0(P.S.textures, P.S.srgbLut, st.alphaTex, interp2(st.uv0, st.uv1, st.uv2, lam)).w;
         if (opacity - 0.5f < 0.f) return;

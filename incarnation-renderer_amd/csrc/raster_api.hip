@@ -132,7 +132,7 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     if (recCap > 0xffffffffull || bigCap > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "scene too large for the visibility queues");
     if (ctx->rasterBytes < need || !ctx->rasterBlock) {
         HIP_TRY(hipStreamSynchronize(stream));
-        if (ctx->rasterBlock) { HIP_TRY(hipFree(ctx->rasterBlock)); ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; }
+        if (ctx->rasterBlock) { HIP_TRY(hipFree(ctx->rasterBlock)); ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr; }
         HIP_TRY(hipMalloc(&ctx->rasterBlock, need));
         ctx->rasterBytes = need;
     }
@@ -228,6 +228,16 @@ int incr_light_cull(incr_context* ctx, const incr_light_cull_desc* d, incr_strea
 }
 
 // ---------------------------------------------------------------------------------------------- visibility
+// Introspection (bench / tuning): the queue counters the last incr_visibility call left behind --
+// [0] screen triangles after clip + cull, [1] band items, [2] small triangles, [3] whole-triangle items.
+int incr_visibility_get_stats(incr_context* ctx, uint32_t out_counters[4]) {
+    if (!ctx || !out_counters) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!ctx->rasterBlock || !ctx->rasterCounters) return fail(INCR_ERR_INVALID_ARGUMENT, "incr_visibility has not run yet");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_counters, ctx->rasterCounters, 16, hipMemcpyDeviceToHost));
+    return INCR_OK;
+}
+
 int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_stream stream) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
@@ -245,6 +255,7 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
     if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, sc->host.meshletPackedTriangles.size(), (hipStream_t)stream, &ws))) return rc;
     P.packed = ws.packed; P.recs = ws.recs; P.alphas = ws.alphas; P.bigQueue = ws.bigQueue; P.smallQueue = ws.smallQueue; P.wholeQueue = ws.wholeQueue;
     P.vqCounters = ws.counters; P.recCap = ws.recCap; P.bigCap = ws.bigCap;
+    ctx->rasterCounters = ws.counters;
     HIP_TRY(incr_launch_visibility(&P, P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
     return INCR_OK;
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     # frame level (C++ host mirror of Renderer::Render)
     "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
-    "incr_renderer_set_band", "incr_renderer_tonemap",
+    "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.incr_renderer_surface.restype = vp; L.incr_renderer_surface.argtypes = [vp, C.c_int]
     L.incr_renderer_set_band.restype = C.c_int; L.incr_renderer_set_band.argtypes = [vp, u32, u32]
     L.incr_renderer_tonemap.restype = C.c_int; L.incr_renderer_tonemap.argtypes = [vp]
+    L.incr_visibility_get_stats.restype = C.c_int; L.incr_visibility_get_stats.argtypes = [vp, C.POINTER(u32)]
     _lib = L
     return L
 

@@ -266,6 +266,9 @@ typedef struct incr_visibility_desc {
     float*    depth_buffer;            /* device, res_x*res_y D32_FLOAT */
 } incr_visibility_desc;
 int incr_visibility(incr_context* ctx, const incr_visibility_desc* desc, incr_stream stream);
+/* Introspection for the bench: work-queue counters of the last incr_visibility call (synchronises the device):
+ * [0] screen triangles after clip + cull, [1] band items of large triangles, [2] small triangles, [3] whole-triangle items. */
+int incr_visibility_get_stats(incr_context* ctx, uint32_t out_counters[4]);
 
 /*
  * RenderJob::GBufferComputePass::Execute (render-jobs/gbuffer-compute-pass.inl; shaders/geo-raster/gbuffer-compute.hlsl):

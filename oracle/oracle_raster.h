@@ -9,7 +9,7 @@
 //   * viewport: sx = (x/w * 0.5 + 0.5) * W, sy = (0.5 - y/w * 0.5) * H, snapped to 24.8 fixed point (round half up),
 //     clamped to +-2^20 pixels; sample point = pixel centre; D3D top-left fill rule on exact integer edge functions;
 //   * front face = counter-clockwise on screen (visibility-pass.inl FrontCounterClockwise = TRUE);
-//   * depth = z0 + l1 (z1 - z0) + l2 (z2 - z0) with l = (float)((double)E / (double)area), clamped to <= 1;
+//   * depth = z0 + l1 (z1 - z0) + l2 (z2 - z0) with l = (float)((double)E * (1.0 / (double)area)), clamped to <= 1;
 //   * depth test GREATER_EQUAL in draw order: default list, then double-sided list, each in ascending meshlet id,
 //     triangles in ascending index -> among equal depths the LAST drawn fragment wins;
 //   * pixel-shader interpolants (uv) use the same screen-space barycentric formula as the G-buffer pass;
@@ -209,6 +209,7 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
     const int32_t px0 = std::max(0, (minX + 127) >> 8), px1 = std::min((int32_t)rt.W - 1, (maxX - 128) >> 8);
     const int32_t py0 = std::max((int32_t)rt.y0, (minY + 127) >> 8), py1 = std::min((int32_t)rt.y1 - 1, (maxY - 128) >> 8);
     auto topLeft = [](int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; };
+    const double invArea = 1.0 / (double)area;
     const int64_t b01 = topLeft(v1.X - v0.X, v1.Y - v0.Y) ? 0 : -1, b12 = topLeft(v2.X - v1.X, v2.Y - v1.Y) ? 0 : -1, b20 = topLeft(v0.X - v2.X, v0.Y - v2.Y) ? 0 : -1;
     const float W = (float)rt.W, H = (float)rt.H;
     for (int32_t py = py0; py <= py1; ++py)
@@ -218,7 +219,7 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
             const int64_t E12 = (int64_t)(v2.X - v1.X) * (Sy - v1.Y) - (int64_t)(v2.Y - v1.Y) * (Sx - v1.X);
             const int64_t E20 = (int64_t)(v0.X - v2.X) * (Sy - v2.Y) - (int64_t)(v0.Y - v2.Y) * (Sx - v2.X);
             if (E01 + b01 < 0 || E12 + b12 < 0 || E20 + b20 < 0) continue;
-            const float l1 = (float)((double)E20 / (double)area), l2 = (float)((double)E01 / (double)area);
+            const float l1 = (float)((double)E20 * invArea), l2 = (float)((double)E01 * invArea);
             float depth = (v0.z + l1 * (v1.z - v0.z)) + l2 * (v2.z - v0.z);
             if (!(depth >= 0.f)) continue;
             if (depth > 1.f) depth = 1.f;

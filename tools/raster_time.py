@@ -29,3 +29,7 @@ ctx.synchronize()
 dt = (time.time() - t) / a.frames
 print("raster frame %.3f ms (%dx%d, %d meshlets)" % (dt * 1e3, W, H, scene.num_meshlets))
 print("counts", rr.surf.download("counts"), "stats", rr.surf.download("render_stats"), "shadow rays", rr.surf.download("ray_stats").light_shadow_rays)
+import ctypes as C
+st = (C.c_uint32 * 4)()
+rt.check(ctx.lib.incr_visibility_get_stats(ctx.handle, st))
+print("visibility queues: screen triangles %d, band items %d, small %d, whole %d" % tuple(st))

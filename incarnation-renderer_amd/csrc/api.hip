@@ -283,7 +283,12 @@ uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* sh) {
 // ---------------------------------------------------------------------------------------------- passes
 // Per-frame Preetham sun terms (preetham.hlsli:53-89): depend only on the sun direction and turbidity.
 static float saturate_h(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
-static void perez_from_turbidity(float t, incr_perez_distribution* p) {
+} // extern "C"
+void incr_perez_from_turbidity(float t, incr_perez_distribution* p);
+void incr_sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, incr::SkySun* out);
+static void perez_from_turbidity(float t, incr_perez_distribution* p) { incr_perez_from_turbidity(t, p); }
+static void sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, SkySun* out) { incr_sky_sun_terms(s, t, pc, out); }
+void incr_perez_from_turbidity(float t, incr_perez_distribution* p) {
     // render-jobs/path-tracing.inl:134-140 (double literals * float t, rounded by the Vector4 constructor)
     const double A[3] = {0.1787 * t - 1.4630, -0.0193 * t - 0.2592, -0.0167 * t - 0.2608};
     const double B[3] = {-0.3554 * t + 0.4275, -0.0665 * t + 0.0008, -0.0950 * t + 0.0092};
@@ -293,7 +298,7 @@ static void perez_from_turbidity(float t, incr_perez_distribution* p) {
     for (int i = 0; i < 3; ++i) { p->A[i] = (float)A[i]; p->B[i] = (float)B[i]; p->C[i] = (float)C[i]; p->D[i] = (float)D[i]; p->E[i] = (float)E[i]; }
     p->A[3] = p->B[3] = p->C[3] = p->D[3] = p->E[3] = 0.f;
 }
-static void sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, SkySun* out) {
+void incr_sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, SkySun* out) {
     const float cosS = saturate_h(s[1]);
     const float thetaS = acosf(cosS);
     const float k_Pi = 3.14159265358979323846f;
@@ -315,6 +320,7 @@ static void sky_sun_terms(const float s[3], float t, const incr_perez_distributi
     }
     out->pad[0] = out->pad[1] = out->pad[2] = 0.f;
 }
+extern "C" {
 
 int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream stream) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");

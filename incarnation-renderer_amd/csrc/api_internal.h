@@ -66,6 +66,9 @@ template <class T> static int upload_vec(T** dptr, const T* src, size_t count) {
     return INCR_OK;
 }
 
+// Preetham constants (api.hip): Perez coefficients from turbidity (path-tracing.inl:134-140) and the per-frame sun terms
+void incr_perez_from_turbidity(float t, incr_perez_distribution* p);
+void incr_sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, incr::SkySun* out);
 // scene part of the traversal / shading kernel arguments (api.hip)
 void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, incr::PtParams& P);
 // raster_api.hip: bake + upload the per-meshlet-vertex attribute arrays; free them

@@ -147,6 +147,15 @@ Result ClusteredLightingPass::Execute(Sync* jobSync, const Desc& p, const bool b
     return done(jobSync->Execute(token, [&] { return incr_clustered_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
+Result DynamicSkyPass::Execute(Sync* jobSync, const Desc& p) {            // dynamic-sky.inl:16-170
+    const size_t token = jobSync->GetToken();
+    incr_dynamic_sky_desc d = {};
+    d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
+    d.turbidity = p.renderConfig.Turbidity; d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_dynamic_sky(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
 Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa-resolve.inl:16-118
     const size_t token = jobSync->GetToken();
     incr_view_constants vc = {};
@@ -353,7 +362,15 @@ int Render(State& s, const FRenderState& renderState) {
             }
         }
 
-        // environment map / dynamic sky background, debug viz, highlight (:1929-2001): outside this library
+        if (c.EnvSkyMode == 1) {                                               // :1946-1959 (the HDRI envmap branch :1929-1944 is outside this library)
+            DynamicSkyPass::Desc skyDesc = {};
+            skyDesc.colorTarget = &s.hdrRasterSceneColor; skyDesc.depthStencilTarget = &s.depthBuffer;
+            skyDesc.resX = resX; skyDesc.resY = resX;                          // sic: the reference passes resX twice (:1951-1952); unused by the pass
+            skyDesc.scene = scene; skyDesc.view = &renderState.m_view; skyDesc.jitter = pixelJitter; skyDesc.renderConfig = c;
+            skyDesc.viewConstantBuffer = &cbViewConstants;
+            DynamicSkyPass::Execute(jobSync, skyDesc);
+        }
+        // debug viz, highlight (:1961-2001): outside this library
 
         FShaderSurface* hdrOut = &s.hdrRasterSceneColor;
         if (c.EnableTAA) {                                                     // :2003-2026

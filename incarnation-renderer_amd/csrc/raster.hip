@@ -633,6 +633,23 @@ __global__ __launch_bounds__(256) void clustered_lighting_kernel(const Clustered
     add_color(P.L, i, radiance);
 }
 
+// ---------------------------------------------------------------------------------------------- dynamic sky background
+// dynamic-sky.hlsl: a full-screen triangle at z = 0.0001 under GREATER_EQUAL (dynamic-sky.inl:100-102) overwrites every
+// pixel whose depth is <= 0.0001 with 1000 x Preetham along the direction the SCREEN uv maps to in lat-long
+// parameterisation (the reference shader uses the interpolated uv, not the view ray).
+__global__ __launch_bounds__(256) void dynamic_sky_kernel(const DynamicSkyParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.y1) return;
+    const size_t i = (size_t)y * P.W + x;
+    if (!(0.0001f >= P.depth[i])) return;
+    const f2 uv = {((float)x + 0.5f) / (float)P.W, ((float)y + 0.5f) / (float)P.H};
+    const float theta = K_PI * uv.y, phi = K_PI * (uv.x * 2.f - 1.f);                 // LatlongUV2Polar (common/math.hlsli:46-52)
+    const float sint = sinf(theta), cost = cosf(theta), sinp = sinf(phi), cosp = cosf(phi);
+    const f3 dir = {sint * sinp, cost, sint * cosp};                                  // Polar2Cartesian(..., World) = p.xzy
+    const f3 radiance = 1000.f * CalculateSkyRadianceRGB(P.sun, normalize(dir), P.perez);
+    P.color[i] = pack_r11g11b10(radiance, P.rounding);
+}
+
 // ---------------------------------------------------------------------------------------------- TAA resolve
 DI f3 load_hdr(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {
     if (x >= W || y >= H) return {0.f, 0.f, 0.f};
@@ -738,6 +755,11 @@ extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStre
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
     hipLaunchKernelGGL(clustered_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(dynamic_sky_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -20,6 +21,7 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------- scene data
 namespace {
@@ -124,7 +126,9 @@ struct RasterWorkspace {
 };
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws) {
-    const size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
+    size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
+    // test hook: a tiny band queue forces the overflow path (large triangles scanned whole by one wave)
+    if (const char* cap = pixels ? getenv("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
     const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
@@ -325,6 +329,25 @@ int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_des
     P.bias = -P.scale * logf(nearPlane);                                                      // :102
     P.requiresClear = d->requires_clear;
     HIP_TRY(incr_launch_clustered_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- dynamic sky background
+int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->color_target || !d->depth_buffer) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    DynamicSkyParams P; memset(&P, 0, sizeof P);
+    P.W = d->view->res_x; P.H = d->view->res_y; scissor_rows(*d->view, &P.y0, &P.y1);
+    P.rounding = d->storage_rounding; P.color = d->color_target; P.depth = d->depth_buffer;
+    incr_perez_from_turbidity(d->turbidity, &P.perez);                   // dynamic-sky.inl:119-126
+    const float* s = d->scene->host.sunDir;                              // Vector3 L = scene->m_sunDir; L.Normalize() (:146-147)
+    const V3 L = normalize3(v3(s[0], s[1], s[2]));
+    const float Ln[3] = {L.x, L.y, L.z};
+    incr_sky_sun_terms(Ln, d->turbidity, P.perez, &P.sun);
+    HIP_TRY(incr_launch_dynamic_sky(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 

@@ -112,6 +112,12 @@ struct ClusteredParams {
     int32_t requiresClear;
 };
 
+struct DynamicSkyParams {
+    uint32_t W, H, y0, y1; int32_t rounding;
+    uint32_t* __restrict__ color; const float* __restrict__ depth;
+    incr_perez_distribution perez; SkySun sun;
+};
+
 struct TaaParams {
     uint32_t W, H, historyIndex; int32_t rounding;
     const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;

@@ -209,6 +209,11 @@ class ClusteredLightingDesc(C.Structure):
                 ("cluster_dim", C.c_uint32 * 3), ("cluster_depth_extent", C.c_float), ("requires_clear", C.c_int32)]
 
 
+class DynamicSkyDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("color_target", C.c_void_p), ("depth_buffer", C.c_void_p),
+                ("turbidity", C.c_float), ("storage_rounding", C.c_int32)]
+
+
 class TaaResolveDesc(C.Structure):
     _fields_ = [("view", _VC), ("hdr_scene_color", C.c_void_p), ("history_in", C.c_void_p), ("history_out", C.c_void_p),
                 ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32)]

@@ -223,6 +223,11 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
         d.cluster_dim[:] = dims
         d.cluster_depth_extent, d.requires_clear = cfg.ClusterDepthExtent, 1 if sun == -1 else 0
         out.append(("clustered_lighting", d))
+    if cfg.EnvSkyMode == 1:         # renderer.cpp:1929-1959: dynamic sky fills the background (the HDRI envmap pass is not in this library)
+        d = A.DynamicSkyDesc(); d.scene, d.view = scene_handle, vcp
+        d.color_target, d.depth_buffer = surf["color"], surf["depth"]
+        d.turbidity, d.storage_rounding = cfg.Turbidity, storage_rounding
+        out.append(("dynamic_sky", d))
     if cfg.EnableTAA:
         d = A.TaaResolveDesc(); d.view = C.pointer(vc_taa)
         d.hdr_scene_color, d.depth_buffer = surf["color"], surf["depth"]
@@ -301,7 +306,7 @@ class RasterRenderer:
 
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
-                   taa_resolve="incr_taa_resolve")
+                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg

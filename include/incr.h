@@ -332,6 +332,19 @@ typedef struct incr_clustered_lighting_desc {
 } incr_clustered_lighting_desc;
 int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* desc, incr_stream stream);
 
+/* RenderJob::DynamicSkyPass::Execute (render-jobs/dynamic-sky.inl; shaders/environment-sky/dynamic-sky.hlsl): fills every
+ * pixel at the far plane (depth <= 0.0001) with 1000 * Preetham sky radiance.  The reference shader looks the sky up along
+ * the lat-long direction of the pixel's SCREEN uv (not the view ray); that is what this pass does too. */
+typedef struct incr_dynamic_sky_desc {
+    const incr_scene* scene;           /* m_sunDir */
+    const incr_view_constants* view;   /* resolution + scissor rows */
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT */
+    const float* depth_buffer;
+    float    turbidity;                /* FConfig::Turbidity */
+    int32_t  storage_rounding;
+} incr_dynamic_sky_desc;
+int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* desc, incr_stream stream);
+
 /* RenderJob::TAAResolvePass::Execute (render-jobs/taa-resolve.inl; shaders/postprocess/taa-resolve.hlsl).  The reference
  * reads and writes ONE accumulation surface in place (a data race across pixels); here history is read from
  * `history_in` and the result written to `history_out` (they may not alias): the race-free reading of the shader. */

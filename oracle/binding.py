@@ -68,6 +68,7 @@ def lib():
         L.orc_direct_lighting.argtypes = [vp, C.POINTER(A.DirectLightingDesc), C.POINTER(C.c_uint64)]
         L.orc_clustered_lighting.argtypes = [vp, C.POINTER(A.ClusteredLightingDesc)]
         L.orc_taa_resolve.argtypes = [C.POINTER(A.TaaResolveDesc)]
+        L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
         L.orc_oct_roundtrip.argtypes = [fp, fp, fp]
         _lib = L
     return _lib
@@ -200,6 +201,8 @@ def run_pass(scene, name, desc):
             C.cast(desc.ray_stats, C.POINTER(C.c_uint64))[3] += rays.value      # incr_ray_stats::light_shadow_rays
     elif name == "clustered_lighting":
         L.orc_clustered_lighting(h, C.byref(desc))
+    elif name == "dynamic_sky":
+        L.orc_dynamic_sky(h, C.byref(desc))
     elif name == "taa_resolve":
         L.orc_taa_resolve(C.byref(desc))
     else:

@@ -481,6 +481,27 @@ static void sky_lighting(const Scene& s, const incr_lighting_inputs& in, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dynamic sky background
+// shaders/environment-sky/dynamic-sky.hlsl:21-49 + render-jobs/dynamic-sky.inl:100-102,119-153: full-screen triangle at
+// z = 0.0001, depth GREATER_EQUAL, blend off; the sky direction comes from the SCREEN uv in lat-long parameterisation
+// (common/math.hlsli:46-79), not from the view ray.
+static void dynamic_sky(const Scene& s, const incr_view_constants& vc, uint32_t* color, const float* depth, float turbidity, int rounding) {
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    incr_perez_distribution pc; perez_from_turbidity(turbidity, &pc);
+    const float3 L = normalize(f3(s.d.sun_dir[0], s.d.sun_dir[1], s.d.sun_dir[2]));
+    const SkySunTerms sun = sky_sun_terms(L, turbidity, pc);
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        if (!(0.0001f >= depth[i])) continue;
+        const float2 uv = {((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
+        const float theta = k_Pi * uv.y, phi = k_Pi * (uv.x * 2.f - 1.f);
+        const float sint = sinf(theta), cost = cosf(theta), sinp = sinf(phi), cosp = cosf(phi);
+        const float3 dir = {sint * sinp, cost, sint * cosp};
+        color[i] = pack_r11g11b10(1000.f * CalculateSkyRadianceRGB(sun, normalize(dir), pc), rounding);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TAA resolve
 static inline float3 load_hdr(const uint32_t* img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {       // Texture2D.Load: out of bounds -> 0
     if (x >= W || y >= H) return {0, 0, 0};
@@ -562,6 +583,9 @@ void orc_direct_lighting(void* scene, const incr_direct_lighting_desc* d, uint64
 }
 void orc_clustered_lighting(void* scene, const incr_clustered_lighting_desc* d) {
     clustered_lighting(*(Scene*)scene, d->in, d->culled_light_lists, d->light_grid, d->cluster_dim, d->cluster_depth_extent, d->requires_clear);
+}
+void orc_dynamic_sky(void* scene, const incr_dynamic_sky_desc* d) {
+    dynamic_sky(*(Scene*)scene, *d->view, d->color_target, d->depth_buffer, d->turbidity, d->storage_rounding);
 }
 void orc_taa_resolve(const incr_taa_resolve_desc* d) {
     taa_resolve(*d->view, d->hdr_scene_color, d->history_in, d->history_out, d->depth_buffer, d->history_index, d->storage_rounding);

@@ -221,6 +221,34 @@ def test_row_band_renderers_equal_full_frame(rt, R, A, sio, gpu_ctx, sponza_smal
         gscene.close()
 
 
+def test_visibility_band_queue_overflow_path(rt, R, A, sio, gpu_ctx, sponza_small, monkeypatch):
+    """Large triangles are cut into band items; when the band queue is full they are scanned whole by one wave instead.
+    Forcing a tiny queue must not change a single id or depth bit."""
+    import os
+    W, H = 640, 360
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    try:
+        def frame():
+            hr = R.HostRenderer(gpu_ctx, gscene, W, H)
+            hr.render(view); gpu_ctx.synchronize()
+            st = (C.c_uint32 * 4)()
+            rt.check(gpu_ctx.lib.incr_visibility_get_stats(gpu_ctx.handle, st))
+            out = hr.download(A.SURFACE_VISIBILITY), hr.download(A.SURFACE_DEPTH), list(st)
+            hr.close()
+            return out
+        vis0, depth0, st0 = frame()
+        assert st0[0] > 0 and st0[1] > 0 and st0[2] > 0 and st0[3] == 0        # triangles, band items, small items, no overflow
+        monkeypatch.setenv("INCR_VIS_BAND_QUEUE_CAP", "16")
+        vis1, depth1, st1 = frame()
+        monkeypatch.delenv("INCR_VIS_BAND_QUEUE_CAP")
+        assert st1[0] == st0[0] and st1[2] == st0[2] and st1[3] > 0            # same triangles, most large ones took the overflow path
+        np.testing.assert_array_equal(vis1, vis0)
+        np.testing.assert_array_equal(depth1, depth0)
+    finally:
+        gscene.close()
+
+
 def test_rccl_collective_on_library_surface(rt, R, A, sio, gpu_ctx, helmet):
     """bench.py gathers the TAA bands with torch.distributed directly on the renderer's surface (CUDA array interface over
     the raw pointer).  One-rank RCCL group: the aliasing tensor must see the surface and the collective must write it."""

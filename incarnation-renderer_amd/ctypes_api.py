@@ -219,6 +219,12 @@ class TaaResolveDesc(C.Structure):
                 ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32)]
 
 
+class SkyIblInfo(C.Structure):
+    _fields_ = [("cubemap_res", C.c_uint32), ("num_mips", C.c_uint32), ("latlong_r11g11b10", C.c_void_p),
+                ("source_cube_r11g11b10", C.c_void_p), ("envmap_r11g11b10", C.c_void_p), ("sh9_rgba", C.c_void_p),
+                ("latlong_texels", C.c_uint64), ("cube_texels", C.c_uint64)]
+
+
 class RendererScene(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("directional_light_index", C.c_int32), ("punctual_light_count", C.c_uint32),
                 ("meshlet_count", C.c_uint32), ("skylight_sh9_rgba", C.c_void_p)]

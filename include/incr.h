@@ -360,6 +360,30 @@ typedef struct incr_taa_resolve_desc {
 int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* desc, incr_stream stream);
 
 /* =====================================================================================================
+ * Sky and IBL precompute: the producers of the envmap / skylight-probe / env-BRDF inputs.
+ * ===================================================================================================== */
+/* FScene::UpdateDynamicSky (src/scene.cpp:1657-1790): Preetham lat-long texture (x 0.04) -> 2x2 box mip chain ->
+ * cube map per level -> GGX prefilter (1024 Hammersley samples, roughness = level / levels) -> SH9 projection + reduction.
+ * The object owns the products (R11G11B10_FLOAT mip chains packed level after level; cubes as [level][face][y][x]);
+ * pass *inout_ibl == NULL to create it, the same object again to refresh it after the sun moved. */
+typedef struct incr_sky_ibl incr_sky_ibl;
+typedef struct incr_sky_ibl_info {
+    uint32_t cubemap_res, num_mips;             /* FConfig::EnvmapResolution (256), CalcMipCount(res, res) */
+    const uint32_t* latlong_r11g11b10;          /* device: 2*res x res lat-long sky, all levels */
+    const uint32_t* source_cube_r11g11b10;      /* device: unfiltered cube, all levels */
+    const uint32_t* envmap_r11g11b10;           /* device: prefiltered cube = FScene::m_dynamicSkyEnvmap, all levels */
+    const float*    sh9_rgba;                   /* device: 9 x float4 = FScene::m_dynamicSkySH */
+    uint64_t latlong_texels, cube_texels;       /* texels over all levels */
+} incr_sky_ibl_info;
+int incr_update_dynamic_sky(incr_context* ctx, const incr_scene* scene, uint32_t envmap_resolution, float turbidity, int32_t storage_rounding,
+                            incr_stream stream, incr_sky_ibl** inout_ibl);
+int incr_sky_ibl_get_info(const incr_sky_ibl* ibl, incr_sky_ibl_info* out_info);
+int incr_sky_ibl_destroy(incr_context* ctx, incr_sky_ibl* ibl);
+/* Renderer::GenerateEnvBrdfTexture (src/renderer.cpp:169-245; split-sum-approx/brdf-integration.hlsl): R16G16_FLOAT LUT,
+ * x = NoV, y = 1 - roughness, 1024 samples per texel.  out_rg16f: device, width*height u32. */
+int incr_generate_env_brdf(incr_context* ctx, uint32_t width, uint32_t height, int32_t storage_rounding, void* out_rg16f, incr_stream stream);
+
+/* =====================================================================================================
  * Frame level: the DLL exports Initialize / Render / Teardown (inc/demo-interface.h:10-16) over the C++ host mirror
  * of Renderer::Render (csrc/host/renderer.cpp: RenderJob::<Pass>::Execute + the path-trace and raster branches of
  * src/renderer.cpp:1676-2036).  One incr_renderer owns the frame's surfaces and the state Renderer keeps in statics

@@ -70,6 +70,11 @@ def lib():
         L.orc_taa_resolve.argtypes = [C.POINTER(A.TaaResolveDesc)]
         L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
         L.orc_oct_roundtrip.argtypes = [fp, fp, fp]
+        # sky / IBL precompute (oracle_ibl.h)
+        L.orc_ibl_sizes.restype = C.c_uint64; L.orc_ibl_sizes.argtypes = [u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_update_dynamic_sky.argtypes = [fp, C.c_float, u32, u32, C.c_int, vp, vp, vp, vp]
+        L.orc_env_brdf.argtypes = [u32, u32, u32, vp, C.c_int]
+        L.orc_cube_sample.argtypes = [vp, u32, u32, fp, C.c_float, fp]
         _lib = L
     return _lib
 
@@ -207,6 +212,24 @@ def run_pass(scene, name, desc):
         L.orc_taa_resolve(C.byref(desc))
     else:
         raise KeyError(name)
+
+
+# ---- sky / IBL precompute ----------------------------------------------------------------------------------
+def update_dynamic_sky(sun_dir, turbidity=2.0, resolution=256, sample_count=1024, rounding=0):
+    """FScene::UpdateDynamicSky on the CPU: dict(latlong, source_cube, envmap: packed u32 level chains; sh9: 9x4 f32)."""
+    ll, cu = C.c_uint64(), C.c_uint64()
+    mips = lib().orc_ibl_sizes(resolution, C.byref(ll), C.byref(cu))
+    out = dict(latlong=np.zeros(ll.value, np.uint32), source_cube=np.zeros(cu.value, np.uint32), envmap=np.zeros(cu.value, np.uint32),
+               sh9=np.zeros((9, 4), np.float32), mips=int(mips))
+    lib().orc_update_dynamic_sky(_fa(sun_dir), turbidity, resolution, sample_count, rounding, out["latlong"].ctypes.data, out["source_cube"].ctypes.data,
+                                 out["envmap"].ctypes.data, out["sh9"].ctypes.data)
+    return out
+
+
+def env_brdf(width, height, num_samples=1024, rounding=0):
+    out = np.zeros((height, width), np.uint32)
+    lib().orc_env_brdf(width, height, num_samples, out.ctypes.data, rounding)
+    return out
 
 
 def tonemap(history_u32, exposure=13.0, viewmode=0):

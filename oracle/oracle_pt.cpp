@@ -1021,3 +1021,6 @@ void orc_tonemap(const uint32_t* hdr_r11g11b10, uint8_t* ldr_rgba8, uint32_t res
 
 // raster half of the hot path: shares the scene access, texture unit and BRDF code above
 #include "oracle_raster.h"
+
+// sky / IBL precompute feeding the hot path
+#include "oracle_ibl.h"

@@ -1,0 +1,208 @@
+"""Sky / IBL precompute: oracle properties on the CPU, HIP-vs-oracle parity on the GPU.
+The chain goes through sinf/cosf/expf/tanf/acosf/atan2f/log2f, which differ in the last bit between glibc and the device
+math library, so radiance surfaces are compared within one R11G11B10 storage step (2^-5 relative on blue, 2^-6 on red /
+green) instead of bit for bit; everything that is pure arithmetic on given inputs is compared exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def levels_2d(flat, res):
+    out, off = [], 0
+    w, h = 2 * res, res
+    while h >= 1:
+        out.append(flat[off:off + w * h].reshape(h, w)); off += w * h
+        w, h = max(w >> 1, 1), h >> 1
+    return out
+
+
+def levels_cube(flat, res):
+    out, off, n = [], 0, res
+    while n >= 1:
+        out.append(flat[off:off + 6 * n * n].reshape(6, n, n)); off += 6 * n * n
+        n >>= 1
+    return out
+
+
+def env_dir(face, u, v):
+    """split-sum-approx/prefilter.hlsl GetEnvDir."""
+    vx, vy = 2 * u - 1, -2 * v + 1
+    d = [(1, vy, -vx), (-1, vy, vx), (vx, 1, -vy), (vx, -1, vy), (vx, vy, 1), (-vx, vy, -1)][face]
+    d = np.array(d, dtype=np.float64)
+    return d / np.linalg.norm(d)
+
+
+SUN = (0.35, 0.8, 0.48)
+
+
+@pytest.fixture(scope="module")
+def sky16(ob):
+    return ob.update_dynamic_sky(SUN, 2.0, resolution=16)
+
+
+def test_oracle_latlong_and_mips(ob, sky16):
+    res = 16
+    lv = levels_2d(sky16["latlong"], res)
+    assert [l.shape for l in lv] == [(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)] and sky16["mips"] == 5
+    # level 0 = 0.04 * Preetham along the lat-long direction of the texel centre
+    rad = ob.unpack_r11g11b10(lv[0])
+    sun = np.array(SUN) / np.linalg.norm(SUN)
+    for (y, x) in ((2, 3), (5, 17), (7, 30)):
+        theta, phi = np.pi * (y + 0.5) / res, np.pi * ((x + 0.5) / (2 * res) * 2 - 1)
+        d = np.array([np.sin(theta) * np.sin(phi), np.cos(theta), np.sin(theta) * np.cos(phi)])
+        out = (C.c_float * 3)()
+        ob.lib().orc_sky_radiance((C.c_float * 3)(*sun), (C.c_float * 3)(*d), 2.0, out)
+        want = 0.04 * np.array(out[:])
+        assert (rad[y, x] <= want * (1 + 1e-5)).all() and (rad[y, x] >= want * (1 - 2.0 ** -5)).all()      # truncating store
+    # every level is the 2x2 box filter of the one above (one storage step of slack)
+    for a, b in zip(lv[:-1], lv[1:]):
+        fa = ob.unpack_r11g11b10(a)
+        box = 0.25 * (fa[0::2, 0::2] + fa[0::2, 1::2] + fa[1::2, 0::2] + fa[1::2, 1::2])
+        fb = ob.unpack_r11g11b10(b)
+        assert (fb <= box * (1 + 1e-5)).all() and (fb >= box * (1 - 2.0 ** -5) - 1e-6).all()
+
+
+def test_oracle_cube_conventions(ob, sky16):
+    """The cube sampler (D3D face table) and GetEnvDir (the writer's face table) agree: sampling along the direction of a
+    texel centre returns that texel."""
+    res = 16
+    cube = levels_cube(sky16["source_cube"], res)
+    flat = np.ascontiguousarray(sky16["source_cube"])
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        face, x, y = int(rng.integers(6)), int(rng.integers(res)), int(rng.integers(res))
+        d = env_dir(face, (x + 0.5) / res, (y + 0.5) / res).astype(np.float32)
+        out = (C.c_float * 3)()
+        ob.lib().orc_cube_sample(flat.ctypes.data, res, 5, (C.c_float * 3)(*d), 0.0, out)
+        want = ob.unpack_r11g11b10(cube[0][face, y, x])
+        np.testing.assert_allclose(np.array(out[:]), want, rtol=2e-5, atol=1e-7)
+    # +Y face looks at the zenith: brighter than the -Y face of a daytime sky
+    up, down = ob.unpack_r11g11b10(cube[0][2]).mean(), ob.unpack_r11g11b10(cube[0][3])
+    assert np.isfinite(up) and up > 0
+
+
+def test_oracle_prefilter_level0_and_sh(ob, sky16):
+    res = 16
+    src, env = levels_cube(sky16["source_cube"], res), levels_cube(sky16["envmap"], res)
+    flat = np.ascontiguousarray(sky16["source_cube"])
+    # roughness 0: all 1024 samples point along R = GetEnvDir(face, x / n, y / n) -> the prefiltered texel is the bilinear
+    # source sample at that (corner) direction
+    for face, x, y in ((0, 3, 4), (2, 8, 8), (5, 15, 1), (3, 0, 9)):
+        d = env_dir(face, x / res, y / res).astype(np.float32)
+        out = (C.c_float * 3)()
+        ob.lib().orc_cube_sample(flat.ctypes.data, res, 5, (C.c_float * 3)(*d), 0.0, out)
+        got = ob.unpack_r11g11b10(env[0][face, y, x])
+        want = np.array(out[:])
+        assert (got <= want * (1 + 1e-4)).all() and (got >= want * (1 - 2.0 ** -5 - 1e-4)).all()
+    # rougher levels are smoother: the spread over a face shrinks
+    spread = [float(np.ptp(ob.unpack_r11g11b10(l[4])[..., 1])) for l in env[:3]]
+    assert spread[2] <= spread[0] + 1e-6
+    # SH9: coefficient i = sum over texels of radiance * basis_i * sin(theta) dTheta dPhi
+    lv0 = ob.unpack_r11g11b10(levels_2d(sky16["latlong"], res)[0]).astype(np.float64)
+    H, W = res, 2 * res
+    ys, xs = np.mgrid[0:H, 0:W]
+    theta, phi = np.pi * (ys + 0.5) / H, np.pi * ((xs + 0.5) / W * 2 - 1)
+    d = np.stack([np.sin(theta) * np.sin(phi), np.cos(theta), np.sin(theta) * np.cos(phi)], -1)
+    K = [0.282095, 0.488603, 0.488603, 0.488603, 1.092548, 1.092548, 0.315392, 1.092548, 0.546274]
+    basis = [K[0] + 0 * theta, K[1] * d[..., 1], K[2] * d[..., 2], K[3] * d[..., 0], K[4] * d[..., 0] * d[..., 1], K[5] * d[..., 1] * d[..., 2],
+             K[6] * (3 * d[..., 2] ** 2 - 1), K[7] * d[..., 0] * d[..., 2], K[8] * (d[..., 0] ** 2 - d[..., 1] ** 2)]
+    w = np.sin(theta) * (np.pi / H) * (2 * np.pi / W)
+    for i in range(9):
+        want = (lv0 * (basis[i] * w)[..., None]).sum(axis=(0, 1))
+        np.testing.assert_allclose(sky16["sh9"][i, :3], want, rtol=2e-4, atol=2e-5)
+
+
+def test_oracle_env_brdf(ob):
+    W = H = 32
+    lut = ob.env_brdf(W, H)
+    a = (lut & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+    b = (lut >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    assert np.isfinite(a).all() and np.isfinite(b).all() and (a >= 0).all() and (b >= 0).all()
+    assert (a[:, 0] == 0).all() and (b[:, 0] == 0).all()                   # NoV = 0 column: no sample passes NoV > 0
+    assert ((a + b)[:, W // 2:] <= 1.02).all()                             # away from grazing angles scale + bias stay below 1
+    # smooth (y = H-1 is roughness 1/H), facing the surface (NoV -> 1): scale ~ 1, bias ~ 0
+    assert a[H - 1, W - 1] > 0.9 and b[H - 1, W - 1] < 0.05
+    # independent float64 evaluation of the same integral for one texel
+    x, y, n = 20, 12, 1024
+    NoV, rough = x / W, 1 - y / H
+    V = np.array([np.sqrt(1 - NoV * NoV), 0, NoV])
+    A = B = 0.0
+    for i in range(n):
+        bits = int("{:032b}".format(i)[::-1], 2)
+        u1, u2 = i / n, bits / 2.0 ** 32
+        al = rough * rough
+        ct = np.sqrt((1 - u2) / (1 + (al * al - 1) * u2)); st = np.sqrt(1 - ct * ct); ph = 2 * np.pi * u1
+        Hh = np.array([st * np.sin(ph), st * np.cos(ph), ct])
+        L = 2 * np.dot(V, Hh) * Hh - V
+        L /= np.linalg.norm(L)
+        NoL, NoH, VoH = min(max(L[2], 0), 1), min(max(Hh[2], 0), 1), min(max(np.dot(V, Hh), 0), 1)
+        if NoL > 0 and NoV > 0:
+            k = 0.5 * al * al
+            G = (NoV / (NoV * (1 - k) + k)) * (NoL / (NoL * (1 - k) + k))
+            gv = G * VoH / (NoH * NoV); fc = (1 - VoH) ** 5
+            A += (1 - fc) * gv; B += fc * gv
+    assert a[y, x] == pytest.approx(A / n, rel=2e-3) and b[y, x] == pytest.approx(B / n, rel=2e-3, abs=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ GPU parity
+def radiance_close(ob, got, want, what, steps=1.0):
+    fa, fb = ob.unpack_r11g11b10(got), ob.unpack_r11g11b10(want)
+    assert (np.isfinite(fa) == np.isfinite(fb)).all(), what
+    fin = np.isfinite(fa) & np.isfinite(fb)
+    tol = np.array([2.0 ** -6, 2.0 ** -6, 2.0 ** -5]) * steps
+    err = np.abs(fa - fb)
+    ref = np.maximum(np.abs(fb), 1e-6)
+    bad = fin & (err > ref * tol + 1e-7)
+    assert not bad.any(), "%s: %d texels outside %.1f storage step(s), worst rel %g" % (what, int(bad.sum()), steps, float((err / ref)[fin].max()))
+    return float((got == want).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_dynamic_sky_chain_matches_oracle(rt, ob, A, gpu_ctx, helmet):
+    ibl_mod = __import__("importlib").import_module("incarnation-renderer_amd.ibl")
+    res = 32
+    gscene = gpu_ctx.create_scene(helmet)
+    try:
+        sky = ibl_mod.SkyIbl(gpu_ctx, gscene, resolution=res, turbidity=2.0)
+        g = sky.download()
+        o = ob.update_dynamic_sky(helmet.sun_dir, 2.0, resolution=res)
+        assert sky.info.num_mips == o["mips"] == 6 and g["latlong"].size == o["latlong"].size and g["envmap"].size == o["envmap"].size
+        same = radiance_close(ob, g["latlong"], o["latlong"], "lat-long sky + mips")
+        assert same > 0.98
+        assert radiance_close(ob, g["source_cube"], o["source_cube"], "source cube") > 0.97
+        # the prefilter sums 1024 samples of already-quantised texels: two storage steps
+        assert radiance_close(ob, g["envmap"], o["envmap"], "prefiltered envmap", steps=2.0) > 0.9
+        np.testing.assert_allclose(g["sh9"][:, :3], o["sh9"][:, :3], rtol=2e-3, atol=2e-4)
+        # refreshing after the sun moved reuses the buffers and changes the result
+        before = g["sh9"].copy()
+        sun = (C.c_float * 3)(0.1, 0.3, -0.9)
+        rt.check(gpu_ctx.lib.incr_scene_set_sun_dir(gpu_ctx.handle, gscene.handle, sun))
+        ptr = sky.info.envmap_r11g11b10
+        sky.update()
+        assert sky.info.envmap_r11g11b10 == ptr and not np.allclose(sky.download()["sh9"], before)
+        o2 = ob.update_dynamic_sky((0.1, 0.3, -0.9), 2.0, resolution=res)
+        np.testing.assert_allclose(sky.download()["sh9"][:, :3], o2["sh9"][:, :3], rtol=2e-3, atol=2e-4)
+        sky.close()
+        # bad arguments
+        h = C.c_void_p()
+        assert gpu_ctx.lib.incr_update_dynamic_sky(gpu_ctx.handle, gscene.handle, 48, 2.0, 0, None, C.byref(h)) == -1
+        assert b"power of two" in gpu_ctx.lib.incr_last_error()
+    finally:
+        gscene.close()
+
+
+@pytest.mark.gpu
+def test_gpu_env_brdf_matches_oracle(rt, ob, gpu_ctx):
+    ibl_mod = __import__("importlib").import_module("incarnation-renderer_amd.ibl")
+    W, H = 64, 48
+    buf = ibl_mod.generate_env_brdf(gpu_ctx, W, H)
+    gpu_ctx.synchronize()
+    g = gpu_ctx.download(buf, (H, W), np.uint32)
+    gpu_ctx.free(buf)
+    o = ob.env_brdf(W, H)
+    for shift in (0, 16):
+        a = ((g >> shift) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+        b = ((o >> shift) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+        np.testing.assert_allclose(a, b, rtol=2.0 ** -9, atol=2.0 ** -14)         # sinf/cosf of the sample azimuth: within two f16 steps
+    assert (g == o).mean() > 0.9

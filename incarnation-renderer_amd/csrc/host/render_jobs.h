@@ -68,6 +68,9 @@ struct FScene {
     size_t m_punctualLightCount = 0;            // GetPunctualLightCount()
     size_t m_meshletCount = 0;
     const float* m_skylightSh9 = nullptr;       // device, 9 x float4 (m_skylight.m_shTextureIndex), may be NULL
+    const uint32_t* m_skylightEnvmap = nullptr; // device, prefiltered cube with all levels (m_skylight.m_envmapTextureIndex), may be NULL
+    uint32_t m_envmapRes = 0, m_envmapMips = 0;
+    FTexture m_envBRDF; uint32_t m_envBrdfWidth = 0, m_envBrdfHeight = 0;     // Renderer::s_envBRDF lives in the renderer there
     int    GetDirectionalLight() const { return m_directionalLightIndex; }
     size_t GetPunctualLightCount() const { return m_punctualLightCount; }
 };

@@ -122,6 +122,10 @@ Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky
     d.sh9_rgba = p.scene->m_skylightSh9;
     d.ambient_occlusion = (p.renderConfig.EnableHBAO && p.ambientOcclusionTex) ? (const uint8_t*)p.ambientOcclusionTex->m_devicePtr : nullptr;
     d.sky_brightness = p.renderConfig.SkyBrightness; d.diffuse_ibl = p.renderConfig.EnableDiffuseIBL ? 1 : 0;
+    d.prefiltered_envmap = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;
+    d.env_brdf = p.envBRDFTex ? (const uint32_t*)p.envBRDFTex->m_devicePtr : nullptr;
+    d.env_brdf_width = p.scene->m_envBrdfWidth; d.env_brdf_height = p.scene->m_envBrdfHeight;
+    d.specular_ibl = p.renderConfig.EnableSpecularIBL ? 1 : 0;
     return done(jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
@@ -333,6 +337,7 @@ int Render(State& s, const FRenderState& renderState) {
             skyLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
             skyLightingDesc.renderConfig = c; skyLightingDesc.scene = scene; skyLightingDesc.view = &renderState.m_view; skyLightingDesc.jitter = pixelJitter;
             skyLightingDesc.resX = resX; skyLightingDesc.resY = resY; skyLightingDesc.viewConstantBuffer = &cbViewConstants;
+            skyLightingDesc.envBRDFTex = scene->m_envBRDF.m_devicePtr ? const_cast<FTexture*>(&scene->m_envBRDF) : nullptr;   // s_envBRDF.get()
             SkyLightingPass::Execute(jobSync, skyLightingDesc);
         }
 
@@ -435,6 +440,9 @@ int incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x, 
     r->scene.m_punctualLightCount = scene->punctual_light_count;
     r->scene.m_meshletCount = scene->meshlet_count;
     r->scene.m_skylightSh9 = scene->skylight_sh9_rgba;
+    r->scene.m_skylightEnvmap = scene->prefiltered_envmap; r->scene.m_envmapRes = scene->envmap_res; r->scene.m_envmapMips = scene->envmap_mips;
+    r->scene.m_envBRDF.m_devicePtr = const_cast<uint32_t*>(scene->env_brdf);
+    r->scene.m_envBrdfWidth = scene->env_brdf_width; r->scene.m_envBrdfHeight = scene->env_brdf_height;
     incr_renderer_set_config(r, config);
     const int rc = Renderer::Initialize(r->state, ctx, stream, res_x, res_y, scene->meshlet_count, r->config);
     if (rc) { Renderer::Teardown(r->state); delete r; return rc; }
@@ -454,6 +462,7 @@ int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
     f.MaxLightsPerCluster = (int)c->max_lights_per_cluster; f.ClusterDepthExtent = c->cluster_depth_extent;
     f.MaxSampleCount = c->max_sample_count; f.Pathtracing_CameraAperture = c->camera_aperture; f.Pathtracing_CameraFocalLength = c->camera_focal_length;
     f.Turbidity = c->turbidity; f.EnvSkyMode = c->env_sky_mode; f.StorageRounding = c->storage_rounding;
+    f.EnableSpecularIBL = c->enable_specular_ibl != 0;
     return INCR_OK;
 }
 

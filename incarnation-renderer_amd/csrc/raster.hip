@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pt_shade.h"
+#include "ibl_device.h"
 #include "raster_params.h"
 
 namespace incr {
@@ -542,6 +543,20 @@ DI f3 ShIrradiance(f3 n, const float4* __restrict__ sh) {                   // s
     for (int i = 0; i < 9; ++i) { const float4 s = sh[i]; irr = irr + mk3(s.x, s.y, s.z) * c[i]; }
     return irr;
 }
+DI f2 sample_rg16f_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, f2 uv) {      // R16G16_FLOAT LUT, CLAMP, level 0
+    float u = uv.x, v = uv.y;
+    if (!(u == u)) u = 0.f;
+    if (!(v == v)) v = 0.f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1)); y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const uint32_t a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1], c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
+    const f2 t00 = {f16_bits_to_f32(a & 0xffffu), f16_bits_to_f32(a >> 16)}, t10 = {f16_bits_to_f32(b & 0xffffu), f16_bits_to_f32(b >> 16)};
+    const f2 t01 = {f16_bits_to_f32(c & 0xffffu), f16_bits_to_f32(c >> 16)}, t11 = {f16_bits_to_f32(d & 0xffffu), f16_bits_to_f32(d >> 16)};
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    return {(t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy, (t00.y * wx0 + t10.y * fx) * wy0 + (t01.y * wx0 + t11.y * fx) * fy};
+}
 __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.L.W || y >= P.L.y1) return;
@@ -553,6 +568,22 @@ __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
         const f3 shDiffuse = ((albedo * K_INV_PI) * ShIrradiance(g.N, P.sh9)) * 5.f;
         const f3 occluded = g.ao * shDiffuse;
         radiance = radiance + P.skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));
+    }
+    if (P.envmap) {                                                              // sky-lighting.hlsl:98-116: split-sum specular IBL
+        f2 sp = screen_pos(x, y, P.L.W, P.L.H); sp.y = -sp.y;
+        const f4 wp = mul_vec4({sp.x, sp.y, P.L.depth[i], 1.f}, P.skyInvViewProj);
+        const f3 worldPos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+        const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
+        const f3 V = normalize(eye - worldPos);
+        const float NoV = hmax(dot(g.N, V), 0.01f);
+        const f3 F0 = g.metallic * g.basecolor + (1.f - g.metallic) * 0.04f;
+        const f3 R = normalize(reflect(-V, g.N));
+        const CubeChain env = {P.envmapRes, P.envmapMips, P.envmap};
+        const f3 prefilteredColor = cube_sample_trilinear(env, R, g.roughness * ((float)P.envmapMips - 1.f));
+        const f2 envBrdf = sample_rg16f_bilinear_clamp(P.envBrdf, P.envBrdfW, P.envBrdfH, {NoV, g.roughness});
+        const f3 specularIBL = prefilteredColor * (F0 * envBrdf.x + envBrdf.y);
+        const f3 occludedSpec = g.ao * specularIBL;
+        radiance = radiance + P.skyBrightness * (specularIBL + g.aoBlend * (occludedSpec - specularIBL));
     }
     const float hbao = P.ao ? (float)P.ao[i] / 255.f : 1.f;
     add_color(P.L, i, hbao * radiance);

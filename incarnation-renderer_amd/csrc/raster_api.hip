@@ -294,6 +294,13 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
     int rc = fill_lighting(d->in, P.L);
     if (rc) return rc;
     P.sh9 = (const float4*)d->sh9_rgba; P.ao = d->ambient_occlusion; P.skyBrightness = d->sky_brightness; P.diffuseIbl = d->diffuse_ibl;
+    if (d->specular_ibl && d->prefiltered_envmap && d->env_brdf) {        // g_envmapIndex != -1 && g_envBrdfTextureIndex != -1
+        if (!d->envmap_res || !d->envmap_mips || d->envmap_mips > 16 || !d->env_brdf_width || !d->env_brdf_height)
+            return fail(INCR_ERR_INVALID_ARGUMENT, "specular IBL inputs: zero envmap / LUT dimensions");
+        P.envmap = d->prefiltered_envmap; P.envmapRes = d->envmap_res; P.envmapMips = d->envmap_mips;
+        P.envBrdf = d->env_brdf; P.envBrdfW = d->env_brdf_width; P.envBrdfH = d->env_brdf_height;
+        memcpy(P.skyInvViewProj, d->in.view->sky_inv_view_proj.m, 64);
+    }
     HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }

@@ -100,7 +100,12 @@ struct LightingParams {
     uint32_t y0, y1;
 };
 
-struct SkyParams { LightingParams L; const float4* __restrict__ sh9; const uint8_t* __restrict__ ao; float skyBrightness; int32_t diffuseIbl; };
+struct SkyParams {
+    LightingParams L; const float4* __restrict__ sh9; const uint8_t* __restrict__ ao; float skyBrightness; int32_t diffuseIbl;
+    const uint32_t* __restrict__ envmap; uint32_t envmapRes, envmapMips;       // prefiltered cube, all levels (NULL = no specular IBL)
+    const uint32_t* __restrict__ envBrdf; uint32_t envBrdfW, envBrdfH;
+    float skyInvViewProj[16];                                                  // sky-lighting.inl:124
+};
 
 struct DirectParams { LightingParams L; PtParams S; uint32_t sunIndex; };
 

@@ -197,7 +197,9 @@ class LightingInputs(C.Structure):
 
 class SkyLightingDesc(C.Structure):
     _fields_ = [("inp", LightingInputs), ("sh9_rgba", C.c_void_p), ("ambient_occlusion", C.c_void_p),
-                ("sky_brightness", C.c_float), ("diffuse_ibl", C.c_int32)]
+                ("sky_brightness", C.c_float), ("diffuse_ibl", C.c_int32),
+                ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
+                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32), ("specular_ibl", C.c_int32)]
 
 
 class DirectLightingDesc(C.Structure):
@@ -227,7 +229,9 @@ class SkyIblInfo(C.Structure):
 
 class RendererScene(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("directional_light_index", C.c_int32), ("punctual_light_count", C.c_uint32),
-                ("meshlet_count", C.c_uint32), ("skylight_sh9_rgba", C.c_void_p)]
+                ("meshlet_count", C.c_uint32), ("skylight_sh9_rgba", C.c_void_p),
+                ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
+                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32)]
 
 
 class RendererConfig(C.Structure):
@@ -236,7 +240,7 @@ class RendererConfig(C.Structure):
                 ("exposure", C.c_float), ("sky_brightness", C.c_float), ("camera_near_plane", C.c_float),
                 ("light_cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32), ("cluster_depth_extent", C.c_float),
                 ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
-                ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32)]
+                ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32)]
 
 
 (SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,

@@ -173,7 +173,7 @@ def with_scissor(vc, row_begin, row_end):
     return c
 
 
-def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig, storage_rounding=0, have_sh=True, band=None):
+def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig, storage_rounding=0, have_sh=True, band=None, ibl=None):
     """All pass descs of one raster frame over a dict of surface pointers (device pointers for the HIP library, host
     pointers for the oracle: both take the same structs).  Returns an ordered list of (pass name, desc).
     band = (row_begin, row_end): the sort-first multi-GPU variant -- draw and shade the band plus a one-row halo,
@@ -212,6 +212,12 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
         d.sh9_rgba = surf["sh9"] if have_sh else None
         d.ambient_occlusion = None
         d.sky_brightness, d.diffuse_ibl = cfg.SkyBrightness, 1 if cfg.EnableDiffuseIBL else 0
+        d.specular_ibl = 1 if cfg.EnableSpecularIBL else 0
+        if ibl is not None:         # IblInputs: pointers valid for whoever runs the pass (device for the library, host for the oracle)
+            if ibl.sh9:
+                d.sh9_rgba = ibl.sh9
+            d.prefiltered_envmap, d.envmap_res, d.envmap_mips = ibl.envmap, ibl.envmap_res, ibl.envmap_mips
+            d.env_brdf, d.env_brdf_width, d.env_brdf_height = ibl.env_brdf, ibl.env_brdf_size[0], ibl.env_brdf_size[1]
         out.append(("sky_lighting", d))
     if sun != -1 and cfg.EnableDirectLighting:
         d = A.DirectLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
@@ -247,7 +253,21 @@ def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
     c.max_lights_per_cluster, c.cluster_depth_extent = cfg.MaxLightsPerCluster, cfg.ClusterDepthExtent
     c.max_sample_count, c.camera_aperture, c.camera_focal_length = cfg.MaxSampleCount, cfg.Pathtracing_CameraAperture, cfg.Pathtracing_CameraFocalLength
     c.turbidity, c.env_sky_mode, c.storage_rounding = cfg.Turbidity, cfg.EnvSkyMode, storage_rounding
+    c.enable_specular_ibl = int(cfg.EnableSpecularIBL)
     return c
+
+
+class IblInputs:
+    """Device pointers of the sky-lighting inputs that the precompute produces (ibl.SkyIbl + ibl.generate_env_brdf)."""
+
+    def __init__(self, sh9=None, envmap=None, envmap_res=0, envmap_mips=0, env_brdf=None, env_brdf_size=(0, 0)):
+        self.sh9, self.envmap, self.envmap_res, self.envmap_mips = sh9, envmap, envmap_res, envmap_mips
+        self.env_brdf, self.env_brdf_size = env_brdf, env_brdf_size
+
+    @staticmethod
+    def from_sky(sky, env_brdf=None, env_brdf_size=(0, 0)):
+        i = sky.info
+        return IblInputs(i.sh9_rgba, i.envmap_r11g11b10, i.cubemap_res, i.num_mips, env_brdf, env_brdf_size)
 
 
 class HostRenderer:
@@ -255,7 +275,7 @@ class HostRenderer:
     This is the production frame loop; RasterRenderer below issues the same passes one by one from Python and exists so
     that tests can compare every intermediate surface with the oracle."""
 
-    def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig, path_trace=False, sh9_rgb=None, stream=None, storage_rounding=0):
+    def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig, path_trace=False, sh9_rgb=None, stream=None, storage_rounding=0, ibl=None):
         self.ctx, self.scene, self.res_x, self.res_y = ctx, scene, res_x, res_y
         self.sh9 = None
         if sh9_rgb is not None:
@@ -268,6 +288,11 @@ class HostRenderer:
         s.punctual_light_count = punctual_light_count(scene.packed)
         s.meshlet_count = getattr(scene.packed, "num_meshlets", 0)
         s.skylight_sh9_rgba = self.sh9
+        if ibl is not None:         # products of the sky / IBL precompute (IblInputs)
+            if ibl.sh9:
+                s.skylight_sh9_rgba = ibl.sh9
+            s.prefiltered_envmap, s.envmap_res, s.envmap_mips = ibl.envmap, ibl.envmap_res, ibl.envmap_mips
+            s.env_brdf, s.env_brdf_width, s.env_brdf_height = ibl.env_brdf, ibl.env_brdf_size[0], ibl.env_brdf_size[1]
         c = renderer_config(cfg, path_trace, storage_rounding)
         self.handle = C.c_void_p()
         rt.check(ctx.lib.incr_renderer_create(ctx.handle, stream, res_x, res_y, C.byref(s), C.byref(c), C.byref(self.handle)))

@@ -300,15 +300,19 @@ typedef struct incr_lighting_inputs {
     int32_t  storage_rounding;
 } incr_lighting_inputs;
 
-/* RenderJob::SkyLightingPass::Execute (render-jobs/sky-lighting.inl; shaders/lighting/sky-lighting.hlsl): SH9 diffuse IBL.
- * The specular IBL branch needs the prefiltered environment cube + env-BRDF LUT (SURVEY.md 8f "next"): this
- * entry point behaves like the shader with g_envmapIndex == -1. */
+/* RenderJob::SkyLightingPass::Execute (render-jobs/sky-lighting.inl; shaders/lighting/sky-lighting.hlsl): SH9 diffuse IBL
+ * + split-sum specular IBL (prefiltered environment cube x env-BRDF LUT, both from the precompute entry points below). */
 typedef struct incr_sky_lighting_desc {
     incr_lighting_inputs in;
     const float* sh9_rgba;             /* device, 9 x float4: the skylight probe texture (RGBA32F 9x1); NULL = g_skylightProbeIndex -1 */
     const uint8_t* ambient_occlusion;  /* device, R8_UNORM; NULL = cleared to 1 (HBAO disabled, renderer.cpp:1818-1838) */
     float    sky_brightness;           /* FConfig::SkyBrightness */
     int32_t  diffuse_ibl;              /* FConfig::EnableDiffuseIBL */
+    const uint32_t* prefiltered_envmap;/* device, R11G11B10_FLOAT cube, all levels packed (incr_sky_ibl_info::envmap_r11g11b10); NULL = g_envmapIndex -1 */
+    uint32_t envmap_res, envmap_mips;
+    const uint32_t* env_brdf;          /* device, R16G16_FLOAT LUT (incr_generate_env_brdf); NULL = g_envBrdfTextureIndex -1 */
+    uint32_t env_brdf_width, env_brdf_height;
+    int32_t  specular_ibl;             /* FConfig::EnableSpecularIBL */
 } incr_sky_lighting_desc;
 int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* desc, incr_stream stream);
 
@@ -395,7 +399,11 @@ typedef struct incr_renderer_scene {       /* what Renderer::Render asks FScene 
     int32_t  directional_light_index;      /* FScene::GetDirectionalLight() (-1 = none) */
     uint32_t punctual_light_count;         /* FScene::GetPunctualLightCount() */
     uint32_t meshlet_count;                /* FScene::m_meshletCount */
-    const float* skylight_sh9_rgba;        /* device, 9 x float4 skylight probe; NULL = none */
+    const float* skylight_sh9_rgba;        /* device, 9 x float4 skylight probe (m_skylight.m_shTextureIndex); NULL = none */
+    const uint32_t* prefiltered_envmap;    /* device, m_skylight.m_envmapTextureIndex: prefiltered cube, all levels; NULL = none */
+    uint32_t envmap_res, envmap_mips;
+    const uint32_t* env_brdf;              /* device, Renderer::s_envBRDF (R16G16_FLOAT); NULL = none */
+    uint32_t env_brdf_width, env_brdf_height;
 } incr_renderer_scene;
 typedef struct incr_renderer_config {      /* FConfig fields the frame reads (inc/common.h:6-48) */
     int32_t  path_trace, viewmode, enable_taa, frustum_culling, enable_direct_lighting, enable_sky_lighting, enable_diffuse_ibl;
@@ -405,6 +413,7 @@ typedef struct incr_renderer_config {      /* FConfig fields the frame reads (in
     uint32_t max_sample_count;
     float    camera_aperture, camera_focal_length, turbidity;
     int32_t  env_sky_mode, storage_rounding;
+    int32_t  enable_specular_ibl;
 } incr_renderer_config;
 enum {
     INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,

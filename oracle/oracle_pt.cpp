@@ -1019,8 +1019,8 @@ void orc_tonemap(const uint32_t* hdr_r11g11b10, uint8_t* ldr_rgba8, uint32_t res
 
 } // extern "C"
 
+// sky / IBL precompute feeding the hot path; its cube-map sampler is also what the sky-lighting pass uses
+#include "oracle_ibl.h"
+
 // raster half of the hot path: shares the scene access, texture unit and BRDF code above
 #include "oracle_raster.h"
-
-// sky / IBL precompute feeding the hot path
-#include "oracle_ibl.h"

@@ -459,10 +459,31 @@ static float3 ShIrradiance(float3 n, const float3 sh[9]) {
     return irr;
 }
 // shaders/lighting/sky-lighting.hlsl:36-119 with g_envmapIndex == -1 (no specular IBL inputs this round)
-static void sky_lighting(const Scene& s, const incr_lighting_inputs& in, const float* sh9rgba, const uint8_t* aoTex, float skyBrightness, int diffuseIbl) {
+// R16G16_FLOAT LUT, bilinear, CLAMP addressing, level 0
+static float2 sample_rg16f_bilinear_clamp(const uint32_t* img, uint32_t W, uint32_t H, float2 uv) {
+    float u = uv.x, v = uv.y;
+    if (!(u == u)) u = 0.f;
+    if (!(v == v)) v = 0.f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1)); y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = std::min(x0 + 1, W - 1), y1 = std::min(y0 + 1, H - 1);
+    auto ld = [&](uint32_t xx, uint32_t yy) -> float2 { const uint32_t t = img[(size_t)yy * W + xx]; return {f16_to_f32((uint16_t)(t & 0xffffu)), f16_to_f32((uint16_t)(t >> 16))}; };
+    const float2 t00 = ld(x0, y0), t10 = ld(x1, y0), t01 = ld(x0, y1), t11 = ld(x1, y1);
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    return {(t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy, (t00.y * wx0 + t10.y * fx) * wy0 + (t01.y * wx0 + t11.y * fx) * fy};
+}
+static void sky_lighting(const Scene& s, const incr_sky_lighting_desc& d) {
     (void)s;
+    const incr_lighting_inputs& in = d.in;
+    const float* sh9rgba = d.sh9_rgba; const uint8_t* aoTex = d.ambient_occlusion;
+    const float skyBrightness = d.sky_brightness; const int diffuseIbl = d.diffuse_ibl;
+    const bool specular = d.specular_ibl && d.prefiltered_envmap && d.env_brdf;
+    const CubeChain env = {d.envmap_res, d.envmap_mips, d.prefiltered_envmap};
     const incr_view_constants& vc = *in.view;
-    const uint32_t W = vc.res_x;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 ivp = to_mat4(vc.sky_inv_view_proj);
+    const float3 eye = {vc.eye_pos[0], vc.eye_pos[1], vc.eye_pos[2]};
     float3 sh[9];
     if (sh9rgba) for (int k = 0; k < 9; ++k) sh[k] = {sh9rgba[k * 4], sh9rgba[k * 4 + 1], sh9rgba[k * 4 + 2]};
     uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
@@ -475,6 +496,20 @@ static void sky_lighting(const Scene& s, const incr_lighting_inputs& in, const f
             const float3 shDiffuse = ((albedo * Fd_Lambert()) * ShIrradiance(g.N, sh)) * 5.f;
             const float3 occluded = g.ao * shDiffuse;
             radiance += skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));      // lerp(a, b, t) = a + t (b - a)
+        }
+        if (specular) {                                                                        // sky-lighting.hlsl:98-116
+            float2 sp = screen_pos(x, y, W, H); sp.y = -sp.y;
+            const float4 wp = mul_vec4({sp.x, sp.y, in.depth_buffer[i], 1.f}, ivp);
+            const float3 worldPos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+            const float3 V = normalize(eye - worldPos);
+            const float NoV = hmax(dot(g.N, V), 0.01f);
+            const float3 F0 = g.metallic * g.basecolor + (1.f - g.metallic) * 0.04f;
+            const float3 R = normalize(reflect(-V, g.N));
+            const float3 prefilteredColor = cube_sample_trilinear(env, R, g.roughness * ((float)d.envmap_mips - 1.f));
+            const float2 envBrdf = sample_rg16f_bilinear_clamp(d.env_brdf, d.env_brdf_width, d.env_brdf_height, {NoV, g.roughness});
+            const float3 specularIBL = prefilteredColor * (F0 * envBrdf.x + envBrdf.y);
+            const float3 occludedSpec = g.ao * specularIBL;
+            radiance += skyBrightness * (specularIBL + g.aoBlend * (occludedSpec - specularIBL));
         }
         const float hbao = aoTex ? (float)aoTex[i] / 255.f : 1.f;
         add_color(in.color_target, i, hbao * radiance, in.storage_rounding);
@@ -576,7 +611,7 @@ void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
     gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding);
 }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {
-    sky_lighting(*(Scene*)scene, d->in, d->sh9_rgba, d->ambient_occlusion, d->sky_brightness, d->diffuse_ibl);
+    sky_lighting(*(Scene*)scene, *d);
 }
 void orc_direct_lighting(void* scene, const incr_direct_lighting_desc* d, uint64_t* shadowRays) {
     direct_lighting(*(Scene*)scene, d->in, d->directional_light_index, shadowRays);

@@ -206,3 +206,41 @@ def test_gpu_env_brdf_matches_oracle(rt, ob, gpu_ctx):
         b = ((o >> shift) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
         np.testing.assert_allclose(a, b, rtol=2.0 ** -9, atol=2.0 ** -14)         # sinf/cosf of the sample azimuth: within two f16 steps
     assert (g == o).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_gpu_frame_with_specular_ibl(rt, R, ob, A, sio, gpu_ctx, sponza_small):
+    """Raster frame with the precomputed sky inputs wired in (SH9 probe, prefiltered environment cube, env-BRDF LUT): the
+    sky-lighting pass of the library against the oracle's, both fed the SAME products (downloaded from the GPU)."""
+    from test_raster_host_and_oracle import run_oracle_frame
+    from test_gpu_raster import colour_close
+    ibl_mod = __import__("importlib").import_module("incarnation-renderer_amd.ibl")
+    W, H, LW, LH = 256, 144, 64, 64
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    osc = ob.OracleScene(sponza_small)
+    try:
+        sky = ibl_mod.SkyIbl(gpu_ctx, gscene, resolution=32)
+        lut = ibl_mod.generate_env_brdf(gpu_ctx, LW, LH)
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, ibl=R.IblInputs.from_sky(sky, lut, (LW, LH)))
+        hr.render(view); gpu_ctx.synchronize()
+        got = hr.download(A.SURFACE_HDR_RASTER)
+        # the same frame without the specular term is darker on metallic / smooth pixels
+        hr2 = R.HostRenderer(gpu_ctx, gscene, W, H, ibl=R.IblInputs(sh9=sky.info.sh9_rgba))
+        hr2.render(view); gpu_ctx.synchronize()
+        base = hr2.download(A.SURFACE_HDR_RASTER)
+        assert (ob.unpack_r11g11b10(got).sum(-1) >= ob.unpack_r11g11b10(base).sum(-1) * 0.999).mean() > 0.99 and not np.array_equal(got, base)
+        # oracle with the GPU's products as inputs
+        prod = sky.download()
+        lut_host = gpu_ctx.download(lut, (LH, LW), np.uint32)
+        env_host, sh_host = np.ascontiguousarray(prod["envmap"]), np.ascontiguousarray(prod["sh9"])
+        hs = ob.HostSurfaces(W, H, sponza_small.num_meshlets, 16 * 9 * 24, 64)
+        vc = R.make_view_constants(view, W, H, R.pixel_jitter(0, W, H))
+        ibl_host = R.IblInputs(sh_host.ctypes.data, env_host.ctypes.data, 32, sky.info.num_mips, lut_host.ctypes.data, (LW, LH))
+        for name, d in R.build_descs(None, sponza_small, vc, hs.ptr, 0, ibl=ibl_host):
+            ob.run_pass(osc, name, d)
+        frac = colour_close(ob, got, hs.arr["color"], "colour target with specular IBL")
+        assert frac > 0.995, frac
+        hr.close(); hr2.close(); sky.close(); gpu_ctx.free(lut)
+    finally:
+        osc.close(); gscene.close()

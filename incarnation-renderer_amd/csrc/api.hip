@@ -354,6 +354,10 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     const float Lm[3] = {L.x, L.y, L.z};
     sky_sun_terms(Lm, d->turbidity, P.perez, &P.sunMiss);
     sky_sun_terms(sc->host.sunDir, d->turbidity, P.perez, &P.sunEnv);
+    if (d->envmap_r11g11b10) {
+        if (!d->envmap_res || !d->envmap_mips || d->envmap_mips > 16) return fail(INCR_ERR_INVALID_ARGUMENT, "envmap given with zero resolution / level count");
+        P.envmap = d->envmap_r11g11b10; P.envmapRes = d->envmap_res; P.envmapMips = d->envmap_mips;
+    }
     P.rowBlockHeight = d->shard.row_block_height; P.rowBlockFirst = d->shard.row_block_first; P.rowBlockStride = d->shard.row_block_stride ? d->shard.row_block_stride : 1;
     P.localRows = incr_shard_local_rows(d->res_y, &d->shard);
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;

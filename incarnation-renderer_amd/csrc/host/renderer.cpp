@@ -55,6 +55,7 @@ Result PathTracing::Execute(Sync* jobSync, const Desc& p) {               // pat
     d.env_sky_mode = p.renderConfig.EnvSkyMode; d.direct_lighting = p.renderConfig.EnableDirectLighting ? 1 : 0;
     d.viewmode = p.renderConfig.Viewmode; d.turbidity = p.renderConfig.Turbidity; d.sky_brightness = p.renderConfig.SkyBrightness;
     d.storage_rounding = p.renderConfig.StorageRounding;
+    d.envmap_r11g11b10 = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;   // :203 envmapTextureIndex
     return done(jobSync->Execute(token, [&] { return incr_pathtrace(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 

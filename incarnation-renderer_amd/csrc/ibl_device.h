@@ -62,7 +62,15 @@ DI f3 cube_sample_trilinear(const CubeChain& c, f3 dir, float level) {
     return c0 * (1.f - f) + c1 * f;
 }
 
-DI f3 latlong_dir(f2 uv) {              // common/math.hlsli:46-79: LatlongUV2Polar + Polar2Cartesian(..., World)
+// Radiance arriving along `dir` for the path tracer's sky next-event estimate: envmap.SampleLevel(g_envmapSampler, dir, 0)
+// (pathtracing.hlsl:240-243; sampler s0: MIN_MAG_LINEAR_MIP_POINT) on the prefiltered sky cube when the caller provides
+// it, else the analytic 0.04 * Preetham that level 0 of the cube is made from.
+DI f3 sky_env_radiance(const PtParams& P, f3 dir) {
+    if (P.envmap) return cube_sample_level(CubeChain{P.envmapRes, P.envmapMips, P.envmap}, dir, 0u);
+    return 0.04f * CalculateSkyRadianceRGB(P.sunEnv, dir, P.perez);
+}
+
+DI f3 latlong_dir(f2 uv) {            // common/math.hlsli:46-79: LatlongUV2Polar + Polar2Cartesian(..., World)
     const float theta = K_PI * uv.y, phi = K_PI * (uv.x * 2.f - 1.f);
     const float sint = sinf(theta), cost = cosf(theta), sinp = sinf(phi), cosp = cosf(phi);
     return {sint * sinp, cost, sint * cosp};

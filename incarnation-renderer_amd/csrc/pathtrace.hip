@@ -14,6 +14,7 @@
 // traversal stack staged in LDS ([entry][lane] layout: conflict-free ds_read/ds_write_b32) and a
 // private-memory overflow that is only touched by pathological rays.
 #include "pt_traverse.h"
+#include "ibl_device.h"
 #include <algorithm>
 
 namespace incr {
@@ -200,7 +201,7 @@ DI f4 trace_pixel(const PtParams& P, LaneStack& st, uint32_t px, uint32_t py, Co
         {   // skylight :239-244
             const f2 u = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
             const f3 sampleDir = CosineSampleHemisphere(u);
-            const f3 radianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, sampleDir, P.perez));
+            const f3 radianceIn = P.skyBrightness * sky_env_radiance(P, sampleDir);
             const f3 r = attenuation * GetSkyRadiance(P, st, radianceIn, sampleDir, hitPosition, matInfo, N, V, cnt);
             color.x += r.x; color.y += r.y; color.z += r.z;
         }

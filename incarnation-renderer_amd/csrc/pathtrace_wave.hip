@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void pathtrace_wave_kernel(const PtParams P
         if (shading) {
             const f2 u = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
             skyDir = CosineSampleHemisphere(u);
-            skyRadianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, skyDir, P.perez));
+            skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             skyNoL = saturate(dot(N, skyDir));
             skyNeedsShadow = skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f);
             ws.skyDir[0][lane] = skyDir.x; ws.skyDir[1][lane] = skyDir.y; ws.skyDir[2][lane] = skyDir.z;

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
                     // sky sample :239-244
                     const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
                     const f3 skyDir = CosineSampleHemisphere(us);
-                    const f3 skyRadianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, skyDir, P.perez));
+                    const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
                     const float skyNoL = saturate(dot(N, skyDir));
                     if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req[3] |= 0x80000000u; cnt.skyShadow++; }
                     // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
             }
         }
         {   // sky sample (pathtracing.hlsl:239-244 + lighting/common.hlsli:145-202)
-            const f3 skyRadianceIn = P.skyBrightness * (0.04f * CalculateSkyRadianceRGB(P.sunEnv, skyDir, P.perez));
+            const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
             if (words[3] >> 31) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);

@@ -40,6 +40,9 @@ struct PtParams {
     uint32_t gridDim[3];
     const uint32_t* __restrict__ gridCellOffsets;
     const uint32_t* __restrict__ gridCellLights;
+    // prefiltered sky cube for the sky next-event estimate (NULL = analytic 0.04 * Preetham)
+    const uint32_t* __restrict__ envmap;
+    uint32_t envmapRes, envmapMips;
 };
 
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).

@@ -4,6 +4,7 @@
 // fused integrate pass (shaders/raytracing/pathtrace-integrate.hlsl:16-31).
 #pragma once
 #include "pt_traverse.h"
+#include "ibl_device.h"
 
 namespace incr {
 

@@ -129,6 +129,7 @@ class PathtraceDesc(C.Structure):
         ("env_sky_mode", C.c_int32), ("direct_lighting", C.c_int32), ("viewmode", C.c_int32),
         ("turbidity", C.c_float), ("sky_brightness", C.c_float), ("storage_rounding", C.c_int32),
         ("ray_stats", C.c_void_p),
+        ("envmap_r11g11b10", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
     ]
 
 

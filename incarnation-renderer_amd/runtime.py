@@ -221,9 +221,12 @@ class Scene:
             self.handle = C.c_void_p()
 
 
-def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FConfig, storage_rounding=0):
-    """Fill an incr_pathtrace_desc from FConfig defaults (inc/common.h:6-48) and an FView."""
+def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FConfig, storage_rounding=0, envmap=None):
+    """Fill an incr_pathtrace_desc from FConfig defaults (inc/common.h:6-48) and an FView.
+    envmap = (pointer, resolution, levels) of the prefiltered sky cube (ibl.SkyIbl) or None for the analytic stand-in."""
     d = A.PathtraceDesc()
+    if envmap is not None:
+        d.envmap_r11g11b10, d.envmap_res, d.envmap_mips = envmap
     d.res_x, d.res_y = res_x, res_y
     if shard is not None:
         d.shard = shard
@@ -254,8 +257,8 @@ class PathTracer:
         ctx.clear(self.history, self.rows * res_x * 4)
         ctx.clear(self.stats, C.sizeof(A.RayStats))
 
-    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True):
-        d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding)
+    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True, envmap=None):
+        d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding, envmap)
         d.scene = self.scene.handle
         d.target_rgba16f, d.history_r11g11b10 = self.target, self.history
         d.ray_stats = self.stats if count_rays else None

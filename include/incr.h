@@ -114,6 +114,12 @@ typedef struct incr_pathtrace_desc {
     float    sky_brightness;         /* FConfig::SkyBrightness (25000)                                           */
     int32_t  storage_rounding;       /* 0 = round-toward-zero typed-UAV stores (D3D11.3 spec 3.2.3.3), 1 = nearest-even */
     incr_ray_stats* ray_stats;       /* device, optional (NULL = do not count); ACCUMULATED, caller clears        */
+    /* GlobalCbLayout::envmapTextureIndex = FScene::m_skylight.m_envmapTextureIndex (path-tracing.inl:203): the prefiltered
+     * sky cube that chsMain samples at level 0 for the sky next-event estimate (pathtracing.hlsl:240-243).  Device pointer to
+     * all levels packed (incr_sky_ibl_info::envmap_r11g11b10).  NULL = evaluate 0.04 * Preetham(sun) analytically instead
+     * (what level 0 of that cube approximates; DESIGN.md deviation Q15). */
+    const uint32_t* envmap_r11g11b10;
+    uint32_t envmap_res, envmap_mips;
 } incr_pathtrace_desc;
 int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);
 

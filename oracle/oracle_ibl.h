@@ -56,6 +56,7 @@ static float3 cube_sample_level(const CubeChain& c, float3 dir, uint32_t level) 
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
 }
+static float3 env_cube_level0(const uint32_t* data, uint32_t N, uint32_t mips, float3 dir) { return cube_sample_level({N, mips, data}, dir, 0u); }
 static float3 cube_sample_trilinear(const CubeChain& c, float3 dir, float level) {
     if (!(level > 0.f)) level = 0.f;                       // also NaN
     const float top = (float)(c.mips - 1);

@@ -642,7 +642,9 @@ struct Frame {            // per-call constants (path-tracing.inl:134-217 Global
     int directLighting, viewmode, lightCount;
     incr_perez_distribution perez;
     SkySunTerms sunMiss, sunEnv;
+    const uint32_t* envmap; uint32_t envmapRes, envmapMips;     // GlobalCbLayout::envmapTextureIndex (NULL: analytic stand-in)
 };
+static float3 env_cube_level0(const uint32_t* data, uint32_t N, uint32_t mips, float3 dir);      // oracle_ibl.h
 
 struct Ray { float3 o, d; float tmin, tmax; };
 
@@ -755,8 +757,10 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         {   // Skylight contribution :239-244 (Q1: tangent-space direction used as a world direction)
             float2 u = SamplePoint(pixelIdx, f.sampleIdx, sampleSetIndex, f.sqrtSampleCount, f.numPixels);
             float3 sampleDir = CosineSampleHemisphere(u);
-            // Q15 first cut: envCube mip 0 ~= 0.04 * Preetham(scene sun dir); evaluated analytically
-            float3 radianceIn = f.skyBrightness * (0.04f * CalculateSkyRadianceRGB(f.sunEnv, sampleDir, f.perez));
+            // envmap.SampleLevel(g_envmapSampler, sampleDir, 0) on the prefiltered sky cube when the caller supplies it
+            // (oracle_ibl.h); else Q15: level 0 of that cube ~= 0.04 * Preetham(scene sun dir), evaluated analytically
+            float3 radianceIn = f.skyBrightness * (f.envmap ? env_cube_level0(f.envmap, f.envmapRes, f.envmapMips, sampleDir)
+                                                            : 0.04f * CalculateSkyRadianceRGB(f.sunEnv, sampleDir, f.perez));
             float3 r = attenuation * GetSkyRadiance(s, radianceIn, sampleDir, hitPosition, matInfo, N, V, rs);
             color.x += r.x; color.y += r.y; color.z += r.z;
         }
@@ -835,6 +839,7 @@ static Frame make_frame(const Scene& s, const PtDesc& d) {
     L = normalize(L);
     f.sunMiss = sky_sun_terms(L, d.turbidity, f.perez);
     f.sunEnv = sky_sun_terms(f3(s.d.sun_dir[0], s.d.sun_dir[1], s.d.sun_dir[2]), d.turbidity, f.perez);
+    f.envmap = d.envmap_r11g11b10; f.envmapRes = d.envmap_res; f.envmapMips = d.envmap_mips;
     return f;
 }
 

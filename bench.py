@@ -48,7 +48,7 @@ def build_scene(name, texture_size):
     raise SystemExit("unknown scene " + name)
 
 
-def cpu_baseline(packed, view, res, seconds_hint):
+def cpu_baseline(packed, view, res, seconds_hint, envmap=None):
     """Oracle (scalar CPU restatement, kind "port") on a bounded sample of the same workload."""
     from oracle import binding as ob
     rt = importlib.import_module(PKG + ".runtime")
@@ -59,12 +59,12 @@ def cpu_baseline(packed, view, res, seconds_hint):
     W, H = res
     pw, ph = max(W // 4, 16), max(H // 4, 16)
     t0 = time.time()
-    osc.pathtrace(rt.make_pathtrace_desc(sio.FView().reset(packed, aspect=pw / ph), pw, ph, 1), num_threads=cores)
+    osc.pathtrace(rt.make_pathtrace_desc(sio.FView().reset(packed, aspect=pw / ph), pw, ph, 1, envmap=envmap), num_threads=cores)
     probe = max(time.time() - t0, 1e-3)
     scale = min(max((seconds_hint / (probe * 16.0)) ** 0.5, 1.0), 3840.0 / W)
     W, H = int(W * scale) // 8 * 8, int(H * scale) // 8 * 8
     view = sio.FView().reset(packed, aspect=W / H)
-    d = rt.make_pathtrace_desc(view, W, H, 1)
+    d = rt.make_pathtrace_desc(view, W, H, 1, envmap=envmap)
     t0 = time.time()
     r = osc.pathtrace(d, num_threads=cores)
     dt = time.time() - t0
@@ -79,8 +79,6 @@ def cpu_baseline(packed, view, res, seconds_hint):
 # G-buffer read 4, write 16; direct read 16, rw 8; clustered read 24, rw 8; sky read 17, rw 8; TAA read 12, write 4;
 # tonemap read 4, write 4 => 133 B/pixel (geometry, light lists and textures are extra and small).
 RASTER_B_PX = 133
-RASTER_SH9 = [[1.0, 1.1, 1.3], [0.3, 0.3, 0.35], [0.1, 0.1, 0.2], [-0.05, -0.04, -0.02], [0.02, 0.02, 0.03],
-              [0.04, 0.05, 0.05], [-0.03, -0.03, -0.02], [0.01, 0.02, 0.02], [0.05, 0.04, 0.03]]
 
 
 class _DeviceWords:
@@ -90,12 +88,12 @@ class _DeviceWords:
         self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
 
-def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, torch, dist, rank, world, dev):
+def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, torch, dist, rank, world, dev, ibl_inputs):
     """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM.
     world > 1: every rank renders its row band; one RCCL all_gather of the TAA bands per frame; rank 0 tonemaps."""
     R = importlib.import_module(PKG + ".raster")
     A = importlib.import_module(PKG + ".ctypes_api")
-    rr = R.HostRenderer(ctx, scene, W, H, sh9_rgb=RASTER_SH9, stream=stream_handle)      # C++ Renderer::Render (csrc/host/renderer.cpp)
+    rr = R.HostRenderer(ctx, scene, W, H, stream=stream_handle, ibl=ibl_inputs)      # C++ Renderer::Render (csrc/host/renderer.cpp)
     rows = (H + world - 1) // world
     tensors = {}
     if world > 1:
@@ -136,9 +134,9 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     alg = float(W) * H * RASTER_B_PX
     return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world,
             "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
-            "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), TAA on, 1 sun shadow ray/pixel"
+            "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA"
                         % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1])),
-            "passes": "batch_cull, light_cull, visibility, gbuffer, sky_lighting, direct_lighting, clustered_lighting, taa_resolve, tonemap",
+            "passes": "batch_cull, light_cull, visibility, gbuffer, sky_lighting, direct_lighting, clustered_lighting, dynamic_sky, taa_resolve, tonemap",
             "sun_shadow_rays_per_frame": int(rays), "algorithmic_bytes_per_frame": int(alg),
             "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
@@ -186,6 +184,16 @@ def main():
     ctx = rt.Context(local_rank)
     scene = ctx.create_scene(packed)
     info = scene.info()
+    # load-time precompute, as the reference does once per scene / sun change (FScene::UpdateDynamicSky at
+    # EnvmapResolution 256, Renderer::GenerateEnvBrdfTexture 512x512): feeds the sky NEE of the path tracer and sky lighting
+    ibl_mod = importlib.import_module(PKG + ".ibl")
+    t_ibl = time.perf_counter()
+    sky = ibl_mod.SkyIbl(ctx, scene)
+    env_brdf = ibl_mod.generate_env_brdf(ctx, 512, 512)
+    ctx.synchronize()
+    t_ibl = time.perf_counter() - t_ibl
+    envmap = (sky.info.envmap_r11g11b10, sky.info.cubemap_res, sky.info.num_mips)
+    ibl_inputs = importlib.import_module(PKG + ".raster").IblInputs.from_sky(sky, env_brdf, (512, 512))
 
     shard = A.Shard(0, 0, 1) if world == 1 else A.Shard(8, rank, world)
     rows = ctx.lib.incr_shard_local_rows(H, C.byref(shard))
@@ -197,7 +205,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def step(sample_index, e0=None, e1=None):
-        d = rt.make_pathtrace_desc(view, W, H, sample_index, shard)
+        d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap)
         d.scene = scene.handle
         if args.no_direct_lighting:
             d.direct_lighting = 0
@@ -247,7 +255,8 @@ def main():
     # at N > 1 every rank renders its row band and the TAA bands are all-gathered (sort-first)
     raster_out = None
     if not args.no_raster:
-        raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev)
+        raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs)
+        raster_out["sky_ibl_precompute_ms"] = round(t_ibl * 1e3, 2)      # once per scene / sun change, not per frame
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
@@ -301,7 +310,9 @@ def main():
             out["raster"] = raster_out
         if world == 1 and not args.no_cpu_baseline:
             cw, ch = (int(v) for v in args.cpu_res.lower().split("x"))
-            out["cpu_baseline"] = cpu_baseline(packed, sio.FView().reset(packed, aspect=cw / ch), (cw, ch), 20)
+            host_env = np.ascontiguousarray(sky.download()["envmap"])      # the same sky cube, on the host, for the CPU port
+            out["cpu_baseline"] = cpu_baseline(packed, sio.FView().reset(packed, aspect=cw / ch), (cw, ch), 20,
+                                               envmap=(host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips))
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

@@ -55,6 +55,11 @@ struct incr_scene {
     // raster path (meshlets resolved through the accessor indirection once, at scene creation)
     incr_gpu_meshlet* dMeshlets = nullptr; uint32_t* dPackedTris = nullptr; uint32_t* dMeshVisibility = nullptr;
     float4* dMvPos = nullptr; float2* dMvUv = nullptr; float4* dMvNormal = nullptr; float4* dMvTangent = nullptr;
+    // primitive (non-meshlet) raster path: per-primitive draws, widened indices, vertex arrays, 64-triangle chunk table
+    incr::PrimDraw* dPrimDraws = nullptr; uint32_t* dPrimIndices = nullptr;
+    float4* dPvPos = nullptr; float2* dPvUv = nullptr; float4* dPvNormal = nullptr; float4* dPvTangent = nullptr;
+    uint32_t* dChunkPrim = nullptr; uint32_t* dChunkFirstTri = nullptr;
+    uint32_t numPrimChunks = 0;
 };
 
 // one zeroed element of slack: the traversal fetches 80 bytes per step, also when the step is a 48-byte triangle

@@ -67,6 +67,7 @@ struct FScene {
     int    m_directionalLightIndex = -1;        // GetDirectionalLight(): global index of the first directional scene light
     size_t m_punctualLightCount = 0;            // GetPunctualLightCount()
     size_t m_meshletCount = 0;
+    size_t m_primitiveCount = 0;
     const float* m_skylightSh9 = nullptr;       // device, 9 x float4 (m_skylight.m_shTextureIndex), may be NULL
     const uint32_t* m_skylightEnvmap = nullptr; // device, prefiltered cube with all levels (m_skylight.m_envmapTextureIndex), may be NULL
     uint32_t m_envmapRes = 0, m_envmapMips = 0;

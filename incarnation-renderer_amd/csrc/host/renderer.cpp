@@ -4,6 +4,7 @@
 // through include/incr.h, exactly what a maintainer of the reference would link against.
 #include "render_jobs.h"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -77,6 +78,7 @@ Result BatchCullingPass::Execute(Sync* jobSync, const Desc& p) {          // bat
     d.counts = (uint32_t*)p.batchCountsBuffer->m_devicePtr;
     d.render_stats = p.renderStatsBuffer ? (incr_render_stats*)p.renderStatsBuffer->m_devicePtr : nullptr;
     d.frustum_culling = p.renderConfig.FrustumCulling ? 1 : 0;
+    d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // cs_meshlet_cull_main : cs_primitive_cull_main
     return done(jobSync->Execute(token, [&] { return incr_batch_cull(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
@@ -101,6 +103,7 @@ Result VisibilityPass::Execute(Sync* jobSync, const Desc& p) {            // vis
     d.double_sided_list = (const incr_draw_cmd*)p.indirectArgsBuffer_DoubleSided->m_devicePtr;
     d.counts = (const uint32_t*)p.indirectCountsBuffer->m_devicePtr;
     d.vis_buffer = (uint32_t*)p.visBufferTarget->m_devicePtr; d.depth_buffer = (float*)p.depthStencilTarget->m_devicePtr;
+    d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // visibility-pass.inl:96-97
     return done(jobSync->Execute(token, [&] { return incr_visibility(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
@@ -112,6 +115,7 @@ Result GBufferComputePass::Execute(Sync* jobSync, const Desc& p) {        // gbu
     d.gbuffer_basecolor = (uint32_t*)p.gbufferTargets[0]->m_devicePtr; d.gbuffer_normals = (uint32_t*)p.gbufferTargets[1]->m_devicePtr;
     d.gbuffer_metallic_roughness_ao = (uint32_t*)p.gbufferTargets[2]->m_devicePtr;
     d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.storage_rounding = p.renderConfig.StorageRounding;
+    d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // USING_MESHLETS, gbuffer-compute-pass.inl:56
     return done(jobSync->Execute(token, [&] { return incr_gbuffer(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
@@ -300,7 +304,8 @@ int Render(State& s, const FRenderState& renderState) {
         batchCullDesc.batchArgsBuffer_Default = &s.batchArgsBuffer_Default; batchCullDesc.batchArgsBuffer_DoubleSided = &s.batchArgsBuffer_DoubleSided;
         batchCullDesc.batchCountsBuffer = &s.batchCountsBuffer;
         batchCullDesc.sceneConstantBuffer = scene; batchCullDesc.viewConstantBuffer = &cbViewConstants;
-        batchCullDesc.drawCount = scene->m_meshletCount; batchCullDesc.renderConfig = c; batchCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
+        const size_t numDraws = c.UseMeshlets ? scene->m_meshletCount : scene->m_primitiveCount;   // :1375-1377
+        batchCullDesc.drawCount = numDraws; batchCullDesc.renderConfig = c; batchCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
         BatchCullingPass::Execute(jobSync, batchCullDesc);
 
         const size_t punctualLightCount = scene->GetPunctualLightCount();
@@ -318,7 +323,7 @@ int Render(State& s, const FRenderState& renderState) {
         visDesc.indirectArgsBuffer_Default = &s.batchArgsBuffer_Default; visDesc.indirectArgsBuffer_DoubleSided = &s.batchArgsBuffer_DoubleSided;
         visDesc.indirectCountsBuffer = &s.batchCountsBuffer;
         visDesc.sceneConstantBuffer = scene; visDesc.viewConstantBuffer = &cbViewConstants;
-        visDesc.resX = resX; visDesc.resY = resY; visDesc.drawCount = scene->m_meshletCount; visDesc.renderConfig = c;
+        visDesc.resX = resX; visDesc.resY = resY; visDesc.drawCount = numDraws; visDesc.renderConfig = c;
         VisibilityPass::Execute(jobSync, visDesc);
 
         GBufferComputePass::Desc gbufferComputeDesc = {};                      // :1765-1781
@@ -445,7 +450,9 @@ int incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x, 
     r->scene.m_envBRDF.m_devicePtr = const_cast<uint32_t*>(scene->env_brdf);
     r->scene.m_envBrdfWidth = scene->env_brdf_width; r->scene.m_envBrdfHeight = scene->env_brdf_height;
     incr_renderer_set_config(r, config);
-    const int rc = Renderer::Initialize(r->state, ctx, stream, res_x, res_y, scene->meshlet_count, r->config);
+    r->scene.m_primitiveCount = scene->primitive_count;
+    // draw lists sized for either path, so FConfig::UseMeshlets can change between frames (renderer.cpp:1375-1377 numDraws)
+    const int rc = Renderer::Initialize(r->state, ctx, stream, res_x, res_y, std::max(scene->meshlet_count, scene->primitive_count), r->config);
     if (rc) { Renderer::Teardown(r->state); delete r; return rc; }
     *out = r;
     return INCR_OK;
@@ -464,6 +471,7 @@ int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
     f.MaxSampleCount = c->max_sample_count; f.Pathtracing_CameraAperture = c->camera_aperture; f.Pathtracing_CameraFocalLength = c->camera_focal_length;
     f.Turbidity = c->turbidity; f.EnvSkyMode = c->env_sky_mode; f.StorageRounding = c->storage_rounding;
     f.EnableSpecularIBL = c->enable_specular_ibl != 0;
+    f.UseMeshlets = c->use_primitives == 0;
     return INCR_OK;
 }
 

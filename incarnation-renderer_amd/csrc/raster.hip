@@ -97,33 +97,44 @@ __global__ __launch_bounds__(64) void mesh_frame_kernel(const RasterScene S, con
 }
 
 // ---------------------------------------------------------------------------------------------- batch culling
-// cs_meshlet_cull_main (batch-culling.hlsl:119-193).  One 1024-lane workgroup walks the meshlets in id order and
-// compacts with ballots + an LDS scan, so both lists come out in ascending meshlet id without atomics.
+// cs_meshlet_cull_main / cs_primitive_cull_main (batch-culling.hlsl:47-193).  One 1024-lane workgroup walks the meshlets
+// (or primitives) in id order and compacts with ballots + an LDS scan, so both lists come out in ascending id without atomics.
 __global__ __launch_bounds__(1024) void batch_cull_kernel(const RasterScene S, const MeshFrame* __restrict__ frames, int frustumCulling,
                                                            incr_draw_cmd* __restrict__ defList, incr_draw_cmd* __restrict__ dsList,
-                                                           uint32_t* __restrict__ counts, incr_render_stats* __restrict__ stats) {
+                                                           uint32_t* __restrict__ counts, incr_render_stats* __restrict__ stats,
+                                                           const PrimDraw* __restrict__ prims, uint32_t numPrims) {
     __shared__ uint32_t s_cnt[2][16];
     __shared__ uint32_t s_base[2];
     __shared__ uint32_t s_culled;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid == 0) { s_base[0] = s_base[1] = 0; s_culled = 0; }
     __syncthreads();
-    for (uint32_t start = 0; start < S.numMeshlets; start += 1024) {
+    const uint32_t numItems = prims ? numPrims : S.numMeshlets;
+    for (uint32_t start = 0; start < numItems; start += 1024) {
         const uint32_t id = start + tid;
         int cls = 0;                                   // 1 default list, 2 double-sided list, 3 culled
         uint32_t vcount = 0;
-        if (id < S.numMeshlets) {
-            const incr_gpu_meshlet m = S.meshlets[id];
-            if (S.meshVisibility[m.meshIndex] != 0) {
+        if (id < numItems) {
+            int32_t meshIndex, materialIndex; float sphere[4];
+            if (prims) {
+                const PrimDraw d = prims[id];
+                meshIndex = d.meshIndex; materialIndex = d.materialIndex; vcount = d.pad[0];
+                sphere[0] = d.sphere[0]; sphere[1] = d.sphere[1]; sphere[2] = d.sphere[2]; sphere[3] = d.sphere[3];
+            } else {
+                const incr_gpu_meshlet m = S.meshlets[id];
+                meshIndex = m.meshIndex; materialIndex = m.materialIndex; vcount = m.triangleCount * 3u;
+                sphere[0] = m.boundingSphere[0]; sphere[1] = m.boundingSphere[1]; sphere[2] = m.boundingSphere[2]; sphere[3] = m.boundingSphere[3];
+            }
+            if (S.meshVisibility[meshIndex] != 0) {
                 bool inside = true;
                 if (frustumCulling) {
-                    const MeshFrame& f = frames[m.meshIndex];
-                    const f3 c = {m.boundingSphere[0], m.boundingSphere[1], m.boundingSphere[2]};
-                    const float r = m.boundingSphere[3];
+                    const MeshFrame& f = frames[meshIndex];
+                    const f3 c = {sphere[0], sphere[1], sphere[2]};
+                    const float r = sphere[3];
 #pragma unroll
                     for (int p = 0; p < 5; ++p) inside = inside && (dot4p(c, f.planes[p]) + r * f.planeLen[p] >= 0);
                 }
-                if (inside) { cls = S.materials[m.materialIndex].doubleSided ? 2 : 1; vcount = m.triangleCount * 3u; }
+                if (inside) cls = S.materials[materialIndex].doubleSided ? 2 : 1;
                 else cls = 3;
             }
         }
@@ -332,12 +343,83 @@ DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     return true;
 }
 
-// vs_meshlet_main + primitive assembly, clipping, viewport, culling (visibility-pass.hlsl:57-97): one wave per draw command
+// Primitive assembly for one triangle per lane: near-plane clip, viewport snap, facing / culling, 48-byte record, filing by
+// bounding-box size.  MUST be called by all 64 lanes (queue slots are allocated with ballots: one atomic per wave and
+// queue instead of one per triangle -- 930 K same-address atomics cost 9 ms on the Bistro-scale scene).
+DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float4 c0, const float4 c1, const float4 c2,
+                      const float2 uvA, const float2 uvB, const float2 uvC, uint32_t key, int32_t alphaTex, bool cullBack) {
+    const float Wf = (float)P.W, Hf = (float)P.H;
+    const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
+    ClipVert poly[4]; int np = 0;
+    bool in[3]; int nin = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k] ? 1 : 0; }
+    if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+    else if (nin > 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = (k + 1) % 3;
+            if (in[k]) poly[np++] = cv[k];
+            if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
+        }
+    }
+    ScreenVert sv[4] = {}; bool ok = valid && np >= 3;
+    for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], Wf, Hf, &sv[k]);
+    for (int s = 0; s < 2; ++s) {                                // a clipped triangle is a fan of two
+        ScreenVert v0 = sv[0], v1 = sv[s + 1], v2 = sv[s + 2];
+        SubTri st;
+        bool have = ok && (s == 0 || np == 4);
+        if (have) have = orient_subtri(v0, v1, v2, cullBack);
+        if (have) have = setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, &st);
+        const unsigned long long hm = __ballot(have);
+        if (hm == 0ull) continue;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t rbase = 0;
+        const int leader = __ffsll((long long)hm) - 1;
+        if ((int)lane == leader) rbase = atomicAdd(P.vqCounters + 0, (uint32_t)__popcll(hm));
+        rbase = (uint32_t)__shfl((int)rbase, leader, 64);
+        const uint32_t idx = rbase + (uint32_t)__popcll(hm & below);
+        have = have && idx < P.recCap;                           // cannot fail: recCap = 2 x scene triangles
+        const uint32_t bw = have ? (uint32_t)(st.px1 - st.px0 + 1) : 0u, bh = have ? (uint32_t)(st.py1 - st.py0 + 1) : 0u;
+        const bool small = have && bw * bh <= (uint32_t)kBigBoxPixels;
+        const unsigned long long sm = __ballot(small);
+        if (sm != 0ull) {
+            uint32_t sbase = 0;
+            const int sleader = __ffsll((long long)sm) - 1;
+            if ((int)lane == sleader) sbase = atomicAdd(P.vqCounters + 2, (uint32_t)__popcll(sm));
+            sbase = (uint32_t)__shfl((int)sbase, sleader, 64);
+            if (small) P.smallQueue[sbase + (uint32_t)__popcll(sm & below)] = idx;
+        }
+        if (!have) continue;
+        SubTriRec r;
+        r.X0 = v0.X; r.Y0 = v0.Y; r.X1 = v1.X; r.Y1 = v1.Y; r.X2 = v2.X; r.Y2 = v2.Y; r.z0 = v0.z; r.z1 = v1.z; r.z2 = v2.z;
+        r.key = key; r.alphaTex = alphaTex; r.pad = 0;
+        P.recs[idx] = r;
+        if (alphaTex >= 0) {
+            SubTriAlpha al;
+            al.p[0] = c0.x; al.p[1] = c0.y; al.p[2] = c0.z; al.p[3] = c0.w; al.p[4] = c1.x; al.p[5] = c1.y; al.p[6] = c1.z; al.p[7] = c1.w;
+            al.p[8] = c2.x; al.p[9] = c2.y; al.p[10] = c2.z; al.p[11] = c2.w;
+            al.uv[0] = uvA.x; al.uv[1] = uvA.y; al.uv[2] = uvB.x; al.uv[3] = uvB.y; al.uv[4] = uvC.x; al.uv[5] = uvC.y; al.pad[0] = al.pad[1] = 0.f;
+            P.alphas[idx] = al;
+        }
+        if (small) continue;
+        const uint32_t tw = (bw + 7u) >> 3, th = (bh + 7u) >> 3;
+        const uint32_t rowsPerItem = max(1u, 64u / tw), nItems = (th + rowsPerItem - 1u) / rowsPerItem;
+        const uint32_t base = atomicAdd(P.vqCounters + 1, nItems);
+        if (base + nItems <= P.bigCap) {
+            for (uint32_t i = 0; i < nItems; ++i) P.bigQueue[base + i] = make_uint2(idx, ((i * rowsPerItem) << 16) | min(rowsPerItem, th - i * rowsPerItem));
+        } else {                                                 // band queue full: neutralise the reserved slots, scan the triangle whole
+            for (uint32_t i = base; i < min(base + nItems, P.bigCap); ++i) P.bigQueue[i] = make_uint2(idx, 0u);
+            P.wholeQueue[atomicAdd(P.vqCounters + 3, 1u)] = idx;
+        }
+    }
+}
+
+// vs_meshlet_main + primitive assembly (visibility-pass.hlsl:57-97): one wave per draw command
 __global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisParams P) {
     __shared__ float4 s_clip[kVisWaves][kMaxMeshletVerts];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n0 = P.counts[0], n1 = P.counts[1];
-    const float Wf = (float)P.W, Hf = (float)P.H;
     for (uint32_t job = blockIdx.x * kVisWaves + wave; job < n0 + n1; job += gridDim.x * kVisWaves) {
         const uint32_t list = job >= n0 ? 1u : 0u;
         const incr_draw_cmd cmd = P.lists[list][list ? job - n0 : job];
@@ -357,7 +439,7 @@ __global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisPara
         int32_t alphaTex = mat.baseColorTextureIndex;
         if (alphaTex >= 0 && P.S.textures[alphaTex].pad[0]) alphaTex = -1;      // alpha is 255 everywhere: the clip can never fire
         const uint32_t ntri = cmd.vertex_count / 3u;
-        for (uint32_t t0 = 0; t0 < ntri; t0 += 64) {             // wave-uniform trip count: queue slots are allocated with ballots
+        for (uint32_t t0 = 0; t0 < ntri; t0 += 64) {             // wave-uniform trip count
             const uint32_t tri = t0 + lane;
             const bool valid = tri < ntri;
             const uint32_t packed = valid ? P.S.packedTris[m.triangleBegin + tri] : 0u;
@@ -365,76 +447,50 @@ __global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisPara
 #pragma unroll
             for (uint32_t k = 0; k < 3; ++k) li[k] = min(0xffu & (packed >> ((2u - k) * 10u)), nv - 1u);
             const float4 c0 = s_clip[wave][li[0]], c1 = s_clip[wave][li[1]], c2 = s_clip[wave][li[2]];
-            const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
-            ClipVert poly[4]; int np = 0;
-            bool in[3]; int nin = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k] ? 1 : 0; }
-            if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
-            else if (nin > 0) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int j = (k + 1) % 3;
-                    if (in[k]) poly[np++] = cv[k];
-                    if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
-                }
-            }
-            ScreenVert sv[4] = {}; bool ok = valid && np >= 3;
-            for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], Wf, Hf, &sv[k]);
-            for (int s = 0; s < 2; ++s) {                        // a clipped triangle is a fan of two
-                ScreenVert v0 = sv[0], v1 = sv[s + 1], v2 = sv[s + 2];
-                SubTri st;
-                bool have = ok && (s == 0 || np == 4);
-                if (have) have = orient_subtri(v0, v1, v2, list == 0);
-                if (have) have = setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, &st);
-                // one atomic per wave and queue instead of one per triangle (930 K same-address atomics cost 9 ms on the
-                // Bistro-scale scene): the lowest lane reserves popcount slots, the others take theirs by rank
-                const unsigned long long hm = __ballot(have);
-                if (hm == 0ull) continue;
-                const unsigned long long below = (1ull << lane) - 1ull;
-                uint32_t rbase = 0;
-                const int leader = __ffsll((long long)hm) - 1;
-                if ((int)lane == leader) rbase = atomicAdd(P.vqCounters + 0, (uint32_t)__popcll(hm));
-                rbase = (uint32_t)__shfl((int)rbase, leader, 64);
-                const uint32_t idx = rbase + (uint32_t)__popcll(hm & below);
-                have = have && idx < P.recCap;                   // cannot fail: recCap = 2 x scene triangles
-                const uint32_t bw = have ? (uint32_t)(st.px1 - st.px0 + 1) : 0u, bh = have ? (uint32_t)(st.py1 - st.py0 + 1) : 0u;
-                const bool small = have && bw * bh <= (uint32_t)kBigBoxPixels;
-                const unsigned long long sm = __ballot(small);
-                if (sm != 0ull) {
-                    uint32_t sbase = 0;
-                    const int sleader = __ffsll((long long)sm) - 1;
-                    if ((int)lane == sleader) sbase = atomicAdd(P.vqCounters + 2, (uint32_t)__popcll(sm));
-                    sbase = (uint32_t)__shfl((int)sbase, sleader, 64);
-                    if (small) P.smallQueue[sbase + (uint32_t)__popcll(sm & below)] = idx;
-                }
-                if (!have) continue;
-                SubTriRec r;
-                r.X0 = v0.X; r.Y0 = v0.Y; r.X1 = v1.X; r.Y1 = v1.Y; r.X2 = v2.X; r.Y2 = v2.Y; r.z0 = v0.z; r.z1 = v1.z; r.z2 = v2.z;
-                r.key = (list << 31) | ((cmd.id << 7) | tri); r.alphaTex = alphaTex; r.pad = 0;
-                P.recs[idx] = r;
-                if (alphaTex >= 0) {
-                    const float2 a = P.S.mvUv[m.vertexBegin + li[0]], b = P.S.mvUv[m.vertexBegin + li[1]], c = P.S.mvUv[m.vertexBegin + li[2]];
-                    SubTriAlpha al;
-                    al.p[0] = c0.x; al.p[1] = c0.y; al.p[2] = c0.z; al.p[3] = c0.w; al.p[4] = c1.x; al.p[5] = c1.y; al.p[6] = c1.z; al.p[7] = c1.w;
-                    al.p[8] = c2.x; al.p[9] = c2.y; al.p[10] = c2.z; al.p[11] = c2.w;
-                    al.uv[0] = a.x; al.uv[1] = a.y; al.uv[2] = b.x; al.uv[3] = b.y; al.uv[4] = c.x; al.uv[5] = c.y; al.pad[0] = al.pad[1] = 0.f;
-                    P.alphas[idx] = al;
-                }
-                if (small) continue;
-                const uint32_t tw = (bw + 7u) >> 3, th = (bh + 7u) >> 3;
-                const uint32_t rowsPerItem = max(1u, 64u / tw), nItems = (th + rowsPerItem - 1u) / rowsPerItem;
-                const uint32_t base = atomicAdd(P.vqCounters + 1, nItems);
-                if (base + nItems <= P.bigCap) {
-                    for (uint32_t i = 0; i < nItems; ++i) P.bigQueue[base + i] = make_uint2(idx, ((i * rowsPerItem) << 16) | min(rowsPerItem, th - i * rowsPerItem));
-                } else {                                         // band queue full: neutralise the reserved slots, scan the triangle whole
-                    for (uint32_t i = base; i < min(base + nItems, P.bigCap); ++i) P.bigQueue[i] = make_uint2(idx, 0u);
-                    P.wholeQueue[atomicAdd(P.vqCounters + 3, 1u)] = idx;
-                }
-            }
+            float2 uvA = make_float2(0.f, 0.f), uvB = uvA, uvC = uvA;
+            if (alphaTex >= 0) { uvA = P.S.mvUv[m.vertexBegin + li[0]]; uvB = P.S.mvUv[m.vertexBegin + li[1]]; uvC = P.S.mvUv[m.vertexBegin + li[2]]; }
+            emit_triangle(P, lane, valid, c0, c1, c2, uvA, uvB, uvC, (list << 31) | ((cmd.id << 7) | tri), alphaTex, list == 0);
         }
         __builtin_amdgcn_wave_barrier();                         // s_clip[wave] is rewritten by the next job
     }
+}
+
+// vs_primitive_main + primitive assembly (visibility-pass.hlsl:32-55; FConfig::UseMeshlets == false): the draw commands
+// name whole primitives (up to 2^20 triangles), so the work is cut into static 64-triangle chunks, one per wave; a
+// chunk looks up whether its primitive survived culling (primFlags: 0 = not drawn, 1 = default list, 2 = double-sided).
+__global__ __launch_bounds__(256) void vis_setup_prim_kernel(const VisParams P) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const RasterPrims& R = P.prims;
+    for (uint32_t chunk = blockIdx.x * 4 + wave; chunk < R.numChunks; chunk += gridDim.x * 4) {
+        const uint32_t prim = R.chunkPrim[chunk];
+        const uint32_t flag = R.primFlags[prim];
+        if (flag == 0u) continue;                                 // wave-uniform
+        const uint32_t list = flag - 1u;
+        const PrimDraw d = R.draws[prim];
+        const float* __restrict__ l2w = P.S.meshLocalToWorld + (size_t)d.meshIndex * 16;
+        int32_t alphaTex = P.S.materials[d.materialIndex].baseColorTextureIndex;
+        if (alphaTex >= 0 && P.S.textures[alphaTex].pad[0]) alphaTex = -1;
+        const uint32_t tri = R.chunkFirstTri[chunk] + lane;
+        const bool valid = tri < d.indexCount / 3u;
+        float4 c[3]; float2 uv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                             // vs_primitive_main:44-50
+            const uint32_t vi = valid ? R.indices[d.indexBegin + tri * 3u + (uint32_t)k] : 0u;
+            const float4 pos = R.pvPos[d.vertexBase + vi];
+            const f4 worldPos = mul_vec4({pos.x, pos.y, pos.z, 1.f}, l2w);
+            const f4 cc = mul_vec4(worldPos, P.viewProj);
+            c[k] = make_float4(cc.x, cc.y, cc.z, cc.w);
+            uv[k] = alphaTex >= 0 ? R.pvUv[d.vertexBase + vi] : make_float2(0.f, 0.f);
+        }
+        emit_triangle(P, lane, valid, c[0], c[1], c[2], uv[0], uv[1], uv[2], (list << 31) | ((prim << 20) | tri), alphaTex, list == 0);
+    }
+}
+// draw lists -> per-primitive flags for the chunked set-up above
+__global__ __launch_bounds__(256) void prim_flags_kernel(const incr_draw_cmd* __restrict__ defList, const incr_draw_cmd* __restrict__ dsList,
+                                                         const uint32_t* __restrict__ counts, uint32_t* __restrict__ flags) {
+    const uint32_t n0 = counts[0], n1 = counts[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += gridDim.x * blockDim.x)
+        flags[i < n0 ? defList[i].id : dsList[i - n0].id] = i < n0 ? 1u : 2u;
 }
 
 // rasteriser + ps_meshlet_main (visibility-pass.hlsl:99-118): persistent waves over the three queues
@@ -492,29 +548,51 @@ __global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
     const size_t i = (size_t)y * P.W + x;
     const uint32_t v = P.vis[i];
     if (v == 0xFFFFF000u) { P.g0[i] = 0; P.g1[i] = 0; P.g2[i] = 0; P.color[i] = 0; return; }
-    const uint32_t meshletId = v >> 7, tri = v & 127u;
-    const incr_gpu_meshlet m = P.S.meshlets[meshletId];
-    const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
-    const MeshFrame& mf = P.frames[m.meshIndex];
+    // DecodeMeshletVisibility / DecodePrimitiveVisibility + Get{Meshlet,Primitive}TriangleData (gbuffer-compute.hlsl:96-156)
+    int32_t meshIndex, materialIndex;
     f4 p[3]; f2 uv[3]; f3 nrm[3]; f3 tan[3]; float tanW0 = 0.f;
+    if (P.usePrims) {
+        const uint32_t primId = v >> 20, tri = v & 0xfffffu;
+        if (primId >= P.prims.numPrims) { P.g0[i] = 0; P.g1[i] = 0; P.g2[i] = 0; P.color[i] = 0; return; }   // not a primitive-path id
+        const PrimDraw d = P.prims.draws[primId];
+        if (tri * 3u + 2u >= d.indexCount) { P.g0[i] = 0; P.g1[i] = 0; P.g2[i] = 0; P.color[i] = 0; return; }
+        meshIndex = d.meshIndex; materialIndex = d.materialIndex;
+        const MeshFrame& mf = P.frames[meshIndex];
 #pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-        const uint32_t vi = m.vertexBegin + (0xffu & (packed >> ((2u - k) * 10u)));
-        const float4 pos = P.S.mvPos[vi];
-        p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, mf.localToClip);
-        const float2 t = P.S.mvUv[vi]; uv[k] = {t.x, t.y};
-        const float4 n = P.S.mvNormal[vi]; nrm[k] = {n.x, n.y, n.z};
-        const float4 tg = P.S.mvTangent[vi]; tan[k] = {tg.x, tg.y, tg.z};
-        if (k == 0) tanW0 = tg.w;
+        for (uint32_t k = 0; k < 3; ++k) {
+            const uint32_t vi = d.vertexBase + P.prims.indices[d.indexBegin + tri * 3u + k];
+            const float4 pos = P.prims.pvPos[vi];
+            p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, mf.localToClip);
+            const float2 t = P.prims.pvUv[vi]; uv[k] = {t.x, t.y};
+            const float4 n = P.prims.pvNormal[vi]; nrm[k] = {n.x, n.y, n.z};
+            const float4 tg = P.prims.pvTangent[vi]; tan[k] = {tg.x, tg.y, tg.z};
+            if (k == 0) tanW0 = tg.w;
+        }
+    } else {
+        const uint32_t meshletId = v >> 7, tri = v & 127u;
+        const incr_gpu_meshlet m = P.S.meshlets[meshletId];
+        meshIndex = m.meshIndex; materialIndex = m.materialIndex;
+        const uint32_t packed = P.S.packedTris[m.triangleBegin + tri];
+        const MeshFrame& mf = P.frames[meshIndex];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+            const uint32_t vi = m.vertexBegin + (0xffu & (packed >> ((2u - k) * 10u)));
+            const float4 pos = P.S.mvPos[vi];
+            p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, mf.localToClip);
+            const float2 t = P.S.mvUv[vi]; uv[k] = {t.x, t.y};
+            const float4 n = P.S.mvNormal[vi]; nrm[k] = {n.x, n.y, n.z};
+            const float4 tg = P.S.mvTangent[vi]; tan[k] = {tg.x, tg.y, tg.z};
+            if (k == 0) tanW0 = tg.w;
+        }
     }
     const f3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
     f3 N = normalize(interp3(nrm[0], nrm[1], nrm[2], lam));
     const f3 T = normalize(interp3(tan[0], tan[1], tan[2], lam));
     const f3 B = normalize(cross(N, T) * tanW0);
     const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
-    const MatProps mi = EvaluateMaterialProperties(P.S.materials[m.materialIndex], P.S.textures, P.S.srgbLut, UV);
+    const MatProps mi = EvaluateMaterialProperties(P.S.materials[materialIndex], P.S.textures, P.S.srgbLut, UV);
     if (mi.bHasNormalmap) {
-        const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)m.meshIndex * 16;
+        const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)meshIndex * 16;
         const f3 l0 = {L[0], L[1], L[2]}, l1 = {L[4], L[5], L[6]}, l2 = {L[8], L[9], L[10]};
         const f3 r0 = mul_vec3_m3(T, l0, l1, l2), r1 = mul_vec3_m3(B, l0, l1, l2), r2 = mul_vec3_m3(N, l0, l1, l2);
         N = normalize(mul_vec3_m3(mi.normalmap, r0, r1, r2));
@@ -763,8 +841,8 @@ extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFr
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_batch_cull(const RasterScene* S, const MeshFrame* frames, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
-                                             uint32_t* counts, incr_render_stats* stats, hipStream_t stream) {
-    hipLaunchKernelGGL(batch_cull_kernel, dim3(1), dim3(1024), 0, stream, *S, frames, frustumCulling, defList, dsList, counts, stats);
+                                             uint32_t* counts, incr_render_stats* stats, const PrimDraw* prims, uint32_t numPrims, hipStream_t stream) {
+    hipLaunchKernelGGL(batch_cull_kernel, dim3(1), dim3(1024), 0, stream, *S, frames, frustumCulling, defList, dsList, counts, stats, prims, numPrims);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_light_cull(const LightCullParams* p, hipStream_t stream) {
@@ -781,7 +859,14 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
     if ((e = hipMemsetAsync(p->vqCounters, 0, 64, stream)) != hipSuccess) return e;
     if (maxJobs) {
         const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
-        hipLaunchKernelGGL(vis_setup_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
+        if (p->prims.draws) {            // primitive path: draw lists -> flags, then one wave per 64-triangle chunk
+            if ((e = hipMemsetAsync(p->prims.primFlags, 0, (size_t)p->prims.numPrims * 4, stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(prim_flags_kernel, dim3(std::max(1u, std::min((p->prims.numPrims + 255u) / 256u, 256u))), dim3(256), 0, stream,
+                               p->lists[0], p->lists[1], p->counts, p->prims.primFlags);
+            hipLaunchKernelGGL(vis_setup_prim_kernel, dim3(blocks), dim3(256), 0, stream, *p);
+        } else {
+            hipLaunchKernelGGL(vis_setup_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(vis_scan_kernel, dim3((uint32_t)numCUs * 8u), dim3(256), 0, stream, *p);
         if ((e = hipGetLastError()) != hipSuccess) return e;

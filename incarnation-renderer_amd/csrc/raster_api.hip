@@ -13,7 +13,7 @@ using namespace incr;
 
 extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFrame* vf, MeshFrame* out, hipStream_t stream);
 extern "C" hipError_t incr_launch_batch_cull(const RasterScene* S, const MeshFrame* frames, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
-                                             uint32_t* counts, incr_render_stats* stats, hipStream_t stream);
+                                             uint32_t* counts, incr_render_stats* stats, const PrimDraw* prims, uint32_t numPrims, hipStream_t stream);
 extern "C" hipError_t incr_launch_light_cull(const LightCullParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJobs, int numCUs, uint32_t* vis, float* depth, hipStream_t stream);
 extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t stream);
@@ -94,10 +94,55 @@ int incr_raster_scene_upload(incr_scene* sc) {
     if (!rc) rc = upload_vec(&sc->dMvUv, uv.data(), nv);
     if (!rc) rc = upload_vec(&sc->dMvNormal, nrm.data(), nv);
     if (!rc) rc = upload_vec(&sc->dMvTangent, tan.data(), nv);
+    if (rc) return rc;
+
+    // ---- primitive (non-meshlet) path: per primitive, the index list widened to 32 bit (MeshMaterial::GetUint,
+    // mesh-material.hlsli:5-43: 2- or 4-byte indices) and the attributes of vertices 0 .. max index ----
+    std::vector<PrimDraw> draws(h.primitives.size());
+    std::vector<uint32_t> indices, chunkPrim, chunkFirstTri;
+    std::vector<float4> ppos, pnrm, ptan; std::vector<float2> puv;
+    for (size_t pi = 0; pi < h.primitives.size(); ++pi) {
+        const incr_gpu_primitive& pr = h.primitives[pi];
+        PrimDraw& d = draws[pi];
+        memset(&d, 0, sizeof d);
+        d.indexBegin = (uint32_t)indices.size(); d.indexCount = pr.indexCount > 0 ? (uint32_t)pr.indexCount / 3u * 3u : 0u;
+        d.vertexBase = (uint32_t)ppos.size(); d.meshIndex = pr.meshIndex; d.materialIndex = pr.materialIndex;
+        memcpy(d.sphere, pr.boundingSphere, 16);
+        d.pad[0] = pr.indexCount > 0 ? (uint32_t)pr.indexCount : 0u;     // the draw's vertexCount, batch-culling.hlsl:87
+        uint32_t stride = 0; size_t avail = 0;
+        const uint8_t* ib = accessor_base(h, pr.indexAccessor, &stride, &avail);
+        uint32_t maxIndex = 0;
+        for (uint32_t i = 0; i < d.indexCount; ++i) {
+            uint32_t v = 0;
+            if (ib && stride == 2 && (size_t)i * 2 + 2 <= avail) { uint16_t t; memcpy(&t, ib + (size_t)i * 2, 2); v = t; }
+            else if (ib && stride == 4 && (size_t)i * 4 + 4 <= avail) memcpy(&v, ib + (size_t)i * 4, 4);
+            indices.push_back(v); maxIndex = std::max(maxIndex, v);
+        }
+        if (d.indexCount / 3u > (1u << 20)) return fail(INCR_ERR_INVALID_ARGUMENT, "primitive %zu has more than 2^20 triangles: does not fit the visibility encoding", pi);
+        const uint32_t nverts = d.indexCount ? maxIndex + 1u : 0u;
+        for (uint32_t v = 0; v < nverts; ++v) {
+            float f[4];
+            fetch(h, pr.positionAccessor, v, 3, f); ppos.push_back(make_float4(f[0], f[1], f[2], 0.f));
+            fetch(h, pr.uvAccessor, v, 2, f); puv.push_back(make_float2(f[0], f[1]));
+            fetch(h, pr.normalAccessor, v, 3, f); pnrm.push_back(make_float4(f[0], f[1], f[2], 0.f));
+            fetch(h, pr.tangentAccessor, v, 4, f); ptan.push_back(make_float4(f[0], f[1], f[2], f[3]));
+        }
+        for (uint32_t t = 0; t < d.indexCount / 3u; t += 64) { chunkPrim.push_back((uint32_t)pi); chunkFirstTri.push_back(t); }
+    }
+    sc->numPrimChunks = (uint32_t)chunkPrim.size();
+    rc = upload_vec(&sc->dPrimDraws, draws.data(), draws.size());
+    if (!rc) rc = upload_vec(&sc->dPrimIndices, indices.data(), indices.size());
+    if (!rc) rc = upload_vec(&sc->dPvPos, ppos.data(), ppos.size());
+    if (!rc) rc = upload_vec(&sc->dPvUv, puv.data(), puv.size());
+    if (!rc) rc = upload_vec(&sc->dPvNormal, pnrm.data(), pnrm.size());
+    if (!rc) rc = upload_vec(&sc->dPvTangent, ptan.data(), ptan.size());
+    if (!rc) rc = upload_vec(&sc->dChunkPrim, chunkPrim.data(), chunkPrim.size());
+    if (!rc) rc = upload_vec(&sc->dChunkFirstTri, chunkFirstTri.data(), chunkFirstTri.size());
     return rc;
 }
 void incr_raster_scene_free(incr_scene* sc) {
-    void* ptrs[] = {sc->dMeshlets, sc->dPackedTris, sc->dMeshVisibility, sc->dMvPos, sc->dMvUv, sc->dMvNormal, sc->dMvTangent};
+    void* ptrs[] = {sc->dMeshlets, sc->dPackedTris, sc->dMeshVisibility, sc->dMvPos, sc->dMvUv, sc->dMvNormal, sc->dMvTangent,
+                    sc->dPrimDraws, sc->dPrimIndices, sc->dPvPos, sc->dPvUv, sc->dPvNormal, sc->dPvTangent, sc->dChunkPrim, sc->dChunkFirstTri};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -111,6 +156,17 @@ void fill_raster_scene(const incr_context* ctx, const incr_scene* sc, RasterScen
     S.meshLocalToWorld = sc->dMeshLocalToWorld; S.materials = sc->dMaterials; S.textures = sc->dTextures; S.srgbLut = ctx->srgbLut;
     S.numMeshlets = (uint32_t)sc->host.meshlets.size(); S.numMeshes = (uint32_t)sc->host.meshTransforms.size();
 }
+// FConfig::UseMeshlets == false.  The order key of the visibility pass keeps bit 31 for the draw list, so the primitive
+// id has 11 bits there (EncodePrimitiveVisibility itself has 12, encoding.hlsli:8-11).
+int fill_raster_prims(const incr_scene* sc, uint32_t* primFlags, RasterPrims& R) {
+    const size_t n = sc->host.primitives.size();
+    if (n >= 2048) return fail(INCR_ERR_INVALID_ARGUMENT, "%zu primitives: the primitive path holds at most 2047 (use meshlets)", n);
+    R.draws = sc->dPrimDraws; R.indices = sc->dPrimIndices;
+    R.pvPos = sc->dPvPos; R.pvUv = sc->dPvUv; R.pvNormal = sc->dPvNormal; R.pvTangent = sc->dPvTangent;
+    R.chunkPrim = sc->dChunkPrim; R.chunkFirstTri = sc->dChunkFirstTri; R.primFlags = primFlags;
+    R.numPrims = (uint32_t)n; R.numChunks = sc->numPrimChunks;
+    return INCR_OK;
+}
 void fill_view_frame(const incr_view_constants& vc, ViewFrame& vf) {
     memcpy(vf.viewProj, vc.view_proj_transform.m, 64); memcpy(vf.cullViewProj, vc.cull_view_proj_transform.m, 64);
     memcpy(vf.invViewProj, vc.inv_view_proj_transform.m, 64); memcpy(vf.invProj, vc.inv_proj_transform.m, 64);
@@ -123,16 +179,18 @@ struct RasterWorkspace {
     MeshFrame* frames; uint32_t* counters; unsigned long long* packed;
     SubTriRec* recs; SubTriAlpha* alphas; uint32_t* smallQueue; uint32_t* wholeQueue; uint2* bigQueue;
     uint32_t recCap, bigCap;
+    uint32_t* primFlags;                   // primitive path: one word per primitive
 };
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws) {
+int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws, size_t prims = 0) {
     size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
     // test hook: a tiny band queue forces the overflow path (large triangles scanned whole by one wave)
     if (const char* cap = pixels ? getenv("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
     const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
-    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig;
+    const size_t szFlags = align256((prims + 1) * 4);
+    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig + szFlags;
     if (recCap > 0xffffffffull || bigCap > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "scene too large for the visibility queues");
     if (ctx->rasterBytes < need || !ctx->rasterBlock) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -148,7 +206,8 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     ws->alphas = (SubTriAlpha*)p; p += szAlpha;
     ws->smallQueue = (uint32_t*)p; p += szSmall;
     ws->wholeQueue = (uint32_t*)p; p += szWhole;
-    ws->bigQueue = (uint2*)p;
+    ws->bigQueue = (uint2*)p; p += szBig;
+    ws->primFlags = (uint32_t*)p;
     ws->recCap = (uint32_t)recCap; ws->bigCap = (uint32_t)bigCap;
     return INCR_OK;
 }
@@ -198,7 +257,8 @@ int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* d, incr_strea
     RasterWorkspace ws;
     if ((rc = ensure_raster_workspace(ctx, 0, S.numMeshes, 0, (hipStream_t)stream, &ws))) return rc;
     HIP_TRY(incr_launch_mesh_frames(&S, &vf, ws.frames, (hipStream_t)stream));
-    HIP_TRY(incr_launch_batch_cull(&S, ws.frames, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, d->render_stats, (hipStream_t)stream));
+    HIP_TRY(incr_launch_batch_cull(&S, ws.frames, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, d->render_stats,
+                                   d->use_primitives ? sc->dPrimDraws : nullptr, (uint32_t)sc->host.primitives.size(), (hipStream_t)stream));
     return INCR_OK;
 }
 
@@ -256,11 +316,14 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
     scissor_rows(*d->view, &P.y0, &P.y1);
     P.lists[0] = d->default_list; P.lists[1] = d->double_sided_list; P.counts = d->counts;
     RasterWorkspace ws;
-    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, sc->host.meshletPackedTriangles.size(), (hipStream_t)stream, &ws))) return rc;
+    size_t tris = sc->host.meshletPackedTriangles.size();
+    if (d->use_primitives) { tris = 0; for (const incr_gpu_primitive& pr : sc->host.primitives) tris += pr.indexCount > 0 ? (size_t)pr.indexCount / 3 : 0; }
+    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size()))) return rc;
+    if (d->use_primitives && (rc = fill_raster_prims(sc, ws.primFlags, P.prims))) return rc;
     P.packed = ws.packed; P.recs = ws.recs; P.alphas = ws.alphas; P.bigQueue = ws.bigQueue; P.smallQueue = ws.smallQueue; P.wholeQueue = ws.wholeQueue;
     P.vqCounters = ws.counters; P.recCap = ws.recCap; P.bigCap = ws.bigCap;
     ctx->rasterCounters = ws.counters;
-    HIP_TRY(incr_launch_visibility(&P, P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
+    HIP_TRY(incr_launch_visibility(&P, d->use_primitives ? P.prims.numChunks : P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
     return INCR_OK;
 }
 
@@ -282,6 +345,7 @@ int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stre
     scissor_rows(*d->view, &P.y0, &P.y1);
     P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao; P.color = d->color_target;
     P.rounding = d->storage_rounding;
+    if (d->use_primitives) { P.usePrims = 1; if ((rc = fill_raster_prims(sc, nullptr, P.prims))) return rc; }
     HIP_TRY(incr_launch_gbuffer(&P, (hipStream_t)stream));
     return INCR_OK;
 }

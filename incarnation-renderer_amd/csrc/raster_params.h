@@ -27,6 +27,19 @@ struct RasterScene {
     uint32_t numMeshlets, numMeshes;
 };
 
+// The primitive (non-meshlet) path, FConfig::UseMeshlets == false: per-primitive index / vertex arrays resolved out of the
+// accessors at scene creation, and a static table that cuts every primitive into 64-triangle chunks.
+struct PrimDraw { uint32_t indexBegin, indexCount, vertexBase; int32_t meshIndex, materialIndex; float sphere[4]; uint32_t pad[3]; };
+static_assert(sizeof(PrimDraw) == 48, "PrimDraw layout");
+struct RasterPrims {
+    const PrimDraw* __restrict__ draws;
+    const uint32_t* __restrict__ indices;     // GetUint(i, indexAccessor) widened to 32 bit
+    const float4* __restrict__ pvPos; const float2* __restrict__ pvUv; const float4* __restrict__ pvNormal; const float4* __restrict__ pvTangent;
+    const uint32_t* __restrict__ chunkPrim; const uint32_t* __restrict__ chunkFirstTri;
+    uint32_t* __restrict__ primFlags;         // per frame: 0 not drawn, 1 default list, 2 double-sided list
+    uint32_t numPrims, numChunks;
+};
+
 // Per-mesh, per-frame constants (mesh_frame_kernel): 176 B.
 struct MeshFrame {
     float localToClip[16];     // mul(localToWorld, viewProj)                   gbuffer-compute.hlsl:196-197
@@ -78,6 +91,7 @@ struct VisParams {
     uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors
     uint32_t recCap, bigCap;
     uint32_t y0, y1;                                 // scissor rows [y0, y1) (incr_view_constants::scissor_y0/y1)
+    RasterPrims prims;                               // primitive path only
 };
 
 struct GBufferParams {
@@ -88,6 +102,7 @@ struct GBufferParams {
     uint32_t* __restrict__ g0; uint32_t* __restrict__ g1; uint32_t* __restrict__ g2; uint32_t* __restrict__ color;
     int32_t rounding;
     uint32_t y0, y1;
+    int32_t usePrims; RasterPrims prims;             // !USING_MESHLETS
 };
 
 struct LightingParams {

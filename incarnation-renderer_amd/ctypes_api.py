@@ -170,7 +170,7 @@ _VC = C.POINTER(ViewConstants)
 
 class BatchCullDesc(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("view", _VC), ("default_list", C.c_void_p), ("double_sided_list", C.c_void_p),
-                ("counts", C.c_void_p), ("render_stats", C.c_void_p), ("frustum_culling", C.c_int32)]
+                ("counts", C.c_void_p), ("render_stats", C.c_void_p), ("frustum_culling", C.c_int32), ("use_primitives", C.c_int32)]
 
 
 class LightCullDesc(C.Structure):
@@ -181,13 +181,13 @@ class LightCullDesc(C.Structure):
 
 class VisibilityDesc(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("view", _VC), ("default_list", C.c_void_p), ("double_sided_list", C.c_void_p),
-                ("counts", C.c_void_p), ("vis_buffer", C.c_void_p), ("depth_buffer", C.c_void_p)]
+                ("counts", C.c_void_p), ("vis_buffer", C.c_void_p), ("depth_buffer", C.c_void_p), ("use_primitives", C.c_int32)]
 
 
 class GBufferDesc(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("view", _VC), ("vis_buffer", C.c_void_p), ("gbuffer_basecolor", C.c_void_p),
                 ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p), ("color_target", C.c_void_p),
-                ("storage_rounding", C.c_int32)]
+                ("storage_rounding", C.c_int32), ("use_primitives", C.c_int32)]
 
 
 class LightingInputs(C.Structure):
@@ -232,7 +232,8 @@ class RendererScene(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("directional_light_index", C.c_int32), ("punctual_light_count", C.c_uint32),
                 ("meshlet_count", C.c_uint32), ("skylight_sh9_rgba", C.c_void_p),
                 ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
-                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32)]
+                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32),
+                ("primitive_count", C.c_uint32)]
 
 
 class RendererConfig(C.Structure):
@@ -241,7 +242,8 @@ class RendererConfig(C.Structure):
                 ("exposure", C.c_float), ("sky_brightness", C.c_float), ("camera_near_plane", C.c_float),
                 ("light_cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32), ("cluster_depth_extent", C.c_float),
                 ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
-                ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32)]
+                ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32),
+                ("use_primitives", C.c_int32)]
 
 
 (SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,

@@ -189,6 +189,8 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
     d = A.BatchCullDesc(); d.scene, d.view = scene_handle, vcp
     d.default_list, d.double_sided_list, d.counts, d.render_stats = surf["default_list"], surf["double_sided_list"], surf["counts"], surf["render_stats"]
     d.frustum_culling = 1 if cfg.FrustumCulling else 0
+    use_prims = 0 if cfg.UseMeshlets else 1          # renderer.cpp:1716-1761: the primitive variants of cull / visibility / gbuffer
+    d.use_primitives = use_prims
     out.append(("batch_cull", d))
     punctual = punctual_light_count(packed_scene)
     sun = directional_light_index(packed_scene)
@@ -202,10 +204,12 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
     d = A.VisibilityDesc(); d.scene, d.view = scene_handle, vcp
     d.default_list, d.double_sided_list, d.counts = surf["default_list"], surf["double_sided_list"], surf["counts"]
     d.vis_buffer, d.depth_buffer = surf["vis"], surf["depth"]
+    d.use_primitives = use_prims
     out.append(("visibility", d))
     d = A.GBufferDesc(); d.scene, d.view = scene_handle, vcp
     d.vis_buffer, d.gbuffer_basecolor, d.gbuffer_normals, d.gbuffer_metallic_roughness_ao = surf["vis"], surf["gbuffer_basecolor"], surf["gbuffer_normals"], surf["gbuffer_mra"]
     d.color_target, d.storage_rounding = surf["color"], storage_rounding
+    d.use_primitives = use_prims
     out.append(("gbuffer", d))
     if cfg.EnableSkyLighting:
         d = A.SkyLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
@@ -254,6 +258,7 @@ def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
     c.max_sample_count, c.camera_aperture, c.camera_focal_length = cfg.MaxSampleCount, cfg.Pathtracing_CameraAperture, cfg.Pathtracing_CameraFocalLength
     c.turbidity, c.env_sky_mode, c.storage_rounding = cfg.Turbidity, cfg.EnvSkyMode, storage_rounding
     c.enable_specular_ibl = int(cfg.EnableSpecularIBL)
+    c.use_primitives = 0 if cfg.UseMeshlets else 1
     return c
 
 
@@ -287,6 +292,7 @@ class HostRenderer:
         s.directional_light_index = directional_light_index(scene.packed)
         s.punctual_light_count = punctual_light_count(scene.packed)
         s.meshlet_count = getattr(scene.packed, "num_meshlets", 0)
+        s.primitive_count = sum(len(p) for p in scene.packed.mesh_primitives)
         s.skylight_sh9_rgba = self.sh9
         if ibl is not None:         # products of the sky / IBL precompute (IblInputs)
             if ibl.sh9:
@@ -336,7 +342,8 @@ class RasterRenderer:
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg
         self.res_x, self.res_y = res_x, res_y
-        self.surf = RasterSurfaces(ctx, res_x, res_y, getattr(scene.packed, "num_meshlets", 0), cfg)
+        draws = max(getattr(scene.packed, "num_meshlets", 0), sum(len(p) for p in scene.packed.mesh_primitives))   # renderer.cpp:1375-1377
+        self.surf = RasterSurfaces(ctx, res_x, res_y, draws, cfg)
         self.prev_view_proj = None
         self.frame_index = 0
         self.have_sh = False

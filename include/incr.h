@@ -233,6 +233,7 @@ typedef struct incr_batch_cull_desc {
     uint32_t* counts;                  /* device, 2 x u32: {default, double-sided}  (batchCountsBuffer)  */
     incr_render_stats* render_stats;   /* device, optional: m_culledObjects is stored                    */
     int32_t  frustum_culling;          /* FConfig::FrustumCulling */
+    int32_t  use_primitives;           /* !FConfig::UseMeshlets: cs_primitive_cull_main, ids are primitive ids, vertex_count = index count */
 } incr_batch_cull_desc;
 int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* desc, incr_stream stream);
 
@@ -270,6 +271,8 @@ typedef struct incr_visibility_desc {
     const uint32_t* counts;            /* device, from incr_batch_cull */
     uint32_t* vis_buffer;              /* device, res_x*res_y R32_UINT */
     float*    depth_buffer;            /* device, res_x*res_y D32_FLOAT */
+    int32_t   use_primitives;          /* !FConfig::UseMeshlets: vs_primitive_main / ps_primitive_main, vis = primitiveId << 20 | triangle
+                                          (at most 2047 primitives: the depth-tie order key keeps one bit for the draw list) */
 } incr_visibility_desc;
 int incr_visibility(incr_context* ctx, const incr_visibility_desc* desc, incr_stream stream);
 /* Introspection for the bench: work-queue counters of the last incr_visibility call (synchronises the device):
@@ -290,6 +293,7 @@ typedef struct incr_gbuffer_desc {
     uint32_t* gbuffer_metallic_roughness_ao; /* device, R8G8B8A8_UNORM */
     uint32_t* color_target;            /* device, R11G11B10_FLOAT */
     int32_t  storage_rounding;         /* as incr_pathtrace_desc::storage_rounding */
+    int32_t  use_primitives;           /* !FConfig::UseMeshlets -> USING_MESHLETS=0 (DecodePrimitiveVisibility, GetPrimitiveTriangleData) */
 } incr_gbuffer_desc;
 int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* desc, incr_stream stream);
 
@@ -410,6 +414,7 @@ typedef struct incr_renderer_scene {       /* what Renderer::Render asks FScene 
     uint32_t envmap_res, envmap_mips;
     const uint32_t* env_brdf;              /* device, Renderer::s_envBRDF (R16G16_FLOAT); NULL = none */
     uint32_t env_brdf_width, env_brdf_height;
+    uint32_t primitive_count;              /* FScene::m_primitiveCount (draw count when !FConfig::UseMeshlets, renderer.cpp:1375-1377) */
 } incr_renderer_scene;
 typedef struct incr_renderer_config {      /* FConfig fields the frame reads (inc/common.h:6-48) */
     int32_t  path_trace, viewmode, enable_taa, frustum_culling, enable_direct_lighting, enable_sky_lighting, enable_diffuse_ibl;
@@ -420,6 +425,7 @@ typedef struct incr_renderer_config {      /* FConfig fields the frame reads (in
     float    camera_aperture, camera_focal_length, turbidity;
     int32_t  env_sky_mode, storage_rounding;
     int32_t  enable_specular_ibl;
+    int32_t  use_primitives;               /* !FConfig::UseMeshlets: primitive variants of culling / visibility / G-buffer */
 } incr_renderer_config;
 enum {
     INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,

@@ -77,10 +77,23 @@ static bool BatchFrustumCull(const float sphere[4], const Mat4& localToWorld, co
         && (dot4p(c, b) + rad * len3(b) >= 0) && (dot4p(c, t) + rad * len3(t) >= 0);
 }
 // cs_meshlet_cull_main :119-193 (lists in ascending meshlet id: one of the orders the atomic append can produce)
+// and cs_primitive_cull_main :53-117 (usePrims)
 static void batch_cull(const Scene& s, const incr_view_constants& vc, int frustumCulling, incr_draw_cmd* defList, incr_draw_cmd* dsList,
-                       uint32_t counts[2], int32_t* culled) {
+                       uint32_t counts[2], int32_t* culled, bool usePrims = false) {
     counts[0] = counts[1] = 0; *culled = 0;
     const Mat4 cvp = to_mat4(vc.cull_view_proj_transform);
+    if (usePrims) {
+        for (uint32_t id = 0; id < s.d.num_primitives; ++id) {
+            const incr_gpu_primitive& pr = s.d.primitives[id];
+            const uint32_t visible = s.d.mesh_visibility ? s.d.mesh_visibility[pr.meshIndex] : 1u;
+            if (!visible) continue;
+            if (!frustumCulling || BatchFrustumCull(pr.boundingSphere, mesh_local_to_world(s, pr.meshIndex), cvp)) {
+                const incr_draw_cmd cmd = {id, pr.indexCount > 0 ? (uint32_t)pr.indexCount : 0u};
+                if (s.d.materials[pr.materialIndex].doubleSided) dsList[counts[1]++] = cmd; else defList[counts[0]++] = cmd;
+            } else ++*culled;
+        }
+        return;
+    }
     for (uint32_t id = 0; id < s.d.num_meshlets; ++id) {
         const incr_gpu_meshlet& m = s.d.meshlets[id];
         const uint32_t visible = s.d.mesh_visibility ? s.d.mesh_visibility[m.meshIndex] : 1u;
@@ -235,8 +248,9 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
 }
 
 // visibility-pass.hlsl vs_meshlet_main + ps_meshlet_main over both draw lists
+// (usePrims: vs_primitive_main :32-55 + ps_primitive_main -- a draw command names a whole primitive, SV_PrimitiveID is the triangle)
 static void visibility_pass(const Scene& s, const incr_view_constants& vc, const incr_draw_cmd* defList, const incr_draw_cmd* dsList,
-                            const uint32_t counts[2], uint32_t* vis, float* depthOut) {
+                            const uint32_t counts[2], uint32_t* vis, float* depthOut, bool usePrims = false) {
     RasterTarget rt; rt.W = vc.res_x; rt.H = vc.res_y; rt.packed.assign((size_t)rt.W * rt.H, 0);
     scissor_rows(vc, &rt.y0, &rt.y1);
     const Mat4 viewProj = to_mat4(vc.view_proj_transform);
@@ -244,21 +258,24 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
     for (int list = 0; list < 2; ++list) {
         const incr_draw_cmd* cmds = list ? dsList : defList;
         for (uint32_t c = 0; c < counts[list]; ++c) {
-            const uint32_t meshletId = cmds[c].id;
-            const incr_gpu_meshlet& m = s.d.meshlets[meshletId];
-            const Mat4 localToWorld = mesh_local_to_world(s, m.meshIndex);
-            const incr_material& mat = s.d.materials[m.materialIndex];
+            const uint32_t objectId = cmds[c].id;                 // meshlet id, or primitive id
+            const incr_gpu_meshlet* m = usePrims ? nullptr : &s.d.meshlets[objectId];
+            const incr_gpu_primitive* pr = usePrims ? &s.d.primitives[objectId] : nullptr;
+            const Mat4 localToWorld = mesh_local_to_world(s, usePrims ? pr->meshIndex : m->meshIndex);
+            const incr_material& mat = s.d.materials[usePrims ? pr->materialIndex : m->materialIndex];
+            const int posAcc = usePrims ? pr->positionAccessor : m->positionAccessor, uvAcc = usePrims ? pr->uvAccessor : m->uvAccessor;
             for (uint32_t tri = 0; tri < cmds[c].vertex_count / 3u; ++tri) {
-                uint32_t vi[3]; meshlet_tri_verts(s, m, tri, vi);
+                uint32_t vi[3];
+                if (usePrims) GetUint3(s, (int)(tri * 3u), pr->indexAccessor, vi); else meshlet_tri_verts(s, *m, tri, vi);
                 ClipVert cv[3]; float4 p[3]; float2 uv[3];
                 for (int k = 0; k < 3; ++k) {
-                    const float3 pos = GetFloat3(s, (int)vi[k], m.positionAccessor);
+                    const float3 pos = GetFloat3(s, (int)vi[k], posAcc);
                     const float4 worldPos = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToWorld);
                     p[k] = mul_vec4(worldPos, viewProj);
                     cv[k] = {p[k].x, p[k].y, p[k].z, p[k].w};
-                    uv[k] = GetFloat2(s, (int)vi[k], m.uvAccessor);
+                    uv[k] = GetFloat2(s, (int)vi[k], uvAcc);
                 }
-                const uint32_t key = ((uint32_t)list << 31) | ((meshletId << 7) | tri);
+                const uint32_t key = ((uint32_t)list << 31) | (usePrims ? ((objectId << 20) | tri) : ((objectId << 7) | tri));
                 // near-plane clip (z <= w)
                 bool in[3]; int nin = 0;
                 for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
@@ -307,8 +324,9 @@ static inline float3 mul_vec3_m3(float3 v, const float r0[3], const float r1[3],
     return {(v.x * r0[0] + v.y * r1[0]) + v.z * r2[0], (v.x * r0[1] + v.y * r1[1]) + v.z * r2[1], (v.x * r0[2] + v.y * r1[2]) + v.z * r2[2]};
 }
 // gbuffer-compute.hlsl:157-253 cs_main (USING_MESHLETS = 1)
+// usePrims: USING_MESHLETS = 0 (DecodePrimitiveVisibility + GetPrimitiveTriangleData :96-121)
 static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const uint32_t* vis, uint32_t* g0, uint32_t* g1, uint32_t* g2,
-                         uint32_t* color, int rounding) {
+                         uint32_t* color, int rounding, bool usePrims = false) {
     const uint32_t W = vc.res_x, H = vc.res_y;
     const Mat4 viewProj = to_mat4(vc.view_proj_transform);
     uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
@@ -317,25 +335,36 @@ static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const ui
         color[i] = 0;                                              // gbuffer-compute-pass.inl:94-100 clear
         const uint32_t v = vis[i];
         if (v == 0xFFFFF000u) { g0[i] = 0; g1[i] = 0; g2[i] = 0; continue; }
-        const uint32_t meshletId = v >> 7, tri = v & 127u;
-        const incr_gpu_meshlet& m = s.d.meshlets[meshletId];
-        uint32_t vi[3]; meshlet_tri_verts(s, m, tri, vi);
-        const Mat4 localToWorld = mesh_local_to_world(s, m.meshIndex);
+        uint32_t vi[3]; int meshIndex, materialIndex, posAcc, uvAcc, nrmAcc, tanAcc;
+        if (usePrims) {
+            const uint32_t primId = v >> 20, tri = v & 0xfffffu;
+            const incr_gpu_primitive& pr = s.d.primitives[primId];
+            GetUint3(s, (int)(tri * 3u), pr.indexAccessor, vi);
+            meshIndex = pr.meshIndex; materialIndex = pr.materialIndex;
+            posAcc = pr.positionAccessor; uvAcc = pr.uvAccessor; nrmAcc = pr.normalAccessor; tanAcc = pr.tangentAccessor;
+        } else {
+            const uint32_t meshletId = v >> 7, tri = v & 127u;
+            const incr_gpu_meshlet& m = s.d.meshlets[meshletId];
+            meshlet_tri_verts(s, m, tri, vi);
+            meshIndex = m.meshIndex; materialIndex = m.materialIndex;
+            posAcc = m.positionAccessor; uvAcc = m.uvAccessor; nrmAcc = m.normalAccessor; tanAcc = m.tangentAccessor;
+        }
+        const Mat4 localToWorld = mesh_local_to_world(s, meshIndex);
         const Mat4 localToClip = mat_mul(localToWorld, viewProj);
         float4 p[3]; float2 uv[3]; float3 nrm[3]; float4 tan[3];
         for (int k = 0; k < 3; ++k) {
-            const float3 pos = GetFloat3(s, (int)vi[k], m.positionAccessor);
+            const float3 pos = GetFloat3(s, (int)vi[k], posAcc);
             p[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToClip);
-            uv[k] = GetFloat2(s, (int)vi[k], m.uvAccessor);
-            nrm[k] = GetFloat3(s, (int)vi[k], m.normalAccessor);
-            tan[k] = GetFloat4(s, (int)vi[k], m.tangentAccessor);
+            uv[k] = GetFloat2(s, (int)vi[k], uvAcc);
+            nrm[k] = GetFloat3(s, (int)vi[k], nrmAcc);
+            tan[k] = GetFloat4(s, (int)vi[k], tanAcc);
         }
         const float3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc(x, y, (float)W, (float)H));
         float3 N = normalize(interp3(nrm[0], nrm[1], nrm[2], lam));
         const float3 T = normalize(interp3({tan[0].x, tan[0].y, tan[0].z}, {tan[1].x, tan[1].y, tan[1].z}, {tan[2].x, tan[2].y, tan[2].z}, lam));
         const float3 B = normalize(cross(N, T) * tan[0].w);
         const float2 UV = interp2(uv[0], uv[1], uv[2], lam);
-        const MatProps mi = EvaluateMaterialProperties(s, s.d.materials[m.materialIndex], UV);
+        const MatProps mi = EvaluateMaterialProperties(s, s.d.materials[materialIndex], UV);
         if (mi.bHasNormalmap) {
             // tangentToWorld = mul(float3x3(T, B, N), (float3x3)localToWorld); N = normalize(mul(normalmap, tangentToWorld))
             const float* L = localToWorld.m;
@@ -598,17 +627,17 @@ void orc_pixel_jitter(uint32_t frameIndex, uint32_t resX, uint32_t resY, float o
 void orc_view_constants(const incr_view* view, const incr_view* cull, const float jitter[2], const incr_matrix* prev, float nearPlane,
                         uint32_t resX, uint32_t resY, incr_view_constants* out) { make_view_constants(view, cull, jitter, prev, nearPlane, resX, resY, out); }
 void orc_batch_cull(void* scene, const incr_batch_cull_desc* d, int32_t* culled) {
-    batch_cull(*(Scene*)scene, *d->view, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, culled);
+    batch_cull(*(Scene*)scene, *d->view, d->frustum_culling, d->default_list, d->double_sided_list, d->counts, culled, d->use_primitives != 0);
 }
 void orc_light_cull(void* scene, const incr_light_cull_desc* d, int32_t* culled) {
     light_cull(*(Scene*)scene, *d->view, d->cluster_dim, d->max_lights_per_cluster, d->cluster_depth_extent, d->culled_light_lists, d->light_grid,
                d->culled_light_count, culled);
 }
 void orc_visibility(void* scene, const incr_visibility_desc* d) {
-    visibility_pass(*(Scene*)scene, *d->view, d->default_list, d->double_sided_list, d->counts, d->vis_buffer, d->depth_buffer);
+    visibility_pass(*(Scene*)scene, *d->view, d->default_list, d->double_sided_list, d->counts, d->vis_buffer, d->depth_buffer, d->use_primitives != 0);
 }
 void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
-    gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding);
+    gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding, d->use_primitives != 0);
 }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {
     sky_lighting(*(Scene*)scene, *d);

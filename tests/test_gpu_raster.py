@@ -119,6 +119,52 @@ def test_raster_options_and_edges(rt, R, ob, A, sio, gpu_ctx, sponza_small, synt
         gscene.close()
 
 
+@pytest.mark.parametrize("which,W,H", [("helmet", 200, 200), ("sponza_small", 320, 180)])
+def test_raster_primitive_path_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, H):
+    """FConfig::UseMeshlets == false (cs_primitive_cull_main, vs/ps_primitive_main, GetPrimitiveTriangleData): bit-exact
+    against the oracle's primitive variants, through the pass-by-pass path and through the C++ host renderer; a row band of
+    the primitive path equals the same rows of the full frame."""
+    class Prims(A.FConfig):
+        UseMeshlets = False
+    scene = request.getfixturevalue(which)
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    osc = ob.OracleScene(scene)
+    try:
+        g = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, Prims, frames=2)
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Prims, sh9_rgb=DEFAULT_SH9)
+        band = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Prims, sh9_rgb=DEFAULT_SH9)
+        y0, y1 = H // 3, 2 * H // 3
+        band.set_band(y0, y1)
+        prev, hs = None, None
+        for frame, (vc, gs) in enumerate(g):
+            vco, hs = run_oracle_frame(ob, R, A, scene, osc, view, W, H, frame_index=frame, prev=prev, hs=hs, cfg=Prims)
+            prev = R.matrix_to_numpy(vco.unjittered_view_proj)
+            o = hs.arr
+            np.testing.assert_array_equal(gs["counts"], o["counts"])
+            assert o["counts"].sum() + o["render_stats"][0] == sum(len(p) for p in scene.mesh_primitives)
+            for name, n in (("default_list", o["counts"][0]), ("double_sided_list", o["counts"][1])):
+                np.testing.assert_array_equal(gs[name][:n], o[name][:n])
+            np.testing.assert_array_equal(gs["render_stats"], o["render_stats"])
+            np.testing.assert_array_equal(gs["vis"], o["vis"])
+            assert (gs["vis"] != 0xFFFFF000).mean() > 0.3
+            np.testing.assert_array_equal(gs["depth"].view(np.uint32), o["depth"].view(np.uint32))
+            for name in INT_SURFACES[1:]:
+                np.testing.assert_array_equal(gs[name], o[name], err_msg=name)
+            assert colour_close(ob, gs["color"], o["color"], "colour target") > 0.999
+            assert colour_close(ob, gs["taa%d" % (frame & 1)], o["taa%d" % (frame & 1)], "taa") > 0.995
+            hr.render(view); band.render(view); gpu_ctx.synchronize()
+            for which_s, name in ((A.SURFACE_VISIBILITY, "vis"), (A.SURFACE_DEPTH, "depth"), (A.SURFACE_GBUFFER_NORMALS, "gbuffer_normals"),
+                                  (A.SURFACE_HDR_RASTER, "color"), (A.SURFACE_TAA_ACCUMULATION, "taa%d" % (frame & 1))):
+                full = hr.download(which_s)
+                np.testing.assert_array_equal(full, gs[name].view(np.uint32), err_msg="C++ renderer frame %d %s" % (frame, name))
+                if frame == 0:      # later frames need the gathered history (test_row_band_renderers_equal_full_frame)
+                    np.testing.assert_array_equal(band.download(which_s)[y0:y1], full[y0:y1], err_msg="band %s" % name)
+        hr.close(); band.close()
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

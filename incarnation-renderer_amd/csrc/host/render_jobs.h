@@ -35,6 +35,7 @@ struct FConfig {
     bool  FrustumCulling = true;
     bool  EnableTAA = true;
     bool  EnableHBAO = false;
+    bool  UseBentNormals = EnableHBAO;
     bool  UseMeshlets = true;
     bool  FreezeCulling = false;
     int   LightClusterDimX = 16, LightClusterDimY = 9, LightClusterDimZ = 24;
@@ -151,6 +152,15 @@ struct Desc {
     FShaderSurface* sourceVisBuffer; FShaderSurface* colorTarget; FShaderSurface* gbufferTargets[3]; FShaderSurface* depthStencilTarget;
     const FScene* sceneConstantBuffer; FSystemBuffer* viewConstantBuffer;
     uint32_t resX; uint32_t resY; const FScene* scene; FConfig renderConfig;
+};
+Result Execute(Sync* jobSync, const Desc& passDesc);
+}
+namespace HBAO {             // render-jobs/hbao.inl:3-14
+struct Desc {
+    FShaderSurface* aoTarget; FShaderSurface* bentNormalTarget; FShaderSurface* depthStencil; FShaderSurface* gbufferNormals;
+    const FScene* sceneConstantBuffer; FSystemBuffer* viewConstantBuffer;
+    FConfig renderConfig; uint32_t resX; uint32_t resY;
+    FShaderBuffer* rayStatsBuffer = nullptr;        // not in the reference: incr_ray_stats accumulation
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }

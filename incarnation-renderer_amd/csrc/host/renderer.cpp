@@ -131,7 +131,20 @@ Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky
     d.env_brdf = p.envBRDFTex ? (const uint32_t*)p.envBRDFTex->m_devicePtr : nullptr;
     d.env_brdf_width = p.scene->m_envBrdfWidth; d.env_brdf_height = p.scene->m_envBrdfHeight;
     d.specular_ibl = p.renderConfig.EnableSpecularIBL ? 1 : 0;
+    d.bent_normals = (p.renderConfig.EnableHBAO && p.bentNormalsTex) ? (const uint32_t*)p.bentNormalsTex->m_devicePtr : nullptr;
+    d.use_bent_normals = p.renderConfig.UseBentNormals ? 1 : 0;          // sky-lighting.inl:65
     return done(jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
+Result HBAO::Execute(Sync* jobSync, const Desc& p) {                      // hbao.inl:16-105
+    const size_t token = jobSync->GetToken();
+    incr_hbao_desc d = {};
+    d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.depth_buffer = (const float*)p.depthStencil->m_devicePtr; d.gbuffer_normals = (const uint32_t*)p.gbufferNormals->m_devicePtr;
+    d.ao_target = (uint8_t*)p.aoTarget->m_devicePtr; d.bent_normal_target = (uint32_t*)p.bentNormalTarget->m_devicePtr;
+    d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
+    d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_hbao(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
 Result DirectLightingPass::Execute(Sync* jobSync, const Desc& p) {        // direct-lighting.inl:18-112
@@ -205,6 +218,7 @@ struct State {
     // surfaces (renderer.cpp:1364-1520; transient per frame there, persistent here)
     FShaderSurface hdrRasterSceneColor, hdrRaytraceSceneColor, depthBuffer, visBuffer, gbuffer_basecolor, gbuffer_normals, gbuffer_metallicRoughnessAo;
     FShaderSurface pathtraceHistoryBuffer, taaAccumulationBuffer[2], backBuffer;
+    FShaderSurface aoBuffer, bentNormalsBuffer;                // R8_UNORM, R16G16_FLOAT (renderer.cpp:1443-1459)
     FShaderBuffer batchArgsBuffer_Default, batchArgsBuffer_DoubleSided, batchCountsBuffer, culledLightCountBuffer, culledLightListsBuffer, lightGridBuffer;
     FShaderBuffer renderStatsBuffer, rayStatsBuffer;
     std::vector<void*> allocations;
@@ -243,6 +257,8 @@ int Initialize(State& s, incr_context* ctx, incr_stream stream, uint32_t resX, u
         if (!rc) rc = alloc(s, &f.m_devicePtr, (uint64_t)resX * (resY + kBandSlackRows) * 4, true);
     }
     if (!rc) rc = surface(s, s.hdrRaytraceSceneColor, 8, true);
+    if (!rc) rc = surface(s, s.aoBuffer, 1, true);
+    if (!rc) rc = surface(s, s.bentNormalsBuffer, 4, true);
     const uint64_t clusters = (uint64_t)c.LightClusterDimX * c.LightClusterDimY * c.LightClusterDimZ;
     if (!rc) rc = buffer(s, s.batchArgsBuffer_Default, (meshletCount + 1) * sizeof(incr_draw_cmd));
     if (!rc) rc = buffer(s, s.batchArgsBuffer_DoubleSided, (meshletCount + 1) * sizeof(incr_draw_cmd));
@@ -334,13 +350,22 @@ int Render(State& s, const FRenderState& renderState) {
         gbufferComputeDesc.resX = resX; gbufferComputeDesc.resY = resY; gbufferComputeDesc.scene = scene; gbufferComputeDesc.renderConfig = c;
         GBufferComputePass::Execute(jobSync, gbufferComputeDesc);
 
-        // decals (:1784-1798) and HBAO (:1801-1840) are outside this library: AO reads as 1 (the cleared aoBuffer)
+        // decals (:1784-1798) are outside this library
+        if (c.EnableHBAO) {                                                    // :1801-1815; else both targets read as cleared to 1 (:1816-1841)
+            HBAO::Desc hbaoDesc = {};
+            hbaoDesc.aoTarget = &s.aoBuffer; hbaoDesc.bentNormalTarget = &s.bentNormalsBuffer;
+            hbaoDesc.depthStencil = &s.depthBuffer; hbaoDesc.gbufferNormals = &s.gbuffer_normals;
+            hbaoDesc.sceneConstantBuffer = scene; hbaoDesc.viewConstantBuffer = &cbViewConstants;
+            hbaoDesc.renderConfig = c; hbaoDesc.resX = resX; hbaoDesc.resY = resY; hbaoDesc.rayStatsBuffer = &s.rayStatsBuffer;
+            HBAO::Execute(jobSync, hbaoDesc);
+        }
 
         if (c.EnableSkyLighting) {                                             // :1843-1863
             SkyLightingPass::Desc skyLightingDesc = {};
             skyLightingDesc.colorTarget = &s.hdrRasterSceneColor; skyLightingDesc.depthStencilTex = &s.depthBuffer;
             skyLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; skyLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
             skyLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
+            skyLightingDesc.ambientOcclusionTex = &s.aoBuffer; skyLightingDesc.bentNormalsTex = &s.bentNormalsBuffer;
             skyLightingDesc.renderConfig = c; skyLightingDesc.scene = scene; skyLightingDesc.view = &renderState.m_view; skyLightingDesc.jitter = pixelJitter;
             skyLightingDesc.resX = resX; skyLightingDesc.resY = resY; skyLightingDesc.viewConstantBuffer = &cbViewConstants;
             skyLightingDesc.envBRDFTex = scene->m_envBRDF.m_devicePtr ? const_cast<FTexture*>(&scene->m_envBRDF) : nullptr;   // s_envBRDF.get()
@@ -472,6 +497,7 @@ int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
     f.Turbidity = c->turbidity; f.EnvSkyMode = c->env_sky_mode; f.StorageRounding = c->storage_rounding;
     f.EnableSpecularIBL = c->enable_specular_ibl != 0;
     f.UseMeshlets = c->use_primitives == 0;
+    f.EnableHBAO = c->enable_hbao != 0; f.UseBentNormals = c->use_bent_normals != 0;
     return INCR_OK;
 }
 
@@ -517,6 +543,8 @@ void* incr_renderer_surface(incr_renderer* r, int which) {
     case INCR_SURFACE_RENDER_STATS: return s.renderStatsBuffer.m_devicePtr;
     case INCR_SURFACE_RAY_STATS: return s.rayStatsBuffer.m_devicePtr;
     case INCR_SURFACE_BATCH_COUNTS: return s.batchCountsBuffer.m_devicePtr;
+    case INCR_SURFACE_AMBIENT_OCCLUSION: return s.aoBuffer.m_devicePtr;
+    case INCR_SURFACE_BENT_NORMALS: return s.bentNormalsBuffer.m_devicePtr;
     default: return nullptr;
     }
 }

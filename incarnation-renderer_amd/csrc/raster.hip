@@ -664,7 +664,12 @@ __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
     f3 radiance = {0.f, 0.f, 0.f};
     if (P.diffuseIbl && P.sh9) {
         const f3 albedo = (1.f - g.metallic) * g.basecolor;
-        const f3 shDiffuse = ((albedo * K_INV_PI) * ShIrradiance(g.N, P.sh9)) * 5.f;
+        f3 samplingNormal = g.N;
+        if (P.useBent) {                                                         // USE_BENT_NORMALS, sky-lighting.hlsl:88-92
+            const uint32_t b = P.bent ? P.bent[i] : 0x3c003c00u;                 // HBAO off: cleared to (1, 1)
+            samplingNormal = OctDecode({f16_bits_to_f32(b & 0xffffu), f16_bits_to_f32(b >> 16)});
+        }
+        const f3 shDiffuse = ((albedo * K_INV_PI) * ShIrradiance(samplingNormal, P.sh9)) * 5.f;
         const f3 occluded = g.ao * shDiffuse;
         radiance = radiance + P.skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));
     }
@@ -719,6 +724,105 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
             if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
         }
         add_color(P.L, i, radiance);
+    }
+    if (P.S.stats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.S.stats->light_shadow_rays, (unsigned long long)rays);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- HBAO
+// shaders/postprocess/hbao.hlsl.  cos / sin / acos are fixed polynomial evaluations (HLSL leaves their
+// precision open): Cody-Waite reduction by pi/2 + Taylor polynomials on [-pi/4, pi/4], the arcsine series with the
+// half-angle identity, rsqrt(x) = 1 / sqrt(x) -- operation for operation what the CPU oracle evaluates.
+DI void hb_reduce(float x, float& r, int& q) {
+    const float kf = floorf(x * 0.636619747f + 0.5f);
+    r = (x - kf * 1.5707963705062866f) - kf * -4.3711388286737929e-08f;
+    q = (kf == kf) ? ((int)kf & 3) : 0;
+}
+DI float hb_sin_poly(float r) {
+    const float z = r * r;
+    return r + (r * z) * (-0.166666672f + z * (0.00833333377f + z * (-0.000198412701f + z * 2.75573188e-06f)));
+}
+DI float hb_cos_poly(float r) {
+    const float z = r * r;
+    return 1.f + z * (-0.5f + z * (0.0416666679f + z * (-0.00138888892f + z * (2.48015876e-05f + z * -2.755732e-07f))));
+}
+DI void hb_sincos(float x, float& s, float& c) {
+    float r; int q; hb_reduce(x, r, q);
+    const float sp = hb_sin_poly(r), cp = hb_cos_poly(r);
+    s = (q & 1) ? cp : sp; if (q & 2) s = -s;
+    c = (q & 1) ? sp : cp; if ((q + 1) & 2) c = -c;
+}
+DI float hb_asin_half(float x) {
+    const float z = x * x;
+    const float p = 0.166666672f + z * (0.075000003f + z * (0.0446428582f + z * (0.030381944f + z * (0.0223721582f + z * (0.0173527636f
+                  + z * (0.0139648439f + z * (0.0115518011f + z * (0.00976160914f + z * (0.00839033537f + z * 0.007312526f)))))))));
+    return x + (x * z) * p;
+}
+DI float hb_acos(float x) {
+    if (!(fabsf(x) > 0.5f)) return 1.5707963705062866f - (hb_asin_half(x) - -4.3711388286737929e-08f);
+    if (x > 0.f) return 2.f * hb_asin_half(sqrtf((1.f - x) * 0.5f));
+    return 3.1415927410125732f - (2.f * hb_asin_half(sqrtf((1.f + x) * 0.5f)) - -8.7422776573475858e-08f);
+}
+DI uint32_t hb_f16(float v, int rounding) { return v != v ? 0x7fffu : f32_to_f16_bits(v, rounding); }
+
+static constexpr float kHbaoPi = 3.14159265358979323846f;
+// ComputeHorizonAngle (hbao.hlsl:66-93): binary search of the horizon, at most 4 ray queries (TMin 0.1, TMax 1)
+DI float hbao_horizon(const PtParams& S, LaneStack& st, float start, f3 pos, f3 sliceX, f3 sliceY, bool finitePos, uint32_t& rays) {
+    const float terminate = kHbaoPi / 36.f;
+    float lo = 0.f, hi = start;
+    for (int k = 0; k < 4 && (hi - lo) > terminate; ++k) {
+        const float a = lo + 0.5f * (hi - lo);
+        float sa, ca; hb_sincos(a, sa, ca);
+        const f3 dir = ca * sliceY + sa * sliceX;
+        ++rays;
+        const bool finite = finitePos && isfinite(dir.x) && isfinite(dir.y) && isfinite(dir.z);
+        if (finite && trace_any(S, st, pos, dir, 0.1f, 1.f)) hi = a; else lo = a;
+    }
+    return hi;
+}
+__global__ __launch_bounds__(kBlock) void hbao_kernel(const HbaoParams P) {            // cs_main, hbao.hlsl:109-175
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = P.y0 + blockIdx.y * 4 + (tid >> 6);
+    uint32_t rays = 0;
+    if (x < P.W && y < P.y1) {
+        LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
+        const size_t i = (size_t)y * P.W + x;
+        const f2 ndc = pixel_ndc(x, y, (float)P.W, (float)P.H);
+        const f4 wp = mul_vec4({ndc.x, ndc.y, P.depth[i], 1.f}, P.invViewProj);
+        const f3 pos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+        const bool finitePos = isfinite(pos.x) && isfinite(pos.y) && isfinite(pos.z);
+        const f3 eye = {P.eye[0], P.eye[1], P.eye[2]}, camUp = {P.camUp[0], P.camUp[1], P.camUp[2]};
+        const f3 localAt = normalize(eye - pos);
+        const f3 localRight = normalize(cross(localAt, camUp));
+        const f3 localUp = cross(localRight, localAt);
+        const uint32_t n = P.normals[i];
+        const f3 N = OctDecode({f16_bits_to_f32(n & 0xffffu), f16_bits_to_f32(n >> 16)});
+        float azimuth = 0.f, sumAO = 0.f;
+        f3 avgBent = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k) {
+            float sa, ca; hb_sincos(azimuth, sa, ca);
+            const f3 sliceT = ca * localRight + sa * localUp;
+            const float pnx = dot(N, sliceT), pny = dot(N, localAt);
+            const float t = -dot(sliceT, N) / dot(localAt, N);
+            const float horizon = hb_acos(t * (1.f / sqrtf(1.f + t * t)));
+            const float theta1 = hbao_horizon(P.S, st, horizon, pos, sliceT, localAt, finitePos, rays);
+            const float theta0 = -hbao_horizon(P.S, st, horizon, pos, -sliceT, localAt, finitePos, rays);
+            float s0, c0, s1, c1; hb_sincos(theta0, s0, c0); hb_sincos(theta1, s1, c1);
+            const float nx = 0.5f * (((theta1 - theta0) + s0 * c0) - s1 * c1);
+            const float ny = 0.5f * ((2.f - c0 * c0) - c1 * c1);
+            sumAO += pnx * nx + pny * ny;
+            avgBent = avgBent + normalize(sliceT * nx + localAt * ny);
+            azimuth += kHbaoPi / 4.f;
+        }
+        const float aoRaw = sumAO / 4.f;
+        const float ao = !(aoRaw > 0.f) ? 0.f : (aoRaw > 1.f ? 1.f : aoRaw);
+        P.ao[i] = (uint8_t)unorm8(ao);
+        const f2 oct = OctEncode(normalize(avgBent));
+        P.bent[i] = hb_f16(oct.x, P.rounding) | (hb_f16(oct.y, P.rounding) << 16);
     }
     if (P.S.stats) {
 #pragma unroll
@@ -887,6 +991,11 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
     hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(hbao_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {

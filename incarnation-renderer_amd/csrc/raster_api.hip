@@ -20,6 +20,7 @@ extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t st
 extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
@@ -365,7 +366,28 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
         P.envBrdf = d->env_brdf; P.envBrdfW = d->env_brdf_width; P.envBrdfH = d->env_brdf_height;
         memcpy(P.skyInvViewProj, d->in.view->sky_inv_view_proj.m, 64);
     }
+    P.bent = d->bent_normals; P.useBent = d->use_bent_normals;
     HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- HBAO
+int incr_hbao(incr_context* ctx, const incr_hbao_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->depth_buffer || !d->gbuffer_normals || !d->ao_target || !d->bent_normal_target) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    HbaoParams P; memset(&P, 0, sizeof P);
+    P.W = d->view->res_x; P.H = d->view->res_y;
+    scissor_rows(*d->view, &P.y0, &P.y1);
+    P.rounding = d->storage_rounding;
+    P.depth = d->depth_buffer; P.normals = d->gbuffer_normals; P.ao = d->ao_target; P.bent = d->bent_normal_target;
+    memcpy(P.invViewProj, d->view->inv_view_proj_transform.m, 64);
+    memcpy(P.eye, d->view->eye_pos, 12); memcpy(P.camUp, d->view->camera_up, 12);
+    incr_fill_scene_params(ctx, d->scene, P.S);
+    P.S.stats = d->ray_stats;
+    HIP_TRY(incr_launch_hbao(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 

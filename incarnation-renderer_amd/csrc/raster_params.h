@@ -120,6 +120,15 @@ struct SkyParams {
     const uint32_t* __restrict__ envmap; uint32_t envmapRes, envmapMips;       // prefiltered cube, all levels (NULL = no specular IBL)
     const uint32_t* __restrict__ envBrdf; uint32_t envBrdfW, envBrdfH;
     float skyInvViewProj[16];                                                  // sky-lighting.inl:124
+    const uint32_t* __restrict__ bent; int32_t useBent;                        // USE_BENT_NORMALS
+};
+
+struct HbaoParams {
+    uint32_t W, H, y0, y1; int32_t rounding;
+    const float* __restrict__ depth; const uint32_t* __restrict__ normals;
+    uint8_t* __restrict__ ao; uint32_t* __restrict__ bent;
+    float invViewProj[16], eye[3], camUp[3];
+    PtParams S;
 };
 
 struct DirectParams { LightingParams L; PtParams S; uint32_t sunIndex; };

@@ -150,7 +150,7 @@ class ViewConstants(C.Structure):
         "cull_view_proj_transform", "prev_view_proj_transform", "lightcull_proj_transform", "lightcull_inv_view_proj",
         "sky_inv_view_proj", "unjittered_view_proj", "taa_inv_view_proj")] + [
         ("eye_pos", c_float3), ("near_plane", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("jitter", C.c_float * 2),
-        ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32)]
+        ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32), ("camera_up", c_float3), ("pad0", C.c_float)]
 
 
 class DrawCmd(C.Structure):
@@ -200,7 +200,13 @@ class SkyLightingDesc(C.Structure):
     _fields_ = [("inp", LightingInputs), ("sh9_rgba", C.c_void_p), ("ambient_occlusion", C.c_void_p),
                 ("sky_brightness", C.c_float), ("diffuse_ibl", C.c_int32),
                 ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
-                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32), ("specular_ibl", C.c_int32)]
+                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32), ("specular_ibl", C.c_int32),
+                ("bent_normals", C.c_void_p), ("use_bent_normals", C.c_int32)]
+
+
+class HbaoDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("depth_buffer", C.c_void_p), ("gbuffer_normals", C.c_void_p),
+                ("ao_target", C.c_void_p), ("bent_normal_target", C.c_void_p), ("ray_stats", C.c_void_p), ("storage_rounding", C.c_int32)]
 
 
 class DirectLightingDesc(C.Structure):
@@ -243,12 +249,12 @@ class RendererConfig(C.Structure):
                 ("light_cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32), ("cluster_depth_extent", C.c_float),
                 ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
                 ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32),
-                ("use_primitives", C.c_int32)]
+                ("use_primitives", C.c_int32), ("enable_hbao", C.c_int32), ("use_bent_normals", C.c_int32)]
 
 
 (SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,
  SURFACE_VISIBILITY, SURFACE_GBUFFER_BASECOLOR, SURFACE_GBUFFER_NORMALS, SURFACE_GBUFFER_MRA, SURFACE_RENDER_STATS, SURFACE_RAY_STATS,
- SURFACE_BATCH_COUNTS) = range(13)
+ SURFACE_BATCH_COUNTS, SURFACE_AMBIENT_OCCLUSION, SURFACE_BENT_NORMALS) = range(15)
 
 
 # FConfig defaults the hot path reads (reference: source/demo-dll/inc/common.h:6-48)
@@ -268,6 +274,7 @@ class FConfig:
     FrustumCulling = True
     EnableTAA = True
     EnableHBAO = False
+    UseBentNormals = False           # inc/common.h:29 `UseBentNormals = EnableHBAO`
     UseMeshlets = True
     LightClusterDimX, LightClusterDimY, LightClusterDimZ = 16, 9, 24
     MaxLightsPerCluster = 64

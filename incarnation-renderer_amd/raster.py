@@ -112,6 +112,8 @@ class RasterSurfaces:
         self.num_meshlets = num_meshlets
         self.ptr["default_list"] = ctx.buffer(max(num_meshlets, 1) * 8)
         self.ptr["double_sided_list"] = ctx.buffer(max(num_meshlets, 1) * 8)
+        self.ptr["ao"] = ctx.buffer(n)                      # R8_UNORM hbao target
+        self.ptr["bent_normals"] = ctx.buffer(n * 4)        # R16G16_FLOAT
         self.ptr["counts"] = ctx.buffer(8)
         self.ptr["render_stats"] = ctx.buffer(8)
         self.ptr["light_lists"] = ctx.buffer(self.clusters * self.max_lights * 4)
@@ -131,8 +133,10 @@ class RasterSurfaces:
         shape2 = (self.res_y, self.res_x)
         if name == "depth":
             return ctx.download(self.ptr[name], shape2, np.float32)
-        if name in self.SPECS:
+        if name in self.SPECS or name == "bent_normals":
             return ctx.download(self.ptr[name], shape2, np.uint32)
+        if name == "ao":
+            return ctx.download(self.ptr[name], shape2, np.uint8)
         if name in ("default_list", "double_sided_list"):
             return ctx.download(self.ptr[name], (max(self.num_meshlets, 1), 2), np.uint32)
         if name == "counts":
@@ -211,10 +215,18 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
     d.color_target, d.storage_rounding = surf["color"], storage_rounding
     d.use_primitives = use_prims
     out.append(("gbuffer", d))
+    if cfg.EnableHBAO:              # renderer.cpp:1801-1815; off = both targets cleared to 1 = NULL inputs of sky lighting
+        d = A.HbaoDesc(); d.scene, d.view = scene_handle, vcp
+        d.depth_buffer, d.gbuffer_normals = surf["depth"], surf["gbuffer_normals"]
+        d.ao_target, d.bent_normal_target, d.ray_stats = surf["ao"], surf["bent_normals"], surf["ray_stats"]
+        d.storage_rounding = storage_rounding
+        out.append(("hbao", d))
     if cfg.EnableSkyLighting:
         d = A.SkyLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
         d.sh9_rgba = surf["sh9"] if have_sh else None
-        d.ambient_occlusion = None
+        d.ambient_occlusion = surf["ao"] if cfg.EnableHBAO else None
+        d.bent_normals = surf["bent_normals"] if cfg.EnableHBAO else None
+        d.use_bent_normals = 1 if cfg.UseBentNormals else 0
         d.sky_brightness, d.diffuse_ibl = cfg.SkyBrightness, 1 if cfg.EnableDiffuseIBL else 0
         d.specular_ibl = 1 if cfg.EnableSpecularIBL else 0
         if ibl is not None:         # IblInputs: pointers valid for whoever runs the pass (device for the library, host for the oracle)
@@ -259,6 +271,7 @@ def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
     c.turbidity, c.env_sky_mode, c.storage_rounding = cfg.Turbidity, cfg.EnvSkyMode, storage_rounding
     c.enable_specular_ibl = int(cfg.EnableSpecularIBL)
     c.use_primitives = 0 if cfg.UseMeshlets else 1
+    c.enable_hbao, c.use_bent_normals = int(cfg.EnableHBAO), int(cfg.UseBentNormals)
     return c
 
 
@@ -337,7 +350,7 @@ class RasterRenderer:
 
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
-                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky")
+                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg

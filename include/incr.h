@@ -208,6 +208,8 @@ typedef struct incr_view_constants {
     uint32_t res_x, res_y;
     float    jitter[2];
     uint32_t scissor_y0, scissor_y1;         /* rows [y0, y1) a pass touches (sort-first multi-GPU row bands); 0,0 = the whole frame */
+    float    camera_up[3];                   /* FViewConstants::m_cameraUpVector = view.m_up                  renderer.cpp:1660 */
+    float    pad0;
 } incr_view_constants;
 /* renderer.cpp:126-131: jitter = 2 * (Halton(i,2), Halton(i,3)) - 0.5) / res for i = frame_index % 16. */
 void incr_pixel_jitter(uint32_t frame_index, uint32_t res_x, uint32_t res_y, float out_jitter[2]);
@@ -297,6 +299,26 @@ typedef struct incr_gbuffer_desc {
 } incr_gbuffer_desc;
 int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* desc, incr_stream stream);
 
+/*
+ * RenderJob::HBAO::Execute (render-jobs/hbao.inl:16-105; shaders/postprocess/hbao.hlsl): ray-traced horizon-based
+ * ambient occlusion.  Per pixel 4 azimuthal slices x 2 horizons x a binary search of at most 4 any-hit ray queries
+ * (TMin 0.1, TMax 1, back faces culled) against the scene BVH, integrated against the projected normal; writes the
+ * occlusion factor sky lighting multiplies by and the octahedral bent normal.  FConfig::EnableHBAO is off by default:
+ * the frame then clears both targets to 1 (renderer.cpp:1816-1841 = ambient_occlusion NULL in incr_sky_lighting_desc).
+ * cos / sin / acos are evaluated by fixed polynomials so the result does not depend on a math library.
+ */
+typedef struct incr_hbao_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;   /* inv_view_proj_transform, eye_pos, camera_up, resolution, scissor rows */
+    const float*    depth_buffer;
+    const uint32_t* gbuffer_normals;   /* device, R16G16_FLOAT (octahedral) */
+    uint8_t*  ao_target;               /* device, R8_UNORM */
+    uint32_t* bent_normal_target;      /* device, R16G16_FLOAT (octahedral) */
+    incr_ray_stats* ray_stats;         /* device, optional: light_shadow_rays accumulated (the pass's ray queries) */
+    int32_t  storage_rounding;
+} incr_hbao_desc;
+int incr_hbao(incr_context* ctx, const incr_hbao_desc* desc, incr_stream stream);
+
 /* Inputs shared by the three deferred lighting passes. */
 typedef struct incr_lighting_inputs {
     const incr_scene* scene;
@@ -323,6 +345,8 @@ typedef struct incr_sky_lighting_desc {
     const uint32_t* env_brdf;          /* device, R16G16_FLOAT LUT (incr_generate_env_brdf); NULL = g_envBrdfTextureIndex -1 */
     uint32_t env_brdf_width, env_brdf_height;
     int32_t  specular_ibl;             /* FConfig::EnableSpecularIBL */
+    const uint32_t* bent_normals;      /* device, R16G16_FLOAT (octahedral) from incr_hbao; read when use_bent_normals; NULL = cleared to (1, 1) */
+    int32_t  use_bent_normals;         /* FConfig::UseBentNormals -> USE_BENT_NORMALS (sky-lighting.inl:65): the SH9 lookup normal */
 } incr_sky_lighting_desc;
 int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* desc, incr_stream stream);
 
@@ -426,12 +450,13 @@ typedef struct incr_renderer_config {      /* FConfig fields the frame reads (in
     int32_t  env_sky_mode, storage_rounding;
     int32_t  enable_specular_ibl;
     int32_t  use_primitives;               /* !FConfig::UseMeshlets: primitive variants of culling / visibility / G-buffer */
+    int32_t  enable_hbao, use_bent_normals;/* FConfig::EnableHBAO, FConfig::UseBentNormals */
 } incr_renderer_config;
 enum {
     INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,
     INCR_SURFACE_TAA_ACCUMULATION, INCR_SURFACE_DEPTH, INCR_SURFACE_VISIBILITY, INCR_SURFACE_GBUFFER_BASECOLOR,
     INCR_SURFACE_GBUFFER_NORMALS, INCR_SURFACE_GBUFFER_METALLIC_ROUGHNESS_AO, INCR_SURFACE_RENDER_STATS, INCR_SURFACE_RAY_STATS,
-    INCR_SURFACE_BATCH_COUNTS
+    INCR_SURFACE_BATCH_COUNTS, INCR_SURFACE_AMBIENT_OCCLUSION, INCR_SURFACE_BENT_NORMALS
 };
 int   incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x, uint32_t res_y, const incr_renderer_scene* scene,
                            const incr_renderer_config* config /* NULL = FConfig defaults */, incr_renderer** out_renderer);

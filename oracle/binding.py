@@ -69,6 +69,8 @@ def lib():
         L.orc_clustered_lighting.argtypes = [vp, C.POINTER(A.ClusteredLightingDesc)]
         L.orc_taa_resolve.argtypes = [C.POINTER(A.TaaResolveDesc)]
         L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
+        L.orc_hbao.argtypes = [vp, C.POINTER(A.HbaoDesc), C.POINTER(C.c_uint64)]
+        L.orc_hb_math.argtypes = [C.c_float, fp]
         L.orc_oct_roundtrip.argtypes = [fp, fp, fp]
         # sky / IBL precompute (oracle_ibl.h)
         L.orc_ibl_sizes.restype = C.c_uint64; L.orc_ibl_sizes.argtypes = [u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -167,6 +169,8 @@ class HostSurfaces:
         n = (res_y, res_x)
         self.arr = {k: np.zeros(n, dtype=np.uint32) for k in ("vis", "gbuffer_basecolor", "gbuffer_normals", "gbuffer_mra", "color", "taa0", "taa1", "ldr")}
         self.arr["depth"] = np.zeros(n, dtype=np.float32)
+        self.arr["ao"] = np.zeros(n, dtype=np.uint8)                 # R8_UNORM hbao target
+        self.arr["bent_normals"] = np.zeros(n, dtype=np.uint32)      # R16G16_FLOAT
         self.arr["default_list"] = np.zeros((max(num_meshlets, 1), 2), dtype=np.uint32)
         self.arr["double_sided_list"] = np.zeros((max(num_meshlets, 1), 2), dtype=np.uint32)
         self.arr["counts"] = np.zeros(2, dtype=np.uint32)
@@ -197,6 +201,11 @@ def run_pass(scene, name, desc):
         L.orc_visibility(h, C.byref(desc))
     elif name == "gbuffer":
         L.orc_gbuffer(h, C.byref(desc))
+    elif name == "hbao":
+        rays = C.c_uint64()
+        L.orc_hbao(h, C.byref(desc), C.byref(rays))
+        if desc.ray_stats:
+            C.cast(desc.ray_stats, C.POINTER(C.c_uint64))[3] += rays.value
     elif name == "sky_lighting":
         L.orc_sky_lighting(h, C.byref(desc))
     elif name == "direct_lighting":

@@ -43,7 +43,7 @@ static void make_view_constants(const incr_view* view, const incr_view* cull, co
     put(&o->lightcull_inv_view_proj, mat_inverse(mat_mul(mat_mul(Vc, Pc), T)));            // light-culling.inl:112
     put(&o->sky_inv_view_proj, mat_inverse(mat_mul(VP, T)));                               // sky-lighting.inl:124
     put(&o->unjittered_view_proj, VP); put(&o->taa_inv_view_proj, mat_inverse(VP));       // renderer.cpp:2007-2017
-    for (int i = 0; i < 3; ++i) o->eye_pos[i] = view->position[i];
+    for (int i = 0; i < 3; ++i) { o->eye_pos[i] = view->position[i]; o->camera_up[i] = view->up[i]; }      // renderer.cpp:1659-1660
     o->near_plane = nearPlane; o->res_x = resX; o->res_y = resY; o->jitter[0] = jx; o->jitter[1] = jy;
 }
 
@@ -381,6 +381,110 @@ static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const ui
     }
 }
 
+// ------------------------------------------------------------------------------------------------ HBAO
+// shaders/postprocess/hbao.hlsl:1-175.  HLSL leaves the precision of cos / sin / acos / rsqrt to the implementation; the
+// pinned choice is a fixed evaluation both sides restate: Cody-Waite reduction by pi/2 + Taylor polynomials
+// in Horner form for sin / cos on [-pi, pi], the arcsine series through x^23 with the half-angle identity for acos,
+// rsqrt(x) = 1 / sqrt(x), saturate(NaN) = 0, NaN stored to R16_FLOAT as 0x7FFF.
+static inline void hb_reduce(float x, float* r, int* q) {
+    const float kf = floorf(x * 0.636619747f + 0.5f);
+    *r = (x - kf * 1.5707963705062866f) - kf * -4.3711388286737929e-08f;
+    *q = (kf == kf) ? ((int)kf & 3) : 0;
+}
+static inline float hb_sin_poly(float r) {
+    const float z = r * r;
+    return r + (r * z) * (-0.166666672f + z * (0.00833333377f + z * (-0.000198412701f + z * 2.75573188e-06f)));
+}
+static inline float hb_cos_poly(float r) {
+    const float z = r * r;
+    return 1.f + z * (-0.5f + z * (0.0416666679f + z * (-0.00138888892f + z * (2.48015876e-05f + z * -2.755732e-07f))));
+}
+static inline float hb_sin(float x) {
+    float r; int q; hb_reduce(x, &r, &q);
+    const float s = (q & 1) ? hb_cos_poly(r) : hb_sin_poly(r);
+    return (q & 2) ? -s : s;
+}
+static inline float hb_cos(float x) {
+    float r; int q; hb_reduce(x, &r, &q);
+    const float c = (q & 1) ? hb_sin_poly(r) : hb_cos_poly(r);
+    return ((q + 1) & 2) ? -c : c;
+}
+static inline float hb_asin_half(float x) {            // |x| <= 0.5 (plus rounding)
+    const float z = x * x;
+    const float p = 0.166666672f + z * (0.075000003f + z * (0.0446428582f + z * (0.030381944f + z * (0.0223721582f + z * (0.0173527636f
+                  + z * (0.0139648439f + z * (0.0115518011f + z * (0.00976160914f + z * (0.00839033537f + z * 0.007312526f)))))))));
+    return x + (x * z) * p;
+}
+static inline float hb_acos(float x) {
+    if (!(fabsf(x) > 0.5f)) return 1.5707963705062866f - (hb_asin_half(x) - -4.3711388286737929e-08f);
+    if (x > 0.f) return 2.f * hb_asin_half(sqrtf((1.f - x) * 0.5f));
+    return 3.1415927410125732f - (2.f * hb_asin_half(sqrtf((1.f + x) * 0.5f)) - -8.7422776573475858e-08f);
+}
+static inline float hb_saturate(float v) { return !(v > 0.f) ? 0.f : (v > 1.f ? 1.f : v); }
+static inline uint32_t hb_f16(float v, int rounding) { return v != v ? 0x7fffu : (uint32_t)f32_to_f16(v, rounding); }
+
+static const float kHbaoPi = 3.14159265358979323846f;
+static const uint32_t kHbaoNumSlices = 4, kHbaoMaxTracesPerSlice = 4;
+
+static bool hbao_ray_hit(const Scene& s, float3 origin, float3 dir, uint64_t* rays) {            // RayHit :41-64
+    ++*rays;
+    if (!finite_ray(origin, dir)) return false;
+    return trace_any(s, origin, dir, 0.1f, 1.f);
+}
+static float ComputeHorizonAngle(const Scene& s, float horizonAngleStart, float3 pos, float3 sliceX, float3 sliceY, uint64_t* rays) {   // :66-93
+    const float terminate = kHbaoPi / 36.f;
+    float minHorizonAngle = 0.f, maxHorizonAngle = horizonAngleStart;
+    uint32_t traceIdx = 0;
+    while (traceIdx < kHbaoMaxTracesPerSlice && (maxHorizonAngle - minHorizonAngle) > terminate) {
+        const float a = minHorizonAngle + 0.5f * (maxHorizonAngle - minHorizonAngle);
+        const float3 dir = hb_cos(a) * sliceY + hb_sin(a) * sliceX;
+        if (hbao_ray_hit(s, pos, dir, rays)) maxHorizonAngle = a; else minHorizonAngle = a;
+        ++traceIdx;
+    }
+    return maxHorizonAngle;
+}
+static void hbao_pass(const Scene& s, const incr_hbao_desc& d, uint64_t* rayCount) {           // cs_main :109-175
+    const incr_view_constants& vc = *d.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 ivp = to_mat4(vc.inv_view_proj_transform);
+    const float3 eye = {vc.eye_pos[0], vc.eye_pos[1], vc.eye_pos[2]}, camUp = {vc.camera_up[0], vc.camera_up[1], vc.camera_up[2]};
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    uint64_t rays = 0;
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const float2 ndc = pixel_ndc(x, y, (float)W, (float)H);                      // (xy + 0.5) / res, y flipped
+        const float4 wp = mul_vec4({ndc.x, ndc.y, d.depth_buffer[i], 1.f}, ivp);
+        const float3 pos = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+        const float3 localAt = normalize(eye - pos);
+        const float3 localRight = normalize(cross(localAt, camUp));
+        const float3 localUp = cross(localRight, localAt);
+        const uint32_t n = d.gbuffer_normals[i];
+        const float3 N = OctDecode({f16_to_f32((uint16_t)(n & 0xffffu)), f16_to_f32((uint16_t)(n >> 16))});
+        float azimuth = 0.f, sumAO = 0.f;
+        float3 avgBent = {0.f, 0.f, 0.f};
+        for (uint32_t k = 0; k < kHbaoNumSlices; ++k) {
+            const float3 sliceT = hb_cos(azimuth) * localRight + hb_sin(azimuth) * localUp;
+            const float pnx = dot(N, sliceT), pny = dot(N, localAt);
+            const float t = -dot(sliceT, N) / dot(localAt, N);
+            const float horizon = hb_acos(t * (1.f / sqrtf(1.f + t * t)));
+            // GatherAO :95-106
+            const float theta1 = ComputeHorizonAngle(s, horizon, pos, sliceT, localAt, &rays);
+            const float theta0 = -ComputeHorizonAngle(s, horizon, pos, -sliceT, localAt, &rays);
+            const float s0 = hb_sin(theta0), c0 = hb_cos(theta0), s1 = hb_sin(theta1), c1 = hb_cos(theta1);
+            const float nx = 0.5f * (((theta1 - theta0) + s0 * c0) - s1 * c1);
+            const float ny = 0.5f * ((2.f - c0 * c0) - c1 * c1);
+            sumAO += pnx * nx + pny * ny;
+            avgBent = avgBent + normalize(sliceT * nx + localAt * ny);
+            azimuth += kHbaoPi / (float)kHbaoNumSlices;
+        }
+        const float ao = hb_saturate(sumAO / (float)kHbaoNumSlices);
+        d.ao_target[i] = (uint8_t)unorm8(ao);
+        const float2 oct = OctEncode(normalize(avgBent));
+        d.bent_normal_target[i] = hb_f16(oct.x, d.storage_rounding) | (hb_f16(oct.y, d.storage_rounding) << 16);
+    }
+    if (rayCount) *rayCount += rays;
+}
+
 // ------------------------------------------------------------------------------------------------ deferred lighting
 struct GBufferPixel { float3 basecolor, N; float metallic, roughness, ao, aoBlend; };
 static inline GBufferPixel read_gbuffer(const incr_lighting_inputs& in, size_t i) {
@@ -522,7 +626,12 @@ static void sky_lighting(const Scene& s, const incr_sky_lighting_desc& d) {
         float3 radiance = {0, 0, 0};
         if (diffuseIbl && sh9rgba) {
             const float3 albedo = (1.f - g.metallic) * g.basecolor;
-            const float3 shDiffuse = ((albedo * Fd_Lambert()) * ShIrradiance(g.N, sh)) * 5.f;
+            float3 samplingNormal = g.N;
+            if (d.use_bent_normals) {                                                          // USE_BENT_NORMALS, sky-lighting.hlsl:88-92
+                const uint32_t b = d.bent_normals ? d.bent_normals[i] : 0x3c003c00u;          // HBAO off: cleared to (1, 1)
+                samplingNormal = OctDecode({f16_to_f32((uint16_t)(b & 0xffffu)), f16_to_f32((uint16_t)(b >> 16))});
+            }
+            const float3 shDiffuse = ((albedo * Fd_Lambert()) * ShIrradiance(samplingNormal, sh)) * 5.f;
             const float3 occluded = g.ao * shDiffuse;
             radiance += skyBrightness * (shDiffuse + g.aoBlend * (occluded - shDiffuse));      // lerp(a, b, t) = a + t (b - a)
         }
@@ -639,6 +748,8 @@ void orc_visibility(void* scene, const incr_visibility_desc* d) {
 void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
     gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding, d->use_primitives != 0);
 }
+void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }
+void orc_hb_math(float x, float out[3]) { out[0] = hb_sin(x); out[1] = hb_cos(x); out[2] = hb_acos(x); }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {
     sky_lighting(*(Scene*)scene, *d);
 }

@@ -165,6 +165,50 @@ def test_raster_primitive_path_parity(request, rt, R, ob, A, sio, gpu_ctx, which
         osc.close(); gscene.close()
 
 
+@pytest.mark.parametrize("which,W,H", [("helmet", 160, 160), ("sponza_small", 256, 144)])
+def test_hbao_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, H):
+    """incr_hbao (hbao.hlsl): the pass evaluates its trigonometry with pinned polynomials and its ray queries are
+    order-independent any-hit tests, so occlusion factors, bent normals and the ray count are bit-exact against the oracle;
+    sky lighting with USE_BENT_NORMALS on top stays within the colour tolerance.  Also through the C++ host renderer."""
+    class Hbao(A.FConfig):
+        EnableHBAO = True
+        UseBentNormals = True
+    scene = request.getfixturevalue(which)
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    osc = ob.OracleScene(scene)
+    try:
+        rr = R.RasterRenderer(gpu_ctx, gscene, W, H, Hbao); rr.set_sh9(DEFAULT_SH9)
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Hbao, sh9_rgb=DEFAULT_SH9)
+        rr.render(view); hr.render(view); gpu_ctx.synchronize()
+        _, hs = run_oracle_frame(ob, R, A, scene, osc, view, W, H, cfg=Hbao)
+        o = hs.arr
+        np.testing.assert_array_equal(rr.surf.download("vis"), o["vis"])
+        ao, bent = rr.surf.download("ao"), rr.surf.download("bent_normals")
+        np.testing.assert_array_equal(ao, o["ao"])
+        np.testing.assert_array_equal(bent, o["bent_normals"])
+        assert rr.surf.download("ray_stats").light_shadow_rays == int(o["ray_stats"][3])
+        covered = o["vis"] != 0xFFFFF000
+        assert 0 < (ao[covered] < 255).mean() < 1
+        assert colour_close(ob, rr.surf.download("color"), o["color"], "colour with HBAO") > 0.999
+        np.testing.assert_array_equal(hr.download(A.SURFACE_AMBIENT_OCCLUSION, dtype=np.uint8), ao)
+        np.testing.assert_array_equal(hr.download(A.SURFACE_BENT_NORMALS), bent)
+        np.testing.assert_array_equal(hr.download(A.SURFACE_HDR_RASTER), rr.surf.download("color"))
+        # a row band of the pass equals the same rows of the full frame
+        band = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Hbao, sh9_rgb=DEFAULT_SH9)
+        y0, y1 = H // 4, H // 2
+        band.set_band(y0, y1); band.render(view); gpu_ctx.synchronize()
+        np.testing.assert_array_equal(band.download(A.SURFACE_AMBIENT_OCCLUSION, dtype=np.uint8)[y0:y1], ao[y0:y1])
+        np.testing.assert_array_equal(band.download(A.SURFACE_HDR_RASTER)[y0:y1], rr.surf.download("color")[y0:y1])
+        rr.close(); hr.close(); band.close()
+        # bad arguments
+        d = A.HbaoDesc(); d.scene = gscene.handle
+        vc = R.make_view_constants(view, W, H); d.view = C.pointer(vc)
+        assert gpu_ctx.lib.incr_hbao(gpu_ctx.handle, C.byref(d), None) == -1 and b"NULL" in gpu_ctx.lib.incr_last_error()
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

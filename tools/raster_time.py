@@ -10,14 +10,19 @@ rt = importlib.import_module("incarnation-renderer_amd.runtime")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--res", default="3840x2160"); ap.add_argument("--frames", type=int, default=20); ap.add_argument("--texture-size", type=int, default=256)
+ap.add_argument("--hbao", action="store_true"); ap.add_argument("--prims", action="store_true")
 a = ap.parse_args()
+class Cfg(A.FConfig):
+    EnableHBAO = a.hbao
+    UseBentNormals = a.hbao
+    UseMeshlets = not a.prims
 W, H = map(int, a.res.split("x"))
 t = time.time(); scene = synth.sponza_stat(texture_size=a.texture_size); print("scene %.1fs" % (time.time() - t))
 t = time.time(); R.generate_meshlets(scene); print("meshlets %d in %.1fs" % (scene.num_meshlets, time.time() - t))
 ctx = rt.Context(0)
 t = time.time(); gs = ctx.create_scene(scene); print("upload %.1fs" % (time.time() - t))
 view = sio.FView().reset(scene, aspect=W / H)
-rr = R.RasterRenderer(ctx, gs, W, H)
+rr = R.RasterRenderer(ctx, gs, W, H, Cfg)
 rr.set_sh9(np.ones((9, 3), np.float32) * 0.1)
 for _ in range(3):
     rr.render(view)

@@ -327,7 +327,8 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     if (!d->res_x || !d->res_y) return fail(INCR_ERR_INVALID_ARGUMENT, "zero resolution");
     if ((uint64_t)d->res_x * d->res_y > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "resolution overflows the 32-bit pixel index of the sampler");
-    if (d->env_sky_mode != 1) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode %d unsupported: only the dynamic (Preetham) sky is implemented", d->env_sky_mode);
+    if (d->env_sky_mode != 0 && d->env_sky_mode != 1) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode %d unsupported (0 = HDRI cube, 1 = dynamic sky)", d->env_sky_mode);
+    if (d->env_sky_mode == 0 && !d->envmap_r11g11b10) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode 0 (HDRI) needs envmap_r11g11b10: the miss shader samples the cube");
     if (d->viewmode < 0 || d->viewmode > 5) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d unsupported (0..5)", d->viewmode);
     if (d->max_sample_count < 1) return fail(INCR_ERR_INVALID_ARGUMENT, "max_sample_count must be >= 1");
     if (d->shard.row_block_height && !d->shard.row_block_stride) return fail(INCR_ERR_INVALID_ARGUMENT, "row_block_stride must be >= 1");
@@ -358,6 +359,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
         if (!d->envmap_res || !d->envmap_mips || d->envmap_mips > 16) return fail(INCR_ERR_INVALID_ARGUMENT, "envmap given with zero resolution / level count");
         P.envmap = d->envmap_r11g11b10; P.envmapRes = d->envmap_res; P.envmapMips = d->envmap_mips;
     }
+    P.envSkyMode = d->env_sky_mode;
     P.rowBlockHeight = d->shard.row_block_height; P.rowBlockFirst = d->shard.row_block_first; P.rowBlockStride = d->shard.row_block_stride ? d->shard.row_block_stride : 1;
     P.localRows = incr_shard_local_rows(d->res_y, &d->shard);
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;

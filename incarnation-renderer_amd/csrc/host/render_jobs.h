@@ -204,6 +204,15 @@ struct Desc {
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }
+namespace EnvironmentmapPass { // render-jobs/environmentmap.inl:3-14
+struct Desc {
+    FShaderSurface* colorTarget; FShaderSurface* depthStencilTarget;
+    uint32_t resX; uint32_t resY;
+    const FScene* scene; const FView* view; Vector2 jitter; FConfig renderConfig;
+    FSystemBuffer* viewConstantBuffer = nullptr;    // invParallaxViewProjMatrix + resolution + scissor rows
+};
+Result Execute(Sync* jobSync, const Desc& passDesc);
+}
 namespace TAAResolvePass {   // render-jobs/taa-resolve.inl:3-14
 struct Desc {
     FShaderSurface* source; FShaderSurface* target;

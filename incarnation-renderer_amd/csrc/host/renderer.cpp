@@ -178,6 +178,16 @@ Result DynamicSkyPass::Execute(Sync* jobSync, const Desc& p) {            // dyn
     return done(jobSync->Execute(token, [&] { return incr_dynamic_sky(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
+Result EnvironmentmapPass::Execute(Sync* jobSync, const Desc& p) {        // environmentmap.inl:16-150
+    const size_t token = jobSync->GetToken();
+    incr_environmentmap_desc d = {};
+    d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
+    d.envmap_r11g11b10 = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;   // m_skylight.m_envmapTextureIndex
+    d.sky_brightness = p.renderConfig.SkyBrightness; d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_environmentmap(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
 Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa-resolve.inl:16-118
     const size_t token = jobSync->GetToken();
     incr_view_constants vc = {};
@@ -398,7 +408,14 @@ int Render(State& s, const FRenderState& renderState) {
             }
         }
 
-        if (c.EnvSkyMode == 1) {                                               // :1946-1959 (the HDRI envmap branch :1929-1944 is outside this library)
+        if (c.EnvSkyMode == 0) {                                               // EnvSkyMode::HDRI :1927-1943
+            EnvironmentmapPass::Desc envmapDesc = {};
+            envmapDesc.colorTarget = &s.hdrRasterSceneColor; envmapDesc.depthStencilTarget = &s.depthBuffer;
+            envmapDesc.resX = resX; envmapDesc.resY = resY;
+            envmapDesc.scene = scene; envmapDesc.view = &renderState.m_view; envmapDesc.jitter = pixelJitter; envmapDesc.renderConfig = c;
+            envmapDesc.viewConstantBuffer = &cbViewConstants;
+            EnvironmentmapPass::Execute(jobSync, envmapDesc);
+        } else {                                                               // :1944-1959
             DynamicSkyPass::Desc skyDesc = {};
             skyDesc.colorTarget = &s.hdrRasterSceneColor; skyDesc.depthStencilTarget = &s.depthBuffer;
             skyDesc.resX = resX; skyDesc.resY = resX;                          // sic: the reference passes resX twice (:1951-1952); unused by the pass

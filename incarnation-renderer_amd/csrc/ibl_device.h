@@ -70,6 +70,13 @@ DI f3 sky_env_radiance(const PtParams& P, f3 dir) {
     return 0.04f * CalculateSkyRadianceRGB(P.sunEnv, dir, P.perez);
 }
 
+// Miss shaders (pathtracing.hlsl:304-319): msEnvmap adds attenuation * skyBrightness * envmap.SampleLevel(dir, 0),
+// msDynamicSky adds attenuation * 1000 * Preetham(dir).
+DI f3 sky_miss_add(const PtParams& P, f3 attenuation, f3 dir) {
+    if (P.envSkyMode == 0) return (attenuation * P.skyBrightness) * cube_sample_level(CubeChain{P.envmapRes, P.envmapMips, P.envmap}, dir, 0u);
+    return attenuation * 1000 * CalculateSkyRadianceRGB(P.sunMiss, dir, P.perez);
+}
+
 DI f3 latlong_dir(f2 uv) {            // common/math.hlsli:46-79: LatlongUV2Polar + Polar2Cartesian(..., World)
     const float theta = K_PI * uv.y, phi = K_PI * (uv.x * 2.f - 1.f);
     const float sint = sinf(theta), cost = cosf(theta), sinp = sinf(phi), cosp = cosf(phi);

@@ -138,9 +138,8 @@ DI f4 trace_pixel(const PtParams& P, LaneStack& st, uint32_t px, uint32_t py, Co
         first = false;
         Hit hit;
         if (!trace_closest(P, st, ray.o, ray.d, ray.tmin, ray.tmax, &hit)) {
-            // msDynamicSky -- pathtracing.hlsl:311-319
-            const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, ray.d, P.perez);
-            const f3 add = attenuation * 1000 * sky;
+            // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
+            const f3 add = sky_miss_add(P, attenuation, ray.d);
             color.x += add.x; color.y += add.y; color.z += add.z;
             break;
         }

@@ -109,9 +109,8 @@ __global__ __launch_bounds__(kBlock) void pathtrace_wave_kernel(const PtParams P
             if (isCameraRay) cnt.camera++; else cnt.bounce++;
             isCameraRay = false;
             gotHit = trace_closest(P, st, ray.o, ray.d, ray.tmin, ray.tmax, &hit);
-            if (!gotHit) {   // msDynamicSky -- pathtracing.hlsl:311-319
-                const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, ray.d, P.perez);
-                const f3 add = attenuation * 1000 * sky;
+            if (!gotHit) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
+                const f3 add = sky_miss_add(P, attenuation, ray.d);
                 color.x += add.x; color.y += add.y; color.z += add.z;
                 store_pixel(P, px, ly, color);
                 alive = false;

@@ -215,9 +215,8 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
             f4 color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};
             float4* vtx = vertex_of(B, pid);
-            if (h.x == kMissTri) {   // msDynamicSky -- pathtracing.hlsl:311-319
-                const f3 sky = CalculateSkyRadianceRGB(P.sunMiss, rayD, P.perez);
-                const f3 add = attenuation * 1000 * sky;
+            if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
+                const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
                 store_pixel(P, px, ly, color);
                 vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));

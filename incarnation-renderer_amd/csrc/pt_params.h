@@ -43,6 +43,7 @@ struct PtParams {
     // prefiltered sky cube for the sky next-event estimate (NULL = analytic 0.04 * Preetham)
     const uint32_t* __restrict__ envmap;
     uint32_t envmapRes, envmapMips;
+    int32_t envSkyMode;                       // 0 = HDRI cube in the miss shader (msEnvmap), 1 = dynamic Preetham sky (msDynamicSky)
 };
 
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).

@@ -884,6 +884,19 @@ __global__ __launch_bounds__(256) void dynamic_sky_kernel(const DynamicSkyParams
     P.color[i] = pack_r11g11b10(radiance, P.rounding);
 }
 
+// envmap.hlsl:22-54 (EnvSkyMode::HDRI background): sky_brightness * cube along the translation-free view ray
+__global__ __launch_bounds__(256) void environmentmap_kernel(const EnvmapParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.y1) return;
+    const size_t i = (size_t)y * P.W + x;
+    if (!(0.0001f >= P.depth[i])) return;
+    const f2 ndc = pixel_ndc(x, y, (float)P.W, (float)P.H);
+    const f4 wp = mul_vec4({ndc.x, ndc.y, 0.0001f, 1.f}, P.invParallaxViewProj);
+    const f3 dir = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+    const f3 luminance = P.skyBrightness * cube_sample_level(CubeChain{P.envmapRes, P.envmapMips, P.envmap}, dir, 0u);
+    P.color[i] = pack_r11g11b10(luminance, P.rounding);
+}
+
 // ---------------------------------------------------------------------------------------------- TAA resolve
 DI f3 load_hdr(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {
     if (x >= W || y >= H) return {0.f, 0.f, 0.f};
@@ -1006,6 +1019,11 @@ extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, h
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(dynamic_sky_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(environmentmap_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream) {

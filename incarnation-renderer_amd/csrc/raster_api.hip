@@ -21,6 +21,7 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
@@ -441,6 +442,23 @@ int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* d, incr_str
     const float Ln[3] = {L.x, L.y, L.z};
     incr_sky_sun_terms(Ln, d->turbidity, P.perez, &P.sun);
     HIP_TRY(incr_launch_dynamic_sky(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->color_target || !d->depth_buffer) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    if (!d->envmap_r11g11b10 || !d->envmap_res || !d->envmap_mips || d->envmap_mips > 16) return fail(INCR_ERR_INVALID_ARGUMENT, "environment cube missing or zero-sized");
+    EnvmapParams P; memset(&P, 0, sizeof P);
+    P.W = d->view->res_x; P.H = d->view->res_y; scissor_rows(*d->view, &P.y0, &P.y1);
+    P.rounding = d->storage_rounding; P.color = d->color_target; P.depth = d->depth_buffer;
+    P.envmap = d->envmap_r11g11b10; P.envmapRes = d->envmap_res; P.envmapMips = d->envmap_mips;
+    P.skyBrightness = d->sky_brightness;
+    memcpy(P.invParallaxViewProj, d->view->envmap_inv_parallax_view_proj.m, 64);
+    HIP_TRY(incr_launch_environmentmap(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 

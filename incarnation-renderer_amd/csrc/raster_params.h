@@ -147,6 +147,13 @@ struct DynamicSkyParams {
     incr_perez_distribution perez; SkySun sun;
 };
 
+struct EnvmapParams {
+    uint32_t W, H, y0, y1; int32_t rounding;
+    uint32_t* __restrict__ color; const float* __restrict__ depth;
+    const uint32_t* __restrict__ envmap; uint32_t envmapRes, envmapMips;
+    float skyBrightness, invParallaxViewProj[16];
+};
+
 struct TaaParams {
     uint32_t W, H, historyIndex; int32_t rounding;
     const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;

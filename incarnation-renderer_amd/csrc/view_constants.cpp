@@ -60,6 +60,9 @@ int incr_make_view_constants(const incr_view* view, const incr_view* culling_vie
     store(&out->sky_inv_view_proj, m44_inverse(m44_mul(VP, T)));
     store(&out->unjittered_view_proj, VP);
     store(&out->taa_inv_view_proj, m44_inverse(VP));
+    M44 parallaxView = V;                                      // environmentmap.inl:127-128: Translation(Vector3::Zero)
+    parallaxView.m[12] = parallaxView.m[13] = parallaxView.m[14] = 0.f;
+    store(&out->envmap_inv_parallax_view_proj, m44_inverse(m44_mul(parallaxView, P)));
     for (int i = 0; i < 3; ++i) { out->eye_pos[i] = view->position[i]; out->camera_up[i] = view->up[i]; }
     out->near_plane = near_plane;
     out->res_x = res_x; out->res_y = res_y;

@@ -150,7 +150,8 @@ class ViewConstants(C.Structure):
         "cull_view_proj_transform", "prev_view_proj_transform", "lightcull_proj_transform", "lightcull_inv_view_proj",
         "sky_inv_view_proj", "unjittered_view_proj", "taa_inv_view_proj")] + [
         ("eye_pos", c_float3), ("near_plane", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("jitter", C.c_float * 2),
-        ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32), ("camera_up", c_float3), ("pad0", C.c_float)]
+        ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32), ("camera_up", c_float3), ("pad0", C.c_float),
+        ("envmap_inv_parallax_view_proj", Matrix)]
 
 
 class DrawCmd(C.Structure):
@@ -202,6 +203,11 @@ class SkyLightingDesc(C.Structure):
                 ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
                 ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32), ("specular_ibl", C.c_int32),
                 ("bent_normals", C.c_void_p), ("use_bent_normals", C.c_int32)]
+
+
+class EnvironmentmapDesc(C.Structure):
+    _fields_ = [("view", _VC), ("color_target", C.c_void_p), ("depth_buffer", C.c_void_p), ("envmap_r11g11b10", C.c_void_p),
+                ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32), ("sky_brightness", C.c_float), ("storage_rounding", C.c_int32)]
 
 
 class HbaoDesc(C.Structure):

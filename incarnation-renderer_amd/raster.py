@@ -245,7 +245,15 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
         d.cluster_dim[:] = dims
         d.cluster_depth_extent, d.requires_clear = cfg.ClusterDepthExtent, 1 if sun == -1 else 0
         out.append(("clustered_lighting", d))
-    if cfg.EnvSkyMode == 1:         # renderer.cpp:1929-1959: dynamic sky fills the background (the HDRI envmap pass is not in this library)
+    if cfg.EnvSkyMode == 0:         # renderer.cpp:1927-1943 EnvSkyMode::HDRI: the environment cube fills the background
+        if ibl is None or not ibl.envmap:
+            raise ValueError("EnvSkyMode 0 (HDRI) needs the environment cube (IblInputs.envmap)")
+        d = A.EnvironmentmapDesc(); d.view = vcp
+        d.color_target, d.depth_buffer = surf["color"], surf["depth"]
+        d.envmap_r11g11b10, d.envmap_res, d.envmap_mips = ibl.envmap, ibl.envmap_res, ibl.envmap_mips
+        d.sky_brightness, d.storage_rounding = cfg.SkyBrightness, storage_rounding
+        out.append(("environmentmap", d))
+    else:                           # :1944-1959: dynamic sky
         d = A.DynamicSkyDesc(); d.scene, d.view = scene_handle, vcp
         d.color_target, d.depth_buffer = surf["color"], surf["depth"]
         d.turbidity, d.storage_rounding = cfg.Turbidity, storage_rounding
@@ -350,7 +358,7 @@ class RasterRenderer:
 
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
-                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao")
+                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg
@@ -376,7 +384,8 @@ class RasterRenderer:
         ctx, lib = self.ctx, self.ctx.lib
         vc = vc if vc is not None else self.view_constants(view)
         self.last_vc = vc
-        for name, d in build_descs(self.scene.handle, self.scene.packed, vc, self.surf.ptr, self.frame_index, self.cfg, storage_rounding, self.have_sh):
+        for name, d in build_descs(self.scene.handle, self.scene.packed, vc, self.surf.ptr, self.frame_index, self.cfg, storage_rounding, self.have_sh,
+                                   ibl=getattr(self, "ibl", None)):      # self.ibl: IblInputs with device pointers (optional)
             rt.check(getattr(lib, self.PASS_FN[name])(ctx.handle, C.byref(d), stream))
         hdr = self.surf.ptr["taa%d" % (self.frame_index & 1)] if self.cfg.EnableTAA else self.surf.ptr["color"]
         if tonemap:

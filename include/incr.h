@@ -210,6 +210,7 @@ typedef struct incr_view_constants {
     uint32_t scissor_y0, scissor_y1;         /* rows [y0, y1) a pass touches (sort-first multi-GPU row bands); 0,0 = the whole frame */
     float    camera_up[3];                   /* FViewConstants::m_cameraUpVector = view.m_up                  renderer.cpp:1660 */
     float    pad0;
+    incr_matrix envmap_inv_parallax_view_proj; /* ((V with translation zeroed) * P)^-1               environmentmap.inl:127-133 */
 } incr_view_constants;
 /* renderer.cpp:126-131: jitter = 2 * (Halton(i,2), Halton(i,3)) - 0.5) / res for i = frame_index % 16. */
 void incr_pixel_jitter(uint32_t frame_index, uint32_t res_x, uint32_t res_y, float out_jitter[2]);
@@ -382,6 +383,22 @@ typedef struct incr_dynamic_sky_desc {
     int32_t  storage_rounding;
 } incr_dynamic_sky_desc;
 int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* desc, incr_stream stream);
+
+/* RenderJob::EnvironmentmapPass::Execute (render-jobs/environmentmap.inl; shaders/environment-sky/envmap.hlsl), the
+ * background of EnvSkyMode::HDRI: every pixel at the far plane (depth <= 0.0001) becomes sky_brightness * envmap(view ray),
+ * the ray taken through the translation-free view (view->envmap_inv_parallax_view_proj).  The cube is the scene's
+ * m_skylight.m_envmapTextureIndex in the packed level layout of incr_sky_ibl_info::envmap_r11g11b10; it is sampled at
+ * level 0 (the anisotropic sampler of the reference magnifies a 256^2 face at any display resolution). */
+typedef struct incr_environmentmap_desc {
+    const incr_view_constants* view;
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT */
+    const float* depth_buffer;
+    const uint32_t* envmap_r11g11b10;  /* device, cube, all levels packed */
+    uint32_t envmap_res, envmap_mips;
+    float    sky_brightness;           /* FConfig::SkyBrightness */
+    int32_t  storage_rounding;
+} incr_environmentmap_desc;
+int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* desc, incr_stream stream);
 
 /* RenderJob::TAAResolvePass::Execute (render-jobs/taa-resolve.inl; shaders/postprocess/taa-resolve.hlsl).  The reference
  * reads and writes ONE accumulation surface in place (a data race across pixels); here history is read from

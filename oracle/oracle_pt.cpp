@@ -639,7 +639,7 @@ struct Frame {            // per-call constants (path-tracing.inl:134-217 Global
     Mat4 projectionToWorld, cameraMatrix, sceneRotation;
     uint32_t W, H, numPixels, sampleIdx, sqrtSampleCount;
     float aperture, focalLength, skyBrightness, turbidity;
-    int directLighting, viewmode, lightCount;
+    int directLighting, viewmode, lightCount, envSkyMode;
     incr_perez_distribution perez;
     SkySunTerms sunMiss, sunEnv;
     const uint32_t* envmap; uint32_t envmapRes, envmapMips;     // GlobalCbLayout::envmapTextureIndex (NULL: analytic stand-in)
@@ -689,9 +689,13 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         first = false;
         Hit hit;
         if (!trace_closest(s, ray.o, ray.d, ray.tmin, ray.tmax, &hit)) {
-            // msDynamicSky -- pathtracing.hlsl:311-319  (msEnvmap, mode 0, needs the HDRI cube: not in the first cut)
-            float3 sky = CalculateSkyRadianceRGB(f.sunMiss, ray.d, f.perez);
-            float3 add = attenuation * 1000 * sky;
+            float3 add;
+            if (f.envSkyMode == 0) {                   // msEnvmap -- pathtracing.hlsl:304-309 (EnvSkyMode::HDRI)
+                add = (attenuation * f.skyBrightness) * env_cube_level0(f.envmap, f.envmapRes, f.envmapMips, ray.d);
+            } else {                                   // msDynamicSky -- pathtracing.hlsl:311-319
+                float3 sky = CalculateSkyRadianceRGB(f.sunMiss, ray.d, f.perez);
+                add = attenuation * 1000 * sky;
+            }
             color.x += add.x; color.y += add.y; color.z += add.z;
             break;
         }
@@ -822,7 +826,7 @@ static Frame make_frame(const Scene& s, const PtDesc& d) {
     f.sqrtSampleCount = (uint32_t)std::sqrt((double)d.max_sample_count);     // :207 std::sqrt(MaxSampleCount)
     f.aperture = d.camera_aperture; f.focalLength = d.camera_focal_length;
     f.skyBrightness = d.sky_brightness; f.turbidity = d.turbidity;
-    f.directLighting = d.direct_lighting; f.viewmode = d.viewmode;
+    f.directLighting = d.direct_lighting; f.viewmode = d.viewmode; f.envSkyMode = d.env_sky_mode;
     f.lightCount = (int)s.d.num_global_lights;                               // :198 m_globalLightList.size()
     perez_from_turbidity(d.turbidity, &f.perez);
     // Sun direction for the miss shader (:181-189)
@@ -946,7 +950,7 @@ void orc_trace_rays(void* scene, uint32_t n, const float* origins, const float* 
 // `float_target` (optional, local_rows*res_x*4 floats) receives the un-quantised payload colour.
 int orc_pathtrace(void* scene, const PtDesc* d, int num_threads, float* float_target) {
     const Scene& s = *(Scene*)scene;
-    if (d->env_sky_mode != 1) return -1;
+    if (d->env_sky_mode != 1 && !(d->env_sky_mode == 0 && d->envmap_r11g11b10)) return -1;
     const Frame f = make_frame(s, *d);
     const uint32_t localRows = shard_local_rows(d->res_y, d->shard);
     uint16_t* target = (uint16_t*)d->target_rgba16f;

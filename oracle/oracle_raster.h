@@ -44,6 +44,8 @@ static void make_view_constants(const incr_view* view, const incr_view* cull, co
     put(&o->sky_inv_view_proj, mat_inverse(mat_mul(VP, T)));                               // sky-lighting.inl:124
     put(&o->unjittered_view_proj, VP); put(&o->taa_inv_view_proj, mat_inverse(VP));       // renderer.cpp:2007-2017
     for (int i = 0; i < 3; ++i) { o->eye_pos[i] = view->position[i]; o->camera_up[i] = view->up[i]; }      // renderer.cpp:1659-1660
+    Mat4 parallaxView = V; parallaxView.m[12] = parallaxView.m[13] = parallaxView.m[14] = 0.f;             // environmentmap.inl:127-133
+    put(&o->envmap_inv_parallax_view_proj, mat_inverse(mat_mul(parallaxView, P)));
     o->near_plane = nearPlane; o->res_x = resX; o->res_y = resY; o->jitter[0] = jx; o->jitter[1] = jy;
 }
 
@@ -675,6 +677,26 @@ static void dynamic_sky(const Scene& s, const incr_view_constants& vc, uint32_t*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ HDRI background
+// shaders/environment-sky/envmap.hlsl:22-54 + render-jobs/environmentmap.inl:100-146: full-screen triangle at z = 0.0001,
+// depth GREATER_EQUAL, blend off; the interpolated clip position of the pixel centre goes through
+// ((V without translation) * P)^-1 and the cube is sampled along it (pinned: level 0, DESIGN.md 3 texture unit).
+static void environmentmap_pass(const incr_environmentmap_desc& d) {
+    const incr_view_constants& vc = *d.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 inv = to_mat4(vc.envmap_inv_parallax_view_proj);
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        if (!(0.0001f >= d.depth_buffer[i])) continue;
+        const float2 ndc = pixel_ndc(x, y, (float)W, (float)H);
+        float4 wp = mul_vec4({ndc.x, ndc.y, 0.0001f, 1.f}, inv);
+        const float3 dir = {wp.x / wp.w, wp.y / wp.w, wp.z / wp.w};
+        const float3 luminance = d.sky_brightness * env_cube_level0(d.envmap_r11g11b10, d.envmap_res, d.envmap_mips, dir);
+        d.color_target[i] = pack_r11g11b10(luminance, d.storage_rounding);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TAA resolve
 static inline float3 load_hdr(const uint32_t* img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {       // Texture2D.Load: out of bounds -> 0
     if (x >= W || y >= H) return {0, 0, 0};
@@ -748,6 +770,7 @@ void orc_visibility(void* scene, const incr_visibility_desc* d) {
 void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
     gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding, d->use_primitives != 0);
 }
+void orc_environmentmap(const incr_environmentmap_desc* d) { environmentmap_pass(*d); }
 void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }
 void orc_hb_math(float x, float out[3]) { out[0] = hb_sin(x); out[1] = hb_cos(x); out[2] = hb_acos(x); }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {

@@ -280,3 +280,68 @@ def test_gpu_pathtrace_with_sky_cube(rt, ob, A, sio, gpu_ctx, helmet, helmet_ora
         pt.close(); pt2.close(); sky.close()
     finally:
         gscene.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hdri_sky_mode(rt, R, ob, A, sio, gpu_ctx, helmet, helmet_oracle):
+    """EnvSkyMode::HDRI (mode 0): the raster background comes from RenderJob::EnvironmentmapPass (envmap.hlsl) and the path
+    tracer's miss shader is msEnvmap -- both sample level 0 of the scene's environment cube.  Any cube in the packed level
+    layout serves; the prefiltered dynamic-sky cube is the one the precompute produces here."""
+    from test_raster_host_and_oracle import run_oracle_frame
+    ibl_mod = __import__("importlib").import_module("incarnation-renderer_amd.ibl")
+    class Hdri(A.FConfig):
+        EnvSkyMode = 0
+        MaxSampleCount = 16
+    W = H = 192
+    view = sio.FView().reset(helmet, aspect=1.0)
+    gscene = gpu_ctx.create_scene(helmet)
+    try:
+        sky = ibl_mod.SkyIbl(gpu_ctx, gscene, resolution=64)
+        host_env = np.ascontiguousarray(sky.download()["envmap"])
+        dev_ibl = R.IblInputs(None, sky.info.envmap_r11g11b10, sky.info.cubemap_res, sky.info.num_mips)
+        host_ibl = R.IblInputs(None, host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips)
+        # raster: pass by pass and through the C++ renderer against the oracle
+        rr = R.RasterRenderer(gpu_ctx, gscene, W, H, Hdri); rr.ibl = dev_ibl
+        vc = rr.render(view); gpu_ctx.synchronize()
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Hdri, ibl=dev_ibl)
+        hr.render(view); gpu_ctx.synchronize()
+        hs = ob.HostSurfaces(W, H, helmet.num_meshlets, 16 * 9 * 24, 64)
+        for name, d in R.build_descs(None, helmet, vc, hs.ptr, 0, Hdri, ibl=host_ibl):
+            ob.run_pass(helmet_oracle, name, d)
+        color = rr.surf.download("color")
+        background = hs.arr["vis"] == 0xFFFFF000
+        assert 0.2 < background.mean() < 0.9
+        np.testing.assert_array_equal(color[background], hs.arr["color"][background])       # cube taps + one multiply: exact
+        np.testing.assert_array_equal(hr.download(A.SURFACE_HDR_RASTER), color)
+        lum = ob.unpack_r11g11b10(color[background]).sum(-1)
+        assert np.isfinite(lum).all() and lum.min() > 0 and lum.std() > 0
+        # the dynamic-sky mode paints something else there
+        rr1 = R.RasterRenderer(gpu_ctx, gscene, W, H); rr1.render(view); gpu_ctx.synchronize()
+        assert not np.array_equal(rr1.surf.download("color")[background], color[background])
+        rr.close(); rr1.close(); hr.close()
+        # a missing cube is an error, not a silent fallback
+        rr2 = R.RasterRenderer(gpu_ctx, gscene, W, H, Hdri)
+        with pytest.raises(ValueError):
+            rr2.render(view)
+        rr2.close()
+        # path tracer: msEnvmap
+        env_dev = (sky.info.envmap_r11g11b10, sky.info.cubemap_res, sky.info.num_mips)
+        pt = rt.PathTracer(gpu_ctx, gscene, W, H)
+        pt.render(view, 1, cfg=Hdri, envmap=env_dev)
+        g = pt.read()
+        d = rt.make_pathtrace_desc(view, W, H, 1, cfg=Hdri, envmap=(host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips))
+        o = helmet_oracle.pathtrace(d, num_threads=8)
+        assert g["stats"].total_rays() == o["stats"].total_rays()
+        gt = g["target"].view(np.float16).astype(np.float32); ot = o["target"].view(np.float16).astype(np.float32)
+        same = (g["target"] == o["target"]).all(axis=-1)
+        rel = np.abs(gt - ot) / np.maximum(np.abs(ot), 1e-3)
+        ok = same | (rel <= 2.0 ** -7).all(axis=-1)
+        assert ok.mean() > 0.999 and same.mean() > 0.995, (ok.mean(), same.mean())
+        # primary rays that miss see the cube, not the analytic sky
+        pt1 = rt.PathTracer(gpu_ctx, gscene, W, H); pt1.render(view, 1, envmap=env_dev)
+        assert not np.array_equal(pt1.read()["target"][0, 0], g["target"][0, 0])
+        with pytest.raises(rt.IncrError):
+            pt.render(view, 1, cfg=Hdri)                                                  # mode 0 without a cube
+        pt.close(); pt1.close(); sky.close()
+    finally:
+        gscene.close()

@@ -213,6 +213,15 @@ struct Desc {
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }
+namespace DebugVizPass {     // render-jobs/debug-visualization.inl:3-18
+struct Desc {
+    FShaderSurface* visBuffer; FShaderSurface* gbuffers[3]; FShaderSurface* target; FShaderSurface* depthBuffer;
+    FShaderSurface* aoBuffer; FShaderSurface* bentNormalsBuffer; FShaderBuffer* indirectArgsBuffer;
+    Vector2 jitter; FConfig renderConfig; const FScene* scene; const FView* view;
+    const FScene* sceneConstantBuffer; FSystemBuffer* viewConstantBuffer;
+};
+Result Execute(Sync* jobSync, const Desc& passDesc);
+}
 namespace TAAResolvePass {   // render-jobs/taa-resolve.inl:3-14
 struct Desc {
     FShaderSurface* source; FShaderSurface* target;

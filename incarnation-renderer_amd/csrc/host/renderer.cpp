@@ -188,6 +188,23 @@ Result EnvironmentmapPass::Execute(Sync* jobSync, const Desc& p) {        // env
     return done(jobSync->Execute(token, [&] { return incr_environmentmap(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
+Result DebugVizPass::Execute(Sync* jobSync, const Desc& p) {              // debug-visualization.inl:20-170
+    const size_t token = jobSync->GetToken();
+    incr_debug_viz_desc d = {};
+    d.view = &p.viewConstantBuffer->m_viewConstants; d.viewmode = p.renderConfig.Viewmode;
+    d.vis_buffer = (const uint32_t*)p.visBuffer->m_devicePtr;
+    d.gbuffer_basecolor = (const uint32_t*)p.gbuffers[0]->m_devicePtr; d.gbuffer_normals = (const uint32_t*)p.gbuffers[1]->m_devicePtr;
+    d.gbuffer_metallic_roughness_ao = (const uint32_t*)p.gbuffers[2]->m_devicePtr;
+    d.depth_buffer = (const float*)p.depthBuffer->m_devicePtr;
+    // with HBAO off the frame clears both targets to 1 (renderer.cpp:1816-1841) = NULL here
+    d.ambient_occlusion = (p.renderConfig.EnableHBAO && p.aoBuffer) ? (const uint8_t*)p.aoBuffer->m_devicePtr : nullptr;
+    d.bent_normals = (p.renderConfig.EnableHBAO && p.bentNormalsBuffer) ? (const uint32_t*)p.bentNormalsBuffer->m_devicePtr : nullptr;
+    d.color_target = (uint32_t*)p.target->m_devicePtr;
+    d.light_cluster_slices = (uint32_t)p.renderConfig.LightClusterDimZ;    // :150
+    d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1; d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_debug_visualization(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
 Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa-resolve.inl:16-118
     const size_t token = jobSync->GetToken();
     incr_view_constants vc = {};
@@ -423,7 +440,16 @@ int Render(State& s, const FRenderState& renderState) {
             skyDesc.viewConstantBuffer = &cbViewConstants;
             DynamicSkyPass::Execute(jobSync, skyDesc);
         }
-        // debug viz, highlight (:1961-2001): outside this library
+        const bool bDebugView = c.Viewmode != 0 && c.Viewmode != 1;            // :1961 (Normal, LightingOnly)
+        if (bDebugView) {                                                      // :1962-1984; the editor's highlight pass (:1986-2000) is UI
+            DebugVizPass::Desc desc = {};
+            desc.visBuffer = &s.visBuffer; desc.gbuffers[0] = &s.gbuffer_basecolor; desc.gbuffers[1] = &s.gbuffer_normals;
+            desc.gbuffers[2] = &s.gbuffer_metallicRoughnessAo; desc.target = &s.hdrRasterSceneColor; desc.depthBuffer = &s.depthBuffer;
+            desc.aoBuffer = &s.aoBuffer; desc.bentNormalsBuffer = &s.bentNormalsBuffer; desc.indirectArgsBuffer = nullptr;
+            desc.jitter = pixelJitter; desc.renderConfig = c; desc.scene = scene; desc.view = &renderState.m_view;
+            desc.sceneConstantBuffer = scene; desc.viewConstantBuffer = &cbViewConstants;
+            DebugVizPass::Execute(jobSync, desc);
+        }
 
         FShaderSurface* hdrOut = &s.hdrRasterSceneColor;
         if (c.EnableTAA) {                                                     // :2003-2026

@@ -897,6 +897,58 @@ __global__ __launch_bounds__(256) void environmentmap_kernel(const EnvmapParams 
     P.color[i] = pack_r11g11b10(luminance, P.rounding);
 }
 
+// ---------------------------------------------------------------------------------------------- debug views
+// debug-visualization.hlsl:52-203: overwrites the HDR colour target, no depth test, no blending
+DI f3 hsv2rgb(f3 hsv) {                                                       // common/color-space.hlsli:2-48
+    f3 sat;
+    while (hsv.x < 0) hsv.x += 360;
+    while (hsv.x > 360) hsv.x -= 360;
+    if (hsv.x < 120) { sat.x = (120 - hsv.x) / 60.0f; sat.y = hsv.x / 60.0f; sat.z = 0; }
+    else if (hsv.x < 240) { sat.x = 0; sat.y = (240 - hsv.x) / 60.0f; sat.z = (hsv.x - 120) / 60.0f; }
+    else { sat.x = (hsv.x - 240) / 60.0f; sat.y = 0; sat.z = (360 - hsv.x) / 60.0f; }
+    sat.x = hmin(sat.x, 1.f); sat.y = hmin(sat.y, 1.f); sat.z = hmin(sat.z, 1.f);
+    return {((1 - hsv.y) + hsv.y * sat.x) * hsv.z, ((1 - hsv.y) + hsv.y * sat.y) * hsv.z, ((1 - hsv.y) + hsv.y * sat.z) * hsv.z};
+}
+DI float debug_halton(uint32_t sampleIndex, uint32_t base) {                  // common/uniform-sampling.hlsli:123-136
+    float result = 0.f, f = 1.f;
+    while (sampleIndex > 0) { f = f / (float)base; result += f * (float)(sampleIndex % base); sampleIndex = sampleIndex / base; }
+    return result;
+}
+__global__ __launch_bounds__(256) void debug_viz_kernel(const DebugVizParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.y1) return;
+    const size_t i = (size_t)y * P.W + x;
+    f3 c = {0.f, 0.f, 0.f};
+    switch (P.viewmode) {
+    case 2: { const float g = unpack_unorm8x4(P.g2[i]).y; c = {g, g, g}; break; }
+    case 3: { const float r = unpack_unorm8x4(P.g2[i]).x; c = {r, r, r}; break; }
+    case 4: { const f4 b = unpack_unorm8x4(P.g0[i]); c = {b.x, b.y, b.z}; break; }
+    case 8: case 9: {
+        const uint32_t v = P.vis[i];
+        const uint32_t objectId = P.usePrims ? v >> 20 : v >> 7, triangleId = P.usePrims ? v & 0xfffffu : v & 127u;
+        c = P.viewmode == 8 ? hsv2rgb({debug_halton(objectId, 3) * 360.f, 0.85f, 0.95f}) : hsv2rgb({debug_halton(triangleId, 5) * 360.f, 0.85f, 0.95f});
+        break;
+    }
+    case 10: case 13: {
+        const uint32_t n = P.viewmode == 10 ? P.g1[i] : (P.bent ? P.bent[i] : 0x3c003c00u);
+        const f3 N = OctDecode({f16_bits_to_f32(n & 0xffffu), f16_bits_to_f32(n >> 16)});
+        c = {N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f};
+        break;
+    }
+    case 11: {
+        const f2 uv = {((float)x + 0.5f) / (float)P.W, ((float)y + 0.5f) / (float)P.H};
+        const f4 pv = mul_vec4({2.f * uv.x - 1.f, -2.f * uv.y + 1.f, hmax(0.001f, P.depth[i]), 1.f}, P.invProj);
+        const float z = pv.z / pv.w;
+        const uint32_t sliceIndex = ftou(floorf(P.sliceScale * logf(z) + P.sliceBias));
+        c = hsv2rgb({(float)sliceIndex / P.numSlices * 360.f, 0.85f, 0.95f});
+        break;
+    }
+    case 12: { const float a = P.ao ? (float)P.ao[i] / 255.f : 1.f; c = {a, a, a}; break; }
+    default: break;
+    }
+    P.color[i] = pack_r11g11b10(c, P.rounding);
+}
+
 // ---------------------------------------------------------------------------------------------- TAA resolve
 DI f3 load_hdr(const uint32_t* __restrict__ img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {
     if (x >= W || y >= H) return {0.f, 0.f, 0.f};
@@ -1024,6 +1076,11 @@ extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStre
 extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(environmentmap_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(debug_viz_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream) {

@@ -22,6 +22,7 @@ extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStre
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
@@ -459,6 +460,30 @@ int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* d, in
     P.skyBrightness = d->sky_brightness;
     memcpy(P.invParallaxViewProj, d->view->envmap_inv_parallax_view_proj.m, 64);
     HIP_TRY(incr_launch_environmentmap(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+int incr_debug_visualization(incr_context* ctx, const incr_debug_viz_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->color_target) return fail(INCR_ERR_INVALID_ARGUMENT, "color_target is NULL");
+    const int m = d->viewmode;
+    if (m < 0 || m > 13) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d out of range (0..13)", m);
+    if (((m == 2 || m == 3) && !d->gbuffer_metallic_roughness_ao) || (m == 4 && !d->gbuffer_basecolor) || ((m == 8 || m == 9) && !d->vis_buffer) ||
+        (m == 10 && !d->gbuffer_normals) || (m == 11 && (!d->depth_buffer || !d->light_cluster_slices)))
+        return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d: its source surface is NULL", m);
+    DebugVizParams P; memset(&P, 0, sizeof P);
+    P.W = d->view->res_x; P.H = d->view->res_y; scissor_rows(*d->view, &P.y0, &P.y1);
+    P.rounding = d->storage_rounding; P.viewmode = m; P.usePrims = d->use_primitives;
+    P.vis = d->vis_buffer; P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao;
+    P.depth = d->depth_buffer; P.ao = d->ambient_occlusion; P.bent = d->bent_normals; P.color = d->color_target;
+    // debug-visualization.hlsl:176-181: zFar 1000, zNear 5 -- logf of the constants once, on the host
+    P.numSlices = (float)d->light_cluster_slices;
+    P.sliceScale = P.numSlices / logf(1000.f / 5.f); P.sliceBias = -logf(5.f) * P.sliceScale;
+    memcpy(P.invProj, d->view->inv_proj_transform.m, 64);
+    HIP_TRY(incr_launch_debug_viz(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 

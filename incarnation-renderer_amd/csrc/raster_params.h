@@ -154,6 +154,15 @@ struct EnvmapParams {
     float skyBrightness, invParallaxViewProj[16];
 };
 
+struct DebugVizParams {
+    uint32_t W, H, y0, y1; int32_t rounding, viewmode, usePrims;
+    const uint32_t* __restrict__ vis; const uint32_t* __restrict__ g0; const uint32_t* __restrict__ g1; const uint32_t* __restrict__ g2;
+    const float* __restrict__ depth; const uint8_t* __restrict__ ao; const uint32_t* __restrict__ bent;
+    uint32_t* __restrict__ color;
+    float numSlices, sliceScale, sliceBias;        // slices / log(1000 / 5), -log(5) * scale: logf once on the host
+    float invProj[16];
+};
+
 struct TaaParams {
     uint32_t W, H, historyIndex; int32_t rounding;
     const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;

@@ -210,6 +210,13 @@ class EnvironmentmapDesc(C.Structure):
                 ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32), ("sky_brightness", C.c_float), ("storage_rounding", C.c_int32)]
 
 
+class DebugVizDesc(C.Structure):
+    _fields_ = [("view", _VC), ("viewmode", C.c_int32), ("vis_buffer", C.c_void_p), ("gbuffer_basecolor", C.c_void_p),
+                ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p), ("depth_buffer", C.c_void_p),
+                ("ambient_occlusion", C.c_void_p), ("bent_normals", C.c_void_p), ("color_target", C.c_void_p),
+                ("light_cluster_slices", C.c_uint32), ("use_primitives", C.c_int32), ("storage_rounding", C.c_int32)]
+
+
 class HbaoDesc(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("view", _VC), ("depth_buffer", C.c_void_p), ("gbuffer_normals", C.c_void_p),
                 ("ao_target", C.c_void_p), ("bent_normal_target", C.c_void_p), ("ray_stats", C.c_void_p), ("storage_rounding", C.c_int32)]

@@ -258,6 +258,14 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
         d.color_target, d.depth_buffer = surf["color"], surf["depth"]
         d.turbidity, d.storage_rounding = cfg.Turbidity, storage_rounding
         out.append(("dynamic_sky", d))
+    if cfg.Viewmode not in (0, 1):  # renderer.cpp:1961-1984 bDebugView
+        d = A.DebugVizDesc(); d.view, d.viewmode = vcp, cfg.Viewmode
+        d.vis_buffer, d.gbuffer_basecolor, d.gbuffer_normals, d.gbuffer_metallic_roughness_ao = surf["vis"], surf["gbuffer_basecolor"], surf["gbuffer_normals"], surf["gbuffer_mra"]
+        d.depth_buffer, d.color_target = surf["depth"], surf["color"]
+        d.ambient_occlusion = surf["ao"] if cfg.EnableHBAO else None
+        d.bent_normals = surf["bent_normals"] if cfg.EnableHBAO else None
+        d.light_cluster_slices, d.use_primitives, d.storage_rounding = cfg.LightClusterDimZ, use_prims, storage_rounding
+        out.append(("debug_visualization", d))
     if cfg.EnableTAA:
         d = A.TaaResolveDesc(); d.view = C.pointer(vc_taa)
         d.hdr_scene_color, d.depth_buffer = surf["color"], surf["depth"]
@@ -358,7 +366,7 @@ class RasterRenderer:
 
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
-                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap")
+                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap", debug_visualization="incr_debug_visualization")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg

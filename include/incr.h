@@ -400,6 +400,28 @@ typedef struct incr_environmentmap_desc {
 } incr_environmentmap_desc;
 int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* desc, incr_stream stream);
 
+/* RenderJob::DebugVizPass::Execute (render-jobs/debug-visualization.inl; shaders/postprocess/debug-visualization.hlsl): when
+ * FConfig::Viewmode is neither Normal (0) nor LightingOnly (1) a full-screen pass overwrites the HDR colour target with
+ * Roughness 2, Metallic 3, BaseColor 4, ObjectIds 8 / TriangleIds 9 (Halton hue of the visibility id), Normalmap 10,
+ * LightClusterSlices 11, AmbientOcclusion 12, BentNormals 13; the other modes write 0.  The mouse-pick store that feeds
+ * the editor's highlight pass is UI and not part of this library. */
+typedef struct incr_debug_viz_desc {
+    const incr_view_constants* view;
+    int32_t  viewmode;
+    const uint32_t* vis_buffer;
+    const uint32_t* gbuffer_basecolor;
+    const uint32_t* gbuffer_normals;
+    const uint32_t* gbuffer_metallic_roughness_ao;
+    const float*    depth_buffer;
+    const uint8_t*  ambient_occlusion; /* NULL = cleared to 1 */
+    const uint32_t* bent_normals;      /* NULL = cleared to (1, 1) */
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT */
+    uint32_t light_cluster_slices;     /* FConfig::LightClusterDimZ */
+    int32_t  use_primitives;           /* USING_MESHLETS = 0 */
+    int32_t  storage_rounding;
+} incr_debug_viz_desc;
+int incr_debug_visualization(incr_context* ctx, const incr_debug_viz_desc* desc, incr_stream stream);
+
 /* RenderJob::TAAResolvePass::Execute (render-jobs/taa-resolve.inl; shaders/postprocess/taa-resolve.hlsl).  The reference
  * reads and writes ONE accumulation surface in place (a data race across pixels); here history is read from
  * `history_in` and the result written to `history_out` (they may not alias): the race-free reading of the shader. */

@@ -70,6 +70,7 @@ def lib():
         L.orc_taa_resolve.argtypes = [C.POINTER(A.TaaResolveDesc)]
         L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
         L.orc_environmentmap.argtypes = [C.POINTER(A.EnvironmentmapDesc)]
+        L.orc_debug_visualization.argtypes = [C.POINTER(A.DebugVizDesc)]
         L.orc_hbao.argtypes = [vp, C.POINTER(A.HbaoDesc), C.POINTER(C.c_uint64)]
         L.orc_hb_math.argtypes = [C.c_float, fp]
         L.orc_oct_roundtrip.argtypes = [fp, fp, fp]
@@ -220,6 +221,8 @@ def run_pass(scene, name, desc):
         L.orc_dynamic_sky(h, C.byref(desc))
     elif name == "environmentmap":
         L.orc_environmentmap(C.byref(desc))
+    elif name == "debug_visualization":
+        L.orc_debug_visualization(C.byref(desc))
     elif name == "taa_resolve":
         L.orc_taa_resolve(C.byref(desc))
     else:

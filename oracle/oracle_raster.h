@@ -697,6 +697,67 @@ static void environmentmap_pass(const incr_environmentmap_desc& d) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ debug views
+// shaders/postprocess/debug-visualization.hlsl:52-203 + render-jobs/debug-visualization.inl: a full-screen pass without
+// depth test or blending that overwrites the HDR colour target when Viewmode is neither Normal nor LightingOnly.
+// (The mouse-pick store into the highlight pass's indirect args, :97-131, is UI and not restated.)
+static float3 hsv2rgb(float3 hsv) {                                           // common/color-space.hlsli:2-48
+    float3 sat;
+    while (hsv.x < 0) hsv.x += 360;
+    while (hsv.x > 360) hsv.x -= 360;
+    if (hsv.x < 120) { sat.x = (120 - hsv.x) / 60.0f; sat.y = hsv.x / 60.0f; sat.z = 0; }
+    else if (hsv.x < 240) { sat.x = 0; sat.y = (240 - hsv.x) / 60.0f; sat.z = (hsv.x - 120) / 60.0f; }
+    else { sat.x = (hsv.x - 240) / 60.0f; sat.y = 0; sat.z = (360 - hsv.x) / 60.0f; }
+    sat.x = hmin(sat.x, 1.f); sat.y = hmin(sat.y, 1.f); sat.z = hmin(sat.z, 1.f);
+    return {((1 - hsv.y) + hsv.y * sat.x) * hsv.z, ((1 - hsv.y) + hsv.y * sat.y) * hsv.z, ((1 - hsv.y) + hsv.y * sat.z) * hsv.z};
+}
+static float DebugHalton(uint32_t sampleIndex, uint32_t base) {               // common/uniform-sampling.hlsli:123-136
+    float result = 0.f, f = 1.f;
+    while (sampleIndex > 0) { f = f / (float)base; result += f * (float)(sampleIndex % base); sampleIndex = sampleIndex / base; }
+    return result;
+}
+static void debug_visualization(const incr_debug_viz_desc& d) {
+    const incr_view_constants& vc = *d.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    const Mat4 ip = to_mat4(vc.inv_proj_transform);
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        float3 c = {0.f, 0.f, 0.f};
+        switch (d.viewmode) {
+        case 2: { const float g = unpack_unorm8x4(d.gbuffer_metallic_roughness_ao[i]).y; c = {g, g, g}; break; }
+        case 3: { const float r = unpack_unorm8x4(d.gbuffer_metallic_roughness_ao[i]).x; c = {r, r, r}; break; }
+        case 4: { const float4 b = unpack_unorm8x4(d.gbuffer_basecolor[i]); c = {b.x, b.y, b.z}; break; }
+        case 8: case 9: {
+            const uint32_t v = d.vis_buffer[i];
+            const uint32_t objectId = d.use_primitives ? v >> 20 : v >> 7, triangleId = d.use_primitives ? v & 0xfffffu : v & 127u;
+            c = d.viewmode == 8 ? hsv2rgb({DebugHalton(objectId, 3) * 360.f, 0.85f, 0.95f}) : hsv2rgb({DebugHalton(triangleId, 5) * 360.f, 0.85f, 0.95f});
+            break;
+        }
+        case 10: case 13: {
+            const uint32_t n = d.viewmode == 10 ? d.gbuffer_normals[i] : (d.bent_normals ? d.bent_normals[i] : 0x3c003c00u);
+            const float3 N = OctDecode({f16_to_f32((uint16_t)(n & 0xffffu)), f16_to_f32((uint16_t)(n >> 16))});
+            c = {N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f};
+            break;
+        }
+        case 11: {
+            const float2 uv = {((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
+            const float4 ndc = {2.f * uv.x - 1.f, -2.f * uv.y + 1.f, hmax(0.001f, d.depth_buffer[i]), 1.f};
+            const float4 pv = mul_vec4(ndc, ip);
+            const float z = pv.z / pv.w;
+            const float numSlices = (float)d.light_cluster_slices;
+            const float scale = numSlices / logf(1000.f / 5.f), bias = -logf(5.f) * scale;
+            const uint32_t sliceIndex = ftou(floorf(scale * logf(z) + bias));
+            c = hsv2rgb({(float)sliceIndex / numSlices * 360.f, 0.85f, 0.95f});
+            break;
+        }
+        case 12: { const float a = d.ambient_occlusion ? (float)d.ambient_occlusion[i] / 255.f : 1.f; c = {a, a, a}; break; }
+        default: break;                                                       // Emissive / NanCheck / Reflections: return 0.xxxx
+        }
+        d.color_target[i] = pack_r11g11b10(c, d.storage_rounding);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TAA resolve
 static inline float3 load_hdr(const uint32_t* img, uint32_t W, uint32_t H, uint32_t x, uint32_t y) {       // Texture2D.Load: out of bounds -> 0
     if (x >= W || y >= H) return {0, 0, 0};
@@ -771,6 +832,7 @@ void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
     gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding, d->use_primitives != 0);
 }
 void orc_environmentmap(const incr_environmentmap_desc* d) { environmentmap_pass(*d); }
+void orc_debug_visualization(const incr_debug_viz_desc* d) { debug_visualization(*d); }
 void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }
 void orc_hb_math(float x, float out[3]) { out[0] = hb_sin(x); out[1] = hb_cos(x); out[2] = hb_acos(x); }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {

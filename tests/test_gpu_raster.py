@@ -209,6 +209,53 @@ def test_hbao_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, H):
         osc.close(); gscene.close()
 
 
+def test_debug_view_modes_parity(rt, R, ob, A, sio, gpu_ctx, sponza_small):
+    """RenderJob::DebugVizPass: every Viewmode the shader implements (and the ones it answers with 0), bit-exact against
+    the oracle except LightClusterSlices, whose per-pixel logf may move a pixel across a slice boundary."""
+    W, H = 192, 108
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    osc = ob.OracleScene(sponza_small)
+    try:
+        seen = {}
+        for mode in (2, 3, 4, 5, 8, 9, 10, 11, 12, 13):
+            class Cfg(A.FConfig):
+                Viewmode = mode
+                EnableHBAO = mode in (12, 13)
+                UseBentNormals = mode in (12, 13)
+                EnableTAA = False
+            (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, Cfg)
+            _, hs = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H, cfg=Cfg)
+            if mode == 11:
+                assert (gs["color"] == hs.arr["color"]).mean() > 0.999
+            else:
+                np.testing.assert_array_equal(gs["color"], hs.arr["color"], err_msg="viewmode %d" % mode)
+            # tonemap passes debug views through (tonemap.hlsl:35-37): LDR = sRGB-encoded colour target, +-1 LSB (powf)
+            ldr = ob.tonemap(gs["color"], Cfg.Exposure, mode)
+            assert np.abs(gs["ldr"].view(np.uint8).reshape(H, W, 4).astype(np.int32) - ldr.astype(np.int32)).max() <= 1
+            seen[mode] = gs["color"]
+            # the C++ renderer takes the same branch
+            hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Cfg, sh9_rgb=DEFAULT_SH9)
+            hr.render(view); gpu_ctx.synchronize()
+            np.testing.assert_array_equal(hr.download(A.SURFACE_HDR_RASTER), gs["color"], err_msg="C++ renderer viewmode %d" % mode)
+            hr.close()
+        assert (seen[5] == 0).all()                                                  # Emissive is not a raster debug view: 0.xxxx
+        vis = hs.arr["vis"]
+        for mode, key in ((8, vis >> 7), (9, vis & 127)):                            # one colour per id, several ids
+            cols = {}
+            for k, c in zip(key.ravel()[::7], seen[mode].ravel()[::7]):
+                assert cols.setdefault(int(k), int(c)) == int(c)
+            assert len(set(cols.values())) > 10
+        assert len(np.unique(seen[11])) > 3 and len(np.unique(seen[12])) > 16
+        d = A.DebugVizDesc(); vc2 = R.make_view_constants(view, W, H); d.view = C.pointer(vc2); d.viewmode = 4
+        d.color_target = gpu_ctx.buffer(W * H * 4)
+        assert gpu_ctx.lib.incr_debug_visualization(gpu_ctx.handle, C.byref(d), None) == -1 and b"source surface" in gpu_ctx.lib.incr_last_error()
+        d.viewmode = 14
+        assert gpu_ctx.lib.incr_debug_visualization(gpu_ctx.handle, C.byref(d), None) == -1
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

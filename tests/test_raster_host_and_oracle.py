@@ -343,6 +343,34 @@ def test_oracle_hbao_and_bent_normals(sponza_small, sio, R, ob, A):
     osc.close()
 
 
+def test_oracle_debug_views(helmet, sio, R, ob, A):
+    """debug-visualization.hlsl restated: the colour target is overwritten by the selected G-buffer channel / id hue."""
+    W = H = 96
+    osc = ob.OracleScene(helmet)
+    view = sio.FView().reset(helmet, aspect=1.0)
+    out = {}
+    for mode in (3, 4, 7, 9, 10):
+        class Cfg(A.FConfig):
+            Viewmode = mode
+            EnableTAA = False
+        _, hs = run_oracle_frame(ob, R, A, helmet, osc, view, W, H, cfg=Cfg)
+        out[mode] = (ob.unpack_r11g11b10(hs.arr["color"]), hs)
+    covered = out[3][1].arr["vis"] != 0xFFFFF000
+    mra = out[3][1].arr["gbuffer_mra"]
+    np.testing.assert_allclose(out[3][0][..., 0], (mra & 255) / 255.0, atol=1 / 64)            # metallic, 6-bit mantissa store
+    assert (out[3][0][..., 0] == out[3][0][..., 1]).all()
+    base = out[4][1].arr["gbuffer_basecolor"]
+    np.testing.assert_allclose(out[4][0][..., 2], ((base >> 16) & 255) / 255.0, atol=1 / 32)
+    assert (out[7][1].arr["color"] == 0).all()                                                 # Reflections: not a raster view -> 0
+    tri = (out[9][1].arr["vis"] & 127)[covered]
+    cols = out[9][1].arr["color"][covered]
+    assert len({(int(t), int(c)) for t, c in zip(tri, cols)}) == len(set(tri.tolist())) > 20     # one hue per triangle id
+    g1 = out[10][1].arr["gbuffer_normals"]
+    n10 = out[10][0][covered]
+    assert (n10 >= 0).all() and (n10 <= 1.0).all() and n10.std() > 0.05 and g1[covered].any()
+    osc.close()
+
+
 def test_oct_encoding_round_trip(ob):
     rng = np.random.default_rng(3)
     n = rng.normal(size=(500, 3)).astype(np.float32)

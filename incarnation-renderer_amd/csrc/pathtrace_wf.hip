@@ -36,7 +36,16 @@
 namespace incr {
 
 static constexpr int kWfBlock = 256;
-static constexpr int kWfStackLds = 8;                   // LDS stack entries per lane in the traversal kernels
+// Waves per SIMD the shade / accumulate kernels are compiled for (measured at 4K Sponza-stat, ms per frame for
+// 3 / 4 / 5 / 6 / 8 waves: shade 7.5 / 7.5 / 9.5 / 10.8 / 10.9, accumulate 4.6 / 3.8 / 5.0 / 5.3 / 5.9): one more resident
+// wave pays for accumulate; below 128 VGPRs both kernels spill and lose more than the occupancy gives.
+#ifndef INCR_SHADE_WAVES
+#define INCR_SHADE_WAVES 3
+#endif
+#ifndef INCR_ACCUM_WAVES
+#define INCR_ACCUM_WAVES 4
+#endif
+static constexpr int kWfStackLds = 8;                  // LDS stack entries per lane in the traversal kernels
 using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shadow) traversal
 using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
 static constexpr uint32_t kSkySlot = 127;               // bit 127 of the request mask = the sky sample
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(kWfBlock, 8) void wf_extend_kernel(const PtParams P
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-__global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce) {
+__global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     Counters cnt = {0, 0, 0, 0, 0};
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
                     const f3 V = -rayD;
                     const f3 attenV = attenuation;
                     // ---- enumerate the shadow rays of this vertex as a request mask ----
-                    uint32_t req[4] = {0u, 0u, 0u, 0u};
+                    uint32_t req0 = 0u, req1 = 0u, req2 = 0u, req3 = 0u;      // four registers: a dynamically indexed req[4] would live in scratch
                     uint32_t flags = 0u;
                     const bool finiteAtt = fabsf(attenV.x) < 3.0e38f && fabsf(attenV.y) < 3.0e38f && fabsf(attenV.z) < 3.0e38f;
                     const uint32_t numCells = P.gridDim[0] * P.gridDim[1] * P.gridDim[2];
@@ -282,7 +291,11 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
                             incr_light light; const float* m; bool haveT;
                             load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
                             const LightSample s = light_setup(light, m, haveT, hitPosition, N);
-                            if (s.needsShadow) { req[k >> 5] |= 1u << (k & 31u); cnt.lightShadow++; }
+                            if (s.needsShadow) {
+                                const uint32_t bit = 1u << (k & 31u);
+                                if (k < 32u) req0 |= bit; else if (k < 64u) req1 |= bit; else if (k < 96u) req2 |= bit; else req3 |= bit;
+                                cnt.lightShadow++;
+                            }
                         }
                         for (uint32_t k = n; k < hi - lo; ++k) {      // > 127 candidates in one cell: traced inside accumulate, counted here
                             incr_light light; const float* m; bool haveT;
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
                     const f3 skyDir = CosineSampleHemisphere(us);
                     const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
                     const float skyNoL = saturate(dot(N, skyDir));
-                    if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req[3] |= 0x80000000u; cnt.skyShadow++; }
+                    if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req3 |= 0x80000000u; cnt.skyShadow++; }
                     // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
                     if (pathLength < 4) {
                         uint32_t setCopy = sampleSetIndex;
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(const PtParams P, co
                     // accumulate needs V = -rayD, but rayD[pid] may now hold the continuation ray: keep the incoming direction in
                     // the record (x) and in the no longer needed t/u slots of the hit buffer (y, z)
                     vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, rayD.x);
-                    *(uint4*)(vtx + 5) = make_uint4(req[0], req[1], req[2], req[3]);
+                    *(uint4*)(vtx + 5) = make_uint4(req0, req1, req2, req3);
                     B.hit[pid] = make_uint4(h.x, __float_as_uint(rayD.y), __float_as_uint(rayD.z), 0u);
                 }
             }
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
-__global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
+__global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
     const uint32_t count = B.counters[bounce];
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
@@ -459,7 +472,6 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
         MatProps matInfo = {};
         matInfo.basecolor = basecolor; matInfo.metallic = v0.w; matInfo.roughness = v1.w;
         const uint32_t cell = __float_as_uint(v3.w);
-        const uint32_t words[4] = {vis.x, vis.y, vis.z, vis.w};
         if (P.directLighting && P.lightCount > 0) {
             const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
             const uint32_t n = hi - lo;
@@ -469,7 +481,10 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
                 const LightSample s = light_setup(light, m, haveT, hitPosition, N);
                 f3 radianceOut = {0.f, 0.f, 0.f};
                 bool visible;
-                if (k < kSkySlot) visible = (words[k >> 5] >> (k & 31u)) & 1u;
+                if (k < kSkySlot) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
+                    const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
+                    visible = (w >> (k & 31u)) & 1u;
+                }
                 else {   // more than 127 candidate lights in one cell: traced here (slow path, private-memory stack)
                     visible = false;
                     if (s.needsShadow) { LaneStackT<0, 1> ps; ps.bind(nullptr, nullptr); ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_accumulate_kernel(const PtParams 
             const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
-            if (words[3] >> 31) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
+            if (vis.w >> 31) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
         }

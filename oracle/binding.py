@@ -71,6 +71,7 @@ def lib():
         L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
         L.orc_environmentmap.argtypes = [C.POINTER(A.EnvironmentmapDesc)]
         L.orc_debug_visualization.argtypes = [C.POINTER(A.DebugVizDesc)]
+        L.orc_cluster_frustum.argtypes = [C.POINTER(u32), C.POINTER(u32), C.c_float, C.c_float, C.POINTER(A.Matrix), C.POINTER(A.Matrix), fp]
         L.orc_hbao.argtypes = [vp, C.POINTER(A.HbaoDesc), C.POINTER(C.c_uint64)]
         L.orc_hb_math.argtypes = [C.c_float, fp]
         L.orc_oct_roundtrip.argtypes = [fp, fp, fp]

@@ -831,6 +831,11 @@ void orc_visibility(void* scene, const incr_visibility_desc* d) {
 void orc_gbuffer(void* scene, const incr_gbuffer_desc* d) {
     gbuffer_pass(*(Scene*)scene, *d->view, d->vis_buffer, d->gbuffer_basecolor, d->gbuffer_normals, d->gbuffer_metallic_roughness_ao, d->color_target, d->storage_rounding, d->use_primitives != 0);
 }
+// KAT hook: the six planes (near, far, left, right, bottom, top) of one light cluster, 24 floats
+void orc_cluster_frustum(const uint32_t ci[3], const uint32_t grid[3], float zNear, float zFar, const incr_matrix* proj, const incr_matrix* invViewProj, float out[24]) {
+    const Frustum6 f = GetClusterFrustum(ci, grid, zNear, zFar, to_mat4(*proj), to_mat4(*invViewProj));
+    memcpy(out, &f, sizeof f);
+}
 void orc_environmentmap(const incr_environmentmap_desc* d) { environmentmap_pass(*d); }
 void orc_debug_visualization(const incr_debug_viz_desc* d) { debug_visualization(*d); }
 void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }

@@ -256,6 +256,30 @@ def test_debug_view_modes_parity(rt, R, ob, A, sio, gpu_ctx, sponza_small):
         osc.close(); gscene.close()
 
 
+def test_raster_crop_matches_committed_golden(rt, R, ob, A, sio, gpu_ctx, helmet):
+    """tests/golden/helmet_raster_64.npz (tools/make_golden.py): the HIP frame reproduces the committed 64x64 ids, depth and
+    G-buffers bit for bit, and the colour target within one storage step."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "helmet_raster_64.npz"))
+    W = H = 64
+
+    class NoTaa(A.FConfig):
+        EnableTAA = False
+    view = sio.FView().reset(helmet, aspect=1.0)
+    gscene = gpu_ctx.create_scene(helmet)
+    try:
+        (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, NoTaa, sh9=np.full((9, 3), 0.25, np.float32))
+        np.testing.assert_array_equal(gs["counts"], g["counts"])
+        np.testing.assert_array_equal(gs["vis"], g["vis"])
+        np.testing.assert_array_equal(gs["depth"].view(np.uint32), g["depth"].view(np.uint32))
+        for key, name in (("g0", "gbuffer_basecolor"), ("g1", "gbuffer_normals"), ("g2", "gbuffer_mra")):
+            np.testing.assert_array_equal(gs[name], g[key], err_msg=key)
+        assert colour_close(ob, gs["color"], g["color"], "colour vs golden") > 0.999
+    finally:
+        gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

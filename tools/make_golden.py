@@ -56,3 +56,75 @@ for n in (2, 3, 4):
 np.savez_compressed(os.path.join(G, "helmet_64.npz"), origins=o, dirs=dr, ids=ids, tuv=tuv, target1=target1, history4=hist,
                     stats=np.array(stats, dtype=np.int64), view=np.asarray(view.view_transform), proj=np.asarray(view.projection_transform))
 print("golden written:", os.listdir(G))
+
+# 3. scalar known-answer tables: float results stored as uint32 bit patterns
+def bits(v):
+    return int(np.float32(v).view(np.uint32))
+
+
+kat = {}
+f3 = lambda *v: (C.c_float * 3)(*v)
+rng = np.random.default_rng(0x6B41)
+rows = []
+for NoH, r in ((1.0, 0.5), (0.9, 0.1), (0.5, 0.9), (0.25, 0.35), (0.001, 1.0)):
+    rows.append(dict(NoH=NoH, r=r, ggx=bits(L.orc_ggx(NoH, r)), pdf=bits(L.orc_ggx_pdf(NoH, r))))
+kat["ggx"] = rows
+kat["g_smith"] = [dict(NoV=a, NoL=b, r=c, direct=bits(L.orc_g_smith_direct(a, b, c)), correlated=bits(L.orc_g_smith_ggx_correlated(a, b, c)))
+                  for a, b, c in ((1.0, 1.0, 0.5), (0.3, 0.8, 0.2), (0.05, 0.5, 0.9), (0.7, 0.001, 0.04))]
+rows = []
+for u, f0 in ((1.0, (0.04, 0.04, 0.04)), (0.5, (0.04, 0.04, 0.04)), (0.0, (0.04, 0.04, 0.04)), (0.2, (1.0, 0.71, 0.29))):
+    o3 = f3(0, 0, 0); L.orc_f_schlick(u, f3(*f0), o3); rows.append(dict(u=u, f0=list(f0), out=[bits(x) for x in o3]))
+kat["f_schlick"] = rows
+kat["exposure"] = [dict(ev100=e, out=bits(L.orc_exposure(e))) for e in (0, 9, 13, 15)]
+rows = []
+for x in ((0.0, 0.18, 1.0), (2.5, 10.0, 1e4), (0.01, 0.5, 0.75)):
+    o3 = f3(0, 0, 0); L.orc_aces_film(f3(*x), o3); rows.append(dict(x=list(x), out=[bits(v) for v in o3]))
+kat["aces_film"] = rows
+sun = sio.sun_direction_from_time_of_day()            # ToD defaults 11.0 h / day 200 / lat 42.5 (inc/common.h:43-46)
+rows = []
+for e in ((0, 1, 0), (1, 0.2, 0), (-0.5, 0.5, 0.7), (0.3, 0.05, -0.9), tuple(float(v) for v in sun), (0, -0.2, 1)):
+    en = np.array(e, np.float64); en = (en / np.linalg.norm(en)).astype(np.float32)
+    o3 = f3(0, 0, 0); L.orc_sky_radiance(f3(*sun), f3(*en), 2.0, o3)
+    rows.append(dict(dir=[bits(v) for v in en], out=[bits(v) for v in o3]))
+kat["preetham"] = dict(sun=[bits(v) for v in sun], turbidity=2.0, samples=rows)
+rows = []
+for _ in range(24):
+    n = rng.normal(size=3); n = (n / np.linalg.norm(n)).astype(np.float32)
+    enc, dec = (C.c_float * 2)(), f3(0, 0, 0)
+    L.orc_oct_roundtrip(f3(*n), enc, dec)
+    rows.append(dict(n=[bits(v) for v in n], enc=[bits(v) for v in enc], dec=[bits(v) for v in dec]))
+kat["oct"] = rows
+kat["visibility_encoding"] = dict(clear=0xFFFFF000, meshlet=[dict(id=i, tri=t, value=(i << 7) | t) for i, t in ((0, 0), (1, 5), (3042, 125), (0xFFFFFF, 127))],
+                                 primitive=[dict(id=i, tri=t, value=(i << 20) | t) for i, t in ((0, 0), (24, 99999), (2046, 0xFFFFF))])
+# cluster grid 16x9x24, near 1, extent 200: slice depths, the pixel->slice scale / bias, frustum planes of two clusters
+import math
+sp = synth = importlib.import_module(PKG + ".synth")
+R = importlib.import_module(PKG + ".raster")
+scene3 = synth.sponza_stat(texture_size=8, tri_scale=1 / 64.0)
+view3 = sio.FView().reset(scene3, aspect=16 / 9)
+vc3 = R.make_view_constants(view3, 1920, 1080)
+grid = (C.c_uint32 * 3)(16, 9, 24)
+planes = {}
+for ci in ((0, 0, 0), (15, 8, 23), (7, 4, 11)):
+    out24 = (C.c_float * 24)()
+    L.orc_cluster_frustum((C.c_uint32 * 3)(*ci), grid, 1.0, 200.0, C.byref(vc3.lightcull_proj_transform), C.byref(vc3.lightcull_inv_view_proj), out24)
+    planes["%d,%d,%d" % ci] = [bits(v) for v in out24]
+scale = np.float32(24.0) / np.float32(math.log(200.0 / 1.0)); bias = -scale * np.float32(math.log(1.0))
+kat["clusters"] = dict(grid=[16, 9, 24], near=1.0, extent=200.0, slice_depths=[bits(np.float32(1.0) * np.float32(np.float32(200.0) ** np.float32(k / 24.0))) for k in (0, 1, 12, 24)],
+                       scale=bits(scale), bias=bits(bias), planes=planes)
+with open(os.path.join(G, "scalar_kats.json"), "w") as f:
+    json.dump(kat, f)
+
+# 4. raster crop (item 9): helmet 64x64 frame without TAA -- visibility ids, depth, G-buffers, colour target
+class NoTaa(A.FConfig):
+    EnableTAA = False
+R.generate_meshlets(s)
+osc = ob.OracleScene(s)                                # a new oracle scene: the first one was packed before the meshlets existed
+hs = ob.HostSurfaces(W, H, s.num_meshlets, 16 * 9 * 24, 64)
+hs.arr["sh9"][:, :3] = 0.25
+vcr = R.make_view_constants(view, W, H)
+for name, dsc in R.build_descs(None, s, vcr, hs.ptr, 0, NoTaa):
+    ob.run_pass(osc, name, dsc)
+np.savez_compressed(os.path.join(G, "helmet_raster_64.npz"), vis=hs.arr["vis"], depth=hs.arr["depth"], g0=hs.arr["gbuffer_basecolor"],
+                    g1=hs.arr["gbuffer_normals"], g2=hs.arr["gbuffer_mra"], color=hs.arr["color"], counts=hs.arr["counts"])
+print("golden written:", sorted(os.listdir(G)))

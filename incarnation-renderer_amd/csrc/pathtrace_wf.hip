@@ -48,7 +48,7 @@ static constexpr int kWfBlock = 256;
 static constexpr int kWfStackLds = 8;                  // LDS stack entries per lane in the traversal kernels
 using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shadow) traversal
 using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
-static constexpr uint32_t kSkySlot = 127;               // bit 127 of the request mask = the sky sample
+static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
 static constexpr uint32_t kChunk = 512;                 // items a wave takes from the device-wide cursor at a time
 static constexpr uint32_t kRefillThreshold = 12;        // refill when at least this many lanes are idle
@@ -437,10 +437,16 @@ __global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P
                 }
                 trav_any_begin(T, origin, L, 0.1f, 1000.f);                            // lighting/common.hlsli:96-100
                 st.reset();
+                // (A last-occluder cache -- test the triangle that blocked the previous ray of this (light-grid cell, light)
+                // first -- was measured and dropped: 24.3 -> 25.1 ms per frame; the requested light rays are within the
+                // lights' 4-unit range window and mostly unoccluded, so the extra triangle test is pure overhead.)
                 tracing = true;
             }
         }
         // ---- one traversal step ----
+        // (Voting for one kind of step per iteration -- node tests or triangle tests, whichever serves more lanes per issued
+        // instruction, the other lanes waiting -- was measured and dropped: extend 19.3 -> 19.3, shadow 24.0 -> 25.1 ms per
+        // frame.  The step is bound by its dependent 80-byte fetch, not by issue slots.)
         if (tracing && trav_any_step(P, st, T)) {
             if (T.occluded) {
                 const uint32_t w = curSlot >> 5, m = 1u << (curSlot & 31u);

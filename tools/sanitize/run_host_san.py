@@ -1,0 +1,74 @@
+"""Drives tools/sanitize/_build/libincr_host_san.so (ASan + UBSan build of the host-only C++) over the test scenes.
+Run through tests/test_host_sanitizers.py, which sets LD_PRELOAD to libasan; exits non-zero on any finding."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+PKG = "incarnation-renderer_amd"
+A = importlib.import_module(PKG + ".ctypes_api")
+sio = importlib.import_module(PKG + ".scene_io")
+synth = importlib.import_module(PKG + ".synth")
+
+L = C.CDLL(os.path.join(ROOT, "tools", "sanitize", "_build", "libincr_host_san.so"))
+vp, u32 = C.c_void_p, C.c_uint32
+L.san_build_scene.restype = C.c_int
+L.san_build_scene.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_uint64), C.c_char_p, u32]
+L.incr_meshletize.restype = C.c_int
+L.incr_meshletize.argtypes = [vp, u32, vp, u32, u32, u32, u32, C.POINTER(vp)]
+L.incr_meshlet_set_counts.restype = u32; L.incr_meshlet_set_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+L.incr_meshlet_set_copy.restype = C.c_int; L.incr_meshlet_set_copy.argtypes = [vp, vp, vp, vp]
+L.incr_meshlet_set_free.restype = None; L.incr_meshlet_set_free.argtypes = [vp]
+L.incr_make_view_constants.restype = C.c_int
+L.incr_make_view_constants.argtypes = [C.POINTER(A.View), C.POINTER(A.View), C.POINTER(C.c_float), C.POINTER(A.Matrix), C.c_float, u32, u32, C.POINTER(A.ViewConstants)]
+
+
+def build(scene, name):
+    d = scene.to_desc()
+    counts = (C.c_uint64 * 4)(); why = C.create_string_buffer(256)
+    rc = L.san_build_scene(C.byref(d), counts, why, 256)
+    assert rc == 0, (name, rc, why.value)
+    assert counts[0] == scene.num_triangles and counts[1] > 0, (name, list(counts))
+    print("%s: %d triangles, %d nodes, %d grid offsets, %d grid lights" % ((name,) + tuple(counts)))
+
+
+def meshletize(scene, name):
+    total = 0
+    for prims in scene.mesh_primitives:
+        for p in prims:
+            n = p["index_count"]
+            stride = scene.accessors[p["index"]][2]
+            idx = np.ascontiguousarray(scene.accessor_array(p["index"], np.uint16 if stride == 2 else np.uint32, 1, n).astype(np.uint32).ravel())
+            nverts = int(idx.max()) + 1 if n else 0
+            pos = np.ascontiguousarray(scene.accessor_array(p["position"], np.float32, 3, nverts))
+            h = vp()
+            rc = L.incr_meshletize(idx.ctypes.data, n, pos.ctypes.data, nverts, 12, 64, 126, C.byref(h))
+            assert rc == 0, (name, rc)
+            nv, nt = u32(), u32()
+            nm = L.incr_meshlet_set_counts(h, C.byref(nv), C.byref(nt))
+            ml = (A.GpuMeshlet * max(nm, 1))(); vi = np.zeros(max(nv.value, 1), np.uint32); tri = np.zeros(max(nt.value, 1), np.uint32)
+            assert L.incr_meshlet_set_copy(h, C.cast(ml, vp), vi.ctypes.data, tri.ctypes.data) == 0
+            assert nt.value == n // 3
+            L.incr_meshlet_set_free(h)
+            total += nm
+    print("%s: %d meshlets" % (name, total))
+
+
+helmet = sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+sponza = synth.sponza_stat(texture_size=8, tri_scale=1.0 / 16.0)
+edge = synth.sponza_stat(texture_size=8, tri_scale=1.0 / 64.0, with_lights=False)
+edge.mesh_visibility = [0] * len(edge.mesh_primitives)          # nothing visible: empty BVH
+for scene, name in ((helmet, "helmet"), (sponza, "sponza_small")):
+    build(scene, name)
+    meshletize(scene, name)
+d = edge.to_desc(); counts = (C.c_uint64 * 4)(); why = C.create_string_buffer(256)
+assert L.san_build_scene(C.byref(d), counts, why, 256) == 0 and counts[0] == 0, (list(counts), why.value)
+view = sio.FView().reset(helmet, aspect=1.0).to_ctypes()
+vc = A.ViewConstants()
+assert L.incr_make_view_constants(C.byref(view), None, (C.c_float * 2)(0.001, -0.002), None, 1.0, 640, 480, C.byref(vc)) == 0
+assert L.incr_make_view_constants(None, None, None, None, 1.0, 640, 480, C.byref(vc)) != 0
+print("host sanitizer run clean")

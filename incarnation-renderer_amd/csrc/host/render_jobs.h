@@ -174,6 +174,15 @@ struct Desc {
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }
+namespace ForwardLightingPass { // render-jobs/forward-pass.inl:3-15
+struct Desc {
+    FShaderSurface* colorTarget; FShaderSurface* depthStencilTarget;
+    uint32_t resX; uint32_t resY;
+    const FScene* scene; const FScene* sceneConstantBuffer; FSystemBuffer* viewConstantBuffer; FConfig renderConfig;
+    FShaderBuffer* rayStatsBuffer = nullptr;        // not in the reference: incr_ray_stats accumulation
+};
+Result Execute(Sync* jobSync, const Desc& passDesc);
+}
 namespace DirectLightingPass { // render-jobs/direct-lighting.inl:3-16
 struct Desc {
     int directionalLightIndex;

@@ -147,6 +147,21 @@ Result HBAO::Execute(Sync* jobSync, const Desc& p) {                      // hba
     return done(jobSync->Execute(token, [&] { return incr_hbao(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
+Result ForwardLightingPass::Execute(Sync* jobSync, const Desc& p) {       // forward-pass.inl:17-190
+    const size_t token = jobSync->GetToken();
+    incr_forward_lighting_desc d = {};
+    d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (float*)p.depthStencilTarget->m_devicePtr;
+    d.sh9_rgba = p.scene->m_skylightSh9;                                  // g_sceneCb.m_skylightProbeIndex
+    d.prefiltered_envmap = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;
+    d.env_brdf = (const uint32_t*)p.scene->m_envBRDF.m_devicePtr; d.env_brdf_width = p.scene->m_envBrdfWidth; d.env_brdf_height = p.scene->m_envBrdfHeight;
+    d.viewmode = p.renderConfig.Viewmode; d.direct_lighting = p.renderConfig.EnableDirectLighting ? 1 : 0;      // forward-pass.inl:95-101 macros
+    d.diffuse_ibl = p.renderConfig.EnableDiffuseIBL ? 1 : 0; d.specular_ibl = p.renderConfig.EnableSpecularIBL ? 1 : 0;
+    d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
+    d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_forward_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
 Result DirectLightingPass::Execute(Sync* jobSync, const Desc& p) {        // direct-lighting.inl:18-112
     const size_t token = jobSync->GetToken();
     incr_direct_lighting_desc d = {};
@@ -399,7 +414,14 @@ int Render(State& s, const FRenderState& renderState) {
             SkyLightingPass::Execute(jobSync, skyLightingDesc);
         }
 
-        if (!c.ForwardLighting) {                                              // :1866-1926 (forward lighting itself is out of scope)
+        if (c.ForwardLighting) {                                               // :1865-1881
+            ForwardLightingPass::Desc forwardDesc = {};
+            forwardDesc.colorTarget = &s.hdrRasterSceneColor; forwardDesc.depthStencilTarget = &s.depthBuffer;
+            forwardDesc.resX = resX; forwardDesc.resY = resY;
+            forwardDesc.scene = scene; forwardDesc.sceneConstantBuffer = scene; forwardDesc.viewConstantBuffer = &cbViewConstants;
+            forwardDesc.renderConfig = c; forwardDesc.rayStatsBuffer = &s.rayStatsBuffer;
+            ForwardLightingPass::Execute(jobSync, forwardDesc);
+        } else {                                                               // :1882-1926
             const int directionalLightIndex = scene->GetDirectionalLight();
             if (directionalLightIndex != -1 && c.EnableDirectLighting) {
                 DirectLightingPass::Desc directLightingDesc = {};
@@ -541,6 +563,7 @@ int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
     f.EnableSpecularIBL = c->enable_specular_ibl != 0;
     f.UseMeshlets = c->use_primitives == 0;
     f.EnableHBAO = c->enable_hbao != 0; f.UseBentNormals = c->use_bent_normals != 0;
+    f.ForwardLighting = c->forward_lighting != 0;
     return INCR_OK;
 }
 

@@ -482,8 +482,16 @@ __global__ __launch_bounds__(256) void vis_setup_prim_kernel(const VisParams P) 
             c[k] = make_float4(cc.x, cc.y, cc.z, cc.w);
             uv[k] = alphaTex >= 0 ? R.pvUv[d.vertexBase + vi] : make_float2(0.f, 0.f);
         }
-        emit_triangle(P, lane, valid, c[0], c[1], c[2], uv[0], uv[1], uv[2], (list << 31) | ((prim << 20) | tri), alphaTex, list == 0);
+        // the forward pass draws primitive by primitive in scene order: no list bit in the depth-tie order key
+        emit_triangle(P, lane, valid, c[0], c[1], c[2], uv[0], uv[1], uv[2], ((P.forward ? 0u : list) << 31) | ((prim << 20) | tri), alphaTex, list == 0);
     }
+}
+// forward-pass.inl:68-179: every primitive of every visible mesh is drawn; CullMode NONE for double-sided materials
+__global__ __launch_bounds__(256) void forward_flags_kernel(const RasterScene S, const PrimDraw* __restrict__ draws, uint32_t numPrims, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numPrims) return;
+    const PrimDraw d = draws[i];
+    flags[i] = S.meshVisibility[d.meshIndex] == 0u ? 0u : (S.materials[d.materialIndex].doubleSided ? 2u : 1u);
 }
 // draw lists -> per-primitive flags for the chunked set-up above
 __global__ __launch_bounds__(256) void prim_flags_kernel(const incr_draw_cmd* __restrict__ defList, const incr_draw_cmd* __restrict__ dsList,
@@ -831,6 +839,114 @@ __global__ __launch_bounds__(kBlock) void hbao_kernel(const HbaoParams P) {     
     }
 }
 
+// ---------------------------------------------------------------------------------------------- forward lighting
+// forward-pass.hlsl vs_main + ps_main over the nearest fragment the forward-order visibility pass found: vertex-shader
+// outputs re-evaluated per pixel and interpolated with the G-buffer pass's barycentric formula.
+__global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardParams P) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = P.y0 + blockIdx.y * 4 + (tid >> 6);
+    uint32_t rays = 0;
+    if (x < P.W && y < P.y1) {
+        const size_t i = (size_t)y * P.W + x;
+        const uint32_t v = P.vis[i];
+        const uint32_t primId = v >> 20, tri = v & 0xfffffu;
+        f3 out = {0.8f, 0.8f, 1.f};                                                  // clearColor, forward-pass.inl:62
+        bool covered = v != 0xFFFFF000u && primId < P.prims.numPrims;
+        PrimDraw d = {};
+        if (covered) { d = P.prims.draws[primId]; covered = tri * 3u + 2u < d.indexCount; }
+        if (covered) {
+            LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
+            const float* __restrict__ l2w = P.S.meshLocalToWorld + (size_t)d.meshIndex * 16;
+            f4 clip[3], wpos[3]; f2 uv[3]; f3 nW[3], tW[3], bW[3];
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {                                       // vs_main :57-90
+                const uint32_t vi = d.vertexBase + P.prims.indices[d.indexBegin + tri * 3u + k];
+                const float4 pos = P.prims.pvPos[vi];
+                wpos[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, l2w);
+                clip[k] = mul_vec4(wpos[k], P.viewProj);
+                const float2 t = P.prims.pvUv[vi]; uv[k] = {t.x, t.y};
+                const float4 n4 = P.prims.pvNormal[vi], t4 = P.prims.pvTangent[vi];
+                const f3 normal = {n4.x, n4.y, n4.z}, tangent = {t4.x, t4.y, t4.z};
+                const f3 bitangent = cross(normal, tangent) * t4.w;
+                const f4 a = mul_vec4({normal.x, normal.y, normal.z, 0.f}, l2w), b = mul_vec4({tangent.x, tangent.y, tangent.z, 0.f}, l2w);
+                const f4 c = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, l2w);
+                nW[k] = {a.x, a.y, a.z}; tW[k] = {b.x, b.y, b.z}; bW[k] = {c.x, c.y, c.z};
+            }
+            const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
+            const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
+            const incr_material mat = P.S.materials[d.materialIndex];
+            const MatProps p = EvaluateMaterialProperties(mat, P.S.textures, P.S.srgbLut, UV);
+            bool done = true;
+            if (P.viewmode == 2) out = mk3(p.roughness);                             // ps_main :95-105 (`#if VIWEMODE == 1` never fires)
+            else if (P.viewmode == 3) out = mk3(p.metallic);
+            else if (P.viewmode == 4) out = p.basecolor;
+            else if (P.viewmode == 5) out = p.emissive;
+            else done = false;
+            if (!done) {
+                const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
+                f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
+                if (p.bHasNormalmap) {
+                    const f3 nm = p.normalmap;
+                    N = normalize(mk3((nm.x * T.x + nm.y * B.x) + nm.z * N.x, (nm.x * T.y + nm.y * B.y) + nm.z * N.y, (nm.x * T.z + nm.y * B.z) + nm.z * N.z));
+                }
+                const f3 wp = interp3({wpos[0].x, wpos[0].y, wpos[0].z}, {wpos[1].x, wpos[1].y, wpos[1].z}, {wpos[2].x, wpos[2].y, wpos[2].z}, lam);
+                const float ww = (lam.x * wpos[0].w + lam.y * wpos[1].w) + lam.z * wpos[2].w;
+                const f3 worldPos = {wp.x / ww, wp.y / ww, wp.z / ww};
+                const f3 eye = {P.eye[0], P.eye[1], P.eye[2]};
+                const f3 V = normalize(eye - worldPos);
+                f3 radiance = p.emissive * 20000;
+                const CubeChain env = {P.envmapRes, P.envmapMips, P.envmap};
+                if (P.viewmode == 7 && P.envmap) {                                   // Reflections :123-131
+                    out = cube_sample_trilinear(env, normalize(reflect(-V, N)), 0.f);
+                    done = true;
+                }
+                if (!done) {
+                    if (P.directLighting) {                                          // :133-147
+                        for (uint32_t lightIndex = 0; lightIndex < P.Pt.numSceneLights; ++lightIndex) {
+                            incr_light light; const float* m; bool haveT;
+                            load_light(P.Pt, (int)lightIndex, light, m, haveT);
+                            const LightSample s = light_setup(light, m, haveT, wp, N);
+                            if (s.needsShadow) {
+                                bool lit = true;
+                                if (light.type == INCR_LIGHT_DIRECTIONAL) {          // !PATH_TRACING: only the sun is shadowed
+                                    ++rays;
+                                    const bool finite = isfinite(wp.x) && isfinite(wp.y) && isfinite(wp.z) && isfinite(s.L.x) && isfinite(s.L.y) && isfinite(s.L.z);
+                                    lit = !finite || !trace_any(P.Pt, st, wp, s.L, 0.1f, 1000.f);
+                                }
+                                if (lit) radiance = radiance + light_shade(s, p.basecolor, p.metallic, p.roughness, N, V);
+                            }
+                        }
+                    }
+                    float transmission = mat.transmissionFactor;                     // material/common.hlsli:83-88
+                    if (mat.transmissionTextureIndex != -1) transmission *= SampleLevel0(P.S.textures, P.S.srgbLut, mat.transmissionTextureIndex, UV).x;
+                    if (P.diffuseIbl && P.sh9) {                                     // :149-165
+                        const f3 albedo = ((1.f - p.metallic) * (1.f - transmission)) * p.basecolor;
+                        const f3 shDiffuse = (albedo * K_INV_PI) * ShIrradiance(N, P.sh9);
+                        radiance = radiance + (shDiffuse + p.aoblend * (p.ao * shDiffuse - shDiffuse));
+                    }
+                    if (P.specularIbl && P.envmap && P.envBrdf) {                    // :167-185
+                        const float NoV = hmax(dot(N, V), 0.01f);
+                        const f3 F0 = p.metallic * p.basecolor + (1.f - p.metallic) * 0.04f;
+                        const f3 R = normalize(reflect(-V, N));
+                        const f3 prefilteredColor = cube_sample_trilinear(env, R, p.roughness * ((float)P.envmapMips - 1.f));
+                        const f2 envBrdf = sample_rg16f_bilinear_clamp(P.envBrdf, P.envBrdfW, P.envBrdfH, {NoV, p.roughness});
+                        const f3 specularIBL = prefilteredColor * (F0 * envBrdf.x + envBrdf.y);
+                        radiance = radiance + (specularIBL + p.aoblend * (p.ao * specularIBL - specularIBL));
+                    }
+                    out = radiance;
+                }
+            }
+        }
+        P.color[i] = pack_r11g11b10(out, P.rounding);
+    }
+    if (P.Pt.stats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.Pt.stats->light_shadow_rays, (unsigned long long)rays);
+    }
+}
+
 // clustered-lighting.hlsl:35-115 + cluster-culling.hlsli:26-41
 __global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1029,9 +1145,13 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
     if (maxJobs) {
         const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
         if (p->prims.draws) {            // primitive path: draw lists -> flags, then one wave per 64-triangle chunk
-            if ((e = hipMemsetAsync(p->prims.primFlags, 0, (size_t)p->prims.numPrims * 4, stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(prim_flags_kernel, dim3(std::max(1u, std::min((p->prims.numPrims + 255u) / 256u, 256u))), dim3(256), 0, stream,
-                               p->lists[0], p->lists[1], p->counts, p->prims.primFlags);
+            if (p->forward) {
+                hipLaunchKernelGGL(forward_flags_kernel, dim3((p->prims.numPrims + 255u) / 256u), dim3(256), 0, stream, p->S, p->prims.draws, p->prims.numPrims, p->prims.primFlags);
+            } else {
+                if ((e = hipMemsetAsync(p->prims.primFlags, 0, (size_t)p->prims.numPrims * 4, stream)) != hipSuccess) return e;
+                hipLaunchKernelGGL(prim_flags_kernel, dim3(std::max(1u, std::min((p->prims.numPrims + 255u) / 256u, 256u))), dim3(256), 0, stream,
+                                   p->lists[0], p->lists[1], p->counts, p->prims.primFlags);
+            }
             hipLaunchKernelGGL(vis_setup_prim_kernel, dim3(blocks), dim3(256), 0, stream, *p);
         } else {
             hipLaunchKernelGGL(vis_setup_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
@@ -1061,6 +1181,11 @@ extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStre
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(hbao_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0) return hipSuccess;
+    hipLaunchKernelGGL(forward_shade_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {

@@ -21,6 +21,7 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
@@ -183,6 +184,7 @@ struct RasterWorkspace {
     SubTriRec* recs; SubTriAlpha* alphas; uint32_t* smallQueue; uint32_t* wholeQueue; uint2* bigQueue;
     uint32_t recCap, bigCap;
     uint32_t* primFlags;                   // primitive path: one word per primitive
+    uint32_t* ids;                         // forward pass: its own visibility ids (the frame's vis buffer keeps the deferred ids)
 };
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws, size_t prims = 0) {
@@ -192,8 +194,8 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
-    const size_t szFlags = align256((prims + 1) * 4);
-    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig + szFlags;
+    const size_t szFlags = align256((prims + 1) * 4), szIds = align256(pixels * 4);
+    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig + szFlags + szIds;
     if (recCap > 0xffffffffull || bigCap > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "scene too large for the visibility queues");
     if (ctx->rasterBytes < need || !ctx->rasterBlock) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -210,7 +212,8 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     ws->smallQueue = (uint32_t*)p; p += szSmall;
     ws->wholeQueue = (uint32_t*)p; p += szWhole;
     ws->bigQueue = (uint2*)p; p += szBig;
-    ws->primFlags = (uint32_t*)p;
+    ws->primFlags = (uint32_t*)p; p += szFlags;
+    ws->ids = (uint32_t*)p;
     ws->recCap = (uint32_t)recCap; ws->bigCap = (uint32_t)bigCap;
     return INCR_OK;
 }
@@ -370,6 +373,53 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
     }
     P.bent = d->bent_normals; P.useBent = d->use_bent_normals;
     HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- forward lighting
+int incr_forward_lighting(incr_context* ctx, const incr_forward_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->color_target || !d->depth_buffer) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    if (d->viewmode < 0 || d->viewmode > 13) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d out of range (0..13)", d->viewmode);
+    const incr_scene* sc = d->scene;
+    // 1. nearest fragment per pixel: the primitive visibility pass in forward order (every primitive of every visible mesh)
+    VisParams V; memset(&V, 0, sizeof V);
+    fill_raster_scene(ctx, sc, V.S);
+    memcpy(V.viewProj, d->view->view_proj_transform.m, 64);
+    V.W = d->view->res_x; V.H = d->view->res_y;
+    scissor_rows(*d->view, &V.y0, &V.y1);
+    V.forward = 1;
+    size_t tris = 0;
+    for (const incr_gpu_primitive& pr : sc->host.primitives) tris += pr.indexCount > 0 ? (size_t)pr.indexCount / 3 : 0;
+    RasterWorkspace ws;
+    if ((rc = ensure_raster_workspace(ctx, (size_t)V.W * V.H, V.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size()))) return rc;
+    if ((rc = fill_raster_prims(sc, ws.primFlags, V.prims))) return rc;
+    V.packed = ws.packed; V.recs = ws.recs; V.alphas = ws.alphas; V.bigQueue = ws.bigQueue; V.smallQueue = ws.smallQueue; V.wholeQueue = ws.wholeQueue;
+    V.vqCounters = ws.counters; V.recCap = ws.recCap; V.bigCap = ws.bigCap;
+    ctx->rasterCounters = ws.counters;
+    HIP_TRY(incr_launch_visibility(&V, V.prims.numChunks, ctx->props.multiProcessorCount, ws.ids, d->depth_buffer, (hipStream_t)stream));
+    // 2. pixel shader
+    ForwardParams P; memset(&P, 0, sizeof P);
+    P.S = V.S; P.prims = V.prims;
+    incr_fill_scene_params(ctx, sc, P.Pt);
+    P.Pt.stats = d->ray_stats;
+    P.W = V.W; P.H = V.H; P.y0 = V.y0; P.y1 = V.y1; P.rounding = d->storage_rounding;
+    P.vis = ws.ids; P.color = d->color_target;
+    memcpy(P.viewProj, d->view->view_proj_transform.m, 64); memcpy(P.eye, d->view->eye_pos, 12);
+    P.sh9 = (const float4*)d->sh9_rgba;
+    if (d->prefiltered_envmap) {
+        if (!d->envmap_res || !d->envmap_mips || d->envmap_mips > 16) return fail(INCR_ERR_INVALID_ARGUMENT, "envmap given with zero resolution / level count");
+        P.envmap = d->prefiltered_envmap; P.envmapRes = d->envmap_res; P.envmapMips = d->envmap_mips;
+    }
+    if (d->env_brdf) {
+        if (!d->env_brdf_width || !d->env_brdf_height) return fail(INCR_ERR_INVALID_ARGUMENT, "env BRDF LUT given with zero size");
+        P.envBrdf = d->env_brdf; P.envBrdfW = d->env_brdf_width; P.envBrdfH = d->env_brdf_height;
+    }
+    P.viewmode = d->viewmode; P.directLighting = d->direct_lighting; P.diffuseIbl = d->diffuse_ibl; P.specularIbl = d->specular_ibl;
+    HIP_TRY(incr_launch_forward_shade(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 

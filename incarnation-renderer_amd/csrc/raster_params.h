@@ -92,6 +92,18 @@ struct VisParams {
     uint32_t recCap, bigCap;
     uint32_t y0, y1;                                 // scissor rows [y0, y1) (incr_view_constants::scissor_y0/y1)
     RasterPrims prims;                               // primitive path only
+    int32_t forward;                                 // forward pass: every primitive of every visible mesh in scene order, cull mode from the material
+};
+
+struct ForwardParams {
+    RasterScene S; RasterPrims prims; PtParams Pt;   // Pt: lights + BVH for the sun's shadow query
+    uint32_t W, H, y0, y1; int32_t rounding;
+    const uint32_t* __restrict__ vis; uint32_t* __restrict__ color;
+    float viewProj[16], eye[3];
+    const float4* __restrict__ sh9;
+    const uint32_t* __restrict__ envmap; uint32_t envmapRes, envmapMips;
+    const uint32_t* __restrict__ envBrdf; uint32_t envBrdfW, envBrdfH;
+    int32_t viewmode, directLighting, diffuseIbl, specularIbl;
 };
 
 struct GBufferParams {

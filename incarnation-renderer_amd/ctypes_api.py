@@ -217,6 +217,14 @@ class DebugVizDesc(C.Structure):
                 ("light_cluster_slices", C.c_uint32), ("use_primitives", C.c_int32), ("storage_rounding", C.c_int32)]
 
 
+class ForwardLightingDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("color_target", C.c_void_p), ("depth_buffer", C.c_void_p), ("sh9_rgba", C.c_void_p),
+                ("prefiltered_envmap", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
+                ("env_brdf", C.c_void_p), ("env_brdf_width", C.c_uint32), ("env_brdf_height", C.c_uint32),
+                ("viewmode", C.c_int32), ("direct_lighting", C.c_int32), ("diffuse_ibl", C.c_int32), ("specular_ibl", C.c_int32),
+                ("ray_stats", C.c_void_p), ("storage_rounding", C.c_int32)]
+
+
 class HbaoDesc(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("view", _VC), ("depth_buffer", C.c_void_p), ("gbuffer_normals", C.c_void_p),
                 ("ao_target", C.c_void_p), ("bent_normal_target", C.c_void_p), ("ray_stats", C.c_void_p), ("storage_rounding", C.c_int32)]
@@ -262,7 +270,8 @@ class RendererConfig(C.Structure):
                 ("light_cluster_dim", C.c_uint32 * 3), ("max_lights_per_cluster", C.c_uint32), ("cluster_depth_extent", C.c_float),
                 ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
                 ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32),
-                ("use_primitives", C.c_int32), ("enable_hbao", C.c_int32), ("use_bent_normals", C.c_int32)]
+                ("use_primitives", C.c_int32), ("enable_hbao", C.c_int32), ("use_bent_normals", C.c_int32),
+                ("forward_lighting", C.c_int32)]
 
 
 (SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,

@@ -235,11 +235,24 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
             d.prefiltered_envmap, d.envmap_res, d.envmap_mips = ibl.envmap, ibl.envmap_res, ibl.envmap_mips
             d.env_brdf, d.env_brdf_width, d.env_brdf_height = ibl.env_brdf, ibl.env_brdf_size[0], ibl.env_brdf_size[1]
         out.append(("sky_lighting", d))
-    if sun != -1 and cfg.EnableDirectLighting:
+    if cfg.ForwardLighting:         # renderer.cpp:1865-1880: the forward pass replaces the deferred direct + clustered passes
+        d = A.ForwardLightingDesc(); d.scene, d.view = scene_handle, vcp
+        d.color_target, d.depth_buffer = surf["color"], surf["depth"]
+        d.sh9_rgba = surf["sh9"] if have_sh else None
+        if ibl is not None:
+            if ibl.sh9:
+                d.sh9_rgba = ibl.sh9
+            d.prefiltered_envmap, d.envmap_res, d.envmap_mips = ibl.envmap, ibl.envmap_res, ibl.envmap_mips
+            d.env_brdf, d.env_brdf_width, d.env_brdf_height = ibl.env_brdf, ibl.env_brdf_size[0], ibl.env_brdf_size[1]
+        d.viewmode, d.direct_lighting = cfg.Viewmode, 1 if cfg.EnableDirectLighting else 0
+        d.diffuse_ibl, d.specular_ibl = 1 if cfg.EnableDiffuseIBL else 0, 1 if cfg.EnableSpecularIBL else 0
+        d.ray_stats, d.storage_rounding = surf["ray_stats"], storage_rounding
+        out.append(("forward_lighting", d))
+    if sun != -1 and cfg.EnableDirectLighting and not cfg.ForwardLighting:
         d = A.DirectLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
         d.directional_light_index, d.ray_stats = sun, surf["ray_stats"]
         out.append(("direct_lighting", d))
-    if punctual > 0 and cfg.EnableDirectLighting:
+    if punctual > 0 and cfg.EnableDirectLighting and not cfg.ForwardLighting:
         d = A.ClusteredLightingDesc(); d.inp = lighting_inputs(scene_handle, vc, surf, cfg, storage_rounding)
         d.culled_light_lists, d.light_grid = surf["light_lists"], surf["light_grid"]
         d.cluster_dim[:] = dims
@@ -288,6 +301,7 @@ def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
     c.enable_specular_ibl = int(cfg.EnableSpecularIBL)
     c.use_primitives = 0 if cfg.UseMeshlets else 1
     c.enable_hbao, c.use_bent_normals = int(cfg.EnableHBAO), int(cfg.UseBentNormals)
+    c.forward_lighting = int(cfg.ForwardLighting)
     return c
 
 
@@ -366,7 +380,8 @@ class RasterRenderer:
 
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
-                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap", debug_visualization="incr_debug_visualization")
+                   taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap", debug_visualization="incr_debug_visualization",
+                   forward_lighting="incr_forward_lighting")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg

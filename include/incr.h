@@ -371,6 +371,27 @@ typedef struct incr_clustered_lighting_desc {
 } incr_clustered_lighting_desc;
 int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* desc, incr_stream stream);
 
+/* RenderJob::ForwardLightingPass::Execute (render-jobs/forward-pass.inl; shaders/geo-raster/forward-pass.hlsl), the
+ * FConfig::ForwardLighting alternative to the deferred direct + clustered passes: clears the colour target to (0.8, 0.8, 1)
+ * and depth to 0, draws every primitive of every visible mesh (no frustum culling, cull mode from the material, alpha test
+ * clip(opacity - 0.5), depth GREATER_EQUAL with writes) and shades in the pixel shader: emissive * 20000 + every scene light
+ * (sun with a ray-traced shadow) + SH9 diffuse + split-sum specular IBL.  Here: primitive visibility in scene order into a
+ * library-owned id surface, then one shading kernel.  Viewmode 2..5 and 7 return material channels / reflections as the
+ * shader does (its LightingOnly branch is dead code: `#if VIWEMODE == 1`).  At most 2047 primitives. */
+typedef struct incr_forward_lighting_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    uint32_t* color_target;            /* device, R11G11B10_FLOAT */
+    float*    depth_buffer;            /* device, cleared and written */
+    const float* sh9_rgba;             /* as incr_sky_lighting_desc */
+    const uint32_t* prefiltered_envmap; uint32_t envmap_res, envmap_mips;
+    const uint32_t* env_brdf;          uint32_t env_brdf_width, env_brdf_height;
+    int32_t  viewmode, direct_lighting, diffuse_ibl, specular_ibl;
+    incr_ray_stats* ray_stats;         /* device, optional: light_shadow_rays accumulated */
+    int32_t  storage_rounding;
+} incr_forward_lighting_desc;
+int incr_forward_lighting(incr_context* ctx, const incr_forward_lighting_desc* desc, incr_stream stream);
+
 /* RenderJob::DynamicSkyPass::Execute (render-jobs/dynamic-sky.inl; shaders/environment-sky/dynamic-sky.hlsl): fills every
  * pixel at the far plane (depth <= 0.0001) with 1000 * Preetham sky radiance.  The reference shader looks the sky up along
  * the lat-long direction of the pixel's SCREEN uv (not the view ray); that is what this pass does too. */
@@ -490,6 +511,7 @@ typedef struct incr_renderer_config {      /* FConfig fields the frame reads (in
     int32_t  enable_specular_ibl;
     int32_t  use_primitives;               /* !FConfig::UseMeshlets: primitive variants of culling / visibility / G-buffer */
     int32_t  enable_hbao, use_bent_normals;/* FConfig::EnableHBAO, FConfig::UseBentNormals */
+    int32_t  forward_lighting;             /* FConfig::ForwardLighting */
 } incr_renderer_config;
 enum {
     INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,

@@ -252,7 +252,7 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
 // visibility-pass.hlsl vs_meshlet_main + ps_meshlet_main over both draw lists
 // (usePrims: vs_primitive_main :32-55 + ps_primitive_main -- a draw command names a whole primitive, SV_PrimitiveID is the triangle)
 static void visibility_pass(const Scene& s, const incr_view_constants& vc, const incr_draw_cmd* defList, const incr_draw_cmd* dsList,
-                            const uint32_t counts[2], uint32_t* vis, float* depthOut, bool usePrims = false) {
+                            const uint32_t counts[2], uint32_t* vis, float* depthOut, bool usePrims = false, bool forward = false) {
     RasterTarget rt; rt.W = vc.res_x; rt.H = vc.res_y; rt.packed.assign((size_t)rt.W * rt.H, 0);
     scissor_rows(vc, &rt.y0, &rt.y1);
     const Mat4 viewProj = to_mat4(vc.view_proj_transform);
@@ -277,7 +277,9 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
                     cv[k] = {p[k].x, p[k].y, p[k].z, p[k].w};
                     uv[k] = GetFloat2(s, (int)vi[k], uvAcc);
                 }
-                const uint32_t key = ((uint32_t)list << 31) | (usePrims ? ((objectId << 20) | tri) : ((objectId << 7) | tri));
+                // forward pass (forward-pass.inl:68-179): one draw per primitive in scene order, cull mode from the material
+                const bool cullBack = forward ? !mat.doubleSided : list == 0;
+                const uint32_t key = ((forward ? 0u : (uint32_t)list) << 31) | (usePrims ? ((objectId << 20) | tri) : ((objectId << 7) | tri));
                 // near-plane clip (z <= w)
                 bool in[3]; int nin = 0;
                 for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
@@ -292,8 +294,8 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
                 ScreenVert sv[4]; bool ok = true;
                 for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], W, H, &sv[k]);
                 if (!ok) continue;
-                raster_subtri(s, rt, sv[0], sv[1], sv[2], list == 0, key, mat, p, uv);
-                if (np == 4) raster_subtri(s, rt, sv[0], sv[2], sv[3], list == 0, key, mat, p, uv);
+                raster_subtri(s, rt, sv[0], sv[1], sv[2], cullBack, key, mat, p, uv);
+                if (np == 4) raster_subtri(s, rt, sv[0], sv[2], sv[3], cullBack, key, mat, p, uv);
             }
         }
     }
@@ -677,6 +679,115 @@ static void dynamic_sky(const Scene& s, const incr_view_constants& vc, uint32_t*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward lighting
+// render-jobs/forward-pass.inl:17-190 + shaders/geo-raster/forward-pass.hlsl (FConfig::ForwardLighting): clears colour to
+// (0.8, 0.8, 1) and depth to 0, draws every primitive of every visible mesh (no frustum culling; cull mode from the
+// material; depth GREATER_EQUAL with writes; clip(opacity - 0.5)) and shades in the pixel shader.  The nearest fragment per
+// pixel is found with the primitive visibility pass in forward order; vertex-shader outputs are interpolated with the
+// G-buffer pass's screen-space barycentric formula (the pinned attribute interpolation).
+static void forward_lighting(const Scene& s, const incr_forward_lighting_desc& d, uint64_t* shadowRays) {
+    const incr_view_constants& vc = *d.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    std::vector<incr_draw_cmd> cmds;
+    for (uint32_t id = 0; id < s.d.num_primitives; ++id) {
+        const incr_gpu_primitive& pr = s.d.primitives[id];
+        if (s.d.mesh_visibility && !s.d.mesh_visibility[pr.meshIndex]) continue;               // forward-pass.inl:70-74 bHidden
+        cmds.push_back({id, pr.indexCount > 0 ? (uint32_t)pr.indexCount : 0u});
+    }
+    const uint32_t counts[2] = {(uint32_t)cmds.size(), 0u};
+    std::vector<uint32_t> ids((size_t)W * H, 0xFFFFF000u);
+    visibility_pass(s, vc, cmds.data(), nullptr, counts, ids.data(), d.depth_buffer, true, true);
+    const Mat4 viewProj = to_mat4(vc.view_proj_transform);
+    const float3 eye = {vc.eye_pos[0], vc.eye_pos[1], vc.eye_pos[2]};
+    const bool specular = d.specular_ibl && d.prefiltered_envmap && d.env_brdf;
+    const CubeChain env = {d.envmap_res, d.envmap_mips, d.prefiltered_envmap};
+    float3 sh[9];
+    if (d.sh9_rgba) for (int k = 0; k < 9; ++k) sh[k] = {d.sh9_rgba[k * 4], d.sh9_rgba[k * 4 + 1], d.sh9_rgba[k * 4 + 2]};
+    RayStats rs;
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    for (uint32_t y = y0; y < y1; ++y) for (uint32_t x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const uint32_t v = ids[i];
+        if (v == 0xFFFFF000u) { d.color_target[i] = pack_r11g11b10({0.8f, 0.8f, 1.f}, d.storage_rounding); continue; }
+        const incr_gpu_primitive& pr = s.d.primitives[v >> 20];
+        uint32_t vi[3]; GetUint3(s, (int)((v & 0xfffffu) * 3u), pr.indexAccessor, vi);
+        const Mat4 localToWorld = mesh_local_to_world(s, pr.meshIndex);
+        float4 clip[3], wpos[3]; float2 uv[3]; float3 nW[3], tW[3], bW[3];
+        for (int k = 0; k < 3; ++k) {                                                          // vs_main :57-90
+            const float3 pos = GetFloat3(s, (int)vi[k], pr.positionAccessor);
+            wpos[k] = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToWorld);
+            clip[k] = mul_vec4(wpos[k], viewProj);
+            uv[k] = GetFloat2(s, (int)vi[k], pr.uvAccessor);
+            const float3 normal = GetFloat3(s, (int)vi[k], pr.normalAccessor);
+            const float4 pt = GetFloat4(s, (int)vi[k], pr.tangentAccessor);
+            const float3 tangent = {pt.x, pt.y, pt.z};
+            const float3 bitangent = cross(normal, tangent) * pt.w;
+            const float4 n4 = mul_vec4({normal.x, normal.y, normal.z, 0.f}, localToWorld), t4 = mul_vec4({tangent.x, tangent.y, tangent.z, 0.f}, localToWorld);
+            const float4 b4 = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, localToWorld);
+            nW[k] = {n4.x, n4.y, n4.z}; tW[k] = {t4.x, t4.y, t4.z}; bW[k] = {b4.x, b4.y, b4.z};
+        }
+        const float3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(x, y, (float)W, (float)H));
+        const float2 UV = interp2(uv[0], uv[1], uv[2], lam);
+        const incr_material& mat = s.d.materials[pr.materialIndex];
+        MatProps p = EvaluateMaterialProperties(s, mat, UV);
+        float3 out = {0.f, 0.f, 0.f};
+        bool done = true;
+        if (d.viewmode == 2) out = f3(p.roughness);                                            // ps_main :95-105 (VIEWMODE 1 is a typo there: no effect)
+        else if (d.viewmode == 3) out = f3(p.metallic);
+        else if (d.viewmode == 4) out = p.basecolor;
+        else if (d.viewmode == 5) out = p.emissive;
+        else done = false;
+        if (!done) {
+            const float3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
+            float3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
+            if (p.bHasNormalmap) {
+                const float3 nm = p.normalmap;
+                N = normalize(f3((nm.x * T.x + nm.y * B.x) + nm.z * N.x, (nm.x * T.y + nm.y * B.y) + nm.z * N.y, (nm.x * T.z + nm.y * B.z) + nm.z * N.z));
+            }
+            const float3 wp = interp3({wpos[0].x, wpos[0].y, wpos[0].z}, {wpos[1].x, wpos[1].y, wpos[1].z}, {wpos[2].x, wpos[2].y, wpos[2].z}, lam);
+            const float ww = (lam.x * wpos[0].w + lam.y * wpos[1].w) + lam.z * wpos[2].w;
+            const float3 worldPos = {wp.x / ww, wp.y / ww, wp.z / ww};
+            const float3 V = normalize(eye - worldPos);
+            float3 radiance = p.emissive * 20000;
+            if (d.viewmode == 7 && d.prefiltered_envmap) {                                     // Reflections :123-131
+                const float3 R = normalize(reflect(-V, N));
+                out = cube_sample_trilinear(env, R, 0.f);
+                done = true;
+            }
+            if (!done) {
+                if (d.direct_lighting) {                                                       // :133-147, input.worldPos.xyz (not divided)
+                    for (uint32_t lightIndex = 0; lightIndex < s.d.num_scene_lights; ++lightIndex) {
+                        const int lightId = s.d.light_indices[lightIndex];
+                        incr_light light{}; Mat4 lightTransform{};
+                        if ((uint32_t)lightId < s.d.num_global_lights) light = s.d.global_lights[lightId];
+                        if ((uint32_t)lightId < s.d.num_scene_lights) lightTransform = to_mat4(s.d.light_transforms[lightId]);
+                        radiance += GetDirectRadiance(s, light, lightTransform, wp, p.basecolor, p.metallic, p.roughness, N, V, false, &rs);
+                    }
+                }
+                float transmission = mat.transmissionFactor;                                   // material/common.hlsli:83-88
+                if (mat.transmissionTextureIndex != -1) transmission *= SampleLevel0(s, mat.transmissionTextureIndex, UV).x;
+                if (d.diffuse_ibl && d.sh9_rgba) {                                             // :149-165
+                    const float3 albedo = ((1.f - p.metallic) * (1.f - transmission)) * p.basecolor;
+                    const float3 shDiffuse = (albedo * Fd_Lambert()) * ShIrradiance(N, sh);
+                    radiance += shDiffuse + p.aoblend * (p.ao * shDiffuse - shDiffuse);
+                }
+                if (specular) {                                                                // :167-185
+                    const float NoV = hmax(dot(N, V), 0.01f);
+                    const float3 F0 = p.metallic * p.basecolor + (1.f - p.metallic) * 0.04f;
+                    const float3 R = normalize(reflect(-V, N));
+                    const float3 prefilteredColor = cube_sample_trilinear(env, R, p.roughness * ((float)d.envmap_mips - 1.f));
+                    const float2 envBrdf = sample_rg16f_bilinear_clamp(d.env_brdf, d.env_brdf_width, d.env_brdf_height, {NoV, p.roughness});
+                    const float3 specularIBL = prefilteredColor * (F0 * envBrdf.x + envBrdf.y);
+                    radiance += specularIBL + p.aoblend * (p.ao * specularIBL - specularIBL);
+                }
+                out = radiance;
+            }
+        }
+        d.color_target[i] = pack_r11g11b10(out, d.storage_rounding);
+    }
+    if (shadowRays) *shadowRays += rs.lightShadow;
+}
+
 // ------------------------------------------------------------------------------------------------ HDRI background
 // shaders/environment-sky/envmap.hlsl:22-54 + render-jobs/environmentmap.inl:100-146: full-screen triangle at z = 0.0001,
 // depth GREATER_EQUAL, blend off; the interpolated clip position of the pixel centre goes through
@@ -838,6 +949,7 @@ void orc_cluster_frustum(const uint32_t ci[3], const uint32_t grid[3], float zNe
 }
 void orc_environmentmap(const incr_environmentmap_desc* d) { environmentmap_pass(*d); }
 void orc_debug_visualization(const incr_debug_viz_desc* d) { debug_visualization(*d); }
+void orc_forward_lighting(void* scene, const incr_forward_lighting_desc* d, uint64_t* shadowRays) { forward_lighting(*(Scene*)scene, *d, shadowRays); }
 void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }
 void orc_hb_math(float x, float out[3]) { out[0] = hb_sin(x); out[1] = hb_cos(x); out[2] = hb_acos(x); }
 void orc_sky_lighting(void* scene, const incr_sky_lighting_desc* d) {

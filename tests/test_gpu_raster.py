@@ -280,6 +280,62 @@ def test_raster_crop_matches_committed_golden(rt, R, ob, A, sio, gpu_ctx, helmet
         gscene.close()
 
 
+@pytest.mark.parametrize("which,W,H", [("helmet", 160, 160), ("sponza_small", 256, 144)])
+def test_forward_lighting_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, H):
+    """FConfig::ForwardLighting (forward-pass.hlsl): depth bit-exact, colour within the storage-step tolerance of the deferred
+    passes (same light functions), shadow-ray count equal; the shader's material view modes and the clear colour through the
+    pass on its own; the whole frame through the C++ renderer."""
+    class Forward(A.FConfig):
+        ForwardLighting = True
+    scene = request.getfixturevalue(which)
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    osc = ob.OracleScene(scene)
+    try:
+        g = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, Forward, frames=2)
+        hr = R.HostRenderer(gpu_ctx, gscene, W, H, cfg=Forward, sh9_rgb=DEFAULT_SH9)
+        prev, hs = None, None
+        for frame, (vc, gs) in enumerate(g):
+            vco, hs = run_oracle_frame(ob, R, A, scene, osc, view, W, H, frame_index=frame, prev=prev, hs=hs, cfg=Forward)
+            prev = R.matrix_to_numpy(vco.unjittered_view_proj)
+            o = hs.arr
+            np.testing.assert_array_equal(gs["depth"].view(np.uint32), o["depth"].view(np.uint32))
+            assert colour_close(ob, gs["color"], o["color"], "forward colour") > 0.995
+            assert colour_close(ob, gs["taa%d" % (frame & 1)], o["taa%d" % (frame & 1)], "forward taa") > 0.99
+            assert gs["ray_stats"].light_shadow_rays == int(o["ray_stats"][3])
+            hr.render(view); gpu_ctx.synchronize()
+            np.testing.assert_array_equal(hr.download(A.SURFACE_HDR_RASTER), gs["color"].view(np.uint32), err_msg="C++ renderer frame %d" % frame)
+            np.testing.assert_array_equal(hr.download(A.SURFACE_DEPTH), gs["depth"].view(np.uint32))
+        hr.close()
+        # the pass on its own: clear colour behind the geometry, material channels in the shader's view modes
+        surf = R.RasterSurfaces(gpu_ctx, W, H, scene.num_meshlets)
+        hs2 = ob.HostSurfaces(W, H, scene.num_meshlets, 16 * 9 * 24, 64)
+        hs2.arr["sh9"][:, :3] = DEFAULT_SH9
+        gpu_ctx.upload(surf.ptr["sh9"], hs2.arr["sh9"])
+        vc = R.make_view_constants(view, W, H)
+        for mode in (0, 2, 3, 4, 5):
+            class M(Forward):
+                Viewmode = mode
+                EnableTAA = False
+            for (name, dg), (_, do) in zip(R.build_descs(gscene.handle, scene, vc, surf.ptr, 0, M), R.build_descs(None, scene, vc, hs2.ptr, 0, M)):
+                rt.check(getattr(gpu_ctx.lib, R.RasterRenderer.PASS_FN[name])(gpu_ctx.handle, C.byref(dg), None))
+                ob.run_pass(osc, name, do)
+                if name == "forward_lighting":
+                    break
+            gpu_ctx.synchronize()
+            col = surf.download("color")
+            if mode == 0:
+                assert colour_close(ob, col, hs2.arr["color"], "forward pass") > 0.995
+            else:
+                np.testing.assert_array_equal(col, hs2.arr["color"], err_msg="forward viewmode %d" % mode)
+            background = hs2.arr["depth"] == 0
+            if background.any():
+                assert (col[background] == ob.lib().orc_pack_r11g11b10((C.c_float * 3)(0.8, 0.8, 1.0), 0)).all()
+        surf.close()
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

@@ -371,6 +371,56 @@ def test_oracle_debug_views(helmet, sio, R, ob, A):
     osc.close()
 
 
+def test_oracle_forward_lighting(helmet, sponza_small, sio, R, ob, A):
+    """forward-pass.hlsl restated on top of the primitive visibility pass: same nearest fragments as the deferred frame,
+    the clear colour behind them, emissive-only output when every light term is off, material channels in the debug modes."""
+    W, H = 128, 72
+    for scene in (helmet, sponza_small):
+        osc = ob.OracleScene(scene)
+        view = sio.FView().reset(scene, aspect=W / H)
+
+        class Deferred(A.FConfig):
+            EnableTAA = False
+            EnableDirectLighting = False
+            EnableSkyLighting = False
+
+        class Forward(Deferred):
+            ForwardLighting = True
+            EnableDiffuseIBL = False
+            EnableSpecularIBL = False
+
+        class ForwardBase(Forward):
+            Viewmode = 4
+        _, hd = run_oracle_frame(ob, R, A, scene, osc, view, W, H, cfg=Deferred)
+        _, hf = run_oracle_frame(ob, R, A, scene, osc, view, W, H, cfg=Forward)
+        # (in a whole frame the debug-view pass overwrites these modes afterwards, renderer.cpp:1961: stop at the forward pass)
+        hb = ob.HostSurfaces(W, H, scene.num_meshlets, 16 * 9 * 24, 64)
+        vcb = R.make_view_constants(view, W, H)
+        for name, d in R.build_descs(None, scene, vcb, hb.ptr, 0, ForwardBase):
+            ob.run_pass(osc, name, d)
+            if name == "forward_lighting":
+                break
+        covered = hd.arr["vis"] != 0xFFFFF000
+        # no frustum culling and per-primitive draws change neither coverage nor depth
+        np.testing.assert_array_equal(hf.arr["depth"].view(np.uint32), hd.arr["depth"].view(np.uint32))
+        # nothing but emissive * 20000 left: exactly what the G-buffer pass put into the colour target -- wherever both paths
+        # interpolate the same uv, i.e. everywhere except the dynamic-sky background
+        # (the G-buffer pass projects with the combined localToClip matrix, the forward vertex shader in two steps: the
+        # barycentrics differ in the last bits and a few emissive texels with them)
+        same = hf.arr["color"][covered] == hd.arr["color"][covered]
+        assert same.mean() > 0.98
+        if (~covered).any():
+            bg = ob.unpack_r11g11b10(hf.arr["color"][~covered])
+            # the dynamic sky pass runs after the forward pass and fills the far plane: no clear colour survives in the frame
+            assert np.isfinite(bg).all()
+        # base colour view: the G-buffer's UNORM8 base colour, re-quantised to R11G11B10
+        g0 = hd.arr["gbuffer_basecolor"][covered]
+        want = np.stack([(g0 >> s) & 255 for s in (0, 8, 16)], -1) / 255.0
+        got = ob.unpack_r11g11b10(hb.arr["color"][covered])
+        assert np.abs(got - want).max() < 1 / 32 + 1 / 255
+        osc.close()
+
+
 def test_oct_encoding_round_trip(ob):
     rng = np.random.default_rng(3)
     n = rng.normal(size=(500, 3)).astype(np.float32)

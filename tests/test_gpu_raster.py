@@ -336,6 +336,44 @@ def test_forward_lighting_parity(request, rt, R, ob, A, sio, gpu_ctx, which, W, 
         osc.close(); gscene.close()
 
 
+def test_raster_tiny_and_empty_frames(rt, R, ob, A, sio, gpu_ctx, sponza_small):
+    """Ragged and degenerate frames through every optional pass at once (primitive path off / on, HBAO, forward lighting):
+    1x1, 3x2 and 65x1 targets, and a camera that looks away from the whole scene (every draw culled, all background)."""
+    class Everything(A.FConfig):
+        EnableHBAO = True
+        UseBentNormals = True
+
+    class EverythingPrims(Everything):
+        UseMeshlets = False
+        ForwardLighting = True
+    gscene = gpu_ctx.create_scene(sponza_small)
+    osc = ob.OracleScene(sponza_small)
+    try:
+        for cfg in (Everything, EverythingPrims):
+            for W, H in ((1, 1), (3, 2), (65, 1), (2, 67)):
+                view = sio.FView().reset(sponza_small, aspect=W / H)
+                (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, cfg)
+                _, hs = run_oracle_frame(ob, R, A, sponza_small, osc, view, W, H, cfg=cfg)
+                np.testing.assert_array_equal(gs["vis"], hs.arr["vis"])
+                np.testing.assert_array_equal(gs["depth"].view(np.uint32), hs.arr["depth"].view(np.uint32))
+                assert colour_close(ob, gs["color"], hs.arr["color"], "%dx%d colour" % (W, H)) >= 0.5
+            # looking straight away from the atrium: nothing survives culling, nothing is rasterised
+            W, H = 96, 54
+            view = sio.FView().reset(sponza_small, aspect=W / H)
+            away = sio.FView().reset(sponza_small, aspect=W / H)
+            away.position = np.asarray(view.position, np.float32) - 500.0 * np.asarray(view.look, np.float32)
+            away.look = -np.asarray(view.look, np.float32); away.right = -np.asarray(view.right, np.float32)
+            away.update_view_transform()
+            (vc, gs), = gpu_frame(rt, R, gpu_ctx, gscene, away, W, H, cfg)
+            _, hs = run_oracle_frame(ob, R, A, sponza_small, osc, away, W, H, cfg=cfg)
+            np.testing.assert_array_equal(gs["counts"], hs.arr["counts"])
+            np.testing.assert_array_equal(gs["vis"], hs.arr["vis"])
+            np.testing.assert_array_equal(gs["depth"].view(np.uint32), hs.arr["depth"].view(np.uint32))
+            assert colour_close(ob, gs["color"], hs.arr["color"], "away colour") > 0.99
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

@@ -60,6 +60,11 @@ struct incr_scene {
     float4* dPvPos = nullptr; float2* dPvUv = nullptr; float4* dPvNormal = nullptr; float4* dPvTangent = nullptr;
     uint32_t* dChunkPrim = nullptr; uint32_t* dChunkFirstTri = nullptr;
     uint32_t numPrimChunks = 0;
+    // decals (FScene::m_sceneMeshDecals): the same baked layout, one localToWorld (mesh transform * root transform) per decal draw
+    incr::PrimDraw* dDecalDraws = nullptr; uint32_t* dDecalIndices = nullptr;
+    float4* dDvPos = nullptr; float2* dDvUv = nullptr; float4* dDvNormal = nullptr; float4* dDvTangent = nullptr;
+    uint32_t* dDecalChunkPrim = nullptr; uint32_t* dDecalChunkFirstTri = nullptr; float* dDecalLocalToWorld = nullptr;
+    uint32_t numDecalChunks = 0, numDecals = 0;
 };
 
 // one zeroed element of slack: the traversal fetches 80 bytes per step, also when the step is a 48-byte triangle

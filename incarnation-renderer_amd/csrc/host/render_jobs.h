@@ -155,6 +155,14 @@ struct Desc {
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }
+namespace GBufferRasterPass { // render-jobs/gbuffer-raster-pass.inl:3-15 (decals)
+struct Desc {
+    FShaderSurface* sourceVisBuffer; FShaderSurface* colorTarget; FShaderSurface* gbufferTargets[3]; FShaderSurface* depthStencilTarget;
+    const FScene* sceneConstantBuffer; FSystemBuffer* viewConstantBuffer;
+    uint32_t resX; uint32_t resY; const FScene* scene; FConfig renderConfig;
+};
+Result Execute(Sync* jobSync, const Desc& passDesc);
+}
 namespace HBAO {             // render-jobs/hbao.inl:3-14
 struct Desc {
     FShaderSurface* aoTarget; FShaderSurface* bentNormalTarget; FShaderSurface* depthStencil; FShaderSurface* gbufferNormals;

@@ -136,6 +136,17 @@ Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky
     return done(jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
+Result GBufferRasterPass::Execute(Sync* jobSync, const Desc& p) {         // gbuffer-raster-pass.inl:17-233
+    const size_t token = jobSync->GetToken();
+    incr_gbuffer_decals_desc d = {};
+    d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
+    d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
+    d.gbuffer_basecolor = (uint32_t*)p.gbufferTargets[0]->m_devicePtr; d.gbuffer_normals = (uint32_t*)p.gbufferTargets[1]->m_devicePtr;
+    d.gbuffer_metallic_roughness_ao = (uint32_t*)p.gbufferTargets[2]->m_devicePtr;
+    d.storage_rounding = p.renderConfig.StorageRounding;
+    return done(jobSync->Execute(token, [&] { return incr_gbuffer_decals(jobSync->m_ctx, &d, jobSync->m_stream); }));
+}
+
 Result HBAO::Execute(Sync* jobSync, const Desc& p) {                      // hbao.inl:16-105
     const size_t token = jobSync->GetToken();
     incr_hbao_desc d = {};
@@ -273,10 +284,11 @@ struct State {
 static constexpr uint32_t kBandSlackRows = 64;                  // TAA surfaces hold ceil(H/N)*N rows for an equal-sized all_gather
 
 static int alloc(State& s, void** out, uint64_t bytes, bool clear) {
+    bytes = (bytes + 3) & ~3ull;                 // whole words: the R8 surface of an odd-sized frame is cleared 32 bits at a time
     int rc = incr_buffer_create(s.ctx, bytes, out);
     if (rc) return rc;
     s.allocations.push_back(*out);
-    return clear ? incr_buffer_clear(s.ctx, *out, 0, (bytes + 3) & ~3ull, nullptr) : INCR_OK;
+    return clear ? incr_buffer_clear(s.ctx, *out, 0, bytes, nullptr) : INCR_OK;
 }
 static int surface(State& s, FShaderSurface& f, uint32_t texelBytes, bool clear = false) {
     f.m_width = s.resX; f.m_height = s.resY; f.m_texelBytes = texelBytes;
@@ -392,7 +404,14 @@ int Render(State& s, const FRenderState& renderState) {
         gbufferComputeDesc.resX = resX; gbufferComputeDesc.resY = resY; gbufferComputeDesc.scene = scene; gbufferComputeDesc.renderConfig = c;
         GBufferComputePass::Execute(jobSync, gbufferComputeDesc);
 
-        // decals (:1784-1798) are outside this library
+        GBufferRasterPass::Desc gbufferRasterDesc = {};                        // decals :1783-1798 (a no-op for scenes without any)
+        gbufferRasterDesc.sourceVisBuffer = &s.visBuffer; gbufferRasterDesc.colorTarget = &s.hdrRasterSceneColor;
+        gbufferRasterDesc.gbufferTargets[0] = &s.gbuffer_basecolor; gbufferRasterDesc.gbufferTargets[1] = &s.gbuffer_normals;
+        gbufferRasterDesc.gbufferTargets[2] = &s.gbuffer_metallicRoughnessAo; gbufferRasterDesc.depthStencilTarget = &s.depthBuffer;
+        gbufferRasterDesc.sceneConstantBuffer = scene; gbufferRasterDesc.viewConstantBuffer = &cbViewConstants;
+        gbufferRasterDesc.resX = resX; gbufferRasterDesc.resY = resY; gbufferRasterDesc.scene = scene; gbufferRasterDesc.renderConfig = c;
+        GBufferRasterPass::Execute(jobSync, gbufferRasterDesc);
+
         if (c.EnableHBAO) {                                                    // :1801-1815; else both targets read as cleared to 1 (:1816-1841)
             HBAO::Desc hbaoDesc = {};
             hbaoDesc.aoTarget = &s.aoBuffer; hbaoDesc.bentNormalTarget = &s.bentNormalsBuffer;

@@ -947,6 +947,171 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------- decals
+// gbuffer-raster.hlsl vs_main + primitive assembly: one wave per 64-triangle chunk of the decal draws; every triangle
+// writes its (at most two) clockwise screen triangles into its own two slots, so slot order = draw order.
+__global__ __launch_bounds__(256) void decal_setup_kernel(const DecalParams P) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const RasterPrims& R = P.prims;
+    const float fW = (float)P.W, fH = (float)P.H;
+    for (uint32_t chunk = blockIdx.x * 4 + wave; chunk < R.numChunks; chunk += gridDim.x * 4) {
+        const uint32_t prim = R.chunkPrim[chunk];
+        const PrimDraw d = R.draws[prim];
+        const float* __restrict__ l2w = P.decalLocalToWorld + (size_t)d.meshIndex * 16;
+        const bool cullBack = P.S.materials[d.materialIndex].doubleSided == 0;
+        const uint32_t tri = R.chunkFirstTri[chunk] + lane;
+        SubTriRec out[2];
+        out[0].key = out[1].key = 0xffffffffu;
+        if (tri < d.indexCount / 3u) {
+            ClipVert cv[3];
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const float4 pos = R.pvPos[d.vertexBase + R.indices[d.indexBegin + tri * 3u + k]];
+                const f4 c = mul_vec4(mul_vec4({pos.x, pos.y, pos.z, 1.f}, l2w), P.viewProj);
+                cv[k] = {c.x, c.y, c.z, c.w};
+            }
+            bool in[3]; int nin = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
+            ClipVert poly[4]; int np = 0;
+            if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+            else if (nin > 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int j = (k + 1) % 3;
+                    if (in[k]) poly[np++] = cv[k];
+                    if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
+                }
+            }
+            ScreenVert sv[4]; bool ok = np >= 3;
+            for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], fW, fH, &sv[k]);
+            if (ok) {
+                for (int j = 0; j < (np == 4 ? 2 : 1); ++j) {
+                    ScreenVert a = sv[0], b = sv[1 + j], c = sv[2 + j];
+                    if (!orient_subtri(a, b, c, cullBack)) continue;
+                    SubTriRec& r = out[j];
+                    r.X0 = a.X; r.Y0 = a.Y; r.X1 = b.X; r.Y1 = b.Y; r.X2 = c.X; r.Y2 = c.Y; r.z0 = a.z; r.z1 = b.z; r.z2 = c.z;
+                    r.key = (prim << 20) | tri; r.alphaTex = -1; r.pad = 0;
+                }
+            }
+        }
+        const size_t slot = ((size_t)chunk * 64 + lane) * 2;
+        P.recs[slot] = out[0]; P.recs[slot + 1] = out[1];
+    }
+}
+static constexpr uint32_t kDecalListCap = 1024;
+// Per fragment: gbuffer-raster.hlsl ps_main + the blend states of gbuffer-raster-pass.inl:126-183
+DI void decal_fragment(const DecalParams& P, const SubTriRec& r, uint32_t px, uint32_t py, float sceneDepth, uint32_t& g0, uint32_t& g1, uint32_t& g2, bool& dirty) {
+    const long long Sx = (long long)px * 256 + 128, Sy = (long long)py * 256 + 128;
+    const int32_t dx01 = r.X1 - r.X0, dy01 = r.Y1 - r.Y0, dx12 = r.X2 - r.X1, dy12 = r.Y2 - r.Y1, dx20 = r.X0 - r.X2, dy20 = r.Y0 - r.Y2;
+    const long long E01 = (long long)dx01 * (Sy - r.Y0) - (long long)dy01 * (Sx - r.X0);
+    const long long E12 = (long long)dx12 * (Sy - r.Y1) - (long long)dy12 * (Sx - r.X1);
+    const long long E20 = (long long)dx20 * (Sy - r.Y2) - (long long)dy20 * (Sx - r.X2);
+    if (E01 + (top_left(dx01, dy01) ? 0 : -1) < 0 || E12 + (top_left(dx12, dy12) ? 0 : -1) < 0 || E20 + (top_left(dx20, dy20) ? 0 : -1) < 0) return;
+    const long long area = (long long)(r.X1 - r.X0) * (r.Y2 - r.Y0) - (long long)(r.X2 - r.X0) * (r.Y1 - r.Y0);
+    const double invArea = 1.0 / (double)area;
+    const float l1 = (float)((double)E20 * invArea), l2 = (float)((double)E01 * invArea);
+    float depth = (r.z0 + l1 * (r.z1 - r.z0)) + l2 * (r.z2 - r.z0);
+    if (!(depth >= 0.f)) return;
+    if (depth > 1.f) depth = 1.f;
+    if (!(depth >= sceneDepth)) return;                                              // GREATER_EQUAL, no depth write
+    const PrimDraw d = P.prims.draws[r.key >> 20];
+    const uint32_t tri = r.key & 0xfffffu;
+    const float* __restrict__ l2w = P.decalLocalToWorld + (size_t)d.meshIndex * 16;
+    f4 clip[3]; f2 uv[3]; f3 nW[3], tW[3], bW[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {                                               // vs_main :46-78
+        const uint32_t vi = d.vertexBase + P.prims.indices[d.indexBegin + tri * 3u + k];
+        const float4 pos = P.prims.pvPos[vi];
+        clip[k] = mul_vec4(mul_vec4({pos.x, pos.y, pos.z, 1.f}, l2w), P.viewProj);
+        const float2 t = P.prims.pvUv[vi]; uv[k] = {t.x, t.y};
+        const float4 n4 = P.prims.pvNormal[vi], t4 = P.prims.pvTangent[vi];
+        const f3 normal = {n4.x, n4.y, n4.z}, tangent = {t4.x, t4.y, t4.z};
+        const f3 bitangent = cross(normal, tangent) * t4.w;
+        const f4 a = mul_vec4({normal.x, normal.y, normal.z, 0.f}, l2w), b = mul_vec4({tangent.x, tangent.y, tangent.z, 0.f}, l2w);
+        const f4 c = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, l2w);
+        nW[k] = {a.x, a.y, a.z}; tW[k] = {b.x, b.y, b.z}; bW[k] = {c.x, c.y, c.z};
+    }
+    const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(px, py, (float)P.W, (float)P.H));
+    const incr_material mat = P.S.materials[d.materialIndex];
+    const MatProps p = EvaluateMaterialProperties(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam));
+    const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
+    f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
+    if (p.bHasNormalmap) {
+        const f3 nm = p.normalmap;
+        N = normalize(mk3((nm.x * T.x + nm.y * B.x) + nm.z * N.x, (nm.x * T.y + nm.y * B.y) + nm.z * N.y, (nm.x * T.z + nm.y * B.z) + nm.z * N.z));
+    }
+    const f4 dst = unpack_unorm8x4(g0);
+    const float a = p.opacity, ia = 1.f - a;
+    g0 = pack_unorm8x4({p.basecolor.x * a + dst.x * ia, p.basecolor.y * a + dst.y * ia, p.basecolor.z * a + dst.z * ia, a * a + dst.w * ia});
+    if (mat.normalTextureIndex != -1) {
+        const f2 oct = OctEncode(N);
+        g1 = f32_to_f16_bits(oct.x, P.rounding) | (f32_to_f16_bits(oct.y, P.rounding) << 16);
+    }
+    if (mat.metallicRoughnessTextureIndex != -1) g2 = pack_unorm8x4({p.metallic, p.roughness, p.ao, p.aoblend});
+    dirty = true;
+}
+// One 64x4 pixel tile per workgroup: the slots are culled against the tile in order (ballot prefix + LDS), then every pixel
+// walks the surviving list front to back -- sequential per pixel, so the blend order is the slot order.
+__global__ __launch_bounds__(256) void decal_blend_kernel(const DecalParams P) {
+    __shared__ uint32_t s_list[kDecalListCap];
+    __shared__ uint32_t s_waveCnt[4];
+    __shared__ uint32_t s_count;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tx0 = blockIdx.x * 64, ty0 = P.y0 + blockIdx.y * 4;
+    const uint32_t px = tx0 + lane, py = ty0 + wave;
+    const bool inside = px < P.W && py < P.y1;
+    const size_t i = (size_t)py * P.W + px;
+    uint32_t g0 = 0, g1 = 0, g2 = 0; float sceneDepth = 0.f; bool dirty = false;
+    if (inside) { g0 = P.g0[i]; g1 = P.g1[i]; g2 = P.g2[i]; sceneDepth = P.depth[i]; }
+    const int32_t tileX0 = (int32_t)tx0, tileX1 = (int32_t)min(tx0 + 63u, P.W - 1u), tileY0 = (int32_t)ty0, tileY1 = (int32_t)min(ty0 + 3u, P.y1 - 1u);
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        const uint32_t n = s_count;
+        if (inside) {
+            for (uint32_t k = 0; k < n; ++k) {
+                const SubTriRec r = P.recs[s_list[k]];
+                const int32_t minX = min(r.X0, min(r.X1, r.X2)), maxX = max(r.X0, max(r.X1, r.X2));
+                const int32_t minY = min(r.Y0, min(r.Y1, r.Y2)), maxY = max(r.Y0, max(r.Y1, r.Y2));
+                if ((int32_t)px < ((minX + 127) >> 8) || (int32_t)px > ((maxX - 128) >> 8) || (int32_t)py < ((minY + 127) >> 8) || (int32_t)py > ((maxY - 128) >> 8)) continue;
+                decal_fragment(P, r, px, py, sceneDepth, g0, g1, g2, dirty);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+    };
+    for (uint32_t base = 0; base < P.numSlots; base += 256) {
+        if (s_count + 256u > P.listCap) flush();
+        const uint32_t slot = base + tid;
+        bool hit = false;
+        if (slot < P.numSlots) {
+            const SubTriRec r = P.recs[slot];
+            if (r.key != 0xffffffffu) {
+                const int32_t minX = min(r.X0, min(r.X1, r.X2)), maxX = max(r.X0, max(r.X1, r.X2));
+                const int32_t minY = min(r.Y0, min(r.Y1, r.Y2)), maxY = max(r.Y0, max(r.Y1, r.Y2));
+                const int32_t bx0 = (minX + 127) >> 8, bx1 = (maxX - 128) >> 8, by0 = (minY + 127) >> 8, by1 = (maxY - 128) >> 8;
+                hit = bx0 <= tileX1 && bx1 >= tileX0 && by0 <= tileY1 && by1 >= tileY0 && bx0 <= bx1 && by0 <= by1;
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_waveCnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (hit) {
+            uint32_t off = s_count;
+            for (uint32_t w = 0; w < wave; ++w) off += s_waveCnt[w];
+            off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            s_list[off] = slot;
+        }
+        __syncthreads();
+        if (tid == 0) s_count += s_waveCnt[0] + s_waveCnt[1] + s_waveCnt[2] + s_waveCnt[3];
+        __syncthreads();
+    }
+    flush();
+    if (inside && dirty) { P.g0[i] = g0; P.g1[i] = g1; P.g2[i] = g2; }
+}
+
 // clustered-lighting.hlsl:35-115 + cluster-culling.hlsli:26-41
 __global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1181,6 +1346,14 @@ extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStre
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(hbao_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipStream_t stream) {
+    if (!p->W || p->y1 <= p->y0 || !p->prims.numChunks) return hipSuccess;
+    hipLaunchKernelGGL(decal_setup_kernel, dim3(std::min<uint32_t>((p->prims.numChunks + 3u) / 4u, (uint32_t)numCUs * 8u)), dim3(256), 0, stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(decal_blend_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream) {

@@ -22,6 +22,7 @@ extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStre
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipStream_t stream);
 extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
@@ -57,6 +58,12 @@ void fetch(const HostScene& s, int accessorIndex, uint32_t index, int ncomp, flo
 }
 
 } // namespace
+
+struct BakedPrims {
+    std::vector<PrimDraw> draws; std::vector<uint32_t> indices, chunkPrim, chunkFirstTri;
+    std::vector<float4> pos, nrm, tan; std::vector<float2> uv;
+};
+static int bake_primitives(const HostScene& h, const std::vector<incr_gpu_primitive>& prims, const char* what, BakedPrims* out);
 
 int incr_raster_scene_upload(incr_scene* sc) {
     const HostScene& h = sc->host;
@@ -100,13 +107,53 @@ int incr_raster_scene_upload(incr_scene* sc) {
     if (!rc) rc = upload_vec(&sc->dMvTangent, tan.data(), nv);
     if (rc) return rc;
 
-    // ---- primitive (non-meshlet) path: per primitive, the index list widened to 32 bit (MeshMaterial::GetUint,
-    // mesh-material.hlsli:5-43: 2- or 4-byte indices) and the attributes of vertices 0 .. max index ----
-    std::vector<PrimDraw> draws(h.primitives.size());
-    std::vector<uint32_t> indices, chunkPrim, chunkFirstTri;
-    std::vector<float4> ppos, pnrm, ptan; std::vector<float2> puv;
-    for (size_t pi = 0; pi < h.primitives.size(); ++pi) {
-        const incr_gpu_primitive& pr = h.primitives[pi];
+    BakedPrims bp;
+    if ((rc = bake_primitives(h, h.primitives, "primitive", &bp))) return rc;
+    sc->numPrimChunks = (uint32_t)bp.chunkPrim.size();
+    rc = upload_vec(&sc->dPrimDraws, bp.draws.data(), bp.draws.size());
+    if (!rc) rc = upload_vec(&sc->dPrimIndices, bp.indices.data(), bp.indices.size());
+    if (!rc) rc = upload_vec(&sc->dPvPos, bp.pos.data(), bp.pos.size());
+    if (!rc) rc = upload_vec(&sc->dPvUv, bp.uv.data(), bp.uv.size());
+    if (!rc) rc = upload_vec(&sc->dPvNormal, bp.nrm.data(), bp.nrm.size());
+    if (!rc) rc = upload_vec(&sc->dPvTangent, bp.tan.data(), bp.tan.size());
+    if (!rc) rc = upload_vec(&sc->dChunkPrim, bp.chunkPrim.data(), bp.chunkPrim.size());
+    if (!rc) rc = upload_vec(&sc->dChunkFirstTri, bp.chunkFirstTri.data(), bp.chunkFirstTri.size());
+    if (rc) return rc;
+
+    // ---- decals (FScene::m_sceneMeshDecals): the same bake; meshIndex of a decal draw indexes dDecalLocalToWorld ----
+    BakedPrims bd;
+    std::vector<incr_gpu_primitive> decals = h.decalPrimitives;
+    for (size_t i = 0; i < decals.size(); ++i) {
+        if (decals[i].materialIndex < 0 || (size_t)decals[i].materialIndex >= h.materials.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "decal primitive %zu: materialIndex out of range", i);
+        decals[i].meshIndex = (int32_t)i;
+    }
+    if ((rc = bake_primitives(h, decals, "decal primitive", &bd))) return rc;
+    std::vector<float> l2w(decals.size() * 16);
+    for (size_t i = 0; i < decals.size(); ++i) {       // mul(g_primCb.localToWorld, g_sceneCb.m_sceneRotation), gbuffer-raster.hlsl:51
+        const M44 m = m44_mul(h.decalTransforms[i], h.rootTransform);
+        memcpy(&l2w[i * 16], m.m, 64);
+    }
+    sc->numDecalChunks = (uint32_t)bd.chunkPrim.size(); sc->numDecals = (uint32_t)decals.size();
+    rc = upload_vec(&sc->dDecalDraws, bd.draws.data(), bd.draws.size());
+    if (!rc) rc = upload_vec(&sc->dDecalIndices, bd.indices.data(), bd.indices.size());
+    if (!rc) rc = upload_vec(&sc->dDvPos, bd.pos.data(), bd.pos.size());
+    if (!rc) rc = upload_vec(&sc->dDvUv, bd.uv.data(), bd.uv.size());
+    if (!rc) rc = upload_vec(&sc->dDvNormal, bd.nrm.data(), bd.nrm.size());
+    if (!rc) rc = upload_vec(&sc->dDvTangent, bd.tan.data(), bd.tan.size());
+    if (!rc) rc = upload_vec(&sc->dDecalChunkPrim, bd.chunkPrim.data(), bd.chunkPrim.size());
+    if (!rc) rc = upload_vec(&sc->dDecalChunkFirstTri, bd.chunkFirstTri.data(), bd.chunkFirstTri.size());
+    if (!rc) rc = upload_vec(&sc->dDecalLocalToWorld, l2w.data(), l2w.size());
+    return rc;
+}
+
+// Per primitive: the index list widened to 32 bit (MeshMaterial::GetUint, mesh-material.hlsli:5-43: 2- or 4-byte
+// indices), the attributes of vertices 0 .. max index, and a table that cuts the triangles into 64-triangle chunks.
+static int bake_primitives(const HostScene& h, const std::vector<incr_gpu_primitive>& prims, const char* what, BakedPrims* out) {
+    std::vector<PrimDraw>& draws = out->draws; draws.assign(prims.size(), PrimDraw{});
+    std::vector<uint32_t>& indices = out->indices; std::vector<uint32_t>& chunkPrim = out->chunkPrim; std::vector<uint32_t>& chunkFirstTri = out->chunkFirstTri;
+    std::vector<float4>& ppos = out->pos; std::vector<float4>& pnrm = out->nrm; std::vector<float4>& ptan = out->tan; std::vector<float2>& puv = out->uv;
+    for (size_t pi = 0; pi < prims.size(); ++pi) {
+        const incr_gpu_primitive& pr = prims[pi];
         PrimDraw& d = draws[pi];
         memset(&d, 0, sizeof d);
         d.indexBegin = (uint32_t)indices.size(); d.indexCount = pr.indexCount > 0 ? (uint32_t)pr.indexCount / 3u * 3u : 0u;
@@ -122,7 +169,7 @@ int incr_raster_scene_upload(incr_scene* sc) {
             else if (ib && stride == 4 && (size_t)i * 4 + 4 <= avail) memcpy(&v, ib + (size_t)i * 4, 4);
             indices.push_back(v); maxIndex = std::max(maxIndex, v);
         }
-        if (d.indexCount / 3u > (1u << 20)) return fail(INCR_ERR_INVALID_ARGUMENT, "primitive %zu has more than 2^20 triangles: does not fit the visibility encoding", pi);
+        if (d.indexCount / 3u > (1u << 20)) return fail(INCR_ERR_INVALID_ARGUMENT, "%s %zu has more than 2^20 triangles: does not fit the visibility encoding", what, pi);
         const uint32_t nverts = d.indexCount ? maxIndex + 1u : 0u;
         for (uint32_t v = 0; v < nverts; ++v) {
             float f[4];
@@ -133,20 +180,13 @@ int incr_raster_scene_upload(incr_scene* sc) {
         }
         for (uint32_t t = 0; t < d.indexCount / 3u; t += 64) { chunkPrim.push_back((uint32_t)pi); chunkFirstTri.push_back(t); }
     }
-    sc->numPrimChunks = (uint32_t)chunkPrim.size();
-    rc = upload_vec(&sc->dPrimDraws, draws.data(), draws.size());
-    if (!rc) rc = upload_vec(&sc->dPrimIndices, indices.data(), indices.size());
-    if (!rc) rc = upload_vec(&sc->dPvPos, ppos.data(), ppos.size());
-    if (!rc) rc = upload_vec(&sc->dPvUv, puv.data(), puv.size());
-    if (!rc) rc = upload_vec(&sc->dPvNormal, pnrm.data(), pnrm.size());
-    if (!rc) rc = upload_vec(&sc->dPvTangent, ptan.data(), ptan.size());
-    if (!rc) rc = upload_vec(&sc->dChunkPrim, chunkPrim.data(), chunkPrim.size());
-    if (!rc) rc = upload_vec(&sc->dChunkFirstTri, chunkFirstTri.data(), chunkFirstTri.size());
-    return rc;
+    return INCR_OK;
 }
 void incr_raster_scene_free(incr_scene* sc) {
     void* ptrs[] = {sc->dMeshlets, sc->dPackedTris, sc->dMeshVisibility, sc->dMvPos, sc->dMvUv, sc->dMvNormal, sc->dMvTangent,
-                    sc->dPrimDraws, sc->dPrimIndices, sc->dPvPos, sc->dPvUv, sc->dPvNormal, sc->dPvTangent, sc->dChunkPrim, sc->dChunkFirstTri};
+                    sc->dPrimDraws, sc->dPrimIndices, sc->dPvPos, sc->dPvUv, sc->dPvNormal, sc->dPvTangent, sc->dChunkPrim, sc->dChunkFirstTri,
+                    sc->dDecalDraws, sc->dDecalIndices, sc->dDvPos, sc->dDvUv, sc->dDvNormal, sc->dDvTangent, sc->dDecalChunkPrim, sc->dDecalChunkFirstTri,
+                    sc->dDecalLocalToWorld};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -373,6 +413,40 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
     }
     P.bent = d->bent_normals; P.useBent = d->use_bent_normals;
     HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decals
+int incr_gbuffer_decals(incr_context* ctx, const incr_gbuffer_decals_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
+    int rc = check_view(d->view);
+    if (rc) return rc;
+    if (!d->depth_buffer || !d->gbuffer_basecolor || !d->gbuffer_normals || !d->gbuffer_metallic_roughness_ao) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL surface");
+    const incr_scene* sc = d->scene;
+    if (!sc->numDecals || !sc->numDecalChunks) return INCR_OK;                    // no decals in this scene
+    if (sc->numDecals >= 4096) return fail(INCR_ERR_INVALID_ARGUMENT, "%u decal primitives: at most 4095 (12-bit id in the record key)", sc->numDecals);
+    DecalParams P; memset(&P, 0, sizeof P);
+    fill_raster_scene(ctx, sc, P.S);
+    P.prims.draws = sc->dDecalDraws; P.prims.indices = sc->dDecalIndices;
+    P.prims.pvPos = sc->dDvPos; P.prims.pvUv = sc->dDvUv; P.prims.pvNormal = sc->dDvNormal; P.prims.pvTangent = sc->dDvTangent;
+    P.prims.chunkPrim = sc->dDecalChunkPrim; P.prims.chunkFirstTri = sc->dDecalChunkFirstTri;
+    P.prims.numPrims = sc->numDecals; P.prims.numChunks = sc->numDecalChunks;
+    P.decalLocalToWorld = sc->dDecalLocalToWorld;
+    memcpy(P.viewProj, d->view->view_proj_transform.m, 64);
+    P.W = d->view->res_x; P.H = d->view->res_y; scissor_rows(*d->view, &P.y0, &P.y1);
+    P.rounding = d->storage_rounding;
+    P.depth = d->depth_buffer; P.g0 = d->gbuffer_basecolor; P.g1 = d->gbuffer_normals; P.g2 = d->gbuffer_metallic_roughness_ao;
+    // two record slots per decal triangle of every chunk: the visibility workspace's record array is reused
+    const size_t slots = (size_t)sc->numDecalChunks * 64 * 2;
+    RasterWorkspace ws;
+    if ((rc = ensure_raster_workspace(ctx, 1, P.S.numMeshes, slots / 2 + 1, (hipStream_t)stream, &ws))) return rc;
+    if (ws.recCap < slots) return fail(INCR_ERR_OUT_OF_MEMORY, "decal record workspace too small");
+    P.recs = ws.recs; P.numSlots = (uint32_t)slots;
+    P.listCap = 1024;
+    // test hook: a small tile list forces flushes in the middle of the slot walk (the blend order must survive them)
+    if (const char* cap = getenv("INCR_DECAL_LIST_CAP")) { const unsigned long v = strtoul(cap, nullptr, 10); P.listCap = v < 256 ? 256u : (v > 1024 ? 1024u : (uint32_t)v); }
+    HIP_TRY(incr_launch_decals(&P, ctx->props.multiProcessorCount, (hipStream_t)stream));
     return INCR_OK;
 }
 

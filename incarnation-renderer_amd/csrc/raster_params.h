@@ -95,6 +95,19 @@ struct VisParams {
     int32_t forward;                                 // forward pass: every primitive of every visible mesh in scene order, cull mode from the material
 };
 
+// Decal G-buffer pass: `prims` carries the baked decal draws (meshIndex = decal index into decalLocalToWorld); every decal
+// triangle owns two fixed record slots (near-plane clipping yields at most two screen triangles), key 0xffffffff = empty.
+struct DecalParams {
+    RasterScene S; RasterPrims prims;
+    const float* __restrict__ decalLocalToWorld;
+    float viewProj[16];
+    uint32_t W, H, y0, y1; int32_t rounding;
+    const float* __restrict__ depth;
+    uint32_t* __restrict__ g0; uint32_t* __restrict__ g1; uint32_t* __restrict__ g2;
+    SubTriRec* __restrict__ recs; uint32_t numSlots;
+    uint32_t listCap;                                // entries of the per-tile LDS list before it is flushed (256 .. 1024)
+};
+
 struct ForwardParams {
     RasterScene S; RasterPrims prims; PtParams Pt;   // Pt: lights + BVH for the sun's shadow query
     uint32_t W, H, y0, y1; int32_t rounding;

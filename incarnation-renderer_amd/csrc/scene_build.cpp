@@ -37,6 +37,12 @@ void copy_scene_desc(const incr_scene_desc& d, HostScene& s) {
     for (uint32_t i = 0; i < d.num_scene_lights; ++i) s.lightTransforms[i] = m44_from(d.light_transforms[i]);
     s.rootTransform = m44_from(d.root_transform);
     memcpy(s.sunDir, d.sun_dir, 12);
+    s.decalPrimitives.clear(); s.decalTransforms.clear();
+    if (d.num_decal_primitives && d.decal_primitives && d.decal_transforms) {
+        s.decalPrimitives.assign(d.decal_primitives, d.decal_primitives + d.num_decal_primitives);
+        s.decalTransforms.resize(d.num_decal_primitives);
+        for (uint32_t i = 0; i < d.num_decal_primitives; ++i) s.decalTransforms[i] = m44_from(d.decal_transforms[i]);
+    }
 }
 
 // ---- accessor fetchers: the rules of shaders/common/mesh-material.hlsli:45-170, resolved on the host ----

@@ -26,6 +26,9 @@ struct HostScene {
     std::vector<M44> lightTransforms;
     M44 rootTransform;
     float sunDir[3];
+    // FScene::m_sceneMeshDecals: drawn by the decal G-buffer pass only (not in `primitives`, not in the BVH)
+    std::vector<incr_gpu_primitive> decalPrimitives;
+    std::vector<M44> decalTransforms;      // per decal primitive
 };
 
 struct HostBvh {

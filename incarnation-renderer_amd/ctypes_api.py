@@ -93,6 +93,7 @@ class SceneDesc(C.Structure):
         ("light_transforms", C.POINTER(Matrix)),
         ("root_transform", Matrix),
         ("sun_dir", c_float3), ("reserved", C.c_uint32),
+        ("num_decal_primitives", C.c_uint32), ("decal_primitives", C.POINTER(GpuPrimitive)), ("decal_transforms", C.POINTER(Matrix)),
     ]
 
 
@@ -215,6 +216,11 @@ class DebugVizDesc(C.Structure):
                 ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p), ("depth_buffer", C.c_void_p),
                 ("ambient_occlusion", C.c_void_p), ("bent_normals", C.c_void_p), ("color_target", C.c_void_p),
                 ("light_cluster_slices", C.c_uint32), ("use_primitives", C.c_int32), ("storage_rounding", C.c_int32)]
+
+
+class GBufferDecalsDesc(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("view", _VC), ("depth_buffer", C.c_void_p), ("gbuffer_basecolor", C.c_void_p),
+                ("gbuffer_normals", C.c_void_p), ("gbuffer_metallic_roughness_ao", C.c_void_p), ("storage_rounding", C.c_int32)]
 
 
 class ForwardLightingDesc(C.Structure):

@@ -215,6 +215,11 @@ def build_descs(scene_handle, packed_scene, vc, surf, frame_index, cfg=A.FConfig
     d.color_target, d.storage_rounding = surf["color"], storage_rounding
     d.use_primitives = use_prims
     out.append(("gbuffer", d))
+    if getattr(packed_scene, "decal_primitives", None):      # renderer.cpp:1783-1798 GBufferRasterPass (decals), unconditional there
+        d = A.GBufferDecalsDesc(); d.scene, d.view = scene_handle, vcp
+        d.depth_buffer, d.gbuffer_basecolor, d.gbuffer_normals, d.gbuffer_metallic_roughness_ao = surf["depth"], surf["gbuffer_basecolor"], surf["gbuffer_normals"], surf["gbuffer_mra"]
+        d.storage_rounding = storage_rounding
+        out.append(("gbuffer_decals", d))
     if cfg.EnableHBAO:              # renderer.cpp:1801-1815; off = both targets cleared to 1 = NULL inputs of sky lighting
         d = A.HbaoDesc(); d.scene, d.view = scene_handle, vcp
         d.depth_buffer, d.gbuffer_normals = surf["depth"], surf["gbuffer_normals"]
@@ -381,7 +386,7 @@ class RasterRenderer:
     PASS_FN = dict(batch_cull="incr_batch_cull", light_cull="incr_light_cull", visibility="incr_visibility", gbuffer="incr_gbuffer",
                    sky_lighting="incr_sky_lighting", direct_lighting="incr_direct_lighting", clustered_lighting="incr_clustered_lighting",
                    taa_resolve="incr_taa_resolve", dynamic_sky="incr_dynamic_sky", hbao="incr_hbao", environmentmap="incr_environmentmap", debug_visualization="incr_debug_visualization",
-                   forward_lighting="incr_forward_lighting")
+                   forward_lighting="incr_forward_lighting", gbuffer_decals="incr_gbuffer_decals")
 
     def __init__(self, ctx, scene, res_x, res_y, cfg=A.FConfig):
         self.ctx, self.scene, self.cfg = ctx, scene, cfg

@@ -26,7 +26,7 @@ EXPORTS = [
     "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
     "incr_sky_lighting", "incr_direct_lighting", "incr_clustered_lighting", "incr_taa_resolve", "incr_dynamic_sky",
-    "incr_hbao", "incr_environmentmap", "incr_debug_visualization", "incr_forward_lighting",
+    "incr_hbao", "incr_environmentmap", "incr_debug_visualization", "incr_forward_lighting", "incr_gbuffer_decals",
     # frame level (C++ host mirror of Renderer::Render)
     "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
@@ -102,7 +102,8 @@ def load():
                        ("incr_gbuffer", A.GBufferDesc), ("incr_sky_lighting", A.SkyLightingDesc), ("incr_direct_lighting", A.DirectLightingDesc),
                        ("incr_clustered_lighting", A.ClusteredLightingDesc), ("incr_taa_resolve", A.TaaResolveDesc),
                        ("incr_dynamic_sky", A.DynamicSkyDesc), ("incr_hbao", A.HbaoDesc), ("incr_environmentmap", A.EnvironmentmapDesc),
-                       ("incr_debug_visualization", A.DebugVizDesc), ("incr_forward_lighting", A.ForwardLightingDesc)):
+                       ("incr_debug_visualization", A.DebugVizDesc), ("incr_forward_lighting", A.ForwardLightingDesc),
+                       ("incr_gbuffer_decals", A.GBufferDecalsDesc)):
         fn = getattr(L, name)
         fn.restype = C.c_int; fn.argtypes = [vp, C.POINTER(desc), vp]
     L.incr_renderer_create.restype = C.c_int

@@ -181,6 +181,7 @@ class PackedScene:
         self.mesh_names = []
         self.mesh_primitives = []    # per mesh: list of dict(index, position, uv, normal, tangent, material, index_count, sphere)
         self.mesh_transforms = []    # per mesh 4x4
+        self.decal_primitives = []   # FScene::m_sceneMeshDecals flattened: list of (primitive dict, mesh 4x4), in draw order
         self.mesh_visibility = None
         self.materials = []          # list of A.Material
         self.textures = []           # list of (np.uint8 HxWx4, format)
@@ -288,6 +289,20 @@ class PackedScene:
         d.root_transform = to_matrix(self.root_transform)
         for i in range(3):
             d.sun_dir[i] = float(self.sun_dir[i])
+        if self.decal_primitives:
+            dps = []
+            for p, _ in self.decal_primitives:
+                g = A.GpuPrimitive()
+                for i in range(4):
+                    g.boundingSphere[i] = float(p["sphere"][i])
+                g.meshIndex = 0
+                g.indexAccessor, g.positionAccessor = p["index"], p["position"]
+                g.uvAccessor, g.normalAccessor, g.tangentAccessor = p["uv"], p["normal"], p["tangent"]
+                g.materialIndex, g.indicesPerTriangle, g.indexCount = p["material"], 3, p["index_count"]
+                dps.append(g)
+            d.num_decal_primitives = len(dps)
+            d.decal_primitives = C.cast(arr(A.GpuPrimitive, dps), C.POINTER(A.GpuPrimitive))
+            d.decal_transforms = C.cast(arr(A.Matrix, [to_matrix(m) for _, m in self.decal_primitives]), C.POINTER(A.Matrix))
         self._desc = d
         return d
 
@@ -415,9 +430,12 @@ def load_gltf(path, load_images=True, max_texture_size=None):
                 prims.append(dict(index=p["indices"], position=at["POSITION"], uv=at.get("TEXCOORD_0", -1),
                                   normal=at.get("NORMAL", -1), tangent=at.get("TANGENT", -1), material=p.get("material", 0),
                                   index_count=g["accessors"][p["indices"]]["count"], sphere=_bounding_sphere(pos)))
-            s.mesh_names.append(mesh.get("name", ""))
-            s.mesh_primitives.append(prims)
-            s.mesh_transforms.append(world)
+            if mesh.get("name", "").startswith("decal"):          # scene.cpp:281: decal meshes live in their own entity list
+                s.decal_primitives.extend((p, world) for p in prims)
+            else:
+                s.mesh_names.append(mesh.get("name", ""))
+                s.mesh_primitives.append(prims)
+                s.mesh_transforms.append(world)
         light_ext = n.get("extensions", {}).get("KHR_lights_punctual")
         if light_ext is not None:
             s.light_indices.append(light_ext["light"])

@@ -418,3 +418,48 @@ def bistro_scale(num_instances=1024, tris_per_mesh=2800, num_materials=100, text
     s.cameras.append({"transform": cam_world, "yfov": 0.7, "aspect": 16 / 9})
     add_light_rig(s, seed, 64, ((-side * 1.4, side * 1.4), (0.8, 4.0), (-side * 1.4, side * 1.4)))
     return s
+
+
+def add_decals(s, seed=SPONZA_SEED, texture_size=64):
+    """Decal meshes for the Sponza-stat atrium (the reference keeps meshes named "decal*" in FScene::m_sceneMeshDecals,
+    scene.cpp:281): four primitives over the nave floor in front of the camera, overlapping each other, with the material
+    combinations the decal pass distinguishes -- base colour only, + normal map, + metallic-roughness map, double-sided."""
+    sc = f32(SPONZA_NODE_SCALE)
+    parts = [
+        # (sheet function, triangles, aspect, uv tile, material flags (normal map, mr map, double sided), alpha stream)
+        (plane([-7.5, 0.03, 1.2], [5.0, 0, 0], [0, 0, -2.6]), 2, 2.0, (1.0, 1.0), (False, False, False)),
+        (plane([-5.5, 0.05, 2.0], [4.0, 0, 0], [0, 0, -3.2]), 8, 1.2, (2.0, 2.0), (True, True, False)),
+        (plane([-4.0, 0.9, 1.6], [3.0, 0.4, 0], [0, 0.2, -3.0], 0.25, (2, 2)), 200, 1.0, (1.0, 1.0), (True, False, True)),
+        (plane([-9.0, 0.04, -0.4], [6.0, 0, 0], [0, 0, -1.0]), 2, 6.0, (3.0, 1.0), (False, True, False)),
+    ]
+    prim_arrays, flags = [], []
+    for fn, ntri, aspect, tile, fl in parts:
+        P, N, T4, UV, I = sheet(fn, ntri, aspect, tile)
+        prim_arrays.append(((P / sc).astype(f32), N.astype(f32), T4.astype(f32), UV.astype(f32), I.astype(np.uint16)))
+        flags.append(fl)
+    first_material = len(s.materials)
+    prims = _pack_geometry(s, prim_arrays, lambda k: first_material + k)
+    # _pack_geometry appends a NEW buffer: its views must point at it
+    new_buffer = len(s.buffers) - 1
+    nviews = 5 * len(prim_arrays)
+    s.buffer_views[-nviews:] = [(new_buffer, off, size) for (_, off, size) in s.buffer_views[-nviews:]]
+    for k, (has_nm, has_mr, double_sided) in enumerate(flags):
+        base, mr, nm = make_material_textures(seed, 200 + k, texture_size, False)
+        alpha = value_noise(seed, 900 + k, texture_size, 3, 2)
+        base[..., 3] = np.round(np.clip(0.15 + 0.85 * alpha, 0, 1) * 255).astype(np.uint8)      # opacity = base colour alpha
+        m = A.Material()
+        for n in A._MAT_TEX:
+            setattr(m, n + "TextureIndex", -1); setattr(m, n + "SamplerIndex", -1)
+        for i in range(3):
+            m.baseColorFactor[i] = 1.0; m.emissiveFactor[i] = 0.0
+        m.metallicFactor, m.roughnessFactor, m.aoStrength = 1.0, 1.0, 1.0
+        m.baseColorTextureIndex = s.add_texture(base, A.TEX_RGBA8_SRGB)
+        if has_mr:
+            m.metallicRoughnessTextureIndex = s.add_texture(mr, A.TEX_BGRA8_SWIZZLE_RG)
+        if has_nm:
+            m.normalTextureIndex = s.add_texture(nm, A.TEX_RG_SNORM)
+        m.alphaMode, m.doubleSided = A.ALPHA_BLEND if hasattr(A, "ALPHA_BLEND") else A.ALPHA_MASKED, 1 if double_sided else 0
+        s.materials.append(m)
+    world = s.mesh_transforms[0]
+    s.decal_primitives.extend((p, world) for p in prims)
+    return s

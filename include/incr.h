@@ -301,6 +301,26 @@ typedef struct incr_gbuffer_desc {
 int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* desc, incr_stream stream);
 
 /*
+ * RenderJob::GBufferRasterPass::Execute (render-jobs/gbuffer-raster-pass.inl; shaders/geo-raster/gbuffer-raster.hlsl): the
+ * decals of the scene (incr_scene_desc::decal_primitives) drawn in order over the G-buffers after incr_gbuffer.  Depth
+ * test GREATER_EQUAL against the scene depth, no depth writes, no alpha clip; base colour blended SRC_ALPHA / INV_SRC_ALPHA
+ * (colour and alpha channels alike, re-quantised to UNORM8 after every fragment), normals replaced only by decals with a
+ * normal map, metallic / roughness / ao only by decals with a metallic-roughness map.  A scene without decals makes this a
+ * no-op.  Here: one set-up kernel files every decal triangle in a fixed slot, one kernel per pixel tile walks the slots in
+ * draw order -- the blend order is the reference's draw order, whatever the scheduling.
+ */
+typedef struct incr_gbuffer_decals_desc {
+    const incr_scene* scene;
+    const incr_view_constants* view;
+    const float* depth_buffer;
+    uint32_t* gbuffer_basecolor;
+    uint32_t* gbuffer_normals;
+    uint32_t* gbuffer_metallic_roughness_ao;
+    int32_t  storage_rounding;
+} incr_gbuffer_decals_desc;
+int incr_gbuffer_decals(incr_context* ctx, const incr_gbuffer_decals_desc* desc, incr_stream stream);
+
+/*
  * RenderJob::HBAO::Execute (render-jobs/hbao.inl:16-105; shaders/postprocess/hbao.hlsl): ray-traced horizon-based
  * ambient occlusion.  Per pixel 4 azimuthal slices x 2 horizons x a binary search of at most 4 any-hit ray queries
  * (TMin 0.1, TMax 1, back faces culled) against the scene BVH, integrated against the projected normal; writes the

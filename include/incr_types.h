@@ -171,6 +171,10 @@ typedef struct incr_scene_desc {
     incr_matrix root_transform;           /* FScene::m_rootTransform == shader `sceneRotation` */
     float    sun_dir[3];                  /* FScene::m_sunDir from time of day (scene.cpp:1594-1655); feeds the dynamic-sky environment */
     uint32_t reserved;
+    /* FScene::m_sceneMeshDecals (scene.cpp:281: meshes whose name starts with "decal"): kept out of the packed primitives
+     * and the BVH, drawn only by the decal G-buffer pass (incr_gbuffer_decals).  Accessors / materials index the arrays above. */
+    uint32_t num_decal_primitives;        const incr_gpu_primitive* decal_primitives;   /* in draw order: mesh, then primitive */
+                                          const incr_matrix* decal_transforms;         /* per decal PRIMITIVE: its mesh's m_transformList entry */
 } incr_scene_desc;
 
 /* FView (inc/renderer.h) fields the passes read. */

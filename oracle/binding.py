@@ -71,6 +71,7 @@ def lib():
         L.orc_dynamic_sky.argtypes = [vp, C.POINTER(A.DynamicSkyDesc)]
         L.orc_environmentmap.argtypes = [C.POINTER(A.EnvironmentmapDesc)]
         L.orc_debug_visualization.argtypes = [C.POINTER(A.DebugVizDesc)]
+        L.orc_gbuffer_decals.argtypes = [vp, C.POINTER(A.GBufferDecalsDesc)]
         L.orc_forward_lighting.argtypes = [vp, C.POINTER(A.ForwardLightingDesc), C.POINTER(C.c_uint64)]
         L.orc_cluster_frustum.argtypes = [C.POINTER(u32), C.POINTER(u32), C.c_float, C.c_float, C.POINTER(A.Matrix), C.POINTER(A.Matrix), fp]
         L.orc_hbao.argtypes = [vp, C.POINTER(A.HbaoDesc), C.POINTER(C.c_uint64)]
@@ -223,6 +224,8 @@ def run_pass(scene, name, desc):
         L.orc_dynamic_sky(h, C.byref(desc))
     elif name == "environmentmap":
         L.orc_environmentmap(C.byref(desc))
+    elif name == "gbuffer_decals":
+        L.orc_gbuffer_decals(h, C.byref(desc))
     elif name == "forward_lighting":
         rays = C.c_uint64()
         L.orc_forward_lighting(h, C.byref(desc), C.byref(rays))

@@ -385,6 +385,106 @@ static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const ui
     }
 }
 
+// ------------------------------------------------------------------------------------------------ decals
+// render-jobs/gbuffer-raster-pass.inl:17-233 + shaders/geo-raster/gbuffer-raster.hlsl: every primitive of
+// FScene::m_sceneMeshDecals is drawn in order over the G-buffers -- depth test GREATER_EQUAL against the scene depth without
+// writes, back faces culled unless the material is double-sided, RT0 (base colour) blended SRC_ALPHA / INV_SRC_ALPHA in
+// colour AND alpha, RT1 (normals) overwritten only when the decal has a normal map, RT2 only when it has a
+// metallic-roughness map.  Rasterisation rules as the visibility pass; UNORM8 blending in float, stored per fragment.
+template <class F> static void raster_cover(uint32_t W, uint32_t y0, uint32_t y1, ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, F frag) {
+    int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
+    if (area == 0) return;
+    if (area > 0) { if (cullBack) return; }
+    else { ScreenVert t = v1; v1 = v2; v2 = t; area = -area; }
+    const int32_t minX = std::min(v0.X, std::min(v1.X, v2.X)), maxX = std::max(v0.X, std::max(v1.X, v2.X));
+    const int32_t minY = std::min(v0.Y, std::min(v1.Y, v2.Y)), maxY = std::max(v0.Y, std::max(v1.Y, v2.Y));
+    const int32_t px0 = std::max(0, (minX + 127) >> 8), px1 = std::min((int32_t)W - 1, (maxX - 128) >> 8);
+    const int32_t py0 = std::max((int32_t)y0, (minY + 127) >> 8), py1 = std::min((int32_t)y1 - 1, (maxY - 128) >> 8);
+    auto topLeft = [](int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; };
+    const double invArea = 1.0 / (double)area;
+    const int64_t b01 = topLeft(v1.X - v0.X, v1.Y - v0.Y) ? 0 : -1, b12 = topLeft(v2.X - v1.X, v2.Y - v1.Y) ? 0 : -1, b20 = topLeft(v0.X - v2.X, v0.Y - v2.Y) ? 0 : -1;
+    for (int32_t py = py0; py <= py1; ++py)
+        for (int32_t px = px0; px <= px1; ++px) {
+            const int64_t Sx = (int64_t)px * 256 + 128, Sy = (int64_t)py * 256 + 128;
+            const int64_t E01 = (int64_t)(v1.X - v0.X) * (Sy - v0.Y) - (int64_t)(v1.Y - v0.Y) * (Sx - v0.X);
+            const int64_t E12 = (int64_t)(v2.X - v1.X) * (Sy - v1.Y) - (int64_t)(v2.Y - v1.Y) * (Sx - v1.X);
+            const int64_t E20 = (int64_t)(v0.X - v2.X) * (Sy - v2.Y) - (int64_t)(v0.Y - v2.Y) * (Sx - v2.X);
+            if (E01 + b01 < 0 || E12 + b12 < 0 || E20 + b20 < 0) continue;
+            const float l1 = (float)((double)E20 * invArea), l2 = (float)((double)E01 * invArea);
+            float depth = (v0.z + l1 * (v1.z - v0.z)) + l2 * (v2.z - v0.z);
+            if (!(depth >= 0.f)) continue;
+            if (depth > 1.f) depth = 1.f;
+            frag((uint32_t)px, (uint32_t)py, depth);
+        }
+}
+static void gbuffer_decals(const Scene& s, const incr_gbuffer_decals_desc& d) {
+    const incr_view_constants& vc = *d.view;
+    const uint32_t W = vc.res_x, H = vc.res_y;
+    uint32_t y0, y1; scissor_rows(vc, &y0, &y1);
+    const Mat4 viewProj = to_mat4(vc.view_proj_transform), root = to_mat4(s.d.root_transform);
+    const float Wf = (float)W, Hf = (float)H;
+    for (uint32_t di = 0; di < s.d.num_decal_primitives; ++di) {
+        const incr_gpu_primitive& pr = s.d.decal_primitives[di];
+        const incr_material& mat = s.d.materials[pr.materialIndex];
+        const Mat4 localToWorld = mat_mul(to_mat4(s.d.decal_transforms[di]), root);          // gbuffer-raster.hlsl:51
+        const uint32_t ntri = pr.indexCount > 0 ? (uint32_t)pr.indexCount / 3u : 0u;
+        for (uint32_t tri = 0; tri < ntri; ++tri) {
+            uint32_t vi[3]; GetUint3(s, (int)(tri * 3u), pr.indexAccessor, vi);
+            ClipVert cv[3]; float4 clip[3]; float2 uv[3]; float3 nW[3], tW[3], bW[3];
+            for (int k = 0; k < 3; ++k) {                                                     // vs_main :46-78
+                const float3 pos = GetFloat3(s, (int)vi[k], pr.positionAccessor);
+                const float4 worldPos = mul_vec4({pos.x, pos.y, pos.z, 1.f}, localToWorld);
+                clip[k] = mul_vec4(worldPos, viewProj);
+                cv[k] = {clip[k].x, clip[k].y, clip[k].z, clip[k].w};
+                uv[k] = GetFloat2(s, (int)vi[k], pr.uvAccessor);
+                const float3 normal = GetFloat3(s, (int)vi[k], pr.normalAccessor);
+                const float4 pt = GetFloat4(s, (int)vi[k], pr.tangentAccessor);
+                const float3 tangent = {pt.x, pt.y, pt.z};
+                const float3 bitangent = cross(normal, tangent) * pt.w;
+                const float4 n4 = mul_vec4({normal.x, normal.y, normal.z, 0.f}, localToWorld), t4 = mul_vec4({tangent.x, tangent.y, tangent.z, 0.f}, localToWorld);
+                const float4 b4 = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, localToWorld);
+                nW[k] = {n4.x, n4.y, n4.z}; tW[k] = {t4.x, t4.y, t4.z}; bW[k] = {b4.x, b4.y, b4.z};
+            }
+            bool in[3]; int nin = 0;
+            for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
+            if (nin == 0) continue;
+            ClipVert poly[4]; int np = 0;
+            if (nin == 3) { poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2]; np = 3; }
+            else for (int k = 0; k < 3; ++k) {
+                const int j = (k + 1) % 3;
+                if (in[k]) poly[np++] = cv[k];
+                if (in[k] != in[j]) poly[np++] = in[k] ? clip_lerp(cv[k], cv[j]) : clip_lerp(cv[j], cv[k]);
+            }
+            ScreenVert sv[4]; bool ok = true;
+            for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], Wf, Hf, &sv[k]);
+            if (!ok) continue;
+            auto frag = [&](uint32_t px, uint32_t py, float depth) {
+                const size_t i = (size_t)py * W + px;
+                if (!(depth >= d.depth_buffer[i])) return;                                     // GREATER_EQUAL, DepthWriteMask ZERO
+                const float3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(px, py, Wf, Hf));
+                const MatProps p = EvaluateMaterialProperties(s, mat, interp2(uv[0], uv[1], uv[2], lam));
+                const float3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
+                float3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
+                if (p.bHasNormalmap) {
+                    const float3 nm = p.normalmap;
+                    N = normalize(f3((nm.x * T.x + nm.y * B.x) + nm.z * N.x, (nm.x * T.y + nm.y * B.y) + nm.z * N.y, (nm.x * T.z + nm.y * B.z) + nm.z * N.z));
+                }
+                const float4 dst = unpack_unorm8x4(d.gbuffer_basecolor[i]);
+                const float a = p.opacity, ia = 1.f - a;
+                d.gbuffer_basecolor[i] = pack_unorm8x4({p.basecolor.x * a + dst.x * ia, p.basecolor.y * a + dst.y * ia, p.basecolor.z * a + dst.z * ia, a * a + dst.w * ia});
+                if (mat.normalTextureIndex != -1) {
+                    const float2 oct = OctEncode(N);
+                    d.gbuffer_normals[i] = (uint32_t)f32_to_f16(oct.x, d.storage_rounding) | ((uint32_t)f32_to_f16(oct.y, d.storage_rounding) << 16);
+                }
+                if (mat.metallicRoughnessTextureIndex != -1) d.gbuffer_metallic_roughness_ao[i] = pack_unorm8x4({p.metallic, p.roughness, p.ao, p.aoblend});
+            };
+            const bool cullBack = !mat.doubleSided;
+            raster_cover(W, y0, y1, sv[0], sv[1], sv[2], cullBack, frag);
+            if (np == 4) raster_cover(W, y0, y1, sv[0], sv[2], sv[3], cullBack, frag);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ HBAO
 // shaders/postprocess/hbao.hlsl:1-175.  HLSL leaves the precision of cos / sin / acos / rsqrt to the implementation; the
 // pinned choice is a fixed evaluation both sides restate: Cody-Waite reduction by pi/2 + Taylor polynomials
@@ -949,6 +1049,7 @@ void orc_cluster_frustum(const uint32_t ci[3], const uint32_t grid[3], float zNe
 }
 void orc_environmentmap(const incr_environmentmap_desc* d) { environmentmap_pass(*d); }
 void orc_debug_visualization(const incr_debug_viz_desc* d) { debug_visualization(*d); }
+void orc_gbuffer_decals(void* scene, const incr_gbuffer_decals_desc* d) { gbuffer_decals(*(Scene*)scene, *d); }
 void orc_forward_lighting(void* scene, const incr_forward_lighting_desc* d, uint64_t* shadowRays) { forward_lighting(*(Scene*)scene, *d, shadowRays); }
 void orc_hbao(void* scene, const incr_hbao_desc* d, uint64_t* rays) { hbao_pass(*(Scene*)scene, *d, rays); }
 void orc_hb_math(float x, float out[3]) { out[0] = hb_sin(x); out[1] = hb_cos(x); out[2] = hb_acos(x); }

@@ -85,3 +85,9 @@ def gpu_ctx(rt):
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def sponza_decals(synth):
+    """sponza_small plus four overlapping decal primitives (FScene::m_sceneMeshDecals) over the nave floor."""
+    return mod("raster").generate_meshlets(synth.add_decals(synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0)))

@@ -374,6 +374,45 @@ def test_raster_tiny_and_empty_frames(rt, R, ob, A, sio, gpu_ctx, sponza_small):
         osc.close(); gscene.close()
 
 
+def test_decal_gbuffer_pass_parity(rt, R, ob, A, sio, gpu_ctx, sponza_decals, monkeypatch):
+    """incr_gbuffer_decals (gbuffer-raster-pass.inl): four overlapping decal primitives blended in draw order -- G-buffers
+    bit-exact against the oracle at two resolutions, through the C++ renderer, in a row band, and with a forced tiny tile
+    list the result must not change (list flushes keep the order)."""
+    gscene = gpu_ctx.create_scene(sponza_decals)
+    osc = ob.OracleScene(sponza_decals)
+    try:
+        for W, H in ((256, 144), (203, 117)):
+            if W == 203:
+                monkeypatch.setenv("INCR_DECAL_LIST_CAP", "256")          # 896 slots: the tile list is flushed between rounds
+            view = sio.FView().reset(sponza_decals, aspect=W / H)
+            g = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, A.FConfig, frames=2)
+            hr = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9)
+            band = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9)
+            y0, y1 = H // 3, 2 * H // 3
+            band.set_band(y0, y1)
+            prev, hs = None, None
+            for frame, (vc, gs) in enumerate(g):
+                vco, hs = run_oracle_frame(ob, R, A, sponza_decals, osc, view, W, H, frame_index=frame, prev=prev, hs=hs)
+                prev = R.matrix_to_numpy(vco.unjittered_view_proj)
+                o = hs.arr
+                np.testing.assert_array_equal(gs["vis"], o["vis"])
+                for name in INT_SURFACES[1:]:
+                    np.testing.assert_array_equal(gs[name], o[name], err_msg="%s frame %d" % (name, frame))
+                assert ((gs["gbuffer_basecolor"] >> 24) > 0).mean() > 0.05            # decals really landed
+                assert colour_close(ob, gs["color"], o["color"], "colour with decals") > 0.999
+                hr.render(view); band.render(view); gpu_ctx.synchronize()
+                for which_s, name in ((A.SURFACE_GBUFFER_BASECOLOR, "gbuffer_basecolor"), (A.SURFACE_GBUFFER_NORMALS, "gbuffer_normals"),
+                                      (A.SURFACE_GBUFFER_MRA, "gbuffer_mra"), (A.SURFACE_HDR_RASTER, "color")):
+                    np.testing.assert_array_equal(hr.download(which_s), gs[name].view(np.uint32), err_msg="C++ renderer %s" % name)
+                    np.testing.assert_array_equal(band.download(which_s)[y0:y1], gs[name].view(np.uint32)[y0:y1], err_msg="band %s" % name)
+            hr.close(); band.close()
+        # a scene without decals: the pass is a no-op, not an error
+        d = A.GBufferDecalsDesc()
+        assert gpu_ctx.lib.incr_gbuffer_decals(gpu_ctx.handle, C.byref(d), None) == -1
+    finally:
+        osc.close(); gscene.close()
+
+
 def test_raster_bad_arguments(rt, R, A, sio, gpu_ctx, helmet):
     gscene = gpu_ctx.create_scene(helmet)
     try:

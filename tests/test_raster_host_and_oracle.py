@@ -421,6 +421,50 @@ def test_oracle_forward_lighting(helmet, sponza_small, sio, R, ob, A):
         osc.close()
 
 
+def test_oracle_decals(sponza_small, sponza_decals, sio, R, ob, A, tmp_path):
+    """gbuffer-raster-pass restated: decals never touch ids or depth, only blend into the G-buffers inside their footprints,
+    replace normals / metallic-roughness only when their material has the map, and the loader files "decal*" meshes apart."""
+    import json
+    W, H = 192, 108
+
+    class NoTaa(A.FConfig):
+        EnableTAA = False
+    frames = []
+    for scene in (sponza_small, sponza_decals):
+        osc = ob.OracleScene(scene)
+        view = sio.FView().reset(scene, aspect=W / H)
+        frames.append(run_oracle_frame(ob, R, A, scene, osc, view, W, H, cfg=NoTaa)[1])
+        osc.close()
+    a, b = (f.arr for f in frames)
+    np.testing.assert_array_equal(a["vis"], b["vis"])
+    np.testing.assert_array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+    touched = a["gbuffer_basecolor"] != b["gbuffer_basecolor"]
+    assert 0.05 < touched.mean() < 0.6
+    # the blend writes alpha = a*a + dst.a*(1-a) > 0 exactly where a decal fragment passed; the scene's own alpha is 0
+    assert ((b["gbuffer_basecolor"] >> 24) > 0)[touched].mean() > 0.99 and ((a["gbuffer_basecolor"] >> 24) == 0).all()
+    for name in ("gbuffer_normals", "gbuffer_mra"):
+        changed = a[name] != b[name]
+        assert changed.any() and not (changed & ((b["gbuffer_basecolor"] >> 24) == 0)).any(), name
+    # decal 0 and 3 have no normal map, 0 and 2 no metallic-roughness map: some touched pixels keep each of the two surfaces
+    assert (touched & (a["gbuffer_normals"] == b["gbuffer_normals"])).any() and (touched & (a["gbuffer_mra"] == b["gbuffer_mra"])).any()
+    assert (a["color"] != b["color"]).any()                    # and the lighting sees the new G-buffer
+    # loader: meshes whose name starts with "decal" go to the decal list (scene.cpp:281), everything else to the scene meshes
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    blob = tri.tobytes() + np.array([0, 1, 2, 0], np.uint16).tobytes()
+    (tmp_path / "t.bin").write_bytes(blob)
+    acc = [dict(bufferView=0, componentType=5126, count=3, type="VEC3", min=[0, 0, 0], max=[1, 1, 0]), dict(bufferView=1, componentType=5123, count=3, type="SCALAR")]
+    prim = dict(attributes=dict(POSITION=0), indices=1)
+    gltf = dict(asset=dict(version="2.0"), buffers=[dict(uri="t.bin", byteLength=len(blob))],
+                bufferViews=[dict(buffer=0, byteOffset=0, byteLength=36), dict(buffer=0, byteOffset=36, byteLength=6)], accessors=acc,
+                meshes=[dict(name="body", primitives=[prim]), dict(name="decal_sticker", primitives=[prim, prim])],
+                nodes=[dict(mesh=0), dict(mesh=1, translation=[0, 0, 1])], scenes=[dict(nodes=[0, 1])], scene=0)
+    (tmp_path / "t.gltf").write_text(json.dumps(gltf))
+    s = sio.load_gltf(str(tmp_path / "t.gltf"))
+    assert s.mesh_names == ["body"] and len(s.mesh_primitives) == 1 and len(s.decal_primitives) == 2
+    d = s.to_desc()
+    assert d.num_primitives == 1 and d.num_decal_primitives == 2 and d.decal_transforms[1].m[14] != 0.0
+
+
 def test_oct_encoding_round_trip(ob):
     rng = np.random.default_rng(3)
     n = rng.normal(size=(500, 3)).astype(np.float32)

@@ -18,7 +18,7 @@
 //
 // The traversal kernels are PERSISTENT WITH LANE REFILL (Aila & Laine 2009, adapted to 64-wide waves): a wave
 // owns a chunk of rays (resp. vertices) taken from a device-wide cursor; every loop iteration each lane does ONE
-// traversal step (one 4-wide node or one leaf); lanes whose ray is done are handed the next item of the chunk
+// traversal step (one 8-wide node or one leaf triangle); lanes whose ray is done are handed the next item of the chunk
 // as soon as enough lanes are idle, so a wave never idles on its slowest ray (first wavefront version without
 // refill: 16-22 % VALU lane utilisation, profiles/r01_v3_*).  Every wave reaches the exit (cursor exhausted and
 // no lane active), so the grid always drains.

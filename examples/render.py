@@ -1,0 +1,97 @@
+"""Render a frame with the HIP library and write it as a PNG -- the headless stand-in for the reference's window
+(exe/main.cpp presents the back buffer; this writes it).
+
+    python examples/render.py --scene helmet --mode pathtrace --spp 64 --res 1024x1024 --out helmet.png
+    python examples/render.py --scene sponza --mode raster --frames 16 --res 1920x1080 --hbao --out sponza.png
+
+Needs an MI355X (there is no CPU fallback); the PNG encoder itself is plain Python (zlib)."""
+import argparse
+import importlib
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "incarnation-renderer_amd"
+
+
+def write_png(path, rgba8):
+    """rgba8: (H, W, 4) uint8, sRGB-encoded (the back buffer's R8G8B8A8_UNORM_SRGB bytes).  8-bit RGBA, no interlace."""
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 4)], axis=1).tobytes()      # filter type 0 per scanline
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def read_png(path):
+    """Inverse of write_png for its own files (filter 0, RGBA8): used by the tests."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8]); body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) & 0xffffffff == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", body[:8])
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 4)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 4)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--scene", default="helmet", help="helmet | sponza | bistro | path to a .gltf")
+    ap.add_argument("--mode", default="pathtrace", choices=("pathtrace", "raster"))
+    ap.add_argument("--res", default="1280x720"); ap.add_argument("--spp", type=int, default=16, help="path trace: samples accumulated")
+    ap.add_argument("--frames", type=int, default=8, help="raster: frames rendered (TAA converges over the jitter sequence)")
+    ap.add_argument("--hbao", action="store_true"); ap.add_argument("--forward", action="store_true"); ap.add_argument("--viewmode", type=int, default=0)
+    ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--out", default="frame.png")
+    a = ap.parse_args()
+    A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io"); synth = importlib.import_module(PKG + ".synth")
+    rt = importlib.import_module(PKG + ".runtime"); R = importlib.import_module(PKG + ".raster"); ibl = importlib.import_module(PKG + ".ibl")
+    W, H = (int(v) for v in a.res.lower().split("x"))
+    if a.scene == "helmet":
+        packed = sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"))
+    elif a.scene == "sponza":
+        packed = synth.add_decals(synth.sponza_stat(texture_size=a.texture_size), texture_size=a.texture_size)
+    elif a.scene == "bistro":
+        packed = synth.bistro_scale(texture_size=min(a.texture_size, 256))
+    else:
+        packed = sio.load_gltf(a.scene)
+    R.generate_meshlets(packed)
+
+    class Cfg(A.FConfig):
+        EnableHBAO = a.hbao
+        UseBentNormals = a.hbao
+        ForwardLighting = a.forward
+        Viewmode = a.viewmode
+        MaxSampleCount = max(A.FConfig.MaxSampleCount, a.spp + 1)
+    ctx = rt.Context(0)
+    scene = ctx.create_scene(packed)
+    view = sio.FView().reset(packed, aspect=W / H)
+    sky = ibl.SkyIbl(ctx, scene)
+    lut = ibl.generate_env_brdf(ctx, 512, 512)
+    hr = R.HostRenderer(ctx, scene, W, H, cfg=Cfg, path_trace=(a.mode == "pathtrace"), ibl=R.IblInputs.from_sky(sky, lut, (512, 512)))
+    for _ in range(a.spp if a.mode == "pathtrace" else a.frames):
+        hr.render(view)
+    (culled_objects, culled_lights), rays = hr.stats()
+    ldr = hr.download(A.SURFACE_BACK_BUFFER).view(np.uint8).reshape(H, W, 4).copy()
+    ldr[..., 3] = 255
+    write_png(a.out, ldr)
+    print("%s: %dx%d %s, %d rays traced, %d objects / %d lights culled in the last frame" % (a.out, W, H, a.mode, rays.total_rays(), culled_objects, culled_lights))
+    hr.close(); sky.close(); ctx.free(lut); scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,7 @@ struct Desc {
     FShaderBuffer* lightPropertiesBuffer; FShaderBuffer* lightTransformsBuffer;     // owned by incr_scene here; may be NULL
     uint32_t currentSampleIndex; uint32_t resX; uint32_t resY;
     const FScene* scene; const FView* view; FConfig renderConfig;
+    FShaderBuffer* rayStatsBuffer = nullptr;        // not in the reference: incr_ray_stats accumulation
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }

@@ -57,6 +57,7 @@ Result PathTracing::Execute(Sync* jobSync, const Desc& p) {               // pat
     d.viewmode = p.renderConfig.Viewmode; d.turbidity = p.renderConfig.Turbidity; d.sky_brightness = p.renderConfig.SkyBrightness;
     d.storage_rounding = p.renderConfig.StorageRounding;
     d.envmap_r11g11b10 = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;   // :203 envmapTextureIndex
+    d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
     return done(jobSync->Execute(token, [&] { return incr_pathtrace(jobSync->m_ctx, &d, jobSync->m_stream); }));
 }
 
@@ -363,6 +364,7 @@ int Render(State& s, const FRenderState& renderState) {
             pathtraceDesc.currentSampleIndex = s.pathtraceCurrentSampleIndex;
             pathtraceDesc.resX = resX; pathtraceDesc.resY = resY;
             pathtraceDesc.scene = scene; pathtraceDesc.view = &renderState.m_view; pathtraceDesc.renderConfig = c;
+            pathtraceDesc.rayStatsBuffer = &s.rayStatsBuffer;
             PathTracing::Execute(jobSync, pathtraceDesc);
             s.pathtraceCurrentSampleIndex++;                                   // accumulate samples
         }
@@ -610,6 +612,17 @@ int incr_renderer_set_band(incr_renderer* r, uint32_t row_begin, uint32_t row_en
 }
 int incr_renderer_tonemap(incr_renderer* r) { return r ? Renderer::Tonemap(r->state, r->config) : INCR_ERR_INVALID_ARGUMENT; }
 const char* incr_renderer_last_error(const incr_renderer* r) { return r ? r->error.c_str() : ""; }
+
+// renderer.cpp:2064-2076 + Renderer::GetRenderStats: the statistics of the last frame, read back after the stream has drained
+int incr_renderer_get_stats(incr_renderer* r, incr_render_stats* out_render_stats, incr_ray_stats* out_ray_stats) {
+    if (!r) return INCR_ERR_INVALID_ARGUMENT;
+    Renderer::State& s = r->state;
+    int rc = incr_stream_synchronize(s.ctx, s.jobSync.m_stream);
+    if (!rc && out_render_stats) rc = incr_buffer_download(s.ctx, out_render_stats, s.renderStatsBuffer.m_devicePtr, sizeof *out_render_stats, s.jobSync.m_stream);
+    if (!rc && out_ray_stats) rc = incr_buffer_download(s.ctx, out_ray_stats, s.rayStatsBuffer.m_devicePtr, sizeof *out_ray_stats, s.jobSync.m_stream);
+    if (rc) r->error = incr_last_error();
+    return rc;
+}
 
 void* incr_renderer_surface(incr_renderer* r, int which) {
     if (!r) return nullptr;

@@ -368,6 +368,12 @@ class HostRenderer:
     def surface_ptr(self, which):
         return self.ctx.lib.incr_renderer_surface(self.handle, which)
 
+    def stats(self):
+        """Renderer::GetRenderStats: ((culled objects, culled lights) of the last frame, accumulated RayStats)."""
+        rs, rays = (C.c_int32 * 2)(), A.RayStats()
+        rt.check(self.ctx.lib.incr_renderer_get_stats(self.handle, C.byref(rs), C.byref(rays)))
+        return (rs[0], rs[1]), rays
+
     def download(self, which, dtype=np.uint32, texel_words=1):
         shape = (self.res_y, self.res_x) if texel_words == 1 else (self.res_y, self.res_x, texel_words)
         return self.ctx.download(self.surface_ptr(which), shape, dtype)

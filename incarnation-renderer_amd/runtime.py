@@ -30,7 +30,7 @@ EXPORTS = [
     # frame level (C++ host mirror of Renderer::Render)
     "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
-    "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats",
+    "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats", "incr_renderer_get_stats",
     # sky / IBL precompute
     "incr_update_dynamic_sky", "incr_sky_ibl_get_info", "incr_sky_ibl_destroy", "incr_generate_env_brdf",
 ]
@@ -116,6 +116,7 @@ def load():
     L.incr_renderer_surface.restype = vp; L.incr_renderer_surface.argtypes = [vp, C.c_int]
     L.incr_renderer_set_band.restype = C.c_int; L.incr_renderer_set_band.argtypes = [vp, u32, u32]
     L.incr_renderer_tonemap.restype = C.c_int; L.incr_renderer_tonemap.argtypes = [vp]
+    L.incr_renderer_get_stats.restype = C.c_int; L.incr_renderer_get_stats.argtypes = [vp, C.POINTER(C.c_int32 * 2), C.POINTER(A.RayStats)]
     L.incr_visibility_get_stats.restype = C.c_int; L.incr_visibility_get_stats.argtypes = [vp, C.POINTER(u32)]
     L.incr_update_dynamic_sky.restype = C.c_int; L.incr_update_dynamic_sky.argtypes = [vp, vp, u32, C.c_float, C.c_int32, vp, C.POINTER(vp)]
     L.incr_sky_ibl_get_info.restype = C.c_int; L.incr_sky_ibl_get_info.argtypes = [vp, C.POINTER(A.SkyIblInfo)]

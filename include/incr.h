@@ -555,6 +555,9 @@ void  incr_renderer_reset_accumulation(incr_renderer* renderer);      /* Rendere
 int   incr_renderer_set_band(incr_renderer* renderer, uint32_t row_begin, uint32_t row_end);
 int   incr_renderer_tonemap(incr_renderer* renderer);
 const char* incr_renderer_last_error(const incr_renderer* renderer);
+/* Renderer::GetRenderStats (the read-back at the end of Render, renderer.cpp:2064-2076): culled objects / lights of the last
+ * frame and the ray statistics accumulated so far.  Waits for the renderer's stream.  Either pointer may be NULL. */
+int   incr_renderer_get_stats(incr_renderer* renderer, incr_render_stats* out_render_stats, incr_ray_stats* out_ray_stats);
 void* incr_renderer_surface(incr_renderer* renderer, int which);      /* device pointer of a frame surface (INCR_SURFACE_*) */
 
 #ifdef __cplusplus

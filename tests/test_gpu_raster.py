@@ -456,6 +456,9 @@ def test_cpp_host_renderer_matches_pass_by_pass(rt, R, A, sio, gpu_ctx, sponza_s
                 a = hr.download(which)
                 b = rr.surf.download(name)
                 np.testing.assert_array_equal(a, b.view(np.uint32), err_msg="frame %d %s" % (frame, name))
+        (culled_objects, culled_lights), rays = hr.stats()                         # Renderer::GetRenderStats read-back
+        assert [culled_objects, culled_lights] == list(rr.surf.download("render_stats")) and culled_objects > 0
+        assert rays.light_shadow_rays == rr.surf.download("ray_stats").light_shadow_rays > 0
         hr.close(); rr.close()
         # path-trace branch: samples 1..MaxSampleCount-1, then the accumulation stops (renderer.cpp:1681)
         class Cfg(A.FConfig):
@@ -465,6 +468,7 @@ def test_cpp_host_renderer_matches_pass_by_pass(rt, R, A, sio, gpu_ctx, sponza_s
         for n in (1, 2, 3):
             hr.render(view); pt.render(view, sample_index=n, cfg=Cfg)
             np.testing.assert_array_equal(hr.download(A.SURFACE_PATHTRACE_HISTORY), pt.read()["history"], err_msg="sample %d" % n)
+        assert hr.stats()[1].total_rays() == pt.read()["stats"].total_rays() > 0
         before = hr.download(A.SURFACE_PATHTRACE_HISTORY)
         hr.render(view)                                      # sample index 4 == MaxSampleCount: no further sample
         np.testing.assert_array_equal(hr.download(A.SURFACE_PATHTRACE_HISTORY), before)

@@ -61,3 +61,27 @@ def test_shard_rows_match_oracle(rt, ob, A):
     H, h, n = 2160, 8, 8
     total = sum(lib.incr_shard_local_rows(H, C.byref(A.Shard(h, r, n))) for r in range(n))
     assert total >= H and total - H < n * h
+
+
+def test_header_is_plain_c_and_ctypes_mirrors_match(A, tmp_path):
+    """include/incr.h compiles as C99 (the boundary is a C ABI, not a C++ one) and every struct the Python binding mirrors
+    has the size the C compiler gives it."""
+    import subprocess
+    pairs = [("incr_scene_desc", A.SceneDesc), ("incr_view", A.View), ("incr_view_constants", A.ViewConstants), ("incr_pathtrace_desc", A.PathtraceDesc),
+             ("incr_tonemap_desc", A.TonemapDesc), ("incr_batch_cull_desc", A.BatchCullDesc), ("incr_light_cull_desc", A.LightCullDesc),
+             ("incr_visibility_desc", A.VisibilityDesc), ("incr_gbuffer_desc", A.GBufferDesc), ("incr_gbuffer_decals_desc", A.GBufferDecalsDesc),
+             ("incr_hbao_desc", A.HbaoDesc), ("incr_lighting_inputs", A.LightingInputs), ("incr_sky_lighting_desc", A.SkyLightingDesc),
+             ("incr_direct_lighting_desc", A.DirectLightingDesc), ("incr_clustered_lighting_desc", A.ClusteredLightingDesc),
+             ("incr_forward_lighting_desc", A.ForwardLightingDesc), ("incr_dynamic_sky_desc", A.DynamicSkyDesc),
+             ("incr_environmentmap_desc", A.EnvironmentmapDesc), ("incr_debug_viz_desc", A.DebugVizDesc), ("incr_taa_resolve_desc", A.TaaResolveDesc),
+             ("incr_renderer_scene", A.RendererScene), ("incr_renderer_config", A.RendererConfig), ("incr_sky_ibl_info", A.SkyIblInfo),
+             ("incr_draw_cmd", A.DrawCmd), ("incr_ray_stats", A.RayStats), ("incr_shard", A.Shard), ("incr_gpu_primitive", A.GpuPrimitive),
+             ("incr_gpu_meshlet", A.GpuMeshlet), ("incr_material", A.Material), ("incr_light", A.Light)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "incr.h"\nint main(void) {\n' +
+                   "".join('    printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, mirror in pairs:
+        assert int(out[name]) == C.sizeof(mirror), "%s: C %s vs ctypes %d" % (name, out[name], C.sizeof(mirror))

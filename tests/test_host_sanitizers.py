@@ -20,4 +20,4 @@ def test_host_code_is_clean_under_asan_ubsan():
     r = subprocess.run([sys.executable, os.path.join(san, "run_host_san.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
-    assert "host sanitizer run clean" in r.stdout
+    assert "host sanitizer run clean" in r.stdout and "host sanitizer fuzz clean" in r.stdout

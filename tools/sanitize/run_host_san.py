@@ -72,3 +72,38 @@ vc = A.ViewConstants()
 assert L.incr_make_view_constants(C.byref(view), None, (C.c_float * 2)(0.001, -0.002), None, 1.0, 640, 480, C.byref(vc)) == 0
 assert L.incr_make_view_constants(None, None, None, None, 1.0, 640, 480, C.byref(vc)) != 0
 print("host sanitizer run clean")
+
+
+# ---- fuzz: random triangle soups with the degenerate cases a loader can hand over ----------------------------
+def soup_scene(rng, ntri, kind):
+    s = sio.PackedScene()
+    nv = max(3, ntri // 2 + 3)
+    P = rng.uniform(-5, 5, (nv, 3)).astype(np.float32)
+    if kind == "degenerate":
+        P[: nv // 2] = P[0]                                   # half the vertices coincide: zero-area triangles
+    elif kind == "huge":
+        P *= np.float32(1e18)
+    elif kind == "flat":
+        P[:, 1] = 0.0                                         # everything in one plane: zero-thickness boxes
+    I = rng.integers(0, nv, (ntri, 3)).astype(np.uint32 if kind == "u32" else np.uint16)
+    N = np.tile(np.array([0, 1, 0], np.float32), (nv, 1)); T4 = np.tile(np.array([1, 0, 0, 1], np.float32), (nv, 1))
+    UV = rng.uniform(0, 1, (nv, 2)).astype(np.float32)
+    prims = synth._pack_geometry(s, [(P, N, T4, UV, I)], lambda k: 0)
+    s.mesh_names.append("soup"); s.mesh_primitives.append(prims); s.mesh_transforms.append(sio.mat_identity())
+    m = A.Material()
+    for n in A._MAT_TEX:
+        setattr(m, n + "TextureIndex", -1); setattr(m, n + "SamplerIndex", -1)
+    s.materials.append(m)
+    s.finalize_sun_light()
+    return s
+
+
+rng = np.random.default_rng(0xF22)
+for kind in ("plain", "degenerate", "huge", "flat", "u32"):
+    for ntri in (1, 2, 63, 64, 65, 127, 500, 4097):
+        sc = soup_scene(rng, ntri, kind)
+        d = sc.to_desc(); counts = (C.c_uint64 * 4)(); why = C.create_string_buffer(256)
+        rc = L.san_build_scene(C.byref(d), counts, why, 256)
+        assert rc == 0 and counts[0] == ntri, (kind, ntri, rc, why.value, list(counts))
+        meshletize(sc, "soup-%s-%d" % (kind, ntri))
+print("host sanitizer fuzz clean")

@@ -463,3 +463,37 @@ def add_decals(s, seed=SPONZA_SEED, texture_size=64):
     world = s.mesh_transforms[0]
     s.decal_primitives.extend((p, world) for p in prims)
     return s
+
+
+def triangle_soup(seed, ntri, kind="plain", extent=3.0):
+    """Random triangle soup in front of the default camera (edge-case scenes for the parity tests): kind = plain |
+    degenerate (half the vertices coincide: zero-area triangles, duplicate positions) | flat (all in the plane z = 0:
+    coplanar, depth ties everywhere) | u32 (32-bit indices)."""
+    rng = np.random.default_rng(seed)
+    s = sio.PackedScene()
+    nv = max(3, ntri // 2 + 3)
+    P = rng.uniform(-extent, extent, (nv, 3)).astype(f32)
+    if kind == "degenerate":
+        P[: nv // 2] = P[0]
+    elif kind == "flat":
+        P[:, 2] = 0.0
+    I = rng.integers(0, nv, (ntri, 3)).astype(np.uint32 if kind == "u32" else np.uint16)
+    N = rng.normal(size=(nv, 3)).astype(f32); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    T4 = np.tile(np.array([1, 0, 0, 1], f32), (nv, 1))
+    UV = rng.uniform(0, 1, (nv, 2)).astype(f32)
+    prims = _pack_geometry(s, [(P, N, T4, UV, I)], lambda k: 0)
+    s.mesh_names.append("soup"); s.mesh_primitives.append(prims); s.mesh_transforms.append(sio.mat_identity())
+    m = A.Material()
+    for n in A._MAT_TEX:
+        setattr(m, n + "TextureIndex", -1); setattr(m, n + "SamplerIndex", -1)
+    for i in range(3):
+        m.baseColorFactor[i] = 0.7; m.emissiveFactor[i] = 0.0
+    m.metallicFactor, m.roughnessFactor, m.aoStrength = 0.2, 0.6, 1.0
+    m.alphaMode, m.doubleSided = A.ALPHA_OPAQUE, 1 if kind == "flat" else 0
+    s.materials.append(m)
+    sun = A.Light(); sun.type = A.LIGHT_DIRECTIONAL
+    sun.color[0], sun.color[1], sun.color[2] = 1.0, 1.0, 1.0
+    sun.intensity, sun.range = 100.0, 0.0
+    s.global_lights.append(sun); s.light_indices.append(0); s.light_transforms.append(sio.mat_identity())
+    s.finalize_sun_light()
+    return s

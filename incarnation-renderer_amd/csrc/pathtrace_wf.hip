@@ -112,6 +112,17 @@ struct WaveChunk {
     uint32_t next, end;     // wave-uniform
     bool exhausted;
     DI void init() { next = 0; end = 0; exhausted = false; }
+    // kOneRound variant (the launcher picks it when the whole frame fits one round of the grid, so every list does): a
+    // wave's first chunk is static -- chunk number = its index in the grid -- and the launcher starts the cursors behind
+    // that round.  The 8192 waves of the grid then do not queue on one cursor word just to learn there is nothing left:
+    // waves without a chunk leave at once, the others ask the cursor once, after their chunk (helmet 1080p: 5.3 -> 4.8 ms
+    // per frame).  A separate instantiation because the traversal kernels sit exactly at 64 VGPRs: the same logic as a
+    // run-time branch cost the 4K shadow kernel 20 bytes of spills and 8 % of its time.
+    DI void init_one_round(uint32_t total) {
+        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kChunk);
+        exhausted = b >= total;
+        next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kChunk, total);
+    }
     // returns the item index for this lane or 0xffffffff
     DI uint32_t take(bool idle, uint32_t* __restrict__ cursor, uint32_t total) {
         const unsigned long long m = __ballot(idle);
@@ -166,14 +177,15 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-__global__ __launch_bounds__(kWfBlock, 8) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <bool kOneRound> __global__ __launch_bounds__(kWfBlock, 8) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
     __shared__ float s_keys[kWfStackLds * kWfBlock];
     WfStackK st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
-    WaveChunk chunk; chunk.init();
+    WaveChunk chunk;
+    if constexpr (kOneRound) chunk.init_one_round(total); else chunk.init();
     bool active = false; uint32_t pid = 0;
     TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     uint32_t rays = 0;
@@ -372,13 +384,14 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
 // One lane = one path vertex at a time: the lane traces that vertex's requested shadow rays one after the other
 // (lowest slot first) and writes back the mask with the occluded requests cleared.  No LDS queue, no atomics on
 // the occlusion bits; idle lanes get the next vertices of the wave's chunk.
-__global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <bool kOneRound> __global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
     WfStack st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
-    WaveChunk chunk; chunk.init();
+    WaveChunk chunk;
+    if constexpr (kOneRound) chunk.init_one_round(total); else chunk.init();
     bool haveVertex = false, tracing = false;
     uint32_t pid = 0, cell = 0, curSlot = 0;
     uint32_t rem0 = 0u, rem1 = 0u, rem2 = 0u, rem3 = 0u, occ0 = 0u, occ1 = 0u, occ2 = 0u, occ3 = 0u;
@@ -529,15 +542,24 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const uint32_t blocksAll = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (8 blocks of 4 waves per CU)
     const uint32_t blocksTrav = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
+    // every list of a frame that fits one round of the traversal grid is dealt statically (WaveChunk::init_one_round)
+    const bool oneRound = (uint64_t)p->W * p->localRows <= (uint64_t)blocksTrav * (kWfBlock / 64) * kChunk;
+    if (oneRound) {       // the cursors (counters[16 .. 24)) start behind the statically dealt first round
+        if ((e = hipMemsetD32Async((hipDeviceptr_t)(b->counters + kCursorBase), (int)(blocksTrav * (kWfBlock / 64) * kChunk), 8, stream)) != hipSuccess) return e;
+    }
     int ev = 0;
-    auto mark = [&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
+    auto mark =[&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
     mark();
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX); mark();
     for (int bounce = 0; bounce < 4; ++bounce) {
-        hipLaunchKernelGGL(wf_extend_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+        if (oneRound) hipLaunchKernelGGL(wf_extend_kernel<true>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        else hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        mark();
         hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
         if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
-        hipLaunchKernelGGL(wf_shadow_kernel, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+        if (oneRound) hipLaunchKernelGGL(wf_shadow_kernel<true>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        else hipLaunchKernelGGL(wf_shadow_kernel<false>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        mark();
         hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
     }
     while (ev < 18) mark();                       // unused slots collapse to zero-length intervals

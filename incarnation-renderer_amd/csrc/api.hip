@@ -65,6 +65,10 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     }
     HIP_TRY(hipMalloc((void**)&ctx->srgbLut, sizeof lut));
     HIP_TRY(hipMemcpy(ctx->srgbLut, lut, sizeof lut, hipMemcpyHostToDevice));
+    // 64 ray-count stripes, one 128-byte line each: the lane-per-pixel raster passes count their ray queries here (one
+    // block-reduced atomic per workgroup, spread over 64 L2 lines) and a one-wave kernel folds them into the caller's stats
+    HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
+    HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
     HIP_TRY(hipMalloc((void**)&ctx->tileQueues, kNumTileQueues * 64));      // one 64-byte line per queue head
     HIP_TRY(hipMemset(ctx->tileQueues, 0, kNumTileQueues * 64));
     ctx->nextQueue = 0;
@@ -82,6 +86,7 @@ int incr_teardown(incr_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
+    if (ctx->statStripes) (void)hipFree(ctx->statStripes);
     if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
@@ -464,4 +469,4 @@ int incr_unshard(incr_context* ctx, void* dst, const void* src, uint32_t res_x, 
 
 } // extern "C"
 
-void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P) { fill_scene_params(ctx, sc, P); }
+void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P) { fill_scene_params(ctx, sc, P); P.statStripes = ctx->statStripes; }

@@ -23,6 +23,7 @@ struct incr_context {
     int device;
     hipDeviceProp_t props;
     float* srgbLut;           // 256 floats in HBM
+    unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
     uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
     uint32_t nextQueue;
     int kernelVariant;        // 0 = wavefront multi-kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega),

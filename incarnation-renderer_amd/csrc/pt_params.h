@@ -44,6 +44,7 @@ struct PtParams {
     const uint32_t* __restrict__ envmap;
     uint32_t envmapRes, envmapMips;
     int32_t envSkyMode;                       // 0 = HDRI cube in the miss shader (msEnvmap), 1 = dynamic Preetham sky (msDynamicSky)
+    unsigned long long* statStripes;          // raster passes: 64 striped ray counters (16 words apart), folded into `stats` afterwards
 };
 
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).

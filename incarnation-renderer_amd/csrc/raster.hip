@@ -502,14 +502,33 @@ __global__ __launch_bounds__(256) void prim_flags_kernel(const incr_draw_cmd* __
 }
 
 // rasteriser + ps_meshlet_main (visibility-pass.hlsl:99-118): persistent waves over the three queues
+// A wave's walk over one queue.  Its first `step` entries are static (entry = wave index x step), the cursor hands out what
+// lies behind the grid's first round, `grab` steps per atomic: the three cursors share a cache line, and 8192 waves asking
+// each of them at least once -- plus one atomic per band item -- were ~80 k serialised same-line atomics per frame, most
+// of the kernel's time.  A wave whose static entry is already past the end leaves the queue without touching the cursor.
+struct QueueWalk { uint32_t cur, end; bool done; };
+DI void qw_init(QueueWalk& q, uint32_t n, uint32_t step) {
+    q.cur = __builtin_amdgcn_readfirstlane((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * step);
+    q.end = q.cur + step; q.done = q.cur >= n;
+}
+DI bool qw_next(QueueWalk& q, uint32_t* __restrict__ cursor, uint32_t n, uint32_t step, uint32_t grab, uint32_t* out) {
+    if (q.done) return false;
+    if (q.cur >= q.end) {
+        uint32_t b = 0;
+        if ((threadIdx.x & 63u) == 0) b = atomicAdd(cursor, step * grab);
+        b = __builtin_amdgcn_readfirstlane(b) + gridDim.x * (blockDim.x >> 6) * step;
+        q.cur = b; q.end = b + step * grab;
+    }
+    if (q.cur >= n) { q.done = true; return false; }
+    *out = q.cur; q.cur += step;
+    return true;
+}
 __global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
-    for (;;) {                                                   // band items
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(P.vqCounters + 4, 1u);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= nBig) break;
+    QueueWalk q;
+    qw_init(q, nBig, 1u);
+    for (uint32_t i; qw_next(q, P.vqCounters + 4, nBig, 1u, 4u, &i);) {          // band items
         const uint2 item = P.bigQueue[i];
         const uint32_t rowStart = item.y >> 16, rowCount = item.y & 0xffffu;
         if (!rowCount) continue;
@@ -521,19 +540,13 @@ __global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
         st.py0 += skip; st.py1 = min(st.py1, st.py0 + (int32_t)rowCount * 8 - 1);
         raster_coop(P, st, lane);
     }
-    for (;;) {                                                   // whole large triangles (band-queue overflow)
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(P.vqCounters + 5, 1u);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= nWhole) break;
+    qw_init(q, nWhole, 1u);
+    for (uint32_t i; qw_next(q, P.vqCounters + 5, nWhole, 1u, 1u, &i);) {        // whole large triangles (band-queue overflow)
         SubTri st;
         if (subtri_from_rec(P, P.wholeQueue[i], &st)) raster_coop(P, st, lane);
     }
-    for (;;) {                                                   // small triangles: one per lane
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(P.vqCounters + 6, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= nSmall) break;
+    qw_init(q, nSmall, 64u);
+    for (uint32_t base; qw_next(q, P.vqCounters + 6, nSmall, 64u, 1u, &base);) { // small triangles: one per lane
         const uint32_t i = base + lane;
         SubTri st;
         if (i < nSmall && subtri_from_rec(P, P.smallQueue[i], &st)) raster_serial(P, st);
@@ -701,6 +714,31 @@ __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
     add_color(P.L, i, hbao * radiance);
 }
 
+// Ray statistics of a lane-per-pixel pass (every thread of the block calls this once, outside divergent code).  One atomic
+// per WAVE on the caller's counter was the critical path of the sun pass: 130 k same-address atomics at ~12 ns each are
+// 1.5 ms at 4K.  The block's count is reduced through LDS and added to one of 64 striped counters (own cache lines);
+// fold_ray_stats_kernel moves the stripes into incr_ray_stats::light_shadow_rays after the pass.
+DI void count_rays(const PtParams& S, uint32_t rays) {
+    __shared__ uint32_t s_rays;
+    if (!S.stats) return;                                   // uniform: a kernel argument
+    if (threadIdx.x == 0) s_rays = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(&s_rays, rays);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rays) {
+        if (S.statStripes) atomicAdd(S.statStripes + ((blockIdx.y * gridDim.x + blockIdx.x) & 63u) * 16u, (unsigned long long)s_rays);
+        else atomicAdd((unsigned long long*)&S.stats->light_shadow_rays, (unsigned long long)s_rays);
+    }
+}
+__global__ __launch_bounds__(64) void fold_ray_stats_kernel(unsigned long long* __restrict__ stripes, incr_ray_stats* __restrict__ stats) {
+    unsigned long long v = atomicExch(stripes + threadIdx.x * 16u, 0ull);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0 && v) atomicAdd((unsigned long long*)&stats->light_shadow_rays, v);
+}
+
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115)
 __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectParams P) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
@@ -733,11 +771,7 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
         }
         add_color(P.L, i, radiance);
     }
-    if (P.S.stats) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.S.stats->light_shadow_rays, (unsigned long long)rays);
-    }
+    count_rays(P.S, rays);
 }
 
 // ---------------------------------------------------------------------------------------------- HBAO
@@ -832,11 +866,7 @@ __global__ __launch_bounds__(kBlock) void hbao_kernel(const HbaoParams P) {     
         const f2 oct = OctEncode(normalize(avgBent));
         P.bent[i] = hb_f16(oct.x, P.rounding) | (hb_f16(oct.y, P.rounding) << 16);
     }
-    if (P.S.stats) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.S.stats->light_shadow_rays, (unsigned long long)rays);
-    }
+    count_rays(P.S, rays);
 }
 
 // ---------------------------------------------------------------------------------------------- forward lighting
@@ -940,11 +970,7 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
         }
         P.color[i] = pack_r11g11b10(out, P.rounding);
     }
-    if (P.Pt.stats) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-        if ((tid & 63u) == 0 && rays) atomicAdd((unsigned long long*)&P.Pt.stats->light_shadow_rays, (unsigned long long)rays);
-    }
+    count_rays(P.Pt, rays);
 }
 
 // ---------------------------------------------------------------------------------------------- decals
@@ -1341,11 +1367,13 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
     hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(kBlock), 0, stream, *p);
+    if (p->S.stats && p->S.statStripes) hipLaunchKernelGGL(fold_ray_stats_kernel, dim3(1), dim3(64), 0, stream, p->S.statStripes, p->S.stats);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(hbao_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
+    if (p->S.stats && p->S.statStripes) hipLaunchKernelGGL(fold_ray_stats_kernel, dim3(1), dim3(64), 0, stream, p->S.statStripes, p->S.stats);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipStream_t stream) {
@@ -1359,6 +1387,7 @@ extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipSt
 extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream) {
     if (!p->W || p->y1 <= p->y0) return hipSuccess;
     hipLaunchKernelGGL(forward_shade_kernel, pixel_grid(p->W, p->y0, p->y1), dim3(kBlock), 0, stream, *p);
+    if (p->Pt.stats && p->Pt.statStripes) hipLaunchKernelGGL(fold_ray_stats_kernel, dim3(1), dim3(64), 0, stream, p->Pt.statStripes, p->Pt.stats);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {

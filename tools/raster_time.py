@@ -23,6 +23,8 @@ ctx = rt.Context(0)
 t = time.time(); gs = ctx.create_scene(scene); print("upload %.1fs" % (time.time() - t))
 view = sio.FView().reset(scene, aspect=W / H)
 rr = R.RasterRenderer(ctx, gs, W, H, Cfg)
+if os.environ.get("INCR_NO_RAY_STATS"):
+    rr.surf.ptr["ray_stats_real"], rr.surf.ptr["ray_stats"] = rr.surf.ptr["ray_stats"], None      # passes take NULL = no counting
 rr.set_sh9(np.ones((9, 3), np.float32) * 0.1)
 for _ in range(3):
     rr.render(view)

@@ -370,6 +370,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;
     P.storageRounding = d->storage_rounding;
     P.stats = d->ray_stats;
+    P.statStripes = ctx->kernelVariant == 0 ? ctx->statStripes : nullptr;     // the wavefront kernels count through the striped counters
     upload_grid_params(sc, P);
     if (ctx->kernelVariant == 0) {
         int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);

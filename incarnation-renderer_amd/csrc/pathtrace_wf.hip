@@ -33,6 +33,8 @@
 #include "pt_shade.h"
 #include <algorithm>
 
+extern "C" hipError_t incr_launch_fold_ray_stats(unsigned long long* stripes, incr_ray_stats* stats, hipStream_t stream);   // raster.hip
+
 namespace incr {
 
 static constexpr int kWfBlock = 256;
@@ -73,7 +75,9 @@ DI void add_counters(const PtParams& P, const Counters& cnt) {
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
     }
     if ((threadIdx.x & 63u) == 0) {
-        unsigned long long* s = (unsigned long long*)P.stats;
+        // 64 striped counters (one cache line each, folded into P.stats after the frame) when the context provides them:
+        // 8192 waves x up to 3 counters on ONE line were a queue of same-line atomics at the tail of every kernel
+        unsigned long long* s = P.statStripes ? P.statStripes + (blockIdx.x & 63u) * 16u : (unsigned long long*)P.stats;
 #pragma unroll
         for (int k = 0; k < 5; ++k) if (v[k]) atomicAdd(s + k, (unsigned long long)v[k]);
     }
@@ -562,6 +566,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         mark();
         hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
     }
+    if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, stream);
     while (ev < 18) mark();                       // unused slots collapse to zero-length intervals
     return hipGetLastError();
 }

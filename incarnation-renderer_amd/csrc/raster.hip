@@ -728,15 +728,23 @@ DI void count_rays(const PtParams& S, uint32_t rays) {
     if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(&s_rays, rays);
     __syncthreads();
     if (threadIdx.x == 0 && s_rays) {
-        if (S.statStripes) atomicAdd(S.statStripes + ((blockIdx.y * gridDim.x + blockIdx.x) & 63u) * 16u, (unsigned long long)s_rays);
+        if (S.statStripes) atomicAdd(S.statStripes + ((blockIdx.y * gridDim.x + blockIdx.x) & 63u) * 16u + 3u, (unsigned long long)s_rays);   // word 3 = light_shadow_rays
         else atomicAdd((unsigned long long*)&S.stats->light_shadow_rays, (unsigned long long)s_rays);
     }
 }
+// a stripe holds the five counters of incr_ray_stats in its first five words
 __global__ __launch_bounds__(64) void fold_ray_stats_kernel(unsigned long long* __restrict__ stripes, incr_ray_stats* __restrict__ stats) {
-    unsigned long long v = atomicExch(stripes + threadIdx.x * 16u, 0ull);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (threadIdx.x == 0 && v) atomicAdd((unsigned long long*)&stats->light_shadow_rays, v);
+    for (uint32_t k = 0; k < 5; ++k) {
+        unsigned long long v = atomicExch(stripes + threadIdx.x * 16u + k, 0ull);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0 && v) atomicAdd((unsigned long long*)stats + k, v);
+    }
+}
+extern "C" hipError_t incr_launch_fold_ray_stats(unsigned long long* stripes, incr_ray_stats* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_ray_stats_kernel, dim3(1), dim3(64), 0, stream, stripes, stats);
+    return hipGetLastError();
 }
 
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115)

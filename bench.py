@@ -255,8 +255,11 @@ def main():
     # at N > 1 every rank renders its row band and the TAA bands are all-gathered (sort-first)
     raster_out = None
     if not args.no_raster:
-        raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs)
-        raster_out["sky_ibl_precompute_ms"] = round(t_ibl * 1e3, 2)      # once per scene / sun change, not per frame
+        try:
+            raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs)
+            raster_out["sky_ibl_precompute_ms"] = round(t_ibl * 1e3, 2)      # once per scene / sun change, not per frame
+        except Exception as e:      # the headline (path trace) line must survive a failure of the secondary leg
+            raster_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))

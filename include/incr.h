@@ -81,7 +81,9 @@ typedef struct incr_shard {
 } incr_shard;
 uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* shard);
 
-/* Ray statistics (SURVEY.md 8d "Ray count"): every traversal query, by category. */
+/* Ray statistics (SURVEY.md 8d "Ray count"): every traversal query, by category.  The kernels count into striped counters owned
+ * by the context and fold them into the caller's struct at the end of the call; two calls of ONE context running at the same time
+ * on different streams may therefore see each other's counts (the sum over both structs stays exact). */
 typedef struct incr_ray_stats {
     uint64_t camera_rays;       /* TraceRay from rgsMain                      (pathtracing.hlsl:117) */
     uint64_t bounce_rays;       /* TraceRay from chsMain                      (pathtracing.hlsl:265) */

@@ -52,7 +52,16 @@ using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shad
 using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
-static constexpr uint32_t kChunk = 512;                 // items a wave takes from the device-wide cursor at a time
+// Items a wave takes from the device-wide cursor at a time.  Measured at 4K Sponza-stat, ms per frame for chunks of
+// 32 / 64 / 96 / 128 / 160 / 256 / 512 / 1024 items: 44.9 / 44.5 / 45.5 / 46.3 / 47.7 / 51.4 / 55.0 / 58.6 -- with 8192
+// persistent waves a 512-item chunk is a quarter of a wave's whole share of a 4K list, and the kernel ends on the waves
+// that drew a late one; one wave's worth per grab keeps every SIMD busy to the end (130 k cursor atomics per launch,
+// ~1.5 ms of one L2 channel's time spread over the kernel, still cost less than the tail they remove).
+#ifndef INCR_WF_CHUNK
+#define INCR_WF_CHUNK 64
+#endif
+static constexpr uint32_t kChunk = INCR_WF_CHUNK;
+static constexpr uint32_t kStaticChunk = 512;           // the statically dealt first chunk of the one-round variant
 static constexpr uint32_t kRefillThreshold = 12;        // refill when at least this many lanes are idle
 static constexpr uint32_t kStartThreshold = 8;          // shadow kernel: lanes between rays start together
 static constexpr uint32_t kMissTri = 0xffffffffu;
@@ -123,9 +132,9 @@ struct WaveChunk {
     // per frame).  A separate instantiation because the traversal kernels sit exactly at 64 VGPRs: the same logic as a
     // run-time branch cost the 4K shadow kernel 20 bytes of spills and 8 % of its time.
     DI void init_one_round(uint32_t total) {
-        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kChunk);
+        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kStaticChunk);
         exhausted = b >= total;
-        next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kChunk, total);
+        next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kStaticChunk, total);
     }
     // returns the item index for this lane or 0xffffffff
     DI uint32_t take(bool idle, uint32_t* __restrict__ cursor, uint32_t total) {
@@ -547,9 +556,9 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (8 blocks of 4 waves per CU)
     const uint32_t blocksTrav = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
     // every list of a frame that fits one round of the traversal grid is dealt statically (WaveChunk::init_one_round)
-    const bool oneRound = (uint64_t)p->W * p->localRows <= (uint64_t)blocksTrav * (kWfBlock / 64) * kChunk;
+    const bool oneRound = (uint64_t)p->W * p->localRows <= (uint64_t)blocksTrav * (kWfBlock / 64) * kStaticChunk;
     if (oneRound) {       // the cursors (counters[16 .. 24)) start behind the statically dealt first round
-        if ((e = hipMemsetD32Async((hipDeviceptr_t)(b->counters + kCursorBase), (int)(blocksTrav * (kWfBlock / 64) * kChunk), 8, stream)) != hipSuccess) return e;
+        if ((e = hipMemsetD32Async((hipDeviceptr_t)(b->counters + kCursorBase), (int)(blocksTrav * (kWfBlock / 64) * kStaticChunk), 8, stream)) != hipSuccess) return e;
     }
     int ev = 0;
     auto mark =[&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };

@@ -62,8 +62,14 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
 #endif
 static constexpr uint32_t kChunk = INCR_WF_CHUNK;
 static constexpr uint32_t kStaticChunk = 512;           // the statically dealt first chunk of the one-round variant
-static constexpr uint32_t kRefillThreshold = 12;        // refill when at least this many lanes are idle
-static constexpr uint32_t kStartThreshold = 8;          // shadow kernel: lanes between rays start together
+#ifndef INCR_WF_REFILL
+#define INCR_WF_REFILL 12
+#endif
+#ifndef INCR_WF_START
+#define INCR_WF_START 8
+#endif
+static constexpr uint32_t kRefillThreshold = INCR_WF_REFILL;   // refill when at least this many lanes are idle
+static constexpr uint32_t kStartThreshold = INCR_WF_START;     // shadow kernel: lanes between rays start together
 static constexpr uint32_t kMissTri = 0xffffffffu;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow)
 static constexpr int kCursorBase = 16;

@@ -558,7 +558,13 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     hipError_t e = hipMemsetAsync(b->counters, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
-    const uint32_t blocksAll = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
+    // generate / shade / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer.
+    // Capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms,
+    // uncapped 42.7: a block's 16 strided iterations were another fixed share that the slowest blocks finished late.
+#ifndef INCR_WF_STREAM_BLOCKS_PER_CU
+#define INCR_WF_STREAM_BLOCKS_PER_CU 65536
+#endif
+    const uint32_t blocksAll = std::max(1u, (uint32_t)std::min<uint64_t>((uint64_t)cus * INCR_WF_STREAM_BLOCKS_PER_CU, (total + kWfBlock - 1) / kWfBlock));
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (8 blocks of 4 waves per CU)
     const uint32_t blocksTrav = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
     // every list of a frame that fits one round of the traversal grid is dealt statically (WaveChunk::init_one_round)

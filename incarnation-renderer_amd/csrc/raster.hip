@@ -528,7 +528,10 @@ __global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
     const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
     QueueWalk q;
     qw_init(q, nBig, 1u);
-    for (uint32_t i; qw_next(q, P.vqCounters + 4, nBig, 1u, 4u, &i);) {          // band items
+#ifndef INCR_VIS_GRAB
+#define INCR_VIS_GRAB 4
+#endif
+    for (uint32_t i; qw_next(q, P.vqCounters + 4, nBig, 1u, (uint32_t)INCR_VIS_GRAB, &i);) {          // band items
         const uint2 item = P.bigQueue[i];
         const uint32_t rowStart = item.y >> 16, rowCount = item.y & 0xffffu;
         if (!rowCount) continue;

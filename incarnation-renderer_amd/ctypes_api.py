@@ -236,6 +236,11 @@ class HbaoDesc(C.Structure):
                 ("ao_target", C.c_void_p), ("bent_normal_target", C.c_void_p), ("ray_stats", C.c_void_p), ("storage_rounding", C.c_int32)]
 
 
+class PrefilterNormalRoughnessDesc(C.Structure):
+    _fields_ = [("normalmap", C.c_void_p), ("metallic_roughness", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("num_mips", C.c_uint32), ("reserved", C.c_uint32), ("out_normalmap", C.c_void_p), ("out_metallic_roughness", C.c_void_p)]
+
+
 class DirectLightingDesc(C.Structure):
     _fields_ = [("inp", LightingInputs), ("directional_light_index", C.c_int32), ("ray_stats", C.c_void_p)]
 

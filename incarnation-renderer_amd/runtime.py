@@ -33,6 +33,8 @@ EXPORTS = [
     "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats", "incr_renderer_get_stats",
     # sky / IBL precompute
     "incr_update_dynamic_sky", "incr_sky_ibl_get_info", "incr_sky_ibl_destroy", "incr_generate_env_brdf",
+    # texture ingest, GPU step
+    "incr_compressed_mip_count", "incr_mip_chain_texels", "incr_prefilter_normal_roughness",
 ]
 
 
@@ -122,6 +124,9 @@ def load():
     L.incr_sky_ibl_get_info.restype = C.c_int; L.incr_sky_ibl_get_info.argtypes = [vp, C.POINTER(A.SkyIblInfo)]
     L.incr_sky_ibl_destroy.restype = C.c_int; L.incr_sky_ibl_destroy.argtypes = [vp, vp]
     L.incr_generate_env_brdf.restype = C.c_int; L.incr_generate_env_brdf.argtypes = [vp, u32, u32, C.c_int32, vp, vp]
+    L.incr_compressed_mip_count.restype = u32; L.incr_compressed_mip_count.argtypes = [u32, u32]
+    L.incr_mip_chain_texels.restype = u64; L.incr_mip_chain_texels.argtypes = [u32, u32, u32]
+    L.incr_prefilter_normal_roughness.restype = C.c_int; L.incr_prefilter_normal_roughness.argtypes = [vp, C.POINTER(A.PrefilterNormalRoughnessDesc), vp]
     _lib = L
     return L
 

@@ -504,6 +504,29 @@ int incr_sky_ibl_destroy(incr_context* ctx, incr_sky_ibl* ibl);
 int incr_generate_env_brdf(incr_context* ctx, uint32_t width, uint32_t height, int32_t storage_rounding, void* out_rg16f, incr_stream stream);
 
 /* =====================================================================================================
+ * Texture ingest, GPU step: FScene::PrefilterNormalRoughnessTextures (src/scene.cpp:1157-1320;
+ * shaders/content-pipeline/prefilter-normal-roughness.hlsl) -- vMF filtering of a normal map together with its
+ * metallic-roughness map.  Level 0: normal map copied, metallic-roughness stored .bgra (metal in R, roughness in G).
+ * Level k >= 1: every texel averages the vMF mean vectors of its 2^k x 2^k base-level footprint and converts the mean back
+ * to (normal * 0.5 + 0.5, 0) and (average metalness, widened roughness, 0, 0).  Both outputs are R8G8B8A8_UNORM, levels
+ * packed one after another (level k is (width >> k) x (height >> k), row-major); the reference's BC5 compression of the
+ * read-back is not part of the path.  Blocks until the chain is written (the reference waits on its read-back here).
+ * ===================================================================================================== */
+typedef struct incr_prefilter_normal_roughness_desc {
+    const uint8_t* normalmap;           /* device, width*height RGBA8 as decoded from the image (tangent-space normal in rgb) */
+    const uint8_t* metallic_roughness;  /* device, width*height RGBA8 as decoded (glTF: roughness in G, metalness in B); same size (scene.cpp:1282) */
+    uint32_t width, height;
+    uint32_t num_mips;                  /* = incr_compressed_mip_count(width, height) */
+    uint32_t reserved;
+    uint8_t* out_normalmap;             /* device, incr_mip_chain_texels(width, height, num_mips) * 4 bytes */
+    uint8_t* out_metallic_roughness;    /* device, same size */
+} incr_prefilter_normal_roughness_desc;
+/* RenderUtils12::CalcMipCount(w, h, bCompressed = true) (inc/backend-d3d12.h:456-471): levels down to 4x4. */
+uint32_t incr_compressed_mip_count(uint32_t width, uint32_t height);
+uint64_t incr_mip_chain_texels(uint32_t width, uint32_t height, uint32_t num_mips);
+int incr_prefilter_normal_roughness(incr_context* ctx, const incr_prefilter_normal_roughness_desc* desc, incr_stream stream);
+
+/* =====================================================================================================
  * Frame level: the DLL exports Initialize / Render / Teardown (inc/demo-interface.h:10-16) over the C++ host mirror
  * of Renderer::Render (csrc/host/renderer.cpp: RenderJob::<Pass>::Execute + the path-trace and raster branches of
  * src/renderer.cpp:1676-2036).  One incr_renderer owns the frame's surfaces and the state Renderer keeps in statics

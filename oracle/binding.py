@@ -82,8 +82,27 @@ def lib():
         L.orc_update_dynamic_sky.argtypes = [fp, C.c_float, u32, u32, C.c_int, vp, vp, vp, vp]
         L.orc_env_brdf.argtypes = [u32, u32, u32, vp, C.c_int]
         L.orc_cube_sample.argtypes = [vp, u32, u32, fp, C.c_float, fp]
+        # texture ingest (oracle_content.cpp)
+        L.orc_compressed_mip_count.restype = u32; L.orc_compressed_mip_count.argtypes = [u32, u32]
+        L.orc_prefilter_normal_roughness.restype = u32; L.orc_prefilter_normal_roughness.argtypes = [vp, vp, u32, u32, vp, vp]
         _lib = L
     return _lib
+
+
+def prefilter_normal_roughness(normalmap, metallic_roughness):
+    """(H, W, 4) uint8 maps -> (normal levels, metal-rough levels), each a list of (H>>k, W>>k, 4) uint8 arrays."""
+    L = lib()
+    n = np.ascontiguousarray(normalmap, np.uint8); m = np.ascontiguousarray(metallic_roughness, np.uint8)
+    H, W = n.shape[:2]
+    mips = L.orc_compressed_mip_count(W, H)
+    texels = sum((W >> k) * (H >> k) for k in range(mips))
+    on = np.zeros((texels, 4), np.uint8); om = np.zeros((texels, 4), np.uint8)
+    assert L.orc_prefilter_normal_roughness(n.ctypes.data, m.ctypes.data, W, H, on.ctypes.data, om.ctypes.data) == mips
+    out_n, out_m, off = [], [], 0
+    for k in range(mips):
+        w, h = W >> k, H >> k
+        out_n.append(on[off:off + w * h].reshape(h, w, 4)); out_m.append(om[off:off + w * h].reshape(h, w, 4)); off += w * h
+    return out_n, out_m
 
 
 def _fa(vals):

@@ -70,7 +70,7 @@ def test_header_is_plain_c_and_ctypes_mirrors_match(A, tmp_path):
     pairs = [("incr_scene_desc", A.SceneDesc), ("incr_view", A.View), ("incr_view_constants", A.ViewConstants), ("incr_pathtrace_desc", A.PathtraceDesc),
              ("incr_tonemap_desc", A.TonemapDesc), ("incr_batch_cull_desc", A.BatchCullDesc), ("incr_light_cull_desc", A.LightCullDesc),
              ("incr_visibility_desc", A.VisibilityDesc), ("incr_gbuffer_desc", A.GBufferDesc), ("incr_gbuffer_decals_desc", A.GBufferDecalsDesc),
-             ("incr_hbao_desc", A.HbaoDesc), ("incr_lighting_inputs", A.LightingInputs), ("incr_sky_lighting_desc", A.SkyLightingDesc),
+             ("incr_hbao_desc", A.HbaoDesc), ("incr_prefilter_normal_roughness_desc", A.PrefilterNormalRoughnessDesc), ("incr_lighting_inputs", A.LightingInputs), ("incr_sky_lighting_desc", A.SkyLightingDesc),
              ("incr_direct_lighting_desc", A.DirectLightingDesc), ("incr_clustered_lighting_desc", A.ClusteredLightingDesc),
              ("incr_forward_lighting_desc", A.ForwardLightingDesc), ("incr_dynamic_sky_desc", A.DynamicSkyDesc),
              ("incr_environmentmap_desc", A.EnvironmentmapDesc), ("incr_debug_viz_desc", A.DebugVizDesc), ("incr_taa_resolve_desc", A.TaaResolveDesc),

@@ -322,16 +322,49 @@ def _bounding_sphere(pos):
 
 
 def load_gltf(path, load_images=True, max_texture_size=None):
-    """Minimal glTF 2.0 (.gltf + external .bin + external images) loader -> PackedScene."""
+    """glTF 2.0 loader -> PackedScene: .gltf (external or `data:` buffers and images) and binary .glb (embedded BIN chunk,
+    bufferView images) -- the two containers tinygltf's LoadASCIIFromFile / LoadBinaryFromFile accept (scene.cpp:113-130)."""
+    import base64
+    import io
+    import struct
     from PIL import Image
 
     base = os.path.dirname(os.path.abspath(path))
-    with open(path, "r") as f:
-        g = json.load(f)
+    with open(path, "rb") as f:
+        blob = f.read()
+    glb_bin = None
+    if blob[:4] == b"glTF":                                   # GLB: 12-byte header, then (length, type, payload) chunks
+        magic, version, total = struct.unpack_from("<4sII", blob, 0)
+        if version != 2 or total > len(blob):
+            raise ValueError("%s: not a glTF 2 binary container" % path)
+        off, g = 12, None
+        while off + 8 <= total:
+            clen, ctype = struct.unpack_from("<II", blob, off)
+            chunk = blob[off + 8:off + 8 + clen]
+            if ctype == 0x4E4F534A and g is None:             # 'JSON'
+                g = json.loads(chunk.decode("utf-8"))
+            elif ctype == 0x004E4942 and glb_bin is None:     # 'BIN\0'
+                glb_bin = chunk
+            off += 8 + ((clen + 3) & ~3)
+        if g is None:
+            raise ValueError("%s: GLB without a JSON chunk" % path)
+    else:
+        g = json.loads(blob.decode("utf-8"))
+
+    def uri_bytes(uri):
+        if uri.startswith("data:"):
+            return base64.b64decode(uri.split(",", 1)[1])
+        with open(os.path.join(base, uri), "rb") as f:
+            return f.read()
+
     s = PackedScene()
     for b in g.get("buffers", []):
-        with open(os.path.join(base, b["uri"]), "rb") as f:
-            raw = np.frombuffer(f.read(), dtype=np.uint8).copy()
+        if "uri" in b:
+            raw = np.frombuffer(uri_bytes(b["uri"]), dtype=np.uint8)[:b["byteLength"]].copy()
+        else:
+            if glb_bin is None:
+                raise ValueError("%s: buffer without uri outside a GLB" % path)
+            raw = np.frombuffer(glb_bin, dtype=np.uint8)[:b["byteLength"]].copy()
         pad = (-raw.size) % 16 + 16          # slack so dword-aligned 16-bit index unpack never reads past the end
         s.buffers.append(np.concatenate([raw, np.zeros(pad, dtype=np.uint8)]))
     for v in g.get("bufferViews", []):
@@ -346,7 +379,13 @@ def load_gltf(path, load_images=True, max_texture_size=None):
 
     def image_rgba(image_index):
         if image_index not in image_cache:
-            img = Image.open(os.path.join(base, g["images"][image_index]["uri"])).convert("RGBA")
+            im = g["images"][image_index]
+            if "uri" in im:
+                data = uri_bytes(im["uri"])
+            else:                                              # embedded: the encoded file sits in a bufferView
+                bi, bo, bl = s.buffer_views[im["bufferView"]]
+                data = s.buffers[bi][bo:bo + bl].tobytes()
+            img = Image.open(io.BytesIO(data)).convert("RGBA")    # "Source Images are always 4 channel 8bpp" (scene.cpp:1167)
             if max_texture_size and max(img.size) > max_texture_size:
                 img = img.resize((max_texture_size, max_texture_size), Image.BOX)
             image_cache[image_index] = np.asarray(img, dtype=np.uint8).copy()

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 
 def test_helmet_packing(helmet, A):
@@ -134,3 +134,50 @@ def test_masked_geometry_and_lights_in_oracle(sponza_small_oracle, sponza_small,
     assert st.camera_rays == 96 * 54 and st.light_shadow_rays > 0 and st.sky_shadow_rays > 0
     t = r["target"].view(np.float16).astype(np.float32)
     assert np.isfinite(t).mean() > 0.99 and t[..., :3].max() > 0
+
+
+def test_glb_and_data_uri_containers_load_identically(sio, tmp_path):
+    """The same asset as .gltf + files, as .gltf with data: URIs and as a binary .glb (JSON + BIN chunks, bufferView images)
+    must pack to identical scene arrays -- the containers tinygltf accepts (scene.cpp:113-130)."""
+    import base64
+    import json
+    import struct
+    src_dir = os.path.join(ROOT, "assets", "damaged-helmet")
+    want = sio.load_gltf(os.path.join(src_dir, "DamagedHelmet.gltf"), max_texture_size=64)
+    g = json.load(open(os.path.join(src_dir, "DamagedHelmet.gltf")))
+    read = lambda uri: open(os.path.join(src_dir, uri), "rb").read()
+
+    # (1) data: URIs
+    gd = json.loads(json.dumps(g))
+    for b in gd["buffers"]:
+        b["uri"] = "data:application/octet-stream;base64," + base64.b64encode(read(b["uri"])).decode()
+    for im in gd["images"]:
+        im["uri"] = "data:image/jpeg;base64," + base64.b64encode(read(im["uri"])).decode()
+    p1 = tmp_path / "inline.gltf"; p1.write_text(json.dumps(gd))
+
+    # (2) GLB: one BIN chunk = the geometry buffer followed by the encoded images, each behind a new bufferView
+    gb = json.loads(json.dumps(g))
+    assert len(gb["buffers"]) == 1
+    binary = bytearray(read(gb["buffers"][0]["uri"]))
+    for im in gb["images"]:
+        data = read(im.pop("uri"))
+        while len(binary) % 4: binary.append(0)
+        gb["bufferViews"].append({"buffer": 0, "byteOffset": len(binary), "byteLength": len(data)})
+        im["bufferView"] = len(gb["bufferViews"]) - 1; im["mimeType"] = "image/jpeg"
+        binary += data
+    del gb["buffers"][0]["uri"]; gb["buffers"][0]["byteLength"] = len(binary)
+    js = json.dumps(gb).encode(); js += b" " * (-len(js) % 4)
+    binary += b"\0" * (-len(binary) % 4)
+    p2 = tmp_path / "packed.glb"
+    p2.write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(binary)) + struct.pack("<II", len(js), 0x4E4F534A) + js
+                   + struct.pack("<II", len(binary), 0x004E4942) + bytes(binary))
+
+    for p in (p1, p2):
+        got = sio.load_gltf(str(p), max_texture_size=64)
+        assert len(got.textures) == len(want.textures) and len(got.materials) == len(want.materials)
+        for (a, fa), (b, fb) in zip(got.textures, want.textures):
+            assert fa == fb and np.array_equal(a, b)
+        assert len(got.mesh_primitives) == len(want.mesh_primitives) and got.accessors == want.accessors and got.num_triangles == want.num_triangles
+        n = len(want.buffers[0]) - 32                                   # the loader pads every buffer
+        assert np.array_equal(got.buffers[0][:n], want.buffers[0][:n])
+        assert bytes(got.materials[0]) == bytes(want.materials[0])

@@ -66,7 +66,7 @@ static constexpr uint32_t kStaticChunk = 512;           // the statically dealt 
 #define INCR_WF_REFILL 12
 #endif
 #ifndef INCR_WF_START
-#define INCR_WF_START 8
+#define INCR_WF_START 16    // A/B at 4K Sponza-stat with kChunk 64 (tools/ab_flags.sh): 4/8/12/16/20/24/32/48 -> shadow 18.7/18.0/17.8/17.6/17.7/17.9/18.5/21.4 ms per frame
 #endif
 static constexpr uint32_t kRefillThreshold = INCR_WF_REFILL;   // refill when at least this many lanes are idle
 static constexpr uint32_t kStartThreshold = INCR_WF_START;     // shadow kernel: lanes between rays start together

@@ -263,14 +263,15 @@ def main():
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
-        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 17 launches (generate + 4 x extend / shade /
-        # shadow / accumulate); the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
-        # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit.
+        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 21 launches (generate + 4 x extend / shade /
+        # shadow_gen / shadow / accumulate); the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
+        # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
         per_kernel = {"incr::wf_generate_kernel": (prof.generate_ms, max(prof.frames, 1), rows * W * 64.0 * args.steps),
                       "incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
                       "incr::wf_shade_kernel": (prof.shade_ms, max(prof.launches[1], 1), float(ls[4]) * B_HIT),
-                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[2], 1), float(ls[2] + ls[3]) * b_ray),
-                      "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[3], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
+                      "incr::wf_shadow_gen_kernel": (prof.shadow_gen_ms, max(prof.launches[2], 1), float(ls[2] + ls[3]) * 32.0 + float(ls[4]) * 52.0),
+                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3]) * b_ray),
+                      "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[4], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
         dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
         dom_ms, dom_launches, dom_bytes = per_kernel[dominant]
         kernel_ms = dom_ms / dom_launches if dom_ms > 0 else call_ms

@@ -16,9 +16,7 @@
 
 using namespace incr;
 
-extern "C" hipError_t incr_launch_pathtrace(const incr::PtParams* p, hipStream_t stream);
-extern "C" hipError_t incr_launch_pathtrace_wave(const incr::PtParams* p, uint32_t* tileQueue, int numCUs, hipStream_t stream);
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream, hipEvent_t* events);
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -31,7 +29,7 @@ int incr_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
-static constexpr uint32_t kNumTileQueues = 64;
+static constexpr int kProfEvents = 22;      // per recorded incr_pathtrace call: start + generate + 4 x (extend, shade, shadow_gen, shadow, accumulate)
 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
 
@@ -69,11 +67,8 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     // block-reduced atomic per workgroup, spread over 64 L2 lines) and a one-wave kernel folds them into the caller's stats
     HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
     HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
-    HIP_TRY(hipMalloc((void**)&ctx->tileQueues, kNumTileQueues * 64));      // one 64-byte line per queue head
-    HIP_TRY(hipMemset(ctx->tileQueues, 0, kNumTileQueues * 64));
-    ctx->nextQueue = 0;
-    const char* kv = getenv("INCR_PT_KERNEL");
-    ctx->kernelVariant = (kv && !strcmp(kv, "mega")) ? 1 : (kv && !strcmp(kv, "wave")) ? 2 : 0;
+    const char* rc = getenv("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
+    ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 8u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
     ctx->profiling = false; ctx->profFrames = 0;
     ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
@@ -87,7 +82,6 @@ int incr_teardown(incr_context* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->statStripes) (void)hipFree(ctx->statStripes);
-    if (ctx->tileQueues) (void)hipFree(ctx->tileQueues);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
@@ -155,10 +149,12 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 }
 
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned).
+// 176 B of path state + raysPerPath x 32 B of shadow-ray queue per pixel: 3.6 GB at 4K -- 1.2 % of the 288 GB.
 static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t stream) {
     if (numPaths == 0) numPaths = 1;
     const uint64_t n = (numPaths + 255) & ~255ull;
-    const uint64_t need = n * (16 * 5 + 96 + 4 * 3) + 4096;
+    const uint64_t rayCap = std::min<uint64_t>(n * ctx->raysPerPath, 0xfffffff0ull);
+    const uint64_t need = n * (16 * 5 + 96 + 4 * 3) + 4096 + (rayCap + 1) * 32;
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
@@ -171,6 +167,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t
     w.rayO = (float4*)p; p += n * 16; w.rayD = (float4*)p; p += n * 16; w.color = (float4*)p; p += n * 16; w.atten = (float4*)p; p += n * 16;
     w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 96;
     w.liveA = (uint32_t*)p; p += n * 4; w.liveB = (uint32_t*)p; p += n * 4; w.hitList = (uint32_t*)p; p += n * 4;
+    w.rayQ = (float4*)p; w.rayCap = (uint32_t)rayCap;
     w.numPaths = (uint32_t)numPaths;
     return INCR_OK;
 }
@@ -207,6 +204,11 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         for (int32_t t : idx) if (t < -1 || t >= (int32_t)desc->num_textures) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "material %u: texture index %d out of range", i, t); }
     }
     build_world_bvh(sc->host, sc->bvh);
+    if (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes) {
+        const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
+        delete sc;
+        return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes);
+    }
     int rc = upload_bvh(sc);
     if (!rc) rc = upload_vec(&sc->dMaterials, sc->host.materials.data(), sc->host.materials.size());
     if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
@@ -370,23 +372,18 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.target = (uint16_t*)d->target_rgba16f; P.history = (uint32_t*)d->history_r11g11b10;
     P.storageRounding = d->storage_rounding;
     P.stats = d->ray_stats;
-    P.statStripes = ctx->kernelVariant == 0 ? ctx->statStripes : nullptr;     // the wavefront kernels count through the striped counters
+    P.statStripes = ctx->statStripes;     // the wavefront kernels count through the striped counters
     upload_grid_params(sc, P);
-    if (ctx->kernelVariant == 0) {
-        int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);
-        if (rc) return rc;
-        hipEvent_t* ev = nullptr;
-        if (ctx->profiling) {
-            while (ctx->profEvents.size() < (ctx->profFrames + 1) * 18) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
-            ev = ctx->profEvents.data() + ctx->profFrames * 18;
-            ctx->profFrames++;
-        }
-        HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, (hipStream_t)stream, ev));
-    } else if (ctx->kernelVariant == 1) HIP_TRY(incr_launch_pathtrace(&P, (hipStream_t)stream));
-    else {
-        uint32_t* q = ctx->tileQueues + (size_t)(ctx->nextQueue++ % kNumTileQueues) * 16;
-        HIP_TRY(incr_launch_pathtrace_wave(&P, q, ctx->props.multiProcessorCount, (hipStream_t)stream));
+    int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);
+    if (rc) return rc;
+    hipEvent_t* ev = nullptr;
+    if (ctx->profiling) {
+        while (ctx->profEvents.size() < (ctx->profFrames + 1) * kProfEvents) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
+        ev = ctx->profEvents.data() + ctx->profFrames * kProfEvents;
+        ctx->profFrames++;
     }
+    const uint32_t stackEntries = sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1;
+    HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, stackEntries, (hipStream_t)stream, ev));
     return INCR_OK;
 }
 
@@ -439,12 +436,12 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     memset(out, 0, sizeof *out);
     ctx->profiling = false;
     HIP_TRY(hipDeviceSynchronize());
-    double* cls[4] = {&out->extend_ms, &out->shade_ms, &out->shadow_ms, &out->accumulate_ms};
+    double* cls[5] = {&out->extend_ms, &out->shade_ms, &out->shadow_gen_ms, &out->shadow_ms, &out->accumulate_ms};
     for (size_t f = 0; f < ctx->profFrames; ++f) {
-        hipEvent_t* ev = ctx->profEvents.data() + f * 18;
+        hipEvent_t* ev = ctx->profEvents.data() + f * kProfEvents;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); out->generate_ms += ms;
-        for (int k = 0; k < 16; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k & 3] += ms; if (ms > 0.f) out->launches[k & 3]++; }
+        for (int k = 0; k < 20; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++; }
     }
     out->frames = (uint32_t)ctx->profFrames;
     ctx->profFrames = 0;

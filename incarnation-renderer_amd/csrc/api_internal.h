@@ -24,15 +24,12 @@ struct incr_context {
     hipDeviceProp_t props;
     float* srgbLut;           // 256 floats in HBM
     unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
-    uint32_t* tileQueues;     // ring of tile-queue heads for the persistent path-trace kernel (one word per launch in flight)
-    uint32_t nextQueue;
-    int kernelVariant;        // 0 = wavefront multi-kernel (default), 1 = lane-per-pixel megakernel (INCR_PT_KERNEL=mega),
-                              // 2 = persistent single-kernel wavefront (INCR_PT_KERNEL=wave)
+    uint32_t raysPerPath;     // shadow-ray queue slots per path of the wavefront path tracer (8; INCR_WF_RAYS_PER_PATH)
     incr::WfBuffers wf;       // path-state workspace of the wavefront path tracer, grown on demand
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
     bool profiling;                                   // incr_profile_begin .. incr_profile_end
-    std::vector<hipEvent_t> profEvents;               // 18 per recorded incr_pathtrace call
+    std::vector<hipEvent_t> profEvents;               // 22 per recorded incr_pathtrace call
     size_t profFrames;
     // raster path workspace (raster_api.hip): 64-bit depth|id surface of the visibility pass + per-mesh frame constants
     void* rasterBlock;

@@ -17,12 +17,19 @@ namespace incr {
 struct alignas(16) BvhNode8 {
     float ox, oy, oz;            // node box minimum
     uint8_t ex, ey, ez, imask;   // per-axis scale exponent (IEEE biased), bit k of imask: child k is an inner node
-    uint32_t childBase;          // inner children are stored contiguously from here, in slot order
+    uint32_t childBase;          // inner child in slot k is node childBase + k (see SLOT ORDER)
     uint32_t triBase;            // triangles of the leaf children are stored contiguously from here
-    uint8_t meta[8];             // leaf child: (count << 5) | offset from triBase (count 1..4, offset <= 28); 0: inner or empty
+    uint8_t meta[8];             // leaf child: (count << 5) | offset from triBase (count 1..4, offset <= 28); empty: 0;
+                                 // inner: 0, except meta[0] = the node's sort axis (0..2) when slot 0 is inner
     uint8_t qlox[8], qloy[8], qloz[8];
     uint8_t qhix[8], qhiy[8], qhiz[8];
 };
+// SLOT ORDER (traversal relies on it): the inner children occupy slots 0 .. n-1 (imask == (1 << n) - 1), sorted by box
+// centre along the node's longest axis (the "sort axis"); leaf children follow, empty slots last.  A traversal stack
+// entry can then name ALL pending inner children of a node in one word: childBase << 9 | reverse << 8 | slot mask --
+// the stack never holds more than one entry per tree level, so it fits LDS for any tree (kMaxBvhDepth).
+static constexpr uint32_t kMaxBvhNodes = 1u << 23;     // childBase must fit 23 bits of a stack entry
+static constexpr uint32_t kMaxBvhDepth = 25;           // deepest tree the traversal kernels carry a stack for (24 entries)
 static_assert(sizeof(BvhNode8) == 80, "node8 must be 5 x 16 bytes");
 
 #ifndef INCR_MAX_LEAF_TRIS

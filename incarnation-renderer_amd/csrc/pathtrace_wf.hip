@@ -1,6 +1,6 @@
 // pathtrace_wf.hip -- the production path tracer: a WAVEFRONT (multi-kernel) formulation for gfx950.
 //
-// Why not one megakernel (pathtrace.hip / pathtrace_wave.hip)?  Measured on MI355X (profiles/r01_v2_*):
+// Why not one megakernel?  Measured on MI355X in round 1 (profiles/r01_v2_*, the variants have since been removed):
 // the fused kernels need 147-169 VGPRs (2-3 waves per SIMD), waves spend 64 % of their cycles waiting on
 // memory, VALU lanes are 31 % utilised, and HBM/L2-miss traffic is only ~150 GB/s -- the path is LATENCY
 // bound, not bandwidth bound.  MI355X has 288 GB of HBM3E at ~8 TB/s, so the cure is to keep the per-path
@@ -12,7 +12,9 @@
 //     shade      miss: msDynamicSky + store.  hit: chsMain part 1 -- surface, material, emissive, sky sample,
 //                ENUMERATE the shadow rays as a request bit-mask per vertex, BRDF-sampled continuation ray,
 //                append to L_{b+1}                                                                    [no traversal]
-//     shadow     RayQuery stand-in: traces the requested shadow rays, clears the bits of occluded ones [traversal only]
+//     shadow_gen expands the request masks into a flat queue of shadow rays (origin, direction, path, slot): one lane
+//                per RAY, whatever the number of lights per vertex                                      [no traversal]
+//     shadow     RayQuery stand-in: traces the queued shadow rays, clears the request bit of occluded ones [traversal only]
 //     accumulate chsMain part 2: evaluates the unoccluded lights IN THE REFERENCE'S LOOP ORDER, then the sky
 //                sample, adds them to payload.color; finished paths are stored + integrated            [no traversal]
 //
@@ -23,8 +25,7 @@
 // refill: 16-22 % VALU lane utilisation, profiles/r01_v3_*).  Every wave reaches the exit (cursor exhausted and
 // no lane active), so the grid always drains.
 //
-// The float operations per pixel and their order are exactly those of pathtrace.hip (= the reference HLSL),
-// so all kernel variants are bit-identical; only the schedule differs.
+// The float operations per pixel and their order are exactly those of the reference HLSL; only the schedule differs.
 //
 // Light loop: chsMain loops over ALL scene lights per hit (pathtracing.hlsl:230-236).  A world-space light
 // grid (scene_build.h LightGrid) yields, per hit, the ascending sub-list of lights that can be non-zero there;
@@ -44,14 +45,18 @@ static constexpr int kWfBlock = 256;
 #ifndef INCR_SHADE_WAVES
 #define INCR_SHADE_WAVES 3
 #endif
+#ifndef INCR_EXTEND_WAVES
+#define INCR_EXTEND_WAVES 8     // waves per SIMD of the closest-hit kernel with the 8-entry stack (LDS allows 8)
+#endif
 #ifndef INCR_ACCUM_WAVES
 #define INCR_ACCUM_WAVES 4
 #endif
-static constexpr int kWfStackLds = 8;                  // LDS stack entries per lane in the traversal kernels
-using WfStack = LaneStackT<kWfStackLds, kWfBlock>;              // any-hit (shadow) traversal
-using WfStackK = LaneStackT<kWfStackLds, kWfBlock, true>;       // closest-hit traversal: keyed, culls popped nodes beyond the best hit
+// LDS stack entries per lane in the traversal kernels: a template parameter, the launcher picks the smallest of
+// 8 / 16 / 24 that holds the scene's tree (one entry per level, pt_traverse.h) -- Sponza-stat and Bistro-scale take 8.
+template <int N> using WfStack = LaneStackT<N, kWfBlock>;              // any-hit (shadow) traversal
+template <int N> using WfStackK = LaneStackT<N, kWfBlock, true>;       // closest-hit traversal: keyed, drops groups beyond the best hit
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
-static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
+static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u;
 // Items a wave takes from the device-wide cursor at a time.  Measured at 4K Sponza-stat, ms per frame for chunks of
 // 32 / 64 / 96 / 128 / 160 / 256 / 512 / 1024 items: 44.9 / 44.5 / 45.5 / 46.3 / 47.7 / 51.4 / 55.0 / 58.6 -- with 8192
 // persistent waves a 512-item chunk is a quarter of a wave's whole share of a 4K list, and the kernel ends on the waves
@@ -61,18 +66,13 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u;
 #define INCR_WF_CHUNK 64
 #endif
 static constexpr uint32_t kChunk = INCR_WF_CHUNK;
-static constexpr uint32_t kStaticChunk = 512;           // the statically dealt first chunk of the one-round variant
 #ifndef INCR_WF_REFILL
 #define INCR_WF_REFILL 12
 #endif
-#ifndef INCR_WF_START
-#define INCR_WF_START 16    // A/B at 4K Sponza-stat with kChunk 64 (tools/ab_flags.sh): 4/8/12/16/20/24/32/48 -> shadow 18.7/18.0/17.8/17.6/17.7/17.9/18.5/21.4 ms per frame
-#endif
 static constexpr uint32_t kRefillThreshold = INCR_WF_REFILL;   // refill when at least this many lanes are idle
-static constexpr uint32_t kStartThreshold = INCR_WF_START;     // shadow kernel: lanes between rays start together
 static constexpr uint32_t kMissTri = 0xffffffffu;
-// counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow)
-static constexpr int kCursorBase = 16;
+// counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
+static constexpr int kCursorBase = 16, kRayCountBase = 32;
 
 // vertex record: 6 float4 per path
 //   [0] hitPos.xyz, metallic   [1] N.xyz, roughness   [2] basecolor.xyz, flags   [3] attenuation at the vertex .xyz, cell
@@ -130,17 +130,14 @@ DI uint32_t light_cell(const PtParams& P, f3 p) {
 struct WaveChunk {
     uint32_t next, end;     // wave-uniform
     bool exhausted;
-    DI void init() { next = 0; end = 0; exhausted = false; }
-    // kOneRound variant (the launcher picks it when the whole frame fits one round of the grid, so every list does): a
-    // wave's first chunk is static -- chunk number = its index in the grid -- and the launcher starts the cursors behind
-    // that round.  The 8192 waves of the grid then do not queue on one cursor word just to learn there is nothing left:
-    // waves without a chunk leave at once, the others ask the cursor once, after their chunk (helmet 1080p: 5.3 -> 4.8 ms
-    // per frame).  A separate instantiation because the traversal kernels sit exactly at 64 VGPRs: the same logic as a
-    // run-time branch cost the 4K shadow kernel 20 bytes of spills and 8 % of its time.
-    DI void init_one_round(uint32_t total) {
-        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kStaticChunk);
+    // A wave's FIRST chunk is static -- chunk number = its index in the grid -- and the launcher starts the cursors behind
+    // that round: the 8192 waves of the grid do not queue on one cursor word for their first item (or just to learn there
+    // is nothing left: a wave without a static chunk leaves at once).  Chunks are kChunk items in both rounds, so a short
+    // list (a 1/8 framebuffer shard, a late bounce) still spreads over every wave that can get one.
+    DI void init_static(uint32_t total) {
+        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kChunk);
         exhausted = b >= total;
-        next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kStaticChunk, total);
+        next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kChunk, total);
     }
     // returns the item index for this lane or 0xffffffff
     DI uint32_t take(bool idle, uint32_t* __restrict__ cursor, uint32_t total) {
@@ -196,15 +193,14 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-template <bool kOneRound> __global__ __launch_bounds__(kWfBlock, 8) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
-    __shared__ float s_keys[kWfStackLds * kWfBlock];
-    WfStackK st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 16 ? 5 : 3)) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+    __shared__ uint32_t s_stack[N * kWfBlock];
+    __shared__ float s_keys[N * kWfBlock];
+    WfStackK<N> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
-    WaveChunk chunk;
-    if constexpr (kOneRound) chunk.init_one_round(total); else chunk.init();
+    WaveChunk chunk; chunk.init_static(total);
     bool active = false; uint32_t pid = 0;
     TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     uint32_t rays = 0;
@@ -399,92 +395,124 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
     add_counters(P, cnt);
 }
 
-// ------------------------------------------------------------------------------------------------ shadow
-// One lane = one path vertex at a time: the lane traces that vertex's requested shadow rays one after the other
-// (lowest slot first) and writes back the mask with the occluded requests cleared.  No LDS queue, no atomics on
-// the occlusion bits; idle lanes get the next vertices of the wave's chunk.
-template <bool kOneRound> __global__ __launch_bounds__(kWfBlock, 8) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    __shared__ uint32_t s_stack[kWfStackLds * kWfBlock];
-    WfStack st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
+// ------------------------------------------------------------------------------------------------ shadow rays
+// Round 1 gave every lane of the shadow kernel one path VERTEX and let it trace that vertex's requested rays one after
+// the other, the ~200-instruction light / ray set-up of each ray included: set-up ran for a handful of lanes on nearly
+// every iteration of the traversal loop (34 % VALU lane utilisation).  Now the set-up is its own streaming kernel with
+// one lane per RAY and the traversal kernel reads a flat, coalesced ray queue (32 B per ray: origin + path id, direction
+// + request slot); rays of one vertex are neighbours in the queue, so neighbouring lanes leave from the same point.
+//
+// Queue capacity is a soft limit (rayCap = 8 rays per path, four to five times what the light grid asks for on the
+// bench scenes): a workgroup whose rays do not fit flags its vertices kFlagInlineShadow and accumulate traces those
+// requests itself -- slower, same result, nothing is dropped.
+DI uint32_t nth_set_bit(uint32_t word, uint32_t j) {          // position of the j-th (0-based) set bit of `word`
+    uint32_t pos = 0u;
+#pragma unroll
+    for (uint32_t sft = 16u; sft > 0u; sft >>= 1) {
+        const uint32_t c = (uint32_t)__popc((word >> pos) & ((1u << sft) - 1u));
+        if (j >= c) { j -= c; pos += sft; }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams P, const WfBuffers B, int bounce) {
+    __shared__ uint32_t s_prefix[kWfBlock + 1];
+    __shared__ uint32_t s_waveTotal[kWfBlock / 64];
+    __shared__ uint32_t s_pid[kWfBlock];
+    __shared__ uint4 s_mask[kWfBlock];
+    __shared__ uint32_t s_base;
+    const uint32_t count = B.counters[bounce];
+    if (blockIdx.x * kWfBlock >= count) return;
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
-    const uint32_t total = B.counters[bounce];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * kWfBlock + tid;
+    uint32_t pid = 0; uint4 req = make_uint4(0u, 0u, 0u, 0u);
+    if (i < count) { pid = live[i]; req = *(const uint4*)(vertex_of(B, pid) + 5); }
+    const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
+    // exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+    if (lane == 63u) s_waveTotal[wave] = incl;
+    s_pid[tid] = pid; s_mask[tid] = req;
+    __syncthreads();
+    uint32_t waveBase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
+    s_prefix[tid] = waveBase + incl - n;
+    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
+    __syncthreads();
+    if (total == 0u) return;
+    const uint32_t base = s_base;
+    if (base + total > B.rayCap || base + total < base) {
+        // queue full: these vertices are traced by accumulate; the part of the claimed range that lies inside the queue
+        // is filled with null rays so that the traversal kernel never reads an unwritten record
+        if (n) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagInlineShadow)); }
+        for (uint32_t r = tid; r < total && base + r < B.rayCap; r += kWfBlock) {
+            B.rayQ[(size_t)(base + r) * 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+            B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(0.f, 0.f, 1.f, 0.f);
+        }
+        return;
+    }
+    for (uint32_t r = tid; r < total; r += kWfBlock) {
+        // owner vertex: the last v with s_prefix[v] <= r
+        uint32_t lo = 0u, hi = kWfBlock;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= r) lo = mid; else hi = mid; }
+        uint32_t j = r - s_prefix[lo];
+        const uint4 m = s_mask[lo];
+        const uint32_t vp = s_pid[lo];
+        uint32_t word = m.x, wbase = 0u;
+        const uint32_t c0 = (uint32_t)__popc(m.x), c1 = (uint32_t)__popc(m.y), c2 = (uint32_t)__popc(m.z);
+        if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
+        const uint32_t slot = wbase + nth_set_bit(word, j);
+        const float4* vtx = vertex_of(B, vp);
+        const float4 v0 = vtx[0];
+        const f3 origin = {v0.x, v0.y, v0.z};
+        f3 L;
+        if (slot == kSkySlot) { const float4 v4 = vtx[4]; L = {v4.x, v4.y, v4.z}; }
+        else {
+            const uint32_t cell = __float_as_uint(vtx[3].w);
+            const uint32_t li = P.gridCellLights[P.gridCellOffsets[cell] + slot];
+            incr_light light; const float* lm; bool haveT;
+            load_light(P, (int)li, light, lm, haveT);
+            L = light_setup(light, lm, haveT, origin, {0.f, 0.f, 0.f}).L;      // the same L shade computed (N does not enter L)
+        }
+        B.rayQ[(size_t)(base + r) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
+        B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
+    }
+}
+
+// Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray clears
+// its request bit (one fire-and-forget atomic; unoccluded rays -- the majority of the light rays -- write nothing).
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+    __shared__ uint32_t s_stack[N * kWfBlock];
+    WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
+    const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
-    WaveChunk chunk;
-    if constexpr (kOneRound) chunk.init_one_round(total); else chunk.init();
-    bool haveVertex = false, tracing = false;
-    uint32_t pid = 0, cell = 0, curSlot = 0;
-    uint32_t rem0 = 0u, rem1 = 0u, rem2 = 0u, rem3 = 0u, occ0 = 0u, occ1 = 0u, occ2 = 0u, occ3 = 0u;
-    f3 origin = {0.f, 0.f, 0.f};
+    WaveChunk chunk; chunk.init_static(total);
+    bool active = false;
+    uint32_t pid = 0, slot = 0;
     TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     for (;;) {
-        // ---- vertices for lanes that have none ----
-        const unsigned long long busy = __ballot(haveVertex);
-        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
-        if (!chunk.exhausted && (idle >= kRefillThreshold || busy == 0ull)) {
-            const uint32_t item = chunk.take(!haveVertex, cursor, total);
+        const unsigned long long act = __ballot(active);
+        const uint32_t idle = 64u - (uint32_t)__popcll(act);
+        if (!chunk.exhausted && (idle >= kRefillThreshold || act == 0ull)) {
+            const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) {
-                pid = live[item];
-                const float4* vtx = vertex_of(B, pid);
-                const uint4 req = *(const uint4*)(vtx + 5);
-                if (req.x | req.y | req.z | req.w) {
-                    const float4 v0 = vtx[0], v3 = vtx[3];
-                    origin = {v0.x, v0.y, v0.z}; cell = __float_as_uint(v3.w);
-                    rem0 = req.x; rem1 = req.y; rem2 = req.z; rem3 = req.w;
-                    occ0 = occ1 = occ2 = occ3 = 0u;
-                    haveVertex = true; tracing = false;
+                const float4 a = B.rayQ[(size_t)item * 2], b = B.rayQ[(size_t)item * 2 + 1];
+                pid = __float_as_uint(a.w); slot = __float_as_uint(b.w);
+                if (pid != 0xffffffffu) {
+                    trav_any_begin(T, {a.x, a.y, a.z}, {b.x, b.y, b.z}, 0.1f, 1000.f);     // lighting/common.hlsli:96-100
+                    st.reset();
+                    active = true;
                 }
             }
         }
-        if (__ballot(haveVertex) == 0ull) { if (chunk.exhausted) break; else continue; }
-        // ---- next shadow ray for lanes between rays ----
-        // Starting a ray costs ~200 VALU instructions (light set-up with its divisions, ray set-up); run alone it would
-        // execute for one or two lanes on nearly every iteration.  Lanes between rays therefore wait until
-        // kStartThreshold of them are ready (or nothing is being traced) and start together (A/B on MI355X, Sponza-stat
-        // 4K: threshold 1 / 4 / 8 / 16 / 32 -> 26.7 / 25.7 / 24.6 / 24.7 / 26.8 ms per frame in this kernel).
-        const bool between = haveVertex && !tracing;
-        const unsigned long long bmask = __ballot(between);
-        const bool startNow = bmask != 0ull && ((uint32_t)__popcll(bmask) >= kStartThreshold || __ballot(tracing) == 0ull);
-        if (between && startNow) {
-            const int w = rem0 ? 0 : rem1 ? 1 : rem2 ? 2 : rem3 ? 3 : -1;
-            if (w < 0) {      // vertex finished: write back the surviving requests
-                if (occ0 | occ1 | occ2 | occ3) {
-                    uint4* dst = (uint4*)(vertex_of(B, pid) + 5);
-                    const uint4 req = *dst;
-                    *dst = make_uint4(req.x & ~occ0, req.y & ~occ1, req.z & ~occ2, req.w & ~occ3);
-                }
-                haveVertex = false;
-            } else {
-                const uint32_t word = w == 0 ? rem0 : w == 1 ? rem1 : w == 2 ? rem2 : rem3;
-                const uint32_t bit = (uint32_t)__builtin_ctz(word);
-                const uint32_t cleared = word & (word - 1u);
-                if (w == 0) rem0 = cleared; else if (w == 1) rem1 = cleared; else if (w == 2) rem2 = cleared; else rem3 = cleared;
-                curSlot = (uint32_t)w * 32u + bit;
-                f3 L;
-                if (curSlot == kSkySlot) { const float4 v4 = vertex_of(B, pid)[4]; L = {v4.x, v4.y, v4.z}; }
-                else {
-                    const uint32_t li = P.gridCellLights[P.gridCellOffsets[cell] + curSlot];
-                    incr_light light; const float* m; bool haveT;
-                    load_light(P, (int)li, light, m, haveT);
-                    L = light_setup(light, m, haveT, origin, {0.f, 0.f, 0.f}).L;      // the same L shade computed (N does not enter L)
-                }
-                trav_any_begin(T, origin, L, 0.1f, 1000.f);                            // lighting/common.hlsli:96-100
-                st.reset();
-                // (A last-occluder cache -- test the triangle that blocked the previous ray of this (light-grid cell, light)
-                // first -- was measured and dropped: 24.3 -> 25.1 ms per frame; the requested light rays are within the
-                // lights' 4-unit range window and mostly unoccluded, so the extra triangle test is pure overhead.)
-                tracing = true;
-            }
-        }
-        // ---- one traversal step ----
-        // (Voting for one kind of step per iteration -- node tests or triangle tests, whichever serves more lanes per issued
-        // instruction, the other lanes waiting -- was measured and dropped: extend 19.3 -> 19.3, shadow 24.0 -> 25.1 ms per
-        // frame.  The step is bound by its dependent 80-byte fetch, not by issue slots.)
-        if (tracing && trav_any_step(P, st, T)) {
-            if (T.occluded) {
-                const uint32_t w = curSlot >> 5, m = 1u << (curSlot & 31u);
-                if (w == 0) occ0 |= m; else if (w == 1) occ1 |= m; else if (w == 2) occ2 |= m; else occ3 |= m;
-            }
-            tracing = false;
+        if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
+        if (active && trav_any_step(P, st, T)) {
+            if (T.occluded) atomicAnd((uint32_t*)(vertex_of(B, pid) + 5) + (slot >> 5), ~(1u << (slot & 31u)));
+            active = false;
         }
     }
 }
@@ -499,6 +527,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
         const float4 v2 = vtx[2];
         const uint32_t flags = __float_as_uint(v2.w);
         if (flags & kFlagSkip) continue;
+        const bool inlineShadow = flags & kFlagInlineShadow;
         const float4 v0 = vtx[0], v1 = vtx[1], v3 = vtx[3], v4 = vtx[4];
         const uint4 vis = *(const uint4*)(vtx + 5);
         const uint4 h = B.hit[pid];
@@ -519,13 +548,13 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
                 const LightSample s = light_setup(light, m, haveT, hitPosition, N);
                 f3 radianceOut = {0.f, 0.f, 0.f};
                 bool visible;
-                if (k < kSkySlot) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
+                if (k < kSkySlot && !inlineShadow) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
                     const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
                     visible = (w >> (k & 31u)) & 1u;
                 }
-                else {   // more than 127 candidate lights in one cell: traced here (slow path, private-memory stack)
+                else {   // more than 127 candidate lights in one cell, or the ray queue was full: traced here (slow path, private-memory stack)
                     visible = false;
-                    if (s.needsShadow) { LaneStackT<0, 1> ps; ps.bind(nullptr, nullptr); ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
+                    if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
                 }
                 if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
                 const f3 r = attenV * radianceOut;
@@ -536,7 +565,9 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
-            if (vis.w >> 31) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
+            bool skyVisible = vis.w >> 31;
+            if (skyVisible && inlineShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; skyVisible = !trace_any(P, ps, hitPosition, skyDir, 0.1f, 1000.f); }
+            if (skyVisible) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
         }
@@ -548,46 +579,59 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
 } // namespace incr
 
 // ---- launcher ------------------------------------------------------------------------------------------
-// `events` (optional, 18 entries): recorded on `stream` before the first kernel and after every kernel
-// (generate, then extend / shade / shadow / accumulate per bounce) so that the host can attribute time per kernel.
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, hipStream_t stream, hipEvent_t* events) {
+namespace incr {
+__global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters, uint32_t extendStart, uint32_t shadowStart) {
+    const uint32_t i = threadIdx.x;
+    uint32_t v = 0u;
+    if (i >= (uint32_t)kCursorBase && i < (uint32_t)kCursorBase + 8u) v = ((i - kCursorBase) & 1u) ? shadowStart : extendStart;   // behind the static first round
+    counters[i] = v;
+}
+template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
+    hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
+}
+template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
+    hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
+}
+} // namespace incr
+
+// `events` (optional, 22 entries): recorded on `stream` before the first kernel and after every kernel
+// (generate, then extend / shade / shadow_gen / shadow / accumulate per bounce) so that the host can attribute time per kernel.
+// `stackEntries`: LDS stack entries per lane the scene's tree needs (maxDepth - 1); 8, 16 or 24 are instantiated.
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;
     const uint32_t total = tilesX * tilesY * 64u;
     if (total == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(b->counters, 0, 64 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    if (stackEntries > 24u) return hipErrorInvalidValue;
+    const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 16u ? 16 : 24);
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
-    // generate / shade / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer.
+    // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer.
     // Capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms,
     // uncapped 42.7: a block's 16 strided iterations were another fixed share that the slowest blocks finished late.
 #ifndef INCR_WF_STREAM_BLOCKS_PER_CU
 #define INCR_WF_STREAM_BLOCKS_PER_CU 65536
 #endif
     const uint32_t blocksAll = std::max(1u, (uint32_t)std::min<uint64_t>((uint64_t)cus * INCR_WF_STREAM_BLOCKS_PER_CU, (total + kWfBlock - 1) / kWfBlock));
-    // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (8 blocks of 4 waves per CU)
-    const uint32_t blocksTrav = std::max(1u, std::min(cus * 8u, (total + kWfBlock - 1) / kWfBlock));
-    // every list of a frame that fits one round of the traversal grid is dealt statically (WaveChunk::init_one_round)
-    const bool oneRound = (uint64_t)p->W * p->localRows <= (uint64_t)blocksTrav * (kWfBlock / 64) * kStaticChunk;
-    if (oneRound) {       // the cursors (counters[16 .. 24)) start behind the statically dealt first round
-        if ((e = hipMemsetD32Async((hipDeviceptr_t)(b->counters + kCursorBase), (int)(blocksTrav * (kWfBlock / 64) * kStaticChunk), 8, stream)) != hipSuccess) return e;
-    }
+    // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 16 ? 5u : 3u), shadowPerCU = sv <= 16 ? 8u : 6u;
+    const uint32_t blocksExtend = std::max(1u, std::min(cus * extendPerCU, (total + kWfBlock - 1) / kWfBlock));
+    const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
+    hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, stream, b->counters, blocksExtend * (kWfBlock / 64) * kChunk, blocksShadow * (kWfBlock / 64) * kChunk);
     int ev = 0;
     auto mark =[&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
     mark();
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX); mark();
     for (int bounce = 0; bounce < 4; ++bounce) {
-        if (oneRound) hipLaunchKernelGGL(wf_extend_kernel<true>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        else hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        if (sv == 8) launch_extend<8>(blocksExtend, stream, *p, *b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend, stream, *p, *b, bounce); else launch_extend<24>(blocksExtend, stream, *p, *b, bounce);
         mark();
         hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
         if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
-        if (oneRound) hipLaunchKernelGGL(wf_shadow_kernel<true>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
-        else hipLaunchKernelGGL(wf_shadow_kernel<false>, dim3(blocksTrav), dim3(kWfBlock), 0, stream, *p, *b, bounce);
+        hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+        if (sv == 8) launch_shadow<8>(blocksShadow, stream, *p, *b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, stream, *p, *b, bounce); else launch_shadow<24>(blocksShadow, stream, *p, *b, bounce);
         mark();
         hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
     }
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, stream);
-    while (ev < 18) mark();                       // unused slots collapse to zero-length intervals
+    while (ev < 22) mark();                       // unused slots collapse to zero-length intervals
     return hipGetLastError();
 }

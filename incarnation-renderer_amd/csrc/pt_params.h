@@ -58,7 +58,9 @@ struct WfBuffers {
     uint32_t* liveA;     // path ids entering the current bounce
     uint32_t* liveB;     // path ids entering the next bounce
     uint32_t* hitList;   // path ids that hit geometry in the current bounce
-    uint32_t* counters;  // 8 words per bounce: [1] paths that hit geometry, [2] paths continuing to the next bounce
+    uint32_t* counters;  // 64 words: list lengths, traversal cursors, shadow-ray counts (pathtrace_wf.hip kCursorBase / kRayCountBase)
+    float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, request slot}
+    uint32_t rayCap;     // rays the queue holds (soft limit: overflowing vertices are traced inside accumulate)
     uint32_t numPaths;
 };
 

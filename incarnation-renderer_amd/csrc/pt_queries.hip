@@ -1,0 +1,95 @@
+// pt_queries.hip -- the small kernels around the path tracer: incr_trace_rays (batch of inline ray queries, the
+// RayQuery / TraceRay stand-in exposed for tests and tools), TonemapPass and the shard un-interleave.
+// The integrator itself is pathtrace_wf.hip.  (Round 1 also kept a one-launch megakernel and a persistent-wave variant
+// of the integrator here; both were 2x slower than the wavefront kernels and were removed in round 2.)
+#include "pt_traverse.h"
+#include "ibl_device.h"
+#include <algorithm>
+
+namespace incr {
+
+// incr_trace_rays: batch of inline ray queries (debug / RayQuery stand-in); one lane per ray
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const PtParams P, uint32_t n, const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                            float tmin, float tmax, int anyHit, uint32_t* __restrict__ ids, float* __restrict__ tuv) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= n) return;
+    LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
+    const f3 o = {origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]}, d = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
+    uint4 id = make_uint4(0, 0, 0, 0); f3 r = {0.f, 0.f, 0.f};
+    if (anyHit) id.x = trace_any(P, st, o, d, tmin, tmax) ? 1u : 0u;
+    else {
+#ifdef INCR_TRAV_STATS
+        TravClosest T; trav_closest_begin(T, o, d, tmin, tmax); st.reset();
+        while (!trav_closest_step(P, st, T)) {}
+        id = make_uint4(T.found ? 1u : 0u, T.nNodes, T.nTris, 0u);
+        r = {T.best, 0.f, 0.f};
+#else
+        Hit h;
+        if (trace_closest(P, st, o, d, tmin, tmax, &h)) {
+            const TriShade* __restrict__ sh = P.shade + h.tri;
+            id = make_uint4(1u, sh->instance, sh->geometry, sh->primitive);
+            r = {h.t, h.u, h.v};
+        }
+#endif
+    }
+    *(uint4*)(ids + (size_t)i * 4) = id;
+    tuv[(size_t)i * 3] = r.x; tuv[(size_t)i * 3 + 1] = r.y; tuv[(size_t)i * 3 + 2] = r.z;
+}
+
+// TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode
+DI uint32_t linear_to_srgb8(float c) {
+    if (!(c > 0.f)) c = 0.f;
+    if (c > 1.f) c = 1.f;
+    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.f / 2.4f) - 0.055f;
+    return (uint32_t)floorf(e * 255.f + 0.5f);
+}
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
+    const float e = Exposure(ev100);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const f3 h = unpack_r11g11b10(hdr[i]);
+        f3 l;
+        if (viewmode != 0 && viewmode != 1) l = h; else l = ACESFilm(h * e);
+        ldr[i] = linear_to_srgb8(l.x) | (linear_to_srgb8(l.y) << 8) | (linear_to_srgb8(l.z) << 16) | 0xff000000u;
+    }
+}
+
+// un-interleave gathered shards: src [numShards][localRows][W] -> dst [H][W]
+__global__ __launch_bounds__(256) void unshard_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t W, uint32_t H,
+                                                      uint32_t h, uint32_t numShards, uint32_t localRows, uint32_t texelBytes) {
+    const size_t rowBytes = (size_t)W * texelBytes;
+    const size_t total = (size_t)H * rowBytes / 4;       // dword granularity (texelBytes is a multiple of 4)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t byte = i * 4;
+        const uint32_t y = (uint32_t)(byte / rowBytes); const size_t xo = byte % rowBytes;
+        const uint32_t blk = y / h, r = y % h;
+        const uint32_t shard = blk % numShards, k = blk / numShards;
+        const size_t srcOff = ((size_t)shard * localRows + (size_t)k * h + r) * rowBytes + xo;
+        *(uint32_t*)(dst + byte) = *(const uint32_t*)(src + srcOff);
+    }
+}
+
+} // namespace incr
+
+// ---- launchers (called from api.cpp) -----------------------------------------------------------------
+extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
+                                             int anyHit, uint32_t* ids, float* tuv, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(incr::trace_rays_kernel, dim3((n + incr::kBlock - 1) / incr::kBlock), dim3(incr::kBlock), 0, stream, *p, n, origins, dirs, tmin, tmax, anyHit, ids, tuv);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(incr::tonemap_kernel, dim3(blocks), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
+                                          uint32_t localRows, uint32_t texelBytes, hipStream_t stream) {
+    const size_t total = (size_t)H * W * texelBytes / 4;
+    if (!total) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(incr::unshard_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, W, H, h, numShards, localRows, texelBytes);
+    return hipGetLastError();
+}

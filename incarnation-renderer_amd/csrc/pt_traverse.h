@@ -15,19 +15,22 @@
 namespace incr {
 
 static constexpr int kBlock = 256;
-static constexpr int kStackLds = 24;      // LDS-resident entries per lane in the single-kernel variants
-static constexpr int kStackOvf = 72;      // private overflow (8-wide SAH trees stay far below this)
+static constexpr int kStackLds = 24;      // stack entries per lane of the lane-per-pixel kernels (= kMaxBvhDepth - 1)
 
 struct Hit { float t, u, v; uint32_t tri; };
 
-// Per-lane traversal stack: the first NLDS entries live in LDS ([entry][lane], stride STRIDE dwords: lanes of a
-// wave hit 64 consecutive banks), deeper entries in a private (scratch) array that only pathological rays touch.
-// KEYED stacks also keep each entry's box-entry distance so that closest-hit traversal can drop popped nodes
-// that lie beyond the current best hit without fetching them.
+// Per-lane traversal stack, LDS only ([entry][lane], stride STRIDE dwords: the lanes of a wave hit 64 consecutive banks).
+// An entry names ALL pending inner children of one node -- childBase << 9 | reverse << 8 | slot mask (device_types.h
+// SLOT ORDER) -- so the stack holds at most one entry per tree level: N >= maxDepth - 1 can never overflow and there is
+// no private (scratch) spill array.  Round 1 pushed one entry per child: 8 LDS entries overflowed for ~10 % of the rays
+// (p90 depth 8, max 22 on Sponza-stat), i.e. on nearly every wave step, and cost 20 M scratch-store instructions per
+// launch; per node the depth is p99 5, max 7 (tools/trav_sim).  The host picks N from incr_scene's maxDepth.
+// KEYED stacks also keep, per entry, the smallest box-entry distance of the group: closest-hit traversal drops a
+// whole group that lies beyond the current best hit without fetching any of its nodes.
 template <int NLDS, int STRIDE, bool KEYED = false>
 struct LaneStackT {
     static constexpr bool kKeyed = KEYED;
-    static constexpr int kCap = kStackOvf + kStackLds;
+    static constexpr int kCap = NLDS;
     // explicit LDS address space: through a generic pointer the pushes/pops compile to flat_* instructions
     __attribute__((address_space(3))) uint32_t* lds;      // &stack[0][tid]
     __attribute__((address_space(3))) float* ldsKey;      // &keys[0][tid]   (KEYED only)
@@ -35,26 +38,30 @@ struct LaneStackT {
         lds = (__attribute__((address_space(3))) uint32_t*)stackBase;
         ldsKey = (__attribute__((address_space(3))) float*)keyBase;
     }
-    uint32_t ovf[kCap - NLDS];
-    float ovfKey[KEYED ? kCap - NLDS : 1];
     int sp;
     DI void reset() { sp = 0; }
     DI void push(uint32_t v, float key = 0.f) {
-        if constexpr (NLDS > 0) {
-            if (sp < NLDS) { lds[sp * STRIDE] = v; if constexpr (KEYED) ldsKey[sp * STRIDE] = key; ++sp; return; }
-        }
-        if (sp < kCap) { ovf[sp - NLDS] = v; if constexpr (KEYED) ovfKey[sp - NLDS] = key; ++sp; }   // deeper is unreachable for a valid tree
+        if (sp < NLDS) { lds[sp * STRIDE] = v; if constexpr (KEYED) ldsKey[sp * STRIDE] = key; ++sp; }      // sp == NLDS: unreachable for a checked tree
     }
-    DI uint32_t pop(float* key = nullptr) {
-        --sp;
-        if constexpr (NLDS > 0) {
-            if (sp < NLDS) { if constexpr (KEYED) *key = ldsKey[sp * STRIDE]; return lds[sp * STRIDE]; }
-        }
-        if constexpr (KEYED) *key = ovfKey[sp - NLDS];
-        return ovf[sp - NLDS];
-    }
+    DI uint32_t top() const { return lds[(sp - 1) * STRIDE]; }
+    DI float topKey() const { return ldsKey[(sp - 1) * STRIDE]; }
+    DI void setTop(uint32_t v) { lds[(sp - 1) * STRIDE] = v; }
+    DI void drop() { --sp; }
+};
+// Private-memory flavour for the rare inline queries of kernels that own no LDS stack (pathtrace_wf.hip accumulate).
+template <int N>
+struct PrivStackT {
+    static constexpr bool kKeyed = false;
+    uint32_t e[N]; int sp;
+    DI void reset() { sp = 0; }
+    DI void push(uint32_t v, float = 0.f) { if (sp < N) e[sp++] = v; }
+    DI uint32_t top() const { return e[sp - 1]; }
+    DI float topKey() const { return 0.f; }
+    DI void setTop(uint32_t v) { e[sp - 1] = v; }
+    DI void drop() { --sp; }
 };
 using LaneStack = LaneStackT<kStackLds, kBlock>;
+DI uint32_t stack_entry(uint32_t childBase, bool reverse, uint32_t slotMask) { return childBase << 9 | (reverse ? 0x100u : 0u) | slotMask; }
 
 // Moeller-Trumbore on the stored (v0, e1, e2); every operation unfused and in a pinned order: t, u, v are part of
 // the parity contract (bit-exact against the CPU oracle).  a, b, c = the three dwordx4 of a TriIsect record.
@@ -147,7 +154,7 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     N.hitMask = hit;
 }
 DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }
-DI uint32_t node8_child(const Node8& N, uint32_t k) { return N.childBase + (uint32_t)__popc(N.imask & ((1u << k) - 1u)); }
+DI uint32_t node8_child(const Node8& N, uint32_t k) { return N.childBase + k; }      // SLOT ORDER: inner children sit in slots 0 .. n-1
 // bit i set <=> triangle triBase + i belongs to a leaf child whose box the ray overlaps
 DI uint32_t node8_tri_mask(const Node8& N) {
     uint32_t leaves = N.hitMask & ~N.imask, m = 0u;
@@ -159,12 +166,14 @@ DI uint32_t node8_tri_mask(const Node8& N) {
     return m;
 }
 
-// One fetch per step: 80 bytes at the node, or 48 (+32 over-read, the arrays are padded) at the pending triangle.
+// One fetch per step: 80 bytes at the node, or 48 at the pending triangle (the last two dwordx4 are only issued by lanes on a
+// node step: every dwordx4 of a divergent gather is its own vector-L1 look-up, the unit this traversal is bound by).
 struct Fetch5 { float4 a, b, c, d, e; };
 DI Fetch5 fetch_step(const PtParams& P, uint32_t cur, uint32_t triBase, uint32_t triMask) {
     const float4* __restrict__ p = triMask ? (const float4*)(P.tris + triBase + (uint32_t)__builtin_ctz(triMask))
                                            : (const float4*)P.nodes + (size_t)cur * 5;
-    Fetch5 f; f.a = p[0]; f.b = p[1]; f.c = p[2]; f.d = p[3]; f.e = p[4];
+    Fetch5 f; f.a = p[0]; f.b = p[1]; f.c = p[2];
+    if (!triMask) { f.d = p[3]; f.e = p[4]; } else { f.d = f.c; f.e = f.c; }
     return f;
 }
 
@@ -174,6 +183,7 @@ struct TravClosest {
     float best, bu, bv; uint32_t bestFlat, bestTri; bool found;
     uint32_t cur; float curKey;          // next node to visit (valid when haveCur)
     uint32_t triBase, triMask;           // pending triangle tests of the node visited last
+    uint32_t negDir;                     // bit a: the ray points down axis a (selects the walk direction through a node's sorted slots)
     bool haveCur;
 #ifdef INCR_TRAV_STATS
     uint32_t nNodes = 0, nTris = 0;      // developer build only: traversal statistics through incr_trace_rays
@@ -183,6 +193,7 @@ DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax;
     T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.bestTri = 0; T.found = false;
     T.cur = 0; T.curKey = 0.f; T.haveCur = true; T.triBase = 0; T.triMask = 0;
+    T.negDir = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
 }
 // returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
@@ -213,39 +224,45 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
         node8_test(f.a, f.b, f.c, f.d, f.e, T.rs, T.tmin, T.best, N);
         T.triBase = N.triBase;
         T.triMask = node8_tri_mask(N);
-        // inner children: the nearest is visited next (after this node's triangles), the others are pushed far-to-near
-        // so that they pop near-to-far (front-to-back order is what makes the keyed culling bite)
-        uint32_t inner = N.hitMask & N.imask; float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 8u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; }
+        // inner children: the nearest is visited next (after this node's triangles); the others wait on the stack as ONE
+        // entry keyed by the smallest of their entry distances and leave it in slot order -- the builder sorted the slots
+        // along the node's longest axis, `reverse` walks them from the ray's side.  Against exact far-to-near pushes this
+        // visits 4-7 % more nodes on Sponza-stat, and saves the selection sort (up to 7 rounds of 8 compares per node).
+        const uint32_t inner = N.hitMask & N.imask;
         T.haveCur = inner != 0u;
         if (inner) {
-            uint32_t rest = inner & ~(1u << nearK);
-            while (rest) {          // (pushing in slot order instead of far-to-near saves the sort but visits more nodes: no gain measured)
-                float farT = -1.f; uint32_t farK = 0u;
+            float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 0u;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (((rest >> k) & 1u) && N.tn[k] > farT) { farT = N.tn[k]; farK = (uint32_t)k; }
-                st.push(node8_child(N, farK), farT);
-                rest &= ~(1u << farK);
+            for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; }
+            const uint32_t rest = inner & ~(1u << nearK);
+            if (rest) {
+                float restT = __uint_as_float(0x7f800000u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if ((rest >> k) & 1u) restT = fminf(restT, N.tn[k]);
+                const uint32_t axis = N.meta0 & 3u;                  // meta[0] of a node whose slot 0 is inner = its sort axis
+                st.push(stack_entry(N.childBase, (T.negDir >> axis) & 1u, rest), restT);
             }
-            T.cur = node8_child(N, nearK); T.curKey = nearT;
+            T.cur = N.childBase + nearK; T.curKey = nearT;
         }
         if (T.triMask) return false;
     }
-    // ---- choose the next node: the nearest child if it still starts before the best hit, else pop ----
-    if (T.haveCur && T.curKey <= T.best) { T.haveCur = false; return false; }      // equal-t ties must still be visited
+    // ---- choose the next node: the nearest child if it still starts before the best hit, else the stack ----
+    if (T.haveCur) { T.haveCur = false; if (T.curKey <= T.best) return false; }      // equal-t ties must still be visited
     while (st.sp > 0) {
-        float k = 0.f;
-        if constexpr (ST::kKeyed) { T.cur = st.pop(&k); if (k > T.best) continue; }
-        else T.cur = st.pop();
-        T.curKey = k;
+        uint32_t e = st.top();
+        if constexpr (ST::kKeyed) { if (st.topKey() > T.best) { st.drop(); continue; } }
+        const uint32_t m = e & 0xffu;
+        const uint32_t k = (e & 0x100u) ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+        T.cur = (e >> 9) + k;
+        e &= ~(1u << k);
+        if (e & 0xffu) st.setTop(e); else st.drop();
         return false;
     }
     return true;
 }
-// NOTE on haveCur: after the node branch sets cur/haveCur, the "choose" block consumes it exactly once: it clears
-// haveCur and returns so that the NEXT step fetches T.cur.  When the triangles of the node come first, haveCur stays
-// set until the last pending triangle has been tested.
+// NOTE on haveCur: after the node branch sets cur/haveCur, the "choose" block consumes it exactly once.  When the
+// triangles of the node come first, haveCur stays set until the last pending triangle has been tested (the fetch of a
+// triangle step does not use T.cur).
 
 // TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit
 template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
@@ -259,39 +276,39 @@ template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d,
 }
 
 // ---------------------------------------------------------------- any hit (shadow rays)
-struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur, triBase, triMask; bool occluded; };
+struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur, triBase, triMask; bool occluded, haveCur; };
 DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
-    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.triBase = 0; T.triMask = 0; T.occluded = false;
+    T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.triBase = 0; T.triMask = 0; T.occluded = false; T.haveCur = false;
 }
 template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
     const Fetch5 f = fetch_step(P, T.cur, T.triBase, T.triMask);
-    bool haveCur = false;
     if (T.triMask) {
         T.triMask &= T.triMask - 1u;
         float t, u, v; uint32_t flat, flags;
         if (tri_intersect(f.a, f.b, f.c, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
         if (T.triMask) return false;
-        // the node that produced these triangles already queued its inner children: continue with the stack
     } else {
         Node8 N;
         node8_test(f.a, f.b, f.c, f.d, f.e, T.rs, T.tmin, T.tmax, N);
         T.triBase = N.triBase;
         T.triMask = node8_tri_mask(N);
-        uint32_t inner = N.hitMask & N.imask;
-        if (T.triMask) {      // triangles first (a hit ends the query); every inner child waits on the stack
-            while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
-            return false;
-        }
+        // inner children in slot order (nearest-first or ray-side-first visit 10 % MORE nodes for shadow rays, tools/trav_sim):
+        // the first is visited next, after this node's triangles (a hit ends the query); the others are one stack entry
+        const uint32_t inner = N.hitMask & N.imask;
+        T.haveCur = inner != 0u;
         if (inner) {
-            const uint32_t k0 = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u;
-            while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push(node8_child(N, k)); }
-            T.cur = node8_child(N, k0);
-            haveCur = true;
+            const uint32_t rest = inner & (inner - 1u);
+            if (rest) st.push(stack_entry(N.childBase, false, rest));
+            T.cur = N.childBase + (uint32_t)__builtin_ctz(inner);
         }
+        if (T.triMask) return false;
     }
-    if (haveCur) return false;
+    if (T.haveCur) { T.haveCur = false; return false; }
     if (st.sp == 0) return true;
-    T.cur = st.pop();
+    uint32_t e = st.top();
+    T.cur = (e >> 9) + (uint32_t)__builtin_ctz(e & 0xffu);
+    e &= e - 1u;                      // the lowest set bit is a slot bit: the mask of a stored entry is never empty
+    if (e & 0xffu) st.setTop(e); else st.drop();
     return false;
 }
 

@@ -119,7 +119,10 @@ struct Builder {
     }
     static inline float axis_of(const V3& v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
 
-    uint32_t build(uint32_t first, uint32_t count) {
+    // depth-capped: past kSahDepth levels the split is the object median along the longest centroid axis, so the
+    // recursion (and the tree) stays logarithmic however the SAH behaves on pathological input
+    static constexpr uint32_t kSahDepth = 48;
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth = 0) {
         const uint32_t me = (uint32_t)nodes.size();
         nodes.push_back({});
         Box bb, cb; box_reset(bb); box_reset(cb);
@@ -157,7 +160,7 @@ struct Builder {
         }
         uint32_t mid = first;
         const float leafCost = box_area(bb) * (float)count;
-        if (bestAxis >= 0 && (count > kMaxLeafTris || bestCost + box_area(bb) * 1.0f < leafCost)) {
+        if (depth < kSahDepth && bestAxis >= 0 && (count > kMaxLeafTris || bestCost + box_area(bb) * 1.0f < leafCost)) {
             const float lo = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
             auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
                 int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), kBins - 1);
@@ -176,8 +179,8 @@ struct Builder {
                 return cx < cy || (cx == cy && x < y);
             });
         }
-        const uint32_t l = build(first, mid - first);
-        const uint32_t r = build(mid, first + count - mid);
+        const uint32_t l = build(first, mid - first, depth + 1);
+        const uint32_t r = build(mid, first + count - mid, depth + 1);
         nodes[me].left = l; nodes[me].right = r; nodes[me].count = 0;
         return me;
     }
@@ -263,6 +266,15 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
             }
             BvhNode8 nd; memset(&nd, 0, sizeof nd);
             const Box& nb = b.nodes[it.n2].box;
+            // SLOT ORDER (device_types.h): inner children first, sorted by box centre along the node's longest axis; then leaves
+            int sortAxis = 0;
+            for (int a = 1; a < 3; ++a) if (nb.hi[a] - nb.lo[a] > nb.hi[sortAxis] - nb.lo[sortAxis]) sortAxis = a;
+            std::stable_sort(kids, kids + nk, [&](uint32_t x, uint32_t y) {
+                const Node2& cx = b.nodes[x]; const Node2& cy = b.nodes[y];
+                if ((cx.count == 0) != (cy.count == 0)) return cx.count == 0;
+                if (cx.count) return false;                                  // leaves keep their collapse order
+                return cx.box.lo[sortAxis] + cx.box.hi[sortAxis] < cy.box.lo[sortAxis] + cy.box.hi[sortAxis];
+            });
             nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
             float scale[3]; uint8_t ebits[3];
             for (int a = 0; a < 3; ++a) {
@@ -300,6 +312,7 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                     for (uint32_t t = c.first; t < c.first + c.count; ++t) leafOrder.push_back(b.order[t]);
                 } else { nd.imask |= (uint8_t)(1u << k); work8.push_back({kids[k], nd.childBase + innerSlot, it.depth + 1}); ++innerSlot; }
             }
+            if (nd.imask & 1u) nd.meta[0] = (uint8_t)sortAxis;
             out.nodes8[it.n8] = nd;
         }
     } else {
@@ -338,6 +351,8 @@ const char* check_bvh(const HostBvh& bvh) {
     const size_t n = bvh.tris.size();
     if (bvh.nodes8.empty()) return "no root node";
     if (bvh.shade.size() != n) return "shading records != triangles";
+    if (bvh.nodes8.size() > kMaxBvhNodes) return "more nodes than a traversal stack entry can address (2^23)";
+    if (bvh.maxDepth > kMaxBvhDepth) return "tree deeper than the traversal stack (25 levels)";
     std::vector<uint8_t> seen(n, 0), seenFlat(n, 0);
     for (size_t i = 0; i < n; ++i) { if (bvh.tris[i].flatId >= n || seenFlat[bvh.tris[i].flatId]) return "flatId is not a permutation"; seenFlat[bvh.tris[i].flatId] = 1; }
     struct Item { uint32_t node; Box parent; bool hasParent; };
@@ -355,9 +370,10 @@ const char* check_bvh(const HostBvh& bvh) {
         const float org[3] = {nd.ox, nd.oy, nd.oz};
         const uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; const uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
         uint32_t innerSlot = 0;
+        if (nd.imask & (nd.imask + 1u)) return "inner children are not in the lowest slots";
+        if ((nd.imask & 1u) && nd.meta[0] > 2) return "sort axis out of range";
         for (int k = 0; k < 8; ++k) {
-            const bool inner = (nd.imask >> k) & 1u, leaf = nd.meta[k] != 0;
-            if (inner && leaf) return "child is both inner and leaf";
+            const bool inner = (nd.imask >> k) & 1u, leaf = !inner && nd.meta[k] != 0;
             if (!inner && !leaf) continue;
             Box bx;
             for (int a = 0; a < 3; ++a) { bx.lo[a] = org[a] + (float)qlo[a][k] * scale[a]; bx.hi[a] = org[a] + (float)qhi[a][k] * scale[a]; }

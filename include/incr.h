@@ -131,8 +131,8 @@ int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_str
  * kernels on the stream it is launched on; incr_profile_end synchronises the device and sums the intervals.
  */
 typedef struct incr_pathtrace_profile {
-    double generate_ms, extend_ms, shade_ms, shadow_ms, accumulate_ms;   /* summed over all recorded calls */
-    uint32_t launches[4];            /* extend, shade, shadow, accumulate launches that did work */
+    double generate_ms, extend_ms, shade_ms, shadow_gen_ms, shadow_ms, accumulate_ms;   /* summed over all recorded calls */
+    uint32_t launches[5];            /* extend, shade, shadow_gen, shadow, accumulate launches that did work */
     uint32_t frames;                 /* recorded incr_pathtrace calls */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);

@@ -1,0 +1,322 @@
+// trav_sim.cpp -- developer tool (not product, not oracle): CPU model of the GPU traversal state machines of
+// csrc/pt_traverse.h over the REAL 8-wide BVH that scene_build.cpp produces, to compare stack disciplines and child
+// orders by step counts and stack depths before spending GPU time.  Built by tools/trav_sim/run.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../incarnation-renderer_amd/csrc/scene_build.h"
+
+using namespace incr;
+
+namespace {
+struct Ray { float o[3], d[3], tmin, tmax; };
+struct NodeT { uint32_t hit; float tn[8]; };
+
+static void node_test(const BvhNode8& n, const Ray& r, const float invd[3], float tmax, NodeT& N) {
+    const uint8_t eb[3] = {n.ex, n.ey, n.ez};
+    const float org[3] = {n.ox, n.oy, n.oz};
+    const uint8_t* qlo[3] = {n.qlox, n.qloy, n.qloz}; const uint8_t* qhi[3] = {n.qhix, n.qhiy, n.qhiz};
+    float a[3], bn[3], bf[3]; bool pos[3];
+    for (int k = 0; k < 3; ++k) {
+        uint32_t bits = (uint32_t)eb[k] << 23; float sc; memcpy(&sc, &bits, 4);
+        a[k] = sc * invd[k];
+        const float b = (org[k] - r.o[k]) * invd[k];
+        const float m = 0.02f * fabsf(a[k]) + 2.4e-7f * fabsf(b);
+        bn[k] = b - m; bf[k] = b + m; pos[k] = a[k] >= 0.f;
+    }
+    N.hit = 0;
+    for (int c = 0; c < 8; ++c) {
+        float t0 = r.tmin, t1 = tmax;
+        for (int k = 0; k < 3; ++k) {
+            const float qn = (float)(pos[k] ? qlo[k][c] : qhi[k][c]), qf = (float)(pos[k] ? qhi[k][c] : qlo[k][c]);
+            const float tn = fmaf(qn, a[k], bn[k]), tf = fmaf(qf, a[k], bf[k]);
+            t0 = fmaxf(t0, tn); t1 = fminf(t1, tf);      // fmaxf/fminf ignore NaN like v_max/v_min
+        }
+        t1 *= 1.0000004f;
+        N.tn[c] = t0;
+        if (t0 <= t1) N.hit |= 1u << c;
+    }
+}
+static uint32_t tri_mask(const BvhNode8& n, uint32_t hit) {
+    uint32_t leaves = hit & ~n.imask, m = 0;
+    for (int k = 0; k < 8; ++k) if ((leaves >> k) & 1u) { const uint32_t meta = n.meta[k]; m |= ((1u << (meta >> 5)) - 1u) << (meta & 31u); }
+    return m;
+}
+static bool tri_isect(const TriIsect& T, const Ray& r, float tmax, float* t) {
+    const float e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z}, v0[3] = {T.v0x, T.v0y, T.v0z};
+    const float pv[3] = {r.d[1] * e2[2] - r.d[2] * e2[1], r.d[2] * e2[0] - r.d[0] * e2[2], r.d[0] * e2[1] - r.d[1] * e2[0]};
+    const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    if (!(det > 0.f)) return false;
+    const float inv = 1.f / det;
+    const float sv[3] = {r.o[0] - v0[0], r.o[1] - v0[1], r.o[2] - v0[2]};
+    const float u = (sv[0] * pv[0] + sv[1] * pv[1] + sv[2] * pv[2]) * inv;
+    if (!(u >= 0.f && u <= 1.f)) return false;
+    const float q[3] = {sv[1] * e1[2] - sv[2] * e1[1], sv[2] * e1[0] - sv[0] * e1[2], sv[0] * e1[1] - sv[1] * e1[0]};
+    const float v = (r.d[0] * q[0] + r.d[1] * q[1] + r.d[2] * q[2]) * inv;
+    if (!(v >= 0.f && u + v <= 1.f)) return false;
+    const float tt = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+    if (!(tt > r.tmin && tt < tmax)) return false;
+    *t = tt; return true;
+}
+static uint32_t child_index(const BvhNode8& n, uint32_t k) { return n.childBase + (uint32_t)__builtin_popcount(n.imask & ((1u << k) - 1u)); }
+
+struct Stats { double rays = 0, nodes = 0, tris = 0, pushes = 0, hits = 0; std::vector<uint32_t> depthHist = std::vector<uint32_t>(128, 0); };
+static void note(Stats& s, uint32_t nodes, uint32_t tris, uint32_t pushes, uint32_t maxDepth, bool hit) {
+    s.rays++; s.nodes += nodes; s.tris += tris; s.pushes += pushes; s.hits += hit; s.depthHist[std::min(maxDepth, 127u)]++;
+}
+
+struct Result { bool found; float t; uint32_t tri; };
+
+// ---- closest hit -------------------------------------------------------------------------------------
+// variant 0: per-child keyed entries pushed far-to-near (round 1).
+// variant 1: nearest child first; the other overlapped inner children as ONE group entry (childBase | mask) with the
+//            minimum entry distance of the group as its key; children of a popped group leave in slot order.
+// variant 2: as 1, slot order reversed when the ray points down the node's sort axis (stored in bits of the entry).
+// variant 3: groups only, no nearest-first (slot order with reversal).
+static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const Ray& r, int variant, Stats& S) {
+    const float invd[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]};
+    float best = r.tmax; bool found = false; uint32_t bestTri = 0, bestFlat = 0xffffffffu;
+    uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
+    struct E { uint32_t node; float key; uint32_t base, mask; bool rev; };
+    std::vector<E> st;
+    auto test_tris = [&](const BvhNode8& n, uint32_t tm) {
+        while (tm) {
+            const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris;
+            float t;
+            if (tri_isect(B.tris[ti], r, r.tmax, &t)) {
+                const uint32_t flat = B.tris[ti].flatId;
+                const bool better = found ? (t < best || (t == best && flat < bestFlat)) : (t < best);
+                if (better) { found = true; best = t; bestTri = ti; bestFlat = flat; }
+            }
+        }
+    };
+    uint32_t cur = 0; bool have = true;
+    for (;;) {
+        if (!have) {
+            bool got = false;
+            while (!st.empty()) {
+                E& e = st.back();
+                if (variant == 0) { const E x = e; st.pop_back(); if (x.key > best) continue; cur = x.node; got = true; break; }
+                if (e.key > best || e.mask == 0) { st.pop_back(); continue; }
+                const uint32_t k = e.rev ? 31u - (uint32_t)__builtin_clz(e.mask) : (uint32_t)__builtin_ctz(e.mask);
+                e.mask &= ~(1u << k);
+                cur = e.base + k;          // requires inner-first slot order (see reorder())
+                if (e.mask == 0) st.pop_back();
+                got = true; break;
+            }
+            if (!got) break;
+        }
+        have = false;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes;
+        NodeT N; node_test(n, r, invd, best, N);
+        test_tris(n, tri_mask(n, N.hit));
+        uint32_t inner = N.hit & n.imask;
+        if (!inner) continue;
+        if (variant == 0) {
+            uint32_t nearK = 8; float nearT = INFINITY;
+            for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = k; }
+            uint32_t rest = inner & ~(1u << nearK);
+            while (rest) {
+                float farT = -1.f; uint32_t farK = 0;
+                for (int k = 0; k < 8; ++k) if (((rest >> k) & 1u) && N.tn[k] > farT) { farT = N.tn[k]; farK = k; }
+                st.push_back({child_index(n, farK), farT, 0, 0, false}); ++pushes;
+                rest &= ~(1u << farK);
+            }
+            maxDepth = std::max<uint32_t>(maxDepth, st.size());
+            if (nearT <= best) { cur = child_index(n, nearK); have = true; }
+        } else {
+            const int ax = sortAxis[cur];
+            const bool rev = (variant >= 2) && r.d[ax] < 0.f;
+            uint32_t rest = inner;
+            if (variant != 3) {
+                uint32_t nearK = 8; float nearT = INFINITY;
+                for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = k; }
+                rest &= ~(1u << nearK);
+                if (nearT <= best) { cur = n.childBase + nearK; have = true; }
+            }
+            if (rest) {
+                float mk = INFINITY;
+                for (int k = 0; k < 8; ++k) if ((rest >> k) & 1u) mk = std::min(mk, N.tn[k]);
+                st.push_back({0, mk, n.childBase, rest, rev}); ++pushes;
+                maxDepth = std::max<uint32_t>(maxDepth, st.size());
+            }
+        }
+    }
+    note(S, nodes, tris, pushes, maxDepth, found);
+    return {found, best, bestTri};
+}
+
+// ---- any hit ----------------------------------------------------------------------------------------
+// variant 0: one entry per overlapped inner child (round 1).  variant 1: one group entry per node.
+static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const Ray& r, int variant, Stats& S) {
+    const float invd[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]};
+    uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
+    std::vector<uint32_t> st;        // variant 0: node indices; variant 1: base << 8 | mask
+    uint32_t cur = 0; bool have = true, occluded = false;
+    for (;;) {
+        if (!have) {
+            if (st.empty()) break;
+            if (variant == 0) { cur = st.back(); st.pop_back(); }
+            else {
+                uint32_t& e = st.back();
+                const bool rev = (e >> 31) & 1u;
+                const uint32_t m = e & 0xffu;
+                const uint32_t k = rev ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+                cur = ((e & 0x7fffffffu) >> 8) + k;
+                e &= ~(1u << k);
+                if ((e & 0xffu) == 0) st.pop_back();
+            }
+        }
+        have = false;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes;
+        NodeT N; node_test(n, r, invd, r.tmax, N);
+        uint32_t tm = tri_mask(n, N.hit);
+        while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) occluded = true; }
+        if (occluded) break;
+        uint32_t inner = N.hit & n.imask;
+        if (!inner) continue;
+        if (variant == 0) {
+            const uint32_t k0 = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u;
+            while (inner) { const uint32_t k = (uint32_t)__builtin_ctz(inner); inner &= inner - 1u; st.push_back(child_index(n, k)); ++pushes; }
+            cur = child_index(n, k0); have = true;
+        } else {
+            const bool rev = variant == 3 && r.d[sortAxis[cur]] < 0.f;
+            uint32_t k0 = rev ? 31u - (uint32_t)__builtin_clz(inner) : (uint32_t)__builtin_ctz(inner);
+            if (variant == 2) { float nt = INFINITY; for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nt) { nt = N.tn[k]; k0 = k; } }
+            inner &= ~(1u << k0);
+            if (inner) { st.push_back(n.childBase << 8 | inner | (rev ? 0x80000000u : 0u)); ++pushes; }
+            cur = n.childBase + k0; have = true;
+        }
+        maxDepth = std::max<uint32_t>(maxDepth, st.size());
+    }
+    note(S, nodes, tris, pushes, maxDepth, occluded);
+    return occluded;
+}
+
+// Slot order: inner children first (slot k of an inner child <=> node childBase + k), optionally sorted along the
+// node's longest axis by child-box centre (sortAxis[node] is recorded for the reversal trick).
+static void reorder(HostBvh& B, std::vector<uint8_t>& sortAxis, bool sortByAxis) {
+    sortAxis.assign(B.nodes8.size(), 0);
+    // process parents before children is not required: every swap stays inside one node's contiguous child block
+    for (size_t ni = 0; ni < B.nodes8.size(); ++ni) {
+        BvhNode8 n = B.nodes8[ni];
+        int ax = 0;
+        { const uint8_t e[3] = {n.ex, n.ey, n.ez}; if (e[1] > e[ax]) ax = 1; if (e[2] > e[ax]) ax = 2; }
+        sortAxis[ni] = (uint8_t)ax;
+        const uint8_t* qlo[3] = {n.qlox, n.qloy, n.qloz}; const uint8_t* qhi[3] = {n.qhix, n.qhiy, n.qhiz};
+        struct C { int slot; bool inner, leaf; int key; };
+        C c[8];
+        for (int k = 0; k < 8; ++k) c[k] = {k, (bool)((n.imask >> k) & 1u), n.meta[k] != 0, (int)qlo[ax][k] + (int)qhi[ax][k]};
+        std::stable_sort(c, c + 8, [&](const C& a, const C& b) {
+            const int ca = a.inner ? 0 : a.leaf ? 1 : 2, cb = b.inner ? 0 : b.leaf ? 1 : 2;
+            if (ca != cb) return ca < cb;
+            if (sortByAxis && a.key != b.key) return a.key < b.key;
+            return false;
+        });
+        BvhNode8 m = n; m.imask = 0;
+        std::vector<BvhNode8> kids;
+        for (int k = 0; k < 8; ++k) {
+            const int s = c[k].slot;
+            m.meta[k] = n.meta[s];
+            m.qlox[k] = n.qlox[s]; m.qloy[k] = n.qloy[s]; m.qloz[k] = n.qloz[s];
+            m.qhix[k] = n.qhix[s]; m.qhiy[k] = n.qhiy[s]; m.qhiz[k] = n.qhiz[s];
+            if (c[k].inner) { m.imask |= (uint8_t)(1u << k); kids.push_back(B.nodes8[child_index(n, (uint32_t)s)]); }
+        }
+        for (size_t k = 0; k < kids.size(); ++k) B.nodes8[n.childBase + k] = kids[k];
+        B.nodes8[ni] = m;
+    }
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static float rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (float)((rng_state >> 40) * (1.0 / 16777216.0)); }
+
+static void print_stats(const char* name, const Stats& s) {
+    uint64_t tot = 0; for (uint32_t h : s.depthHist) tot += h;
+    auto pct = [&](double p) { uint64_t acc = 0; for (size_t d = 0; d < s.depthHist.size(); ++d) { acc += s.depthHist[d]; if ((double)acc >= p * (double)tot) return (int)d; } return 127; };
+    int mx = 0; for (size_t d = 0; d < s.depthHist.size(); ++d) if (s.depthHist[d]) mx = (int)d;
+    printf("  %-26s rays %8.0f  nodes/ray %6.2f  tris/ray %6.2f  pushes/ray %6.2f  hit %.3f  depth p50 %d p90 %d p99 %d p99.9 %d max %d\n",
+           name, s.rays, s.nodes / s.rays, s.tris / s.rays, s.pushes / s.rays, s.hits / s.rays, pct(0.5), pct(0.9), pct(0.99), pct(0.999), mx);
+}
+} // namespace
+
+extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, right, up, look */, float tanHalfFovY, float aspect, int W, int H) {
+    HostScene hs; copy_scene_desc(*desc, hs);
+    const char* why = "";
+    if (!validate_scene(hs, &why)) { printf("scene rejected: %s\n", why); return 1; }
+    HostBvh base; build_world_bvh(hs, base);
+    printf("triangles %zu nodes8 %zu maxDepth %u\n", base.tris.size(), base.nodes8.size(), base.maxDepth);
+    // lights
+    struct PL { float p[3], range; };
+    std::vector<PL> pls; float sun[3] = {0.3f, 0.8f, 0.5f};
+    for (size_t i = 0; i < hs.lightIndices.size(); ++i) {
+        const incr_light& L = hs.globalLights[(size_t)hs.lightIndices[i]];
+        const float* m = hs.lightTransforms[(size_t)hs.lightIndices[i]].m;
+        if (L.type == INCR_LIGHT_POINT) pls.push_back({{m[12], m[13], m[14]}, L.range});
+        else if (L.type == INCR_LIGHT_DIRECTIONAL) { sun[0] = -m[8]; sun[1] = -m[9]; sun[2] = -m[10]; }
+    }
+    printf("point lights %zu\n", pls.size());
+    for (int cfg = 0; cfg < 3; ++cfg) {
+        HostBvh B = base; std::vector<uint8_t> sortAxis(B.nodes8.size(), 0);
+        if (cfg >= 1) reorder(B, sortAxis, cfg == 2);
+        if (const char* e = check_bvh(B)) { printf("cfg %d: BVH check failed: %s\n", cfg, e); return 2; }
+        printf("slot order %s\n", cfg == 0 ? "as built" : cfg == 1 ? "inner first" : "inner first + sorted along longest axis");
+        const int nv = cfg == 0 ? 1 : 4;
+        for (int v = 0; v < nv; ++v) {
+            const int variant = cfg == 0 ? 0 : v;
+            if (cfg == 1 && v >= 2) continue;            // reversal needs the sorted order
+            rng_state = 0x9E3779B97F4A7C15ull;
+            Stats sp, sb, ss, ss0;
+            double checksum = 0;
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+                const float sx = ((x + 0.5f) / W * 2.f - 1.f) * tanHalfFovY * aspect, sy = (1.f - (y + 0.5f) / H * 2.f) * tanHalfFovY;
+                Ray r; float l = 0;
+                for (int k = 0; k < 3; ++k) { r.o[k] = cam[k]; r.d[k] = cam[9 + k] + sx * cam[3 + k] + sy * cam[6 + k]; l += r.d[k] * r.d[k]; }
+                l = 1.f / sqrtf(l); for (int k = 0; k < 3; ++k) r.d[k] *= l;
+                r.tmin = 0.001f; r.tmax = 10000.f;
+                Stats* S = &sp;
+                for (int bounce = 0; bounce < 3; ++bounce) {
+                    const Result h = closest(B, sortAxis, r, variant, *S);
+                    S = &sb;
+                    if (!h.found) break;
+                    checksum += h.t;
+                    const TriIsect& T = B.tris[h.tri];
+                    float n[3] = {T.e1y * T.e2z - T.e1z * T.e2y, T.e1z * T.e2x - T.e1x * T.e2z, T.e1x * T.e2y - T.e1y * T.e2x};
+                    float nl = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    if (n[0] * r.d[0] + n[1] * r.d[1] + n[2] * r.d[2] > 0.f) nl = -nl;
+                    for (int k = 0; k < 3; ++k) n[k] *= nl;
+                    float p[3]; for (int k = 0; k < 3; ++k) p[k] = r.o[k] + h.t * r.d[k];
+                    // shadow rays: sun, in-range point lights, one cosine sky sample
+                    auto shadow = [&](const float d[3], float tmax) {
+                        Ray s; for (int k = 0; k < 3; ++k) { s.o[k] = p[k]; s.d[k] = d[k]; } s.tmin = 0.1f; s.tmax = tmax;
+                        anyhit(B, sortAxis, s, variant, ss);
+                    };
+                    if (sun[0] * n[0] + sun[1] * n[1] + sun[2] * n[2] > 0.f) shadow(sun, 1000.f);
+                    for (const PL& L : pls) {
+                        float d[3] = {L.p[0] - p[0], L.p[1] - p[1], L.p[2] - p[2]};
+                        const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                        if (dist >= L.range) continue;
+                        for (int k = 0; k < 3; ++k) d[k] /= dist;
+                        if (d[0] * n[0] + d[1] * n[1] + d[2] * n[2] > 0.f) shadow(d, 1000.f);     // the reference traces to TMax 1000
+                    }
+                    // cosine direction about n
+                    float t1[3] = {fabsf(n[0]) > 0.5f ? 0.f : 1.f, fabsf(n[0]) > 0.5f ? 1.f : 0.f, 0.f};
+                    float bx[3] = {n[1] * t1[2] - n[2] * t1[1], n[2] * t1[0] - n[0] * t1[2], n[0] * t1[1] - n[1] * t1[0]};
+                    float bl = 1.f / sqrtf(bx[0] * bx[0] + bx[1] * bx[1] + bx[2] * bx[2]); for (int k = 0; k < 3; ++k) bx[k] *= bl;
+                    float by[3] = {n[1] * bx[2] - n[2] * bx[1], n[2] * bx[0] - n[0] * bx[2], n[0] * bx[1] - n[1] * bx[0]};
+                    auto cosdir = [&](float out[3]) {
+                        const float u1 = rnd(), u2 = rnd(), rr = sqrtf(u1), ph = 6.2831853f * u2, z = sqrtf(fmaxf(0.f, 1.f - u1));
+                        for (int k = 0; k < 3; ++k) out[k] = rr * cosf(ph) * bx[k] + rr * sinf(ph) * by[k] + z * n[k];
+                    };
+                    float sd[3]; cosdir(sd); shadow(sd, 1000.f);
+                    float nd[3]; cosdir(nd);
+                    for (int k = 0; k < 3; ++k) { r.o[k] = p[k]; r.d[k] = nd[k]; }
+                }
+            }
+            printf(" variant %d (checksum %.6f)\n", variant, checksum);
+            print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
+        }
+    }
+    return 0;
+}

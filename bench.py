@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
+    ap.add_argument("--spp-per-gather", type=int, default=64,
+                    help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
+                         "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
     args = ap.parse_args()
 
     import torch
@@ -204,7 +207,7 @@ def main():
     full = torch.zeros((H, W), dtype=torch.int32, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev)
 
-    def step(sample_index, e0=None, e1=None):
+    def step(sample_index, e0=None, e1=None, gather=True):
         d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap)
         d.scene = scene.handle
         if args.no_direct_lighting:
@@ -216,7 +219,7 @@ def main():
         ctx.pathtrace(d, stream.cuda_stream)
         if e1 is not None:
             e1.record(stream)
-        if world > 1:   # the one exchange step of the path: gather disjoint framebuffer shards
+        if world > 1 and gather:   # the one exchange step of the path: gather disjoint framebuffer shards (final HDR of the accumulation)
             dist.all_gather_into_tensor(gathered, history)
             ctx.unshard(full.data_ptr(), gathered.data_ptr(), W, H, shard.row_block_height, world, 4, stream.cuda_stream)
 
@@ -234,8 +237,9 @@ def main():
     ctx.profile_begin()        # HIP events around every kernel of incr_pathtrace, recorded on the launch stream
     barrier()
     t0 = time.perf_counter()
+    spg = max(args.spp_per_gather, 1)
     for i in range(args.steps):
-        step(sample, ev[i][0], ev[i][1]); sample += 1
+        step(sample, ev[i][0], ev[i][1], gather=((i + 1) % spg == 0 or i == args.steps - 1)); sample += 1
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_end()
@@ -259,6 +263,8 @@ def main():
             raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs)
             raster_out["sky_ibl_precompute_ms"] = round(t_ibl * 1e3, 2)      # once per scene / sun change, not per frame
         except Exception as e:      # the headline (path trace) line must survive a failure of the secondary leg
+            if world > 1:           # ... but not at N > 1: the leg contains collectives, a rank that skipped them would hang the others
+                raise
             raster_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
@@ -288,7 +294,7 @@ def main():
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
                        "lights": len(packed.global_lights), "texture_size": args.texture_size,
-                       "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of R11G11B10F history",
+                       "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -17,6 +17,9 @@
 using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events);
+extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
+                                             incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
+                                             const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -69,6 +72,8 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
     const char* rc = getenv("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
     ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 8u;
+    const char* se = getenv("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
+    ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
     ctx->profiling = false; ctx->profFrames = 0;
     ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
@@ -131,16 +136,37 @@ int incr_stream_synchronize(incr_context* ctx, incr_stream stream) {
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------- scene
+// Light-grid arrays keep their allocation while the new lists fit (incr_update_bvh re-derives the grid on the stream).
+static int upload_light_grid(incr_scene* sc, hipStream_t stream) {
+    build_light_grid(sc->host, sc->bvh, sc->grid);
+    const size_t no = sc->grid.cellOffsets.size(), nl = sc->grid.cellLights.size();
+    if (no > sc->gridOffsetsCap || !sc->dGridOffsets) {
+        if (sc->dGridOffsets) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(sc->dGridOffsets)); sc->dGridOffsets = nullptr; }
+        sc->gridOffsetsCap = no + 64; HIP_TRY(hipMalloc((void**)&sc->dGridOffsets, sc->gridOffsetsCap * 4));
+    }
+    if (nl > sc->gridLightsCap || !sc->dGridLights) {
+        if (sc->dGridLights) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(sc->dGridLights)); sc->dGridLights = nullptr; }
+        sc->gridLightsCap = nl * 2 + 64; HIP_TRY(hipMalloc((void**)&sc->dGridLights, sc->gridLightsCap * 4));
+    }
+    HIP_TRY(hipMemcpyAsync(sc->dGridOffsets, sc->grid.cellOffsets.data(), no * 4, hipMemcpyHostToDevice, stream));
+    if (nl) HIP_TRY(hipMemcpyAsync(sc->dGridLights, sc->grid.cellLights.data(), nl * 4, hipMemcpyHostToDevice, stream));
+    return INCR_OK;
+}
+
 static int upload_bvh(incr_scene* sc) {
     int rc;
     if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes8.data(), sc->bvh.nodes8.size()))) return rc;
     if ((rc = upload_vec(&sc->dTris, sc->bvh.tris.data(), sc->bvh.tris.size()))) return rc;
     if ((rc = upload_vec(&sc->dShade, sc->bvh.shade.data(), sc->bvh.shade.size()))) return rc;
     if ((rc = upload_vec(&sc->dMeshLocalToWorld, (const float*)sc->bvh.meshLocalToWorld.data(), sc->bvh.meshLocalToWorld.size() * 16))) return rc;
-    build_light_grid(sc->host, sc->bvh, sc->grid);
-    if ((rc = upload_vec(&sc->dGridOffsets, sc->grid.cellOffsets.data(), sc->grid.cellOffsets.size()))) return rc;
-    if ((rc = upload_vec(&sc->dGridLights, sc->grid.cellLights.data(), sc->grid.cellLights.size()))) return rc;
-    return INCR_OK;
+    // inputs of the device-side update (bvh_update.hip)
+    if ((rc = upload_vec(&sc->dTriObj, sc->bvh.triObj.data(), sc->bvh.triObj.size()))) return rc;
+    if ((rc = upload_vec(&sc->dLevelNodes, sc->bvh.levelNodes.data(), sc->bvh.levelNodes.size()))) return rc;
+    std::vector<MeshInstanceInfo> info(sc->host.meshTransforms.size());
+    if ((rc = upload_vec(&sc->dMeshInfo, info.data(), info.size()))) return rc;
+    if (sc->dNodeBoxes) { (void)hipFree(sc->dNodeBoxes); sc->dNodeBoxes = nullptr; }
+    HIP_TRY(hipMalloc(&sc->dNodeBoxes, (sc->bvh.nodes8.size() + 1) * 32));
+    return upload_light_grid(sc, nullptr);
 }
 
 static void upload_grid_params(const incr_scene* sc, PtParams& P) {
@@ -178,7 +204,7 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
-                    sc->dGridOffsets, sc->dGridLights};
+                    sc->dGridOffsets, sc->dGridLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
     incr_raster_scene_free(sc);
@@ -252,9 +278,21 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
         for (size_t i = 0; i < nm; ++i) if (sc->host.meshVisibility[i] != mesh_visibility[i]) { sc->host.meshVisibility[i] = mesh_visibility[i]; dirty = true; }
     if (root_transform && memcmp(sc->host.rootTransform.m, root_transform->m, 64)) { sc->host.rootTransform = m44_from(*root_transform); dirty = true; }
     if (!dirty) return INCR_OK;          // the reference rebuilds its TLAS every frame; ours only when an input changed
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    build_world_bvh(sc->host, sc->bvh);
-    return upload_bvh(sc);
+    // Everything below is ordered on the caller's stream: small uploads (per-mesh matrices and instance ids, the light
+    // grid), then the re-transform and refit kernels of bvh_update.hip.  No host rebuild, no stream synchronise.
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<MeshInstanceInfo>& info = sc->meshInfo;      // scene-lifetime staging for the asynchronous upload
+    refresh_mesh_instances(sc->host, sc->bvh, info);
+    if (nm) {
+        HIP_TRY(hipMemcpyAsync(sc->dMeshLocalToWorld, sc->bvh.meshLocalToWorld.data(), nm * 64, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sc->dMeshInfo, info.data(), nm * sizeof(MeshInstanceInfo), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(incr_launch_bvh_update((uint32_t)sc->bvh.tris.size(), sc->dTriObj, sc->dMeshLocalToWorld, sc->dMeshInfo, sc->dTris, sc->dShade, sc->dNodes,
+                                   sc->dLevelNodes, sc->bvh.levelOffsets.data(), (uint32_t)sc->bvh.levelOffsets.size() - 1u, sc->dNodeBoxes, st));
+    int rc = upload_light_grid(sc, st);
+    if (!rc) rc = incr_raster_scene_update(sc, st);       // raster side: mesh visibility flags, decal transforms
+    return rc;
 }
 
 int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_dir[3]) {
@@ -382,7 +420,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
         ev = ctx->profEvents.data() + ctx->profFrames * kProfEvents;
         ctx->profFrames++;
     }
-    const uint32_t stackEntries = sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1;
+    const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
     HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, stackEntries, (hipStream_t)stream, ev));
     return INCR_OK;
 }
@@ -395,7 +433,7 @@ static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtP
     P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
     P.numGlobalLights = (uint32_t)sc->host.globalLights.size(); P.numSceneLights = (uint32_t)sc->host.lightIndices.size();
     P.lightCount = (int32_t)sc->host.globalLights.size();                     // path-tracing.inl:198 m_globalLightList.size()
-    P.numTris = (uint32_t)sc->bvh.tris.size();
+    P.numTris = (uint32_t)sc->bvh.tris.size(); P.numNodes = (uint32_t)sc->bvh.nodes8.size();
 }
 
 int incr_trace_rays(incr_context* ctx, const incr_scene* sc, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,

@@ -24,6 +24,7 @@ struct incr_context {
     hipDeviceProp_t props;
     float* srgbLut;           // 256 floats in HBM
     unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
+    uint32_t forceStackEntries; // INCR_WF_STACK_ENTRIES (tests): lower bound for the traversal kernels' stack size
     uint32_t raysPerPath;     // shadow-ray queue slots per path of the wavefront path tracer (8; INCR_WF_RAYS_PER_PATH)
     incr::WfBuffers wf;       // path-state workspace of the wavefront path tracer, grown on demand
     void* wfBlock;            // one allocation behind wf
@@ -50,6 +51,10 @@ struct incr_scene {
     uint64_t textureBytes = 0;
     incr::LightGrid grid;
     uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;
+    size_t gridOffsetsCap = 0, gridLightsCap = 0;
+    // device-side acceleration-structure update (bvh_update.hip)
+    incr::TriObject* dTriObj = nullptr; uint32_t* dLevelNodes = nullptr; incr::MeshInstanceInfo* dMeshInfo = nullptr; void* dNodeBoxes = nullptr;
+    std::vector<incr::MeshInstanceInfo> meshInfo;
     // raster path (meshlets resolved through the accessor indirection once, at scene creation)
     incr_gpu_meshlet* dMeshlets = nullptr; uint32_t* dPackedTris = nullptr; uint32_t* dMeshVisibility = nullptr;
     float4* dMvPos = nullptr; float2* dMvUv = nullptr; float4* dMvNormal = nullptr; float4* dMvTangent = nullptr;
@@ -82,3 +87,5 @@ void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, incr:
 // raster_api.hip: bake + upload the per-meshlet-vertex attribute arrays; free them
 int  incr_raster_scene_upload(incr_scene* sc);
 void incr_raster_scene_free(incr_scene* sc);
+// re-upload what the raster passes derive from mesh visibility / the root transform (stream-ordered)
+int  incr_raster_scene_update(incr_scene* sc, hipStream_t stream);

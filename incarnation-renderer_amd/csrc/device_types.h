@@ -45,6 +45,15 @@ struct alignas(16) TriIsect {
 };
 static constexpr uint32_t kTriOpaque = 1u, kTriMirrored = 2u;
 
+// Object-space source of a TriIsect record, leaf order, 48 B: what incr_update_bvh re-transforms on the device when a mesh
+// transform, the root transform or a visibility flag changes (bvh_update.hip).
+struct alignas(16) TriObject {
+    float p0x, p0y, p0z, p1x;
+    float p1y, p1z, p2x, p2y;
+    float p2z; uint32_t mesh; uint32_t flags; uint32_t flatId;      // flags: kTriOpaque only (mirroring is a property of the transform)
+};
+static_assert(sizeof(TriObject) == 48, "tri source record");
+
 // Shading record, leaf order, 128 B: object-space vertex attributes exactly as the accessor fetchers return them.
 struct alignas(128) TriShade {
     float n[3][3];          // GetFloat3(normalAccessor)   (0 when accessor == -1)

@@ -46,30 +46,48 @@ static constexpr int kWfBlock = 256;
 #define INCR_SHADE_WAVES 3
 #endif
 #ifndef INCR_EXTEND_WAVES
-#define INCR_EXTEND_WAVES 8     // waves per SIMD of the closest-hit kernel with the 8-entry stack (LDS allows 8)
+#define INCR_EXTEND_WAVES 7     // waves per SIMD of the closest-hit kernel with the 8-entry stack: at 8 (64 VGPRs) it spills 28 B inside the step; 12.3 / 11.8 / 12.0 ms per 4K frame at 8 / 7 / 6
 #endif
 #ifndef INCR_ACCUM_WAVES
 #define INCR_ACCUM_WAVES 4
 #endif
 // LDS stack entries per lane in the traversal kernels: a template parameter, the launcher picks the smallest of
-// 8 / 16 / 24 that holds the scene's tree (one entry per level, pt_traverse.h) -- Sponza-stat and Bistro-scale take 8.
-template <int N> using WfStack = LaneStackT<N, kWfBlock>;              // any-hit (shadow) traversal
-template <int N> using WfStackK = LaneStackT<N, kWfBlock, true>;       // closest-hit traversal: keyed, drops groups beyond the best hit
+// 8 / 12 / 16 / 24 that holds the scene's tree (one entry per level, pt_traverse.h): Sponza-stat (9 levels) takes 8,
+// Bistro-scale (10 levels) 12.
+template <int N> using WfStack = LaneStackT<N, kWfBlock, false, true>;        // any-hit (shadow) traversal
+template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         // closest-hit traversal: keyed, drops groups beyond the best hit
+// Hottest nodes kept in LDS per workgroup (80 B each), sized so that stack + copy still give the kernels' workgroups per CU
+// out of 160 KB: extend 7 / 6 / 4 / 3 workgroups, shadow 8 / 8 / 8 / 6 at N = 8 / 12 / 16 / 24.
+template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? 80u : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u));
+                                   static constexpr uint32_t kShadow = N <= 8 ? 144u : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u)); };
+DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) {
+    const uint32_t count = min(capacity, P.numNodes);
+    for (uint32_t i = threadIdx.x; i < count * 5u; i += kWfBlock) s_top[i] = ((const float4*)P.nodes)[i];
+    __syncthreads();
+    return count;
+}
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u;
-// Items a wave takes from the device-wide cursor at a time.  Measured at 4K Sponza-stat, ms per frame for chunks of
-// 32 / 64 / 96 / 128 / 160 / 256 / 512 / 1024 items: 44.9 / 44.5 / 45.5 / 46.3 / 47.7 / 51.4 / 55.0 / 58.6 -- with 8192
-// persistent waves a 512-item chunk is a quarter of a wave's whole share of a 4K list, and the kernel ends on the waves
-// that drew a late one; one wave's worth per grab keeps every SIMD busy to the end (130 k cursor atomics per launch,
-// ~1.5 ms of one L2 channel's time spread over the kernel, still cost less than the tail they remove).
-#ifndef INCR_WF_CHUNK
-#define INCR_WF_CHUNK 64
+// Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
+// Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
+// items: 44.9 / 44.5 / 45.5 / 46.3 / 51.4 / 55.0 / 58.6 -- with 8192 persistent waves a 512-item chunk is a quarter of a
+// wave's whole share of a 4K list and the kernel ends on the waves that drew a late one.  Round 2, per kernel
+// (gpurun_out/ab_r2_1.log): extend 12.3 ms at 64 items / 12 lanes, 13.1 at 128 items, 12.6 at 32 lanes; shadow, whose
+// refill is two coalesced loads, 12.2 ms at 64 / 12, 11.8 at 32 lanes, 11.5 at 128 items.
+#ifndef INCR_EXTEND_CHUNK
+#define INCR_EXTEND_CHUNK 64
 #endif
-static constexpr uint32_t kChunk = INCR_WF_CHUNK;
-#ifndef INCR_WF_REFILL
-#define INCR_WF_REFILL 12
+#ifndef INCR_SHADOW_CHUNK
+#define INCR_SHADOW_CHUNK 128
 #endif
-static constexpr uint32_t kRefillThreshold = INCR_WF_REFILL;   // refill when at least this many lanes are idle
+#ifndef INCR_EXTEND_REFILL
+#define INCR_EXTEND_REFILL 16
+#endif
+#ifndef INCR_SHADOW_REFILL
+#define INCR_SHADOW_REFILL 32
+#endif
+static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
+static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;
 static constexpr uint32_t kMissTri = 0xffffffffu;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
 static constexpr int kCursorBase = 16, kRayCountBase = 32;
@@ -127,7 +145,7 @@ DI uint32_t light_cell(const PtParams& P, f3 p) {
 
 // Wave-level work distribution: hands the next items of the wave's chunk to idle lanes (consecutive indices in
 // lane order), taking a new chunk from the device-wide cursor when the current one is used up.
-struct WaveChunk {
+template <uint32_t kChunk> struct WaveChunk {
     uint32_t next, end;     // wave-uniform
     bool exhausted;
     // A wave's FIRST chunk is static -- chunk number = its index in the grid -- and the launcher starts the cursors behind
@@ -193,21 +211,23 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 16 ? 5 : 3)) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 12 ? 6 : (N <= 16 ? 4 : 3))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float s_keys[N * kWfBlock];
+    __shared__ float4 s_top[TopNodes<N>::kExtend * 5];
     WfStackK<N> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
+    st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kExtend));
     const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
-    WaveChunk chunk; chunk.init_static(total);
+    WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
     bool active = false; uint32_t pid = 0;
     TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     uint32_t rays = 0;
     for (;;) {
         const unsigned long long act = __ballot(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
-        if (!chunk.exhausted && (idle >= kRefillThreshold || act == 0ull)) {
+        if (!chunk.exhausted && (idle >= kExtendRefill || act == 0ull)) {
             const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) {
                 pid = live[item];
@@ -487,17 +507,19 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
 // its request bit (one fire-and-forget atomic; unoccluded rays -- the majority of the light rays -- write nothing).
 template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
+    __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
+    st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kShadow));
     const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
-    WaveChunk chunk; chunk.init_static(total);
+    WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false;
     uint32_t pid = 0, slot = 0;
     TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     for (;;) {
         const unsigned long long act = __ballot(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
-        if (!chunk.exhausted && (idle >= kRefillThreshold || act == 0ull)) {
+        if (!chunk.exhausted && (idle >= kShadowRefill || act == 0ull)) {
             const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) {
                 const float4 a = B.rayQ[(size_t)item * 2], b = B.rayQ[(size_t)item * 2 + 1];
@@ -596,14 +618,14 @@ template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, 
 
 // `events` (optional, 22 entries): recorded on `stream` before the first kernel and after every kernel
 // (generate, then extend / shade / shadow_gen / shadow / accumulate per bounce) so that the host can attribute time per kernel.
-// `stackEntries`: LDS stack entries per lane the scene's tree needs (maxDepth - 1); 8, 16 or 24 are instantiated.
+// `stackEntries`: LDS stack entries per lane the scene's tree needs (maxDepth - 1); 8, 12, 16 and 24 are instantiated.
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;
     const uint32_t total = tilesX * tilesY * 64u;
     if (total == 0) return hipSuccess;
     if (stackEntries > 24u) return hipErrorInvalidValue;
-    const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 16u ? 16 : 24);
+    const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer.
     // Capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms,
@@ -613,21 +635,21 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
 #endif
     const uint32_t blocksAll = std::max(1u, (uint32_t)std::min<uint64_t>((uint64_t)cus * INCR_WF_STREAM_BLOCKS_PER_CU, (total + kWfBlock - 1) / kWfBlock));
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 16 ? 5u : 3u), shadowPerCU = sv <= 16 ? 8u : 6u;
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv <= 16 ? 8u : 6u;
     const uint32_t blocksExtend = std::max(1u, std::min(cus * extendPerCU, (total + kWfBlock - 1) / kWfBlock));
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
-    hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, stream, b->counters, blocksExtend * (kWfBlock / 64) * kChunk, blocksShadow * (kWfBlock / 64) * kChunk);
+    hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, stream, b->counters, blocksExtend * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
     int ev = 0;
     auto mark =[&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
     mark();
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX); mark();
     for (int bounce = 0; bounce < 4; ++bounce) {
-        if (sv == 8) launch_extend<8>(blocksExtend, stream, *p, *b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend, stream, *p, *b, bounce); else launch_extend<24>(blocksExtend, stream, *p, *b, bounce);
+        if (sv == 8) launch_extend<8>(blocksExtend, stream, *p, *b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend, stream, *p, *b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend, stream, *p, *b, bounce); else launch_extend<24>(blocksExtend, stream, *p, *b, bounce);
         mark();
         hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
         if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
         hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
-        if (sv == 8) launch_shadow<8>(blocksShadow, stream, *p, *b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, stream, *p, *b, bounce); else launch_shadow<24>(blocksShadow, stream, *p, *b, bounce);
+        if (sv == 8) launch_shadow<8>(blocksShadow, stream, *p, *b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, stream, *p, *b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, stream, *p, *b, bounce); else launch_shadow<24>(blocksShadow, stream, *p, *b, bounce);
         mark();
         hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
     }

@@ -22,7 +22,7 @@ struct PtParams {
     const float* __restrict__ lightTransforms;     // 16 floats per scene light
     uint32_t numGlobalLights, numSceneLights;
     int32_t lightCount;
-    uint32_t numTris;
+    uint32_t numTris, numNodes;
     float projectionToWorld[16];
     float cameraMatrix[16];
     uint32_t W, H, numPixels, sampleIdx, sqrtSampleCount;

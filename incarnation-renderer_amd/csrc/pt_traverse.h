@@ -27,10 +27,15 @@ struct Hit { float t, u, v; uint32_t tri; };
 // launch; per node the depth is p99 5, max 7 (tools/trav_sim).  The host picks N from incr_scene's maxDepth.
 // KEYED stacks also keep, per entry, the smallest box-entry distance of the group: closest-hit traversal drops a
 // whole group that lies beyond the current best hit without fetching any of its nodes.
-template <int NLDS, int STRIDE, bool KEYED = false>
+typedef float incr_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const incr_v4f* LdsNodes;      // native vector type: one ds_read_b128 per element
+template <int NLDS, int STRIDE, bool KEYED = false, bool TOP = false>
 struct LaneStackT {
     static constexpr bool kKeyed = KEYED;
+    static constexpr bool kTop = TOP;          // the workgroup keeps the first `topCount` nodes (the hottest, scene_build.cpp NODE ORDER) in LDS
     static constexpr int kCap = NLDS;
+    LdsNodes topNodes; uint32_t topCount;
+    DI void bind_top(const float4* ldsNodes, uint32_t count) { topNodes = (LdsNodes)ldsNodes; topCount = count; }
     // explicit LDS address space: through a generic pointer the pushes/pops compile to flat_* instructions
     __attribute__((address_space(3))) uint32_t* lds;      // &stack[0][tid]
     __attribute__((address_space(3))) float* ldsKey;      // &keys[0][tid]   (KEYED only)
@@ -52,6 +57,8 @@ struct LaneStackT {
 template <int N>
 struct PrivStackT {
     static constexpr bool kKeyed = false;
+    static constexpr bool kTop = false;
+    LdsNodes topNodes; uint32_t topCount;
     uint32_t e[N]; int sp;
     DI void reset() { sp = 0; }
     DI void push(uint32_t v, float = 0.f) { if (sp < N) e[sp++] = v; }
@@ -167,12 +174,26 @@ DI uint32_t node8_tri_mask(const Node8& N) {
 }
 
 // One fetch per step: 80 bytes at the node, or 48 at the pending triangle (the last two dwordx4 are only issued by lanes on a
-// node step: every dwordx4 of a divergent gather is its own vector-L1 look-up, the unit this traversal is bound by).
+// node step).  Measured on MI355X (tools/microbench/gather_lanes.hip): a divergent dwordx4 gather costs the vector L1 one
+// slot per ACTIVE lane plus a fixed ~22 lanes' worth per wave instruction -- 137 G 80-B records/s chip-wide with all lanes
+// on, the unit this traversal is bound by (idle lanes are nearly free, instructions are not); the same gather out of LDS
+// runs at 461 G records/s.  So the hottest nodes (index < topCount; ~40 % of all node visits for the top three levels of
+// Sponza-stat) are served from a per-workgroup LDS copy when the stack type says so.
 struct Fetch5 { float4 a, b, c, d, e; };
-DI Fetch5 fetch_step(const PtParams& P, uint32_t cur, uint32_t triBase, uint32_t triMask) {
+template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32_t cur, uint32_t triBase, uint32_t triMask) {
+    Fetch5 f;
+    if constexpr (ST::kTop) {
+        if (!triMask && cur < st.topCount) {
+            LdsNodes q = st.topNodes + cur * 5u;
+            const incr_v4f a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+            f.a = make_float4(a.x, a.y, a.z, a.w); f.b = make_float4(b.x, b.y, b.z, b.w); f.c = make_float4(c.x, c.y, c.z, c.w);
+            f.d = make_float4(d.x, d.y, d.z, d.w); f.e = make_float4(e.x, e.y, e.z, e.w);
+            return f;
+        }
+    }
     const float4* __restrict__ p = triMask ? (const float4*)(P.tris + triBase + (uint32_t)__builtin_ctz(triMask))
                                            : (const float4*)P.nodes + (size_t)cur * 5;
-    Fetch5 f; f.a = p[0]; f.b = p[1]; f.c = p[2];
+    f.a = p[0]; f.b = p[1]; f.c = p[2];
     if (!triMask) { f.d = p[3]; f.e = p[4]; } else { f.d = f.c; f.e = f.c; }
     return f;
 }
@@ -197,7 +218,7 @@ DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
 }
 // returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
-    const Fetch5 f = fetch_step(P, T.cur, T.triBase, T.triMask);
+    const Fetch5 f = fetch_step(P, st, T.cur, T.triBase, T.triMask);
     if (T.triMask) {
         // ---- one pending triangle ----
         const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask);
@@ -281,7 +302,7 @@ DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.triBase = 0; T.triMask = 0; T.occluded = false; T.haveCur = false;
 }
 template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
-    const Fetch5 f = fetch_step(P, T.cur, T.triBase, T.triMask);
+    const Fetch5 f = fetch_step(P, st, T.cur, T.triBase, T.triMask);
     if (T.triMask) {
         T.triMask &= T.triMask - 1u;
         float t, u, v; uint32_t flat, flags;

@@ -182,6 +182,19 @@ static int bake_primitives(const HostScene& h, const std::vector<incr_gpu_primit
     }
     return INCR_OK;
 }
+int incr_raster_scene_update(incr_scene* sc, hipStream_t stream) {
+    const HostScene& h = sc->host;
+    // batch culling and the forward-pass flags read dMeshVisibility; decals were baked with meshTransform * rootTransform
+    if (!h.meshVisibility.empty()) HIP_TRY(hipMemcpyAsync(sc->dMeshVisibility, h.meshVisibility.data(), h.meshVisibility.size() * 4, hipMemcpyHostToDevice, stream));
+    if (sc->numDecals) {
+        std::vector<float> l2w((size_t)sc->numDecals * 16);
+        for (size_t i = 0; i < sc->numDecals; ++i) { const M44 m = m44_mul(h.decalTransforms[i], h.rootTransform); memcpy(&l2w[i * 16], m.m, 64); }
+        HIP_TRY(hipMemcpyAsync(sc->dDecalLocalToWorld, l2w.data(), l2w.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));      // l2w is a stack-lifetime staging copy (decals are rare; the BVH path above never waits)
+    }
+    return INCR_OK;
+}
+
 void incr_raster_scene_free(incr_scene* sc) {
     void* ptrs[] = {sc->dMeshlets, sc->dPackedTris, sc->dMeshVisibility, sc->dMvPos, sc->dMvUv, sc->dMvNormal, sc->dMvTangent,
                     sc->dPrimDraws, sc->dPrimIndices, sc->dPvPos, sc->dPvUv, sc->dPvNormal, sc->dPvTangent, sc->dChunkPrim, sc->dChunkFirstTri,

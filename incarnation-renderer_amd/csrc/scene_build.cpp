@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
+#include <limits>
 #include <numeric>
 
 namespace incr {
@@ -187,15 +188,44 @@ struct Builder {
 };
 } // namespace
 
-void build_world_bvh(const HostScene& s, HostBvh& out) {
-    // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform)
-    struct Flat { V3 v0, e1, e2; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; };
-    std::vector<Flat> flat;
-    out.meshLocalToWorld.resize(s.meshTransforms.size());
-    for (size_t m = 0; m < s.meshTransforms.size(); ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+void refresh_mesh_instances(const HostScene& s, HostBvh& out, std::vector<MeshInstanceInfo>& info) {
+    const size_t nm = s.meshTransforms.size();
+    out.meshLocalToWorld.resize(nm); info.resize(nm);
     uint32_t inst = 0;
-    for (uint32_t mesh = 0; mesh < (uint32_t)s.meshTransforms.size(); ++mesh) {
-        if (!s.meshVisibility[mesh]) continue;
+    Box world; box_reset(world);
+    for (size_t m = 0; m < nm; ++m) {
+        out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+        const bool visible = s.meshVisibility[m] != 0;
+        info[m].instance = visible ? inst++ : 0xffffffffu;                 // update-tlas.inl:20-48: one instance per VISIBLE mesh
+        info[m].mirrored = m44_det3(out.meshLocalToWorld[m]) < 0.f ? 1u : 0u;
+        if (visible && out.meshObjBox.size() == nm * 6 && out.meshObjBox[m * 6] <= out.meshObjBox[m * 6 + 3]) {
+            const float* b = &out.meshObjBox[m * 6];
+            for (int c = 0; c < 8; ++c) {
+                const V3 p = m44_transform_point(v3(b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]), out.meshLocalToWorld[m]);
+                const float q[3] = {p.x, p.y, p.z};
+                for (int a = 0; a < 3; ++a) if (q[a] == q[a]) { world.lo[a] = std::min(world.lo[a], q[a]); world.hi[a] = std::max(world.hi[a], q[a]); }
+            }
+        }
+    }
+    out.numInstances = inst;
+    const bool any = world.lo[0] <= world.hi[0];
+    for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? world.lo[a] : 0.f; out.sceneHi[a] = any ? world.hi[a] : 0.f; }
+}
+
+void build_world_bvh(const HostScene& s, HostBvh& out) {
+    // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform).
+    //    Hidden meshes stay in the tree as unhittable (NaN) triangles: incr_update_bvh can then show / hide a mesh by
+    //    re-transforming and refitting on the device, without a rebuild; ids count visible meshes only, as DXR's do.
+    struct Flat { V3 v0, e1, e2; V3 obj[3]; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; bool hidden; };
+    std::vector<Flat> flat;
+    const size_t numMeshes = s.meshTransforms.size();
+    out.meshObjBox.assign(numMeshes * 6, 0.f);
+    for (size_t m = 0; m < numMeshes; ++m) for (int a = 0; a < 3; ++a) { out.meshObjBox[m * 6 + a] = FLT_MAX; out.meshObjBox[m * 6 + 3 + a] = -FLT_MAX; }
+    out.meshLocalToWorld.resize(numMeshes);
+    for (size_t m = 0; m < numMeshes; ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+    uint32_t inst = 0;
+    for (uint32_t mesh = 0; mesh < (uint32_t)numMeshes; ++mesh) {
+        const bool hidden = !s.meshVisibility[mesh];
         const M44& l2w = out.meshLocalToWorld[mesh];
         const bool mirrored = m44_det3(l2w) < 0.f;
         for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
@@ -208,16 +238,24 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                 Flat f;
                 fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
                 V3 v[3];
-                for (int k = 0; k < 3; ++k) { float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos); v[k] = m44_transform_point(v3(pos[0], pos[1], pos[2]), l2w); }
+                for (int k = 0; k < 3; ++k) {
+                    float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos);
+                    f.obj[k] = v3(pos[0], pos[1], pos[2]);
+                    v[k] = m44_transform_point(f.obj[k], l2w);
+                    for (int a = 0; a < 3; ++a) if (pos[a] == pos[a]) {
+                        out.meshObjBox[mesh * 6 + a] = std::min(out.meshObjBox[mesh * 6 + a], pos[a]);
+                        out.meshObjBox[mesh * 6 + 3 + a] = std::max(out.meshObjBox[mesh * 6 + 3 + a], pos[a]);
+                    }
+                }
                 f.v0 = v[0];
                 f.e1 = (mirrored ? v[2] : v[1]) - v[0];
                 f.e2 = (mirrored ? v[1] : v[2]) - v[0];
-                f.inst = inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg;
+                f.inst = hidden ? 0xffffffffu : inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg; f.hidden = hidden;
                 f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
                 flat.push_back(f);
             }
         }
-        ++inst;
+        if (!hidden) ++inst;
     }
     out.numInstances = inst;
 
@@ -235,15 +273,16 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
         for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
         cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
-        box_grow(scene, tb[i]);
+        if (!f.hidden) box_grow(scene, tb[i]);
     }
-    for (int a = 0; a < 3; ++a) { out.sceneLo[a] = n ? scene.lo[a] : 0.f; out.sceneHi[a] = n ? scene.hi[a] : 0.f; }
+    { const bool any = n && scene.lo[0] <= scene.hi[0]; for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? scene.lo[a] : 0.f; out.sceneHi[a] = any ? scene.hi[a] : 0.f; } }
     Builder b(tb, cen);
     if (n) b.build(0, (uint32_t)n);
 
     // 3. collapse BVH2 -> 8-wide quantised nodes (greedy: open the inner child with the largest surface area until the
     //    node has 8 children) and lay the triangles out in NODE order: the leaf children of one node8 own one contiguous run.
     out.nodes8.clear(); out.maxDepth = 0;
+    std::vector<uint32_t> nodeDepth;
     std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
     if (n) {
         struct Item8 { uint32_t n2, n8, depth; };
@@ -253,6 +292,8 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         while (!work8.empty()) {
             const Item8 it = work8.back(); work8.pop_back();
             out.maxDepth = std::max(out.maxDepth, it.depth);
+            if (nodeDepth.size() < out.nodes8.size()) nodeDepth.resize(out.nodes8.size(), 0u);
+            nodeDepth[it.n8] = it.depth;
             uint32_t kids[8]; int nk = 0;
             const Node2& root2 = b.nodes[it.n2];
             if (root2.count) kids[nk++] = it.n2;                    // degenerate: the whole tree is one leaf
@@ -322,15 +363,66 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         out.nodes8.push_back(e);
     }
 
+    // NODE ORDER: best-first by box area -- the root, then repeatedly the children block of the largest node placed so far.
+    // Index order then approximates visit frequency (the top three levels take ~40 % of all node visits on Sponza-stat,
+    // tools/trav_sim), so "index < K" names the K hottest nodes: the traversal kernels keep those in LDS (pt_traverse.h).
+    nodeDepth.resize(out.nodes8.size(), 1u);
+    if (n) {
+        const size_t nn = out.nodes8.size();
+        std::vector<float> area(nn, 0.f);
+        for (size_t i = 0; i < nn; ++i) {
+            const BvhNode8& nd = out.nodes8[i];
+            const uint8_t eb[3] = {nd.ex, nd.ey, nd.ez}; float ext[3];
+            for (int a = 0; a < 3; ++a) { uint32_t bits = (uint32_t)eb[a] << 23; float sc; memcpy(&sc, &bits, 4); ext[a] = 255.f * sc; }
+            area[i] = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];          // area of the node's quantisation frame: monotone down the tree
+        }
+        std::vector<uint32_t> newIndex(nn, 0u);
+        std::vector<std::pair<float, uint32_t>> heap;                                // (area, old index), max-heap
+        uint32_t next = 1; heap.push_back({area[0], 0u});
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end()); const uint32_t o = heap.back().second; heap.pop_back();
+            const BvhNode8& nd = out.nodes8[o];
+            for (uint32_t k = 0; k < 8; ++k) if ((nd.imask >> k) & 1u) {
+                const uint32_t c = nd.childBase + k;
+                newIndex[c] = next++;
+                heap.push_back({area[c], c}); std::push_heap(heap.begin(), heap.end());
+            }
+        }
+        std::vector<BvhNode8> reordered(nn); std::vector<uint32_t> depth2(nn, 1u);
+        for (size_t i = 0; i < nn; ++i) {
+            BvhNode8 nd = out.nodes8[i];
+            if (nd.imask) nd.childBase = newIndex[nd.childBase];
+            reordered[newIndex[i]] = nd; depth2[newIndex[i]] = nodeDepth[i];
+        }
+        out.nodes8.swap(reordered); nodeDepth.swap(depth2);
+    }
+    // node lists by depth (the device refit walks them deepest level first)
+    if (!n) { out.maxDepth = 1; nodeDepth.assign(1, 1u); }
+    out.levelOffsets.assign(out.maxDepth + 1, 0u);
+    for (uint32_t d : nodeDepth) out.levelOffsets[d]++;                     // counts at [depth]
+    for (uint32_t d = 1; d <= out.maxDepth; ++d) out.levelOffsets[d] += out.levelOffsets[d - 1];
+    out.levelNodes.resize(out.nodes8.size());
+    { std::vector<uint32_t> fill(out.levelOffsets.begin(), out.levelOffsets.end() - 1);
+      for (uint32_t i = 0; i < (uint32_t)nodeDepth.size(); ++i) out.levelNodes[fill[nodeDepth[i] - 1]++] = i; }
+
     // 4. emit triangles + shading records in leaf order
-    out.tris.resize(n); out.shade.resize(n);
+    out.tris.resize(n); out.shade.resize(n); out.triObj.resize(n);
     for (size_t i = 0; i < n; ++i) {
         const Flat& f = flat[leafOrder[i]];
+        TriObject& ob = out.triObj[i];
+        ob.p0x = f.obj[0].x; ob.p0y = f.obj[0].y; ob.p0z = f.obj[0].z; ob.p1x = f.obj[1].x; ob.p1y = f.obj[1].y; ob.p1z = f.obj[1].z;
+        ob.p2x = f.obj[2].x; ob.p2y = f.obj[2].y; ob.p2z = f.obj[2].z; ob.mesh = f.mesh; ob.flags = f.flags & kTriOpaque; ob.flatId = leafOrder[i];
         TriIsect& t = out.tris[i];
+        if (f.hidden) {        // unhittable: every comparison of the triangle test fails on NaN
+            const float qnan = std::numeric_limits<float>::quiet_NaN();
+            t.v0x = t.v0y = t.v0z = t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = qnan;
+            t.flatId = leafOrder[i]; t.flags = f.flags; t.pad = 0;
+        } else {
         t.v0x = f.v0.x; t.v0y = f.v0.y; t.v0z = f.v0.z;
         t.e1x = f.e1.x; t.e1y = f.e1.y; t.e1z = f.e1.z;
         t.e2x = f.e2.x; t.e2y = f.e2.y; t.e2z = f.e2.z;
         t.flatId = leafOrder[i]; t.flags = f.flags; t.pad = 0;
+        }
         TriShade& sh = out.shade[i];
         const incr_gpu_primitive& prim = s.primitives[f.primGlobal];
         AccessorRef na, ta, ua;

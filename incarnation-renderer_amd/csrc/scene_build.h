@@ -39,7 +39,17 @@ struct HostBvh {
     uint32_t numInstances = 0;
     uint32_t maxDepth = 0;
     float sceneLo[3], sceneHi[3];
+    // ---- inputs of the device-side update (bvh_update.hip: re-transform + refit, UpdateTLASPass stand-in) ----
+    std::vector<TriObject> triObj;      // leaf order: object-space vertices + mesh / flags / flattened id
+    std::vector<uint32_t> levelNodes;   // node indices sorted by depth (root first)
+    std::vector<uint32_t> levelOffsets; // levelNodes[levelOffsets[d] .. levelOffsets[d + 1]) = the nodes of depth d + 1
+    std::vector<float> meshObjBox;      // 6 floats per mesh: object-space bounds of its positions (lo.xyz, hi.xyz); lo > hi when empty
 };
+
+// per-mesh state the update kernels read: DXR instance index (0xffffffff = hidden) and the mirror flag of its transform
+struct MeshInstanceInfo { uint32_t instance, mirrored; };
+// recompute meshLocalToWorld, the instance numbering and a conservative world box from the host scene's current transforms / visibility
+void refresh_mesh_instances(const HostScene& s, HostBvh& bvh, std::vector<MeshInstanceInfo>& info);
 
 // World-space light grid for the path tracer's next-event estimation.  A cell lists (ascending loop index) every
 // light of the chsMain light loop (pathtracing.hlsl:230-236) that can contribute a NON-ZERO radiance somewhere in

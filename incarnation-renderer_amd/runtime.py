@@ -224,6 +224,14 @@ class Scene:
             for b in bufs:
                 ctx.free(b)
 
+    def update_bvh(self, mesh_transforms=None, mesh_visibility=None, root_transform=None, stream=None):
+        """incr_update_bvh (UpdateTLASPass): new per-mesh transforms (list of 4x4), visibility flags and / or root transform."""
+        from . import scene_io as sio
+        mt = (A.Matrix * len(mesh_transforms))(*[sio.to_matrix(m) for m in mesh_transforms]) if mesh_transforms is not None else None
+        mv = (C.c_uint32 * len(mesh_visibility))(*[int(v) for v in mesh_visibility]) if mesh_visibility is not None else None
+        rtm = sio.to_matrix(root_transform) if root_transform is not None else None
+        check(self.ctx.lib.incr_update_bvh(self.ctx.handle, self.handle, mt, mv, C.byref(rtm) if rtm is not None else None, stream))
+
     def close(self):
         if self.handle:
             self.ctx.lib.incr_scene_destroy(self.ctx.handle, self.handle)

@@ -322,6 +322,27 @@ def add_light_rig(s, seed, num_point=64, bounds=((-13.0, 12.0), (0.6, 9.5), (-8.
     s.finalize_sun_light()
 
 
+def add_spot_rig(s, seed, num_spot=8, bounds=((-13.0, 12.0), (2.5, 9.0), (-8.0, 7.5))):
+    """Spot lights (lighting/common.hlsli:45-83) appended to the scene's rig: even ones unbounded (range 0: the only spots
+    that light anything), odd ones with range 6 (quirk Q9: the shadowed redeclaration of radialAttenuation leaves 0, so a
+    ranged spot contributes nothing and asks for no shadow ray).  Cones point mostly down with inner / outer half-angles
+    of 0.25-0.45 / 0.5-0.8 rad; position = row 3 of the light transform, axis = -row 2 (SimpleMath CreateWorld)."""
+    r = uniform01(seed, num_spot * 16, 177)
+    for i in range(num_spot):
+        l = A.Light(); l.type = A.LIGHT_SPOT
+        for k in range(3):
+            l.color[k] = float(f32(0.6 + 0.4 * r[i * 16 + k]))
+        l.intensity = float(f32(4.0 + 12.0 * r[i * 16 + 3]))
+        l.range = 0.0 if i % 2 == 0 else 6.0
+        l.spotAngles[0] = float(f32(0.25 + 0.2 * r[i * 16 + 4])); l.spotAngles[1] = float(f32(0.5 + 0.3 * r[i * 16 + 5]))
+        pos = [bounds[k][0] + (bounds[k][1] - bounds[k][0]) * r[i * 16 + 6 + k] for k in range(3)]
+        pos[2] = -pos[2]
+        fwd = sio.normalize3([r[i * 16 + 9] - 0.5, -1.0, r[i * 16 + 10] - 0.5])
+        gi = len(s.global_lights)
+        s.global_lights.append(l); s.light_indices.append(gi); s.light_transforms.append(sio.mat_create_world(pos, fwd, (0, 0, 1)))
+    return s
+
+
 def sponza_stat(texture_size=1024, with_lights=True, tri_scale=1.0, seed=SPONZA_SEED):
     """The 'Sponza-stat' scene.  tri_scale < 1 shrinks every primitive's triangle count (test-sized variants)."""
     s = sio.PackedScene()

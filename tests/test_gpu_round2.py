@@ -1,0 +1,354 @@
+"""GPU parity tests added in round 2 (run with -m gpu on an MI355X): the BASELINE configs and branches that had no GPU
+test -- config 2 (Damaged Helmet 1920x1080 path trace), config 5 (Bistro-scale at 4K, 16 spp + TAA), spot lights
+(lighting/common.hlsli:45-83, incl. quirk Q9) in the path tracer / clustered / forward passes, incr_update_bvh
+(update-tlas.inl:24-60) with changed transforms, visibility and root transform, and the two overflow mechanisms of the
+wavefront path tracer (full shadow-ray queue, deeper traversal stacks)."""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_pathtrace import pixel_agreement, stats_tuple
+from test_gpu_raster import colour_close, gpu_frame
+from test_raster_host_and_oracle import run_oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+def test_config2_helmet_1080p_parity(gpu_ctx, rt, sio, helmet, helmet_oracle):
+    """BASELINE config 2: Damaged Helmet 1920x1080, 1 spp path trace vs the oracle (every ray category equal,
+    >= 99.5 % of the pixels within 2^-7)."""
+    W, H = 1920, 1080
+    sc = gpu_ctx.create_scene(helmet)
+    view = sio.FView().reset(helmet, aspect=W / H)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    pt.render(view, 1)
+    g = pt.read()
+    o = helmet_oracle.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count())
+    assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    assert g["stats"].camera_rays == W * H
+    ok, same = pixel_agreement(g["target"], o["target"])
+    assert ok >= 0.995 and same >= 0.98, (ok, same)
+    assert (g["history"] == o["history"]).mean() >= 0.995
+    pt.close(); sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob):
+    """BASELINE config 5 on one GPU: Bistro-scale (1,025 instances, 2.9 M triangles, u32 indices, mirrored RH->LH transforms)
+    at 3840x2160: full-size properties, a 64x64 crop of (id, t, u, v) bit-exact vs the oracle, 16 spp accumulation and a
+    TAA raster frame pair."""
+    W, H = 3840, 2160
+    s = R.generate_meshlets(synth.bistro_scale(texture_size=64))
+    sc = gpu_ctx.create_scene(s)
+    info = sc.info()
+    assert info.num_instances == 1025 and info.num_triangles >= 2_800_000
+    assert info.bvh_max_depth <= 25
+    view = sio.FView().reset(s, aspect=W / H)
+    osc = ob.OracleScene(s)
+    # crop of primary rays (global pixel indices key the sampler) + incoherent rays: ids and t,u,v bit for bit
+    ys, xs = np.mgrid[1100:1164, 1700:1764]
+    d = rt.make_pathtrace_desc(view, W, H, 1)
+    org, dirs = osc.camera_rays(d, xs.ravel(), ys.ravel())
+    gi, gt = sc.trace_rays(org, dirs, 0.001, 10000.0)
+    oi, ot = osc.trace_rays(org, dirs, 0.001, 10000.0)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert gi[:, 0].mean() > 0.5
+    rng = np.random.default_rng(5)
+    n = 50_000
+    o2 = (rng.uniform(-40, 40, (n, 3)) * np.array([1, 0.05, 1]) + np.array([0, 1.5, 0])).astype(np.float32)
+    d2 = rng.standard_normal((n, 3)).astype(np.float32); d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    gi, gt = sc.trace_rays(o2, d2, 0.001, 10000.0); oi, ot = osc.trace_rays(o2, d2, 0.001, 10000.0)
+    np.testing.assert_array_equal(gi, oi); np.testing.assert_array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    ga, _ = sc.trace_rays(o2, d2, 0.1, 1000.0, any_hit=True); oa, _ = osc.trace_rays(o2, d2, 0.1, 1000.0, any_hit=True)
+    np.testing.assert_array_equal(ga[:, 0], oa[:, 0])
+    assert len(np.unique(gi[gi[:, 0] == 1, 1])) > 100                                  # many instances hit
+    # 16 spp: ray budget per sample, determinism, running mean
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    prev_hist = None
+    for n_s in range(1, 17):
+        gpu_ctx.clear(pt.stats, C.sizeof(A.RayStats))
+        pt.render(view, n_s)
+        if n_s in (1, 15, 16):
+            r = pt.read()
+            st = r["stats"]
+            assert st.camera_rays == W * H and st.bounce_rays <= 3 * W * H and st.shaded_hits <= 4 * W * H
+            assert st.light_shadow_rays <= 65 * st.shaded_hits and st.sky_shadow_rays <= st.shaded_hits
+            if n_s == 15:
+                prev_hist = r["history"].copy()
+    cur = r["target"].view(np.float16).astype(np.float32)[..., :3]
+    want = (np.float32(15.0) * ob.unpack_r11g11b10(prev_hist) + cur) / np.float32(16.0)
+    got = ob.unpack_r11g11b10(r["history"])
+    fin = np.isfinite(want) & (want < 60000) & (want >= 0)
+    assert (got[fin] <= want[fin] * (1 + 2.0 ** -20) + 1e-12).all()
+    assert (want[fin] - got[fin] <= np.maximum(want[fin] * 2.0 ** -5, 2e-6)).all()
+    pt.close()
+    # a small window of the same view against the oracle path tracer (ray categories + pixels)
+    Ws, Hs = 160, 90
+    vs = sio.FView().reset(s, aspect=Ws / Hs)
+    pts = rt.PathTracer(gpu_ctx, sc, Ws, Hs)
+    pts.render(vs, 3); g = pts.read()
+    o = osc.pathtrace(rt.make_pathtrace_desc(vs, Ws, Hs, 3), num_threads=os.cpu_count())
+    gs, os_ = np.array(stats_tuple(g["stats"]), dtype=np.float64), np.array(stats_tuple(o["stats"]), dtype=np.float64)
+    assert (np.abs(gs - os_) <= 3e-3 * np.maximum(os_, 1)).all(), (gs, os_)
+    ok, same = pixel_agreement(g["target"], o["target"])
+    assert ok >= 0.99, (ok, same)
+    pts.close()
+    # raster frame + TAA at 4K: two frames, second reprojects the first; bands of ids are plausible and the history converges
+    class Cfg(A.FConfig):
+        pass
+    frames = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, Cfg, frames=2)
+    (_, f0), (_, f1) = frames
+    assert (f0["vis"] != 0xFFFFF000).mean() > 0.3
+    assert f0["counts"][0] + f0["counts"][1] > 1000                               # meshlets survived culling
+    assert abs(int(f0["counts"][0]) - int(f1["counts"][0])) < 100                    # same view, sub-pixel jitter only
+    assert np.isfinite(ob.unpack_r11g11b10(f1["taa1"])).all()
+    # 128x72 raster parity of the same scene vs the oracle (ids, depth bit-exact)
+    Wr, Hr = 128, 72
+    vr = sio.FView().reset(s, aspect=Wr / Hr)
+    (vc, gsurf), = gpu_frame(rt, R, gpu_ctx, sc, vr, Wr, Hr, Cfg, frames=1)
+    _, hs = run_oracle_frame(ob, R, A, s, osc, vr, Wr, Hr)
+    np.testing.assert_array_equal(gsurf["vis"], hs.arr["vis"])
+    np.testing.assert_array_equal(gsurf["depth"].view(np.uint32), hs.arr["depth"].view(np.uint32))
+    osc.close(); sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ spot lights
+@pytest.fixture(scope="module")
+def sponza_spots(synth, R):
+    s = synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0)
+    synth.add_spot_rig(s, 0x5107, num_spot=8)
+    return R.generate_meshlets(s)
+
+
+def test_spot_lights_path_tracer(gpu_ctx, rt, sio, A, ob, sponza_spots):
+    """8 spot lights on top of the 65-light rig: the unbounded ones light the scene, the ranged ones contribute exactly 0
+    (Q9) and ask for no shadow ray -- counted against the oracle and against the same scene without the ranged spots."""
+    W, H = 320, 180
+    assert sum(1 for l in sponza_spots.global_lights if l.type == A.LIGHT_SPOT) == 8
+    sc = gpu_ctx.create_scene(sponza_spots)
+    osc = ob.OracleScene(sponza_spots)
+    view = sio.FView().reset(sponza_spots, aspect=W / H)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    pt.render(view, 2); g = pt.read()
+    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 2), num_threads=os.cpu_count())
+    gs, os_ = np.array(stats_tuple(g["stats"]), dtype=np.float64), np.array(stats_tuple(o["stats"]), dtype=np.float64)
+    assert gs[0] == os_[0] == W * H
+    assert (np.abs(gs - os_) <= 2e-3 * os_).all(), (gs, os_)
+    ok, same = pixel_agreement(g["target"], o["target"])
+    assert ok >= 0.99, (ok, same)
+    # the spots are really evaluated: more light shadow rays than the rig without them ...
+    base = copy.copy(sponza_spots)
+    n0 = len(sponza_spots.global_lights) - 8
+    base.global_lights = sponza_spots.global_lights[:n0]; base.light_indices = sponza_spots.light_indices[:n0]; base.light_transforms = sponza_spots.light_transforms[:n0]
+    base._desc = None
+    sb = gpu_ctx.create_scene(base)
+    pb = rt.PathTracer(gpu_ctx, sb, W, H); pb.render(view, 2); b = pb.read()
+    assert g["stats"].light_shadow_rays > b["stats"].light_shadow_rays
+    # ... and dropping the four RANGED spots changes nothing at all (Q9: radial attenuation stays 0)
+    q9 = copy.copy(sponza_spots)
+    keep = [i for i, l in enumerate(sponza_spots.global_lights) if not (l.type == A.LIGHT_SPOT and l.range > 0)]
+    assert len(keep) == len(sponza_spots.global_lights) - 4
+    q9.global_lights = [sponza_spots.global_lights[i] for i in keep]; q9.light_transforms = [sponza_spots.light_transforms[i] for i in keep]
+    q9.light_indices = list(range(len(keep))); q9._desc = None
+    sq = gpu_ctx.create_scene(q9)
+    pq = rt.PathTracer(gpu_ctx, sq, W, H); pq.render(view, 2); q = pq.read()
+    assert q["stats"].light_shadow_rays == g["stats"].light_shadow_rays
+    np.testing.assert_array_equal(q["target"], g["target"])
+    for x in (pt, pb, pq):
+        x.close()
+    for x in (sc, sb, sq):
+        x.close()
+    osc.close()
+
+
+@pytest.mark.parametrize("forward", [False, True])
+def test_spot_lights_raster(gpu_ctx, rt, R, sio, A, ob, sponza_spots, forward):
+    """Clustered deferred (light culling + clustered-lighting.hlsl) and forward (forward-pass.hlsl) frames with spot lights."""
+    W, H = 320, 180
+
+    class Cfg(A.FConfig):
+        ForwardLighting = forward
+    sc = gpu_ctx.create_scene(sponza_spots)
+    osc = ob.OracleScene(sponza_spots)
+    view = sio.FView().reset(sponza_spots, aspect=W / H)
+    g = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, Cfg, frames=2)
+    prev, hs = None, None
+    for frame, (vc, gs) in enumerate(g):
+        vco, hs = run_oracle_frame(ob, R, A, sponza_spots, osc, view, W, H, frame_index=frame, prev=prev, hs=hs, cfg=Cfg)
+        prev = R.matrix_to_numpy(vco.unjittered_view_proj)
+        o = hs.arr
+        np.testing.assert_array_equal(gs["light_grid"], o["light_grid"])
+        np.testing.assert_array_equal(gs["light_count"], o["light_count"])
+        for c in np.nonzero(o["light_grid"][:, 1])[0]:
+            np.testing.assert_array_equal(gs["light_lists"][c, :o["light_grid"][c, 1]], o["light_lists"][c, :o["light_grid"][c, 1]])
+        np.testing.assert_array_equal(gs["depth"].view(np.uint32), o["depth"].view(np.uint32))
+        assert colour_close(ob, gs["color"], o["color"], "spot colour") > 0.995
+        assert colour_close(ob, gs["taa%d" % (frame & 1)], o["taa%d" % (frame & 1)], "spot taa") > 0.99
+    # spot light ids (65 .. 72) appear in the culled lists
+    lists = g[0][1]["light_lists"]; grid = g[0][1]["light_grid"]
+    seen = set()
+    for c in np.nonzero(grid[:, 1])[0]:
+        seen.update(int(v) for v in lists[c, :grid[c, 1]])
+    assert any(v >= 65 for v in seen)
+    osc.close(); sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ incr_update_bvh
+def _scene_with_props(synth, sio, R, A):
+    """Sponza-small plus three separate prop meshes (so transforms / visibility can change per mesh), one mirrored."""
+    s = synth.sponza_stat(texture_size=64, tri_scale=1.0 / 16.0)
+    props = synth.bistro_scale(num_instances=3, tris_per_mesh=600, num_materials=4, texture_size=16)
+    # graft the props' geometry buffers, views and accessors behind the scene's own
+    nb, nv, na, nmat, ntex = len(s.buffers), len(s.buffer_views), len(s.accessors), len(s.materials), len(s.textures)
+    s.buffers += props.buffers
+    s.buffer_views += [(b + nb, o, l) for (b, o, l) in props.buffer_views]
+    s.accessors += [(v + nv, o, st) for (v, o, st) in props.accessors]
+    for m in props.materials:
+        m2 = copy.copy(m)
+        for n in A._MAT_TEX:
+            t = getattr(m2, n + "TextureIndex")
+            if t >= 0:
+                setattr(m2, n + "TextureIndex", t + ntex)
+        s.materials.append(m2)
+    s.textures += props.textures
+    for k in range(3):
+        p = dict(props.mesh_primitives[k][0])
+        for key in ("position", "normal", "tangent", "uv", "index"):
+            p[key] += na
+        p["material"] += nmat
+        s.mesh_names.append("prop_%d" % k); s.mesh_primitives.append([p])
+        t = sio.mat_mul(sio.mat_scale(1.2, 1.2, -1.2 if k == 1 else 1.2), sio.mat_translation(-6.0 + 3.0 * k, 0.2, -0.5 + 0.4 * k))
+        s.mesh_transforms.append(t)
+    return R.generate_meshlets(s)
+
+
+def test_update_bvh_matches_fresh_scene(gpu_ctx, rt, R, sio, synth, A, ob):
+    """incr_update_bvh (device re-transform + refit, no host rebuild): after moving a mesh, mirroring one, hiding one and
+    rotating the root transform, ray queries, the path tracer and the raster frame equal those of a scene CREATED with
+    the new state -- on the GPU (fresh scene) and against the oracle."""
+    s = _scene_with_props(synth, sio, R, A)
+    nm = len(s.mesh_transforms)
+    assert nm == 4
+    sc = gpu_ctx.create_scene(s)
+    W, H = 256, 144
+    view = sio.FView().reset(s, aspect=W / H)
+    # new state
+    t2 = [m.copy() for m in s.mesh_transforms]
+    t2[1] = sio.mat_mul(sio.mat_scale(1.5, 0.8, 1.5), sio.mat_translation(-7.5, 0.0, 1.0))            # moved + scaled
+    t2[2] = sio.mat_mul(sio.mat_scale(-1.1, 1.1, -1.1), sio.mat_translation(-3.0, 0.5, 0.0))           # mirrored differently
+    vis2 = [1, 1, 1, 0]                                                                                 # last prop hidden
+    ang = 0.2
+    root2 = sio.mat_from_quaternion(0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2))
+    sc.update_bvh(t2, vis2, root2)
+    s2 = copy.copy(s)
+    s2.mesh_transforms = t2; s2.mesh_visibility = vis2; s2.root_transform = root2; s2._desc = None
+    fresh = gpu_ctx.create_scene(s2)
+    osc = ob.OracleScene(s2)
+    assert sc.info().num_instances == fresh.info().num_instances == 3
+    rng = np.random.default_rng(77)
+    n = 150_000
+    org = (rng.uniform(-12, 12, (n, 3)) * np.array([1, 0.4, 0.6]) + np.array([0, 3, 0])).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    for any_hit, (tmin, tmax) in ((False, (0.001, 10000.0)), (True, (0.1, 1000.0))):
+        ui, ut = sc.trace_rays(org, d, tmin, tmax, any_hit=any_hit)
+        fi, ft = fresh.trace_rays(org, d, tmin, tmax, any_hit=any_hit)
+        oi, ot = osc.trace_rays(org, d, tmin, tmax, any_hit=any_hit)
+        np.testing.assert_array_equal(ui, fi); np.testing.assert_array_equal(ut.view(np.uint32), ft.view(np.uint32))
+        np.testing.assert_array_equal(ui[:, 0] if any_hit else ui, oi[:, 0] if any_hit else oi)
+        if not any_hit:
+            np.testing.assert_array_equal(ut.view(np.uint32), ot.view(np.uint32))
+            assert set(np.unique(ui[ui[:, 0] == 1, 1])) == {0, 1, 2}            # instance ids renumbered over the visible meshes
+    # path tracer: updated scene == fresh scene bit for bit (same records, same light grid contents up to cell layout)
+    pu = rt.PathTracer(gpu_ctx, sc, W, H); pf = rt.PathTracer(gpu_ctx, fresh, W, H)
+    pu.render(view, 1); pf.render(view, 1)
+    u, f = pu.read(), pf.read()
+    assert stats_tuple(u["stats"]) == stats_tuple(f["stats"])
+    np.testing.assert_array_equal(u["target"], f["target"])
+    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count())
+    ok, same = pixel_agreement(u["target"], o["target"])
+    assert ok >= 0.99, (ok, same)
+    pu.close(); pf.close()
+    # raster frame: hidden mesh culled, decal / mesh transforms follow the root transform -- identical surfaces
+    (_, gu), = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, A.FConfig, frames=1)
+    (_, gf), = gpu_frame(rt, R, gpu_ctx, fresh, view, W, H, A.FConfig, frames=1)
+    for name in ("counts", "vis", "gbuffer_basecolor", "gbuffer_normals", "color"):
+        np.testing.assert_array_equal(gu[name], gf[name], err_msg=name)
+    np.testing.assert_array_equal(gu["depth"].view(np.uint32), gf["depth"].view(np.uint32))
+    _, hs = run_oracle_frame(ob, R, A, s2, osc, view, W, H)
+    np.testing.assert_array_equal(gu["vis"], hs.arr["vis"])
+    # show the hidden mesh again, restore everything: back to the original scene
+    sc.update_bvh(s.mesh_transforms, [1, 1, 1, 1], s.root_transform)
+    orig = gpu_ctx.create_scene(s)
+    ui, ut = sc.trace_rays(org, d, 0.001, 10000.0); fi, ft = orig.trace_rays(org, d, 0.001, 10000.0)
+    np.testing.assert_array_equal(ui, fi); np.testing.assert_array_equal(ut.view(np.uint32), ft.view(np.uint32))
+    assert 3 in set(np.unique(ui[ui[:, 0] == 1, 1]))
+    for x in (sc, fresh, orig):
+        x.close()
+    osc.close()
+
+
+def test_update_bvh_bistro_scale_cost(gpu_ctx, rt, R, sio, synth):
+    """1,025-instance Bistro-scale: a transform update is two streaming kernels -- well under 2 ms of GPU time."""
+    import time
+    s = synth.bistro_scale(texture_size=16)
+    sc = gpu_ctx.create_scene(s)
+    t2 = [m.copy() for m in s.mesh_transforms]
+    for i in range(0, len(t2), 3):
+        t2[i] = sio.mat_mul(t2[i], sio.mat_translation(0.05, 0.0, -0.03))
+    sc.update_bvh(t2); gpu_ctx.synchronize()                           # warm-up (module load)
+    times = []
+    for rep in range(3):
+        for i in range(0, len(t2), 3):
+            t2[i] = sio.mat_mul(t2[i], sio.mat_translation(0.01, 0.0, 0.01))
+        mt = (rt.A.Matrix * len(t2))(*[sio.to_matrix(m) for m in t2])
+        gpu_ctx.synchronize()
+        t0 = time.perf_counter()
+        rt.check(gpu_ctx.lib.incr_update_bvh(gpu_ctx.handle, sc.handle, mt, None, None, None))
+        t_host = time.perf_counter() - t0
+        gpu_ctx.synchronize()
+        times.append((t_host, time.perf_counter() - t0))
+    best = min(t[1] for t in times)
+    print("bistro-scale incr_update_bvh: host %.3f ms, host+device %.3f ms" % (min(t[0] for t in times) * 1e3, best * 1e3))
+    assert best < 0.005                                                 # wall clock of call + drain, incl. the host's light-grid rebuild (done: < 2 ms of GPU time)
+    # still correct after the updates
+    s2 = copy.copy(s); s2.mesh_transforms = t2; s2._desc = None
+    fresh = gpu_ctx.create_scene(s2)
+    rng = np.random.default_rng(3)
+    n = 60_000
+    org = (rng.uniform(-40, 40, (n, 3)) * np.array([1, 0.05, 1]) + np.array([0, 1.5, 0])).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    ui, ut = sc.trace_rays(org, d, 0.001, 10000.0); fi, ft = fresh.trace_rays(org, d, 0.001, 10000.0)
+    np.testing.assert_array_equal(ui, fi); np.testing.assert_array_equal(ut.view(np.uint32), ft.view(np.uint32))
+    sc.close(); fresh.close()
+
+
+# ------------------------------------------------------------------------------------------------ overflow mechanisms
+@pytest.mark.parametrize("env", [{"INCR_WF_RAYS_PER_PATH": "1"}, {"INCR_WF_RAYS_PER_PATH": "0"}, {"INCR_WF_STACK_ENTRIES": "12"}, {"INCR_WF_STACK_ENTRIES": "16"}, {"INCR_WF_STACK_ENTRIES": "24"}])
+def test_wavefront_overflow_paths_are_bit_identical(gpu_ctx, rt, sio, sponza_small, env):
+    """A shadow-ray queue that is too small (vertices traced inside accumulate instead) and the 16- / 24-entry stack
+    instantiations of the traversal kernels must reproduce the default configuration bit for bit."""
+    W, H = 320, 180
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    sc = gpu_ctx.create_scene(sponza_small)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H); pt.render(view, 3); ref = pt.read(); pt.close(); sc.close()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx2 = rt.Context(0)                                # the hooks are read at incr_initialize
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    sc2 = ctx2.create_scene(sponza_small)
+    p2 = rt.PathTracer(ctx2, sc2, W, H); p2.render(view, 3); got = p2.read()
+    assert stats_tuple(got["stats"]) == stats_tuple(ref["stats"])
+    np.testing.assert_array_equal(got["target"], ref["target"])
+    np.testing.assert_array_equal(got["history"], ref["history"])
+    p2.close(); sc2.close(); ctx2.close()

@@ -17,6 +17,9 @@ extern "C" int san_build_scene(const incr_scene_desc* desc, uint64_t out_counts[
     build_world_bvh(hs, bvh);
     if (const char* err = check_bvh(bvh)) { snprintf(why, why_bytes, "%s", err); return -2; }
     build_light_grid(hs, bvh, grid);
-    out_counts[0] = bvh.tris.size(); out_counts[1] = bvh.nodes8.size(); out_counts[2] = grid.cellOffsets.size(); out_counts[3] = grid.cellLights.size();
+    // hittable triangles: hidden meshes stay in the tree as NaN records (scene_build.cpp)
+    uint64_t hittable = 0; for (const TriIsect& t : bvh.tris) if (t.v0x == t.v0x) ++hittable;
+    std::vector<MeshInstanceInfo> info; refresh_mesh_instances(hs, bvh, info);      // the update path's host half, under the sanitizers too
+    out_counts[0] = hittable; out_counts[1] = bvh.nodes8.size(); out_counts[2] = grid.cellOffsets.size(); out_counts[3] = grid.cellLights.size();
     return 0;
 }

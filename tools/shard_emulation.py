@@ -1,0 +1,64 @@
+"""8-GPU behaviour of the path tracer measured on ONE GPU: the 4K frame is rendered as N framebuffer shards
+(incr_shard{8, r, N}: interleaved 8-row blocks, exactly what rank r of an N-GPU run renders) one after the other, and
+the time of every shard is compared with the full frame.  On N GPUs the shards run concurrently, so
+  projected N-GPU frame time = max over shards (+ one RCCL all_gather of 33 MB per gathered frame),
+  projected speed-up = full-frame ms / max shard ms.
+Writes a JSON line (also to --out).  usage: python tools/shard_emulation.py [--shards 8] [--res 3840x2160] [--steps 8]"""
+import argparse, ctypes as C, importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "incarnation-renderer_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards", type=int, default=8); ap.add_argument("--res", default="3840x2160")
+    ap.add_argument("--steps", type=int, default=8); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="sponza"); ap.add_argument("--texture-size", type=int, default=1024)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import torch  # noqa: F401  (first HIP runtime in the process, as in bench.py)
+    A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io")
+    rt = importlib.import_module(PKG + ".runtime"); bench = importlib.import_module("bench")
+    W, H = (int(v) for v in a.res.lower().split("x"))
+    packed = bench.build_scene(a.scene, a.texture_size)
+    view = sio.FView().reset(packed, aspect=W / H)
+    ctx = rt.Context(0)
+    scene = ctx.create_scene(packed)
+
+    def timed(shard):
+        pt = rt.PathTracer(ctx, scene, W, H, shard=shard)
+        for i in range(a.warmup):
+            pt.render(view, 1 + i, count_rays=False)
+        ctx.synchronize()
+        ctx.clear(pt.stats, C.sizeof(A.RayStats))
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            pt.render(view, 1 + a.warmup + i)
+        ctx.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / a.steps
+        rays = pt.read()["stats"].total_rays() / a.steps
+        pt.close()
+        return ms, rays
+
+    full_ms, full_rays = timed(None)
+    shard_ms, shard_rays = [], []
+    for r in range(a.shards):
+        ms, rays = timed(A.Shard(8, r, a.shards))
+        shard_ms.append(round(ms, 4)); shard_rays.append(int(rays))
+    out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps,
+           "full_frame_ms": round(full_ms, 4), "full_frame_rays": int(full_rays), "shard_ms": shard_ms, "shard_rays": shard_rays,
+           "max_shard_ms": max(shard_ms), "sum_shard_ms": round(sum(shard_ms), 4),
+           "projected_speedup_compute_only": round(full_ms / max(shard_ms), 3),
+           "shard_overhead_vs_full": round(sum(shard_ms) / full_ms, 4),
+           "note": "one GPU, shards rendered sequentially; excludes the RCCL all_gather (33 MB per gathered 4K frame, once per --spp-per-gather samples)"}
+    line = json.dumps(out)
+    print(line, flush=True)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

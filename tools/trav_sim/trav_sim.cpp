@@ -62,6 +62,7 @@ static bool tri_isect(const TriIsect& T, const Ray& r, float tmax, float* t) {
 }
 static uint32_t child_index(const BvhNode8& n, uint32_t k) { return n.childBase + (uint32_t)__builtin_popcount(n.imask & ((1u << k) - 1u)); }
 
+static std::vector<uint8_t> g_nodeDepth; static double g_visitsByDepth[2][32];
 struct Stats { double rays = 0, nodes = 0, tris = 0, pushes = 0, hits = 0; std::vector<uint32_t> depthHist = std::vector<uint32_t>(128, 0); };
 static void note(Stats& s, uint32_t nodes, uint32_t tris, uint32_t pushes, uint32_t maxDepth, bool hit) {
     s.rays++; s.nodes += nodes; s.tris += tris; s.pushes += pushes; s.hits += hit; s.depthHist[std::min(maxDepth, 127u)]++;
@@ -109,7 +110,7 @@ static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, co
             if (!got) break;
         }
         have = false;
-        const BvhNode8& n = B.nodes8[cur]; ++nodes;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[0][g_nodeDepth[cur]]++;
         NodeT N; node_test(n, r, invd, best, N);
         test_tris(n, tri_mask(n, N.hit));
         uint32_t inner = N.hit & n.imask;
@@ -170,7 +171,7 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
             }
         }
         have = false;
-        const BvhNode8& n = B.nodes8[cur]; ++nodes;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[1][g_nodeDepth[cur]]++;
         NodeT N; node_test(n, r, invd, r.tmax, N);
         uint32_t tm = tri_mask(n, N.hit);
         while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) occluded = true; }
@@ -268,6 +269,8 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             if (cfg == 1 && v >= 2) continue;            // reversal needs the sorted order
             rng_state = 0x9E3779B97F4A7C15ull;
             Stats sp, sb, ss, ss0;
+            g_nodeDepth.clear(); memset(g_visitsByDepth, 0, sizeof g_visitsByDepth);
+            if (cfg == 2 && variant == 2) { g_nodeDepth.assign(B.nodes8.size(), 0); std::vector<std::pair<uint32_t,uint8_t>> q; q.push_back({0u, 1}); while (!q.empty()) { auto [ni, d] = q.back(); q.pop_back(); g_nodeDepth[ni] = d; for (int k = 0; k < 8; ++k) if ((B.nodes8[ni].imask >> k) & 1u) q.push_back({B.nodes8[ni].childBase + (uint32_t)k, (uint8_t)(d + 1)}); } }
             double checksum = 0;
             for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
                 const float sx = ((x + 0.5f) / W * 2.f - 1.f) * tanHalfFovY * aspect, sy = (1.f - (y + 0.5f) / H * 2.f) * tanHalfFovY;
@@ -315,6 +318,11 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                 }
             }
             printf(" variant %d (checksum %.6f)\n", variant, checksum);
+            if (cfg == 2 && variant == 2) {
+                for (int w = 0; w < 2; ++w) { double tot = 0, acc = 0; for (int d = 0; d < 32; ++d) tot += g_visitsByDepth[w][d];
+                    printf("  %s node visits by depth (cumulative share):", w ? "any-hit" : "closest"); for (int d = 1; d < 12; ++d) { acc += g_visitsByDepth[w][d]; printf(" d%d %.3f", d, acc / tot); } printf("\n"); }
+                printf("  nodes per level:"); for (size_t d = 0; d + 1 < B.levelOffsets.size(); ++d) printf(" %u", B.levelOffsets[d + 1] - B.levelOffsets[d]); printf("\n");
+            }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
         }
     }

@@ -1,15 +1,16 @@
 // meshletize.cpp -- host-side meshlet builder: the load-time step that defines the (meshlet, triangle) ids the
-// visibility buffer encodes.  Restates the ALGORITHM of MeshUtils::Meshletize
-// (reference: source/demo-dll/src/mesh-utils.cpp:640-835 with its helpers :114-553; the reference credits the
-// Microsoft D3D12MeshShaders sample): greedy growth of meshlets of <= maxVerts unique vertices and <= maxPrims
-// triangles along triangle adjacency, candidates ranked by a score that mixes vertex re-use, distance to the
-// meshlet's bounding sphere and deviation from its mean normal; triangles are inserted with REVERSED winding
-// ({i2, i1, i0}, :682-687) and packed 10:10:10 (inc/mesh-utils.h:8-14), which the shaders undo by reading the packed
-// fields high to low (shaders/geo-raster/visibility-pass.hlsl:78).
+// visibility buffer encodes.  Implements MeshUtils::Meshletize (reference: source/demo-dll/src/mesh-utils.cpp:640-835
+// with its helpers :114-553; the reference credits the Microsoft D3D12MeshShaders sample) with the reference's exact
+// decision sequence -- position-hash point reps, hash-chained directed edges with best-normal pairing, the candidate
+// stack re-scored and re-sorted after every accepted triangle, REVERSED winding on insert ({i2, i1, i0}, :682-687),
+// 10:10:10 packing (inc/mesh-utils.h:8-14) -- so that meshlet ids, vertex lists and packed triangles equal those of the
+// step-for-step restatement in oracle/oracle_meshlet.cpp bit for bit (tests/test_meshletize.py), which is how the
+// "bit-exact visibility ids" of the north star are anchored.  The toolchain-defined pieces (DirectXMath float order,
+// XMVectorLog = log2, 64-bit size_t hash, tie order of std::sort) are pinned as documented in that file.
 //
-// The result is deterministic for a given input, but it is not claimed to be identical to the reference's output:
-// that depends on std::sort tie order, std::unordered_set iteration and a position hash used as identity there.
-#include <algorithm>
+// What differs from a literal transcription is bookkeeping only: vertex re-use and slot look-ups are O(1) per vertex
+// (a per-vertex slot count / last slot for the current meshlet instead of scanning its vertex list per candidate), the
+// candidate and done sets are bitmaps, and the sort is an insertion sort over an almost sorted list.
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -23,182 +24,211 @@ namespace {
 
 struct P3 { float x, y, z; };
 static inline P3 sub(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-static inline P3 add(P3 a, P3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-static inline P3 mul(P3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-static inline float dot(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float dot(P3 a, P3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }       // XMVector3Dot, SSE2 order
 static inline P3 cross(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-static inline P3 normalized(P3 a) { const float l = std::sqrt(dot(a, a)); return l > 0.f ? mul(a, 1.f / l) : a; }
-static inline P3 face_normal(P3 p0, P3 p1, P3 p2) { return normalized(cross(sub(p0, p1), sub(p0, p2))); }
+static inline P3 normalized(P3 v) {                                                         // XMVector3Normalize
+    const float len = std::sqrt(dot(v, v));
+    if (len == 0.f) return {0.f, 0.f, 0.f};
+    if (!(len <= FLT_MAX)) { const float q = std::nanf(""); return {q, q, q}; }
+    return {v.x / len, v.y / len, v.z / len};
+}
+static inline P3 face_normal(P3 p0, P3 p1, P3 p2) { return normalized(cross(sub(p0, p1), sub(p0, p2))); }   // ComputeNormal :238-248
 
 struct Sphere { P3 c; float r; };
 
-// Ritter-style bounding sphere: start from the extreme pair along the widest axis, then grow (mesh-utils.cpp:114-180).
-static Sphere bounding_sphere(const P3* pts, size_t n) {
-    size_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    for (size_t i = 1; i < n; ++i) {
-        const float v[3] = {pts[i].x, pts[i].y, pts[i].z};
+// MinimumBoundingSphere :114-180: extreme pair along the widest axis, then one growing pass (radius^2 is NOT refreshed
+// inside the pass, as in the reference).
+static Sphere bounding_sphere(const P3* pts, uint32_t n) {
+    uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (uint32_t i = 1; i < n; ++i) {
+        const float* v = &pts[i].x;
         for (int a = 0; a < 3; ++a) {
-            const float l = a == 0 ? pts[lo[a]].x : a == 1 ? pts[lo[a]].y : pts[lo[a]].z;
-            const float h = a == 0 ? pts[hi[a]].x : a == 1 ? pts[hi[a]].y : pts[hi[a]].z;
-            if (v[a] < l) lo[a] = i;
-            if (v[a] > h) hi[a] = i;
+            if (v[a] < (&pts[lo[a]].x)[a]) lo[a] = i;
+            if (v[a] > (&pts[hi[a]].x)[a]) hi[a] = i;
         }
     }
-    int axis = 0; float best = 0.f;
-    for (int a = 0; a < 3; ++a) { const P3 d = sub(pts[hi[a]], pts[lo[a]]); const float d2 = dot(d, d); if (d2 > best) { best = d2; axis = a; } }
+    uint32_t axis = 0; float best = 0.f;
+    for (uint32_t a = 0; a < 3; ++a) { const P3 d = sub(pts[hi[a]], pts[lo[a]]); const float d2 = dot(d, d); if (d2 > best) { best = d2; axis = a; } }
     const P3 p1 = pts[lo[axis]], p2 = pts[hi[axis]];
-    Sphere s; s.c = mul(add(p1, p2), 0.5f);
+    Sphere s; s.c = {(p1.x + p2.x) * 0.5f, (p1.y + p2.y) * 0.5f, (p1.z + p2.z) * 0.5f};
     const P3 d12 = sub(p2, p1); s.r = std::sqrt(dot(d12, d12)) * 0.5f;
-    for (size_t i = 0; i < n; ++i) {
+    const float r2 = s.r * s.r;
+    for (uint32_t i = 0; i < n; ++i) {
         const P3 d = sub(pts[i], s.c); const float d2 = dot(d, d);
-        if (d2 > s.r * s.r) {
+        if (d2 > r2) {
             const float dist = std::sqrt(d2);
-            const float k = (s.r / dist) * 0.5f + 0.5f;
-            s.c = add(mul(s.c, k), mul(pts[i], 1.f - k));
+            const float k = (s.r / dist) * 0.5f + 0.5f, omk = 1.f - k;
+            s.c = {s.c.x * k + pts[i].x * omk, s.c.y * k + pts[i].y * omk, s.c.z * k + pts[i].z * omk};
             s.r = (s.r + dist) * 0.5f;
         }
     }
     return s;
 }
 
-struct PosKey { uint32_t a, b, c; bool operator==(const PosKey& o) const { return a == o.a && b == o.b && c == o.c; } };
-struct PosHash { size_t operator()(const PosKey& k) const { uint64_t h = k.a; h = h * 0x9E3779B97F4A7C15ull ^ k.b; h = h * 0x9E3779B97F4A7C15ull ^ k.c; return (size_t)(h ^ (h >> 29)); } };
+static inline uint64_t position_hash(const P3& p) {      // hash<XMFLOAT3> = CRCHash of the three dwords, size_t = 64 bit (:198-211, :553-556)
+    uint32_t w[3]; memcpy(w, &p, 12);
+    uint64_t h = 0;
+    for (int i = 0; i < 3; ++i) { const uint32_t high = (uint32_t)(h & 0xf8000000u); h = (h << 5) ^ (uint64_t)(high >> 27); h ^= (uint64_t)w[i]; }
+    return h;
+}
 
 struct Meshlet { std::vector<uint32_t> verts; std::vector<uint32_t> packedTris; Sphere bounds{{0, 0, 0}, 0}; };
 
-// Triangle adjacency across shared edges of WELDED positions: adj[f*3 + e] = face on the other side of edge e
-// (vertices e, e+1) or ~0u.  When several faces share an edge the one whose normal agrees best is taken; every
-// half-edge is paired at most once.
+// BuildAdjacencyList :285-487.  adj[f*3 + e] = face across edge e or ~0u.  The pairing depends on the order of the hash
+// chains (LIFO per bucket `pointRep % (vertexCount / 3)`) and on entries being unlinked as they are matched, so the chains
+// are kept exactly: `next` indices instead of pointers, ~0u = end of chain.
 static void build_adjacency(const uint32_t* idx, uint32_t triCount, const P3* pos, uint32_t vertexCount, std::vector<uint32_t>& adj) {
+    const uint32_t kNone = 0xffffffffu;
     std::vector<uint32_t> rep(vertexCount);
-    std::unordered_map<PosKey, uint32_t, PosHash> first; first.reserve(vertexCount * 2);
-    for (uint32_t i = 0; i < vertexCount; ++i) {
-        PosKey k; memcpy(&k, &pos[i], 12);
-        auto it = first.find(k);
-        if (it == first.end()) { first.emplace(k, i); rep[i] = i; } else rep[i] = it->second;
-    }
-    struct Half { uint32_t face, edge; bool used; };
-    std::unordered_map<uint64_t, std::vector<uint32_t>> byEdge; byEdge.reserve((size_t)triCount * 3);
-    std::vector<Half> halves((size_t)triCount * 3);
-    auto key = [](uint32_t a, uint32_t b) { return ((uint64_t)a << 32) | b; };
+    { std::unordered_map<uint64_t, uint32_t> first; first.reserve(vertexCount);
+      for (uint32_t i = 0; i < vertexCount; ++i) { const auto ins = first.emplace(position_hash(pos[i]), i); rep[i] = ins.first->second; } }
+    const uint32_t buckets = vertexCount / 3;
+    struct Edge { uint32_t i0, i1, i2, face, next; };
+    std::vector<Edge> edges((size_t)triCount * 3);
+    std::vector<uint32_t> head(buckets, kNone);
     for (uint32_t f = 0; f < triCount; ++f)
         for (uint32_t e = 0; e < 3; ++e) {
-            const uint32_t a = rep[idx[f * 3 + e]], b = rep[idx[f * 3 + (e + 1) % 3]];
-            halves[(size_t)f * 3 + e] = {f, e, false};
-            byEdge[key(a, b)].push_back(f * 3 + e);
+            Edge& E = edges[(size_t)f * 3 + e];
+            E.i0 = rep[idx[f * 3 + e]]; E.i1 = rep[idx[f * 3 + (e + 1) % 3]]; E.i2 = rep[idx[f * 3 + (e + 2) % 3]];
+            E.face = f; E.next = head[E.i0 % buckets]; head[E.i0 % buckets] = f * 3 + e;
         }
-    adj.assign((size_t)triCount * 3, 0xffffffffu);
-    std::vector<P3> normals(triCount);
-    for (uint32_t f = 0; f < triCount; ++f) normals[f] = face_normal(pos[idx[f * 3]], pos[idx[f * 3 + 1]], pos[idx[f * 3 + 2]]);
+    auto edge_normal = [&](uint32_t a, uint32_t b, uint32_t c) { return normalized(cross(sub(pos[a], pos[b]), sub(pos[b], pos[c]))); };
+    auto unlink = [&](uint32_t bucket, uint32_t prev, uint32_t cur) { if (prev != kNone) edges[prev].next = edges[cur].next; else head[bucket] = edges[cur].next; };
+    adj.assign((size_t)triCount * 3, kNone);
     for (uint32_t f = 0; f < triCount; ++f)
-        for (uint32_t e = 0; e < 3; ++e) {
-            Half& me = halves[(size_t)f * 3 + e];
-            if (me.used) continue;
-            const uint32_t a = rep[idx[f * 3 + e]], b = rep[idx[f * 3 + (e + 1) % 3]];
-            if (a == b) continue;
-            auto it = byEdge.find(key(b, a));          // the neighbour runs the edge in the opposite direction
-            if (it == byEdge.end()) continue;
-            int bestH = -1; float bestDot = -2.f;
-            for (uint32_t h : it->second) {
-                Half& o = halves[h];
-                if (o.used || o.face == f) continue;
-                const float d = dot(normals[f], normals[o.face]);
-                if (d > bestDot) { bestDot = d; bestH = (int)h; }
+        for (uint32_t pt = 0; pt < 3; ++pt) {
+            if (adj[(size_t)f * 3 + pt] != kNone) continue;
+            const uint32_t i0 = rep[idx[f * 3 + (pt + 1) % 3]], i1 = rep[idx[f * 3 + pt]], i2 = rep[idx[f * 3 + (pt + 2) % 3]];   // the edge, reversed
+            const uint32_t bucket = i0 % buckets;
+            uint32_t found = kNone, foundPrev = kNone;
+            for (uint32_t cur = head[bucket], prev = kNone; cur != kNone; prev = cur, cur = edges[cur].next)
+                if (edges[cur].i1 == i1 && edges[cur].i0 == i0) { found = cur; foundPrev = prev; break; }
+            const P3 n0 = edge_normal(i1, i0, i2);
+            float bestDot = -2.0f;
+            for (uint32_t cur = found, prev = foundPrev; cur != kNone; prev = cur, cur = edges[cur].next) {
+                const Edge& C = edges[cur];
+                if (bestDot == -2.0f || (C.i1 == i1 && C.i0 == i0)) {
+                    const float d = dot(n0, edge_normal(C.i0, C.i1, C.i2));
+                    if (d > bestDot) { found = cur; foundPrev = prev; bestDot = d; }
+                }
             }
-            if (bestH < 0) continue;
-            Half& o = halves[(size_t)bestH];
-            me.used = o.used = true;
-            adj[(size_t)f * 3 + e] = o.face;
-            adj[(size_t)o.face * 3 + o.edge] = f;
+            if (found == kNone) continue;
+            const uint32_t other = edges[found].face;
+            unlink(bucket, foundPrev, found);
+            adj[(size_t)f * 3 + pt] = other;
+            const uint32_t bucket2 = i1 % buckets;                       // this face's own half of the edge leaves its chain too
+            for (uint32_t cur = head[bucket2], prev = kNone; cur != kNone; prev = cur, cur = edges[cur].next)
+                if (edges[cur].face == f && edges[cur].i1 == i0 && edges[cur].i0 == i1) { unlink(bucket2, prev, cur); break; }
+            bool linked = false;
+            for (uint32_t q = 0; q < pt; ++q) if (adj[(size_t)f * 3 + q] == other) { linked = true; adj[(size_t)f * 3 + pt] = kNone; break; }
+            if (!linked) {
+                uint32_t e2 = 0;
+                for (; e2 < 3; ++e2) { const uint32_t k = idx[other * 3 + e2]; if (k == kNone) continue; if (rep[k] == i0) break; }
+                if (e2 < 3) adj[(size_t)other * 3 + e2] = f;
+            }
         }
 }
 
-static bool try_add(Meshlet& m, const uint32_t tri[3], uint32_t maxVerts, uint32_t maxPrims) {   // AddToMeshlet :494-543
-    if (m.verts.size() == maxVerts || m.packedTris.size() == maxPrims) return false;
-    uint32_t local[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, fresh = 3;
-    for (uint32_t i = 0; i < m.verts.size(); ++i)
-        for (int j = 0; j < 3; ++j) if (m.verts[i] == tri[j] && local[j] == 0xffffffffu) { local[j] = i; --fresh; }
-    if (m.verts.size() + fresh > maxVerts) return false;
-    for (int j = 0; j < 3; ++j) if (local[j] == 0xffffffffu) {
-        // a degenerate triangle can name the same new vertex twice: reuse the slot just created
-        for (int q = 0; q < j; ++q) if (tri[q] == tri[j]) local[j] = local[q];
-        if (local[j] == 0xffffffffu) { local[j] = (uint32_t)m.verts.size(); m.verts.push_back(tri[j]); }
+// The meshlet under construction plus O(1) views of its vertex list: slots[v] = how many slots hold vertex v (a degenerate
+// triangle stores its repeated vertex twice, as in the reference), last[v] = the highest such slot.
+struct Builder {
+    Meshlet* cur = nullptr;
+    std::vector<uint32_t> slots, last, touched;
+    void reset(Meshlet* m) { for (uint32_t v : touched) slots[v] = 0; touched.clear(); cur = m; }
+    uint32_t reuse(const uint32_t tri[3]) const { return slots[tri[0]] + slots[tri[1]] + slots[tri[2]]; }       // ComputeReuse :220-236
+    bool add(const uint32_t tri[3], uint32_t maxVerts, uint32_t maxPrims) {                                     // AddToMeshlet :490-539
+        Meshlet& m = *cur;
+        if (m.verts.size() == maxVerts || m.packedTris.size() == maxPrims) return false;
+        const uint32_t fresh = 3u - reuse(tri);                          // unsigned, like the reference's --newCount per matching slot
+        if ((uint64_t)m.verts.size() + (uint64_t)fresh > maxVerts) return false;   // size_t + uint32 there: a wrapped `fresh` (repeated vertices) rejects
+        uint32_t local[3];
+        for (int j = 0; j < 3; ++j) local[j] = slots[tri[j]] ? last[tri[j]] : 0xffffffffu;      // look-ups see the list BEFORE this triangle's pushes
+        for (int j = 0; j < 3; ++j) if (local[j] == 0xffffffffu) {
+            local[j] = (uint32_t)m.verts.size(); m.verts.push_back(tri[j]);
+            if (!slots[tri[j]]) touched.push_back(tri[j]);
+            slots[tri[j]]++; last[tri[j]] = local[j];
+        }
+        m.packedTris.push_back((local[0] & 1023u) | ((local[1] & 1023u) << 10) | ((local[2] & 1023u) << 20));   // i0:10 | i1:10 | i2:10
+        return true;
     }
-    m.packedTris.push_back((local[0] & 1023u) | ((local[1] & 1023u) << 10) | ((local[2] & 1023u) << 20));   // i0:10 | i1:10 | i2:10
-    return true;
+    bool full(uint32_t maxVerts, uint32_t maxPrims) const { return cur->verts.size() == maxVerts || cur->packedTris.size() == maxPrims; }
+};
+
+static float score(const Builder& b, const Sphere& s, P3 axis, const uint32_t tri[3], const P3 v[3]) {      // ComputeScore :251-283
+    const float reuseScore = 1.f - ((float)b.reuse(tri) / 3.0f);
+    float maxSq = 0.f;
+    for (int j = 0; j < 3; ++j) { const P3 d = sub(s.c, v[j]); maxSq = std::fmax(maxSq, dot(d, d)); }
+    const float locScore = std::log2(maxSq / (s.r * s.r) + 1.f);          // XMVectorLog = base-2 logarithm
+    const float oriScore = (-dot(face_normal(v[0], v[1], v[2]), axis) + 1.f) / 2.0f;
+    return (0.334f * reuseScore + 0.333f * locScore) + 0.333f * oriScore;
 }
 
-static float score(const Meshlet& m, const Sphere& s, P3 axis, const uint32_t tri[3], const P3 v[3]) {      // ComputeScore :251-280
-    uint32_t reuse = 0;
-    for (uint32_t u : m.verts) for (int j = 0; j < 3; ++j) if (u == tri[j]) ++reuse;
-    const float reuseScore = 1.f - (float)reuse / 3.f;
-    float maxSq = 0.f;
-    for (int j = 0; j < 3; ++j) { const P3 d = sub(s.c, v[j]); maxSq = std::max(maxSq, dot(d, d)); }
-    const float locScore = std::log(maxSq / (s.r * s.r) + 1.f);
-    const float oriScore = (1.f - dot(face_normal(v[0], v[1], v[2]), axis)) * 0.5f;
-    return 0.334f * reuseScore + 0.333f * locScore + 0.333f * oriScore;
-}
+struct Cand { uint32_t tri; float score; };
 
 static void meshletize(uint32_t maxVerts, uint32_t maxPrims, const uint32_t* idx, uint32_t indexCount, const P3* pos, uint32_t vertexCount,
                        std::vector<Meshlet>& out) {
     const uint32_t triCount = indexCount / 3;
     out.clear();
-    if (!triCount) return;
+    if (!triCount || vertexCount < 3) return;                             // vertexCount / 3 buckets: the reference divides by zero below 3 vertices
     std::vector<uint32_t> adj;
     build_adjacency(idx, triCount, pos, vertexCount, adj);
     std::vector<uint8_t> done(triCount, 0), queued(triCount, 0);
-    std::vector<std::pair<uint32_t, float>> cand;     // sorted by descending score: the best (lowest) is taken from the back
+    std::vector<uint32_t> queuedList;                                     // members of `queued`, for the clears
+    auto clear_queued = [&]() { for (uint32_t t : queuedList) queued[t] = 0; queuedList.clear(); };
+    auto enqueue = [&](uint32_t t) { if (!queued[t]) { queued[t] = 1; queuedList.push_back(t); } };
+    std::vector<Cand> cand;                                               // a stack: the best (lowest score) candidate is at the back
     std::vector<P3> mpos, mnrm;
+    out.reserve(triCount / 32 + 2);
     out.emplace_back();
-    Sphere sphere{{0, 0, 0}, 0}; P3 axis{0, 0, 1};
+    Builder b; b.slots.assign(vertexCount, 0); b.last.assign(vertexCount, 0); b.reset(&out.back());
+    Sphere sphere{{0, 0, 0}, 0}; P3 axis{0, 0, 0};
     uint32_t seed = 0;
-    cand.push_back({0u, 0.f}); queued[0] = 1;
+    cand.push_back({0u, 0.f}); enqueue(0);
+    auto next_meshlet = [&]() { mpos.clear(); mnrm.clear(); clear_queued(); };
     while (!cand.empty()) {
-        const uint32_t t = cand.back().first; cand.pop_back();
+        const uint32_t t = cand.back().tri; cand.pop_back();
         const uint32_t tri[3] = {idx[t * 3 + 2], idx[t * 3 + 1], idx[t * 3]};          // reversed winding on insert
-        Meshlet* cur = &out.back();
-        if (try_add(*cur, tri, maxVerts, maxPrims)) {
+        if (b.add(tri, maxVerts, maxPrims)) {
             done[t] = 1;
             const P3 p[3] = {pos[tri[0]], pos[tri[1]], pos[tri[2]]};
             mpos.push_back(p[0]); mpos.push_back(p[1]); mpos.push_back(p[2]);
             mnrm.push_back(face_normal(p[0], p[1], p[2]));
-            sphere = bounding_sphere(mpos.data(), mpos.size());
-            cur->bounds = sphere;
-            axis = normalized(bounding_sphere(mnrm.data(), mnrm.size()).c);
+            sphere = bounding_sphere(mpos.data(), (uint32_t)mpos.size());
+            b.cur->bounds = sphere;
+            axis = normalized(bounding_sphere(mnrm.data(), (uint32_t)mnrm.size()).c);
             for (int e = 0; e < 3; ++e) {
                 const uint32_t n = adj[(size_t)t * 3 + e];
                 if (n == 0xffffffffu || done[n] || queued[n]) continue;
-                cand.push_back({n, FLT_MAX}); queued[n] = 1;
+                cand.push_back({n, FLT_MAX}); enqueue(n);
             }
-            for (auto& c : cand) {
-                const uint32_t ci[3] = {idx[c.first * 3], idx[c.first * 3 + 1], idx[c.first * 3 + 2]};
+            for (Cand& c : cand) {
+                const uint32_t ci[3] = {idx[c.tri * 3], idx[c.tri * 3 + 1], idx[c.tri * 3 + 2]};
                 const P3 cv[3] = {pos[ci[0]], pos[ci[1]], pos[ci[2]]};
-                c.second = score(*cur, sphere, axis, ci, cv);
+                c.score = score(b, sphere, axis, ci, cv);
             }
-            if (cur->verts.size() == maxVerts || cur->packedTris.size() == maxPrims) {
-                // meshlet full: the last candidate seeds the next meshlet, everything else goes back to the pool
-                mpos.clear(); mnrm.clear();
-                for (auto& c : cand) queued[c.first] = 0;
-                if (!cand.empty()) { const auto keep = cand.back(); cand.assign(1, keep); queued[keep.first] = 1; }
-                out.emplace_back();
+            if (b.full(maxVerts, maxPrims)) {
+                // meshlet full: the candidate at the back seeds the next meshlet, the others return to the pool
+                next_meshlet();
+                if (!cand.empty()) { const Cand keep = cand.back(); cand.assign(1, keep); enqueue(keep.tri); }
+                out.emplace_back(); b.reset(&out.back());
             } else {
-                std::stable_sort(cand.begin(), cand.end(), [](const std::pair<uint32_t, float>& a, const std::pair<uint32_t, float>& b) { return a.second > b.second; });
+                for (size_t i = 1; i < cand.size(); ++i) {                 // descending by score, ties keep their order
+                    const Cand x = cand[i]; size_t j = i;
+                    while (j > 0 && x.score > cand[j - 1].score) { cand[j] = cand[j - 1]; --j; }
+                    cand[j] = x;
+                }
             }
-        } else if (cand.empty()) {
-            mpos.clear(); mnrm.clear();
-            out.emplace_back();
-            // the triangle that did not fit is still pending: it becomes the seed below (done[t] is still 0)
-            queued[t] = 0;
-        } else {
-            queued[t] = 0;      // could not be added to this meshlet; it stays available for a later one
+        } else if (cand.empty()) {                                          // did not fit and nothing else is waiting: start a new meshlet (t is not
+            next_meshlet();                                                 // marked done, so the seed search below finds it again)
+            out.emplace_back(); b.reset(&out.back());
         }
         if (cand.empty()) {
             while (seed < triCount && done[seed]) ++seed;
             if (seed == triCount) break;
-            cand.push_back({seed, 0.f}); queued[seed] = 1;
+            cand.push_back({seed, 0.f}); enqueue(seed);
         }
     }
-    while (!out.empty() && out.back().packedTris.empty()) out.pop_back();
+    if (!out.empty() && out.back().packedTris.empty()) out.pop_back();
 }
 
 } // namespace

@@ -73,7 +73,8 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 // items: 44.9 / 44.5 / 45.5 / 46.3 / 51.4 / 55.0 / 58.6 -- with 8192 persistent waves a 512-item chunk is a quarter of a
 // wave's whole share of a 4K list and the kernel ends on the waves that drew a late one.  Round 2, per kernel
 // (gpurun_out/ab_r2_1.log): extend 12.3 ms at 64 items / 12 lanes, 13.1 at 128 items, 12.6 at 32 lanes; shadow, whose
-// refill is two coalesced loads, 12.2 ms at 64 / 12, 11.8 at 32 lanes, 11.5 at 128 items.
+// refill is two coalesced loads, 12.2 ms at 64 / 12, 11.8 at 32 lanes, 11.5 at 128 items; with the LDS node copy 11.0 / 11.2 / 11.5 ms at
+// 24 / 32 / 40 lanes and 11.6 at 256 items (gpurun_out/ab_r2_3.log).
 #ifndef INCR_EXTEND_CHUNK
 #define INCR_EXTEND_CHUNK 64
 #endif
@@ -84,7 +85,7 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 #define INCR_EXTEND_REFILL 16
 #endif
 #ifndef INCR_SHADOW_REFILL
-#define INCR_SHADOW_REFILL 32
+#define INCR_SHADOW_REFILL 24
 #endif
 static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
 static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;

@@ -25,7 +25,8 @@ def generate_meshlets(scene, max_verts=MAX_MESHLET_VERTS, max_prims=MAX_MESHLET_
             n = p["index_count"]
             stride = scene.accessors[p["index"]][2]
             idx = scene.accessor_array(p["index"], np.uint16 if stride == 2 else np.uint32, 1, n).astype(np.uint32).ravel()
-            nverts = int(idx.max()) + 1 if n else 0
+            # positions.size() of the POSITION accessor (scene.cpp:1531-1542): the adjacency hash has vertexCount / 3 buckets
+            nverts = max(int(p.get("vertex_count", 0)), int(idx.max()) + 1 if n else 0)
             pos = np.ascontiguousarray(scene.accessor_array(p["position"], np.float32, 3, nverts))
             idx = np.ascontiguousarray(idx)
             handle = C.c_void_p()

@@ -468,7 +468,7 @@ def load_gltf(path, load_images=True, max_texture_size=None):
                 pos = s.accessor_array(at["POSITION"], np.float32, 3, pos_acc["count"])
                 prims.append(dict(index=p["indices"], position=at["POSITION"], uv=at.get("TEXCOORD_0", -1),
                                   normal=at.get("NORMAL", -1), tangent=at.get("TANGENT", -1), material=p.get("material", 0),
-                                  index_count=g["accessors"][p["indices"]]["count"], sphere=_bounding_sphere(pos)))
+                                  index_count=g["accessors"][p["indices"]]["count"], vertex_count=int(pos_acc["count"]), sphere=_bounding_sphere(pos)))
             if mesh.get("name", "").startswith("decal"):          # scene.cpp:281: decal meshes live in their own entity list
                 s.decal_primitives.extend((p, world) for p in prims)
             else:

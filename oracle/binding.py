@@ -105,6 +105,23 @@ def prefilter_normal_roughness(normalmap, metallic_roughness):
     return out_n, out_m
 
 
+def meshletize(indices, positions, max_verts=64, max_prims=126):
+    """oracle/oracle_meshlet.cpp: MeshUtils::Meshletize restated.  Returns dict(counts [n,4] = vertexBegin, vertexCount,
+    triangleBegin, triangleCount; spheres [n,4]; vertex_indices; packed_triangles)."""
+    L = lib()
+    L.orc_meshletize.restype = C.c_void_p
+    L.orc_meshletize.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.orc_meshlets_copy.argtypes = [C.c_void_p] * 5; L.orc_meshlets_free.argtypes = [C.c_void_p]
+    idx = np.ascontiguousarray(indices, dtype=np.uint32).ravel(); pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    nm, nv, nt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    h = L.orc_meshletize(idx.ctypes.data, idx.size, pos.ctypes.data, pos.shape[0], max_verts, max_prims, C.byref(nm), C.byref(nv), C.byref(nt))
+    counts = np.zeros((max(nm.value, 1), 4), np.uint32); spheres = np.zeros((max(nm.value, 1), 4), np.float32)
+    vi = np.zeros(max(nv.value, 1), np.uint32); tri = np.zeros(max(nt.value, 1), np.uint32)
+    L.orc_meshlets_copy(h, counts.ctypes.data, spheres.ctypes.data, vi.ctypes.data, tri.ctypes.data)
+    L.orc_meshlets_free(h)
+    return dict(counts=counts[:nm.value], spheres=spheres[:nm.value], vertex_indices=vi[:nv.value], packed_triangles=tri[:nt.value])
+
+
 def _fa(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 

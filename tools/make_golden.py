@@ -55,6 +55,13 @@ for n in (2, 3, 4):
     stats.append([r["stats"].camera_rays, r["stats"].bounce_rays, r["stats"].sky_shadow_rays, r["stats"].light_shadow_rays, r["stats"].shaded_hits])
 np.savez_compressed(os.path.join(G, "helmet_64.npz"), origins=o, dirs=dr, ids=ids, tuv=tuv, target1=target1, history4=hist,
                     stats=np.array(stats, dtype=np.int64), view=np.asarray(view.view_transform), proj=np.asarray(view.projection_transform))
+# 2b. MeshUtils::Meshletize of the helmet primitive from the oracle restatement (oracle/oracle_meshlet.cpp): meshlet ranges,
+#     bounding spheres, vertex lists and packed triangles -- the ids the visibility buffer encodes
+p0 = s.mesh_primitives[0][0]
+midx = s.accessor_array(p0["index"], np.uint16, 1, p0["index_count"]).astype(np.uint32).ravel()
+mpos = np.ascontiguousarray(s.accessor_array(p0["position"], np.float32, 3, p0["vertex_count"]))
+mm = ob.meshletize(midx, mpos, 64, 126)
+np.savez_compressed(os.path.join(G, "helmet_meshlets.npz"), **mm)
 print("golden written:", os.listdir(G))
 
 # 3. scalar known-answer tables: float results stored as uint32 bit patterns

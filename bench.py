@@ -32,6 +32,17 @@ B_HIT, B_PX = 378, 24
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
+def kernel_source_hash():
+    """Stamp of the path-tracing kernel sources + BVH layout: ties a PMC traffic measurement to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, PKG, "csrc")
+    for f in ("pathtrace_wf.hip", "pt_traverse.h", "pt_shade.h", "pt_device.h", "pt_params.h", "device_types.h", "scene_build.cpp", "Makefile"):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def bytes_per_ray(num_tris):
     return 32 + int(np.ceil(np.log2(max(num_tris, 2)))) * 32 + 36 + 16
 
@@ -127,6 +138,22 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ms = float(tt.item()) / steps * 1e3
+    # per-pass GPU time of one more frame (events on the submission stream) and the algorithmic bytes each pass moves per pixel
+    # (SURVEY.md 8d): visibility 8 (id + depth written), G-buffer 4 + 16, fused lighting 16 read + 8 colour rw (unfused: 3 x 24),
+    # dynamic sky 4 + 4, TAA 12 + 4 (+ 4 LDR when the tonemap is fused), tonemap 4 + 4
+    per_pass = None
+    if world == 1:
+        rr.set_profiling(True); rr.render(view); times = rr.pass_times(); rr.set_profiling(False)
+        bpp = {"visibility": 8, "gbuffer": 20, "deferred_lighting": 24, "sky_lighting": 24, "direct_lighting": 24, "clustered_lighting": 24,
+               "dynamic_sky": 8, "environmentmap": 8, "taa_resolve": 20, "tonemap": 8, "hbao": 13}
+        per_pass = {}
+        for name, t in times:
+            e = per_pass.setdefault(name, {"ms": 0.0})
+            e["ms"] = round(e["ms"] + t, 4)
+        for name, e in per_pass.items():
+            if name in bpp and e["ms"] > 0:
+                e["algorithmic_GBps"] = round(float(W) * H * bpp[name] / (e["ms"] * 1e-3) / 1e9, 1)
+    host_s, g_frames, g_updates, g_rebuilds = rr.frame_info()
     counts = ctx.download(rr.surface_ptr(A.SURFACE_BATCH_COUNTS), (2,), np.uint32)
     raw = ctx.download(rr.surface_ptr(A.SURFACE_RAY_STATS), (C.sizeof(A.RayStats),), np.uint8)
     rays = A.RayStats.from_buffer_copy(raw.tobytes()).light_shadow_rays // (steps + warmup)
@@ -136,7 +163,8 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
             "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
             "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA"
                         % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1])),
-            "passes": "batch_cull, light_cull, visibility, gbuffer, sky_lighting, direct_lighting, clustered_lighting, dynamic_sky, taa_resolve, tonemap",
+            "passes": "batch_cull, light_cull, visibility, gbuffer, deferred_lighting (sky + sun + clustered fused), dynamic_sky, taa_resolve (+ tonemap fused)",
+            "per_pass": per_pass, "host_us_per_frame": round(host_s * 1e6, 1),
             "sun_shadow_rays_per_frame": int(rays), "algorithmic_bytes_per_frame": int(alg),
             "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
@@ -306,14 +334,19 @@ def main():
                                         "achieved": round(frame_alg_bytes / (call_ms * 1e-3) / 1e9, 2)},
                          "kernel_ms_per_step": {k.split("::")[1]: round(v[0] / args.steps, 4) for k, v in per_kernel.items()}},
         }
+        # measured HBM bytes of the dominant kernel: only from a PMC run (tools/pmc.sh) of THESE kernel sources on this workload
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         if os.path.exists(traffic_file):
             try:
                 with open(traffic_file) as f:
                     tj = json.load(f)
-                if tj.get("scene") == args.scene and tj.get("resolution") == [W, H]:
-                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                entry = tj.get("kernels", {}).get(dominant)
+                default_workload = args.scene == "sponza" and [W, H] == [3840, 2160] and not args.no_direct_lighting and args.viewmode == 0
+                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload:
+                    out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tj.get("source")
+                else:
+                    out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources or another workload: not attached"
             except Exception:
                 pass
         if raster_out is not None:

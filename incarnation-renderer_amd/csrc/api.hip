@@ -20,6 +20,9 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
                                              const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream);
+extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
+                                          const float* srgbLut, hipStream_t stream);
+extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
@@ -175,12 +178,12 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 }
 
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned).
-// 176 B of path state + raysPerPath x 32 B of shadow-ray queue per pixel: 3.6 GB at 4K -- 1.2 % of the 288 GB.
+// 220 B of path state + raysPerPath x 32 B of shadow-ray queue per pixel: 3.9 GB at 4K -- 1.4 % of the 288 GB.
 static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t stream) {
     if (numPaths == 0) numPaths = 1;
     const uint64_t n = (numPaths + 255) & ~255ull;
     const uint64_t rayCap = std::min<uint64_t>(n * ctx->raysPerPath, 0xfffffff0ull);
-    const uint64_t need = n * (16 * 5 + 96 + 4 * 3) + 4096 + (rayCap + 1) * 32;
+    const uint64_t need = n * (32 * 2 + 16 * 3 + 96 + 4 * 3) + 4096 + (rayCap + 1) * 32;
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
@@ -190,7 +193,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t
     uint8_t* p = (uint8_t*)ctx->wfBlock;
     WfBuffers& w = ctx->wf;
     w.counters = (uint32_t*)p; p += 4096;
-    w.rayO = (float4*)p; p += n * 16; w.rayD = (float4*)p; p += n * 16; w.color = (float4*)p; p += n * 16; w.atten = (float4*)p; p += n * 16;
+    w.extA = (float4*)p; p += n * 32; w.extB = (float4*)p; p += n * 32; w.color = (float4*)p; p += n * 16; w.atten = (float4*)p; p += n * 16;
     w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 96;
     w.liveA = (uint32_t*)p; p += n * 4; w.liveB = (uint32_t*)p; p += n * 4; w.hitList = (uint32_t*)p; p += n * 4;
     w.rayQ = (float4*)p; w.rayCap = (uint32_t)rayCap;
@@ -240,25 +243,73 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
     if (!rc) rc = upload_vec(&sc->dLightIndices, sc->host.lightIndices.data(), sc->host.lightIndices.size());
     if (!rc) rc = upload_vec(&sc->dLightTransforms, (const float*)sc->host.lightTransforms.data(), sc->host.lightTransforms.size() * 16);
+    // Textures: level 0 as handed over + the mip chain the raster passes sample (texture_mips.hip), all levels in one allocation
     std::vector<DeviceTexture> texs(desc->num_textures);
+    auto mip_levels = [](uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 4 && h >= 4) { ++n; w >>= 1; h >>= 1; } return n ? n : 1u; };      // scene.cpp:1072-1081
+    auto level_dim = [](uint32_t d, uint32_t l) { return std::max(d >> l, 1u); };
     for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
         const incr_texture_desc& t = desc->textures[i];
         if (!t.texels || !t.width || !t.height || t.format > INCR_TEX_BGRA8_SWIZZLE_RG) { rc = fail(INCR_ERR_INVALID_ARGUMENT, "texture %u invalid", i); break; }
         const size_t bytes = (size_t)t.width * t.height * 4;
+        const uint32_t mips = mip_levels(t.width, t.height);
+        size_t chainTexels = 0;
+        for (uint32_t l = 0; l < mips; ++l) chainTexels += (size_t)level_dim(t.width, l) * level_dim(t.height, l);
         void* d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
+        hipError_t e = hipMalloc(&d, chainTexels * 4);
         if (e == hipSuccess) e = hipMemcpy(d, t.texels, bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "texture upload failed: %s", hipGetErrorString(e)); break; }
         sc->dTexels.push_back(d);
-        sc->textureBytes += bytes;
+        sc->textureBytes += chainTexels * 4;
         texs[i].texels = (const uint8_t*)d; texs[i].width = t.width; texs[i].height = t.height; texs[i].format = t.format;
         texs[i].pad[0] = texs[i].pad[1] = texs[i].pad[2] = 0;
         // pad[0] = 1: every alpha texel is 255, so a bilinear alpha sample is 1 up to rounding and can never fail the
-        // 0.5 alpha clip of the visibility pass (raster.hip skips the sample for such textures)
+        // 0.5 alpha clip of the visibility pass (raster.hip skips the sample for such textures); the mips of such a texture are opaque too
         bool opaque = true;
         for (size_t k = 3; k < bytes && opaque; k += 4) opaque = t.texels[k] == 255;
         texs[i].pad[0] = opaque ? 1u : 0u;
+        texs[i].pad[1] = mips;
     }
+    // vMF-filtered chains for the normal + metallic-roughness pair of a material (scene.cpp:1157-1320), box chains for the rest
+    std::vector<uint8_t> haveChain(desc->num_textures, 0);
+    for (uint32_t mi = 0; mi < desc->num_materials && !rc; ++mi) {
+        const int32_t nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
+        if (nt < 0 || mt < 0 || nt == mt || haveChain[(size_t)nt] || haveChain[(size_t)mt]) continue;
+        const DeviceTexture& N = texs[(size_t)nt]; const DeviceTexture& M = texs[(size_t)mt];
+        if (N.width != M.width || N.height != M.height || N.pad[1] < 2 || N.format != INCR_TEX_RG_SNORM || M.format != INCR_TEX_BGRA8_SWIZZLE_RG) continue;
+        if ((N.width >> (N.pad[1] - 1)) << (N.pad[1] - 1) != N.width || (N.height >> (N.pad[1] - 1)) << (N.pad[1] - 1) != N.height) continue;      // 2x2 footprints need even levels
+        size_t chainTexels = 0;
+        for (uint32_t l = 0; l < N.pad[1]; ++l) chainTexels += (size_t)(N.width >> l) * (N.height >> l);
+        void* tmpN = nullptr; void* tmpM = nullptr;
+        hipError_t e = hipMalloc(&tmpN, chainTexels * 4);
+        if (e == hipSuccess) e = hipMalloc(&tmpM, chainTexels * 4);
+        if (e == hipSuccess) {
+            incr_prefilter_normal_roughness_desc pd = {};
+            pd.normalmap = N.texels; pd.metallic_roughness = M.texels; pd.width = N.width; pd.height = N.height; pd.num_mips = N.pad[1];
+            pd.out_normalmap = (uint8_t*)tmpN; pd.out_metallic_roughness = (uint8_t*)tmpM;
+            pd.reserved = 1;        // exact summation order: the chain equals the oracle's bit for bit
+            rc = incr_prefilter_normal_roughness(ctx, &pd, nullptr);
+            const size_t first = (size_t)N.width * N.height;
+            if (!rc) e = incr_launch_mip_adopt_vmf((const uint32_t*)tmpN, (const uint32_t*)tmpM, (uint32_t*)N.texels, (uint32_t*)M.texels, first, chainTexels - first, nullptr);
+            if (!rc && e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (tmpN) (void)hipFree(tmpN);
+        if (tmpM) (void)hipFree(tmpM);
+        if (!rc && e != hipSuccess) rc = fail(INCR_ERR_HIP, "vMF mip chain failed: %s", hipGetErrorString(e));
+        haveChain[(size_t)nt] = haveChain[(size_t)mt] = 1;
+    }
+    for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
+        if (haveChain[i]) continue;
+        const DeviceTexture& T = texs[i];
+        uint32_t* level = (uint32_t*)T.texels;
+        for (uint32_t l = 0; l + 1 < T.pad[1]; ++l) {
+            const uint32_t sw = level_dim(T.width, l), sh = level_dim(T.height, l), dw = level_dim(T.width, l + 1), dh = level_dim(T.height, l + 1);
+            uint32_t* next = level + (size_t)sw * sh;
+            const hipError_t e = incr_launch_mip_box(level, sw, sh, next, dw, dh, T.format, ctx->srgbLut, nullptr);
+            if (e != hipSuccess) { rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); break; }
+            level = next;
+        }
+    }
+    if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
     if (!rc) rc = incr_raster_scene_upload(sc);
     if (rc) { incr_scene_destroy(ctx, sc); return rc; }

@@ -36,7 +36,7 @@ DI float4 vmf_texel(uint32_t n, uint32_t mr) {
     const float roughnessAlpha = (float)((mr >> 8) & 0xffu) * inv255;
     const float metalness = (float)((mr >> 16) & 0xffu) * inv255;
     const float invLambda = 0.5f * roughnessAlpha * roughnessAlpha;
-    const float exp2L = expf(-2.f / invLambda);
+    const float exp2L = pinned_exp_neg(-2.f / invLambda);
     const float cothLambda = invLambda > 0.1f ? (1.f + exp2L) / (1.f - exp2L) : 1.f;
     const float s = cothLambda - invLambda;
     return make_float4(s * sn.x, s * sn.y, s * sn.z, metalness);
@@ -95,6 +95,24 @@ __global__ __launch_bounds__(256) void vmf_level_kernel(const float4* __restrict
     vmf_store(s, count, outN + L.texelOffset + o, outMR + L.texelOffset + o);
 }
 
+// Exact-order variant (incr_prefilter_normal_roughness_desc::reserved = 1): every destination texel walks its 2^k x 2^k footprint of
+// the BASE level with one running sum, y outer / x inner, exactly as the shader (and the oracle) does -- O(texels x levels), but
+// bit-identical chains.  The scene's textures are built with it: the raster passes sample these levels and their G-buffers are
+// compared with the oracle's bit for bit.
+__global__ __launch_bounds__(64) void vmf_level_exact_kernel(const uint32_t* __restrict__ srcN, const uint32_t* __restrict__ srcMR, uint32_t W, uint32_t mip,
+                                                             VmfLevel L, uint32_t* __restrict__ outN, uint32_t* __restrict__ outMR) {
+    const uint32_t x = blockIdx.x * 8u + (threadIdx.x & 7u), y = blockIdx.y * 8u + (threadIdx.x >> 3);
+    if (x >= L.w || y >= L.h) return;
+    const uint32_t fp = 1u << mip;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t yy = 0; yy < fp; ++yy) {
+        const uint64_t row = (uint64_t)(y * fp + yy) * W + (uint64_t)x * fp;
+        for (uint32_t xx = 0; xx < fp; ++xx) s = add4(s, vmf_texel(srcN[row + xx], srcMR[row + xx]));
+    }
+    const uint64_t o = (uint64_t)y * L.w + x;
+    vmf_store(s, (float)(fp * fp), outN + L.texelOffset + o, outMR + L.texelOffset + o);
+}
+
 uint32_t compressed_mip_count(uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 4 && h >= 4) { ++n; w >>= 1; h >>= 1; } return n; }   // CalcMipCount(w, h, true), backend-d3d12.h:456-471
 
 } // namespace
@@ -134,6 +152,16 @@ int incr_prefilter_normal_roughness(incr_context* ctx, const incr_prefilter_norm
     vmf_mip0_kernel<<<dim3((uint32_t)((texels + 255) / 256)), dim3(256), 0, s>>>(srcN, srcMR, outN, outMR, texels);
     HIP_TRY(hipGetLastError());
     if (mips == 1) return INCR_OK;
+    if (d->reserved == 1u) {      // exact order
+        hipError_t e = hipSuccess;
+        for (uint32_t m = 1; m < mips && e == hipSuccess; ++m) {
+            vmf_level_exact_kernel<<<dim3((L[m].w + 7) / 8, (L[m].h + 7) / 8), dim3(64), 0, s>>>(srcN, srcMR, W, m, L[m], outN, outMR);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(INCR_ERR_HIP, "prefilter_normal_roughness: %s", hipGetErrorString(e));
+        return INCR_OK;
+    }
     float4* sums = nullptr;
     if (sumTexels) HIP_TRY(hipMalloc((void**)&sums, sumTexels * sizeof(float4)));
     vmf_mip1_kernel<<<dim3((L[1].w + 31) / 32, (L[1].h + 7) / 8), dim3(256), 0, s>>>(srcN, srcMR, W, L[1], mips > 2 ? sums + sumOff[1] : nullptr, outN, outMR);

@@ -7,9 +7,14 @@
 // stream, so Result::m_task is already complete when Execute returns and m_status carries the error code the reference
 // never had (it asserts: inc/common.h:113-148).
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <future>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../../include/incr.h"
 
@@ -46,6 +51,10 @@ struct FConfig {
     float Pathtracing_CameraFocalLength = 7.f;
     float Turbidity = 2.f;
     int   StorageRounding = 0;          // not in the reference: typed-UAV store rounding (incr_pathtrace_desc::storage_rounding)
+    // not in the reference: how the frame is issued (results are bit-identical either way)
+    bool  FusePasses = true;            // sky + sun + clustered lighting as one kernel, tonemap inside the TAA resolve
+    int   RecordThreads = 0;            // > 0: passes are recorded by that many host threads and submitted in token order (PPL tasks there)
+    bool  UseGraph = false;             // raster frame captured into a HIP graph, updated in place and replayed every frame
 };
 
 // inc/renderer.h FView
@@ -79,28 +88,82 @@ struct FScene {
 
 namespace RenderJob {
 
-// job-sync.h:8-61: token-ordered submission.  One HIP stream is the DIRECT queue; tokens are handed out in call order
-// and Execute launches under the mutex, so passes recorded from several host threads still reach the stream in order.
+// job-sync.h:8-70: token-ordered submission + the task a pass returns.  There, every pass takes a token on the calling
+// thread (= the order of the Execute calls in Renderer::Render), records its command list on a PPL task and submits it to
+// the DIRECT queue when the CPU fence says its predecessor has been submitted; Render joins the tasks at the end of the
+// frame (when_all, renderer.cpp:2039-2041).  Here: one HIP stream is the DIRECT queue, "recording" is the marshalling
+// of the pass's C-ABI descriptor, a small worker pool stands in for the PPL scheduler (m_threads == 0: record inline on
+// the caller's thread), and Execute blocks until every earlier token has launched.
+struct Result {                                    // job-sync.h:66-70: the task that was kicked off
+    std::shared_future<int> m_task;
+    int m_status = INCR_OK;                        // valid once the task is done (inline recording: immediately)
+    bool m_taskDone = true;
+    int wait() { if (m_task.valid()) { m_status = m_task.get(); m_taskDone = true; } return m_status; }
+};
+
 struct Sync {
     incr_context* m_ctx = nullptr;
     incr_stream m_stream = nullptr;
-    size_t m_cpuFenceValue = 0, m_completed = 0;
+    size_t m_cpuFenceValue = 0, m_completed = 0;   // last token handed out / last token submitted (the CPU fence)
     int m_firstError = 0;
     std::string m_firstErrorMessage;
     std::mutex m_mutex;
+    std::condition_variable m_turn;
+    // recording pool
+    int m_threads = 0;
+    std::vector<std::thread> m_workers;
+    std::deque<std::packaged_task<int()>> m_queue;
+    std::mutex m_queueMutex;
+    std::condition_variable m_queueCv;
+    bool m_stop = false;
+    // optional per-pass GPU timing (incr_renderer_set_profiling): one event after every submission of the frame
+    bool m_profile = false;
+    std::vector<std::pair<std::string, void*>> m_marks;     // (pass, hipEvent_t) of the current frame; [0] = frame start
+    void BeginFrameProfile();
+    void MarkPass(const char* passName);
+
+    ~Sync() { SetThreads(0); }
+    void SetThreads(int n) {
+        if (n == m_threads) return;
+        { std::lock_guard<std::mutex> l{m_queueMutex}; m_stop = true; }
+        m_queueCv.notify_all();
+        for (std::thread& t : m_workers) t.join();
+        m_workers.clear(); m_stop = false; m_threads = n;
+        for (int i = 0; i < n; ++i) m_workers.emplace_back([this] {
+            for (;;) {
+                std::packaged_task<int()> task;
+                { std::unique_lock<std::mutex> l{m_queueMutex};
+                  m_queueCv.wait(l, [this] { return m_stop || !m_queue.empty(); });
+                  if (m_queue.empty()) return;
+                  task = std::move(m_queue.front()); m_queue.pop_front(); }
+                task();
+            }
+        });
+    }
     size_t GetToken() { std::lock_guard<std::mutex> l{m_mutex}; return ++m_cpuFenceValue; }
-    template <class Fn> int Execute(size_t token, Fn&& launch) {
-        std::lock_guard<std::mutex> l{m_mutex};
-        (void)token;                                  // single recording thread: tokens already arrive in order
+    // Submits under the token order: waits until token - 1 has been submitted (job-sync.h:38-50), launches, signals.
+    template <class Fn> int Execute(size_t token, Fn&& launch, const char* passName = nullptr) {
+        std::unique_lock<std::mutex> l{m_mutex};
+        m_turn.wait(l, [&] { return m_completed + 1 >= token; });
         const int rc = launch();
+        if (m_profile) MarkPass(passName);
         if (rc != INCR_OK && m_firstError == INCR_OK) { m_firstError = rc; m_firstErrorMessage = incr_last_error(); }
-        ++m_completed;
+        m_completed = token;
+        l.unlock();
+        m_turn.notify_all();
         return rc;
     }
+    // Kicks off a pass's record-and-submit task: on the pool, or inline when there is none.
+    template <class Fn> Result Spawn(Fn&& record) {
+        Result r;
+        if (m_threads == 0) { r.m_status = record(); return r; }
+        std::packaged_task<int()> task(std::forward<Fn>(record));
+        r.m_task = task.get_future().share(); r.m_taskDone = false;
+        { std::lock_guard<std::mutex> l{m_queueMutex}; m_queue.push_back(std::move(task)); }
+        m_queueCv.notify_one();
+        return r;
+    }
 };
-
-// job-sync.h:66-70
-struct Result { bool m_taskDone = true; int m_status = INCR_OK; };
 
 Result UpdateTLAS_Execute(Sync* jobSync, const FScene* scene);       // UpdateTLASPass::Execute(Sync*, const FScene*)
 namespace UpdateTLASPass { inline Result Execute(Sync* jobSync, const FScene* scene) { return UpdateTLAS_Execute(jobSync, scene); } }
@@ -213,6 +276,11 @@ struct Desc {
 };
 Result Execute(Sync* jobSync, const Desc& passDesc, const bool bRequiresClear);
 }
+// FConfig::FusePasses: SkyLightingPass + DirectLightingPass + ClusteredLightingPass as one submission (incr_deferred_lighting);
+// any Desc may be NULL = that pass is skipped this frame, exactly as Render skips it
+namespace DeferredLightingPass {
+Result Execute(Sync* jobSync, const SkyLightingPass::Desc* sky, const DirectLightingPass::Desc* direct, const ClusteredLightingPass::Desc* clustered, const bool bRequiresClear);
+}
 namespace DynamicSkyPass {   // render-jobs/dynamic-sky.inl:3-14
 struct Desc {
     FShaderSurface* colorTarget; FShaderSurface* depthStencilTarget;
@@ -249,6 +317,7 @@ struct Desc {
     FConfig renderConfig;
     FShaderSurface* historySource = nullptr;        // the reference resolves in place; here last frame's accumulation buffer
     uint32_t rowBegin = 0, rowEnd = 0;              // not in the reference: rows this GPU resolves (0,0 = the whole frame)
+    FShaderSurface* tonemapTarget = nullptr;        // not in the reference: FConfig::FusePasses -- TonemapPass of `target` done by the resolve itself
 };
 Result Execute(Sync* jobSync, const Desc& passDesc);
 }

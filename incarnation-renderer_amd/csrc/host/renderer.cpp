@@ -4,6 +4,9 @@
 // through include/incr.h, exactly what a maintainer of the reference would link against.
 #include "render_jobs.h"
 
+#include <hip/hip_runtime_api.h>
+#include <chrono>
+
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -22,8 +25,21 @@ incr_view FView::ToIncr() const {
 
 namespace RenderJob {
 
+// per-pass GPU time: events recorded on the submission stream (HIP events see only that stream)
+void Sync::BeginFrameProfile() {
+    if (!m_profile) return;
+    for (auto& m : m_marks) (void)hipEventDestroy((hipEvent_t)m.second);
+    m_marks.clear();
+    MarkPass("frame_begin");
+}
+void Sync::MarkPass(const char* passName) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, (hipStream_t)m_stream);
+    m_marks.emplace_back(passName ? passName : "pass", (void*)e);
+}
+
 namespace {
-Result done(int rc) { Result r; r.m_taskDone = true; r.m_status = rc; return r; }
 incr_lighting_inputs lighting_inputs(const FScene* scene, const FSystemBuffer* view, FShaderSurface* color, FShaderSurface* depth, FShaderSurface* g0,
                                      FShaderSurface* g1, FShaderSurface* g2, const FConfig& c) {
     incr_lighting_inputs in = {};
@@ -39,12 +55,15 @@ incr_lighting_inputs lighting_inputs(const FScene* scene, const FSystemBuffer* v
 
 Result UpdateTLAS_Execute(Sync* jobSync, const FScene* scene) {           // update-tlas.inl:3-101
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     // transforms / visibility / root transform are unchanged since scene creation unless the owner passed new ones
-    return done(jobSync->Execute(token, [&] { return incr_update_bvh(jobSync->m_ctx, scene->m_incrScene, nullptr, nullptr, nullptr, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_update_bvh(jobSync->m_ctx, scene->m_incrScene, nullptr, nullptr, nullptr, jobSync->m_stream); }, "update_bvh");
+    });
 }
 
 Result PathTracing::Execute(Sync* jobSync, const Desc& p) {               // path-tracing.inl:17-299
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_pathtrace_desc d = {};
     d.scene = p.scene->m_incrScene;
     d.target_rgba16f = p.targetBuffer->m_devicePtr; d.history_r11g11b10 = p.historyBuffer->m_devicePtr;
@@ -58,20 +77,24 @@ Result PathTracing::Execute(Sync* jobSync, const Desc& p) {               // pat
     d.storage_rounding = p.renderConfig.StorageRounding;
     d.envmap_r11g11b10 = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;   // :203 envmapTextureIndex
     d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
-    return done(jobSync->Execute(token, [&] { return incr_pathtrace(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_pathtrace(jobSync->m_ctx, &d, jobSync->m_stream); }, "pathtrace");
+    });
 }
 
 Result TonemapPass::Execute(Sync* jobSync, const Desc& p) {               // tonemap.inl:11-136
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_tonemap_desc d = {};
     d.hdr_r11g11b10 = p.source->m_devicePtr; d.ldr_rgba8 = p.target->m_devicePtr;
     d.res_x = p.source->m_width; d.rows = p.source->m_height;
     d.exposure = p.renderConfig.Exposure; d.viewmode = p.renderConfig.Viewmode;
-    return done(jobSync->Execute(token, [&] { return incr_tonemap(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_tonemap(jobSync->m_ctx, &d, jobSync->m_stream); }, "tonemap");
+    });
 }
 
 Result BatchCullingPass::Execute(Sync* jobSync, const Desc& p) {          // batch-culling.inl:14-131
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_batch_cull_desc d = {};
     d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.default_list = (incr_draw_cmd*)p.batchArgsBuffer_Default->m_devicePtr;
@@ -80,11 +103,13 @@ Result BatchCullingPass::Execute(Sync* jobSync, const Desc& p) {          // bat
     d.render_stats = p.renderStatsBuffer ? (incr_render_stats*)p.renderStatsBuffer->m_devicePtr : nullptr;
     d.frustum_culling = p.renderConfig.FrustumCulling ? 1 : 0;
     d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // cs_meshlet_cull_main : cs_primitive_cull_main
-    return done(jobSync->Execute(token, [&] { return incr_batch_cull(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_batch_cull(jobSync->m_ctx, &d, jobSync->m_stream); }, "batch_cull");
+    });
 }
 
 Result LightCullingPass::Execute(Sync* jobSync, const Desc& p) {          // light-culling.inl:16-152
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_light_cull_desc d = {};
     d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.cluster_dim[0] = (uint32_t)p.renderConfig.LightClusterDimX; d.cluster_dim[1] = (uint32_t)p.renderConfig.LightClusterDimY;
@@ -93,11 +118,13 @@ Result LightCullingPass::Execute(Sync* jobSync, const Desc& p) {          // lig
     d.culled_light_lists = (uint32_t*)p.culledLightListsBuffer->m_devicePtr; d.light_grid = (incr_light_grid_data*)p.lightGridBuffer->m_devicePtr;
     d.culled_light_count = (uint32_t*)p.culledLightCountBuffer->m_devicePtr;
     d.render_stats = p.renderStatsBuffer ? (incr_render_stats*)p.renderStatsBuffer->m_devicePtr : nullptr;
-    return done(jobSync->Execute(token, [&] { return incr_light_cull(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_light_cull(jobSync->m_ctx, &d, jobSync->m_stream); }, "light_cull");
+    });
 }
 
 Result VisibilityPass::Execute(Sync* jobSync, const Desc& p) {            // visibility-pass.inl:19-197
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_visibility_desc d = {};
     d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.default_list = (const incr_draw_cmd*)p.indirectArgsBuffer_Default->m_devicePtr;
@@ -105,11 +132,13 @@ Result VisibilityPass::Execute(Sync* jobSync, const Desc& p) {            // vis
     d.counts = (const uint32_t*)p.indirectCountsBuffer->m_devicePtr;
     d.vis_buffer = (uint32_t*)p.visBufferTarget->m_devicePtr; d.depth_buffer = (float*)p.depthStencilTarget->m_devicePtr;
     d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // visibility-pass.inl:96-97
-    return done(jobSync->Execute(token, [&] { return incr_visibility(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_visibility(jobSync->m_ctx, &d, jobSync->m_stream); }, "visibility");
+    });
 }
 
 Result GBufferComputePass::Execute(Sync* jobSync, const Desc& p) {        // gbuffer-compute-pass.inl:17-123
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_gbuffer_desc d = {};
     d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.vis_buffer = (const uint32_t*)p.sourceVisBuffer->m_devicePtr;
@@ -117,11 +146,11 @@ Result GBufferComputePass::Execute(Sync* jobSync, const Desc& p) {        // gbu
     d.gbuffer_metallic_roughness_ao = (uint32_t*)p.gbufferTargets[2]->m_devicePtr;
     d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.storage_rounding = p.renderConfig.StorageRounding;
     d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1;                // USING_MESHLETS, gbuffer-compute-pass.inl:56
-    return done(jobSync->Execute(token, [&] { return incr_gbuffer(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_gbuffer(jobSync->m_ctx, &d, jobSync->m_stream); }, "gbuffer");
+    });
 }
 
-Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky-lighting.inl:21-150
-    const size_t token = jobSync->GetToken();
+static incr_sky_lighting_desc sky_desc(const SkyLightingPass::Desc& p) {
     incr_sky_lighting_desc d = {};
     d.in = lighting_inputs(p.scene, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
                            p.gbufferMetallicRoughnessAoTex, p.renderConfig);
@@ -134,33 +163,45 @@ Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky
     d.specular_ibl = p.renderConfig.EnableSpecularIBL ? 1 : 0;
     d.bent_normals = (p.renderConfig.EnableHBAO && p.bentNormalsTex) ? (const uint32_t*)p.bentNormalsTex->m_devicePtr : nullptr;
     d.use_bent_normals = p.renderConfig.UseBentNormals ? 1 : 0;          // sky-lighting.inl:65
-    return done(jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return d;
+}
+Result SkyLightingPass::Execute(Sync* jobSync, const Desc& p) {           // sky-lighting.inl:21-150
+    const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
+    const incr_sky_lighting_desc d = sky_desc(p);
+    return jobSync->Execute(token, [&] { return incr_sky_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }, "sky_lighting");
+    });
 }
 
 Result GBufferRasterPass::Execute(Sync* jobSync, const Desc& p) {         // gbuffer-raster-pass.inl:17-233
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_gbuffer_decals_desc d = {};
     d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
     d.gbuffer_basecolor = (uint32_t*)p.gbufferTargets[0]->m_devicePtr; d.gbuffer_normals = (uint32_t*)p.gbufferTargets[1]->m_devicePtr;
     d.gbuffer_metallic_roughness_ao = (uint32_t*)p.gbufferTargets[2]->m_devicePtr;
     d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_gbuffer_decals(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_gbuffer_decals(jobSync->m_ctx, &d, jobSync->m_stream); }, "gbuffer_decals");
+    });
 }
 
 Result HBAO::Execute(Sync* jobSync, const Desc& p) {                      // hbao.inl:16-105
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_hbao_desc d = {};
     d.scene = p.sceneConstantBuffer->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.depth_buffer = (const float*)p.depthStencil->m_devicePtr; d.gbuffer_normals = (const uint32_t*)p.gbufferNormals->m_devicePtr;
     d.ao_target = (uint8_t*)p.aoTarget->m_devicePtr; d.bent_normal_target = (uint32_t*)p.bentNormalTarget->m_devicePtr;
     d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
     d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_hbao(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_hbao(jobSync->m_ctx, &d, jobSync->m_stream); }, "hbao");
+    });
 }
 
 Result ForwardLightingPass::Execute(Sync* jobSync, const Desc& p) {       // forward-pass.inl:17-190
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_forward_lighting_desc d = {};
     d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (float*)p.depthStencilTarget->m_devicePtr;
@@ -171,21 +212,27 @@ Result ForwardLightingPass::Execute(Sync* jobSync, const Desc& p) {       // for
     d.diffuse_ibl = p.renderConfig.EnableDiffuseIBL ? 1 : 0; d.specular_ibl = p.renderConfig.EnableSpecularIBL ? 1 : 0;
     d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
     d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_forward_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_forward_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }, "forward_lighting");
+    });
 }
 
-Result DirectLightingPass::Execute(Sync* jobSync, const Desc& p) {        // direct-lighting.inl:18-112
-    const size_t token = jobSync->GetToken();
+static incr_direct_lighting_desc direct_desc(const DirectLightingPass::Desc& p) {
     incr_direct_lighting_desc d = {};
     d.in = lighting_inputs(p.sceneConstantBuffer, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
                            p.gbufferMetallicRoughnessAoTex, p.renderConfig);
     d.directional_light_index = p.directionalLightIndex;
     d.ray_stats = p.rayStatsBuffer ? (incr_ray_stats*)p.rayStatsBuffer->m_devicePtr : nullptr;
-    return done(jobSync->Execute(token, [&] { return incr_direct_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return d;
+}
+Result DirectLightingPass::Execute(Sync* jobSync, const Desc& p) {        // direct-lighting.inl:18-112
+    const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
+    const incr_direct_lighting_desc d = direct_desc(p);
+    return jobSync->Execute(token, [&] { return incr_direct_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }, "direct_lighting");
+    });
 }
 
-Result ClusteredLightingPass::Execute(Sync* jobSync, const Desc& p, const bool bRequiresClear) {      // clustered-lighting.inl:19-132
-    const size_t token = jobSync->GetToken();
+static incr_clustered_lighting_desc clustered_desc(const ClusteredLightingPass::Desc& p, const bool bRequiresClear) {
     incr_clustered_lighting_desc d = {};
     d.in = lighting_inputs(p.sceneConstantBuffer, p.viewConstantBuffer, p.colorTarget, p.depthStencilTex, p.gbufferBaseColorTex, p.gbufferNormalsTex,
                            p.gbufferMetallicRoughnessAoTex, p.renderConfig);
@@ -193,30 +240,61 @@ Result ClusteredLightingPass::Execute(Sync* jobSync, const Desc& p, const bool b
     d.cluster_dim[0] = (uint32_t)p.renderConfig.LightClusterDimX; d.cluster_dim[1] = (uint32_t)p.renderConfig.LightClusterDimY;
     d.cluster_dim[2] = (uint32_t)p.renderConfig.LightClusterDimZ;
     d.cluster_depth_extent = p.renderConfig.ClusterDepthExtent; d.requires_clear = bRequiresClear ? 1 : 0;
-    return done(jobSync->Execute(token, [&] { return incr_clustered_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return d;
+}
+Result ClusteredLightingPass::Execute(Sync* jobSync, const Desc& p, const bool bRequiresClear) {      // clustered-lighting.inl:19-132
+    const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
+    const incr_clustered_lighting_desc d = clustered_desc(p, bRequiresClear);
+    return jobSync->Execute(token, [&] { return incr_clustered_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }, "clustered_lighting");
+    });
+}
+
+// The three lighting passes of the deferred frame as one submission (one token, one kernel): renderer.cpp:1843-1920
+Result DeferredLightingPass::Execute(Sync* jobSync, const SkyLightingPass::Desc* sky, const DirectLightingPass::Desc* direct,
+                                     const ClusteredLightingPass::Desc* clustered, const bool bRequiresClear) {
+    const size_t token = jobSync->GetToken();
+    struct Parts { bool s, d, c; SkyLightingPass::Desc sky; DirectLightingPass::Desc direct; ClusteredLightingPass::Desc clustered; } parts = {};
+    parts.s = sky != nullptr; parts.d = direct != nullptr; parts.c = clustered != nullptr;
+    if (sky) parts.sky = *sky;
+    if (direct) parts.direct = *direct;
+    if (clustered) parts.clustered = *clustered;
+    return jobSync->Spawn([=]() -> int {
+    incr_sky_lighting_desc ds = {}; incr_direct_lighting_desc dd = {}; incr_clustered_lighting_desc dc = {};
+    if (parts.s) ds = sky_desc(parts.sky);
+    if (parts.d) dd = direct_desc(parts.direct);
+    if (parts.c) dc = clustered_desc(parts.clustered, bRequiresClear);
+    incr_deferred_lighting_desc d = {parts.s ? &ds : nullptr, parts.d ? &dd : nullptr, parts.c ? &dc : nullptr};
+    return jobSync->Execute(token, [&] { return incr_deferred_lighting(jobSync->m_ctx, &d, jobSync->m_stream); }, "deferred_lighting");
+    });
 }
 
 Result DynamicSkyPass::Execute(Sync* jobSync, const Desc& p) {            // dynamic-sky.inl:16-170
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_dynamic_sky_desc d = {};
     d.scene = p.scene->m_incrScene; d.view = &p.viewConstantBuffer->m_viewConstants;
     d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
     d.turbidity = p.renderConfig.Turbidity; d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_dynamic_sky(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_dynamic_sky(jobSync->m_ctx, &d, jobSync->m_stream); }, "dynamic_sky");
+    });
 }
 
 Result EnvironmentmapPass::Execute(Sync* jobSync, const Desc& p) {        // environmentmap.inl:16-150
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_environmentmap_desc d = {};
     d.view = &p.viewConstantBuffer->m_viewConstants;
     d.color_target = (uint32_t*)p.colorTarget->m_devicePtr; d.depth_buffer = (const float*)p.depthStencilTarget->m_devicePtr;
     d.envmap_r11g11b10 = p.scene->m_skylightEnvmap; d.envmap_res = p.scene->m_envmapRes; d.envmap_mips = p.scene->m_envmapMips;   // m_skylight.m_envmapTextureIndex
     d.sky_brightness = p.renderConfig.SkyBrightness; d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_environmentmap(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_environmentmap(jobSync->m_ctx, &d, jobSync->m_stream); }, "environmentmap");
+    });
 }
 
 Result DebugVizPass::Execute(Sync* jobSync, const Desc& p) {              // debug-visualization.inl:20-170
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_debug_viz_desc d = {};
     d.view = &p.viewConstantBuffer->m_viewConstants; d.viewmode = p.renderConfig.Viewmode;
     d.vis_buffer = (const uint32_t*)p.visBuffer->m_devicePtr;
@@ -229,11 +307,13 @@ Result DebugVizPass::Execute(Sync* jobSync, const Desc& p) {              // deb
     d.color_target = (uint32_t*)p.target->m_devicePtr;
     d.light_cluster_slices = (uint32_t)p.renderConfig.LightClusterDimZ;    // :150
     d.use_primitives = p.renderConfig.UseMeshlets ? 0 : 1; d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_debug_visualization(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    return jobSync->Execute(token, [&] { return incr_debug_visualization(jobSync->m_ctx, &d, jobSync->m_stream); }, "debug_visualization");
+    });
 }
 
 Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa-resolve.inl:16-118
     const size_t token = jobSync->GetToken();
+    return jobSync->Spawn([=]() -> int {
     incr_view_constants vc = {};
     vc.taa_inv_view_proj = p.invViewProjectionTransform; vc.prev_view_proj_transform = p.prevViewProjectionTransform;
     vc.res_x = p.resX; vc.res_y = p.resY;
@@ -244,7 +324,9 @@ Result TAAResolvePass::Execute(Sync* jobSync, const Desc& p) {            // taa
     d.history_in = p.historySource ? (const uint32_t*)p.historySource->m_devicePtr : nullptr;
     d.depth_buffer = (const float*)p.depthTexture->m_devicePtr;
     d.history_index = p.historyIndex; d.storage_rounding = p.renderConfig.StorageRounding;
-    return done(jobSync->Execute(token, [&] { return incr_taa_resolve(jobSync->m_ctx, &d, jobSync->m_stream); }));
+    if (p.tonemapTarget) { d.ldr_rgba8 = p.tonemapTarget->m_devicePtr; d.exposure = p.renderConfig.Exposure; d.viewmode = p.renderConfig.Viewmode; }
+    return jobSync->Execute(token, [&] { return incr_taa_resolve(jobSync->m_ctx, &d, jobSync->m_stream); }, "taa_resolve");
+    });
 }
 
 } // namespace RenderJob
@@ -281,6 +363,13 @@ struct State {
     // neighbourhood, resolves TAA for the band only and leaves gather + tonemap to the caller.  0,0 = the whole frame.
     uint32_t bandY0 = 0, bandY1 = 0;
     FShaderSurface* lastHdr = nullptr;                         // what the tonemap of this frame reads
+    // FConfig::UseGraph: the frame's launches are captured, the instantiated graph is updated in place and replayed
+    hipGraphExec_t graphExec = nullptr;
+    hipStream_t captureStream = nullptr;                       // launches are captured here and replayed on the renderer's stream (which may be the null stream)
+    uint64_t graphFrames = 0, graphUpdates = 0, graphRebuilds = 0;
+    int graphStatus = 0;                                       // 0 = ok / unused, else the HIP error that switched graph replay off
+    double clockSeconds = 0.0;                                  // Tick(dt) total (inc/demo-interface.h:12)
+    double hostSecondsLastFrame = 0.0;                          // wall time of Render on the calling thread (record + submit + join)
 };
 static constexpr uint32_t kBandSlackRows = 64;                  // TAA surfaces hold ceil(H/N)*N rows for an equal-sized all_gather
 
@@ -327,6 +416,9 @@ int Initialize(State& s, incr_context* ctx, incr_stream stream, uint32_t resX, u
 }
 
 void Teardown(State& s) {
+    s.jobSync.SetThreads(0);
+    if (s.graphExec) { (void)hipGraphExecDestroy(s.graphExec); s.graphExec = nullptr; }
+    if (s.captureStream) { (void)hipStreamDestroy(s.captureStream); s.captureStream = nullptr; }
     for (void* p : s.allocations) incr_buffer_destroy(s.ctx, p);
     s.allocations.clear();
 }
@@ -355,7 +447,26 @@ int Render(State& s, const FRenderState& renderState) {
         cbViewConstants.m_viewConstants.scissor_y1 = s.bandY1 + 1 < resY ? s.bandY1 + 1 : resY;
     }
 
-    UpdateTLASPass::Execute(jobSync, scene);                                   // :1676
+    const auto hostT0 = std::chrono::steady_clock::now();
+    jobSync->BeginFrameProfile();
+    std::vector<Result> sceneRenderJobs;                                       // :1672 (joined at the end of the frame, :2039-2041)
+    auto job = [&](const Result& r) { sceneRenderJobs.push_back(r); };
+    // HIP-graph replay of the raster frame (not in the reference): launches of this frame are captured instead of executed, the
+    // instantiated graph of the previous frame takes the new kernel arguments in place (hipGraphExecUpdate) and is launched
+    // once.  The first two frames run directly (workspaces grow there); capture needs the launches on one host thread.
+    const bool useGraph = c.UseGraph && !c.PathTrace && s.graphStatus == 0 && s.frameIndex >= 2;
+    jobSync->SetThreads(useGraph ? 0 : c.RecordThreads);
+    const incr_stream frameStream = jobSync->m_stream;
+    if (useGraph) {
+        hipError_t e = hipSuccess;
+        if (!s.captureStream) e = hipStreamCreateWithFlags(&s.captureStream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamBeginCapture(s.captureStream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { s.graphStatus = (int)e; (void)hipGetLastError(); }
+        else jobSync->m_stream = (incr_stream)s.captureStream;
+    }
+    const bool capturing = useGraph && s.graphStatus == 0;
+
+    job(UpdateTLASPass::Execute(jobSync, scene));                              // :1676
 
     if (c.PathTrace) {                                                         // :1679-1709
         if (s.pathtraceCurrentSampleIndex < c.MaxSampleCount) {
@@ -365,12 +476,12 @@ int Render(State& s, const FRenderState& renderState) {
             pathtraceDesc.resX = resX; pathtraceDesc.resY = resY;
             pathtraceDesc.scene = scene; pathtraceDesc.view = &renderState.m_view; pathtraceDesc.renderConfig = c;
             pathtraceDesc.rayStatsBuffer = &s.rayStatsBuffer;
-            PathTracing::Execute(jobSync, pathtraceDesc);
+            job(PathTracing::Execute(jobSync, pathtraceDesc));
             s.pathtraceCurrentSampleIndex++;                                   // accumulate samples
         }
         TonemapPass::Desc tonemapDesc = {};
         tonemapDesc.source = &s.pathtraceHistoryBuffer; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
-        TonemapPass::Execute(jobSync, tonemapDesc);
+        job(TonemapPass::Execute(jobSync, tonemapDesc));
     } else {                                                                   // :1711-2036
         BatchCullingPass::Desc batchCullDesc = {};
         batchCullDesc.batchArgsBuffer_Default = &s.batchArgsBuffer_Default; batchCullDesc.batchArgsBuffer_DoubleSided = &s.batchArgsBuffer_DoubleSided;
@@ -378,7 +489,7 @@ int Render(State& s, const FRenderState& renderState) {
         batchCullDesc.sceneConstantBuffer = scene; batchCullDesc.viewConstantBuffer = &cbViewConstants;
         const size_t numDraws = c.UseMeshlets ? scene->m_meshletCount : scene->m_primitiveCount;   // :1375-1377
         batchCullDesc.drawCount = numDraws; batchCullDesc.renderConfig = c; batchCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
-        BatchCullingPass::Execute(jobSync, batchCullDesc);
+        job(BatchCullingPass::Execute(jobSync, batchCullDesc));
 
         const size_t punctualLightCount = scene->GetPunctualLightCount();
         if (punctualLightCount > 0 && c.EnableDirectLighting) {                // :1727-1744
@@ -387,7 +498,7 @@ int Render(State& s, const FRenderState& renderState) {
             lightCullDesc.lightGridBuffer = &s.lightGridBuffer;
             lightCullDesc.renderConfig = c; lightCullDesc.scene = scene; lightCullDesc.view = &renderState.m_cullingView; lightCullDesc.jitter = pixelJitter;
             lightCullDesc.viewConstantBuffer = &cbViewConstants; lightCullDesc.renderStatsBuffer = &s.renderStatsBuffer;
-            LightCullingPass::Execute(jobSync, lightCullDesc);
+            job(LightCullingPass::Execute(jobSync, lightCullDesc));
         }
 
         VisibilityPass::Desc visDesc = {};                                     // :1747-1762
@@ -396,7 +507,7 @@ int Render(State& s, const FRenderState& renderState) {
         visDesc.indirectCountsBuffer = &s.batchCountsBuffer;
         visDesc.sceneConstantBuffer = scene; visDesc.viewConstantBuffer = &cbViewConstants;
         visDesc.resX = resX; visDesc.resY = resY; visDesc.drawCount = numDraws; visDesc.renderConfig = c;
-        VisibilityPass::Execute(jobSync, visDesc);
+        job(VisibilityPass::Execute(jobSync, visDesc));
 
         GBufferComputePass::Desc gbufferComputeDesc = {};                      // :1765-1781
         gbufferComputeDesc.sourceVisBuffer = &s.visBuffer; gbufferComputeDesc.colorTarget = &s.hdrRasterSceneColor;
@@ -404,7 +515,7 @@ int Render(State& s, const FRenderState& renderState) {
         gbufferComputeDesc.gbufferTargets[2] = &s.gbuffer_metallicRoughnessAo; gbufferComputeDesc.depthStencilTarget = &s.depthBuffer;
         gbufferComputeDesc.sceneConstantBuffer = scene; gbufferComputeDesc.viewConstantBuffer = &cbViewConstants;
         gbufferComputeDesc.resX = resX; gbufferComputeDesc.resY = resY; gbufferComputeDesc.scene = scene; gbufferComputeDesc.renderConfig = c;
-        GBufferComputePass::Execute(jobSync, gbufferComputeDesc);
+        job(GBufferComputePass::Execute(jobSync, gbufferComputeDesc));
 
         GBufferRasterPass::Desc gbufferRasterDesc = {};                        // decals :1783-1798 (a no-op for scenes without any)
         gbufferRasterDesc.sourceVisBuffer = &s.visBuffer; gbufferRasterDesc.colorTarget = &s.hdrRasterSceneColor;
@@ -412,7 +523,7 @@ int Render(State& s, const FRenderState& renderState) {
         gbufferRasterDesc.gbufferTargets[2] = &s.gbuffer_metallicRoughnessAo; gbufferRasterDesc.depthStencilTarget = &s.depthBuffer;
         gbufferRasterDesc.sceneConstantBuffer = scene; gbufferRasterDesc.viewConstantBuffer = &cbViewConstants;
         gbufferRasterDesc.resX = resX; gbufferRasterDesc.resY = resY; gbufferRasterDesc.scene = scene; gbufferRasterDesc.renderConfig = c;
-        GBufferRasterPass::Execute(jobSync, gbufferRasterDesc);
+        job(GBufferRasterPass::Execute(jobSync, gbufferRasterDesc));
 
         if (c.EnableHBAO) {                                                    // :1801-1815; else both targets read as cleared to 1 (:1816-1841)
             HBAO::Desc hbaoDesc = {};
@@ -420,11 +531,14 @@ int Render(State& s, const FRenderState& renderState) {
             hbaoDesc.depthStencil = &s.depthBuffer; hbaoDesc.gbufferNormals = &s.gbuffer_normals;
             hbaoDesc.sceneConstantBuffer = scene; hbaoDesc.viewConstantBuffer = &cbViewConstants;
             hbaoDesc.renderConfig = c; hbaoDesc.resX = resX; hbaoDesc.resY = resY; hbaoDesc.rayStatsBuffer = &s.rayStatsBuffer;
-            HBAO::Execute(jobSync, hbaoDesc);
+            job(HBAO::Execute(jobSync, hbaoDesc));
         }
 
+        // FConfig::FusePasses: the three lighting passes of the deferred frame are described as the reference describes them and
+        // submitted as one (DeferredLightingPass); the forward frame keeps its sky pass
+        const bool fuseLighting = c.FusePasses && !c.ForwardLighting;
+        SkyLightingPass::Desc skyLightingDesc = {};
         if (c.EnableSkyLighting) {                                             // :1843-1863
-            SkyLightingPass::Desc skyLightingDesc = {};
             skyLightingDesc.colorTarget = &s.hdrRasterSceneColor; skyLightingDesc.depthStencilTex = &s.depthBuffer;
             skyLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; skyLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
             skyLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
@@ -432,7 +546,7 @@ int Render(State& s, const FRenderState& renderState) {
             skyLightingDesc.renderConfig = c; skyLightingDesc.scene = scene; skyLightingDesc.view = &renderState.m_view; skyLightingDesc.jitter = pixelJitter;
             skyLightingDesc.resX = resX; skyLightingDesc.resY = resY; skyLightingDesc.viewConstantBuffer = &cbViewConstants;
             skyLightingDesc.envBRDFTex = scene->m_envBRDF.m_devicePtr ? const_cast<FTexture*>(&scene->m_envBRDF) : nullptr;   // s_envBRDF.get()
-            SkyLightingPass::Execute(jobSync, skyLightingDesc);
+            if (!fuseLighting) job(SkyLightingPass::Execute(jobSync, skyLightingDesc));
         }
 
         if (c.ForwardLighting) {                                               // :1865-1881
@@ -441,11 +555,13 @@ int Render(State& s, const FRenderState& renderState) {
             forwardDesc.resX = resX; forwardDesc.resY = resY;
             forwardDesc.scene = scene; forwardDesc.sceneConstantBuffer = scene; forwardDesc.viewConstantBuffer = &cbViewConstants;
             forwardDesc.renderConfig = c; forwardDesc.rayStatsBuffer = &s.rayStatsBuffer;
-            ForwardLightingPass::Execute(jobSync, forwardDesc);
+            job(ForwardLightingPass::Execute(jobSync, forwardDesc));
         } else {                                                               // :1882-1926
             const int directionalLightIndex = scene->GetDirectionalLight();
-            if (directionalLightIndex != -1 && c.EnableDirectLighting) {
-                DirectLightingPass::Desc directLightingDesc = {};
+            const bool haveDirect = directionalLightIndex != -1 && c.EnableDirectLighting, haveClustered = punctualLightCount > 0 && c.EnableDirectLighting;
+            DirectLightingPass::Desc directLightingDesc = {};
+            ClusteredLightingPass::Desc clusteredLightingDesc = {};
+            if (haveDirect) {
                 directLightingDesc.directionalLightIndex = directionalLightIndex;
                 directLightingDesc.colorTarget = &s.hdrRasterSceneColor; directLightingDesc.depthStencilTex = &s.depthBuffer;
                 directLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; directLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
@@ -453,19 +569,21 @@ int Render(State& s, const FRenderState& renderState) {
                 directLightingDesc.sceneConstantBuffer = scene; directLightingDesc.viewConstantBuffer = &cbViewConstants;
                 directLightingDesc.renderConfig = c; directLightingDesc.resX = resX; directLightingDesc.resY = resY;
                 directLightingDesc.rayStatsBuffer = &s.rayStatsBuffer;
-                DirectLightingPass::Execute(jobSync, directLightingDesc);
+                if (!fuseLighting) job(DirectLightingPass::Execute(jobSync, directLightingDesc));
             }
             const bool bRequiresClear = directionalLightIndex == -1;           // :1906
-            if (punctualLightCount > 0 && c.EnableDirectLighting) {
-                ClusteredLightingPass::Desc clusteredLightingDesc = {};
+            if (haveClustered) {
                 clusteredLightingDesc.lightListsBuffer = &s.culledLightListsBuffer; clusteredLightingDesc.lightGridBuffer = &s.lightGridBuffer;
                 clusteredLightingDesc.colorTarget = &s.hdrRasterSceneColor; clusteredLightingDesc.depthStencilTex = &s.depthBuffer;
                 clusteredLightingDesc.gbufferBaseColorTex = &s.gbuffer_basecolor; clusteredLightingDesc.gbufferNormalsTex = &s.gbuffer_normals;
                 clusteredLightingDesc.gbufferMetallicRoughnessAoTex = &s.gbuffer_metallicRoughnessAo;
                 clusteredLightingDesc.sceneConstantBuffer = scene; clusteredLightingDesc.viewConstantBuffer = &cbViewConstants;
                 clusteredLightingDesc.renderConfig = c; clusteredLightingDesc.resX = resX; clusteredLightingDesc.resY = resY;
-                ClusteredLightingPass::Execute(jobSync, clusteredLightingDesc, bRequiresClear);
+                if (!fuseLighting) job(ClusteredLightingPass::Execute(jobSync, clusteredLightingDesc, bRequiresClear));
             }
+            if (fuseLighting && (c.EnableSkyLighting || haveDirect || haveClustered))
+                job(DeferredLightingPass::Execute(jobSync, c.EnableSkyLighting ? &skyLightingDesc : nullptr, haveDirect ? &directLightingDesc : nullptr,
+                                                  haveClustered ? &clusteredLightingDesc : nullptr, bRequiresClear));
         }
 
         if (c.EnvSkyMode == 0) {                                               // EnvSkyMode::HDRI :1927-1943
@@ -474,14 +592,14 @@ int Render(State& s, const FRenderState& renderState) {
             envmapDesc.resX = resX; envmapDesc.resY = resY;
             envmapDesc.scene = scene; envmapDesc.view = &renderState.m_view; envmapDesc.jitter = pixelJitter; envmapDesc.renderConfig = c;
             envmapDesc.viewConstantBuffer = &cbViewConstants;
-            EnvironmentmapPass::Execute(jobSync, envmapDesc);
+            job(EnvironmentmapPass::Execute(jobSync, envmapDesc));
         } else {                                                               // :1944-1959
             DynamicSkyPass::Desc skyDesc = {};
             skyDesc.colorTarget = &s.hdrRasterSceneColor; skyDesc.depthStencilTarget = &s.depthBuffer;
             skyDesc.resX = resX; skyDesc.resY = resX;                          // sic: the reference passes resX twice (:1951-1952); unused by the pass
             skyDesc.scene = scene; skyDesc.view = &renderState.m_view; skyDesc.jitter = pixelJitter; skyDesc.renderConfig = c;
             skyDesc.viewConstantBuffer = &cbViewConstants;
-            DynamicSkyPass::Execute(jobSync, skyDesc);
+            job(DynamicSkyPass::Execute(jobSync, skyDesc));
         }
         const bool bDebugView = c.Viewmode != 0 && c.Viewmode != 1;            // :1961 (Normal, LightingOnly)
         if (bDebugView) {                                                      // :1962-1984; the editor's highlight pass (:1986-2000) is UI
@@ -491,10 +609,11 @@ int Render(State& s, const FRenderState& renderState) {
             desc.aoBuffer = &s.aoBuffer; desc.bentNormalsBuffer = &s.bentNormalsBuffer; desc.indirectArgsBuffer = nullptr;
             desc.jitter = pixelJitter; desc.renderConfig = c; desc.scene = scene; desc.view = &renderState.m_view;
             desc.sceneConstantBuffer = scene; desc.viewConstantBuffer = &cbViewConstants;
-            DebugVizPass::Execute(jobSync, desc);
+            job(DebugVizPass::Execute(jobSync, desc));
         }
 
         FShaderSurface* hdrOut = &s.hdrRasterSceneColor;
+        bool tonemapFused = false;
         if (c.EnableTAA) {                                                     // :2003-2026
             TAAResolvePass::Desc resolveDesc = {};
             resolveDesc.source = &s.hdrRasterSceneColor;
@@ -504,18 +623,42 @@ int Render(State& s, const FRenderState& renderState) {
             resolveDesc.invViewProjectionTransform = cbViewConstants.m_viewConstants.taa_inv_view_proj;      // viewProjectionTransform.Invert()
             resolveDesc.depthTexture = &s.depthBuffer; resolveDesc.renderConfig = c;
             if (banded) { resolveDesc.rowBegin = s.bandY0; resolveDesc.rowEnd = s.bandY1 < resY ? s.bandY1 : resY; }
-            TAAResolvePass::Execute(jobSync, resolveDesc);
+            if (c.FusePasses && !banded) { resolveDesc.tonemapTarget = &s.backBuffer; tonemapFused = true; }      // the resolve presents
+            job(TAAResolvePass::Execute(jobSync, resolveDesc));
             s.prevViewProjectionTransform = cbViewConstants.m_viewConstants.unjittered_view_proj;            // :2025
             hdrOut = resolveDesc.target;
         }
 
         s.lastHdr = hdrOut;
-        if (!banded) {       // with row bands the caller gathers the bands first, then calls Tonemap()
+        if (!banded && !tonemapFused) {       // with row bands the caller gathers the bands first, then calls Tonemap()
             TonemapPass::Desc tonemapDesc = {};                                // :2029-2036
             tonemapDesc.source = hdrOut; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
-            TonemapPass::Execute(jobSync, tonemapDesc);
+            job(TonemapPass::Execute(jobSync, tonemapDesc));
         }
     }
+    for (Result& r : sceneRenderJobs) r.wait();                                // sceneRenderJoinTask.wait() :2039-2041
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(s.captureStream, &graph);
+        jobSync->m_stream = frameStream;
+        if (e == hipSuccess && jobSync->m_firstError == INCR_OK) {
+            if (s.graphExec) {
+                hipGraphExecUpdateResult result; hipGraphNode_t errNode = nullptr;
+                e = hipGraphExecUpdate(s.graphExec, graph, &errNode, &result);
+                if (e == hipSuccess) s.graphUpdates++;
+                else { (void)hipGetLastError(); (void)hipGraphExecDestroy(s.graphExec); s.graphExec = nullptr; e = hipSuccess; }    // topology changed (a pass toggled): rebuild
+            }
+            if (!s.graphExec) { e = hipGraphInstantiate(&s.graphExec, graph, nullptr, nullptr, 0); if (e == hipSuccess) s.graphRebuilds++; }
+            if (e == hipSuccess) e = hipGraphLaunch(s.graphExec, (hipStream_t)jobSync->m_stream);
+            if (e == hipSuccess) s.graphFrames++;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {      // the frame is lost for replay: report, and issue every later frame directly
+            s.graphStatus = (int)e; (void)hipGetLastError();
+            if (jobSync->m_firstError == INCR_OK) { jobSync->m_firstError = INCR_ERR_HIP; jobSync->m_firstErrorMessage = std::string("HIP graph replay failed: ") + hipGetErrorString(e); }
+        }
+    }
+    s.hostSecondsLastFrame = std::chrono::duration<double>(std::chrono::steady_clock::now() - hostT0).count();
     s.frameIndex++;
     s.lastStatus = jobSync->m_firstError;
     if (jobSync->m_firstError != INCR_OK) (void)0;       // the message is in jobSync->m_firstErrorMessage
@@ -529,7 +672,8 @@ int Tonemap(State& s, const FConfig& c) {
     if (!s.lastHdr) return INCR_ERR_INVALID_ARGUMENT;
     RenderJob::TonemapPass::Desc tonemapDesc = {};
     tonemapDesc.source = s.lastHdr; tonemapDesc.target = &s.backBuffer; tonemapDesc.renderConfig = c;
-    return RenderJob::TonemapPass::Execute(&s.jobSync, tonemapDesc).m_status;
+    RenderJob::Result r = RenderJob::TonemapPass::Execute(&s.jobSync, tonemapDesc);
+    return r.wait();
 }
 
 } // namespace Renderer
@@ -585,6 +729,7 @@ int incr_renderer_set_config(incr_renderer* r, const incr_renderer_config* c) {
     f.UseMeshlets = c->use_primitives == 0;
     f.EnableHBAO = c->enable_hbao != 0; f.UseBentNormals = c->use_bent_normals != 0;
     f.ForwardLighting = c->forward_lighting != 0;
+    f.FusePasses = c->unfused_passes == 0; f.RecordThreads = c->record_threads > 0 ? (int)std::min(c->record_threads, 16) : 0; f.UseGraph = c->use_graph != 0;
     return INCR_OK;
 }
 
@@ -603,6 +748,7 @@ int incr_renderer_render(incr_renderer* r, const incr_view* view, const incr_vie
     if (rc) r->error = r->state.jobSync.m_firstErrorMessage;
     return rc;
 }
+double incr_renderer_tick(incr_renderer* r, float dt) { if (!r) return 0.0; if (dt == dt && dt > 0.f) r->state.clockSeconds += (double)dt; return r->state.clockSeconds; }
 void incr_renderer_reset_accumulation(incr_renderer* r) { if (r) Renderer::ResetPathtraceAccumulation(r->state); }
 int incr_renderer_set_band(incr_renderer* r, uint32_t row_begin, uint32_t row_end) {
     if (!r || row_end < row_begin) return INCR_ERR_INVALID_ARGUMENT;
@@ -622,6 +768,37 @@ int incr_renderer_get_stats(incr_renderer* r, incr_render_stats* out_render_stat
     if (!rc && out_ray_stats) rc = incr_buffer_download(s.ctx, out_ray_stats, s.rayStatsBuffer.m_devicePtr, sizeof *out_ray_stats, s.jobSync.m_stream);
     if (rc) r->error = incr_last_error();
     return rc;
+}
+
+int incr_renderer_get_frame_info(incr_renderer* r, double* host_seconds, uint64_t* graph_frames, uint64_t* graph_updates, uint64_t* graph_rebuilds) {
+    if (!r) return INCR_ERR_INVALID_ARGUMENT;
+    if (host_seconds) *host_seconds = r->state.hostSecondsLastFrame;
+    if (graph_frames) *graph_frames = r->state.graphFrames;
+    if (graph_updates) *graph_updates = r->state.graphUpdates;
+    if (graph_rebuilds) *graph_rebuilds = r->state.graphRebuilds;
+    return INCR_OK;
+}
+
+int incr_renderer_set_profiling(incr_renderer* r, int enable) {
+    if (!r) return INCR_ERR_INVALID_ARGUMENT;
+    r->state.jobSync.m_profile = enable != 0;
+    return INCR_OK;
+}
+// GPU milliseconds of every pass of the last profiled frame (direct issue only: a captured frame has no events)
+int incr_renderer_get_pass_times(incr_renderer* r, char (*names)[32], float* ms, uint32_t capacity, uint32_t* count) {
+    if (!r || !count) return INCR_ERR_INVALID_ARGUMENT;
+    RenderJob::Sync& js = r->state.jobSync;
+    *count = 0;
+    if (js.m_marks.size() < 2) return INCR_OK;
+    if (hipEventSynchronize((hipEvent_t)js.m_marks.back().second) != hipSuccess) return INCR_ERR_HIP;
+    for (size_t i = 1; i < js.m_marks.size() && *count < capacity; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, (hipEvent_t)js.m_marks[i - 1].second, (hipEvent_t)js.m_marks[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (names) { strncpy(names[*count], js.m_marks[i].first.c_str(), 31); names[*count][31] = 0; }
+        if (ms) ms[*count] = t;
+        ++*count;
+    }
+    return INCR_OK;
 }
 
 void* incr_renderer_surface(incr_renderer* r, int which) {

@@ -166,6 +166,13 @@ DI f3 ACESFilm(f3 x) {
     const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
     return saturate((x * (a * x + b)) / (x * (c * x + d) + e));
 }
+// R8G8B8A8_UNORM_SRGB render-target encode + the tonemap of one R11G11B10F texel (postprocess/tonemap.hlsl:30-59)
+DI uint32_t linear_to_srgb8(float c) {
+    if (!(c > 0.f)) c = 0.f;
+    if (c > 1.f) c = 1.f;
+    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.f / 2.4f) - 0.055f;
+    return (uint32_t)floorf(e * 255.f + 0.5f);
+}
 
 // ---------------------------------------------------------------- Preetham sky (preetham.hlsli:36-89)
 
@@ -262,9 +269,12 @@ DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t 
     default:                        return {(float)r * inv255, (float)g * inv255, (float)b * inv255, (float)a * inv255};
     }
 }
-DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv) {
-    const DeviceTexture t = textures[texIndex];
-    const int W = (int)t.width, H = (int)t.height;
+// Bilinear, wrap, texel centre + 0.5, float weights, on level `level` of a texture's mip chain (levels packed one after the
+// other behind level 0; level l is max(W >> l, 1) x max(H >> l, 1)).
+DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgbLut, uint32_t level, f2 uv) {
+    int W = (int)t.width, H = (int)t.height;
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; ++l) { off += (size_t)W * H; W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
@@ -273,7 +283,7 @@ DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __re
     float fx = x - x0f, fy = y - y0f;
     int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
     int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
-    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels + off;
     const uint32_t c00 = px[(size_t)y0 * W + x0], c10 = px[(size_t)y0 * W + x1];
     const uint32_t c01 = px[(size_t)y1 * W + x0], c11 = px[(size_t)y1 * W + x1];
     f4 t00 = decode_texel(srgbLut, t.format, c00), t10 = decode_texel(srgbLut, t.format, c10);
@@ -286,24 +296,61 @@ DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __re
     r.w = (t00.w * wx0 + t10.w * fx) * wy0 + (t01.w * wx0 + t11.w * fx) * fy;
     return r;
 }
+// SampleLevel(s, uv, 0): what the path tracer uses (material/common.hlsli:4-5, no UV derivatives there)
+DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv) {
+    return SampleBilinearLevel(textures[texIndex], srgbLut, 0u, uv);
+}
+
+// ---- Sample(s, uv) of the raster passes (material/common.hlsli:6-8 TEX_SAMPLE = Sample outside PATH_TRACING) ----
+// Pinned texture-unit rules: isotropic LOD = log2 of the longer screen-space derivative in texels
+// (D3D11.3 functional spec 7.18.11), the logarithm by exponent + a degree-4 polynomial in the mantissa (|error| < 1.2e-4, the same
+// float operations on host and device), LOD clamped to the chain, its fraction truncated to 8 bits, trilinear = lerp of two
+// bilinear taps.  The reference's sampler is anisotropic (g_anisoSampler); anisotropic footprints are not reproduced.
+DI float pinned_log2(float x) {         // x > 0, finite, normal
+    const uint32_t b = __float_as_uint(x);
+    const float e = (float)((int)(b >> 23) - 127);
+    const float t = __uint_as_float((b & 0x7fffffu) | 0x3f800000u) - 1.f;
+    const float p = 1.4425331354141235f + t * (-0.7161056399345398f + t * (0.4395408034324646f + t * (-0.2250901162624359f + t * 0.05923847481608391f)));
+    return e + t * p;
+}
+DI float texture_lod(const DeviceTexture& t, f2 ddx, f2 ddy) {
+    const float W = (float)t.width, H = (float)t.height;
+    const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
+    const float m = fmaxf(ax * ax + ay * ay, bx * bx + by * by);          // squared length of the longer derivative, in texels
+    if (!(m >= 1.17549435e-38f) || !(m <= 3.0e38f)) return 0.f;            // zero, denormal, NaN or infinite footprint: level 0
+    return 0.5f * pinned_log2(m);
+}
+DI f4 SampleGrad(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv, f2 ddx, f2 ddy) {
+    const DeviceTexture t = textures[texIndex];
+    const uint32_t numMips = t.pad[1] ? t.pad[1] : 1u;
+    float lod = texture_lod(t, ddx, ddy);
+    lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
+    const float l0f = floorf(lod);
+    const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
+    const uint32_t l0 = (uint32_t)l0f;
+    const f4 a = SampleBilinearLevel(t, srgbLut, l0, uv);
+    if (frac == 0.f || l0 + 1u >= numMips) return a;
+    const f4 b = SampleBilinearLevel(t, srgbLut, l0 + 1u, uv);
+    return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac};
+}
 
 // material/common.hlsli:10-115
 struct MatProps { f3 emissive, basecolor; float opacity; bool bHasNormalmap; f3 normalmap; float metallic, roughness, ao, aoblend; };
-DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {
+template <class Sampler> DI MatProps EvaluateMaterialPropertiesT(const incr_material& mat, f2 uv, Sampler sample) {
     MatProps o;
     o.emissive = {mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
-    if (mat.emissiveTextureIndex != -1) { f4 t = SampleLevel0(textures, lut, mat.emissiveTextureIndex, uv); o.emissive = o.emissive * mk3(t.x, t.y, t.z); }
+    if (mat.emissiveTextureIndex != -1) { f4 t = sample(mat.emissiveTextureIndex, uv); o.emissive = o.emissive * mk3(t.x, t.y, t.z); }
     o.basecolor = {mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]};
     o.opacity = 1.f;
     if (mat.baseColorTextureIndex != -1) {
-        f4 t = SampleLevel0(textures, lut, mat.baseColorTextureIndex, uv);
+        f4 t = sample(mat.baseColorTextureIndex, uv);
         o.basecolor = o.basecolor * mk3(t.x, t.y, t.z);
         o.opacity = t.w;
     }
     o.bHasNormalmap = mat.normalTextureIndex != -1;
     o.normalmap = {0.f, 0.f, 1.f};
     if (o.bHasNormalmap) {
-        f4 t = SampleLevel0(textures, lut, mat.normalTextureIndex, uv);
+        f4 t = sample(mat.normalTextureIndex, uv);
         f2 nxy = {t.x, t.y};
         float nz = sqrtf(1.f - dot(nxy, nxy));
         o.normalmap = {nxy.x, nxy.y, nz};
@@ -311,13 +358,38 @@ DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTex
     o.metallic = mat.metallicFactor;
     o.roughness = mat.roughnessFactor;
     if (mat.metallicRoughnessTextureIndex != -1) {
-        f4 t = SampleLevel0(textures, lut, mat.metallicRoughnessTextureIndex, uv);
+        f4 t = sample(mat.metallicRoughnessTextureIndex, uv);
         o.metallic = t.x; o.roughness = t.y;
     }
     o.aoblend = mat.aoStrength;
     o.ao = 1.f;
-    if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(textures, lut, mat.aoTextureIndex, uv).x;
+    if (mat.aoTextureIndex != -1) o.ao = sample(mat.aoTextureIndex, uv).x;
     return o;
+}
+
+DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {      // PATH_TRACING: SampleLevel 0
+    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleLevel0(textures, lut, tex, st); });
+}
+DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy) {   // raster: Sample
+    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleGrad(textures, lut, tex, st, ddx, ddy); });
+}
+
+// exp(x) for x <= 0 with a fixed evaluation (HLSL leaves exp's precision open; the vMF prefilter's exp feeds UNORM8 texels that
+// oracle and product must agree on bit for bit): 2^(x log2 e) = 2^floor * P(frac), P of degree 6 (|error| < 1.7e-7 on [0, 1))
+DI float pinned_exp_neg(float x) {
+    if (!(x > -87.f)) return 0.f;                        // underflow, -inf, NaN
+    const float t = x * 1.44269502162933349609375f;
+    const float fi = floorf(t), f = t - fi;
+    const float p = 1.0f + f * (0.693146824836731f + f * (0.24023109674453735f + f * (0.055478911846876144f + f * (0.009686185978353024f
+                  + f * (0.001238241558894515f + f * 0.000218712622881867f)))));
+    return __uint_as_float(__float_as_uint(p) + (uint32_t)((int)fi << 23));
+}
+
+DI uint32_t tonemap_texel(uint32_t hdrBits, float exposure, int viewmode) {
+    const f3 h = unpack_r11g11b10(hdrBits);
+    f3 l;
+    if (viewmode != 0 && viewmode != 1) l = h; else l = ACESFilm(h * exposure);
+    return linear_to_srgb8(l.x) | (linear_to_srgb8(l.y) << 8) | (linear_to_srgb8(l.z) << 16) | 0xff000000u;
 }
 
 } // namespace incr

@@ -49,8 +49,8 @@ struct PtParams {
 
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).
 struct WfBuffers {
-    float4* rayO;        // origin.xyz
-    float4* rayD;        // direction.xyz
+    float4* extA;        // rays of the even bounces, list order, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, 0}
+    float4* extB;        // rays of the odd bounces
     float4* color;       // payload.color
     float4* atten;       // payload.attenuation.xyz
     uint4*  hit;         // {leaf-order triangle, t, u, v}

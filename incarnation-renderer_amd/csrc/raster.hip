@@ -72,6 +72,17 @@ DI f2 pixel_ndc(uint32_t px, uint32_t py, float W, float H) {
     return n;
 }
 DI f2 interp2(f2 a, f2 b, f2 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y}; }
+// Screen-space UV derivatives for Sample(): the differences a 2x2 quad of threads would form (ddx_coarse / ddy_coarse: taken at the
+// quad's top-left pixel), with all three UVs evaluated on THIS pixel's triangle -- the pixel's own plane extrapolated to its quad
+// neighbours, so the value does not depend on what the neighbouring lanes hold (texture unit).
+struct UvGrad { f2 ddx, ddy; };
+DI UvGrad quad_uv_gradient(f4 p0, f4 p1, f4 p2, f2 uv0, f2 uv1, f2 uv2, uint32_t x, uint32_t y, float W, float H) {
+    const uint32_t x0 = x & ~1u, y0 = y & ~1u;
+    const f2 a = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0, W, H)));
+    const f2 b = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0 + 1u, y0, W, H)));
+    const f2 c = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0 + 1u, W, H)));
+    return {b - a, c - a};
+}
 DI f3 interp3(f3 a, f3 b, f3 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y, (w.x * a.z + w.y * b.z) + w.z * c.z}; }
 DI f3 mul_vec3_m3(f3 v, f3 r0, f3 r1, f3 r2) { return {(v.x * r0.x + v.y * r1.x) + v.z * r2.x, (v.x * r0.y + v.y * r1.y) + v.z * r2.y, (v.x * r0.z + v.y * r1.z) + v.z * r2.z}; }
 
@@ -287,7 +298,8 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
         // fragments skip the check: the atomic is fire-and-forget, a load would put a memory round trip into every step.
         if (v <= __atomic_load_n(dst, __ATOMIC_RELAXED)) return;
         const f3 lam = CalcBarycentrics(st.p0, st.p1, st.p2, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
-        const float opacity = SampleLevel0(P.S.textures, P.S.srgbLut, st.alphaTex, interp2(st.uv0, st.uv1, st.uv2, lam)).w;
+        const UvGrad g = quad_uv_gradient(st.p0, st.p1, st.p2, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
+        const float opacity = SampleGrad(P.S.textures, P.S.srgbLut, st.alphaTex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy).w;
         if (opacity - 0.5f < 0.f) return;
     }
     atomicMax(dst, v);
@@ -556,11 +568,20 @@ __global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
     }
 }
 // packed depth|key -> R32_UINT visibility + D32 depth (clears: 0xFFFFF000 and 0, visibility-pass.inl:68-74)
+// 16 B in (two depth|key words), 8 + 8 B out per lane; `first` is even and n is rounded up by the launcher's padding rule
 __global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long long* __restrict__ packed, uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    auto id_of = [](unsigned long long v) { return v == 0 ? 0xFFFFF000u : (((uint32_t)v - 1u) & 0x7fffffffu); };
+    auto z_of = [](unsigned long long v) { return v == 0 ? 0.f : __uint_as_float((uint32_t)(v >> 32)); };
+    const bool wide = ((((uintptr_t)packed) & 15u) | (((uintptr_t)vis) & 7u) | (((uintptr_t)depth) & 7u)) == 0;
+    const size_t pairs = wide ? n / 2 : 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < pairs; q += (size_t)gridDim.x * blockDim.x) {
+        const ulonglong2 v = ((const ulonglong2*)packed)[q];
+        ((uint2*)vis)[q] = make_uint2(id_of(v.x), id_of(v.y));
+        ((float2*)depth)[q] = make_float2(z_of(v.x), z_of(v.y));
+    }
+    for (size_t i = pairs * 2 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long v = packed[i];
-        if (v == 0) { vis[i] = 0xFFFFF000u; depth[i] = 0.f; }
-        else { vis[i] = ((uint32_t)v - 1u) & 0x7fffffffu; depth[i] = __uint_as_float((uint32_t)(v >> 32)); }
+        vis[i] = id_of(v); depth[i] = z_of(v);
     }
 }
 
@@ -614,7 +635,8 @@ __global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
     const f3 T = normalize(interp3(tan[0], tan[1], tan[2], lam));
     const f3 B = normalize(cross(N, T) * tanW0);
     const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
-    const MatProps mi = EvaluateMaterialProperties(P.S.materials[materialIndex], P.S.textures, P.S.srgbLut, UV);
+    const UvGrad gr = quad_uv_gradient(p[0], p[1], p[2], uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
+    const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
     if (mi.bHasNormalmap) {
         const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)meshIndex * 16;
         const f3 l0 = {L[0], L[1], L[2]}, l1 = {L[4], L[5], L[6]}, l2 = {L[8], L[9], L[10]};
@@ -680,11 +702,8 @@ DI f2 sample_rg16f_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, 
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return {(t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy, (t00.y * wx0 + t10.y * fx) * wy0 + (t01.y * wx0 + t11.y * fx) * fy};
 }
-__global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.L.W || y >= P.L.y1) return;
-    const size_t i = (size_t)y * P.L.W + x;
-    const GBufferPixel g = read_gbuffer(P.L, i);
+// radiance the sky pass adds to pixel (x, y): SH9 diffuse + split-sum specular, scaled by the HBAO factor
+DI f3 sky_radiance(const SkyParams& P, const GBufferPixel& g, uint32_t x, uint32_t y, size_t i) {
     f3 radiance = {0.f, 0.f, 0.f};
     if (P.diffuseIbl && P.sh9) {
         const f3 albedo = (1.f - g.metallic) * g.basecolor;
@@ -714,7 +733,13 @@ __global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
         radiance = radiance + P.skyBrightness * (specularIBL + g.aoBlend * (occludedSpec - specularIBL));
     }
     const float hbao = P.ao ? (float)P.ao[i] / 255.f : 1.f;
-    add_color(P.L, i, hbao * radiance);
+    return hbao * radiance;
+}
+__global__ __launch_bounds__(256) void sky_lighting_kernel(const SkyParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.y1) return;
+    const size_t i = (size_t)y * P.L.W + x;
+    add_color(P.L, i, sky_radiance(P, read_gbuffer(P.L, i), x, y, i));
 }
 
 // Ray statistics of a lane-per-pixel pass (every thread of the block calls this once, outside divergent code).  One atomic
@@ -751,6 +776,29 @@ extern "C" hipError_t incr_launch_fold_ray_stats(unsigned long long* stripes, in
 }
 
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115)
+DI f3 direct_radiance(const DirectParams& P, LaneStack& st, const GBufferPixel& g, uint32_t x, uint32_t y, size_t i, uint32_t& rays) {
+    const f2 sp = screen_pos(x, y, P.L.W, P.L.H);
+    const f4 w = mul_vec4({sp.x, -sp.y, P.L.depth[i], 1.f}, P.L.invViewProj);
+    const f3 worldPos = {w.x / w.w, w.y / w.w, w.z / w.w};
+    const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
+    const f3 V = normalize(eye - worldPos);
+    incr_light light; const float* m; bool haveT;
+    load_global_light(P.S, P.sunIndex, light, m, haveT);
+    const LightSample s = light_setup(light, m, haveT, worldPos, g.N);
+    f3 radiance = {0.f, 0.f, 0.f};
+    if (s.needsShadow) {
+        bool lit = true;
+        if (light.type == INCR_LIGHT_DIRECTIONAL) {
+            ++rays;
+            // background pixels unproject to non-finite positions: such a ray hits nothing (every triangle test fails
+            // on NaN/inf), but the box tests cannot reject it and the walk would visit the whole tree
+            const bool finite = isfinite(worldPos.x) && isfinite(worldPos.y) && isfinite(worldPos.z) && isfinite(s.L.x) && isfinite(s.L.y) && isfinite(s.L.z);
+            lit = !finite || !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f);
+        }
+        if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
+    }
+    return radiance;
+}
 __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectParams P) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const uint32_t tid = threadIdx.x;
@@ -759,28 +807,7 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
     if (x < P.L.W && y < P.L.y1) {
         LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
         const size_t i = (size_t)y * P.L.W + x;
-        const GBufferPixel g = read_gbuffer(P.L, i);
-        const f2 sp = screen_pos(x, y, P.L.W, P.L.H);
-        const f4 w = mul_vec4({sp.x, -sp.y, P.L.depth[i], 1.f}, P.L.invViewProj);
-        const f3 worldPos = {w.x / w.w, w.y / w.w, w.z / w.w};
-        const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
-        const f3 V = normalize(eye - worldPos);
-        incr_light light; const float* m; bool haveT;
-        load_global_light(P.S, P.sunIndex, light, m, haveT);
-        const LightSample s = light_setup(light, m, haveT, worldPos, g.N);
-        f3 radiance = {0.f, 0.f, 0.f};
-        if (s.needsShadow) {
-            bool lit = true;
-            if (light.type == INCR_LIGHT_DIRECTIONAL) {
-                ++rays;
-                // background pixels unproject to non-finite positions: such a ray hits nothing (every triangle test fails
-                // on NaN/inf), but the box tests cannot reject it and the walk would visit the whole tree
-                const bool finite = isfinite(worldPos.x) && isfinite(worldPos.y) && isfinite(worldPos.z) && isfinite(s.L.x) && isfinite(s.L.y) && isfinite(s.L.z);
-                lit = !finite || !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f);
-            }
-            if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
-        }
-        add_color(P.L, i, radiance);
+        add_color(P.L, i, direct_radiance(P, st, read_gbuffer(P.L, i), x, y, i, rays));
     }
     count_rays(P.S, rays);
 }
@@ -917,7 +944,8 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
             const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
             const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
             const incr_material mat = P.S.materials[d.materialIndex];
-            const MatProps p = EvaluateMaterialProperties(mat, P.S.textures, P.S.srgbLut, UV);
+            const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
+            const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);
             bool done = true;
             if (P.viewmode == 2) out = mk3(p.roughness);                             // ps_main :95-105 (`#if VIWEMODE == 1` never fires)
             else if (P.viewmode == 3) out = mk3(p.metallic);
@@ -960,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
                         }
                     }
                     float transmission = mat.transmissionFactor;                     // material/common.hlsli:83-88
-                    if (mat.transmissionTextureIndex != -1) transmission *= SampleLevel0(P.S.textures, P.S.srgbLut, mat.transmissionTextureIndex, UV).x;
+                    if (mat.transmissionTextureIndex != -1) transmission *= SampleGrad(P.S.textures, P.S.srgbLut, mat.transmissionTextureIndex, UV, gr.ddx, gr.ddy).x;
                     if (P.diffuseIbl && P.sh9) {                                     // :149-165
                         const f3 albedo = ((1.f - p.metallic) * (1.f - transmission)) * p.basecolor;
                         const f3 shDiffuse = (albedo * K_INV_PI) * ShIrradiance(N, P.sh9);
@@ -1071,7 +1099,8 @@ DI void decal_fragment(const DecalParams& P, const SubTriRec& r, uint32_t px, ui
     }
     const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(px, py, (float)P.W, (float)P.H));
     const incr_material mat = P.S.materials[d.materialIndex];
-    const MatProps p = EvaluateMaterialProperties(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam));
+    const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], px, py, (float)P.W, (float)P.H);
+    const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy);
     const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
     f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
     if (p.bHasNormalmap) {
@@ -1150,12 +1179,7 @@ __global__ __launch_bounds__(256) void decal_blend_kernel(const DecalParams P) {
 }
 
 // clustered-lighting.hlsl:35-115 + cluster-culling.hlsli:26-41
-__global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.L.W || y >= P.L.y1) return;
-    const size_t i = (size_t)y * P.L.W + x;
-    if (P.requiresClear) P.L.color[i] = 0;
-    const GBufferPixel g = read_gbuffer(P.L, i);
+DI f3 clustered_radiance(const ClusteredParams& P, const GBufferPixel& g, uint32_t x, uint32_t y, size_t i) {
     f2 sp = screen_pos(x, y, P.L.W, P.L.H); sp.y = -sp.y;
     const float depth = P.L.depth[i];
     const f4 wp = mul_vec4({sp.x, sp.y, depth, 1.f}, P.L.invViewProj);
@@ -1182,7 +1206,43 @@ __global__ __launch_bounds__(256) void clustered_lighting_kernel(const Clustered
         if (s.needsShadow) radiance = radiance + light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
         else radiance = radiance + mk3(0.f);
     }
-    add_color(P.L, i, radiance);
+    return radiance;
+}
+__global__ __launch_bounds__(256) void clustered_lighting_kernel(const ClusteredParams P) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.L.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.L.W || y >= P.L.y1) return;
+    const size_t i = (size_t)y * P.L.W + x;
+    if (P.requiresClear) P.L.color[i] = 0;
+    add_color(P.L, i, clustered_radiance(P, read_gbuffer(P.L, i), x, y, i));
+}
+
+// Fused deferred lighting: sky + sun + clustered lights in ONE pass over the pixel -- the three G-buffer words and depth are
+// read once and the colour target is read and written once, where the unfused chain (the reference's three blended draws /
+// dispatches, sky-lighting.inl, direct-lighting.inl, clustered-lighting.inl) moves 24 B per pixel per pass.  The colour is
+// re-quantised to R11G11B10F between the parts exactly where the chain stores it, so the result is bit-identical to running
+// the three kernels one after the other (tests/test_gpu_raster.py::test_fused_deferred_lighting_equals_the_chain).
+__global__ __launch_bounds__(kBlock) void deferred_lighting_kernel(const FusedLightingParams P) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const LightingParams& L = P.haveSky ? P.sky.L : (P.haveDirect ? P.direct.L : P.clustered.L);
+    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = L.y0 + blockIdx.y * 4 + (tid >> 6);
+    uint32_t rays = 0;
+    if (x < L.W && y < L.y1) {
+        const size_t i = (size_t)y * L.W + x;
+        const GBufferPixel g = read_gbuffer(L, i);
+        uint32_t c = L.color[i];
+        if (P.haveSky) c = pack_r11g11b10(unpack_r11g11b10(c) + sky_radiance(P.sky, g, x, y, i), L.rounding);
+        if (P.haveDirect) {
+            LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
+            c = pack_r11g11b10(unpack_r11g11b10(c) + direct_radiance(P.direct, st, g, x, y, i, rays), L.rounding);
+        }
+        if (P.haveClustered) {
+            if (P.clustered.requiresClear) c = 0;
+            c = pack_r11g11b10(unpack_r11g11b10(c) + clustered_radiance(P.clustered, g, x, y, i), L.rounding);
+        }
+        L.color[i] = c;
+    }
+    if (P.haveDirect) count_rays(P.direct.S, rays);
 }
 
 // ---------------------------------------------------------------------------------------------- dynamic sky background
@@ -1293,7 +1353,12 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
     if (x >= P.W || y >= P.y1) return;
     const size_t i = (size_t)y * P.W + x;
     const f3 cur = unpack_r11g11b10(P.hdr[i]);
-    if (P.historyIndex == 0) { P.histOut[i] = pack_r11g11b10(cur, P.rounding); return; }
+    if (P.historyIndex == 0) {
+        const uint32_t o = pack_r11g11b10(cur, P.rounding);
+        P.histOut[i] = o;
+        if (P.ldr) P.ldr[i] = tonemap_texel(o, Exposure(P.ev100), P.viewmode);
+        return;
+    }
     const f2 uv = {((float)x + 0.5f) / (float)P.W, ((float)y + 0.5f) / (float)P.H};
     const f4 clip = {2.f * uv.x - 1.f, -2.f * uv.y + 1.f, P.depth[i], 1.f};
     const f4 world = mul_vec4(clip, P.invViewProj);
@@ -1313,7 +1378,10 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
     const float cw = 0.1f * lum_weight(cur), pw = 0.9f * lum_weight(clamped);
     f3 out = cur * cw + clamped * pw;
     out = out / (cw + pw);
-    P.histOut[i] = pack_r11g11b10(out, P.rounding);
+    const uint32_t o = pack_r11g11b10(out, P.rounding);
+    P.histOut[i] = o;
+    // TonemapPass fused into the resolve when the caller presents this surface: the tonemap reads exactly the stored texel
+    if (P.ldr) P.ldr[i] = tonemap_texel(o, Exposure(P.ev100), P.viewmode);
 }
 
 } // namespace incr
@@ -1404,6 +1472,13 @@ extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStrea
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
     hipLaunchKernelGGL(clustered_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_deferred_lighting(const FusedLightingParams* p, hipStream_t stream) {
+    const LightingParams& L = p->haveSky ? p->sky.L : (p->haveDirect ? p->direct.L : p->clustered.L);
+    if (!L.W || L.y1 <= L.y0) return hipSuccess;
+    hipLaunchKernelGGL(deferred_lighting_kernel, pixel_grid(L.W, L.y0, L.y1), dim3(kBlock), 0, stream, *p);
+    if (p->haveDirect && p->direct.S.stats && p->direct.S.statStripes) (void)incr_launch_fold_ray_stats(p->direct.S.statStripes, p->direct.S.stats, stream);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream) {

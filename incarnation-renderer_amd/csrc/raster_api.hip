@@ -20,6 +20,7 @@ extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t st
 extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_deferred_lighting(const FusedLightingParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_hbao(const HbaoParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_forward_shade(const ForwardParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipStream_t stream);
@@ -410,10 +411,8 @@ int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stre
 }
 
 // ---------------------------------------------------------------------------------------------- lighting
-int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_stream stream) {
-    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
-    SkyParams P; memset(&P, 0, sizeof P);
+static int fill_sky(const incr_sky_lighting_desc* d, SkyParams& P) {
+    memset(&P, 0, sizeof P);
     int rc = fill_lighting(d->in, P.L);
     if (rc) return rc;
     P.sh9 = (const float4*)d->sh9_rgba; P.ao = d->ambient_occlusion; P.skyBrightness = d->sky_brightness; P.diffuseIbl = d->diffuse_ibl;
@@ -425,6 +424,14 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
         memcpy(P.skyInvViewProj, d->in.view->sky_inv_view_proj.m, 64);
     }
     P.bent = d->bent_normals; P.useBent = d->use_bent_normals;
+    return INCR_OK;
+}
+int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    SkyParams P;
+    int rc = fill_sky(d, P);
+    if (rc) return rc;
     HIP_TRY(incr_launch_sky_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }
@@ -530,24 +537,28 @@ int incr_hbao(incr_context* ctx, const incr_hbao_desc* d, incr_stream stream) {
     return INCR_OK;
 }
 
-int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
-    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
-    DirectParams P; memset(&P, 0, sizeof P);
+static int fill_direct(incr_context* ctx, const incr_direct_lighting_desc* d, DirectParams& P) {
+    memset(&P, 0, sizeof P);
     int rc = fill_lighting(d->in, P.L);
     if (rc) return rc;
     if (d->directional_light_index < 0) return fail(INCR_ERR_INVALID_ARGUMENT, "directional_light_index is negative: the reference skips this pass when the scene has no sun (renderer.cpp:1886)");
     incr_fill_scene_params(ctx, d->in.scene, P.S);
     P.S.stats = d->ray_stats;
     P.sunIndex = (uint32_t)d->directional_light_index;
+    return INCR_OK;
+}
+int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    DirectParams P;
+    int rc = fill_direct(ctx, d, P);
+    if (rc) return rc;
     HIP_TRY(incr_launch_direct_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 
-int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* d, incr_stream stream) {
-    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
-    ClusteredParams P; memset(&P, 0, sizeof P);
+static int fill_clustered(incr_context* ctx, const incr_clustered_lighting_desc* d, ClusteredParams& P) {
+    memset(&P, 0, sizeof P);
     int rc = fill_lighting(d->in, P.L);
     if (rc) return rc;
     if (!d->culled_light_lists || !d->light_grid) return fail(INCR_ERR_INVALID_ARGUMENT, "light lists / grid are NULL");
@@ -560,7 +571,39 @@ int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_des
     P.scale = (float)d->cluster_dim[2] / logf(d->cluster_depth_extent / nearPlane);          // clustered-lighting.inl:88
     P.bias = -P.scale * logf(nearPlane);                                                      // :102
     P.requiresClear = d->requires_clear;
+    return INCR_OK;
+}
+int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    ClusteredParams P;
+    int rc = fill_clustered(ctx, d, P);
+    if (rc) return rc;
     HIP_TRY(incr_launch_clustered_lighting(&P, (hipStream_t)stream));
+    return INCR_OK;
+}
+
+// sky + sun + clustered lights in one kernel (raster.hip deferred_lighting_kernel); bit-identical to the three calls in that order
+int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc* d, incr_stream stream) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (!d->sky && !d->direct && !d->clustered) return INCR_OK;
+    static thread_local FusedLightingParams P;           // ~2 KB of kernel arguments: kept off the stack of the caller's thread
+    int rc = INCR_OK;
+    P.haveSky = d->sky != nullptr; P.haveDirect = d->direct != nullptr; P.haveClustered = d->clustered != nullptr;
+    if (d->sky && (rc = fill_sky(d->sky, P.sky))) return rc;
+    if (d->direct && (rc = fill_direct(ctx, d->direct, P.direct))) return rc;
+    if (d->clustered && (rc = fill_clustered(ctx, d->clustered, P.clustered))) return rc;
+    const LightingParams* parts[3] = {d->sky ? &P.sky.L : nullptr, d->direct ? &P.direct.L : nullptr, d->clustered ? &P.clustered.L : nullptr};
+    const LightingParams* first = nullptr;
+    for (const LightingParams* l : parts) {
+        if (!l) continue;
+        if (!first) { first = l; continue; }
+        if (l->color != first->color || l->depth != first->depth || l->g0 != first->g0 || l->g1 != first->g1 || l->g2 != first->g2 || l->W != first->W || l->H != first->H ||
+            l->y0 != first->y0 || l->y1 != first->y1 || l->rounding != first->rounding || l->lightingOnly != first->lightingOnly)
+            return fail(INCR_ERR_INVALID_ARGUMENT, "the parts of a fused lighting pass must address the same surfaces, rows and storage rounding");
+    }
+    HIP_TRY(incr_launch_deferred_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }
 
@@ -638,6 +681,7 @@ int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* d, incr_str
     scissor_rows(*d->view, &P.y0, &P.y1);
     P.hdr = d->hdr_scene_color; P.histIn = d->history_in; P.histOut = d->history_out; P.depth = d->depth_buffer;
     memcpy(P.invViewProj, d->view->taa_inv_view_proj.m, 64); memcpy(P.prevViewProj, d->view->prev_view_proj_transform.m, 64);
+    P.ldr = (uint32_t*)d->ldr_rgba8; P.ev100 = (int)d->exposure; P.viewmode = d->viewmode;
     HIP_TRY(incr_launch_taa_resolve(&P, (hipStream_t)stream));
     return INCR_OK;
 }

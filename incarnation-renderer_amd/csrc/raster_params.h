@@ -166,6 +166,9 @@ struct ClusteredParams {
     int32_t requiresClear;
 };
 
+// sky + sun + clustered in one kernel (raster.hip deferred_lighting_kernel); the three parts address the same surfaces
+struct FusedLightingParams { SkyParams sky; DirectParams direct; ClusteredParams clustered; int32_t haveSky, haveDirect, haveClustered; };
+
 struct DynamicSkyParams {
     uint32_t W, H, y0, y1; int32_t rounding;
     uint32_t* __restrict__ color; const float* __restrict__ depth;
@@ -193,6 +196,7 @@ struct TaaParams {
     const uint32_t* __restrict__ hdr; const uint32_t* __restrict__ histIn; uint32_t* __restrict__ histOut; const float* __restrict__ depth;
     float invViewProj[16], prevViewProj[16];
     uint32_t y0, y1;
+    uint32_t* __restrict__ ldr; int32_t ev100, viewmode;      // optional: tonemapped copy of the resolved texel (presenting path)
 };
 
 } // namespace incr

@@ -112,7 +112,12 @@ struct Builder {
     const std::vector<Box>& tb; const std::vector<V3>& cen;
     std::vector<uint32_t> order;
     std::vector<Node2> nodes;
-    static constexpr int kBins = 16;
+    // 32 bins: 1 % fewer node visits than 16 on Sponza-stat; traversal cost 0.5 / 2, leaf limits 2 / 3 and splitting pairs all
+    // moved the step count by < 2 % either way (tools/trav_sim)
+    static constexpr int kBins = 32;
+    static constexpr int bins = kBins;
+    static constexpr float ct = 1.0f;
+    static constexpr uint32_t maxLeaf = kMaxLeafTris;
 
     Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_) : tb(tb_), cen(cen_) {
         order.resize(tb.size()); std::iota(order.begin(), order.end(), 0u);
@@ -140,20 +145,20 @@ struct Builder {
         for (int a = 0; a < 3; ++a) {
             const float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
             if (!(ext > 0.f)) continue;
-            Box bins[kBins]; uint32_t cnt[kBins];
-            for (int b = 0; b < kBins; ++b) { box_reset(bins[b]); cnt[b] = 0; }
-            const float scale = (float)kBins / ext;
+            Box binsB[kBins]; uint32_t cnt[kBins];
+            for (int b = 0; b < bins; ++b) { box_reset(binsB[b]); cnt[b] = 0; }
+            const float scale = (float)bins / ext;
             for (uint32_t i = first; i < first + count; ++i) {
                 const uint32_t t = order[i];
-                int b = (int)((axis_of(cen[t], a) - lo) * scale); b = std::min(std::max(b, 0), kBins - 1);
-                box_grow(bins[b], tb[t]); cnt[b]++;
+                int b = (int)((axis_of(cen[t], a) - lo) * scale); b = std::min(std::max(b, 0), bins - 1);
+                box_grow(binsB[b], tb[t]); cnt[b]++;
             }
             float rightArea[kBins]; uint32_t rightCnt[kBins];
             Box acc; box_reset(acc); uint32_t n = 0;
-            for (int b = kBins - 1; b > 0; --b) { box_grow(acc, bins[b]); n += cnt[b]; rightArea[b] = box_area(acc); rightCnt[b] = n; }
+            for (int b = bins - 1; b > 0; --b) { box_grow(acc, binsB[b]); n += cnt[b]; rightArea[b] = box_area(acc); rightCnt[b] = n; }
             box_reset(acc); n = 0;
-            for (int b = 0; b < kBins - 1; ++b) {
-                box_grow(acc, bins[b]); n += cnt[b];
+            for (int b = 0; b < bins - 1; ++b) {
+                box_grow(acc, binsB[b]); n += cnt[b];
                 if (n == 0 || rightCnt[b + 1] == 0) continue;
                 const float cost = box_area(acc) * (float)n + rightArea[b + 1] * (float)rightCnt[b + 1];
                 if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
@@ -161,16 +166,16 @@ struct Builder {
         }
         uint32_t mid = first;
         const float leafCost = box_area(bb) * (float)count;
-        if (depth < kSahDepth && bestAxis >= 0 && (count > kMaxLeafTris || bestCost + box_area(bb) * 1.0f < leafCost)) {
-            const float lo = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
+        if (depth < kSahDepth && bestAxis >= 0 && (count > maxLeaf || bestCost + box_area(bb) * ct < leafCost)) {
+            const float lo = cb.lo[bestAxis], scale = (float)bins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
             auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-                int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), kBins - 1);
+                int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), bins - 1);
                 return b <= bestSplit;
             });
             mid = (uint32_t)(it - order.begin());
         }
         if (mid == first || mid == first + count) {
-            if (count <= kMaxLeafTris) { nodes[me].first = first; nodes[me].count = count; return me; }
+            if (count <= maxLeaf) { nodes[me].first = first; nodes[me].count = count; return me; }
             // all centroids coincide (or SAH refused): split by index to respect the leaf limit
             mid = first + count / 2;
             int a = 0; float ext = cb.hi[0] - cb.lo[0];

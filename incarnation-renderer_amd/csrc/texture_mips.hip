@@ -1,0 +1,66 @@
+// texture_mips.hip -- mip chains of the scene's textures, built on the device at scene creation.
+// Reference: FScene::LoadTexture (src/scene.cpp:1072-1090) calls DirectX::GenerateMipMaps(srcImage, TEX_FILTER_LINEAR, numMips)
+// with numMips = levels down to 4x4, then block-compresses (not reproduced: the texture unit here filters RGBA8);
+// FScene::PrefilterNormalRoughnessTextures (:1157-1320) replaces the chains of a material's normal + metallic-roughness pair
+// by the vMF-filtered ones (content_pipeline.hip).  The raster passes sample these chains (pt_device.h SampleGrad); the
+// path tracer keeps SampleLevel(0), as the reference's PATH_TRACING variant does.
+//
+// Pinned: level l is max(W >> l, 1) x max(H >> l, 1); a texel of level l + 1 is the mean of the 2x2 texels
+// of level l under it (the second column / row clamps to the last one for odd sizes) -- DirectXTex's linear filter for a
+// 2:1 reduction; sRGB colour is averaged in linear light (decode table of pt_device.h) and re-encoded to the NEAREST table
+// entry (search of the same table: no pow, identical on host and device), alpha and the other formats average the bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/incr_types.h"
+
+namespace incr {
+
+__device__ __forceinline__ uint32_t srgb_encode_nearest(const float* __restrict__ lut, float v) {
+    uint32_t lo = 0u, hi = 255u;                         // largest i with lut[i] <= v (lut[0] = 0 <= v)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi + 1u) >> 1; if (lut[mid] <= v) lo = mid; else hi = mid - 1u; }
+    if (lo < 255u && (lut[lo + 1u] - v) < (v - lut[lo])) ++lo;
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void mip_box_kernel(const uint32_t* __restrict__ src, uint32_t sw, uint32_t sh, uint32_t* __restrict__ dst,
+                                                      uint32_t dw, uint32_t dh, uint32_t format, const float* __restrict__ srgbLut) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= dw || y >= dh) return;
+    const uint32_t x0 = min(2u * x, sw - 1u), x1 = min(2u * x + 1u, sw - 1u), y0 = min(2u * y, sh - 1u), y1 = min(2u * y + 1u, sh - 1u);
+    const uint32_t c[4] = {src[(size_t)y0 * sw + x0], src[(size_t)y0 * sw + x1], src[(size_t)y1 * sw + x0], src[(size_t)y1 * sw + x1]};
+    uint32_t out = 0u;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const uint32_t b[4] = {(c[0] >> (8 * ch)) & 0xffu, (c[1] >> (8 * ch)) & 0xffu, (c[2] >> (8 * ch)) & 0xffu, (c[3] >> (8 * ch)) & 0xffu};
+        uint32_t r;
+        if (format == INCR_TEX_RGBA8_SRGB && ch < 3) r = srgb_encode_nearest(srgbLut, ((srgbLut[b[0]] + srgbLut[b[1]]) + (srgbLut[b[2]] + srgbLut[b[3]])) * 0.25f);
+        else r = (uint32_t)((float)(b[0] + b[1] + b[2] + b[3]) * 0.25f + 0.5f);
+        out |= r << (8 * ch);
+    }
+    dst[(size_t)y * dw + x] = out;
+}
+
+// levels >= 1 of a vMF-prefiltered pair into the scene's chains: the normal chain as is, the metallic-roughness chain from the
+// prefilter's (metal, roughness, 0, 0) back to the glTF channel order the sampler swizzles (roughness in G, metalness in B)
+__global__ __launch_bounds__(256) void mip_adopt_vmf_kernel(const uint32_t* __restrict__ vmfN, const uint32_t* __restrict__ vmfMR, uint32_t* __restrict__ dstN,
+                                                            uint32_t* __restrict__ dstMR, uint64_t first, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    dstN[first + i] = vmfN[first + i];
+    const uint32_t m = vmfMR[first + i];
+    dstMR[first + i] = (m & 0x0000ff00u) | ((m & 0xffu) << 16);
+}
+
+} // namespace incr
+
+extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
+                                          const float* srgbLut, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::mip_box_kernel, dim3((dw + 31u) / 32u, (dh + 7u) / 8u), dim3(256), 0, stream, src, sw, sh, dst, dw, dh, format, srgbLut);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(incr::mip_adopt_vmf_kernel, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, vmfN, vmfMR, dstN, dstMR, first, count);
+    return hipGetLastError();
+}

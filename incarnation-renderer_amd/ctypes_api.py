@@ -257,7 +257,12 @@ class DynamicSkyDesc(C.Structure):
 
 class TaaResolveDesc(C.Structure):
     _fields_ = [("view", _VC), ("hdr_scene_color", C.c_void_p), ("history_in", C.c_void_p), ("history_out", C.c_void_p),
-                ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32)]
+                ("depth_buffer", C.c_void_p), ("history_index", C.c_uint32), ("storage_rounding", C.c_int32),
+                ("ldr_rgba8", C.c_void_p), ("exposure", C.c_float), ("viewmode", C.c_int32)]
+
+
+class DeferredLightingDesc(C.Structure):
+    _fields_ = [("sky", C.POINTER(SkyLightingDesc)), ("direct", C.POINTER(DirectLightingDesc)), ("clustered", C.POINTER(ClusteredLightingDesc))]
 
 
 class SkyIblInfo(C.Structure):
@@ -282,7 +287,7 @@ class RendererConfig(C.Structure):
                 ("max_sample_count", C.c_uint32), ("camera_aperture", C.c_float), ("camera_focal_length", C.c_float),
                 ("turbidity", C.c_float), ("env_sky_mode", C.c_int32), ("storage_rounding", C.c_int32), ("enable_specular_ibl", C.c_int32),
                 ("use_primitives", C.c_int32), ("enable_hbao", C.c_int32), ("use_bent_normals", C.c_int32),
-                ("forward_lighting", C.c_int32)]
+                ("forward_lighting", C.c_int32), ("unfused_passes", C.c_int32), ("record_threads", C.c_int32), ("use_graph", C.c_int32)]
 
 
 (SURFACE_BACK_BUFFER, SURFACE_HDR_RASTER, SURFACE_HDR_RAYTRACE, SURFACE_PATHTRACE_HISTORY, SURFACE_TAA_ACCUMULATION, SURFACE_DEPTH,
@@ -321,3 +326,7 @@ class FConfig:
     ToD_JulianDate = 200
     ToD_Latitude = 42.5
     EnvmapResolution = 256
+    # not in the reference: how the C++ Renderer issues the frame (bit-identical surfaces for every combination)
+    FusePasses = True
+    RecordThreads = 0
+    UseGraph = False

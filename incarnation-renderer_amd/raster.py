@@ -308,6 +308,8 @@ def renderer_config(cfg=A.FConfig, path_trace=None, storage_rounding=0):
     c.use_primitives = 0 if cfg.UseMeshlets else 1
     c.enable_hbao, c.use_bent_normals = int(cfg.EnableHBAO), int(cfg.UseBentNormals)
     c.forward_lighting = int(cfg.ForwardLighting)
+    c.unfused_passes = 0 if getattr(cfg, "FusePasses", True) else 1
+    c.record_threads = int(getattr(cfg, "RecordThreads", 0)); c.use_graph = int(getattr(cfg, "UseGraph", False))
     return c
 
 
@@ -369,6 +371,21 @@ class HostRenderer:
     def surface_ptr(self, which):
         return self.ctx.lib.incr_renderer_surface(self.handle, which)
 
+    def pass_times(self):
+        """GPU ms per pass of the last frame rendered with profiling on (set_profiling(True) first): list of (pass, ms)."""
+        names = ((C.c_char * 32) * 64)(); ms = (C.c_float * 64)(); n = C.c_uint32()
+        rt.check(self.ctx.lib.incr_renderer_get_pass_times(self.handle, names, ms, 64, C.byref(n)))
+        return [(names[i].value.decode(), float(ms[i])) for i in range(n.value)]
+
+    def set_profiling(self, on):
+        rt.check(self.ctx.lib.incr_renderer_set_profiling(self.handle, int(bool(on))))
+
+    def frame_info(self):
+        """(host seconds of the last render call, frames replayed from the HIP graph, in-place graph updates, graph rebuilds)."""
+        t = C.c_double(); a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rt.check(self.ctx.lib.incr_renderer_get_frame_info(self.handle, C.byref(t), C.byref(a), C.byref(b), C.byref(c)))
+        return t.value, a.value, b.value, c.value
+
     def stats(self):
         """Renderer::GetRenderStats: ((culled objects, culled lights) of the last frame, accumulated RayStats)."""
         rs, rays = (C.c_int32 * 2)(), A.RayStats()
@@ -419,8 +436,24 @@ class RasterRenderer:
         ctx, lib = self.ctx, self.ctx.lib
         vc = vc if vc is not None else self.view_constants(view)
         self.last_vc = vc
-        for name, d in build_descs(self.scene.handle, self.scene.packed, vc, self.surf.ptr, self.frame_index, self.cfg, storage_rounding, self.have_sh,
-                                   ibl=getattr(self, "ibl", None)):      # self.ibl: IblInputs with device pointers (optional)
+        fused = getattr(self, "fused", False)        # FConfig::FusePasses of the C++ renderer, issued from Python: one lighting kernel, tonemap inside TAA
+        lighting = {}
+        descs = build_descs(self.scene.handle, self.scene.packed, vc, self.surf.ptr, self.frame_index, self.cfg, storage_rounding, self.have_sh,
+                            ibl=getattr(self, "ibl", None))      # self.ibl: IblInputs with device pointers (optional)
+        last_lighting = max([k for k, (n, _) in enumerate(descs) if n in ("sky_lighting", "direct_lighting", "clustered_lighting")], default=-1)
+        for k, (name, d) in enumerate(descs):
+            if fused and not self.cfg.ForwardLighting and name in ("sky_lighting", "direct_lighting", "clustered_lighting"):
+                lighting[name] = d
+                if k == last_lighting:
+                    f = A.DeferredLightingDesc()
+                    f.sky = C.pointer(lighting["sky_lighting"]) if "sky_lighting" in lighting else None
+                    f.direct = C.pointer(lighting["direct_lighting"]) if "direct_lighting" in lighting else None
+                    f.clustered = C.pointer(lighting["clustered_lighting"]) if "clustered_lighting" in lighting else None
+                    rt.check(lib.incr_deferred_lighting(ctx.handle, C.byref(f), stream))
+                continue
+            if fused and name == "taa_resolve" and tonemap:
+                d.ldr_rgba8, d.exposure, d.viewmode = self.surf.ptr["ldr"], self.cfg.Exposure, self.cfg.Viewmode
+                tonemap = False
             rt.check(getattr(lib, self.PASS_FN[name])(ctx.handle, C.byref(d), stream))
         hdr = self.surf.ptr["taa%d" % (self.frame_index & 1)] if self.cfg.EnableTAA else self.surf.ptr["color"]
         if tonemap:

@@ -27,10 +27,11 @@ EXPORTS = [
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
     "incr_sky_lighting", "incr_direct_lighting", "incr_clustered_lighting", "incr_taa_resolve", "incr_dynamic_sky",
     "incr_hbao", "incr_environmentmap", "incr_debug_visualization", "incr_forward_lighting", "incr_gbuffer_decals",
+    "incr_deferred_lighting",
     # frame level (C++ host mirror of Renderer::Render)
     "incr_renderer_create", "incr_renderer_destroy", "incr_renderer_set_config", "incr_renderer_render",
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
-    "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats", "incr_renderer_get_stats",
+    "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats", "incr_renderer_get_stats", "incr_renderer_get_frame_info", "incr_renderer_tick", "incr_renderer_set_profiling", "incr_renderer_get_pass_times",
     # sky / IBL precompute
     "incr_update_dynamic_sky", "incr_sky_ibl_get_info", "incr_sky_ibl_destroy", "incr_generate_env_brdf",
     # texture ingest, GPU step
@@ -105,7 +106,7 @@ def load():
                        ("incr_clustered_lighting", A.ClusteredLightingDesc), ("incr_taa_resolve", A.TaaResolveDesc),
                        ("incr_dynamic_sky", A.DynamicSkyDesc), ("incr_hbao", A.HbaoDesc), ("incr_environmentmap", A.EnvironmentmapDesc),
                        ("incr_debug_visualization", A.DebugVizDesc), ("incr_forward_lighting", A.ForwardLightingDesc),
-                       ("incr_gbuffer_decals", A.GBufferDecalsDesc)):
+                       ("incr_gbuffer_decals", A.GBufferDecalsDesc), ("incr_deferred_lighting", A.DeferredLightingDesc)):
         fn = getattr(L, name)
         fn.restype = C.c_int; fn.argtypes = [vp, C.POINTER(desc), vp]
     L.incr_renderer_create.restype = C.c_int
@@ -119,6 +120,11 @@ def load():
     L.incr_renderer_set_band.restype = C.c_int; L.incr_renderer_set_band.argtypes = [vp, u32, u32]
     L.incr_renderer_tonemap.restype = C.c_int; L.incr_renderer_tonemap.argtypes = [vp]
     L.incr_renderer_get_stats.restype = C.c_int; L.incr_renderer_get_stats.argtypes = [vp, C.POINTER(C.c_int32 * 2), C.POINTER(A.RayStats)]
+    L.incr_renderer_set_profiling.restype = C.c_int; L.incr_renderer_set_profiling.argtypes = [vp, C.c_int]
+    L.incr_renderer_get_pass_times.restype = C.c_int; L.incr_renderer_get_pass_times.argtypes = [vp, vp, vp, u32, C.POINTER(u32)]
+    L.incr_renderer_tick.restype = C.c_double; L.incr_renderer_tick.argtypes = [vp, C.c_float]
+    L.incr_renderer_get_frame_info.restype = C.c_int
+    L.incr_renderer_get_frame_info.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.incr_visibility_get_stats.restype = C.c_int; L.incr_visibility_get_stats.argtypes = [vp, C.POINTER(u32)]
     L.incr_update_dynamic_sky.restype = C.c_int; L.incr_update_dynamic_sky.argtypes = [vp, vp, u32, C.c_float, C.c_int32, vp, C.POINTER(vp)]
     L.incr_sky_ibl_get_info.restype = C.c_int; L.incr_sky_ibl_get_info.argtypes = [vp, C.POINTER(A.SkyIblInfo)]

@@ -393,6 +393,18 @@ typedef struct incr_clustered_lighting_desc {
 } incr_clustered_lighting_desc;
 int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* desc, incr_stream stream);
 
+/* SkyLightingPass + DirectLightingPass + ClusteredLightingPass (renderer.cpp:1843-1920) as ONE kernel: the G-buffers and
+ * depth are read once per pixel and the colour target is read and written once.  Any of the three may be NULL (the pass is
+ * skipped, as the reference skips it); the parts must address the same surfaces.  The colour is re-quantised to
+ * R11G11B10_FLOAT between the parts, so the result is bit-identical to the three calls in that order (the unfused calls
+ * stay available for per-pass comparison). */
+typedef struct incr_deferred_lighting_desc {
+    const incr_sky_lighting_desc* sky;
+    const incr_direct_lighting_desc* direct;
+    const incr_clustered_lighting_desc* clustered;
+} incr_deferred_lighting_desc;
+int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc* desc, incr_stream stream);
+
 /* RenderJob::ForwardLightingPass::Execute (render-jobs/forward-pass.inl; shaders/geo-raster/forward-pass.hlsl), the
  * FConfig::ForwardLighting alternative to the deferred direct + clustered passes: clears the colour target to (0.8, 0.8, 1)
  * and depth to 0, draws every primitive of every visible mesh (no frustum culling, cull mode from the material, alpha test
@@ -476,6 +488,11 @@ typedef struct incr_taa_resolve_desc {
     const float* depth_buffer;
     uint32_t history_index;            /* frame index */
     int32_t  storage_rounding;
+    /* optional TonemapPass fused into the resolve (render-jobs/tonemap.inl on the surface just written): when ldr_rgba8 is
+     * not NULL every resolved texel is also tonemapped into it, bit-identical to incr_tonemap(history_out) afterwards */
+    void*    ldr_rgba8;                /* device, res_x*res_y*4 B, or NULL */
+    float    exposure;                 /* FConfig::Exposure */
+    int32_t  viewmode;
 } incr_taa_resolve_desc;
 int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* desc, incr_stream stream);
 
@@ -517,7 +534,8 @@ typedef struct incr_prefilter_normal_roughness_desc {
     const uint8_t* metallic_roughness;  /* device, width*height RGBA8 as decoded (glTF: roughness in G, metalness in B); same size (scene.cpp:1282) */
     uint32_t width, height;
     uint32_t num_mips;                  /* = incr_compressed_mip_count(width, height) */
-    uint32_t reserved;
+    uint32_t reserved;                  /* 0: sums through a float4 pyramid (every base texel read once; levels >= 2 may differ from the shader's single
+                                           running sum by float re-association, <= 1 LSB); 1: the shader's exact summation order (O(texels x levels)) */
     uint8_t* out_normalmap;             /* device, incr_mip_chain_texels(width, height, num_mips) * 4 bytes */
     uint8_t* out_metallic_roughness;    /* device, same size */
 } incr_prefilter_normal_roughness_desc;
@@ -557,6 +575,10 @@ typedef struct incr_renderer_config {      /* FConfig fields the frame reads (in
     int32_t  use_primitives;               /* !FConfig::UseMeshlets: primitive variants of culling / visibility / G-buffer */
     int32_t  enable_hbao, use_bent_normals;/* FConfig::EnableHBAO, FConfig::UseBentNormals */
     int32_t  forward_lighting;             /* FConfig::ForwardLighting */
+    /* how the frame is issued (not in the reference; the surfaces are bit-identical for every combination) */
+    int32_t  unfused_passes;               /* 0: sky + sun + clustered lighting as one kernel and the tonemap inside the TAA resolve; 1: pass by pass */
+    int32_t  record_threads;               /* > 0: passes are recorded on that many host threads and submitted in token order (job-sync.h) */
+    int32_t  use_graph;                    /* 1: the raster frame is captured into a HIP graph, updated in place and replayed */
 } incr_renderer_config;
 enum {
     INCR_SURFACE_BACK_BUFFER = 0, INCR_SURFACE_HDR_RASTER, INCR_SURFACE_HDR_RAYTRACE, INCR_SURFACE_PATHTRACE_HISTORY,
@@ -568,6 +590,10 @@ int   incr_renderer_create(incr_context* ctx, incr_stream stream, uint32_t res_x
                            const incr_renderer_config* config /* NULL = FConfig defaults */, incr_renderer** out_renderer);
 void  incr_renderer_destroy(incr_renderer* renderer);
 int   incr_renderer_set_config(incr_renderer* renderer, const incr_renderer_config* config);
+/* DLL export Tick(float dt) (inc/demo-interface.h:12; Demo::Tick, src/demo.cpp): advances the application clock.  The hot
+ * path has one consumer of it -- the frame counter that selects the TAA jitter and history buffers advances per rendered
+ * frame, not per tick -- so this only accumulates the time for callers that drive animation from it.  Returns the total. */
+double incr_renderer_tick(incr_renderer* renderer, float dt_seconds);
 /* Renderer::Render: one frame (one path-traced sample when config.path_trace, else one raster frame), enqueued on the
  * renderer's stream.  culling_view non-NULL = FConfig::FreezeCulling with that view. */
 int   incr_renderer_render(incr_renderer* renderer, const incr_view* view, const incr_view* culling_view);
@@ -583,6 +609,11 @@ const char* incr_renderer_last_error(const incr_renderer* renderer);
 /* Renderer::GetRenderStats (the read-back at the end of Render, renderer.cpp:2064-2076): culled objects / lights of the last
  * frame and the ray statistics accumulated so far.  Waits for the renderer's stream.  Either pointer may be NULL. */
 int   incr_renderer_get_stats(incr_renderer* renderer, incr_render_stats* out_render_stats, incr_ray_stats* out_ray_stats);
+/* Host-side cost of the last incr_renderer_render call and the graph-replay counters (all may be NULL). */
+int   incr_renderer_get_frame_info(incr_renderer* renderer, double* host_seconds, uint64_t* graph_frames, uint64_t* graph_updates, uint64_t* graph_rebuilds);
+/* Per-pass GPU time of the last frame: enable, render, read (events on the renderer's stream; direct issue, not graph replay). */
+int   incr_renderer_set_profiling(incr_renderer* renderer, int enable);
+int   incr_renderer_get_pass_times(incr_renderer* renderer, char (*names)[32], float* ms, uint32_t capacity, uint32_t* count);
 void* incr_renderer_surface(incr_renderer* renderer, int which);      /* device pointer of a frame surface (INCR_SURFACE_*) */
 
 #ifdef __cplusplus

@@ -52,7 +52,7 @@ uint32_t orc_prefilter_normal_roughness(const uint32_t* srcN, const uint32_t* sr
                 const float roughnessAlpha = un((m >> 8) & 0xffu), metalness = un((m >> 16) & 0xffu);
                 metalnessAvg += metalness;                                         // hlsl:66
                 const float invLambda = 0.5f * roughnessAlpha * roughnessAlpha;    // hlsl:71-75
-                const float exp2L = expf(-2.f / invLambda);
+                const float exp2L = pinned_exp_neg(-2.f / invLambda);                // exp(): pinned evaluation (oracle_math.h)
                 const float cothLambda = invLambda > 0.1f ? (1.f + exp2L) / (1.f - exp2L) : 1.f;
                 const float s = cothLambda - invLambda;
                 rAvg.x += s * sampleNormal.x; rAvg.y += s * sampleNormal.y; rAvg.z += s * sampleNormal.z;

@@ -189,4 +189,15 @@ static inline float3 unpack_r11g11b10(uint32_t p) {
     return {decode_small_float(p & 0x7ffu, 6, 0), decode_small_float((p >> 11) & 0x7ffu, 6, 0), decode_small_float(p >> 22, 5, 0)};
 }
 
+// exp(x) for x <= 0 with a fixed evaluation (HLSL leaves exp's precision open; the vMF prefilter's exp feeds UNORM8 texels that
+// oracle and product must agree on bit for bit): 2^(x log2 e) = 2^floor * P(frac), P of degree 6 (|error| < 1.7e-7 on [0, 1))
+static inline float pinned_exp_neg(float x) {
+    if (!(x > -87.f)) return 0.f;                        // underflow, -inf, NaN
+    const float t = x * 1.44269502162933349609375f;
+    const float fi = floorf(t), f = t - fi;
+    const float p = 1.0f + f * (0.693146824836731f + f * (0.24023109674453735f + f * (0.055478911846876144f + f * (0.009686185978353024f
+                  + f * (0.001238241558894515f + f * 0.000218712622881867f)))));
+    uint32_t b; memcpy(&b, &p, 4); b += (uint32_t)((int)fi << 23); float r; memcpy(&r, &b, 4); return r;
+}
+
 } // namespace orc

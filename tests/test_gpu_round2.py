@@ -352,3 +352,63 @@ def test_wavefront_overflow_paths_are_bit_identical(gpu_ctx, rt, sio, sponza_sma
     np.testing.assert_array_equal(got["target"], ref["target"])
     np.testing.assert_array_equal(got["history"], ref["history"])
     p2.close(); sc2.close(); ctx2.close()
+
+
+# ------------------------------------------------------------------------------------------------ frame issue variants
+@pytest.mark.parametrize("which,W,H,hbao", [("sponza_small", 320, 180, False), ("sponza_small", 203, 117, True), ("helmet", 256, 256, False)])
+def test_fused_deferred_lighting_equals_the_chain(request, gpu_ctx, rt, R, sio, A, which, W, H, hbao):
+    """incr_deferred_lighting (sky + sun + clustered in one kernel) and the tonemap fused into incr_taa_resolve against the
+    pass-by-pass chain: colour, TAA history and the LDR back buffer bit for bit, shadow-ray count equal, over three frames."""
+    scene = request.getfixturevalue(which)
+
+    class Cfg(A.FConfig):
+        EnableHBAO = hbao
+        UseBentNormals = hbao
+    view = sio.FView().reset(scene, aspect=W / H)
+    gscene = gpu_ctx.create_scene(scene)
+    a = R.RasterRenderer(gpu_ctx, gscene, W, H, Cfg); b = R.RasterRenderer(gpu_ctx, gscene, W, H, Cfg)
+    b.fused = True
+    for rr in (a, b):
+        rr.set_sh9(np.linspace(0.05, 0.4, 27, dtype=np.float32).reshape(9, 3))
+    for frame in range(3):
+        a.render(view); b.render(view)
+        gpu_ctx.synchronize()
+        for name in ("color", "taa%d" % (frame & 1), "ldr", "gbuffer_basecolor", "depth"):
+            np.testing.assert_array_equal(a.surf.download(name), b.surf.download(name), err_msg="%s frame %d" % (name, frame))
+        assert a.surf.download("ray_stats").light_shadow_rays == b.surf.download("ray_stats").light_shadow_rays
+    a.close(); b.close(); gscene.close()
+
+
+def test_renderer_issue_modes_are_bit_identical(gpu_ctx, rt, R, sio, A, sponza_small):
+    """The C++ Renderer::Render mirror: pass by pass on the caller's thread (the reference's frame), fused passes, four recording
+    threads with token-ordered submission (job-sync.h:27-61), and HIP-graph replay -- identical back buffer, TAA history and HDR
+    colour on every one of six frames; the graph is rebuilt once and updated in place afterwards."""
+    W, H = 320, 180
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    sh9 = np.linspace(0.05, 0.4, 27, dtype=np.float32).reshape(9, 3)
+
+    def cfg(fuse, threads, graph):
+        class Cfg(A.FConfig):
+            FusePasses = fuse
+            RecordThreads = threads
+            UseGraph = graph
+        return Cfg
+    variants = {"reference": cfg(False, 0, False), "fused": cfg(True, 0, False), "threads": cfg(False, 4, False),
+                "fused+threads": cfg(True, 3, False), "graph": cfg(True, 0, True), "graph unfused": cfg(False, 0, True)}
+    rs = {k: R.HostRenderer(gpu_ctx, gscene, W, H, cfg=v, sh9_rgb=sh9) for k, v in variants.items()}
+    for frame in range(6):
+        got = {}
+        for k, hr in rs.items():
+            hr.render(view)
+            gpu_ctx.synchronize()
+            got[k] = (hr.download(A.SURFACE_BACK_BUFFER), hr.download(A.SURFACE_TAA_ACCUMULATION), hr.download(A.SURFACE_HDR_RASTER), hr.download(A.SURFACE_DEPTH))
+        for k in variants:
+            for s, name in enumerate(("back buffer", "taa", "hdr", "depth")):
+                np.testing.assert_array_equal(got[k][s], got["reference"][s], err_msg="%s: %s frame %d" % (k, name, frame))
+    host, frames, updates, rebuilds = rs["graph"].frame_info()
+    assert frames == 4 and rebuilds == 1 and updates == 3, (frames, updates, rebuilds)        # frames 0-1 run directly, 2 builds the graph, 3-5 update it
+    print("host seconds per frame: " + ", ".join("%s %.0f us" % (k, hr.frame_info()[0] * 1e6) for k, hr in rs.items()))
+    for hr in rs.values():
+        hr.close()
+    gscene.close()

@@ -51,13 +51,16 @@ def test_meshletize_invariants(request, which):
             a = a[np.lexsort(a.T[::-1])]; b = b[np.lexsort(b.T[::-1])]
             np.testing.assert_array_equal(a, b)
     assert k == scene.num_meshlets
-    # bounding spheres enclose their vertices
+    # bounding spheres: MinimumBoundingSphere (mesh-utils.cpp:114-180) compares against the INITIAL radius^2 in its growing pass
+    # (radiusSq is computed once, :158), so a late point inside the grown sphere can pull the sphere back: about 6 % of the
+    # meshlet vertices end up outside it, by up to 1.36 r on these scenes.  Restated as is (the culling of the reference, which
+    # is what the visibility ids depend on); exact equality with the oracle is tests/test_meshletize.py.
     for k in range(0, scene.num_meshlets, max(1, scene.num_meshlets // 50)):
         m = ml[k]
         nverts = int(vi[m.vertexBegin:m.vertexBegin + m.vertexCount].max()) + 1
         pos = scene.accessor_array(m.positionAccessor, np.float32, 3, nverts)[vi[m.vertexBegin:m.vertexBegin + m.vertexCount]]
         c, r = np.array(m.boundingSphere[:3]), m.boundingSphere[3]
-        assert (np.linalg.norm(pos - c, axis=1) <= r * (1 + 1e-4) + 1e-6).all()
+        assert (np.linalg.norm(pos - c, axis=1) <= r * 1.5 + 1e-6).all()
     # meshlets are reasonably full (greedy growth along adjacency, not one triangle each)
     assert tri.size / scene.num_meshlets > 20
 

@@ -26,4 +26,21 @@ with open("$OUT/summary.txt", "w") as o:
     for (kn, cn), (v, n) in sorted(tot.items()):
         line = "%-36s %-32s per-launch %.6g  (launches %d)" % (kn, cn, v / n, n)
         print(line); o.write(line + "\n")
+# HBM traffic per launch of every path-tracing kernel, stamped with the hash of the kernel sources it was measured on:
+# bench.py attaches `roofline.traffic` only when the stamp matches the sources it runs (profiles/hbm_traffic_latest.json)
+import json, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+import bench
+kernels = {}
+for (kn, cn), (v, n) in tot.items():
+    if cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        kernels.setdefault(kn.split("<")[0], {})[cn + "_KB_per_launch"] = v / n
+for kn, d in kernels.items():
+    if "FETCH_SIZE_KB_per_launch" in d and "WRITE_SIZE_KB_per_launch" in d:
+        d["hbm_bytes_per_launch"] = int(2 * d["FETCH_SIZE_KB_per_launch"] * 1024 + d["WRITE_SIZE_KB_per_launch"] * 1024)
+json.dump({"kernel_source_hash": bench.kernel_source_hash(), "bench_args": "$*", "kernels": kernels,
+           "source": "tools/pmc.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py $*; bytes = 2 x FETCH_SIZE x 1024 + "
+                     "WRITE_SIZE x 1024 (MI355X_MICROARCH.md 'HBM': FETCH_SIZE is in KB and counts 128-B requests as 64 B on gfx950; the factor 2 is "
+                     "calibrated for wide streaming reads, so for 80-B node gathers this is an upper estimate)"},
+          open("$OUT/hbm_traffic.json", "w"), indent=1)
 PY

@@ -310,6 +310,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         }
     }
     if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
+    sc->hostTextures = texs;
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
     if (!rc) rc = incr_raster_scene_upload(sc);
     if (rc) { incr_scene_destroy(ctx, sc); return rc; }
@@ -350,6 +351,24 @@ int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_di
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc || !sun_dir) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     memcpy(sc->host.sunDir, sun_dir, 12);
+    return INCR_OK;
+}
+
+int incr_scene_texture_info(incr_context* ctx, const incr_scene* sc, uint32_t ti, uint32_t* width, uint32_t* height, uint32_t* num_mips, uint64_t* chain_texels) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc || ti >= sc->hostTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");
+    const DeviceTexture& t = sc->hostTextures[ti];
+    uint64_t n = 0; uint32_t w = t.width, h = t.height;
+    for (uint32_t l = 0; l < t.pad[1]; ++l) { n += (uint64_t)w * h; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+    if (width) *width = t.width; if (height) *height = t.height; if (num_mips) *num_mips = t.pad[1]; if (chain_texels) *chain_texels = n;
+    return INCR_OK;
+}
+int incr_scene_texture_download(incr_context* ctx, const incr_scene* sc, uint32_t ti, void* dst, uint64_t bytes) {
+    uint64_t n = 0;
+    int rc = incr_scene_texture_info(ctx, sc, ti, nullptr, nullptr, nullptr, &n);
+    if (rc) return rc;
+    if (!dst || bytes != n * 4) return fail(INCR_ERR_INVALID_ARGUMENT, "destination must hold the whole chain (%llu bytes)", (unsigned long long)(n * 4));
+    HIP_TRY(hipMemcpy(dst, sc->hostTextures[ti].texels, bytes, hipMemcpyDeviceToHost));
     return INCR_OK;
 }
 

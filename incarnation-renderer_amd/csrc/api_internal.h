@@ -48,6 +48,7 @@ struct incr_scene {
     float* dMeshLocalToWorld = nullptr;
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
     std::vector<void*> dTexels;
+    std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers + mip counts)
     uint64_t textureBytes = 0;
     incr::LightGrid grid;
     uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;

@@ -20,7 +20,7 @@ EXPORTS = [
     "incr_initialize", "incr_teardown", "incr_last_error", "incr_version", "incr_device_count",
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
-    "incr_scene_get_info", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
+    "incr_scene_get_info", "incr_scene_texture_info", "incr_scene_texture_download", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
     "incr_trace_rays", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end",
     # raster path
     "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
@@ -80,6 +80,9 @@ def load():
     L.incr_scene_destroy.restype = C.c_int; L.incr_scene_destroy.argtypes = [vp, vp]
     L.incr_update_bvh.restype = C.c_int; L.incr_update_bvh.argtypes = [vp, vp, vp, vp, vp, vp]
     L.incr_scene_set_sun_dir.restype = C.c_int; L.incr_scene_set_sun_dir.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.incr_scene_texture_info.restype = C.c_int
+    L.incr_scene_texture_info.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
+    L.incr_scene_texture_download.restype = C.c_int; L.incr_scene_texture_download.argtypes = [vp, vp, u32, vp, u64]
     L.incr_scene_get_info.restype = C.c_int; L.incr_scene_get_info.argtypes = [vp, vp, C.POINTER(A.SceneInfo)]
     L.incr_shard_local_rows.restype = u32; L.incr_shard_local_rows.argtypes = [u32, C.POINTER(A.Shard)]
     L.incr_pathtrace.restype = C.c_int; L.incr_pathtrace.argtypes = [vp, C.POINTER(A.PathtraceDesc), vp]
@@ -229,6 +232,14 @@ class Scene:
         finally:
             for b in bufs:
                 ctx.free(b)
+
+    def texture_chain(self, index):
+        """(width, height, num_mips, uint32 texels of all levels) of scene texture `index` as the raster passes sample it."""
+        w, h, m, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(self.ctx.lib.incr_scene_texture_info(self.ctx.handle, self.handle, index, C.byref(w), C.byref(h), C.byref(m), C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        check(self.ctx.lib.incr_scene_texture_download(self.ctx.handle, self.handle, index, out.ctypes.data, out.nbytes))
+        return w.value, h.value, m.value, out
 
     def update_bvh(self, mesh_transforms=None, mesh_visibility=None, root_transform=None, stream=None):
         """incr_update_bvh (UpdateTLASPass): new per-mesh transforms (list of 4x4), visibility flags and / or root transform."""

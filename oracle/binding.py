@@ -149,6 +149,12 @@ class OracleScene:
     def num_triangles(self):
         return lib().orc_scene_num_triangles(self.handle)
 
+    def texture_chain(self, index, capacity):
+        """(num_mips, uint32 texels of all levels) of the oracle's mip chain of texture `index` (capacity = texel count)."""
+        L = lib(); L.orc_texture_chain.restype = C.c_uint32; L.orc_texture_chain.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+        out = np.zeros(capacity, dtype=np.uint32)
+        return L.orc_texture_chain(self.handle, index, out.ctypes.data, capacity), out
+
     def camera_rays(self, desc, px, py):
         px = np.ascontiguousarray(px, dtype=np.uint32); py = np.ascontiguousarray(py, dtype=np.uint32)
         o = np.zeros((px.size, 3), dtype=np.float32); d = np.zeros((px.size, 3), dtype=np.float32)

@@ -220,6 +220,9 @@ struct Scene {
     std::vector<Mat4> instLocalToWorld;    // per instance (visible mesh)
     std::vector<uint32_t> instMesh;
     std::vector<uint32_t> leafIdx;
+    // mip chains of the textures (levels packed, level 0 first), built at scene creation: see build_texture_mips()
+    std::vector<std::vector<uint32_t>> texChain;
+    std::vector<uint32_t> texMips;
 };
 
 static inline bool acc_valid(const Scene& s, int accessorIndex) { return accessorIndex >= 0 && (uint32_t)accessorIndex < s.d.num_accessors; }
@@ -263,19 +266,23 @@ static float2 GetFloat2(const Scene& s, int index, int accessorIndex) {         
 // shaders/material/common.hlsli:4-8).  Pinned: texel centre at +0.5, float weights,
 // out = (t00*(1-fx) + t10*fx)*(1-fy) + (t01*(1-fx) + t11*fx)*fy.
 // ------------------------------------------------------------------------------------------------
-static float4 decode_texel(const Scene& s, const incr_texture_desc& t, int x, int y) {
-    const uint8_t* p = t.texels + ((size_t)y * t.width + x) * 4;
+static float4 decode_texel_word(const Scene& s, uint32_t format, uint32_t c) {
+    const uint32_t p[4] = {c & 0xffu, (c >> 8) & 0xffu, (c >> 16) & 0xffu, c >> 24};
     const float inv255 = 1.f / 255.f;
-    switch (t.format) {
+    switch (format) {
     case INCR_TEX_RGBA8_SRGB:       return {s.srgb_lut[p[0]], s.srgb_lut[p[1]], s.srgb_lut[p[2]], (float)p[3] * inv255};
     case INCR_TEX_RG_SNORM:         return {2.f * ((float)p[0] * inv255) - 1.f, 2.f * ((float)p[1] * inv255) - 1.f, 0.f, 1.f};
     case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)p[2] * inv255, (float)p[1] * inv255, 0.f, 1.f};
     default:                        return {(float)p[0] * inv255, (float)p[1] * inv255, (float)p[2] * inv255, (float)p[3] * inv255};
     }
 }
-static float4 SampleLevel0(const Scene& s, int texIndex, float2 uv) {
+// bilinear tap on level `level` of the texture's chain (level l is max(W >> l, 1) x max(H >> l, 1))
+static float4 SampleBilinearLevel(const Scene& s, int texIndex, uint32_t level, float2 uv) {
     const incr_texture_desc& t = s.d.textures[texIndex];
-    const int W = (int)t.width, H = (int)t.height;
+    int W = (int)t.width, H = (int)t.height;
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; ++l) { off += (size_t)W * H; W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
+    const uint32_t* px = s.texChain[(size_t)texIndex].data() + off;
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;      // NaN / inf coordinates sample texel (0,0)
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
@@ -284,8 +291,8 @@ static float4 SampleLevel0(const Scene& s, int texIndex, float2 uv) {
     float fx = x - x0f, fy = y - y0f;
     int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
     int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
-    float4 t00 = decode_texel(s, t, x0, y0), t10 = decode_texel(s, t, x1, y0);
-    float4 t01 = decode_texel(s, t, x0, y1), t11 = decode_texel(s, t, x1, y1);
+    float4 t00 = decode_texel_word(s, t.format, px[(size_t)y0 * W + x0]), t10 = decode_texel_word(s, t.format, px[(size_t)y0 * W + x1]);
+    float4 t01 = decode_texel_word(s, t.format, px[(size_t)y1 * W + x0]), t11 = decode_texel_word(s, t.format, px[(size_t)y1 * W + x1]);
     float wx0 = 1.f - fx, wy0 = 1.f - fy;
     float4 r;
     r.x = (t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy;
@@ -294,27 +301,60 @@ static float4 SampleLevel0(const Scene& s, int texIndex, float2 uv) {
     r.w = (t00.w * wx0 + t10.w * fx) * wy0 + (t01.w * wx0 + t11.w * fx) * fy;
     return r;
 }
+static float4 SampleLevel0(const Scene& s, int texIndex, float2 uv) { return SampleBilinearLevel(s, texIndex, 0u, uv); }
+
+// ---- Sample(s, uv) of the raster passes (material/common.hlsli:6-8: TEX_SAMPLE = Sample outside PATH_TRACING) ----
+// Pinned: isotropic LOD = log2 of the longer screen-space UV derivative in texels (D3D11.3 functional spec
+// 7.18.11) with the logarithm evaluated as exponent + a degree-4 polynomial of the mantissa, clamped to the chain, fraction
+// truncated to 8 bits, trilinear lerp of two bilinear taps.  The reference's anisotropic sampler is not reproduced.
+static float pinned_log2(float x) {
+    uint32_t b; memcpy(&b, &x, 4);
+    const float e = (float)((int)(b >> 23) - 127);
+    const uint32_t mb = (b & 0x7fffffu) | 0x3f800000u; float m; memcpy(&m, &mb, 4);
+    const float t = m - 1.f;
+    const float p = 1.4425331354141235f + t * (-0.7161056399345398f + t * (0.4395408034324646f + t * (-0.2250901162624359f + t * 0.05923847481608391f)));
+    return e + t * p;
+}
+static float texture_lod(const incr_texture_desc& t, float2 ddx, float2 ddy) {
+    const float W = (float)t.width, H = (float)t.height;
+    const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
+    const float m = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    if (!(m >= 1.17549435e-38f) || !(m <= 3.0e38f)) return 0.f;
+    return 0.5f * pinned_log2(m);
+}
+static float4 SampleGrad(const Scene& s, int texIndex, float2 uv, float2 ddx, float2 ddy) {
+    const uint32_t numMips = s.texMips[(size_t)texIndex];
+    float lod = texture_lod(s.d.textures[texIndex], ddx, ddy);
+    lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
+    const float l0f = floorf(lod);
+    const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
+    const uint32_t l0 = (uint32_t)l0f;
+    const float4 a = SampleBilinearLevel(s, texIndex, l0, uv);
+    if (frac == 0.f || l0 + 1u >= numMips) return a;
+    const float4 b = SampleBilinearLevel(s, texIndex, l0 + 1u, uv);
+    return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac};
+}
 
 // shaders/material/common.hlsli:10-115 (fields the hot path reads)
 struct MatProps {
     float3 emissive, basecolor; float opacity; bool bHasNormalmap; float3 normalmap;
     float metallic, roughness, ao, aoblend;
 };
-static MatProps EvaluateMaterialProperties(const Scene& s, const incr_material& mat, float2 uv) {
+template <class Sampler> static MatProps EvaluateMaterialPropertiesT(const incr_material& mat, float2 uv, Sampler sample) {
     MatProps o;
     o.emissive = {mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
-    if (mat.emissiveTextureIndex != -1) { float4 t = SampleLevel0(s, mat.emissiveTextureIndex, uv); o.emissive *= f3(t.x, t.y, t.z); }
+    if (mat.emissiveTextureIndex != -1) { float4 t = sample(mat.emissiveTextureIndex, uv); o.emissive *= f3(t.x, t.y, t.z); }
     o.basecolor = {mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]};
     o.opacity = 1.f;   // Q12: left uninitialised by the reference when there is no base-colour texture; pinned to 1
     if (mat.baseColorTextureIndex != -1) {
-        float4 t = SampleLevel0(s, mat.baseColorTextureIndex, uv);
+        float4 t = sample(mat.baseColorTextureIndex, uv);
         o.basecolor *= f3(t.x, t.y, t.z);
         o.opacity = t.w;
     }
     o.bHasNormalmap = mat.normalTextureIndex != -1;
     o.normalmap = {0, 0, 1};
     if (o.bHasNormalmap) {
-        float4 t = SampleLevel0(s, mat.normalTextureIndex, uv);
+        float4 t = sample(mat.normalTextureIndex, uv);
         float2 nxy = {t.x, t.y};
         float nz = sqrtf(1.f - dot(nxy, nxy));
         o.normalmap = {nxy.x, nxy.y, nz};
@@ -322,13 +362,20 @@ static MatProps EvaluateMaterialProperties(const Scene& s, const incr_material& 
     o.metallic = mat.metallicFactor;
     o.roughness = mat.roughnessFactor;
     if (mat.metallicRoughnessTextureIndex != -1) {
-        float4 t = SampleLevel0(s, mat.metallicRoughnessTextureIndex, uv);
+        float4 t = sample(mat.metallicRoughnessTextureIndex, uv);
         o.metallic = t.x; o.roughness = t.y;
     }
     o.aoblend = mat.aoStrength;
     o.ao = 1.f;
-    if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(s, mat.aoTextureIndex, uv).x;
+    if (mat.aoTextureIndex != -1) o.ao = sample(mat.aoTextureIndex, uv).x;
     return o;
+}
+
+static MatProps EvaluateMaterialProperties(const Scene& s, const incr_material& mat, float2 uv) {                     // PATH_TRACING: SampleLevel 0
+    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, float2 st) { return SampleLevel0(s, tex, st); });
+}
+static MatProps EvaluateMaterialPropertiesGrad(const Scene& s, const incr_material& mat, float2 uv, float2 ddx, float2 ddy) {   // raster: Sample
+    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, float2 st) { return SampleGrad(s, tex, st, ddx, ddy); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,6 +910,70 @@ static int64_t shard_global_row(uint32_t res_y, const incr_shard& sh, uint32_t l
     return y < res_y ? (int64_t)y : -1;
 }
 
+// Mip chains (FScene::LoadTexture, src/scene.cpp:1072-1090: GenerateMipMaps(TEX_FILTER_LINEAR) down to 4x4; PrefilterNormalRoughnessTextures
+// :1157-1320 for a material's normal + metallic-roughness pair).  Pinned as in the product (csrc/texture_mips.hip): 2x2 box, odd sizes clamp
+// the second column / row, sRGB colour averaged in linear light and re-encoded to the nearest entry of the decode table, other channels
+// average bytes with round-to-nearest.
+extern "C" uint32_t orc_prefilter_normal_roughness(const uint32_t* srcN, const uint32_t* srcMR, uint32_t W, uint32_t H, uint32_t* outN, uint32_t* outMR);
+static uint32_t srgb_encode_nearest(const float* lut, float v) {
+    uint32_t lo = 0u, hi = 255u;
+    for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi + 1u) >> 1; if (lut[mid] <= v) lo = mid; else hi = mid - 1u; }
+    if (lo < 255u && (lut[lo + 1u] - v) < (v - lut[lo])) ++lo;
+    return lo;
+}
+static void build_texture_mips(Scene& s) {
+    const uint32_t nt = s.d.num_textures;
+    s.texChain.assign(nt, {}); s.texMips.assign(nt, 1u);
+    auto dim = [](uint32_t d, uint32_t l) { return std::max(d >> l, 1u); };
+    for (uint32_t i = 0; i < nt; ++i) {
+        const incr_texture_desc& t = s.d.textures[i];
+        uint32_t n = 0; for (uint32_t w = t.width, h = t.height; w >= 4 && h >= 4; w >>= 1, h >>= 1) ++n;
+        s.texMips[i] = n ? n : 1u;
+        size_t texels = 0; for (uint32_t l = 0; l < s.texMips[i]; ++l) texels += (size_t)dim(t.width, l) * dim(t.height, l);
+        s.texChain[i].assign(texels, 0u);
+        memcpy(s.texChain[i].data(), t.texels, (size_t)t.width * t.height * 4);
+    }
+    std::vector<uint8_t> have(nt, 0);
+    for (uint32_t mi = 0; mi < s.d.num_materials; ++mi) {
+        const int32_t a = s.d.materials[mi].normalTextureIndex, b = s.d.materials[mi].metallicRoughnessTextureIndex;
+        if (a < 0 || b < 0 || a == b || (uint32_t)a >= nt || (uint32_t)b >= nt || have[(size_t)a] || have[(size_t)b]) continue;
+        const incr_texture_desc& N = s.d.textures[a]; const incr_texture_desc& M = s.d.textures[b];
+        const uint32_t mips = s.texMips[(size_t)a];
+        if (N.width != M.width || N.height != M.height || mips < 2 || N.format != INCR_TEX_RG_SNORM || M.format != INCR_TEX_BGRA8_SWIZZLE_RG) continue;
+        if ((N.width >> (mips - 1)) << (mips - 1) != N.width || (N.height >> (mips - 1)) << (mips - 1) != N.height) continue;
+        std::vector<uint32_t> outN(s.texChain[(size_t)a].size()), outM(outN.size());
+        orc_prefilter_normal_roughness(s.texChain[(size_t)a].data(), s.texChain[(size_t)b].data(), N.width, N.height, outN.data(), outM.data());
+        for (size_t k = (size_t)N.width * N.height; k < outN.size(); ++k) {
+            s.texChain[(size_t)a][k] = outN[k];
+            s.texChain[(size_t)b][k] = (outM[k] & 0x0000ff00u) | ((outM[k] & 0xffu) << 16);      // back to the glTF channel order the sampler swizzles
+        }
+        have[(size_t)a] = have[(size_t)b] = 1;
+    }
+    for (uint32_t i = 0; i < nt; ++i) {
+        if (have[i]) continue;
+        const incr_texture_desc& t = s.d.textures[i];
+        uint32_t* level = s.texChain[i].data();
+        for (uint32_t l = 0; l + 1 < s.texMips[i]; ++l) {
+            const uint32_t sw = dim(t.width, l), sh = dim(t.height, l), dw = dim(t.width, l + 1), dh = dim(t.height, l + 1);
+            uint32_t* next = level + (size_t)sw * sh;
+            for (uint32_t y = 0; y < dh; ++y) for (uint32_t x = 0; x < dw; ++x) {
+                const uint32_t x0 = std::min(2u * x, sw - 1u), x1 = std::min(2u * x + 1u, sw - 1u), y0 = std::min(2u * y, sh - 1u), y1 = std::min(2u * y + 1u, sh - 1u);
+                const uint32_t c[4] = {level[(size_t)y0 * sw + x0], level[(size_t)y0 * sw + x1], level[(size_t)y1 * sw + x0], level[(size_t)y1 * sw + x1]};
+                uint32_t out = 0u;
+                for (int ch = 0; ch < 4; ++ch) {
+                    const uint32_t bb[4] = {(c[0] >> (8 * ch)) & 0xffu, (c[1] >> (8 * ch)) & 0xffu, (c[2] >> (8 * ch)) & 0xffu, (c[3] >> (8 * ch)) & 0xffu};
+                    uint32_t r;
+                    if (t.format == INCR_TEX_RGBA8_SRGB && ch < 3) r = srgb_encode_nearest(s.srgb_lut, ((s.srgb_lut[bb[0]] + s.srgb_lut[bb[1]]) + (s.srgb_lut[bb[2]] + s.srgb_lut[bb[3]])) * 0.25f);
+                    else r = (uint32_t)((float)(bb[0] + bb[1] + bb[2] + bb[3]) * 0.25f + 0.5f);
+                    out |= r << (8 * ch);
+                }
+                next[(size_t)y * dw + x] = out;
+            }
+            level = next;
+        }
+    }
+}
+
 extern "C" {
 
 // --- KAT-level exports (golden vectors, unit tests) -------------------------------------------------
@@ -907,12 +1018,23 @@ void* orc_scene_create(const incr_scene_desc* desc) {
         double c = i / 255.0;
         s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
     }
+    build_texture_mips(*s);
     flatten_scene(*s);
     return s;
 }
 void orc_scene_destroy(void* scene) { delete (Scene*)scene; }
 uint64_t orc_scene_num_triangles(void* scene) { return ((Scene*)scene)->tris.size(); }
 
+uint32_t orc_texture_chain(void* scene, uint32_t texIndex, uint32_t* outTexels, uint64_t capacity) {      // returns the level count; copies min(chain, capacity) texels
+    const Scene& s = *(Scene*)scene;
+    if (texIndex >= s.texChain.size()) return 0;
+    const std::vector<uint32_t>& c = s.texChain[texIndex];
+    if (outTexels) memcpy(outTexels, c.data(), std::min<uint64_t>(capacity, c.size()) * 4);
+    return s.texMips[texIndex];
+}
+void orc_sample_texture_grad(void* scene, int texIndex, const float uv[2], const float ddx[2], const float ddy[2], float out[4]) {
+    float4 r = SampleGrad(*(Scene*)scene, texIndex, {uv[0], uv[1]}, {ddx[0], ddx[1]}, {ddy[0], ddy[1]}); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
 void orc_sample_texture(void* scene, int texIndex, const float uv[2], float out[4]) {
     float4 r = SampleLevel0(*(Scene*)scene, texIndex, {uv[0], uv[1]}); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }

@@ -203,6 +203,16 @@ static inline float2 pixel_ndc(uint32_t px, uint32_t py, float W, float H) {   /
     return n;
 }
 static inline float2 interp2(float2 a, float2 b, float2 c, float3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y}; }
+// UV derivatives of Sample(): ddx_coarse / ddy_coarse of the pixel's 2x2 quad, the three UVs taken on the pixel's OWN triangle
+// (its plane extrapolated to the quad's top-left pixel and that pixel's right / lower neighbour) -- pinned, DESIGN.md section 3
+struct UvGrad { float2 ddx, ddy; };
+static inline UvGrad quad_uv_gradient(float4 p0, float4 p1, float4 p2, float2 uv0, float2 uv1, float2 uv2, uint32_t x, uint32_t y, float W, float H) {
+    const uint32_t x0 = x & ~1u, y0 = y & ~1u;
+    const float2 a = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0, W, H)));
+    const float2 b = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0 + 1u, y0, W, H)));
+    const float2 c = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0 + 1u, W, H)));
+    return {{b.x - a.x, b.y - a.y}, {c.x - a.x, c.y - a.y}};
+}
 static inline float3 interp3(float3 a, float3 b, float3 c, float3 w) {
     return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y, (w.x * a.z + w.y * b.z) + w.z * c.z};
 }
@@ -240,7 +250,8 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
             if (depth > 1.f) depth = 1.f;
             if (mat.baseColorTextureIndex != -1) {             // ps_meshlet_main: clip(opacity - 0.5)
                 const float3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc((uint32_t)px, (uint32_t)py, W, H));
-                const float opacity = SampleLevel0(s, mat.baseColorTextureIndex, interp2(uv[0], uv[1], uv[2], lam)).w;
+                const UvGrad g = quad_uv_gradient(p[0], p[1], p[2], uv[0], uv[1], uv[2], (uint32_t)px, (uint32_t)py, W, H);
+                const float opacity = SampleGrad(s, mat.baseColorTextureIndex, interp2(uv[0], uv[1], uv[2], lam), g.ddx, g.ddy).w;
                 if (opacity - 0.5f < 0.f) continue;
             }
             const uint64_t v = ((uint64_t)f2u(depth) << 32) | (uint64_t)(key + 1u);
@@ -368,7 +379,8 @@ static void gbuffer_pass(const Scene& s, const incr_view_constants& vc, const ui
         const float3 T = normalize(interp3({tan[0].x, tan[0].y, tan[0].z}, {tan[1].x, tan[1].y, tan[1].z}, {tan[2].x, tan[2].y, tan[2].z}, lam));
         const float3 B = normalize(cross(N, T) * tan[0].w);
         const float2 UV = interp2(uv[0], uv[1], uv[2], lam);
-        const MatProps mi = EvaluateMaterialProperties(s, s.d.materials[materialIndex], UV);
+        const UvGrad gr = quad_uv_gradient(p[0], p[1], p[2], uv[0], uv[1], uv[2], x, y, (float)W, (float)H);
+        const MatProps mi = EvaluateMaterialPropertiesGrad(s, s.d.materials[materialIndex], UV, gr.ddx, gr.ddy);      // Sample(g_anisoSampler, uv)
         if (mi.bHasNormalmap) {
             // tangentToWorld = mul(float3x3(T, B, N), (float3x3)localToWorld); N = normalize(mul(normalmap, tangentToWorld))
             const float* L = localToWorld.m;
@@ -462,7 +474,8 @@ static void gbuffer_decals(const Scene& s, const incr_gbuffer_decals_desc& d) {
                 const size_t i = (size_t)py * W + px;
                 if (!(depth >= d.depth_buffer[i])) return;                                     // GREATER_EQUAL, DepthWriteMask ZERO
                 const float3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(px, py, Wf, Hf));
-                const MatProps p = EvaluateMaterialProperties(s, mat, interp2(uv[0], uv[1], uv[2], lam));
+                const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], px, py, Wf, Hf);
+                const MatProps p = EvaluateMaterialPropertiesGrad(s, mat, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy);
                 const float3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
                 float3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
                 if (p.bHasNormalmap) {
@@ -829,7 +842,8 @@ static void forward_lighting(const Scene& s, const incr_forward_lighting_desc& d
         const float3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(x, y, (float)W, (float)H));
         const float2 UV = interp2(uv[0], uv[1], uv[2], lam);
         const incr_material& mat = s.d.materials[pr.materialIndex];
-        MatProps p = EvaluateMaterialProperties(s, mat, UV);
+        const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], x, y, (float)W, (float)H);
+        MatProps p = EvaluateMaterialPropertiesGrad(s, mat, UV, gr.ddx, gr.ddy);
         float3 out = {0.f, 0.f, 0.f};
         bool done = true;
         if (d.viewmode == 2) out = f3(p.roughness);                                            // ps_main :95-105 (VIEWMODE 1 is a typo there: no effect)
@@ -865,7 +879,7 @@ static void forward_lighting(const Scene& s, const incr_forward_lighting_desc& d
                     }
                 }
                 float transmission = mat.transmissionFactor;                                   // material/common.hlsli:83-88
-                if (mat.transmissionTextureIndex != -1) transmission *= SampleLevel0(s, mat.transmissionTextureIndex, UV).x;
+                if (mat.transmissionTextureIndex != -1) transmission *= SampleGrad(s, mat.transmissionTextureIndex, UV, gr.ddx, gr.ddy).x;
                 if (d.diffuse_ibl && d.sh9_rgba) {                                             // :149-165
                     const float3 albedo = ((1.f - p.metallic) * (1.f - transmission)) * p.basecolor;
                     const float3 shDiffuse = (albedo * Fd_Lambert()) * ShIrradiance(N, sh);

@@ -67,7 +67,7 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
     return count;
 }
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
-static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u;
+static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
 // Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
 // items: 44.9 / 44.5 / 45.5 / 46.3 / 51.4 / 55.0 / 58.6 -- with 8192 persistent waves a 512-item chunk is a quarter of a
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                                 cnt.lightShadow++;
                             }
                         }
+                        if (hi - lo > kSkySlot) flags |= kFlagManyLights;
                         for (uint32_t k = n; k < hi - lo; ++k) {      // > 127 candidates in one cell: traced inside accumulate, counted here
                             incr_light light; const float* m; bool haveT;
                             load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
@@ -452,6 +453,8 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     __shared__ uint32_t s_waveTotal[kWfBlock / 64];
     __shared__ uint32_t s_pid[kWfBlock];
     __shared__ uint4 s_mask[kWfBlock];
+    __shared__ float4 s_pos[kWfBlock], s_sky[kWfBlock], s_nrm[kWfBlock], s_col[kWfBlock], s_att[kWfBlock];
+    __shared__ float2 s_vyz[kWfBlock];
     __shared__ uint32_t s_base;
     const uint32_t count = B.counters[bounce];
     if (blockIdx.x * kWfBlock >= count) return;
@@ -459,14 +462,30 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t i = blockIdx.x * kWfBlock + tid;
     uint32_t pid = 0; uint4 req = make_uint4(0u, 0u, 0u, 0u);
-    if (i < count) { pid = live[i]; req = *(const uint4*)(vertex_of(B, pid) + 5); }
+    // what a ray needs of its vertex goes to LDS once per vertex (position + first light-list entry of its cell, sky direction, the
+    // BRDF inputs): the rays of a vertex are spread over many lanes, and each used to walk vertex -> cell -> list offset itself
+    float4 vpos = make_float4(0.f, 0.f, 0.f, 0.f), vsky = vpos, vnrm = vpos, vcol = vpos, vatt = vpos; float2 vyz = make_float2(0.f, 0.f);
+    if (i < count) {
+        pid = live[i];
+        const float4* vtx = vertex_of(B, pid);
+        req = *(const uint4*)(vtx + 5);
+        if (req.x | req.y | req.z | req.w) {
+            const float4 v0 = vtx[0], v2 = vtx[2], v3 = vtx[3];
+            const uint4 h = B.hit[pid];
+            vsky = vtx[4]; vnrm = vtx[1];
+            vpos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(P.gridCellOffsets[__float_as_uint(v3.w)]));
+            vcol = make_float4(v2.x, v2.y, v2.z, v0.w);                        // basecolor, metallic
+            vatt = make_float4(v3.x, v3.y, v3.z, vsky.w);                      // attenuation at the vertex, incoming ray direction .x
+            vyz = make_float2(__uint_as_float(h.y), __uint_as_float(h.z));     // incoming ray direction .yz (stashed by shade)
+        }
+    }
     const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
     // exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
     uint32_t incl = n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
     if (lane == 63u) s_waveTotal[wave] = incl;
-    s_pid[tid] = pid; s_mask[tid] = req;
+    s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
     __syncthreads();
     uint32_t waveBase = 0, total = 0;
 #pragma unroll
@@ -486,6 +505,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
         }
         return;
     }
+    if (n) B.rayBase[pid] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
     for (uint32_t r = tid; r < total; r += kWfBlock) {
         // owner vertex: the last v with s_prefix[v] <= r
         uint32_t lo = 0u, hi = kWfBlock;
@@ -498,25 +518,32 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
         const uint32_t c0 = (uint32_t)__popc(m.x), c1 = (uint32_t)__popc(m.y), c2 = (uint32_t)__popc(m.z);
         if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
         const uint32_t slot = wbase + nth_set_bit(word, j);
-        const float4* vtx = vertex_of(B, vp);
-        const float4 v0 = vtx[0];
+        const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
-        f3 L;
-        if (slot == kSkySlot) { const float4 v4 = vtx[4]; L = {v4.x, v4.y, v4.z}; }
+        f3 L, contribution = {0.f, 0.f, 0.f};
+        if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; L = {v4.x, v4.y, v4.z}; }      // the sky term itself is evaluated by accumulate
         else {
-            const uint32_t cell = __float_as_uint(vtx[3].w);
-            const uint32_t li = P.gridCellLights[P.gridCellOffsets[cell] + slot];
+            // chsMain's light loop body for this (vertex, light): GetDirectRadiance with lightVisibility = 1 (lighting/common.hlsli:8-143),
+            // times the path attenuation -- evaluated HERE, one lane per ray, instead of once more per cell light in accumulate
+            const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
             incr_light light; const float* lm; bool haveT;
             load_light(P, (int)li, light, lm, haveT);
-            L = light_setup(light, lm, haveT, origin, {0.f, 0.f, 0.f}).L;      // the same L shade computed (N does not enter L)
+            const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
+            const f3 N = {n4.x, n4.y, n4.z};
+            const LightSample ls = light_setup(light, lm, haveT, origin, N);
+            L = ls.L;
+            const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
+            const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
+            contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
         }
         B.rayQ[(size_t)(base + r) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
         B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
+        B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
     }
 }
 
-// Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray clears
-// its request bit (one fire-and-forget atomic; unoccluded rays -- the majority of the light rays -- write nothing).
+// Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray zeroes the
+// visibility word of its own record (a plain 4-byte store; unoccluded rays -- the majority of the light rays -- write nothing).
 // The loop is software-pipelined around the wave's one blocking wait per iteration (the traversal fetch): a refill only
 // ISSUES its two queue loads, the step of the lanes still tracing runs, and the new rays start after it -- their HBM
 // latency hides behind the step's fetch instead of stalling 40 busy lanes; results of finished lanes are written by the
@@ -530,22 +557,22 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
-    uint32_t pid = 0, slot = 0;
+    uint32_t rayIndex = 0, nextIndex = 0;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
     TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     for (;;) {
         const unsigned long long act = __ballot(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
         if (!chunk.exhausted && (idle >= kShadowRefill || act == 0ull)) {
-            if (occludedDone) { atomicAnd((uint32_t*)(vertex_of(B, pid) + 5) + (slot >> 5), ~(1u << (slot & 31u))); occludedDone = false; }
+            if (occludedDone) { ((float*)(B.rayC + rayIndex))[3] = 0.f; occludedDone = false; }
             const uint32_t item = chunk.take(!active, cursor, total);
-            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; pending = true; }
+            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; nextIndex = item; pending = true; }
         }
         if (active && trav_any_step(P, st, T)) { occludedDone = T.occluded; active = false; }
         if (pending) {
             pending = false;
-            pid = __float_as_uint(qa.w); slot = __float_as_uint(qb.w);
-            if (pid != 0xffffffffu) {
+            rayIndex = nextIndex;
+            if (__float_as_uint(qa.w) != 0xffffffffu) {
                 trav_any_begin(T, {qa.x, qa.y, qa.z}, {qb.x, qb.y, qb.z}, 0.1f, 1000.f);     // lighting/common.hlsli:96-100
                 st.reset();
                 active = true;
@@ -553,7 +580,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf
         }
         if (__ballot(active) == 0ull && chunk.exhausted) break;
     }
-    if (occludedDone) atomicAnd((uint32_t*)(vertex_of(B, pid) + 5) + (slot >> 5), ~(1u << (slot & 31u)));
+    if (occludedDone) ((float*)(B.rayC + rayIndex))[3] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -578,34 +605,50 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
         MatProps matInfo = {};
         matInfo.basecolor = basecolor; matInfo.metallic = v0.w; matInfo.roughness = v1.w;
         const uint32_t cell = __float_as_uint(v3.w);
-        if (P.directLighting && P.lightCount > 0) {
+        // the vertex's queued rays: [rayBase, rayBase + popc(request mask)) in ascending slot order, the sky ray (slot 127) last;
+        // each record carries attenuation * GetDirectRadiance of its light (wf_shadow_gen_kernel) and the visibility the shadow kernel left
+        const uint32_t requested = (uint32_t)(__popc(vis.x) + __popc(vis.y) + __popc(vis.z) + __popc(vis.w));
+        const bool skyRequested = vis.w >> 31;
+        const uint32_t rayBase = requested ? B.rayBase[pid] : 0u;
+        bool skyVisible = skyRequested;
+        if (!(flags & (kFlagInlineShadow | kFlagManyLights))) {
+            // chsMain's light loop (pathtracing.hlsl:230-236) in its order: lights that asked for no ray add exactly attenuation * 0,
+            // occluded ones too; the others add the value computed for their ray
+            const uint32_t lights = requested - (skyRequested ? 1u : 0u);
+            for (uint32_t r = 0; r < lights; ++r) {
+                const float4 c = B.rayC[rayBase + r];
+                if (c.w != 0.f) { color.x += c.x; color.y += c.y; color.z += c.z; }
+            }
+            if (skyRequested) skyVisible = B.rayC[rayBase + lights].w != 0.f;
+        } else if (P.directLighting && P.lightCount > 0) {
+            // slow path: the ray queue was full for this vertex (every request is traced here), or its cell lists more than 127 lights
+            // (the first 127 went through the queue, the rest is traced here)
             const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
             const uint32_t n = hi - lo;
+            uint32_t rank = 0;
             for (uint32_t k = 0; k < n; ++k) {
                 incr_light light; const float* m; bool haveT;
                 load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
                 const LightSample s = light_setup(light, m, haveT, hitPosition, N);
                 f3 radianceOut = {0.f, 0.f, 0.f};
-                bool visible;
+                bool visible = false;
                 if (k < kSkySlot && !inlineShadow) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
                     const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
-                    visible = (w >> (k & 31u)) & 1u;
-                }
-                else {   // more than 127 candidate lights in one cell, or the ray queue was full: traced here (slow path, private-memory stack)
-                    visible = false;
-                    if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
-                }
+                    if ((w >> (k & 31u)) & 1u) { visible = B.rayC[rayBase + rank].w != 0.f; ++rank; }
+                } else if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
                 if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
                 const f3 r = attenV * radianceOut;
                 color.x += r.x; color.y += r.y; color.z += r.z;
+            }
+            if (skyRequested) {
+                if (inlineShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; skyVisible = !trace_any(P, ps, hitPosition, skyDir, 0.1f, 1000.f); }
+                else skyVisible = B.rayC[rayBase + requested - 1u].w != 0.f;
             }
         }
         {   // sky sample (pathtracing.hlsl:239-244 + lighting/common.hlsli:145-202)
             const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
-            bool skyVisible = vis.w >> 31;
-            if (skyVisible && inlineShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; skyVisible = !trace_any(P, ps, hitPosition, skyDir, 0.1f, 1000.f); }
             if (skyVisible) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;

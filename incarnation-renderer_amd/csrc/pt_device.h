@@ -367,8 +367,78 @@ template <class Sampler> DI MatProps EvaluateMaterialPropertiesT(const incr_mate
     return o;
 }
 
-DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {      // PATH_TRACING: SampleLevel 0
-    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleLevel0(textures, lut, tex, st); });
+// PATH_TRACING: SampleLevel(s, uv, 0).  Same arithmetic as EvaluateMaterialPropertiesT with the level-0 sampler, but the memory
+// operations of the three textures nearly every material binds (base colour, normal, metallic-roughness) are issued in three
+// rounds -- all descriptors, then all twelve texels, then the decode -- instead of texture by texture: the shade kernel runs at
+// 3 waves per SIMD and spent two thirds of its cycles waiting, with six DEPENDENT round trips per hit (descriptor -> texels,
+// three times); now there are two.  Emissive and AO textures (rare) keep the plain path.
+struct Level0Tap { const uint32_t* __restrict__ px; uint32_t format; int W, i00, i10, i01, i11; float fx, fy; };
+DI Level0Tap level0_tap(const DeviceTexture& t, f2 uv) {
+    Level0Tap a;
+    const int W = (int)t.width, H = (int)t.height;
+    float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
+    if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
+    if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
+    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    a.fx = x - x0f; a.fy = y - y0f;
+    const int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
+    const int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+    a.px = (const uint32_t*)t.texels; a.format = t.format; a.W = W;
+    a.i00 = y0 * W + x0; a.i10 = y0 * W + x1; a.i01 = y1 * W + x0; a.i11 = y1 * W + x1;
+    return a;
+}
+DI f4 level0_finish(const Level0Tap& a, const float* __restrict__ srgbLut, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+    const f4 t00 = decode_texel(srgbLut, a.format, c00), t10 = decode_texel(srgbLut, a.format, c10);
+    const f4 t01 = decode_texel(srgbLut, a.format, c01), t11 = decode_texel(srgbLut, a.format, c11);
+    const float fx = a.fx, fy = a.fy, wx0 = 1.f - fx, wy0 = 1.f - fy;
+    f4 r;
+    r.x = (t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy;
+    r.y = (t00.y * wx0 + t10.y * fx) * wy0 + (t01.y * wx0 + t11.y * fx) * fy;
+    r.z = (t00.z * wx0 + t10.z * fx) * wy0 + (t01.z * wx0 + t11.z * fx) * fy;
+    r.w = (t00.w * wx0 + t10.w * fx) * wy0 + (t01.w * wx0 + t11.w * fx) * fy;
+    return r;
+}
+DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {
+    const int idx[3] = {mat.baseColorTextureIndex, mat.normalTextureIndex, mat.metallicRoughnessTextureIndex};
+    DeviceTexture t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t[k] = DeviceTexture{nullptr, 1u, 1u, 0u, {0u, 0u, 0u}}; if (idx[k] != -1) t[k] = textures[idx[k]]; }      // round 1: descriptors
+    Level0Tap a[3]; uint32_t c[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                                                                                                              // round 2: texels
+        a[k] = level0_tap(t[k], uv);
+        c[k][0] = c[k][1] = c[k][2] = c[k][3] = 0u;
+        if (idx[k] != -1) { c[k][0] = a[k].px[a[k].i00]; c[k][1] = a[k].px[a[k].i10]; c[k][2] = a[k].px[a[k].i01]; c[k][3] = a[k].px[a[k].i11]; }
+    }
+    MatProps o;                                                                                                                                // round 3: material/common.hlsli:10-115
+    o.emissive = {mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    if (mat.emissiveTextureIndex != -1) { f4 e = SampleLevel0(textures, lut, mat.emissiveTextureIndex, uv); o.emissive = o.emissive * mk3(e.x, e.y, e.z); }
+    o.basecolor = {mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]};
+    o.opacity = 1.f;
+    if (idx[0] != -1) {
+        const f4 b = level0_finish(a[0], lut, c[0][0], c[0][1], c[0][2], c[0][3]);
+        o.basecolor = o.basecolor * mk3(b.x, b.y, b.z);
+        o.opacity = b.w;
+    }
+    o.bHasNormalmap = idx[1] != -1;
+    o.normalmap = {0.f, 0.f, 1.f};
+    if (o.bHasNormalmap) {
+        const f4 n = level0_finish(a[1], lut, c[1][0], c[1][1], c[1][2], c[1][3]);
+        const f2 nxy = {n.x, n.y};
+        const float nz = sqrtf(1.f - dot(nxy, nxy));
+        o.normalmap = {nxy.x, nxy.y, nz};
+    }
+    o.metallic = mat.metallicFactor;
+    o.roughness = mat.roughnessFactor;
+    if (idx[2] != -1) {
+        const f4 m = level0_finish(a[2], lut, c[2][0], c[2][1], c[2][2], c[2][3]);
+        o.metallic = m.x; o.roughness = m.y;
+    }
+    o.aoblend = mat.aoStrength;
+    o.ao = 1.f;
+    if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(textures, lut, mat.aoTextureIndex, uv).x;
+    return o;
 }
 DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy) {   // raster: Sample
     return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleGrad(textures, lut, tex, st, ddx, ddy); });

@@ -60,6 +60,8 @@ struct WfBuffers {
     uint32_t* hitList;   // path ids that hit geometry in the current bounce
     uint32_t* counters;  // 64 words: list lengths, traversal cursors, shadow-ray counts (pathtrace_wf.hip kCursorBase / kRayCountBase)
     float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, request slot}
+    float4* rayC;        // per queued ray: {attenuation * radiance of its light, 1 = unoccluded / 0 = occluded}
+    uint32_t* rayBase;   // per path: index of the first queued ray of its current vertex
     uint32_t rayCap;     // rays the queue holds (soft limit: overflowing vertices are traced inside accumulate)
     uint32_t numPaths;
 };

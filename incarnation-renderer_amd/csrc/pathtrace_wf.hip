@@ -422,6 +422,8 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 }
             }
         }
+        // (Ordering the block's continuation rays by direction octant -- a wave of the next extend launch then holds one or two octants
+        // instead of eight -- was measured and dropped: extend 11.9 -> 11.8 ms per frame, the next bounce's shade 6.65 -> 6.9 ms.)
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
         if (cont) { liveOut[slot] = pid; extOut[(size_t)slot * 2] = nextO; extOut[(size_t)slot * 2 + 1] = nextD; }
     }

@@ -178,12 +178,12 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 }
 
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned).
-// 224 B of path state + raysPerPath x 48 B of shadow-ray queue per pixel: 5.0 GB at 4K -- 1.7 % of the 288 GB.
+// 272 B of path state + raysPerPath x 48 B of shadow-ray queue per pixel: 5.4 GB at 4K -- 1.9 % of the 288 GB.
 static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t stream) {
     if (numPaths == 0) numPaths = 1;
     const uint64_t n = (numPaths + 255) & ~255ull;
     const uint64_t rayCap = std::min<uint64_t>(n * ctx->raysPerPath, 0xfffffff0ull);
-    const uint64_t need = n * (32 * 2 + 16 * 3 + 96 + 4 * 4) + 4096 + (rayCap + 1) * 48;
+    const uint64_t need = n * (32 * 4 + 16 + 128) + 4096 + (rayCap + 1) * 48;
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
@@ -193,10 +193,8 @@ static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t
     uint8_t* p = (uint8_t*)ctx->wfBlock;
     WfBuffers& w = ctx->wf;
     w.counters = (uint32_t*)p; p += 4096;
-    w.extA = (float4*)p; p += n * 32; w.extB = (float4*)p; p += n * 32; w.color = (float4*)p; p += n * 16; w.atten = (float4*)p; p += n * 16;
-    w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 96;
-    w.liveA = (uint32_t*)p; p += n * 4; w.liveB = (uint32_t*)p; p += n * 4; w.hitList = (uint32_t*)p; p += n * 4;
-    w.rayBase = (uint32_t*)p; p += n * 4;
+    w.extA = (float4*)p; p += n * 32; w.extB = (float4*)p; p += n * 32; w.stA = (float4*)p; p += n * 32; w.stB = (float4*)p; p += n * 32;
+    w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 128;
     w.rayQ = (float4*)p; p += (rayCap + 1) * 32; w.rayC = (float4*)p; w.rayCap = (uint32_t)rayCap;
     w.numPaths = (uint32_t)numPaths;
     return INCR_OK;

@@ -93,12 +93,17 @@ static constexpr uint32_t kMissTri = 0xffffffffu;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
 static constexpr int kCursorBase = 16, kRayCountBase = 32;
 
-// vertex record: 6 float4 per path
+// Path state is indexed by LIST SLOT, not by pixel: the rays of a bounce are a flat list (generate / shade append to it), and
+// everything a kernel of that bounce touches -- the ray, the colour / attenuation travelling with it, the hit, the vertex record --
+// lives at the ray's slot.  Every kernel of a bounce walks the list in order, so all of these are coalesced streams; in round 1
+// they were arrays indexed by pixel id, which the list order follows only in bounce 0 (shade ran 1.8x slower per hit on bounces
+// 1-3).  Only the final pixel store is a scatter.
+// vertex record: 8 float4 per list slot
 //   [0] hitPos.xyz, metallic   [1] N.xyz, roughness   [2] basecolor.xyz, flags   [3] attenuation at the vertex .xyz, cell
-//   [4] skyDir.xyz, incoming ray dir .x     [5] request mask (4 x u32): shade sets the bits of the shadow rays it needs,
-//                                               shadow clears the occluded ones, accumulate shades the lights whose bit survived
-//   (incoming ray dir .y/.z live in hit[pid].y/.z after shade)
-DI float4* vertex_of(const WfBuffers& B, uint32_t pid) { return B.vertex + (size_t)pid * 6; }
+//   [4] skyDir.xyz, path id    [5] request mask (4 x u32): the shadow rays shade asks for
+//   [6] payload.color .xyz so far, slot of the continuation ray in the next bounce's list (0xffffffff: the path ends here)
+//   [7] incoming ray direction .xyz, index of the vertex's first queued shadow ray (written by shadow_gen)
+DI float4* vertex_of(const WfBuffers& B, uint32_t slot) { return B.vertex + (size_t)slot * 8; }
 
 DI void add_counters(const PtParams& P, const Counters& cnt) {
     if (!P.stats) return;
@@ -206,12 +211,13 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
                 const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
                 rayO = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pid));
                 rayD = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
-                B.color[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
-                B.atten[pid] = make_float4(1.f, 1.f, 1.f, 0.f);
             }
         }
         const uint32_t slot = block_append(valid, B.counters + 0, s_waveCount, &s_base);
-        if (valid) { B.liveA[slot] = pid; B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD; }
+        if (valid) {
+            B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD;
+            B.stA[(size_t)slot * 2] = make_float4(0.f, 0.f, 0.f, 0.f); B.stA[(size_t)slot * 2 + 1] = make_float4(1.f, 1.f, 1.f, 0.f);      // payload.color, payload.attenuation
+        }
     }
 }
 
@@ -228,7 +234,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
     WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
-    bool active = false; uint32_t pid = 0;
+    bool active = false; uint32_t slot = 0;
     TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     uint32_t rays = 0;
     // (The software-pipelined form of wf_shadow_kernel -- loads issued by the refill, rays started after the step, hits stored
@@ -241,7 +247,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
             const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) {
                 const float4 o = ext[(size_t)item * 2], d = ext[(size_t)item * 2 + 1];
-                pid = __float_as_uint(o.w);
+                slot = item;
                 trav_closest_begin(T, {o.x, o.y, o.z}, {d.x, d.y, d.z}, 0.001f, 10000.0f);     // TMin / TMax of TraceRay (common.hlsli:49-50,119-120)
                 st.reset();
                 active = true; rays++;
@@ -249,7 +255,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
         }
         if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
         if (active && trav_closest_step(P, st, T)) {
-            B.hit[pid] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
+            B.hit[slot] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
                                  : make_uint4(kMissTri, 0u, 0u, 0u);
             active = false;
         }
@@ -266,24 +272,26 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
     const uint32_t count = B.counters[bounce];
     const float4* __restrict__ extIn = (bounce & 1) ? B.extB : B.extA;
     float4* extOut = (bounce & 1) ? B.extA : B.extB;
-    uint32_t* liveOut = (bounce & 1) ? B.liveA : B.liveB;
+    const float4* __restrict__ stIn = (bounce & 1) ? B.stB : B.stA;
+    float4* stOut = (bounce & 1) ? B.stA : B.stB;
     uint32_t* liveCounter = B.counters + bounce + 1;
     for (uint32_t base = blockIdx.x * kWfBlock; base < count; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
-        bool cont = false;
+        bool cont = false, haveVertex = false;
         uint32_t pid = 0;
-        float4 nextO = make_float4(0.f, 0.f, 0.f, 0.f), nextD = nextO;
+        float4 nextO = make_float4(0.f, 0.f, 0.f, 0.f), nextD = nextO, nextA = nextO;
+        f4 color = {0.f, 0.f, 0.f, 0.f};
         if (i < count) {
             const float4 ro = extIn[(size_t)i * 2], rd = extIn[(size_t)i * 2 + 1];
             pid = __float_as_uint(ro.w);
             const uint32_t px = pid % P.W, ly = pid / P.W;
             const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px;
-            const uint4 h = B.hit[pid];
-            const float4 c4 = B.color[pid], a4 = B.atten[pid];
+            const uint4 h = B.hit[i];
+            const float4 c4 = stIn[(size_t)i * 2], a4 = stIn[(size_t)i * 2 + 1];
             const f3 rayD = {rd.x, rd.y, rd.z};
-            f4 color = {c4.x, c4.y, c4.z, c4.w};
+            color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};
-            float4* vtx = vertex_of(B, pid);
+            float4* vtx = vertex_of(B, i);
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
@@ -404,28 +412,29 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                         if (attenuation.x != 0.f || attenuation.y != 0.f || attenuation.z != 0.f) {     // Q2
                             nextO = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(pid));
                             nextD = make_float4(L.x, L.y, L.z, 0.f);
-                            B.atten[pid] = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.f);
+                            nextA = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.f);
                             cont = true;
                         }
                     }
                     if (!cont) flags |= kFlagTerminate;
-                    B.color[pid] = make_float4(color.x, color.y, color.z, color.w);
+                    haveVertex = true;
                     vtx[0] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, matInfo.metallic);
                     vtx[1] = make_float4(N.x, N.y, N.z, matInfo.roughness);
                     vtx[2] = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, __uint_as_float(flags));
                     vtx[3] = make_float4(attenV.x, attenV.y, attenV.z, __uint_as_float(cell));
-                    // accumulate needs V = -rayD of the INCOMING ray: keep that direction in
-                    // the record (x) and in the no longer needed t/u slots of the hit buffer (y, z)
-                    vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, rayD.x);
+                    vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, __uint_as_float(pid));
                     *(uint4*)(vtx + 5) = make_uint4(req0, req1, req2, req3);
-                    B.hit[pid] = make_uint4(h.x, __float_as_uint(rayD.y), __float_as_uint(rayD.z), 0u);
+                    vtx[7] = make_float4(rayD.x, rayD.y, rayD.z, 0.f);              // accumulate / shadow_gen need V = -rayD of the INCOMING ray
                 }
             }
         }
         // (Ordering the block's continuation rays by direction octant -- a wave of the next extend launch then holds one or two octants
         // instead of eight -- was measured and dropped: extend 11.9 -> 11.8 ms per frame, the next bounce's shade 6.65 -> 6.9 ms.)
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
-        if (cont) { liveOut[slot] = pid; extOut[(size_t)slot * 2] = nextO; extOut[(size_t)slot * 2 + 1] = nextD; }
+        // the continuation ray and its attenuation go to the next bounce's list; its colour is written there by accumulate, once the
+        // lights of this vertex are in
+        if (cont) { extOut[(size_t)slot * 2] = nextO; extOut[(size_t)slot * 2 + 1] = nextD; stOut[(size_t)slot * 2 + 1] = nextA; }
+        if (haveVertex) vertex_of(B, i)[6] = make_float4(color.x, color.y, color.z, __uint_as_float(cont ? slot : 0xffffffffu));
     }
     add_counters(P, cnt);
 }
@@ -460,7 +469,6 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     __shared__ uint32_t s_base;
     const uint32_t count = B.counters[bounce];
     if (blockIdx.x * kWfBlock >= count) return;
-    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t i = blockIdx.x * kWfBlock + tid;
     uint32_t pid = 0; uint4 req = make_uint4(0u, 0u, 0u, 0u);
@@ -468,17 +476,16 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     // BRDF inputs): the rays of a vertex are spread over many lanes, and each used to walk vertex -> cell -> list offset itself
     float4 vpos = make_float4(0.f, 0.f, 0.f, 0.f), vsky = vpos, vnrm = vpos, vcol = vpos, vatt = vpos; float2 vyz = make_float2(0.f, 0.f);
     if (i < count) {
-        pid = live[i];
-        const float4* vtx = vertex_of(B, pid);
+        pid = i;                                                                  // "path" = list slot in this kernel
+        const float4* vtx = vertex_of(B, i);
         req = *(const uint4*)(vtx + 5);
         if (req.x | req.y | req.z | req.w) {
-            const float4 v0 = vtx[0], v2 = vtx[2], v3 = vtx[3];
-            const uint4 h = B.hit[pid];
+            const float4 v0 = vtx[0], v2 = vtx[2], v3 = vtx[3], v7 = vtx[7];
             vsky = vtx[4]; vnrm = vtx[1];
             vpos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(P.gridCellOffsets[__float_as_uint(v3.w)]));
             vcol = make_float4(v2.x, v2.y, v2.z, v0.w);                        // basecolor, metallic
-            vatt = make_float4(v3.x, v3.y, v3.z, vsky.w);                      // attenuation at the vertex, incoming ray direction .x
-            vyz = make_float2(__uint_as_float(h.y), __uint_as_float(h.z));     // incoming ray direction .yz (stashed by shade)
+            vatt = make_float4(v3.x, v3.y, v3.z, v7.x);                        // attenuation at the vertex, incoming ray direction .x
+            vyz = make_float2(v7.y, v7.z);                                     // incoming ray direction .yz
         }
     }
     const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
         }
         return;
     }
-    if (n) B.rayBase[pid] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
+    if (n) ((uint32_t*)(vertex_of(B, pid) + 7))[3] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
     for (uint32_t r = tid; r < total; r += kWfBlock) {
         // owner vertex: the last v with s_prefix[v] <= r
         uint32_t lo = 0u, hi = kWfBlock;
@@ -588,22 +595,21 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf
 // ------------------------------------------------------------------------------------------------ accumulate
 __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
     const uint32_t count = B.counters[bounce];
-    const uint32_t* __restrict__ live = (bounce & 1) ? B.liveB : B.liveA;
+    float4* stOut = (bounce & 1) ? B.stA : B.stB;
     for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
-        const uint32_t pid = live[i];
-        const float4* vtx = vertex_of(B, pid);
+        const float4* vtx = vertex_of(B, i);
         const float4 v2 = vtx[2];
         const uint32_t flags = __float_as_uint(v2.w);
         if (flags & kFlagSkip) continue;
         const bool inlineShadow = flags & kFlagInlineShadow;
         const float4 v0 = vtx[0], v1 = vtx[1], v3 = vtx[3], v4 = vtx[4];
         const uint4 vis = *(const uint4*)(vtx + 5);
-        const uint4 h = B.hit[pid];
-        const float4 c4 = B.color[pid];
-        f4 color = {c4.x, c4.y, c4.z, c4.w};
+        const float4 v6 = vtx[6], v7 = vtx[7];
+        const uint32_t pid = __float_as_uint(v4.w), nextSlot = __float_as_uint(v6.w);
+        f4 color = {v6.x, v6.y, v6.z, 0.f};                       // payload.color.w is 0 on every path that reaches a light loop
         const f3 hitPosition = {v0.x, v0.y, v0.z}, N = {v1.x, v1.y, v1.z}, basecolor = {v2.x, v2.y, v2.z}, attenV = {v3.x, v3.y, v3.z};
         const f3 skyDir = {v4.x, v4.y, v4.z};
-        const f3 V = -mk3(v4.w, __uint_as_float(h.y), __uint_as_float(h.z));
+        const f3 V = -mk3(v7.x, v7.y, v7.z);
         MatProps matInfo = {};
         matInfo.basecolor = basecolor; matInfo.metallic = v0.w; matInfo.roughness = v1.w;
         const uint32_t cell = __float_as_uint(v3.w);
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
         // each record carries attenuation * GetDirectRadiance of its light (wf_shadow_gen_kernel) and the visibility the shadow kernel left
         const uint32_t requested = (uint32_t)(__popc(vis.x) + __popc(vis.y) + __popc(vis.z) + __popc(vis.w));
         const bool skyRequested = vis.w >> 31;
-        const uint32_t rayBase = requested ? B.rayBase[pid] : 0u;
+        const uint32_t rayBase = __float_as_uint(v7.w);
         bool skyVisible = skyRequested;
         if (!(flags & (kFlagInlineShadow | kFlagManyLights))) {
             // chsMain's light loop (pathtracing.hlsl:230-236) in its order: lights that asked for no ray add exactly attenuation * 0,
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             color.x += r.x; color.y += r.y; color.z += r.z;
         }
         if (flags & kFlagTerminate) store_pixel(P, pid % P.W, pid / P.W, color);
-        else B.color[pid] = make_float4(color.x, color.y, color.z, color.w);
+        else stOut[(size_t)nextSlot * 2] = make_float4(color.x, color.y, color.z, color.w);
     }
 }
 

@@ -51,20 +51,17 @@ struct PtParams {
 struct WfBuffers {
     float4* extA;        // rays of the even bounces, list order, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, 0}
     float4* extB;        // rays of the odd bounces
-    float4* color;       // payload.color
-    float4* atten;       // payload.attenuation.xyz
-    uint4*  hit;         // {leaf-order triangle, t, u, v}
-    float4* vertex;      // 6 x float4 per path: see pathtrace_wf.hip
-    uint32_t* liveA;     // path ids entering the current bounce
-    uint32_t* liveB;     // path ids entering the next bounce
-    uint32_t* hitList;   // path ids that hit geometry in the current bounce
+    float4* stA;         // state travelling with the rays of the even bounces, 2 x float4: {payload.color} {payload.attenuation.xyz, 0}
+    float4* stB;
+    uint4*  hit;         // per list slot of the current bounce: {leaf-order triangle, t, u, v}
+    float4* vertex;      // 8 x float4 per list slot of the current bounce: see pathtrace_wf.hip
     uint32_t* counters;  // 64 words: list lengths, traversal cursors, shadow-ray counts (pathtrace_wf.hip kCursorBase / kRayCountBase)
-    float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, request slot}
+    float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, vertex slot} {direction.xyz, request slot}
     float4* rayC;        // per queued ray: {attenuation * radiance of its light, 1 = unoccluded / 0 = occluded}
-    uint32_t* rayBase;   // per path: index of the first queued ray of its current vertex
     uint32_t rayCap;     // rays the queue holds (soft limit: overflowing vertices are traced inside accumulate)
     uint32_t numPaths;
 };
+
 
 
 } // namespace incr

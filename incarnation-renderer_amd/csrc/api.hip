@@ -22,6 +22,7 @@ extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriOb
                                              const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
                                           const float* srgbLut, hipStream_t stream);
+extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
@@ -308,6 +309,27 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
             level = next;
         }
     }
+    // The chains above are row-major (what the generators write and incr_scene_texture_download returns); the samplers read a TILED copy
+    sc->linearTextures = texs;
+    for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
+        DeviceTexture& T = texs[i];
+        size_t tiledWords = 0;
+        for (uint32_t l = 0; l < T.pad[1]; ++l) tiledWords += texel_level_words(level_dim(T.width, l), level_dim(T.height, l));
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, tiledWords * 4);
+        if (e == hipSuccess) e = hipMemset(d, 0, tiledWords * 4);
+        if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "tiled texture allocation failed: %s", hipGetErrorString(e)); break; }
+        sc->dTexels.push_back(d);
+        sc->textureBytes += tiledWords * 4;
+        const uint32_t* src = (const uint32_t*)T.texels; uint32_t* dst = (uint32_t*)d;
+        for (uint32_t l = 0; l < T.pad[1] && e == hipSuccess; ++l) {
+            const uint32_t w = level_dim(T.width, l), h = level_dim(T.height, l);
+            e = incr_launch_mip_tile(src, w, h, dst, nullptr);
+            src += (size_t)w * h; dst += texel_level_words(w, h);
+        }
+        if (e != hipSuccess) { rc = fail(INCR_ERR_HIP, "texture tiling failed: %s", hipGetErrorString(e)); break; }
+        T.texels = (const uint8_t*)d;
+    }
     if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
     sc->hostTextures = texs;
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
@@ -355,8 +377,8 @@ int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_di
 
 int incr_scene_texture_info(incr_context* ctx, const incr_scene* sc, uint32_t ti, uint32_t* width, uint32_t* height, uint32_t* num_mips, uint64_t* chain_texels) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    if (!sc || ti >= sc->hostTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");
-    const DeviceTexture& t = sc->hostTextures[ti];
+    if (!sc || ti >= sc->linearTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");
+    const DeviceTexture& t = sc->linearTextures[ti];
     uint64_t n = 0; uint32_t w = t.width, h = t.height;
     for (uint32_t l = 0; l < t.pad[1]; ++l) { n += (uint64_t)w * h; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
     if (width) *width = t.width; if (height) *height = t.height; if (num_mips) *num_mips = t.pad[1]; if (chain_texels) *chain_texels = n;
@@ -367,7 +389,7 @@ int incr_scene_texture_download(incr_context* ctx, const incr_scene* sc, uint32_
     int rc = incr_scene_texture_info(ctx, sc, ti, nullptr, nullptr, nullptr, &n);
     if (rc) return rc;
     if (!dst || bytes != n * 4) return fail(INCR_ERR_INVALID_ARGUMENT, "destination must hold the whole chain (%llu bytes)", (unsigned long long)(n * 4));
-    HIP_TRY(hipMemcpy(dst, sc->hostTextures[ti].texels, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, sc->linearTextures[ti].texels, bytes, hipMemcpyDeviceToHost));      // the row-major chain
     return INCR_OK;
 }
 

@@ -48,7 +48,8 @@ struct incr_scene {
     float* dMeshLocalToWorld = nullptr;
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
     std::vector<void*> dTexels;
-    std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers + mip counts)
+    std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers of the TILED chains + mip counts)
+    std::vector<incr::DeviceTexture> linearTextures;   // the same with the row-major chains (generation, introspection)
     uint64_t textureBytes = 0;
     incr::LightGrid grid;
     uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;

@@ -58,8 +58,17 @@ template <int N> using WfStack = LaneStackT<N, kWfBlock, false, true>;        //
 template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         // closest-hit traversal: keyed, drops groups beyond the best hit
 // Hottest nodes kept in LDS per workgroup (80 B each), sized so that stack + copy still give the kernels' workgroups per CU
 // out of 160 KB: extend 7 / 6 / 4 / 3 workgroups, shadow 8 / 8 / 8 / 6 at N = 8 / 12 / 16 / 24.
-template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? 80u : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u));
-                                   static constexpr uint32_t kShadow = N <= 8 ? 144u : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u)); };
+#ifndef INCR_EXTEND_TOP
+#define INCR_EXTEND_TOP 80
+#endif
+#ifndef INCR_SHADOW_TOP
+#define INCR_SHADOW_TOP 144
+#endif
+#ifndef INCR_SHADOW_WAVES
+#define INCR_SHADOW_WAVES 8
+#endif
+template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? (uint32_t)INCR_EXTEND_TOP : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u));
+                                   static constexpr uint32_t kShadow = N <= 8 ? (uint32_t)INCR_SHADOW_TOP : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u)); };
 DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) {
     const uint32_t count = min(capacity, P.numNodes);
     for (uint32_t i = threadIdx.x; i < count * 5u; i += kWfBlock) s_top[i] = ((const float4*)P.nodes)[i];
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
 // ISSUES its two queue loads, the step of the lanes still tracing runs, and the new rays start after it -- their HBM
 // latency hides behind the step's fetch instead of stalling 40 busy lanes; results of finished lanes are written by the
 // next refill, all of them with one instruction.
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? 8 : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAVES : (N <= 16 ? 8 : 6)) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
@@ -703,7 +712,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
 #endif
     const uint32_t blocksAll = std::max(1u, (uint32_t)std::min<uint64_t>((uint64_t)cus * INCR_WF_STREAM_BLOCKS_PER_CU, (total + kWfBlock - 1) / kWfBlock));
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv <= 16 ? 8u : 6u;
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv == 8 ? (uint32_t)INCR_SHADOW_WAVES : (sv <= 16 ? 8u : 6u);
     const uint32_t blocksExtend = std::max(1u, std::min(cus * extendPerCU, (total + kWfBlock - 1) / kWfBlock));
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
     hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, stream, b->counters, blocksExtend * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);

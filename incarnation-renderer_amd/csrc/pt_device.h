@@ -274,7 +274,7 @@ DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t 
 DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgbLut, uint32_t level, f2 uv) {
     int W = (int)t.width, H = (int)t.height;
     size_t off = 0;
-    for (uint32_t l = 0; l < level; ++l) { off += (size_t)W * H; W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
+    for (uint32_t l = 0; l < level; ++l) { off += texel_level_words((uint32_t)W, (uint32_t)H); W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
@@ -284,8 +284,8 @@ DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgb
     int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
     int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
     const uint32_t* __restrict__ px = (const uint32_t*)t.texels + off;
-    const uint32_t c00 = px[(size_t)y0 * W + x0], c10 = px[(size_t)y0 * W + x1];
-    const uint32_t c01 = px[(size_t)y1 * W + x0], c11 = px[(size_t)y1 * W + x1];
+    const uint32_t c00 = px[texel_tile_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W)], c10 = px[texel_tile_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W)];
+    const uint32_t c01 = px[texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W)], c11 = px[texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W)];
     f4 t00 = decode_texel(srgbLut, t.format, c00), t10 = decode_texel(srgbLut, t.format, c10);
     f4 t01 = decode_texel(srgbLut, t.format, c01), t11 = decode_texel(srgbLut, t.format, c11);
     float wx0 = 1.f - fx, wy0 = 1.f - fy;
@@ -385,7 +385,8 @@ DI Level0Tap level0_tap(const DeviceTexture& t, f2 uv) {
     const int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
     const int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
     a.px = (const uint32_t*)t.texels; a.format = t.format; a.W = W;
-    a.i00 = y0 * W + x0; a.i10 = y0 * W + x1; a.i01 = y1 * W + x0; a.i11 = y1 * W + x1;
+    a.i00 = (int)texel_tile_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W); a.i10 = (int)texel_tile_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W);
+    a.i01 = (int)texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W); a.i11 = (int)texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W);
     return a;
 }
 DI f4 level0_finish(const Level0Tap& a, const float* __restrict__ srgbLut, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/incr_types.h"
+#include "device_types.h"
 
 namespace incr {
 
@@ -52,8 +53,19 @@ __global__ __launch_bounds__(256) void mip_adopt_vmf_kernel(const uint32_t* __re
     dstMR[first + i] = (m & 0x0000ff00u) | ((m & 0xffu) << 16);
 }
 
+// one level of a row-major chain -> the tiled storage the samplers read (device_types.h texel_tile_index); pad texels of edge tiles stay 0
+__global__ __launch_bounds__(256) void mip_tile_kernel(const uint32_t* __restrict__ src, uint32_t w, uint32_t h, uint32_t* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    dst[texel_tile_index(x, y, w)] = src[(size_t)y * w + x];
+}
+
 } // namespace incr
 
+extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::mip_tile_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, src, w, h, dst);
+    return hipGetLastError();
+}
 extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
                                           const float* srgbLut, hipStream_t stream) {
     hipLaunchKernelGGL(incr::mip_box_kernel, dim3((dw + 31u) / 32u, (dh + 7u) / 8u), dim3(256), 0, stream, src, sw, sh, dst, dw, dh, format, srgbLut);

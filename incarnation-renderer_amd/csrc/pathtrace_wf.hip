@@ -354,32 +354,15 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     const f3 V = -rayD;
                     const f3 attenV = attenuation;
                     // ---- enumerate the shadow rays of this vertex as a request mask ----
-                    uint32_t req0 = 0u, req1 = 0u, req2 = 0u, req3 = 0u;      // four registers: a dynamically indexed req[4] would live in scratch
+                    uint32_t req3 = 0u;
                     uint32_t flags = 0u;
                     const bool finiteAtt = fabsf(attenV.x) < 3.0e38f && fabsf(attenV.y) < 3.0e38f && fabsf(attenV.z) < 3.0e38f;
                     const uint32_t numCells = P.gridDim[0] * P.gridDim[1] * P.gridDim[2];
                     uint32_t cell = light_cell(P, hitPosition);
                     if (!finiteAtt) cell = numCells;                      // the catch-all cell lists every light
-                    if (P.directLighting && P.lightCount > 0) {
-                        const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
-                        const uint32_t n = min(hi - lo, kSkySlot);
-                        for (uint32_t k = 0; k < n; ++k) {
-                            incr_light light; const float* m; bool haveT;
-                            load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
-                            const LightSample s = light_setup(light, m, haveT, hitPosition, N);
-                            if (s.needsShadow) {
-                                const uint32_t bit = 1u << (k & 31u);
-                                if (k < 32u) req0 |= bit; else if (k < 64u) req1 |= bit; else if (k < 96u) req2 |= bit; else req3 |= bit;
-                                cnt.lightShadow++;
-                            }
-                        }
-                        if (hi - lo > kSkySlot) flags |= kFlagManyLights;
-                        for (uint32_t k = n; k < hi - lo; ++k) {      // > 127 candidates in one cell: traced inside accumulate, counted here
-                            incr_light light; const float* m; bool haveT;
-                            load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
-                            if (light_setup(light, m, haveT, hitPosition, N).needsShadow) cnt.lightShadow++;
-                        }
-                    }
+                    // (which lights of the cell need a shadow ray -- chsMain's loop over the lights, pathtracing.hlsl:230-236 -- is decided by
+                    // wf_shadow_gen_kernel with one lane per (vertex, light) pair: inside this kernel the loop ran to the longest light list
+                    // of the wave at 3 waves per SIMD and cost 2.6 of its 6.7 ms per frame)
                     // sky sample :239-244
                     const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
                     const f3 skyDir = CosineSampleHemisphere(us);
@@ -432,7 +415,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     vtx[2] = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, __uint_as_float(flags));
                     vtx[3] = make_float4(attenV.x, attenV.y, attenV.z, __uint_as_float(cell));
                     vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, __uint_as_float(pid));
-                    *(uint4*)(vtx + 5) = make_uint4(req0, req1, req2, req3);
+                    *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, req3);              // the sky request; shadow_gen adds the lights'
                     vtx[7] = make_float4(rayD.x, rayD.y, rayD.z, 0.f);              // accumulate / shadow_gen need V = -rayD of the INCOMING ray
                 }
             }
@@ -480,34 +463,77 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     if (blockIdx.x * kWfBlock >= count) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t i = blockIdx.x * kWfBlock + tid;
-    uint32_t pid = 0; uint4 req = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pid = 0, cellLo = 0, cellHi = 0; bool haveVtx = false; uint4 req = make_uint4(0u, 0u, 0u, 0u);
     // what a ray needs of its vertex goes to LDS once per vertex (position + first light-list entry of its cell, sky direction, the
     // BRDF inputs): the rays of a vertex are spread over many lanes, and each used to walk vertex -> cell -> list offset itself
     float4 vpos = make_float4(0.f, 0.f, 0.f, 0.f), vsky = vpos, vnrm = vpos, vcol = vpos, vatt = vpos; float2 vyz = make_float2(0.f, 0.f);
     if (i < count) {
         pid = i;                                                                  // "path" = list slot in this kernel
         const float4* vtx = vertex_of(B, i);
-        req = *(const uint4*)(vtx + 5);
-        if (req.x | req.y | req.z | req.w) {
-            const float4 v0 = vtx[0], v2 = vtx[2], v3 = vtx[3], v7 = vtx[7];
+        const float4 v2 = vtx[2];
+        if (!(__float_as_uint(v2.w) & kFlagSkip)) {                               // a shaded hit (misses and debug views carry no vertex)
+            haveVtx = true;
+            req = *(const uint4*)(vtx + 5);
+            const float4 v0 = vtx[0], v3 = vtx[3], v7 = vtx[7];
             vsky = vtx[4]; vnrm = vtx[1];
-            vpos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(P.gridCellOffsets[__float_as_uint(v3.w)]));
+            if (P.directLighting && P.lightCount > 0) { const uint32_t cell = __float_as_uint(v3.w); cellLo = P.gridCellOffsets[cell]; cellHi = P.gridCellOffsets[cell + 1]; }
+            vpos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(cellLo));
             vcol = make_float4(v2.x, v2.y, v2.z, v0.w);                        // basecolor, metallic
             vatt = make_float4(v3.x, v3.y, v3.z, v7.x);                        // attenuation at the vertex, incoming ray direction .x
             vyz = make_float2(v7.y, v7.z);                                     // incoming ray direction .yz
         }
     }
+    // ---- phase 1: which lights of its cell does every vertex need a shadow ray to?  One lane per (vertex, candidate light) pair:
+    //      GetDirectRadiance's NoL > 0 && any(radianceIn > 0) (lighting/common.hlsli:84-95), the request bit set in LDS
+    const uint32_t cand = haveVtx ? (cellHi - cellLo) : 0u;
+    {
+        uint32_t incl = cand;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+        if (lane == 63u) s_waveTotal[wave] = incl;
+        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
+        __syncthreads();
+        uint32_t waveBase = 0, totalCand = 0;
+#pragma unroll
+        for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; totalCand += c; }
+        s_prefix[tid] = waveBase + incl - cand;
+        if (tid == 0) s_prefix[kWfBlock] = totalCand;
+        __syncthreads();
+        uint32_t lightShadow = 0;
+        for (uint32_t c = tid; c < totalCand; c += kWfBlock) {
+            uint32_t lo = 0u, hi = kWfBlock;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= c) lo = mid; else hi = mid; }
+            const uint32_t k = c - s_prefix[lo];
+            const float4 v0 = s_pos[lo], n4 = s_nrm[lo];
+            incr_light light; const float* lm; bool haveT;
+            load_light(P, (int)P.gridCellLights[__float_as_uint(v0.w) + k], light, lm, haveT);
+            if (light_setup(light, lm, haveT, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
+                ++lightShadow;
+                if (k < kSkySlot) atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
+            }
+        }
+        Counters cnt = {0, 0, 0, lightShadow, 0};
+        add_counters(P, cnt);
+        __syncthreads();
+        req = s_mask[tid];
+        if (haveVtx && cand) {      // the complete request mask goes back to the vertex record (accumulate counts the rays with it)
+            *(uint4*)(vertex_of(B, pid) + 5) = req;
+            if (cand > kSkySlot) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagManyLights)); }
+        }
+    }
     const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
-    // exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
+    // ---- phase 2: the rays.  Exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
     uint32_t incl = n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+    __syncthreads();
     if (lane == 63u) s_waveTotal[wave] = incl;
-    s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
     __syncthreads();
     uint32_t waveBase = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
+    __syncthreads();
     s_prefix[tid] = waveBase + incl - n;
     if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
     __syncthreads();

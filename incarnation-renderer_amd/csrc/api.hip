@@ -157,6 +157,27 @@ static int upload_light_grid(incr_scene* sc, hipStream_t stream) {
     return INCR_OK;
 }
 
+// load_light (pt_shade.h) evaluated once per light loop index on the host: what the shadow_gen kernel keeps in LDS
+static int upload_resolved_lights(incr_scene* sc) {
+    const HostScene& h = sc->host;
+    const size_t n = h.globalLights.size();                 // PtParams::lightCount
+    std::vector<float> rec(n * 20, 0.f);
+    for (size_t li = 0; li < n; ++li) {
+        const int lightId = li < h.lightIndices.size() ? h.lightIndices[li] : 0;
+        incr_light L; memset(&L, 0, sizeof L);
+        if (lightId >= 0 && (size_t)lightId < h.globalLights.size()) L = h.globalLights[(size_t)lightId];
+        const bool haveT = lightId >= 0 && (size_t)lightId < h.lightIndices.size() && (size_t)lightId < h.lightTransforms.size();
+        float m[16] = {0.f};
+        if (haveT) memcpy(m, h.lightTransforms[(size_t)lightId].m, 64);
+        float* r = &rec[li * 20];
+        uint32_t typeBits = (uint32_t)L.type; memcpy(&r[0], &typeBits, 4); r[1] = L.range; r[2] = L.spotAngles[0]; r[3] = L.spotAngles[1];
+        r[4] = L.color[0]; r[5] = L.color[1]; r[6] = L.color[2]; r[7] = L.intensity;
+        r[8] = m[0]; r[9] = m[1]; r[10] = m[2]; r[11] = m[4]; r[12] = m[5]; r[13] = m[6]; r[14] = m[8]; r[15] = m[9];
+        r[16] = m[10]; r[17] = m[12]; r[18] = m[13]; r[19] = m[14];
+    }
+    return upload_vec(&sc->dResolvedLights, rec.data(), rec.size());
+}
+
 static int upload_bvh(incr_scene* sc) {
     int rc;
     if ((rc = upload_vec(&sc->dNodes, sc->bvh.nodes8.data(), sc->bvh.nodes8.size()))) return rc;
@@ -207,7 +228,7 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
-                    sc->dGridOffsets, sc->dGridLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
+                    sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
     incr_raster_scene_free(sc);
@@ -243,6 +264,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
     if (!rc) rc = upload_vec(&sc->dLightIndices, sc->host.lightIndices.data(), sc->host.lightIndices.size());
     if (!rc) rc = upload_vec(&sc->dLightTransforms, (const float*)sc->host.lightTransforms.data(), sc->host.lightTransforms.size() * 16);
+    if (!rc) rc = upload_resolved_lights(sc);
     // Textures: level 0 as handed over + the mip chain the raster passes sample (texture_mips.hip), all levels in one allocation
     std::vector<DeviceTexture> texs(desc->num_textures);
     auto mip_levels = [](uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 4 && h >= 4) { ++n; w >>= 1; h >>= 1; } return n ? n : 1u; };      // scene.cpp:1072-1081
@@ -522,6 +544,7 @@ static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtP
     P.materials = sc->dMaterials; P.textures = sc->dTextures; P.srgbLut = ctx->srgbLut;
     P.meshLocalToWorld = sc->dMeshLocalToWorld;
     P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
+    P.resolvedLights = (const float4*)sc->dResolvedLights;
     P.numGlobalLights = (uint32_t)sc->host.globalLights.size(); P.numSceneLights = (uint32_t)sc->host.lightIndices.size();
     P.lightCount = (int32_t)sc->host.globalLights.size();                     // path-tracing.inl:198 m_globalLightList.size()
     P.numTris = (uint32_t)sc->bvh.tris.size(); P.numNodes = (uint32_t)sc->bvh.nodes8.size();

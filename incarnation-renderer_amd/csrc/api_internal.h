@@ -46,6 +46,7 @@ struct incr_scene {
     incr::BvhNode8* dNodes = nullptr; incr::TriIsect* dTris = nullptr; incr::TriShade* dShade = nullptr;
     incr_material* dMaterials = nullptr; incr::DeviceTexture* dTextures = nullptr;
     float* dMeshLocalToWorld = nullptr;
+    float* dResolvedLights = nullptr;
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
     std::vector<void*> dTexels;
     std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers of the TILED chains + mip counts)

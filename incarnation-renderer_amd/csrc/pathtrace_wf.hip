@@ -75,6 +75,7 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
     __syncthreads();
     return count;
 }
+static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved records shadow_gen keeps in LDS (10 KB)
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
@@ -458,10 +459,16 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     __shared__ uint4 s_mask[kWfBlock];
     __shared__ float4 s_pos[kWfBlock], s_sky[kWfBlock], s_nrm[kWfBlock], s_col[kWfBlock], s_att[kWfBlock];
     __shared__ float2 s_vyz[kWfBlock];
+    __shared__ float4 s_lights[kGenLdsLights * 5];                            // the resolved light table (pt_shade.h), when the scene's lights fit
     __shared__ uint32_t s_base;
     const uint32_t count = B.counters[bounce];
     if (blockIdx.x * kWfBlock >= count) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
+    if (ldsLights) for (uint32_t k = tid; k < (uint32_t)P.lightCount * 5u; k += kWfBlock) s_lights[k] = P.resolvedLights[k];      // visible after the first __syncthreads below
+    auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
+        if (ldsLights) load_light_resolved((const float4*)s_lights, li, light, mm); else load_light_resolved(P.resolvedLights, li, light, mm);
+    };
     const uint32_t i = blockIdx.x * kWfBlock + tid;
     uint32_t pid = 0, cellLo = 0, cellHi = 0; bool haveVtx = false; uint4 req = make_uint4(0u, 0u, 0u, 0u);
     // what a ray needs of its vertex goes to LDS once per vertex (position + first light-list entry of its cell, sky direction, the
@@ -506,9 +513,9 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
             for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= c) lo = mid; else hi = mid; }
             const uint32_t k = c - s_prefix[lo];
             const float4 v0 = s_pos[lo], n4 = s_nrm[lo];
-            incr_light light; const float* lm; bool haveT;
-            load_light(P, (int)P.gridCellLights[__float_as_uint(v0.w) + k], light, lm, haveT);
-            if (light_setup(light, lm, haveT, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
+            incr_light light; float lm[16];
+            fetch_light(P.gridCellLights[__float_as_uint(v0.w) + k], light, lm);
+            if (light_setup(light, lm, true, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
                 ++lightShadow;
                 if (k < kSkySlot) atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
             }
@@ -570,11 +577,11 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
             // chsMain's light loop body for this (vertex, light): GetDirectRadiance with lightVisibility = 1 (lighting/common.hlsli:8-143),
             // times the path attenuation -- evaluated HERE, one lane per ray, instead of once more per cell light in accumulate
             const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
-            incr_light light; const float* lm; bool haveT;
-            load_light(P, (int)li, light, lm, haveT);
+            incr_light light; float lm[16];
+            fetch_light(li, light, lm);
             const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
             const f3 N = {n4.x, n4.y, n4.z};
-            const LightSample ls = light_setup(light, lm, haveT, origin, N);
+            const LightSample ls = light_setup(light, lm, true, origin, N);
             L = ls.L;
             const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
             const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);

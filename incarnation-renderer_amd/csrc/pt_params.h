@@ -20,6 +20,7 @@ struct PtParams {
     const incr_light* __restrict__ globalLights;
     const int32_t* __restrict__ lightIndices;
     const float* __restrict__ lightTransforms;     // 16 floats per scene light
+    const float4* __restrict__ resolvedLights;     // 5 x float4 per light loop index (pt_shade.h load_light_resolved)
     uint32_t numGlobalLights, numSceneLights;
     int32_t lightCount;
     uint32_t numTris, numNodes;

@@ -101,6 +101,19 @@ DI void load_light(const PtParams& P, int lightIndex, incr_light& light, const f
     m = P.lightTransforms + (haveT ? (size_t)lightId * 16 : 0);
 }
 
+// The same fetch out of the RESOLVED light table (api.hip build_resolved_lights: load_light's result per loop index, 5 x float4):
+// [0] type, range, spotAngles  [1] color, intensity  [2] m0 m1 m2 m4  [3] m5 m6 m8 m9  [4] m10 m12 m13 m14 -- the matrix entries
+// light_setup reads; a light without a transform has them zero, as light_setup's `haveTransform ? m[i] : 0` makes them.
+template <class Table> DI void load_light_resolved(Table table, uint32_t lightIndex, incr_light& light, float mm[16]) {
+    const float4 r0 = table[lightIndex * 5u], r1 = table[lightIndex * 5u + 1u], r2 = table[lightIndex * 5u + 2u], r3 = table[lightIndex * 5u + 3u], r4 = table[lightIndex * 5u + 4u];
+    light.type = (int32_t)__float_as_uint(r0.x); light.range = r0.y; light.spotAngles[0] = r0.z; light.spotAngles[1] = r0.w;
+    light.color[0] = r1.x; light.color[1] = r1.y; light.color[2] = r1.z; light.intensity = r1.w;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mm[i] = 0.f;
+    mm[0] = r2.x; mm[1] = r2.y; mm[2] = r2.z; mm[4] = r2.w; mm[5] = r3.x; mm[6] = r3.y; mm[8] = r3.z; mm[9] = r3.w;
+    mm[10] = r4.x; mm[12] = r4.y; mm[13] = r4.z; mm[14] = r4.w;
+}
+
 DI void store_pixel(const PtParams& P, uint32_t x, uint32_t ly, f4 c) {
     const size_t li = (size_t)ly * P.W + x;
     const uint32_t hx = f32_to_f16_bits(c.x, P.storageRounding), hy = f32_to_f16_bits(c.y, P.storageRounding);

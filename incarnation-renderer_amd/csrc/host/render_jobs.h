@@ -3,9 +3,14 @@
 // (reference: source/demo-dll/src/render-jobs/*.inl, job-sync.h).  Desc field names and meanings are the reference's;
 // FShaderBuffer / FShaderSurface / FSystemBuffer carry HBM pointers instead of bindless descriptor indices, and every
 // Execute forwards to one entry point of the C ABI (include/incr.h) on the Sync's HIP stream, in token order.
-// The reference host is MSVC/Windows C++ (PPL tasks, D3D12 command lists); here a pass is an asynchronous launch on a
-// stream, so Result::m_task is already complete when Execute returns and m_status carries the error code the reference
-// never had (it asserts: inc/common.h:113-148).
+// The reference host is MSVC/Windows C++ (PPL tasks, D3D12 command lists, job-sync.h's token fence).  Here a pass is a
+// closure over its Desc handed to Sync::Spawn with the token GetToken() gave it: with FConfig::RecordThreads == 0 the
+// closure runs at once on the calling thread (Result::m_task already complete); with RecordThreads > 0 a pool of host
+// threads runs the closures, each waiting for its token's turn before it submits to the stream (Sync::Execute there),
+// and Result::m_task completes when the pass has been submitted.  m_status carries the error code the reference never
+// had (it asserts: inc/common.h:113-148).  With FConfig::UseGraph the raster frame's submissions are captured into a
+// HIP graph on an internal stream, the instantiated graph is updated in place each frame (hipGraphExecUpdate) and
+// launched on the user's stream: one host submission per frame.
 #pragma once
 #include <condition_variable>
 #include <cstdint>

@@ -231,6 +231,34 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
     }
 }
 
+#ifdef INCR_WF_LANE_STATS
+// Developer build only (tools/lane_stats.py): where the lanes of the traversal waves go.  Per kernel (0 extend, 1 shadow) 8 words:
+// iterations, live lanes, lanes on a node step, lanes on a triangle step, iterations after the cursor ran dry, live lanes in those,
+// iterations that ran a refill, iterations in which only one kind of step was present.
+__device__ unsigned long long g_laneStats[16];
+struct LaneStats {
+    uint32_t it = 0, live = 0, node = 0, tri = 0, drainIt = 0, drainLive = 0, refills = 0, pure = 0;
+    DI void step(bool active, uint32_t triMask, bool exhausted) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(active && !triMask)), t = (uint32_t)__popcll(__ballot(active && triMask));
+        it++; live += n + t; node += n; tri += t; if (exhausted) { drainIt++; drainLive += n + t; } if (!n || !t) pure++;
+    }
+    DI void flush(int k) {
+        if ((threadIdx.x & 63u) == 0) {
+            const uint32_t v[8] = {it, live, node, tri, drainIt, drainLive, refills, pure};
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_laneStats[k * 8 + i], (unsigned long long)v[i]);
+        }
+    }
+};
+extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_laneStats), sizeof(g_laneStats)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_laneStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#define LANE_STATS(x) x
+#else
+#define LANE_STATS(x)
+#endif
+
 // ------------------------------------------------------------------------------------------------ extend
 template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 12 ? 6 : (N <= 16 ? 4 : 3))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
@@ -247,6 +275,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     bool active = false; uint32_t slot = 0;
     TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
     uint32_t rays = 0;
+    LANE_STATS(LaneStats ls;)
     // (The software-pipelined form of wf_shadow_kernel -- loads issued by the refill, rays started after the step, hits stored
     // by the next refill -- was measured here too: 12.2 ms per frame against 11.8; the closest-hit state already fills the
     // 72 VGPRs of 7 waves per SIMD and the eight registers of a ray in flight spill.)
@@ -255,6 +284,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
         if (!chunk.exhausted && (idle >= kExtendRefill || act == 0ull)) {
             const uint32_t item = chunk.take(!active, cursor, total);
+            LANE_STATS(ls.refills++;)
             if (item != 0xffffffffu) {
                 const float4 o = ext[(size_t)item * 2], d = ext[(size_t)item * 2 + 1];
                 slot = item;
@@ -264,12 +294,14 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
             }
         }
         if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
+        LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
         if (active && trav_closest_step(P, st, T)) {
             B.hit[slot] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
                                  : make_uint4(kMissTri, 0u, 0u, 0u);
             active = false;
         }
     }
+    LANE_STATS(ls.flush(0);)
     Counters cnt = {bounce == 0 ? rays : 0u, bounce == 0 ? 0u : rays, 0, 0, 0};
     add_counters(P, cnt);
 }
@@ -611,14 +643,17 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAV
     uint32_t rayIndex = 0, nextIndex = 0;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
     TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
+    LANE_STATS(LaneStats ls;)
     for (;;) {
         const unsigned long long act = __ballot(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
         if (!chunk.exhausted && (idle >= kShadowRefill || act == 0ull)) {
+            LANE_STATS(ls.refills++;)
             if (occludedDone) { ((float*)(B.rayC + rayIndex))[3] = 0.f; occludedDone = false; }
             const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; nextIndex = item; pending = true; }
         }
+        LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
         if (active && trav_any_step(P, st, T)) { occludedDone = T.occluded; active = false; }
         if (pending) {
             pending = false;
@@ -632,6 +667,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAV
         if (__ballot(active) == 0ull && chunk.exhausted) break;
     }
     if (occludedDone) ((float*)(B.rayC + rayIndex))[3] = 0.f;
+    LANE_STATS(ls.flush(1);)
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate

@@ -97,6 +97,13 @@ bool validate_scene(const HostScene& s, const char** why) {
 }
 
 // ---- SAH BVH2 over triangle boxes ------------------------------------------------------------------
+// SAH weights of the wide-BVH collapse: a wide-node visit against one triangle test (tools/trav_sim measures the step counts)
+#ifndef INCR_BVH_COST_NODE
+#define INCR_BVH_COST_NODE 1.0f
+#endif
+#ifndef INCR_BVH_COST_TRI
+#define INCR_BVH_COST_TRI 1.0f
+#endif
 namespace {
 struct Box { float lo[3], hi[3]; };
 static inline void box_reset(Box& b) { for (int a = 0; a < 3; ++a) { b.lo[a] = FLT_MAX; b.hi[a] = -FLT_MAX; } }
@@ -106,7 +113,7 @@ static inline float box_area(const Box& b) {
     if (dx < 0 || dy < 0 || dz < 0) return 0.f;
     return 2.f * (dx * dy + dy * dz + dz * dx);
 }
-struct Node2 { Box box; uint32_t left, right, first, count; };   // count > 0: leaf over order[first .. first+count)
+struct Node2 { Box box; uint32_t left, right, first, count; uint32_t spanFirst, spanCount; };   // count > 0: leaf over order[first .. first+count); span*: the subtree's run of `order` (every node)
 
 struct Builder {
     const std::vector<Box>& tb; const std::vector<V3>& cen;
@@ -116,8 +123,6 @@ struct Builder {
     // moved the step count by < 2 % either way (tools/trav_sim)
     static constexpr int kBins = 32;
     static constexpr int bins = kBins;
-    static constexpr float ct = 1.0f;
-    static constexpr uint32_t maxLeaf = kMaxLeafTris;
 
     Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_) : tb(tb_), cen(cen_) {
         order.resize(tb.size()); std::iota(order.begin(), order.end(), 0u);
@@ -138,8 +143,8 @@ struct Builder {
             const float c[3] = {cen[t].x, cen[t].y, cen[t].z};
             for (int a = 0; a < 3; ++a) { cb.lo[a] = std::min(cb.lo[a], c[a]); cb.hi[a] = std::max(cb.hi[a], c[a]); }
         }
-        nodes[me].box = bb;
-        if (count <= 2) { nodes[me].first = first; nodes[me].count = count; return me; }
+        nodes[me].box = bb; nodes[me].spanFirst = first; nodes[me].spanCount = count;
+        if (count <= 1) { nodes[me].first = first; nodes[me].count = count; return me; }
         // binned SAH over the three axes
         float bestCost = FLT_MAX; int bestAxis = -1, bestSplit = -1;
         for (int a = 0; a < 3; ++a) {
@@ -166,7 +171,8 @@ struct Builder {
         }
         uint32_t mid = first;
         const float leafCost = box_area(bb) * (float)count;
-        if (depth < kSahDepth && bestAxis >= 0 && (count > maxLeaf || bestCost + box_area(bb) * ct < leafCost)) {
+        (void)leafCost;      // the binary tree goes down to single triangles: which subtrees become leaves is the collapse's decision
+        if (depth < kSahDepth && bestAxis >= 0) {
             const float lo = cb.lo[bestAxis], scale = (float)bins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
             auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
                 int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), bins - 1);
@@ -175,8 +181,7 @@ struct Builder {
             mid = (uint32_t)(it - order.begin());
         }
         if (mid == first || mid == first + count) {
-            if (count <= maxLeaf) { nodes[me].first = first; nodes[me].count = count; return me; }
-            // all centroids coincide (or SAH refused): split by index to respect the leaf limit
+            // all centroids coincide (or past the SAH depth): object median along the longest centroid axis
             mid = first + count / 2;
             int a = 0; float ext = cb.hi[0] - cb.lo[0];
             for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; a = k; }
@@ -284,12 +289,56 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     Builder b(tb, cen);
     if (n) b.build(0, (uint32_t)n);
 
-    // 3. collapse BVH2 -> 8-wide quantised nodes (greedy: open the inner child with the largest surface area until the
-    //    node has 8 children) and lay the triangles out in NODE order: the leaf children of one node8 own one contiguous run.
+    // 3. collapse BVH2 -> 8-wide quantised nodes.  Which binary subtrees become the (up to 8) children of a wide node, and which
+    //    become leaves of <= kMaxLeafTris triangles, is chosen by dynamic programming over the SAH cost (Ylitie, Karras, Laine
+    //    2017, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", section 4.1):
+    //      C(n, 1) = min( leaf: A_n * P_n * cTri   [P_n <= kMaxLeafTris],   wide node: A_n * cNode + D(n, 8) )
+    //      C(n, i) = min( D(n, i), C(n, i - 1) ),   D(n, j) = min over 0 < k < j of C(left, k) + C(right, j - k)
+    //    (C(n, i): cheapest way to present subtree n as at most i children of some wide node).  Round 1 opened the child with the
+    //    largest area until a node had 8: on Sponza-stat that left the average node 3.8 children of 8 -- and a node step costs the
+    //    same ~300 VALU instructions however many of its slots are in use; the traversal kernels are VALU-bound.
+    //    Triangles are laid out in NODE order: the leaf children of one node8 own one contiguous run.
     out.nodes8.clear(); out.maxDepth = 0;
     std::vector<uint32_t> nodeDepth;
     std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
     if (n) {
+        const size_t n2 = b.nodes.size();
+        constexpr float cNode = INCR_BVH_COST_NODE, cTri = INCR_BVH_COST_TRI;
+        struct Dp { float c[8]; uint8_t split[9]; bool leaf; };      // c[i], i = 1..7; split[j] = k of D(n, j) (j = 2..8), 0 = "use C(n, j - 1)"
+        std::vector<Dp> dp(n2);
+        for (size_t i = n2; i-- > 0;) {                              // children come after their parent in `nodes`: reverse order is bottom-up
+            const Node2& nd2 = b.nodes[i]; Dp& d = dp[i];
+            float A = box_area(nd2.box);
+            if (!(A >= 0.f)) A = 0.f;                                // NaN boxes
+            A = std::min(A, 1e28f);                                  // keeps every sum of costs finite (<= 2^23 triangles)
+            const float leafC = nd2.spanCount <= kMaxLeafTris ? A * (float)nd2.spanCount * cTri : FLT_MAX;
+            memset(d.split, 0, sizeof d.split);
+            if (nd2.count) { d.leaf = true; for (int k = 1; k < 8; ++k) d.c[k] = leafC; continue; }
+            const Dp& L = dp[nd2.left]; const Dp& R = dp[nd2.right];
+            float D[9];
+            for (int j = 2; j <= 8; ++j) {
+                float bestC = FLT_MAX; int bestK = 1;
+                for (int k = 1; k < j; ++k) { if (k > 7 || j - k > 7) continue; const float c = L.c[k] + R.c[j - k]; if (c < bestC) { bestC = c; bestK = k; } }
+                D[j] = bestC; d.split[j] = (uint8_t)bestK;
+            }
+            const float wide = A * cNode + D[8];
+            d.leaf = nd2.spanCount <= kMaxLeafTris && leafC <= wide;
+            d.c[1] = std::min(leafC, wide);
+            for (int j = 2; j < 8; ++j) { if (D[j] < d.c[j - 1]) d.c[j] = D[j]; else { d.c[j] = d.c[j - 1]; d.split[j] = 0; } }
+        }
+        // the (<= j) children subtree x contributes to a wide node
+        struct Pick { uint32_t node; int j; };
+        auto collect = [&](uint32_t x, int j, uint32_t* kids, int& nk) {
+            Pick stack[32]; int sp = 0; stack[sp++] = {x, j};
+            while (sp) {
+                Pick pk = stack[--sp];
+                const Node2& c = b.nodes[pk.node];
+                while (pk.j > 1 && !c.count && dp[pk.node].split[pk.j] == 0) --pk.j;
+                if (pk.j == 1 || c.count) { kids[nk++] = pk.node; continue; }
+                const int k = dp[pk.node].split[pk.j];
+                stack[sp++] = {c.right, pk.j - k}; stack[sp++] = {c.left, k};
+            }
+        };
         struct Item8 { uint32_t n2, n8, depth; };
         std::vector<Item8> work8;
         out.nodes8.push_back({});
@@ -301,15 +350,9 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
             nodeDepth[it.n8] = it.depth;
             uint32_t kids[8]; int nk = 0;
             const Node2& root2 = b.nodes[it.n2];
-            if (root2.count) kids[nk++] = it.n2;                    // degenerate: the whole tree is one leaf
-            else { kids[nk++] = root2.left; kids[nk++] = root2.right; }
-            while (nk < 8) {
-                int best = -1; float bestA = -1.f;
-                for (int k = 0; k < nk; ++k) { const Node2& c = b.nodes[kids[k]]; if (!c.count) { float a = box_area(c.box); if (a > bestA) { bestA = a; best = k; } } }
-                if (best < 0) break;
-                const Node2& c = b.nodes[kids[best]];
-                kids[best] = c.left; kids[nk++] = c.right;
-            }
+            if (root2.count || (it.n2 == 0 && dp[0].leaf)) kids[nk++] = it.n2;      // degenerate: the whole tree is one leaf
+            else { const int k = dp[it.n2].split[8]; collect(root2.left, k, kids, nk); collect(root2.right, 8 - k, kids, nk); }
+            auto is_leaf = [&](uint32_t x) { return dp[x].leaf; };
             BvhNode8 nd; memset(&nd, 0, sizeof nd);
             const Box& nb = b.nodes[it.n2].box;
             // SLOT ORDER (device_types.h): inner children first, sorted by box centre along the node's longest axis; then leaves
@@ -317,8 +360,8 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
             for (int a = 1; a < 3; ++a) if (nb.hi[a] - nb.lo[a] > nb.hi[sortAxis] - nb.lo[sortAxis]) sortAxis = a;
             std::stable_sort(kids, kids + nk, [&](uint32_t x, uint32_t y) {
                 const Node2& cx = b.nodes[x]; const Node2& cy = b.nodes[y];
-                if ((cx.count == 0) != (cy.count == 0)) return cx.count == 0;
-                if (cx.count) return false;                                  // leaves keep their collapse order
+                if (is_leaf(x) != is_leaf(y)) return !is_leaf(x);
+                if (is_leaf(x)) return false;                                // leaves keep their collapse order
                 return cx.box.lo[sortAxis] + cx.box.hi[sortAxis] < cy.box.lo[sortAxis] + cy.box.hi[sortAxis];
             });
             nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
@@ -338,7 +381,7 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
             nd.triBase = (uint32_t)leafOrder.size();
             nd.childBase = (uint32_t)out.nodes8.size();
             uint32_t numInner = 0;
-            for (int k = 0; k < nk; ++k) if (!b.nodes[kids[k]].count) ++numInner;
+            for (int k = 0; k < nk; ++k) if (!is_leaf(kids[k])) ++numInner;
             out.nodes8.resize(out.nodes8.size() + numInner);
             uint32_t innerSlot = 0;
             uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
@@ -353,9 +396,9 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                     while (hi < 255 && org[a] + (float)hi * scale[a] < c.box.hi[a]) ++hi;
                     qlo[a][k] = (uint8_t)lo; qhi[a][k] = (uint8_t)hi;
                 }
-                if (c.count) {
-                    nd.meta[k] = (uint8_t)((c.count << 5) | ((uint32_t)leafOrder.size() - nd.triBase));
-                    for (uint32_t t = c.first; t < c.first + c.count; ++t) leafOrder.push_back(b.order[t]);
+                if (is_leaf(kids[k])) {
+                    nd.meta[k] = (uint8_t)((c.spanCount << 5) | ((uint32_t)leafOrder.size() - nd.triBase));
+                    for (uint32_t t = c.spanFirst; t < c.spanFirst + c.spanCount; ++t) leafOrder.push_back(b.order[t]);
                 } else { nd.imask |= (uint8_t)(1u << k); work8.push_back({kids[k], nd.childBase + innerSlot, it.depth + 1}); ++innerSlot; }
             }
             if (nd.imask & 1u) nd.meta[0] = (uint8_t)sortAxis;

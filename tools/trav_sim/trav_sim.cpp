@@ -63,6 +63,9 @@ static bool tri_isect(const TriIsect& T, const Ray& r, float tmax, float* t) {
 }
 static uint32_t child_index(const BvhNode8& n, uint32_t k) { return n.childBase + (uint32_t)__builtin_popcount(n.imask & ((1u << k) - 1u)); }
 
+// per-ray step traces for the wave-scheduling model: one byte per node visit = the triangle tests that followed it
+struct Trace { std::vector<uint32_t> start; std::vector<uint8_t> tris; void begin() { start.push_back((uint32_t)tris.size()); } };
+static Trace* g_trace = nullptr;
 static std::vector<uint8_t> g_nodeDepth; static double g_visitsByDepth[2][32];
 struct Stats { double rays = 0, nodes = 0, tris = 0, pushes = 0, hits = 0; std::vector<uint32_t> depthHist = std::vector<uint32_t>(128, 0); };
 static void note(Stats& s, uint32_t nodes, uint32_t tris, uint32_t pushes, uint32_t maxDepth, bool hit) {
@@ -95,6 +98,7 @@ static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, co
         }
     };
     uint32_t cur = 0; bool have = true;
+    if (g_trace) g_trace->begin();
     for (;;) {
         if (!have) {
             bool got = false;
@@ -113,6 +117,7 @@ static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, co
         have = false;
         const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[0][g_nodeDepth[cur]]++;
         NodeT N; node_test(n, r, invd, best, N);
+        if (g_trace) g_trace->tris.push_back((uint8_t)__builtin_popcount(tri_mask(n, N.hit)));
         test_tris(n, tri_mask(n, N.hit));
         uint32_t inner = N.hit & n.imask;
         if (!inner) continue;
@@ -157,6 +162,7 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
     uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
     std::vector<uint32_t> st;        // variant 0: node indices; variant 1: base << 8 | mask
     uint32_t cur = 0; bool have = true, occluded = false;
+    if (g_trace) g_trace->begin();
     for (;;) {
         if (!have) {
             if (st.empty()) break;
@@ -175,7 +181,9 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
         const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[1][g_nodeDepth[cur]]++;
         NodeT N; node_test(n, r, invd, r.tmax, N);
         uint32_t tm = tri_mask(n, N.hit);
+        const uint32_t trisBefore = tris;
         while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) occluded = true; }
+        if (g_trace) g_trace->tris.push_back((uint8_t)(tris - trisBefore));
         if (occluded) break;
         uint32_t inner = N.hit & n.imask;
         if (!inner) continue;
@@ -231,6 +239,100 @@ static void reorder(HostBvh& B, std::vector<uint8_t>& sortAxis, bool sortByAxis)
     }
 }
 
+// ---- wave-scheduling model ---------------------------------------------------------------------------
+// Persistent 64-lane waves over a ray list (chunks of `chunk` rays from a shared cursor, refill when >= `refill` lanes idle).
+// A lane's work is its trace: N, T x t0, N, T x t1, ...  Cost model in VALU instructions per wave iteration:
+// policy 0 (if-if, pt_traverse.h today): every live lane takes its next step, cost = cC + cN [any node lane] + cT [any tri lane].
+// policy 1 (phased): one kind of step per iteration -- the kind with more lanes waiting relative to `bias`; lanes of the other kind idle.
+// policy 2 (threshold): both kinds when each has >= thr lanes, otherwise only the larger.
+struct WaveModel { int policy; int chunk, refill; float cC, cN, cT, bias; int thr; };
+static void wave_model(const char* name, const Trace& tr, size_t nWaves, const WaveModel& M) {
+    const size_t nRays = tr.start.size();
+    struct Lane { bool live = false; uint32_t pos = 0, end = 0; uint32_t trisLeft = 0; bool nodeNext = true; };
+    struct Wave { Lane l[64]; size_t next = 0, end = 0; bool dry = false, done = false; };
+    std::vector<Wave> waves(nWaves);
+    size_t cursor = 0; double cost = 0, iters = 0, steps = 0, nodeLanes = 0, triLanes = 0, nodeIters = 0, triIters = 0;
+    size_t alive = nWaves;
+    while (alive) {
+        for (Wave& w : waves) {
+            if (w.done) continue;
+            int live = 0; for (auto& L : w.l) live += L.live;
+            if (!w.dry && (64 - live >= M.refill || live == 0)) {
+                for (auto& L : w.l) {
+                    if (L.live) continue;
+                    if (w.next >= w.end) { if (cursor >= nRays) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)M.chunk, nRays); cursor = w.end; }
+                    const size_t r = w.next++;
+                    L.live = true; L.pos = tr.start[r]; L.end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); L.trisLeft = 0; L.nodeNext = true;
+                    if (L.pos == L.end) L.live = false; else ++live;
+                }
+            }
+            if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+            int nN = 0, nT = 0;
+            for (auto& L : w.l) if (L.live) { if (L.trisLeft) ++nT; else ++nN; }
+            bool doN = nN > 0, doT = nT > 0;
+            if (M.policy == 1 && nN && nT) { if ((float)nN * M.bias >= (float)nT) doT = false; else doN = false; }
+            if (M.policy == 2 && nN && nT) { if (nN < M.thr && nN <= nT) doN = false; else if (nT < M.thr && nT < nN) doT = false; }
+            cost += M.cC + (doN ? M.cN : 0.f) + (doT ? M.cT : 0.f); iters++;
+            if (doN) { nodeIters++; nodeLanes += nN; } if (doT) { triIters++; triLanes += nT; }
+            for (auto& L : w.l) {
+                if (!L.live) continue;
+                if (L.trisLeft) { if (!doT) continue; --L.trisLeft; ++steps; }
+                else { if (!doN) continue; L.trisLeft = tr.tris[L.pos++]; ++steps; }
+                if (!L.trisLeft && L.pos >= L.end) L.live = false;
+            }
+        }
+    }
+    printf("  %-16s policy %d bias %.2f thr %2d refill %2d: cost/step %6.1f  iters %.3gM  node iters %.0f%% @ %.1f lanes, tri iters %.0f%% @ %.1f lanes\n", name, M.policy, M.bias, M.thr, M.refill,
+           cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0));
+}
+
+// policy 3 (overlap): a lane's node steps run every iteration; the triangles a node step finds go into a per-lane queue of Q
+// (triBase, mask) entries and are tested one per iteration ALONGSIDE the node steps, in iterations where >= thr lanes have
+// one pending or some lane can do nothing else (queue full / no node left).  Triangle order does not change the result.
+static void wave_model_overlap(const char* name, const Trace& tr, size_t nWaves, const WaveModel& M, int Q) {
+    const size_t nRays = tr.start.size();
+    struct Lane { bool live = false; uint32_t pos = 0, end = 0; uint32_t q[8]; int qn = 0; };
+    struct Wave { Lane l[64]; size_t next = 0, end = 0; bool dry = false, done = false; };
+    std::vector<Wave> waves(nWaves);
+    size_t cursor = 0; double cost = 0, iters = 0, steps = 0, nodeLanes = 0, triLanes = 0, nodeIters = 0, triIters = 0, stalls = 0;
+    size_t alive = nWaves;
+    while (alive) {
+        for (Wave& w : waves) {
+            if (w.done) continue;
+            int live = 0; for (auto& L : w.l) live += L.live;
+            if (!w.dry && (64 - live >= M.refill || live == 0)) {
+                for (auto& L : w.l) {
+                    if (L.live) continue;
+                    if (w.next >= w.end) { if (cursor >= nRays) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)M.chunk, nRays); cursor = w.end; }
+                    const size_t r = w.next++;
+                    L.live = true; L.pos = tr.start[r]; L.end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); L.qn = 0;
+                    if (L.pos == L.end) L.live = false; else ++live;
+                }
+            }
+            if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+            int nN = 0, nT = 0, must = 0;
+            for (auto& L : w.l) if (L.live) {
+                const bool canNode = L.pos < L.end && L.qn < Q;
+                if (canNode) ++nN;
+                if (L.qn) { ++nT; if (!canNode) ++must; }
+                if (L.pos < L.end && L.qn >= Q) ++stalls;
+            }
+            const bool doN = nN > 0, doT = nT > 0 && (nT >= M.thr || must >= (int)M.bias || nN == 0);
+            cost += M.cC + (doN ? M.cN : 0.f) + (doT ? M.cT : 0.f); iters++;
+            if (doN) { nodeIters++; nodeLanes += nN; } if (doT) { triIters++; triLanes += nT; }
+            for (auto& L : w.l) {
+                if (!L.live) continue;
+                const bool canNode = L.pos < L.end && L.qn < Q;
+                if (doT && L.qn) { ++steps; if (--L.q[0] == 0) { for (int i = 1; i < L.qn; ++i) L.q[i - 1] = L.q[i]; --L.qn; } }
+                if (canNode) { ++steps; const uint32_t t = tr.tris[L.pos++]; if (t) L.q[L.qn++] = t; }
+                if (L.pos >= L.end && L.qn == 0) L.live = false;
+            }
+        }
+    }
+    printf("  %-16s overlap Q %d thr %2d must %2.0f: cost/step %6.1f  iters %.3gM  node iters %.0f%% @ %.1f lanes, tri iters %.0f%% @ %.1f lanes, stalled lane-iters %.1f%%\n", name, Q, M.thr, M.bias,
+           cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0), 100 * stalls / (iters * 64));
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static float rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (float)((rng_state >> 40) * (1.0 / 16777216.0)); }
 
@@ -272,6 +374,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             if (fast && v != 2) continue;
             rng_state = 0x9E3779B97F4A7C15ull;
             Stats sp, sb, ss, ss0;
+            Trace trP, trB, trS; const bool model = cfg == 2 && variant == 2;
             g_nodeDepth.clear(); memset(g_visitsByDepth, 0, sizeof g_visitsByDepth);
             if (cfg == 2 && variant == 2) { g_nodeDepth.assign(B.nodes8.size(), 0); std::vector<std::pair<uint32_t,uint8_t>> q; q.push_back({0u, 1}); while (!q.empty()) { auto [ni, d] = q.back(); q.pop_back(); g_nodeDepth[ni] = d; for (int k = 0; k < 8; ++k) if ((B.nodes8[ni].imask >> k) & 1u) q.push_back({B.nodes8[ni].childBase + (uint32_t)k, (uint8_t)(d + 1)}); } }
             double checksum = 0;
@@ -283,7 +386,9 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                 r.tmin = 0.001f; r.tmax = 10000.f;
                 Stats* S = &sp;
                 for (int bounce = 0; bounce < 3; ++bounce) {
+                    g_trace = model ? (bounce == 0 ? &trP : &trB) : nullptr;
                     const Result h = closest(B, sortAxis, r, variant, *S);
+                    g_trace = nullptr;
                     S = &sb;
                     if (!h.found) break;
                     checksum += h.t;
@@ -296,7 +401,9 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                     // shadow rays: sun, in-range point lights, one cosine sky sample
                     auto shadow = [&](const float d[3], float tmax) {
                         Ray s; for (int k = 0; k < 3; ++k) { s.o[k] = p[k]; s.d[k] = d[k]; } s.tmin = 0.1f; s.tmax = tmax;
-                        anyhit(B, sortAxis, s, fast ? 1 : variant, ss);
+                        g_trace = model ? &trS : nullptr;
+                        anyhit(B, sortAxis, s, (fast || model) ? 1 : variant, ss);
+                        g_trace = nullptr;
                     };
                     if (sun[0] * n[0] + sun[1] * n[1] + sun[2] * n[2] > 0.f) shadow(sun, 1000.f);
                     for (const PL& L : pls) {
@@ -327,6 +434,17 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                 printf("  nodes per level:"); for (size_t d = 0; d + 1 < B.levelOffsets.size(); ++d) printf(" %u", B.levelOffsets[d + 1] - B.levelOffsets[d]); printf("\n");
             }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
+            if (model) {
+                struct { const char* n; const Trace* t; size_t perWave; int chunk, refill; float cC, cN, cT; } sets[3] = {
+                    {"primary", &trP, 1150, 64, 16, 100, 300, 150}, {"bounce", &trB, 700, 64, 16, 100, 300, 150}, {"shadow", &trS, 1700, 128, 12, 80, 260, 110}};
+                for (auto& S : sets) {
+                    const size_t nW = std::max<size_t>(1, S.t->start.size() / S.perWave);
+                    wave_model(S.n, *S.t, nW, {0, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 0});
+                    for (float bias : {0.5f, 1.f, 2.f}) wave_model(S.n, *S.t, nW, {1, S.chunk, S.refill, S.cC, S.cN, S.cT, bias, 0});
+                    for (int thr : {8, 16, 24}) wave_model(S.n, *S.t, nW, {2, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr});
+                    for (int Q : {2, 4}) for (int thr : {24, 32, 40}) for (float must : {1.f, 8.f, 16.f}) wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT + 30.f, must, thr}, Q);
+                }
+            }
         }
     }
     return 0;

@@ -118,11 +118,11 @@ struct Node8 {              // decoded header of one node + the hit mask / entry
     float tn[8];            // entry distance per child (valid where hitMask is set)
 };
 
+DI uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 DI float ubyte_f(uint32_t packed, int k) { return (float)((packed >> (8 * k)) & 0xffu); }      // v_cvt_f32_ubyteK
 
-// Conservative slab test of the 8 quantised child boxes (n0..n4 = the five dwordx4 of a BvhNode8).  Margins:
-// 0.02 quantum + 2^-22 |b| on every plane for the rounding of a, b and the fma; the far distance is widened by
-// 1 + 4e-7 (Ize 2013 / pbrt robust bounds test).  The exact triangle test -- never the box test -- decides a hit.
+// Conservative slab test of the 8 quantised child boxes (n0..n4 = the five dwordx4 of a BvhNode8); margins below.
+// The exact triangle test -- never the box test -- decides a hit.
 DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4,
                    const RaySetup& r, float tmin, float tmax, Node8& N) {
     const uint32_t em = __float_as_uint(n0.w);
@@ -132,7 +132,10 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float(((em >> 8) & 0xffu) << 23), sz = __uint_as_float(((em >> 16) & 0xffu) << 23);
     const float ax = sx * r.invd.x, ay = sy * r.invd.y, az = sz * r.invd.z;
     const float bx = (n0.x - r.o.x) * r.invd.x, by = (n0.y - r.o.y) * r.invd.y, bz = (n0.z - r.o.z) * r.invd.z;
-    const float mx = 0.02f * fabsf(ax) + 2.4e-7f * fabsf(bx), my = 0.02f * fabsf(ay) + 2.4e-7f * fabsf(by), mz = 0.02f * fabsf(az) + 2.4e-7f * fabsf(bz);
+    // margins: 0.02 quantum + 2^-22 |b| for the rounding of a, b and the fma, plus the 1 + 4e-7 widening of the far distance
+    // (Ize 2013) folded in -- |t| <= 255 |a| + |b| on every plane -- so that no child pays a multiply for it
+    const float mx = 0.0202f * fabsf(ax) + 6.4e-7f * fabsf(bx), my = 0.0202f * fabsf(ay) + 6.4e-7f * fabsf(by), mz = 0.0202f * fabsf(az) + 6.4e-7f * fabsf(bz);
+    const float tmaxW = tmax * 1.0000004f;
     const float bnx = bx - mx, bfx = bx + mx, bny = by - my, bfy = by + my, bnz = bz - mz, bfz = bz + mz;
     // near planes: lo bytes when the direction component is >= 0, hi bytes otherwise
     const bool px = ax >= 0.f, py = ay >= 0.f, pz = az >= 0.f;
@@ -151,13 +154,15 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
         const float tnx = __builtin_fmaf(ubyte_f(nxp, j), ax, bnx), tny = __builtin_fmaf(ubyte_f(nyp, j), ay, bny), tnz = __builtin_fmaf(ubyte_f(nzp, j), az, bnz);
         const float tfx = __builtin_fmaf(ubyte_f(fxp, j), ax, bfx), tfy = __builtin_fmaf(ubyte_f(fyp, j), ay, bfy), tfz = __builtin_fmaf(ubyte_f(fzp, j), az, bfz);
         const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);           // NaN planes (0 * inf) are ignored by max/min
-        const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmax) * 1.0000004f;
+        const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmaxW);
         N.tn[k] = t0;
         hit |= (t0 <= t1) ? (1u << k) : 0u;
     }
     // A slot without a child may come out as "hit": it is not an inner node (imask) and its meta byte is 0, so it adds
     // neither a node to visit nor a triangle to test -- no separate existence mask is needed (dropping it: +3 % rays/s).
-    // (Packing the plane fmas of a child pair into v_pk_fma_f32 was measured too: -7 %, register moves eat the saving.)
+    // (v_pk_fma_f32 for the plane fmas -- child pairs in round 1, the near/far pair of one child in round 2, 24 packed for 48
+    // scalar fmas and 5 % fewer VALU instructions in the kernel -- measured -7 % and -9 %: a packed fp32 fma issues no faster
+    // than the two it replaces on this part, and the register pairs cost occupancy or spills.)
     N.hitMask = hit;
 }
 DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }
@@ -252,18 +257,26 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
         const uint32_t inner = N.hitMask & N.imask;
         T.haveCur = inner != 0u;
         if (inner) {
-            float nearT = __uint_as_float(0x7f800000u); uint32_t nearK = 0u;
+            // smallest and second-smallest entry distance among the overlapped inner children in 5 instructions per slot: the
+            // distances are positive floats, so their bit patterns order like unsigned integers; the low three mantissa bits
+            // carry the slot number (the distance rounds DOWN by < 8 ulp: keys stay lower bounds), slots that are not
+            // overlapped inner children get the all-ones key.  (Two compare-and-select scans cost 98 VALU instructions per
+            // node step against 46 -- and the traversal kernels are VALU-bound.)
+            uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && N.tn[k] < nearT) { nearT = N.tn[k]; nearK = (uint32_t)k; }
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t fill = (uint32_t)__builtin_amdgcn_sbfe((int)~inner, (uint32_t)k, 1u);      // 0 or ~0
+                const uint32_t key = ((__float_as_uint(N.tn[k]) & ~7u) | (uint32_t)k) | fill;
+                m2 = umed3(m1, m2, key);
+                m1 = min(m1, key);
+            }
+            const uint32_t nearK = m1 & 7u;
             const uint32_t rest = inner & ~(1u << nearK);
             if (rest) {
-                float restT = __uint_as_float(0x7f800000u);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if ((rest >> k) & 1u) restT = fminf(restT, N.tn[k]);
                 const uint32_t axis = N.meta0 & 3u;                  // meta[0] of a node whose slot 0 is inner = its sort axis
-                st.push(stack_entry(N.childBase, (T.negDir >> axis) & 1u, rest), restT);
+                st.push(stack_entry(N.childBase, (T.negDir >> axis) & 1u, rest), __uint_as_float(m2 & ~7u));
             }
-            T.cur = N.childBase + nearK; T.curKey = nearT;
+            T.cur = N.childBase + nearK; T.curKey = __uint_as_float(m1 & ~7u);
         }
         if (T.triMask) return false;
     }

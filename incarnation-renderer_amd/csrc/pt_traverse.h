@@ -162,7 +162,8 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     // neither a node to visit nor a triangle to test -- no separate existence mask is needed (dropping it: +3 % rays/s).
     // (v_pk_fma_f32 for the plane fmas -- child pairs in round 1, the near/far pair of one child in round 2, 24 packed for 48
     // scalar fmas and 5 % fewer VALU instructions in the kernel -- measured -7 % and -9 %: a packed fp32 fma issues no faster
-    // than the two it replaces on this part, and the register pairs cost occupancy or spills.)
+    // than the two it replaces on this part, and the register pairs cost occupancy or spills.  Likewise v_perm_b32 building f16
+    // pairs (1024 + q) for v_fma_mix_f32 -- 24 perms + 48 mixed fmas for 48 converts + 48 fmas: shadow 9.1 -> 9.8 ms.)
     N.hitMask = hit;
 }
 DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }

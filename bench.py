@@ -37,7 +37,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, PKG, "csrc")
-    for f in ("pathtrace_wf.hip", "pt_traverse.h", "pt_shade.h", "pt_device.h", "pt_params.h", "device_types.h", "scene_build.cpp", "Makefile"):
+    for f in ("pathtrace_wf.hip", "pt_traverse.h", "pt_shade.h", "pt_device.h", "pt_params.h", "device_types.h", "scene_build.cpp", "api.hip", "api_internal.h", "Makefile"):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -182,6 +182,10 @@ def main():
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
+    ap.add_argument("--pipelines", type=int, default=2,
+                    help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical). "
+                         "With more than one, launches of different bands overlap and stretch each other: the per-kernel times then price launches "
+                         "that share the GPU; --pipelines 1 times every kernel alone (profiles/ holds both)")
     ap.add_argument("--spp-per-gather", type=int, default=64,
                     help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
                          "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
@@ -213,6 +217,7 @@ def main():
     importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
+    ctx.set_pathtrace_pipelines(max(1, min(args.pipelines, 8)))
     scene = ctx.create_scene(packed)
     info = scene.info()
     # load-time precompute, as the reference does once per scene / sun change (FScene::UpdateDynamicSky at
@@ -321,13 +326,16 @@ def main():
             "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
-                       "lights": len(packed.global_lights), "texture_size": args.texture_size,
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": max(1, min(args.pipelines, 8)),
                        "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": dominant, "kernel_ms": round(kernel_ms, 4), "kernel_launches_per_step": dom_launches / args.steps,
+                         "kernel_timing": ("HIP events on each pipeline's stream; %d pipelines overlap, so a launch shares the GPU with the other band's "
+                                           "kernels while it is timed (sum of kernel_ms_per_step > ms_per_step); --pipelines 1 times kernels alone" % args.pipelines)
+                                          if args.pipelines > 1 else "HIP events on the launch stream, one pipeline: every kernel has the GPU to itself",
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX,
                          "whole_call": {"ms": round(call_ms, 4), "algorithmic_bytes": int(frame_alg_bytes),
@@ -342,11 +350,19 @@ def main():
                     tj = json.load(f)
                 entry = tj.get("kernels", {}).get(dominant)
                 default_workload = args.scene == "sponza" and [W, H] == [3840, 2160] and not args.no_direct_lighting and args.viewmode == 0
-                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload:
+                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == max(1, min(args.pipelines, 8)):
                     out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tj.get("source")
+                    # the traversal kernels are VALU-issue bound: instructions per launch x 4 cycles per wave64
+                    # instruction / 1024 SIMDs against the elapsed cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs)
+                    if entry.get("SQ_INSTS_VALU_per_launch") and entry.get("GRBM_GUI_ACTIVE_per_launch"):
+                        issue = entry["SQ_INSTS_VALU_per_launch"] * 4.0 / 1024.0
+                        elapsed = entry["GRBM_GUI_ACTIVE_per_launch"] / 8.0
+                        out["roofline"]["valu"] = {"insts_per_launch": int(entry["SQ_INSTS_VALU_per_launch"]), "issue_cycles_per_simd": int(issue),
+                                                   "elapsed_cycles": int(elapsed), "frac": round(issue / elapsed, 4),
+                                                   "lane_utilisation": round(entry.get("SQ_THREAD_CYCLES_VALU_per_launch", 0.0) / max(entry.get("SQ_ACTIVE_INST_VALU_per_launch", 1.0), 1.0) / 64.0, 4)}
                 else:
-                    out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources or another workload: not attached"
+                    out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources, another workload or another pipeline count: not attached"
             except Exception:
                 pass
         if raster_out is not None:

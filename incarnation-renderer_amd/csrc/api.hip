@@ -16,7 +16,8 @@
 
 using namespace incr;
 
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events);
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
+                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events);
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
                                              const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream);
@@ -36,7 +37,8 @@ int incr_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
-static constexpr int kProfEvents = 22;      // per recorded incr_pathtrace call: start + generate + 4 x (extend, shade, shadow_gen, shadow, accumulate)
+static constexpr int kProfEvents = 22;      // per pipeline of a recorded incr_pathtrace call: start + generate + 4 x (extend, shade, shadow_gen, shadow, accumulate)
+static constexpr int kMaxPipes = 8;
 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
 
@@ -79,6 +81,12 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     const char* se = getenv("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
     ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
+    // pipelines of a path-traced frame (pathtrace_wf.hip): independent bands of tile rows on concurrent streams
+    const char* pe = getenv("INCR_WF_PIPELINES");
+    ctx->wfPipesWanted = pe ? std::min(std::max(atoi(pe), 1), kMaxPipes) : INCR_WF_PIPELINES_DEFAULT;
+    ctx->wfPipes = 1; memset(ctx->wfTileRow, 0, sizeof ctx->wfTileRow);
+    memset(ctx->wfStreams, 0, sizeof ctx->wfStreams); memset(ctx->wfJoin, 0, sizeof ctx->wfJoin);
+    HIP_TRY(hipEventCreateWithFlags(&ctx->wfFork, hipEventDisableTiming));      // the pipelines' own streams are created on first use
     ctx->profiling = false; ctx->profFrames = 0;
     ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
     *out_ctx = ctx;
@@ -92,6 +100,8 @@ int incr_teardown(incr_context* ctx) {
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->statStripes) (void)hipFree(ctx->statStripes);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
+    for (int i = 1; i < kMaxPipes; ++i) { if (ctx->wfStreams[i]) (void)hipStreamDestroy(ctx->wfStreams[i]); if (ctx->wfJoin[i]) (void)hipEventDestroy(ctx->wfJoin[i]); }
+    if (ctx->wfFork) (void)hipEventDestroy(ctx->wfFork);
     if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     delete ctx;
@@ -199,26 +209,41 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
     P.gridCellOffsets = sc->dGridOffsets; P.gridCellLights = sc->dGridLights;
 }
 
-// Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned).
+// Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned) per pipeline.
 // 272 B of path state + raysPerPath x 48 B of shadow-ray queue per pixel: 5.4 GB at 4K -- 1.9 % of the 288 GB.
-static int ensure_wf_workspace(incr_context* ctx, uint64_t numPaths, hipStream_t stream) {
-    if (numPaths == 0) numPaths = 1;
-    const uint64_t n = (numPaths + 255) & ~255ull;
-    const uint64_t rayCap = std::min<uint64_t>(n * ctx->raysPerPath, 0xfffffff0ull);
-    const uint64_t need = n * (32 * 4 + 16 + 128) + 4096 + (rayCap + 1) * 48;
+// A pipeline owns a band of 8-pixel tile rows (equal shares; a frame of fewer tile rows than pipelines uses fewer).
+static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, hipStream_t stream) {
+    const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u;
+    const int pipes = (int)std::max(1u, std::min<uint32_t>((uint32_t)ctx->wfPipesWanted, tilesY / 4u));      // >= 4 tile rows each
+    ctx->wfPipes = pipes;
+    for (int i = 1; i < pipes; ++i) if (!ctx->wfStreams[i]) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->wfStreams[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->wfJoin[i], hipEventDisableTiming));
+    }
+    uint64_t n[kMaxPipes], rayCap[kMaxPipes], need = 0;
+    for (int i = 0; i <= pipes; ++i) ctx->wfTileRow[i] = (uint32_t)((uint64_t)tilesY * i / pipes);
+    for (int i = 0; i < pipes; ++i) {
+        const uint64_t paths = std::max<uint64_t>((uint64_t)(ctx->wfTileRow[i + 1] - ctx->wfTileRow[i]) * tilesX * 64u, 1);
+        n[i] = (paths + 255) & ~255ull;
+        rayCap[i] = std::min<uint64_t>(n[i] * ctx->raysPerPath, 0xfffffff0ull);
+        need += n[i] * (32 * 4 + 16 + 128) + 4096 + (rayCap[i] + 1) * 48;
+    }
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
+        for (int i = 1; i < kMaxPipes; ++i) if (ctx->wfStreams[i]) HIP_TRY(hipStreamSynchronize(ctx->wfStreams[i]));
         if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
         HIP_TRY(hipMalloc(&ctx->wfBlock, need));
         ctx->wfBytes = need;
     }
     uint8_t* p = (uint8_t*)ctx->wfBlock;
-    WfBuffers& w = ctx->wf;
-    w.counters = (uint32_t*)p; p += 4096;
-    w.extA = (float4*)p; p += n * 32; w.extB = (float4*)p; p += n * 32; w.stA = (float4*)p; p += n * 32; w.stB = (float4*)p; p += n * 32;
-    w.hit = (uint4*)p; p += n * 16; w.vertex = (float4*)p; p += n * 128;
-    w.rayQ = (float4*)p; p += (rayCap + 1) * 32; w.rayC = (float4*)p; w.rayCap = (uint32_t)rayCap;
-    w.numPaths = (uint32_t)numPaths;
+    for (int i = 0; i < pipes; ++i) {
+        WfBuffers& w = ctx->wf[i];
+        w.counters = (uint32_t*)p; p += 4096;
+        w.extA = (float4*)p; p += n[i] * 32; w.extB = (float4*)p; p += n[i] * 32; w.stA = (float4*)p; p += n[i] * 32; w.stB = (float4*)p; p += n[i] * 32;
+        w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 128;
+        w.rayQ = (float4*)p; p += (rayCap[i] + 1) * 32; w.rayC = (float4*)p; p += (rayCap[i] + 1) * 16; w.rayCap = (uint32_t)rayCap[i];
+        w.numPaths = (uint32_t)n[i];
+    }
     return INCR_OK;
 }
 
@@ -525,16 +550,19 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.stats = d->ray_stats;
     P.statStripes = ctx->statStripes;     // the wavefront kernels count through the striped counters
     upload_grid_params(sc, P);
-    int rc = ensure_wf_workspace(ctx, (uint64_t)P.localRows * P.W, (hipStream_t)stream);
+    int rc = ensure_wf_workspace(ctx, P.W, P.localRows, (hipStream_t)stream);
     if (rc) return rc;
     hipEvent_t* ev = nullptr;
-    if (ctx->profiling) {
-        while (ctx->profEvents.size() < (ctx->profFrames + 1) * kProfEvents) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
-        ev = ctx->profEvents.data() + ctx->profFrames * kProfEvents;
+    if (ctx->profiling) {       // one record of kMaxPipes x 22 events per call, whatever the pipeline count
+        const size_t perCall = (size_t)kProfEvents * kMaxPipes;
+        while (ctx->profEvents.size() < (ctx->profFrames + 1) * perCall) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
+        ev = ctx->profEvents.data() + ctx->profFrames * perCall;
+        ctx->profPipes.push_back(ctx->wfPipes);
         ctx->profFrames++;
     }
     const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
-    HIP_TRY(incr_launch_pathtrace_wf(&P, &ctx->wf, ctx->props.multiProcessorCount, stackEntries, (hipStream_t)stream, ev));
+    ctx->wfStreams[0] = (hipStream_t)stream;
+    HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev));
     return INCR_OK;
 }
 
@@ -576,9 +604,16 @@ int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info)
     return INCR_OK;
 }
 
+int incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (pipelines > (uint32_t)kMaxPipes) return fail(INCR_ERR_INVALID_ARGUMENT, "at most %d pipelines", kMaxPipes);
+    ctx->wfPipesWanted = pipelines ? (int)pipelines : INCR_WF_PIPELINES_DEFAULT;
+    return INCR_OK;
+}
+
 int incr_profile_begin(incr_context* ctx) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    ctx->profiling = true; ctx->profFrames = 0;
+    ctx->profiling = true; ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }
 
@@ -589,14 +624,16 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     ctx->profiling = false;
     HIP_TRY(hipDeviceSynchronize());
     double* cls[5] = {&out->extend_ms, &out->shade_ms, &out->shadow_gen_ms, &out->shadow_ms, &out->accumulate_ms};
-    for (size_t f = 0; f < ctx->profFrames; ++f) {
-        hipEvent_t* ev = ctx->profEvents.data() + f * kProfEvents;
+    // every pipeline's kernels are timed on the pipeline's own stream; with more than one pipeline the intervals of different
+    // pipelines overlap in time, so the per-kernel sums can exceed the frame's wall time (they price the kernels, not the frame)
+    for (size_t f = 0; f < ctx->profFrames; ++f) for (int pipe = 0; pipe < ctx->profPipes[f]; ++pipe) {
+        hipEvent_t* ev = ctx->profEvents.data() + (f * kMaxPipes + pipe) * kProfEvents;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); out->generate_ms += ms;
         for (int k = 0; k < 20; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++; }
     }
     out->frames = (uint32_t)ctx->profFrames;
-    ctx->profFrames = 0;
+    ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }
 

@@ -19,6 +19,9 @@ int incr_fail(int code, const char* fmt, ...);      // stores the thread's incr_
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? INCR_ERR_OUT_OF_MEMORY : INCR_ERR_HIP, \
                                  "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+#ifndef INCR_WF_PIPELINES_DEFAULT
+#define INCR_WF_PIPELINES_DEFAULT 2
+#endif
 struct incr_context {
     int device;
     hipDeviceProp_t props;
@@ -26,12 +29,18 @@ struct incr_context {
     unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
     uint32_t forceStackEntries; // INCR_WF_STACK_ENTRIES (tests): lower bound for the traversal kernels' stack size
     uint32_t raysPerPath;     // shadow-ray queue slots per path of the wavefront path tracer (8; INCR_WF_RAYS_PER_PATH)
-    incr::WfBuffers wf;       // path-state workspace of the wavefront path tracer, grown on demand
+    incr::WfBuffers wf[8];    // path-state workspace of the wavefront path tracer, one set per pipeline (pathtrace_wf.hip), grown on demand
+    uint32_t wfTileRow[9];    // tile rows [wfTileRow[i], wfTileRow[i + 1]) belong to pipeline i
+    int wfPipes;              // pipelines of the current frame
+    int wfPipesWanted;        // INCR_WF_PIPELINES (default 2)
+    hipStream_t wfStreams[8]; // [0] is filled per call with the caller's stream; the others are library-owned
+    hipEvent_t wfFork, wfJoin[8];
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
     bool profiling;                                   // incr_profile_begin .. incr_profile_end
     std::vector<hipEvent_t> profEvents;               // 22 per recorded incr_pathtrace call
     size_t profFrames;
+    std::vector<int> profPipes;                       // pipelines of every recorded call
     // raster path workspace (raster_api.hip): 64-bit depth|id surface of the visibility pass + per-mesh frame constants
     void* rasterBlock;
     uint64_t rasterBytes;

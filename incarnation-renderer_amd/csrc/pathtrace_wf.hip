@@ -198,13 +198,13 @@ template <uint32_t kChunk> struct WaveChunk {
 };
 
 // ------------------------------------------------------------------------------------------------ generate
-__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX) {
+__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tileBase) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     for (uint32_t base = blockIdx.x * kWfBlock; base < total; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
         // 8x8 pixel tile per wave: the primary rays of a wave walk the same BVH lines
-        const uint32_t tile = i >> 6, w = i & 63u;
+        const uint32_t tile = (i >> 6) + tileBase, w = i & 63u;
         const uint32_t px = (tile % tilesX) * 8u + (w & 7u), ly = (tile / tilesX) * 8u + (w >> 3);
         bool valid = i < total && px < P.W && ly < P.localRows;
         uint32_t pid = 0;
@@ -762,44 +762,67 @@ template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, 
 }
 } // namespace incr
 
-// `events` (optional, 22 entries): recorded on `stream` before the first kernel and after every kernel
-// (generate, then extend / shade / shadow_gen / shadow / accumulate per bounce) so that the host can attribute time per kernel.
-// `stackEntries`: LDS stack entries per lane the scene's tree needs (maxDepth - 1); 8, 12, 16 and 24 are instantiated.
-extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* b, int numCUs, uint32_t stackEntries, hipStream_t stream, hipEvent_t* events) {
+// One frame = `numPipes` independent PIPELINES: pipeline i owns the tile rows [tileRow[i], tileRow[i + 1]) of the (local) frame, its own
+// path-state buffers pipes[i] and its own stream streams[i] (streams[0] = the caller's; the others wait for `fork`, recorded on the
+// caller's stream here, and the caller's stream waits for their `joins` at the end).  Why: a traversal kernel ends on its longest
+// rays -- a ray is a chain of ~30 (max > 150) dependent fetch + test steps, ~2 us each once its wave runs alone -- and with one
+// pipeline the whole GPU waits for that tail 8 times per frame; with two, the other pipeline's kernels fill the machine meanwhile.
+// The effect grows as the frame shrinks (a 1/8 framebuffer shard of an 8-GPU run: profiles/r02_shard_emulation.json).
+// `events` (optional, 22 per pipeline): recorded on the pipeline's stream before its first kernel and after every kernel.
+extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
+                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events) {
     using namespace incr;
-    const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;
-    const uint32_t total = tilesX * tilesY * 64u;
-    if (total == 0) return hipSuccess;
+    const uint32_t tilesX = (p->W + 7u) / 8u;
+    if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
+    if (tileRow[numPipes] == 0) return hipSuccess;
     if (stackEntries > 24u) return hipErrorInvalidValue;
     const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
-    // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer.
-    // Capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms,
-    // uncapped 42.7: a block's 16 strided iterations were another fixed share that the slowest blocks finished late.
-#ifndef INCR_WF_STREAM_BLOCKS_PER_CU
-#define INCR_WF_STREAM_BLOCKS_PER_CU 65536
-#endif
-    const uint32_t blocksAll = std::max(1u, (uint32_t)std::min<uint64_t>((uint64_t)cus * INCR_WF_STREAM_BLOCKS_PER_CU, (total + kWfBlock - 1) / kWfBlock));
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
     const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv == 8 ? (uint32_t)INCR_SHADOW_WAVES : (sv <= 16 ? 8u : 6u);
-    const uint32_t blocksExtend = std::max(1u, std::min(cus * extendPerCU, (total + kWfBlock - 1) / kWfBlock));
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
-    hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, stream, b->counters, blocksExtend * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
-    int ev = 0;
-    auto mark =[&]() { if (events) (void)hipEventRecord(events[ev], stream); ++ev; };
-    mark();
-    hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, total, tilesX); mark();
-    for (int bounce = 0; bounce < 4; ++bounce) {
-        if (sv == 8) launch_extend<8>(blocksExtend, stream, *p, *b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend, stream, *p, *b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend, stream, *p, *b, bounce); else launch_extend<24>(blocksExtend, stream, *p, *b, bounce);
-        mark();
-        hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
-        if (p->viewmode >= 2) break;            // VIEWMODE >= 2 paths end at the first hit
-        hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
-        if (sv == 8) launch_shadow<8>(blocksShadow, stream, *p, *b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, stream, *p, *b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, stream, *p, *b, bounce); else launch_shadow<24>(blocksShadow, stream, *p, *b, bounce);
-        mark();
-        hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll), dim3(kWfBlock), 0, stream, *p, *b, bounce); mark();
+    uint32_t total[8], blocksAll[8], blocksExtend[8];
+    for (int i = 0; i < numPipes; ++i) {
+        total[i] = (tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
+        // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer
+        // (capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms, uncapped 42.7)
+        blocksAll[i] = std::max(1u, (total[i] + kWfBlock - 1) / kWfBlock);
+        blocksExtend[i] = std::max(1u, std::min(cus * extendPerCU, (total[i] + kWfBlock - 1) / kWfBlock));
     }
-    if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, stream);
-    while (ev < 22) mark();                       // unused slots collapse to zero-length intervals
+    if (numPipes > 1) {
+        (void)hipEventRecord(fork, streams[0]);
+        for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
+    }
+    auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
+    // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
+    for (int i = 0; i < numPipes; ++i) {
+        if (!total[i]) continue;
+        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
+        mark(i, 0);
+        hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tileRow[i] * tilesX); mark(i, 1);
+    }
+    int slot = 2;
+    for (int bounce = 0; bounce < 4; ++bounce) {
+        for (int i = 0; i < numPipes; ++i) {
+            if (!total[i]) continue;
+            hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
+            if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+            mark(i, slot);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 1);
+        }
+        if (p->viewmode >= 2) { slot += 2; break; }            // VIEWMODE >= 2 paths end at the first hit
+        for (int i = 0; i < numPipes; ++i) {
+            if (!total[i]) continue;
+            hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
+            hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 2);
+            if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
+            mark(i, slot + 3);
+            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);
+        }
+        slot += 5;
+    }
+    for (int i = 0; i < numPipes; ++i) for (int k = total[i] ? slot : 0; k < 22; ++k) mark(i, k);      // unused slots collapse to zero-length intervals
+    for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
+    if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);
     return hipGetLastError();
 }

@@ -129,11 +129,20 @@ typedef struct incr_pathtrace_desc {
     uint32_t envmap_res, envmap_mips;
 } incr_pathtrace_desc;
 int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);
+/*
+ * Not in the reference: how a path-traced frame is issued.  The frame is cut into `pipelines` bands of 8-pixel tile rows, each
+ * with its own path-state buffers and its own (library-owned) stream; the bands fork from `stream` and join it again inside
+ * incr_pathtrace, so callers see one stream-ordered call.  Results are bit-identical for every count (1..8; 0 = the
+ * default, 2, or the INCR_WF_PIPELINES environment variable read at incr_initialize).  One pipeline leaves the GPU waiting
+ * for the longest rays of each of the eight traversal kernels of a frame; with two the other band's kernels run meanwhile.
+ */
+int  incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines);
 
 /*
  * Per-kernel timing of the path tracer (stands in for the reference's PIX/Tracy GPU zones, inc/profiling.h:10-12):
  * between incr_profile_begin and incr_profile_end every incr_pathtrace call records HIP events around each of its
- * kernels on the stream it is launched on; incr_profile_end synchronises the device and sums the intervals.
+ * kernels on the stream it is launched on; incr_profile_end synchronises the device and sums the intervals.  With more
+ * than one pipeline (above) intervals of different pipelines overlap in time: the sums price the launches, not the frame.
  */
 typedef struct incr_pathtrace_profile {
     double generate_ms, extend_ms, shade_ms, shadow_gen_ms, shadow_ms, accumulate_ms;   /* summed over all recorded calls */

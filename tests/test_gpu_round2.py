@@ -328,10 +328,12 @@ def test_update_bvh_bistro_scale_cost(gpu_ctx, rt, R, sio, synth):
 
 
 # ------------------------------------------------------------------------------------------------ overflow mechanisms
-@pytest.mark.parametrize("env", [{"INCR_WF_RAYS_PER_PATH": "1"}, {"INCR_WF_RAYS_PER_PATH": "0"}, {"INCR_WF_STACK_ENTRIES": "12"}, {"INCR_WF_STACK_ENTRIES": "16"}, {"INCR_WF_STACK_ENTRIES": "24"}])
+@pytest.mark.parametrize("env", [{"INCR_WF_RAYS_PER_PATH": "1"}, {"INCR_WF_RAYS_PER_PATH": "0"}, {"INCR_WF_STACK_ENTRIES": "12"}, {"INCR_WF_STACK_ENTRIES": "16"}, {"INCR_WF_STACK_ENTRIES": "24"},
+                                 {"INCR_WF_PIPELINES": "1"}, {"INCR_WF_PIPELINES": "3"}, {"INCR_WF_PIPELINES": "8"}])
 def test_wavefront_overflow_paths_are_bit_identical(gpu_ctx, rt, sio, sponza_small, env):
-    """A shadow-ray queue that is too small (vertices traced inside accumulate instead) and the 16- / 24-entry stack
-    instantiations of the traversal kernels must reproduce the default configuration bit for bit."""
+    """A shadow-ray queue that is too small (vertices traced inside accumulate instead), the 16- / 24-entry stack
+    instantiations of the traversal kernels, and any number of concurrent pipelines (bands of tile rows on their own
+    streams) must reproduce the default configuration bit for bit."""
     W, H = 320, 180
     view = sio.FView().reset(sponza_small, aspect=W / H)
     sc = gpu_ctx.create_scene(sponza_small)

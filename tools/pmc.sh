@@ -35,12 +35,17 @@ kernels = {}
 for (kn, cn), (v, n) in tot.items():
     if cn in ("FETCH_SIZE", "WRITE_SIZE"):
         kernels.setdefault(kn.split("<")[0], {})[cn + "_KB_per_launch"] = v / n
+    if cn in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):     # VALU issue pressure and lane utilisation
+        kernels.setdefault(kn.split("<")[0], {})[cn + "_per_launch"] = v / n
 for kn, d in kernels.items():
     if "FETCH_SIZE_KB_per_launch" in d and "WRITE_SIZE_KB_per_launch" in d:
         d["hbm_bytes_per_launch"] = int(2 * d["FETCH_SIZE_KB_per_launch"] * 1024 + d["WRITE_SIZE_KB_per_launch"] * 1024)
-json.dump({"kernel_source_hash": bench.kernel_source_hash(), "bench_args": "$*", "kernels": kernels,
+_args = "$*".split()
+_pipes = int(_args[_args.index("--pipelines") + 1]) if "--pipelines" in _args else 2      # bench.py's default
+json.dump({"kernel_source_hash": bench.kernel_source_hash(), "bench_args": "$*", "pipelines": _pipes, "kernels": kernels,
            "source": "tools/pmc.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py $*; bytes = 2 x FETCH_SIZE x 1024 + "
                      "WRITE_SIZE x 1024 (MI355X_MICROARCH.md 'HBM': FETCH_SIZE is in KB and counts 128-B requests as 64 B on gfx950; the factor 2 is "
-                     "calibrated for wide streaming reads, so for 80-B node gathers this is an upper estimate)"},
+                     "calibrated for wide streaming reads, so for 80-B node gathers this is an upper estimate); counter collection serialises the launches, so "
+                     "these are per-launch figures of kernels that have the GPU to themselves, a launch = one pipeline's share of the frame"},
           open("$OUT/hbm_traffic.json", "w"), indent=1)
 PY

@@ -39,19 +39,29 @@ def main():
         ctx.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / a.steps
         rays = pt.read()["stats"].total_rays() / a.steps
+        # per-kernel HIP-event times of the same frames (a second pass: the events serialise the host side a little)
+        ctx.profile_begin()
+        for i in range(a.steps):
+            pt.render(view, 1 + a.warmup + a.steps + i)
+        ctx.synchronize()
+        p = ctx.profile_end()
+        kernels = {k: round(getattr(p, k + "_ms") / a.steps, 4) for k in ("generate", "extend", "shade", "shadow_gen", "shadow", "accumulate")}
         pt.close()
-        return ms, rays
+        return ms, rays, kernels
 
-    full_ms, full_rays = timed(None)
-    shard_ms, shard_rays = [], []
+    full_ms, full_rays, full_kernels = timed(None)
+    shard_ms, shard_rays, shard_kernels = [], [], None
     for r in range(a.shards):
-        ms, rays = timed(A.Shard(8, r, a.shards))
+        ms, rays, kernels = timed(A.Shard(8, r, a.shards))
         shard_ms.append(round(ms, 4)); shard_rays.append(int(rays))
+        if r == 0:
+            shard_kernels = kernels
     out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps,
            "full_frame_ms": round(full_ms, 4), "full_frame_rays": int(full_rays), "shard_ms": shard_ms, "shard_rays": shard_rays,
            "max_shard_ms": max(shard_ms), "sum_shard_ms": round(sum(shard_ms), 4),
            "projected_speedup_compute_only": round(full_ms / max(shard_ms), 3),
            "shard_overhead_vs_full": round(sum(shard_ms) / full_ms, 4),
+           "kernel_ms_full_frame": full_kernels, "kernel_ms_shard0": shard_kernels,
            "note": "one GPU, shards rendered sequentially; excludes the RCCL all_gather (33 MB per gathered 4K frame, once per --spp-per-gather samples)"}
     line = json.dumps(out)
     print(line, flush=True)

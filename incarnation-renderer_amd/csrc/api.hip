@@ -204,6 +204,20 @@ static int upload_bvh(incr_scene* sc) {
     return upload_light_grid(sc, nullptr);
 }
 
+// pt_params.h FastDiv: magic number and shift for exact division of any 32-bit numerator by d >= 2 (d == 1 is passed through)
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f = {d, 0u, 0u};
+    if (d <= 1u) return f;
+    const uint32_t fl = 31u - (uint32_t)__builtin_clz(d);
+    if ((d & (d - 1u)) == 0u) { f.more = fl - 1u; return f; }              // power of two: ((n - 0) >> 1) >> (log2 d - 1)
+    const uint64_t num = 1ull << (32u + fl);
+    uint32_t m = (uint32_t)(num / d); const uint32_t rem = (uint32_t)(num - (uint64_t)m * d);
+    m += m; const uint32_t twice = rem + rem;
+    if (twice >= d || twice < rem) m += 1u;
+    f.magic = m + 1u; f.more = fl;
+    return f;
+}
+
 static void upload_grid_params(const incr_scene* sc, PtParams& P) {
     for (int a = 0; a < 3; ++a) { P.gridLo[a] = sc->grid.lo[a]; P.gridInvCell[a] = sc->grid.invCell[a]; P.gridDim[a] = sc->grid.dim[a]; }
     P.gridCellOffsets = sc->dGridOffsets; P.gridCellLights = sc->dGridLights;
@@ -523,6 +537,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.W = d->res_x; P.H = d->res_y; P.numPixels = d->res_x * d->res_y;
     P.sampleIdx = d->current_sample_index;
     P.sqrtSampleCount = (uint32_t)std::sqrt((double)d->max_sample_count);             // :207
+    P.divW = make_fastdiv(P.W); P.divSqrtN = make_fastdiv(P.sqrtSampleCount); P.divN = make_fastdiv(P.sqrtSampleCount * P.sqrtSampleCount);
     P.aperture = d->camera_aperture; P.focalLength = d->camera_focal_length; P.skyBrightness = d->sky_brightness;
     P.directLighting = d->direct_lighting; P.viewmode = d->viewmode;
     perez_from_turbidity(d->turbidity, &P.perez);

@@ -18,8 +18,9 @@ DI f3 sample2d_bilinear_wrap(const uint32_t* __restrict__ img, uint32_t W, uint3
     if (!(v >= 0.f && v <= 1.f)) v = 0.f;
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const int x0 = (((int)x0f % (int)W) + (int)W) % (int)W, y0 = (((int)y0f % (int)H) + (int)H) % (int)H;
-    const int x1 = (x0 + 1) % (int)W, y1 = (y0 + 1) % (int)H;
+    int x0 = (int)x0f, y0 = (int)y0f;                      // u, v in [0, 1] => floor in [-1, W - 1]: wrap without integer division
+    x0 = x0 < 0 ? x0 + (int)W : x0; y0 = y0 < 0 ? y0 + (int)H : y0;
+    const int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
     const f3 t00 = unpack_r11g11b10(img[(size_t)y0 * W + x0]), t10 = unpack_r11g11b10(img[(size_t)y0 * W + x1]);
     const f3 t01 = unpack_r11g11b10(img[(size_t)y1 * W + x0]), t11 = unpack_r11g11b10(img[(size_t)y1 * W + x1]);
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;

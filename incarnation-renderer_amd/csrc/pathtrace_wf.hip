@@ -216,8 +216,8 @@ __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P,
                 pid = ly * P.W + px;
                 const uint32_t pixelIdx = (uint32_t)gy * P.W + px;
                 uint32_t raygenSampleSetIdx = 0;      // rgsMain -- pathtracing.hlsl:89-119
-                const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
-                const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.sqrtSampleCount, P.numPixels);
+                const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
+                const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
                 const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
                 rayO = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pid));
                 rayD = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
         if (i < count) {
             const float4 ro = extIn[(size_t)i * 2], rd = extIn[(size_t)i * 2 + 1];
             pid = __float_as_uint(ro.w);
-            const uint32_t px = pid % P.W, ly = pid / P.W;
+            const uint32_t ly = fast_div(pid, P.divW), px = pid - ly * P.W;
             const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px;
             const uint4 h = B.hit[i];
             const float4 c4 = stIn[(size_t)i * 2], a4 = stIn[(size_t)i * 2 + 1];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     // wf_shadow_gen_kernel with one lane per (vertex, light) pair: inside this kernel the loop ran to the longest light list
                     // of the wave at 3 waves per SIMD and cost 2.6 of its 6.7 ms per frame)
                     // sky sample :239-244
-                    const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.sqrtSampleCount, P.numPixels);
+                    const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.divSqrtN, P.divN, P.numPixels);
                     const f3 skyDir = CosineSampleHemisphere(us);
                     const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
                     const float skyNoL = saturate(dot(N, skyDir));
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
                     if (pathLength < 4) {
                         uint32_t setCopy = sampleSetIndex;
-                        f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.sqrtSampleCount, P.numPixels);
+                        f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.divSqrtN, P.divN, P.numPixels);
                         f3 L, H;
                         const float t = 0.5f;
                         if (u.x < t) {
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
         }
-        if (flags & kFlagTerminate) store_pixel(P, pid % P.W, pid / P.W, color);
+        if (flags & kFlagTerminate) { const uint32_t ly = fast_div(pid, P.divW); store_pixel(P, pid - ly * P.W, ly, color); }
         else stOut[(size_t)nextSlot * 2] = make_float4(color.x, color.y, color.z, color.w);
     }
 }

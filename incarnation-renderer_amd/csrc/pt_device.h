@@ -64,8 +64,17 @@ DI f4 mul_vec4(f4 v, const float* M) {
     return r;
 }
 
+DI uint32_t fast_div(uint32_t n, const FastDiv& f) {
+    if (f.d == 1u) return n;                                  // wave-uniform
+    const uint32_t q = __umulhi(f.magic, n);
+    return (((n - q) >> 1) + q) >> f.more;
+}
+DI uint32_t fast_mod(uint32_t n, const FastDiv& f) { return n - fast_div(n, f) * f.d; }
+
 // ---------------------------------------------------------------- CMJ sampler (uniform-sampling.hlsli:152-201)
-DI uint32_t CMJ_Permute(uint32_t i, uint32_t l, uint32_t p) {
+// (the divisions by the launch constants nx = ny and N = nx * ny go through FastDiv: same integers)
+DI uint32_t CMJ_Permute(uint32_t i, const FastDiv& dl, uint32_t p) {
+    const uint32_t l = dl.d;
     uint32_t w = l - 1;
     w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
     do {
@@ -82,7 +91,7 @@ DI uint32_t CMJ_Permute(uint32_t i, uint32_t l, uint32_t p) {
         i &= w;
         i ^= i >> 5;
     } while (i >= l);
-    return (i + p) % l;
+    return fast_mod(i + p, dl);
 }
 DI float CMJ_RandFloat(uint32_t i, uint32_t p) {
     i ^= p;
@@ -94,20 +103,21 @@ DI float CMJ_RandFloat(uint32_t i, uint32_t p) {
     i ^= i >> 17; i *= 1 | p >> 18;
     return (float)i * (1.0f / 4294967808.0f);
 }
-DI f2 CorrelatedMultiJitteredSampling(uint32_t sampleIdx, uint32_t nx, uint32_t ny, uint32_t pattern) {
-    uint32_t N = nx * ny;
-    sampleIdx = CMJ_Permute(sampleIdx, N, pattern * 0x51633e2d);
-    uint32_t sx = CMJ_Permute(sampleIdx % nx, nx, pattern * 0x68bc21eb);
-    uint32_t sy = CMJ_Permute(sampleIdx / nx, ny, pattern * 0x02e5be93);
+DI f2 CorrelatedMultiJitteredSampling(uint32_t sampleIdx, const FastDiv& dn, const FastDiv& dN, uint32_t pattern) {      // nx == ny == dn.d, N == dN.d
+    const uint32_t nx = dn.d, ny = dn.d, N = dN.d;
+    sampleIdx = CMJ_Permute(sampleIdx, dN, pattern * 0x51633e2d);
+    const uint32_t row = fast_div(sampleIdx, dn);
+    uint32_t sx = CMJ_Permute(sampleIdx - row * nx, dn, pattern * 0x68bc21eb);
+    uint32_t sy = CMJ_Permute(row, dn, pattern * 0x02e5be93);
     float jx = CMJ_RandFloat(sampleIdx, pattern * 0x967a889b);
     float jy = CMJ_RandFloat(sampleIdx, pattern * 0x368cc8b7);
     return {((float)sx + ((float)sy + jx) / (float)ny) / (float)nx, ((float)sampleIdx + jy) / (float)N};
 }
 // raytracing/common.hlsli:8-14
-DI f2 SamplePoint(uint32_t pixelIdx, uint32_t sampleIdx, uint32_t& setIdx, uint32_t sqrtSampleCount, uint32_t numPixels) {
+DI f2 SamplePoint(uint32_t pixelIdx, uint32_t sampleIdx, uint32_t& setIdx, const FastDiv& divSqrtN, const FastDiv& divN, uint32_t numPixels) {
     const uint32_t permutationIdx = setIdx * numPixels + pixelIdx;
     setIdx += 1;
-    return CorrelatedMultiJitteredSampling(sampleIdx, sqrtSampleCount, sqrtSampleCount, permutationIdx);
+    return CorrelatedMultiJitteredSampling(sampleIdx, divSqrtN, divN, permutationIdx);
 }
 
 #define K_PI 3.14159265358979323846f
@@ -281,8 +291,11 @@ DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgb
     float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
-    int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
-    int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+    // wrap: fu, fv are in [0, 1], so floor(x) is in [-1, W - 1] -- two compares instead of four integer divisions by a run-time W
+    // (~40 VALU instructions each; this function runs 3-10 times per shaded hit / G-buffer pixel)
+    int x0 = (int)x0f, y0 = (int)y0f;
+    x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+    const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     const uint32_t* __restrict__ px = (const uint32_t*)t.texels + off;
     const uint32_t c00 = px[texel_tile_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W)], c10 = px[texel_tile_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W)];
     const uint32_t c01 = px[texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W)], c11 = px[texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W)];
@@ -382,8 +395,9 @@ DI Level0Tap level0_tap(const DeviceTexture& t, f2 uv) {
     const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
     const float x0f = floorf(x), y0f = floorf(y);
     a.fx = x - x0f; a.fy = y - y0f;
-    const int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
-    const int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+    int x0 = (int)x0f, y0 = (int)y0f;                      // wrap without integer division, as in SampleBilinearLevel
+    x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+    const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     a.px = (const uint32_t*)t.texels; a.format = t.format; a.W = W;
     a.i00 = (int)texel_tile_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W); a.i10 = (int)texel_tile_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W);
     a.i01 = (int)texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W); a.i11 = (int)texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W);

@@ -9,6 +9,12 @@ namespace incr {
 // per-frame Preetham sun terms (host computed): sun direction, Yxy at the zenith, Perez F(0, thetaS)
 struct SkySun { float s[3]; float YxyZenith[3]; float F0[3]; float pad[3]; };
 
+// Exact unsigned division by a launch constant in 4 instructions (Granlund & Montgomery 1994, the add-shift form that covers every
+// 32-bit numerator; generated on the host by make_fastdiv in api.hip): q = mulhi(magic, n); ((n - q) >> 1) + q >> more.
+// The compiler does not specialise `n / P.W` or the sampler's `% N` for a uniform divisor: it emits the ~35-instruction
+// per-lane sequence, a dozen times per shaded hit.
+struct FastDiv { uint32_t d, magic, more; };
+
 struct PtParams {
     const BvhNode8* __restrict__ nodes;
     const TriIsect* __restrict__ tris;
@@ -27,6 +33,7 @@ struct PtParams {
     float projectionToWorld[16];
     float cameraMatrix[16];
     uint32_t W, H, numPixels, sampleIdx, sqrtSampleCount;
+    FastDiv divW, divSqrtN, divN;                  // by W, sqrtSampleCount and sqrtSampleCount^2
     float aperture, focalLength, skyBrightness;
     int32_t directLighting, viewmode;
     incr_perez_distribution perez;

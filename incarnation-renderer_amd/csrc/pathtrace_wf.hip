@@ -52,12 +52,12 @@ static constexpr int kWfBlock = 256;
 #define INCR_ACCUM_WAVES 4
 #endif
 // LDS stack entries per lane in the traversal kernels: a template parameter, the launcher picks the smallest of
-// 8 / 12 / 16 / 24 that holds the scene's tree (one entry per level, pt_traverse.h): Sponza-stat (9 levels) takes 8,
-// Bistro-scale (10 levels) 12.
+// 8 / 10 / 12 / 16 / 24 that holds the scene's tree (one entry per level below the root, pt_traverse.h): Sponza-stat and
+// Bistro-scale (10 levels with the SAH-optimal collapse) take 10.
 template <int N> using WfStack = LaneStackT<N, kWfBlock, false, true>;        // any-hit (shadow) traversal
 template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         // closest-hit traversal: keyed, drops groups beyond the best hit
 // Hottest nodes kept in LDS per workgroup (80 B each), sized so that stack + copy still give the kernels' workgroups per CU
-// out of 160 KB: extend 7 / 6 / 4 / 3 workgroups, shadow 8 / 8 / 8 / 6 at N = 8 / 12 / 16 / 24.
+// out of 160 KB: extend 7 / 6 / 6 / 4 / 3 workgroups, shadow 8 / 8 / 8 / 8 / 6 at N = 8 / 10 / 12 / 16 / 24.
 #ifndef INCR_EXTEND_TOP
 #define INCR_EXTEND_TOP 80
 #endif
@@ -67,8 +67,14 @@ template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         /
 #ifndef INCR_SHADOW_WAVES
 #define INCR_SHADOW_WAVES 8
 #endif
-template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? (uint32_t)INCR_EXTEND_TOP : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u));
-                                   static constexpr uint32_t kShadow = N <= 8 ? (uint32_t)INCR_SHADOW_TOP : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u)); };
+#ifndef INCR_EXTEND_TOP10
+#define INCR_EXTEND_TOP10 24
+#endif
+#ifndef INCR_SHADOW_TOP10
+#define INCR_SHADOW_TOP10 120
+#endif
+template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? (uint32_t)INCR_EXTEND_TOP : (N <= 10 ? (uint32_t)INCR_EXTEND_TOP10 : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u)));
+                                   static constexpr uint32_t kShadow = N <= 8 ? (uint32_t)INCR_SHADOW_TOP : (N <= 10 ? (uint32_t)INCR_SHADOW_TOP10 : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u))); };
 DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) {
     const uint32_t count = min(capacity, P.numNodes);
     for (uint32_t i = threadIdx.x; i < count * 5u; i += kWfBlock) s_top[i] = ((const float4*)P.nodes)[i];
@@ -776,10 +782,10 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
     if (tileRow[numPipes] == 0) return hipSuccess;
     if (stackEntries > 24u) return hipErrorInvalidValue;
-    const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24));
+    const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 10u ? 10 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24)));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv == 8 ? (uint32_t)INCR_SHADOW_WAVES : (sv <= 16 ? 8u : 6u);
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv == 8 ? (uint32_t)INCR_SHADOW_WAVES : (sv <= 16 ? 8u : 6u);
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
     uint32_t total[8], blocksAll[8], blocksExtend[8];
     for (int i = 0; i < numPipes; ++i) {
@@ -806,7 +812,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+            if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 1);
         }
@@ -815,7 +821,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
             hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 2);
-            if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
+            if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
             mark(i, slot + 3);
             hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);
         }

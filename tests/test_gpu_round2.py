@@ -328,7 +328,7 @@ def test_update_bvh_bistro_scale_cost(gpu_ctx, rt, R, sio, synth):
 
 
 # ------------------------------------------------------------------------------------------------ overflow mechanisms
-@pytest.mark.parametrize("env", [{"INCR_WF_RAYS_PER_PATH": "1"}, {"INCR_WF_RAYS_PER_PATH": "0"}, {"INCR_WF_STACK_ENTRIES": "12"}, {"INCR_WF_STACK_ENTRIES": "16"}, {"INCR_WF_STACK_ENTRIES": "24"},
+@pytest.mark.parametrize("env", [{"INCR_WF_RAYS_PER_PATH": "1"}, {"INCR_WF_RAYS_PER_PATH": "0"}, {"INCR_WF_STACK_ENTRIES": "10"}, {"INCR_WF_STACK_ENTRIES": "12"}, {"INCR_WF_STACK_ENTRIES": "16"}, {"INCR_WF_STACK_ENTRIES": "24"},
                                  {"INCR_WF_PIPELINES": "1"}, {"INCR_WF_PIPELINES": "3"}, {"INCR_WF_PIPELINES": "8"}])
 def test_wavefront_overflow_paths_are_bit_identical(gpu_ctx, rt, sio, sponza_small, env):
     """A shadow-ray queue that is too small (vertices traced inside accumulate instead), the 16- / 24-entry stack

@@ -347,6 +347,58 @@ DI f4 SampleGrad(const DeviceTexture* __restrict__ textures, const float* __rest
     return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac};
 }
 
+// SampleGrad(...).w with ONE memory round trip: the addresses of the four texels of both trilinear levels are formed first and the
+// eight loads issued together, where SampleGrad's two SampleBilinearLevel calls sit behind a branch on the LOD fraction.  Same
+// arithmetic for the alpha channel (UNORM alpha: a / 255 for the formats that carry one, 1 otherwise), bit for bit.  For the
+// alpha test of the visibility scan (raster.hip fragment), a per-lane serial loop whose cost is its dependent round trips.
+struct BilinearTap { uint32_t i00, i10, i01, i11; float fx, fy; };
+DI BilinearTap bilinear_tap(int W, int H, size_t off, f2 uv) {
+    float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
+    if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
+    if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
+    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    BilinearTap t; t.fx = x - x0f; t.fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+    const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
+    const uint32_t o = (uint32_t)off;
+    t.i00 = o + texel_tile_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W); t.i10 = o + texel_tile_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W);
+    t.i01 = o + texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W); t.i11 = o + texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W);
+    return t;
+}
+DI float texel_alpha(uint32_t format, uint32_t rgba) {
+    return (format == INCR_TEX_RG_SNORM || format == INCR_TEX_BGRA8_SWIZZLE_RG) ? 1.f : (float)(rgba >> 24) * (1.f / 255.f);
+}
+DI float bilinear_alpha(const BilinearTap& t, uint32_t format, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+    const float wx0 = 1.f - t.fx, wy0 = 1.f - t.fy;
+    return (texel_alpha(format, c00) * wx0 + texel_alpha(format, c10) * t.fx) * wy0 + (texel_alpha(format, c01) * wx0 + texel_alpha(format, c11) * t.fx) * t.fy;
+}
+DI float SampleGradAlpha(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy) {
+    const uint32_t numMips = t.pad[1] ? t.pad[1] : 1u;
+    float lod = texture_lod(t, ddx, ddy);
+    lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
+    const float l0f = floorf(lod);
+    const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
+    const uint32_t l0 = (uint32_t)l0f;
+    const bool two = !(frac == 0.f || l0 + 1u >= numMips);
+    int W = (int)t.width, H = (int)t.height;
+    size_t off = 0;
+    for (uint32_t l = 0; l < l0; ++l) { off += texel_level_words((uint32_t)W, (uint32_t)H); W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
+    const BilinearTap ta = bilinear_tap(W, H, off, uv);
+    // the second level's taps fall back to the first level's when there is no second level to blend with: the loads stay unconditional
+    const size_t off1 = two ? off + texel_level_words((uint32_t)W, (uint32_t)H) : off;
+    const int W1 = two ? (W > 1 ? W >> 1 : 1) : W, H1 = two ? (H > 1 ? H >> 1 : 1) : H;
+    const BilinearTap tb = bilinear_tap(W1, H1, off1, uv);
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t a00 = px[ta.i00], a10 = px[ta.i10], a01 = px[ta.i01], a11 = px[ta.i11];
+    const uint32_t b00 = px[tb.i00], b10 = px[tb.i10], b01 = px[tb.i01], b11 = px[tb.i11];
+    const float a = bilinear_alpha(ta, t.format, a00, a10, a01, a11);
+    if (!two) return a;
+    const float b = bilinear_alpha(tb, t.format, b00, b10, b01, b11);
+    return a + (b - a) * frac;
+}
+
 // material/common.hlsli:10-115
 struct MatProps { f3 emissive, basecolor; float opacity; bool bHasNormalmap; f3 normalmap; float metallic, roughness, ao, aoblend; };
 template <class Sampler> DI MatProps EvaluateMaterialPropertiesT(const incr_material& mat, f2 uv, Sampler sample) {

@@ -48,24 +48,33 @@ DI f3 OctDecode(f2 f) {                                                      // 
     n.x += n.x >= 0.f ? -t : t; n.y += n.y >= 0.f ? -t : t;
     return normalize(n);
 }
-// gbuffer-compute.hlsl:19-46 (rcp = 1/x)
-DI f3 CalcBarycentrics(f4 p0, f4 p1, f4 p2, f2 pixelNdc) {
+// gbuffer-compute.hlsl:19-46 (rcp = 1/x), split into the per-triangle part and the per-pixel part: the same operations in the same
+// order, but a caller that evaluates several pixels of one triangle (the four of a derivative quad, the fragments of a scanned
+// triangle) pays the four divisions of the set-up once.
+struct BarySetup { float invW0; f2 ndc0; f3 ddx, ddy; float ddxSum, ddySum; };
+DI BarySetup bary_setup(f4 p0, f4 p1, f4 p2) {
     const f3 invW = {1.f / p0.w, 1.f / p1.w, 1.f / p2.w};
     const f2 ndc0 = {p0.x * invW.x, p0.y * invW.x}, ndc1 = {p1.x * invW.y, p1.y * invW.y}, ndc2 = {p2.x * invW.z, p2.y * invW.z};
     const f2 a = ndc2 - ndc1, b = ndc0 - ndc1;
     const float invDet = 1.f / (a.x * b.y - a.y * b.x);
-    const f3 ddx = {((ndc1.y - ndc2.y) * invDet) * invW.x, ((ndc2.y - ndc0.y) * invDet) * invW.y, ((ndc0.y - ndc1.y) * invDet) * invW.z};
-    const f3 ddy = {((ndc2.x - ndc1.x) * invDet) * invW.x, ((ndc0.x - ndc2.x) * invDet) * invW.y, ((ndc1.x - ndc0.x) * invDet) * invW.z};
-    const float ddxSum = (ddx.x * 1.f + ddx.y * 1.f) + ddx.z * 1.f, ddySum = (ddy.x * 1.f + ddy.y * 1.f) + ddy.z * 1.f;
-    const f2 dv = pixelNdc - ndc0;
-    const float interpInvW = (invW.x + dv.x * ddxSum) + dv.y * ddySum;
+    BarySetup s;
+    s.invW0 = invW.x; s.ndc0 = ndc0;
+    s.ddx = {((ndc1.y - ndc2.y) * invDet) * invW.x, ((ndc2.y - ndc0.y) * invDet) * invW.y, ((ndc0.y - ndc1.y) * invDet) * invW.z};
+    s.ddy = {((ndc2.x - ndc1.x) * invDet) * invW.x, ((ndc0.x - ndc2.x) * invDet) * invW.y, ((ndc1.x - ndc0.x) * invDet) * invW.z};
+    s.ddxSum = (s.ddx.x * 1.f + s.ddx.y * 1.f) + s.ddx.z * 1.f; s.ddySum = (s.ddy.x * 1.f + s.ddy.y * 1.f) + s.ddy.z * 1.f;
+    return s;
+}
+DI f3 bary_eval(const BarySetup& s, f2 pixelNdc) {
+    const f2 dv = pixelNdc - s.ndc0;
+    const float interpInvW = (s.invW0 + dv.x * s.ddxSum) + dv.y * s.ddySum;
     const float interpW = 1.f / interpInvW;
     f3 l;
-    l.x = interpW * ((invW.x + dv.x * ddx.x) + dv.y * ddy.x);
-    l.y = interpW * ((0.0f + dv.x * ddx.y) + dv.y * ddy.y);
-    l.z = interpW * ((0.0f + dv.x * ddx.z) + dv.y * ddy.z);
+    l.x = interpW * ((s.invW0 + dv.x * s.ddx.x) + dv.y * s.ddy.x);
+    l.y = interpW * ((0.0f + dv.x * s.ddx.y) + dv.y * s.ddy.y);
+    l.z = interpW * ((0.0f + dv.x * s.ddx.z) + dv.y * s.ddy.z);
     return l;
 }
+DI f3 CalcBarycentrics(f4 p0, f4 p1, f4 p2, f2 pixelNdc) { return bary_eval(bary_setup(p0, p1, p2), pixelNdc); }
 DI f2 pixel_ndc(uint32_t px, uint32_t py, float W, float H) {
     f2 n = {((float)px + 0.5f) / W, ((float)py + 0.5f) / H};
     n.x = 2.f * n.x - 1.f; n.y = -2.f * n.y + 1.f;
@@ -76,12 +85,15 @@ DI f2 interp2(f2 a, f2 b, f2 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * 
 // quad's top-left pixel), with all three UVs evaluated on THIS pixel's triangle -- the pixel's own plane extrapolated to its quad
 // neighbours, so the value does not depend on what the neighbouring lanes hold (texture unit).
 struct UvGrad { f2 ddx, ddy; };
-DI UvGrad quad_uv_gradient(f4 p0, f4 p1, f4 p2, f2 uv0, f2 uv1, f2 uv2, uint32_t x, uint32_t y, float W, float H) {
+DI UvGrad quad_uv_gradient(const BarySetup& bs, f2 uv0, f2 uv1, f2 uv2, uint32_t x, uint32_t y, float W, float H) {
     const uint32_t x0 = x & ~1u, y0 = y & ~1u;
-    const f2 a = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0, W, H)));
-    const f2 b = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0 + 1u, y0, W, H)));
-    const f2 c = interp2(uv0, uv1, uv2, CalcBarycentrics(p0, p1, p2, pixel_ndc(x0, y0 + 1u, W, H)));
+    const f2 a = interp2(uv0, uv1, uv2, bary_eval(bs, pixel_ndc(x0, y0, W, H)));
+    const f2 b = interp2(uv0, uv1, uv2, bary_eval(bs, pixel_ndc(x0 + 1u, y0, W, H)));
+    const f2 c = interp2(uv0, uv1, uv2, bary_eval(bs, pixel_ndc(x0, y0 + 1u, W, H)));
     return {b - a, c - a};
+}
+DI UvGrad quad_uv_gradient(f4 p0, f4 p1, f4 p2, f2 uv0, f2 uv1, f2 uv2, uint32_t x, uint32_t y, float W, float H) {
+    return quad_uv_gradient(bary_setup(p0, p1, p2), uv0, uv1, uv2, x, y, W, H);
 }
 DI f3 interp3(f3 a, f3 b, f3 c, f3 w) { return {(w.x * a.x + w.y * b.x) + w.z * c.x, (w.x * a.y + w.y * b.y) + w.z * c.y, (w.x * a.z + w.y * b.z) + w.z * c.z}; }
 DI f3 mul_vec3_m3(f3 v, f3 r0, f3 r1, f3 r2) { return {(v.x * r0.x + v.y * r1.x) + v.z * r2.x, (v.x * r0.y + v.y * r1.y) + v.z * r2.y, (v.x * r0.z + v.y * r1.z) + v.z * r2.z}; }
@@ -253,7 +265,8 @@ struct SubTri {
     float z0, dz1, dz2;
     uint32_t key;
     int32_t alphaTex;                    // base-colour texture to alpha-test against, -1 = none
-    f4 p0, p1, p2;                       // clip-space vertices of the ORIGINAL triangle (interpolant set-up)
+    BarySetup bs;                        // interpolant set-up of the ORIGINAL triangle's clip-space vertices (alpha-tested triangles only)
+    DeviceTexture tex;                   // descriptor of alphaTex, fetched once per triangle
     f2 uv0, uv1, uv2;
 };
 DI bool top_left(int32_t dx, int32_t dy) { return (dy == 0 && dx > 0) || dy < 0; }
@@ -294,12 +307,15 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
     const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(st.key + 1u);
     unsigned long long* dst = P.packed + (size_t)py * P.W + px;
     if (st.alphaTex >= 0) {                                        // ps_meshlet_main: clip(opacity - 0.5)
-        // values only grow: a fragment that loses now loses for good -- worth a load before the texture sample.  Opaque
-        // fragments skip the check: the atomic is fire-and-forget, a load would put a memory round trip into every step.
+        // values only grow: a fragment that loses now loses for good -- worth a load before the texture sample (fetching the surface
+        // word and the texels together was measured: +0.16 ms per frame, most alpha fragments lose here).  Opaque fragments skip
+        // the check: the atomic is fire-and-forget, a load would put a memory round trip into every step.
         if (v <= __atomic_load_n(dst, __ATOMIC_RELAXED)) return;
-        const f3 lam = CalcBarycentrics(st.p0, st.p1, st.p2, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
-        const UvGrad g = quad_uv_gradient(st.p0, st.p1, st.p2, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
-        const float opacity = SampleGrad(P.S.textures, P.S.srgbLut, st.alphaTex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy).w;
+        // per-lane serial loop: its cost is its dependent round trips -- the descriptor came with the triangle, the texels of both
+        // trilinear levels are fetched together
+        const f3 lam = bary_eval(st.bs, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
+        const UvGrad g = quad_uv_gradient(st.bs, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
+        const float opacity = SampleGradAlpha(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy);
         if (opacity - 0.5f < 0.f) return;
     }
     atomicMax(dst, v);
@@ -343,8 +359,9 @@ DI void raster_coop(const VisParams& P, const SubTri& st, uint32_t lane) {
 // The result does not depend on the order: depth test and id write are one atomicMax on depth | order key.
 DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriAlpha a = P.alphas[idx];
-    st->p0 = {a.p[0], a.p[1], a.p[2], a.p[3]}; st->p1 = {a.p[4], a.p[5], a.p[6], a.p[7]}; st->p2 = {a.p[8], a.p[9], a.p[10], a.p[11]};
+    st->bs = bary_setup({a.p[0], a.p[1], a.p[2], a.p[3]}, {a.p[4], a.p[5], a.p[6], a.p[7]}, {a.p[8], a.p[9], a.p[10], a.p[11]});
     st->uv0 = {a.uv[0], a.uv[1]}; st->uv1 = {a.uv[2], a.uv[3]}; st->uv2 = {a.uv[4], a.uv[5]};
+    st->tex = P.S.textures[st->alphaTex];
 }
 DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriRec r = P.recs[idx];
@@ -630,12 +647,13 @@ __global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
             if (k == 0) tanW0 = tg.w;
         }
     }
-    const f3 lam = CalcBarycentrics(p[0], p[1], p[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
+    const BarySetup bs = bary_setup(p[0], p[1], p[2]);
+    const f3 lam = bary_eval(bs, pixel_ndc(x, y, (float)P.W, (float)P.H));
     f3 N = normalize(interp3(nrm[0], nrm[1], nrm[2], lam));
     const f3 T = normalize(interp3(tan[0], tan[1], tan[2], lam));
     const f3 B = normalize(cross(N, T) * tanW0);
     const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
-    const UvGrad gr = quad_uv_gradient(p[0], p[1], p[2], uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
+    const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
     const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
     if (mi.bHasNormalmap) {
         const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)meshIndex * 16;
@@ -941,10 +959,11 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
                 const f4 c = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, l2w);
                 nW[k] = {a.x, a.y, a.z}; tW[k] = {b.x, b.y, b.z}; bW[k] = {c.x, c.y, c.z};
             }
-            const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(x, y, (float)P.W, (float)P.H));
+            const BarySetup bs = bary_setup(clip[0], clip[1], clip[2]);
+            const f3 lam = bary_eval(bs, pixel_ndc(x, y, (float)P.W, (float)P.H));
             const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
             const incr_material mat = P.S.materials[d.materialIndex];
-            const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
+            const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
             const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);
             bool done = true;
             if (P.viewmode == 2) out = mk3(p.roughness);                             // ps_main :95-105 (`#if VIWEMODE == 1` never fires)
@@ -1097,9 +1116,10 @@ DI void decal_fragment(const DecalParams& P, const SubTriRec& r, uint32_t px, ui
         const f4 c = mul_vec4({bitangent.x, bitangent.y, bitangent.z, 0.f}, l2w);
         nW[k] = {a.x, a.y, a.z}; tW[k] = {b.x, b.y, b.z}; bW[k] = {c.x, c.y, c.z};
     }
-    const f3 lam = CalcBarycentrics(clip[0], clip[1], clip[2], pixel_ndc(px, py, (float)P.W, (float)P.H));
+    const BarySetup bs = bary_setup(clip[0], clip[1], clip[2]);
+    const f3 lam = bary_eval(bs, pixel_ndc(px, py, (float)P.W, (float)P.H));
     const incr_material mat = P.S.materials[d.materialIndex];
-    const UvGrad gr = quad_uv_gradient(clip[0], clip[1], clip[2], uv[0], uv[1], uv[2], px, py, (float)P.W, (float)P.H);
+    const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], px, py, (float)P.W, (float)P.H);
     const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy);
     const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
     f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));

@@ -828,7 +828,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         slot += 5;
     }
     for (int i = 0; i < numPipes; ++i) for (int k = total[i] ? slot : 0; k < 22; ++k) mark(i, k);      // unused slots collapse to zero-length intervals
-    if (!getenv("INCR_WF_NOJOIN")) for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
+    for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);
     return hipGetLastError();
 }

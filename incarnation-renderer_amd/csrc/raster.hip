@@ -793,40 +793,108 @@ extern "C" hipError_t incr_launch_fold_ray_stats(unsigned long long* stripes, in
     return hipGetLastError();
 }
 
-// direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115)
-DI f3 direct_radiance(const DirectParams& P, LaneStack& st, const GBufferPixel& g, uint32_t x, uint32_t y, size_t i, uint32_t& rays) {
+// ---- the sun's shadow rays as a PACKET ---------------------------------------------------------------------------------------
+// The 64 rays of a wave -- an 8 x 8 pixel tile, one direction (the sun), origins on neighbouring surface points -- walk the tree
+// TOGETHER: the wave visits a node when any of its rays overlaps it, so the node index, the stack, the leaf / triangle loop and
+// the 80 + 48-byte fetches are wave-uniform (scalar registers, scalar loads), and every lane tests ITS ray against the eight
+// boxes / the triangle with the whole wave active.  The lane-per-ray loop (pt_traverse.h trace_any) spends most of its vector
+// instructions on lanes that are idle (no ray for a sky or back-facing pixel, a shorter walk than the neighbour's) or on the other
+// kind of step.  Any-hit is order-independent, and a ray tested against a triangle of a leaf only its neighbours overlap gives the
+// same answer as never testing it, so the result equals trace_any's for every ray.  All 64 lanes must call; `wants` marks the
+// lanes that have a ray.  `stack`: kPacketStack words of LDS per wave.
+static constexpr int kPacketStack = 32;      // one entry per tree level (kMaxBvhDepth = 25)
+DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, f3 d, float tmin, float tmax, bool wants) {
+    const RaySetup rs = ray_setup(o, d);
+    bool alive = wants, occluded = false;
+    int sp = 0;
+    uint32_t cur = 0;
+    bool haveCur = true;
+    for (;;) {
+        if (__ballot(alive) == 0ull) break;
+        if (!haveCur) {
+            if (sp == 0) break;
+            uint32_t e = __builtin_amdgcn_readfirstlane(stack[sp - 1]);
+            cur = (e >> 9) + (uint32_t)__builtin_ctz(e & 0xffu);
+            e &= e - 1u;
+            if (e & 0xffu) stack[sp - 1] = e; else --sp;
+        }
+        haveCur = false;
+        const float4* __restrict__ np = (const float4*)P.nodes + (size_t)cur * 5;        // wave-uniform address: scalar loads
+        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        Node8 N;
+        node8_test(n0, n1, n2, n3, n4, rs, tmin, tmax, N);
+        const uint32_t mine = alive ? N.hitMask : 0u;
+        uint32_t any = 0u;                                                                 // children some live ray overlaps
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= (__ballot((mine >> k) & 1u) != 0ull) ? (1u << k) : 0u;
+        const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
+        Node8 U = N; U.hitMask = any; U.imask = imask;
+        U.meta0 = __builtin_amdgcn_readfirstlane(N.meta0); U.meta1 = __builtin_amdgcn_readfirstlane(N.meta1);
+        uint32_t triMask = node8_tri_mask(U);
+        const uint32_t triBase = __builtin_amdgcn_readfirstlane(N.triBase);
+        while (triMask) {
+            const uint32_t ti = triBase + (uint32_t)__builtin_ctz(triMask);
+            triMask &= triMask - 1u;
+            const float4* __restrict__ tp = (const float4*)(P.tris + ti);
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            float t, u, v; uint32_t flat, flags;
+            if (alive && tri_intersect(a, b, c, rs.o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) { occluded = true; alive = false; }
+            if (__ballot(alive) == 0ull) break;
+        }
+        const uint32_t inner = any & imask;
+        if (inner) {
+            const uint32_t rest = inner & (inner - 1u);
+            if (rest) { if (sp < kPacketStack) stack[sp++] = stack_entry(childBase, false, rest); }
+            cur = childBase + (uint32_t)__builtin_ctz(inner);
+            haveCur = true;
+        }
+    }
+    return occluded;
+}
+
+// direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115), in two halves around the shadow
+// query so that the query can be made by the whole wave at once
+struct DirectSetup { LightSample s; f3 worldPos, V; bool wantsRay; };
+DI DirectSetup direct_setup(const DirectParams& P, const GBufferPixel& g, uint32_t x, uint32_t y, size_t i, uint32_t& rays) {
+    DirectSetup ds;
     const f2 sp = screen_pos(x, y, P.L.W, P.L.H);
     const f4 w = mul_vec4({sp.x, -sp.y, P.L.depth[i], 1.f}, P.L.invViewProj);
-    const f3 worldPos = {w.x / w.w, w.y / w.w, w.z / w.w};
+    ds.worldPos = {w.x / w.w, w.y / w.w, w.z / w.w};
     const f3 eye = {P.L.eye[0], P.L.eye[1], P.L.eye[2]};
-    const f3 V = normalize(eye - worldPos);
+    ds.V = normalize(eye - ds.worldPos);
     incr_light light; const float* m; bool haveT;
     load_global_light(P.S, P.sunIndex, light, m, haveT);
-    const LightSample s = light_setup(light, m, haveT, worldPos, g.N);
-    f3 radiance = {0.f, 0.f, 0.f};
-    if (s.needsShadow) {
-        bool lit = true;
-        if (light.type == INCR_LIGHT_DIRECTIONAL) {
-            ++rays;
-            // background pixels unproject to non-finite positions: such a ray hits nothing (every triangle test fails
-            // on NaN/inf), but the box tests cannot reject it and the walk would visit the whole tree
-            const bool finite = isfinite(worldPos.x) && isfinite(worldPos.y) && isfinite(worldPos.z) && isfinite(s.L.x) && isfinite(s.L.y) && isfinite(s.L.z);
-            lit = !finite || !trace_any(P.S, st, worldPos, s.L, 0.1f, 1000.f);
-        }
-        if (lit) radiance = light_shade(s, g.basecolor, g.metallic, g.roughness, g.N, V);
+    ds.s = light_setup(light, m, haveT, ds.worldPos, g.N);
+    ds.wantsRay = false;
+    if (ds.s.needsShadow && light.type == INCR_LIGHT_DIRECTIONAL) {
+        ++rays;
+        // background pixels unproject to non-finite positions: such a ray hits nothing (every triangle test fails
+        // on NaN/inf), but the box tests cannot reject it and the walk would visit the whole tree
+        ds.wantsRay = isfinite(ds.worldPos.x) && isfinite(ds.worldPos.y) && isfinite(ds.worldPos.z) && isfinite(ds.s.L.x) && isfinite(ds.s.L.y) && isfinite(ds.s.L.z);
     }
-    return radiance;
+    return ds;
+}
+DI f3 direct_finish(const DirectSetup& ds, const GBufferPixel& g, bool occluded) {
+    if (!ds.s.needsShadow || occluded) return {0.f, 0.f, 0.f};
+    return light_shade(ds.s, g.basecolor, g.metallic, g.roughness, g.N, ds.V);
+}
+// Pixel of a lane: one 8 x 8 tile per wave (the packet above wants neighbouring origins), four tiles side by side per workgroup
+DI void tile_pixel(uint32_t y0, uint32_t* x, uint32_t* y) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    *x = blockIdx.x * 32u + (tid >> 6) * 8u + (lane & 7u);
+    *y = y0 + blockIdx.y * 8u + (lane >> 3);
 }
 __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectParams P) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = P.L.y0 + blockIdx.y * 4 + (tid >> 6);
+    __shared__ uint32_t s_stack[(kBlock / 64) * kPacketStack];
+    uint32_t x, y; tile_pixel(P.L.y0, &x, &y);
+    const bool valid = x < P.L.W && y < P.L.y1;
+    const size_t i = valid ? (size_t)y * P.L.W + x : 0;
     uint32_t rays = 0;
-    if (x < P.L.W && y < P.L.y1) {
-        LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
-        const size_t i = (size_t)y * P.L.W + x;
-        add_color(P.L, i, direct_radiance(P, st, read_gbuffer(P.L, i), x, y, i, rays));
-    }
+    GBufferPixel g = {};
+    DirectSetup ds = {};
+    if (valid) { g = read_gbuffer(P.L, i); ds = direct_setup(P, g, x, y, i, rays); }
+    const bool occluded = trace_any_packet(P.S, s_stack + (threadIdx.x >> 6) * kPacketStack, ds.worldPos, ds.s.L, 0.1f, 1000.f, valid && ds.wantsRay);
+    if (valid) add_color(P.L, i, direct_finish(ds, g, occluded));
     count_rays(P.S, rays);
 }
 
@@ -1242,20 +1310,26 @@ __global__ __launch_bounds__(256) void clustered_lighting_kernel(const Clustered
 // re-quantised to R11G11B10F between the parts exactly where the chain stores it, so the result is bit-identical to running
 // the three kernels one after the other (tests/test_gpu_raster.py::test_fused_deferred_lighting_equals_the_chain).
 __global__ __launch_bounds__(kBlock) void deferred_lighting_kernel(const FusedLightingParams P) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_stack[(kBlock / 64) * kPacketStack];
     const LightingParams& L = P.haveSky ? P.sky.L : (P.haveDirect ? P.direct.L : P.clustered.L);
-    const uint32_t x = blockIdx.x * 64 + (tid & 63u), y = L.y0 + blockIdx.y * 4 + (tid >> 6);
+    uint32_t x, y; tile_pixel(L.y0, &x, &y);
+    const bool valid = x < L.W && y < L.y1;
+    const size_t i = valid ? (size_t)y * L.W + x : 0;
     uint32_t rays = 0;
-    if (x < L.W && y < L.y1) {
-        const size_t i = (size_t)y * L.W + x;
-        const GBufferPixel g = read_gbuffer(L, i);
-        uint32_t c = L.color[i];
+    GBufferPixel g = {};
+    uint32_t c = 0;
+    if (valid) {
+        g = read_gbuffer(L, i);
+        c = L.color[i];
         if (P.haveSky) c = pack_r11g11b10(unpack_r11g11b10(c) + sky_radiance(P.sky, g, x, y, i), L.rounding);
-        if (P.haveDirect) {
-            LaneStack st; st.bind(s_stack + tid, nullptr); st.sp = 0;
-            c = pack_r11g11b10(unpack_r11g11b10(c) + direct_radiance(P.direct, st, g, x, y, i, rays), L.rounding);
-        }
+    }
+    if (P.haveDirect) {          // uniform: the shadow query is made by the whole wave (trace_any_packet)
+        DirectSetup ds = {};
+        if (valid) ds = direct_setup(P.direct, g, x, y, i, rays);
+        const bool occluded = trace_any_packet(P.direct.S, s_stack + (threadIdx.x >> 6) * kPacketStack, ds.worldPos, ds.s.L, 0.1f, 1000.f, valid && ds.wantsRay);
+        if (valid) c = pack_r11g11b10(unpack_r11g11b10(c) + direct_finish(ds, g, occluded), L.rounding);
+    }
+    if (valid) {
         if (P.haveClustered) {
             if (P.clustered.requiresClear) c = 0;
             c = pack_r11g11b10(unpack_r11g11b10(c) + clustered_radiance(P.clustered, g, x, y, i), L.rounding);
@@ -1409,6 +1483,7 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
 // ---- launchers (called from raster_api.hip) ------------------------------------------------------------
 using namespace incr;
 static inline dim3 pixel_grid(uint32_t W, uint32_t y0, uint32_t y1) { return dim3((W + 63) / 64, (y1 - y0 + 3) / 4); }
+static inline dim3 tile_grid(uint32_t W, uint32_t y0, uint32_t y1) { return dim3((W + 31) / 32, (y1 - y0 + 7) / 8); }      // tile_pixel: 4 tiles of 8 x 8 per workgroup
 
 extern "C" hipError_t incr_launch_mesh_frames(const RasterScene* S, const ViewFrame* vf, MeshFrame* out, hipStream_t stream) {
     if (!S->numMeshes) return hipSuccess;
@@ -1465,7 +1540,7 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
 }
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
-    hipLaunchKernelGGL(direct_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(kBlock), 0, stream, *p);
+    hipLaunchKernelGGL(direct_lighting_kernel, tile_grid(p->L.W, p->L.y0, p->L.y1), dim3(kBlock), 0, stream, *p);
     if (p->S.stats && p->S.statStripes) hipLaunchKernelGGL(fold_ray_stats_kernel, dim3(1), dim3(64), 0, stream, p->S.statStripes, p->S.stats);
     return hipGetLastError();
 }
@@ -1497,7 +1572,7 @@ extern "C" hipError_t incr_launch_clustered_lighting(const ClusteredParams* p, h
 extern "C" hipError_t incr_launch_deferred_lighting(const FusedLightingParams* p, hipStream_t stream) {
     const LightingParams& L = p->haveSky ? p->sky.L : (p->haveDirect ? p->direct.L : p->clustered.L);
     if (!L.W || L.y1 <= L.y0) return hipSuccess;
-    hipLaunchKernelGGL(deferred_lighting_kernel, pixel_grid(L.W, L.y0, L.y1), dim3(kBlock), 0, stream, *p);
+    hipLaunchKernelGGL(deferred_lighting_kernel, tile_grid(L.W, L.y0, L.y1), dim3(kBlock), 0, stream, *p);
     if (p->haveDirect && p->direct.S.stats && p->direct.S.statStripes) (void)incr_launch_fold_ray_stats(p->direct.S.statStripes, p->direct.S.stats, stream);
     return hipGetLastError();
 }

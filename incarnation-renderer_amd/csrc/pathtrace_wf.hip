@@ -312,6 +312,98 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     add_counters(P, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------ extend, camera rays
+// Bounce 0 only.  The 64 camera rays of a wave are an 8 x 8 pixel tile (wf_generate_kernel) -- lens samples 0.01 apart, directions
+// a pixel apart -- so they walk the tree as ONE PACKET: node index, stack, leaf and triangle loops and the 80 / 48-byte fetches are
+// wave-uniform (scalar registers and scalar loads), and every lane tests ITS ray against the eight boxes / the triangle, with all
+// lanes useful.  The lane-per-ray state machine above spends two thirds of its vector instructions on lanes that are idle or on
+// the other kind of step (34 % VALU lane utilisation) -- the price of incoherent rays, which camera rays are not.
+// Same result as wf_extend_kernel ray by ray: a lane's closest hit is the minimum over the triangles it tests under the
+// (t, flattened id) order, the packet tests a superset of the triangles the lane's own walk would reach, and a triangle outside the
+// boxes a ray overlaps cannot be hit by it.  Children are taken in the first live lane's near-to-far order; a node is entered when
+// any live ray overlaps it closer than that ray's best hit.
+static constexpr int kPacketStack = 32;              // one entry per tree level (kMaxBvhDepth = 25)
+__global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtParams P, const WfBuffers B) {
+    __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
+    uint32_t* stack = s_stack + (threadIdx.x >> 6) * kPacketStack;
+    const uint32_t total = B.counters[0];
+    const uint32_t slot = blockIdx.x * kWfBlock + threadIdx.x;
+    const bool have = slot < total;
+    f3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
+    if (have) { const float4 ro = B.extA[(size_t)slot * 2], rd = B.extA[(size_t)slot * 2 + 1]; o = {ro.x, ro.y, ro.z}; d = {rd.x, rd.y, rd.z}; }
+    const RaySetup rs = ray_setup(o, d);
+    const float tmin = 0.001f;                                      // TMin / TMax of TraceRay (common.hlsli:49-50)
+    float best = 10000.0f, bu = 0.f, bv = 0.f; uint32_t bestFlat = 0xffffffffu, bestTri = 0; bool found = false;
+    const uint32_t negDir = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+    const unsigned long long haveMask = __ballot(have);
+    if (haveMask != 0ull) {
+        const uint32_t lead = (uint32_t)__builtin_ctzll(haveMask);                       // the lane whose ray orders the children
+        const uint32_t leadNeg = (uint32_t)__builtin_amdgcn_readlane((int)negDir, (int)lead);
+        int sp = 0;
+        uint32_t cur = 0; bool haveCur = true;
+        for (;;) {
+            if (!haveCur) {
+                if (sp == 0) break;
+                uint32_t e = __builtin_amdgcn_readfirstlane(stack[sp - 1]);
+                const uint32_t m = e & 0xffu;
+                const uint32_t k = (e & 0x100u) ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+                cur = (e >> 9) + k;
+                e &= ~(1u << k);
+                if (e & 0xffu) stack[sp - 1] = e; else --sp;
+            }
+            haveCur = false;
+            const float4* __restrict__ np = (const float4*)P.nodes + (size_t)cur * 5;      // wave-uniform address: scalar loads
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+            Node8 N;
+            node8_test(n0, n1, n2, n3, n4, rs, tmin, best, N);                               // per lane: its ray, its best hit so far
+            const uint32_t mine = have ? N.hitMask : 0u;
+            uint32_t any = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) any |= (__ballot((mine >> k) & 1u) != 0ull) ? (1u << k) : 0u;
+            const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
+            Node8 U = N; U.hitMask = any; U.imask = imask;
+            U.meta0 = __builtin_amdgcn_readfirstlane(N.meta0); U.meta1 = __builtin_amdgcn_readfirstlane(N.meta1);
+            uint32_t triMask = node8_tri_mask(U);
+            const uint32_t triBase = __builtin_amdgcn_readfirstlane(N.triBase);
+            while (triMask) {
+                const uint32_t ti = triBase + (uint32_t)__builtin_ctz(triMask);
+                triMask &= triMask - 1u;
+                const float4* __restrict__ tp = (const float4*)(P.tris + ti);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v; uint32_t flat, flags;
+                if (have && tri_intersect(a, b, c, rs.o, d, tmin, 10000.0f, &t, &u, &v, &flat, &flags)) {
+                    const bool better = found ? (t < best || (t == best && flat < bestFlat)) : (t < best);      // as trav_closest_step
+                    if (better) {
+                        if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
+                        if ((flags & kTriOpaque) || any_hit_accepts(P, ti, u, v)) { found = true; best = t; bestFlat = flat; bestTri = ti; bu = u; bv = v; }
+                    }
+                }
+            }
+            const uint32_t inner = any & imask;
+            if (inner) {
+                // the lead lane's nearest overlapped child first (if it overlaps none, the first in slot order); the others wait as
+                // one group that leaves in slot order from the lead ray's side (device_types.h SLOT ORDER)
+                uint32_t nearK = (uint32_t)__builtin_ctz(inner); float nearT = __uint_as_float(0x7f800000u);
+                const uint32_t leadHit = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)lead) & imask;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float tk = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(N.tn[k]), (int)lead));
+                    if (((leadHit >> k) & 1u) && tk < nearT) { nearT = tk; nearK = (uint32_t)k; }
+                }
+                const uint32_t rest = inner & ~(1u << nearK);
+                if (rest) {
+                    const uint32_t axis = U.meta0 & 3u;
+                    if (sp < kPacketStack) stack[sp++] = stack_entry(childBase, (leadNeg >> axis) & 1u, rest);
+                }
+                cur = childBase + nearK; haveCur = true;
+            }
+        }
+    }
+    if (have) B.hit[slot] = found ? make_uint4(bestTri, __float_as_uint(best), __float_as_uint(bu), __float_as_uint(bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
+    Counters cnt = {have ? 1u : 0u, 0, 0, 0, 0};
+    add_counters(P, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ shade
 __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
@@ -799,6 +891,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         (void)hipEventRecord(fork, streams[0]);
         for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
     }
+    static const bool packetPrimary = !(getenv("INCR_WF_PACKET_PRIMARY") && atoi(getenv("INCR_WF_PACKET_PRIMARY")) == 0);      // A/B hook
     auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
@@ -812,7 +905,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+            if (bounce == 0 && packetPrimary) hipLaunchKernelGGL(wf_extend_packet_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b);
+            else if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 1);
         }

@@ -6,6 +6,11 @@
  * frame is enqueued on that one stream in call order -- the reference's execution order
  * (render-jobs/job-sync.h:27-61: token-ordered submission on one DIRECT queue).
  *
+ * ONE FRAME IN FLIGHT PER CONTEXT: the path-state workspace of incr_pathtrace and the queues / depth surface of
+ * incr_visibility are owned by the context, not by the stream.  All calls of a context must be ordered on one stream (or
+ * ordered against each other by the caller); two frames of one context on two streams at the same time overwrite each
+ * other's state.  Use one context per concurrent frame.  (The reference has one DIRECT queue and the same property.)
+ *
  * Error convention: every function returns 0 on success, a negative incr_status otherwise, and never
  * aborts or throws (the reference has no error returns: inc/common.h:113-148).  incr_last_error() gives
  * the message for the calling thread.  There is NO CPU fallback: without a HIP device every launch
@@ -87,8 +92,8 @@ typedef struct incr_shard {
 uint32_t incr_shard_local_rows(uint32_t res_y, const incr_shard* shard);
 
 /* Ray statistics (SURVEY.md 8d "Ray count"): every traversal query, by category.  The kernels count into striped counters owned
- * by the context and fold them into the caller's struct at the end of the call; two calls of ONE context running at the same time
- * on different streams may therefore see each other's counts (the sum over both structs stays exact). */
+ * by the context and fold them into the caller's struct at the end of the call (one frame in flight per context, see the top of
+ * this file). */
 typedef struct incr_ray_stats {
     uint64_t camera_rays;       /* TraceRay from rgsMain                      (pathtracing.hlsl:117) */
     uint64_t bounce_rays;       /* TraceRay from chsMain                      (pathtracing.hlsl:265) */

@@ -1,29 +1,30 @@
 // pathtrace_wf.hip -- the production path tracer: a WAVEFRONT (multi-kernel) formulation for gfx950.
 //
 // Why not one megakernel?  Measured on MI355X in round 1 (profiles/r01_v2_*, the variants have since been removed):
-// the fused kernels need 147-169 VGPRs (2-3 waves per SIMD), waves spend 64 % of their cycles waiting on
-// memory, VALU lanes are 31 % utilised, and HBM/L2-miss traffic is only ~150 GB/s -- the path is LATENCY
-// bound, not bandwidth bound.  MI355X has 288 GB of HBM3E at ~8 TB/s, so the cure is to keep the per-path
-// state in HBM (176 B per pixel) and cut the work into lean kernels that each do one thing at high occupancy:
+// the fused kernels need 147-169 VGPRs (2-3 waves per SIMD) and run at 31 % VALU lane utilisation.  MI355X has
+// 288 GB of HBM3E at ~8 TB/s, so the per-path state lives in HBM (272 B + 8 x 48 B of shadow-ray queue per pixel)
+// and the work is cut into lean kernels that each do one thing at high occupancy:
 //
-//   generate   rgsMain: camera ray per pixel (8x8 pixel tiles per wave), live list of bounce 0
-//   per bounce b = 0..3, over the live list L_b:
-//     extend     closest hit (TraceRay stand-in)                                                    [traversal only]
-//     shade      miss: msDynamicSky + store.  hit: chsMain part 1 -- surface, material, emissive, sky sample,
-//                ENUMERATE the shadow rays as a request bit-mask per vertex, BRDF-sampled continuation ray,
-//                append to L_{b+1}                                                                    [no traversal]
-//     shadow_gen expands the request masks into a flat queue of shadow rays (origin, direction, path, slot): one lane
-//                per RAY, whatever the number of lights per vertex                                      [no traversal]
-//     shadow     RayQuery stand-in: traces the queued shadow rays, clears the request bit of occluded ones [traversal only]
-//     accumulate chsMain part 2: evaluates the unoccluded lights IN THE REFERENCE'S LOOP ORDER, then the sky
-//                sample, adds them to payload.color; finished paths are stored + integrated            [no traversal]
+//   generate   rgsMain: camera ray per pixel (8x8 pixel tiles per wave), ray queue of bounce 0
+//   per bounce b = 0..3, over the ray list L_b (everything a kernel touches is indexed by LIST SLOT: coalesced streams):
+//     extend     closest hit (TraceRay stand-in).  b = 0: the camera rays of a tile as ONE PACKET (wf_extend_packet_kernel);
+//                b > 0: persistent waves, one ray per lane, lane refill                              [traversal only]
+//     shade      miss: msDynamicSky + store.  hit: chsMain without its light loop -- surface, material, emissive, sky sample
+//                direction, BRDF-sampled continuation ray appended to L_{b+1}                       [no traversal]
+//     shadow_gen the light loop's candidates: one lane per (vertex, light of the vertex's grid cell) decides whether a shadow
+//                ray is needed (request mask), then one lane per RAY writes the queue record and the light's radiance  [no traversal]
+//     shadow     RayQuery stand-in: traces the queued rays, zeroes the visibility word of occluded ones [traversal only]
+//     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER over the records left visible, then the sky sample; finished
+//                paths are stored + integrated                                                        [no traversal]
 //
-// The traversal kernels are PERSISTENT WITH LANE REFILL (Aila & Laine 2009, adapted to 64-wide waves): a wave
-// owns a chunk of rays (resp. vertices) taken from a device-wide cursor; every loop iteration each lane does ONE
-// traversal step (one 8-wide node or one leaf triangle); lanes whose ray is done are handed the next item of the chunk
-// as soon as enough lanes are idle, so a wave never idles on its slowest ray (first wavefront version without
-// refill: 16-22 % VALU lane utilisation, profiles/r01_v3_*).  Every wave reaches the exit (cursor exhausted and
-// no lane active), so the grid always drains.
+// A frame is issued as two PIPELINES (bands of tile rows on their own streams, launcher below): the other band's kernels fill
+// the GPU while one band's traversal kernel drains its longest rays.
+//
+// The persistent traversal kernels refill lanes (Aila & Laine 2009, adapted to 64-wide waves): a wave owns a chunk of rays taken
+// from a device-wide cursor; every loop iteration each lane does ONE traversal step (one 8-wide node or one leaf triangle); lanes
+// whose ray is done are handed the next rays of the chunk as soon as enough lanes are idle.  Every wave reaches the exit (cursor
+// exhausted and no lane active), so the grid always drains.  They are VALU-ISSUE bound (profiles/r02_pmc_summary*.txt: issue
+// cycles = elapsed cycles, 33-42 % of the lanes useful: a node step and a triangle step are different code).
 //
 // The float operations per pixel and their order are exactly those of the reference HLSL; only the schedule differs.
 //

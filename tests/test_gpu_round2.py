@@ -356,6 +356,24 @@ def test_wavefront_overflow_paths_are_bit_identical(gpu_ctx, rt, sio, sponza_sma
     p2.close(); sc2.close(); ctx2.close()
 
 
+# ------------------------------------------------------------------------------------------------ ragged frames
+@pytest.mark.parametrize("W,H", [(1, 1), (5, 3), (8, 8), (9, 17), (67, 33)])
+def test_ragged_frames_packets_and_pipelines(gpu_ctx, rt, sio, ob, sponza_small, W, H):
+    """Frames that are not a whole number of 8 x 8 tiles / of pipelines: the camera-ray packets run with partly empty waves, a frame
+    of fewer than 8 tile rows runs as one pipeline.  Every ray category and every pixel must equal the oracle's."""
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    sc = gpu_ctx.create_scene(sponza_small)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    pt.render(view, 2)
+    g = pt.read()
+    o = ob.OracleScene(sponza_small).pathtrace(rt.make_pathtrace_desc(view, W, H, 2), num_threads=os.cpu_count())
+    assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    assert g["stats"].camera_rays == W * H
+    ok, same = pixel_agreement(g["target"], o["target"])
+    assert ok == 1.0, (ok, same)
+    pt.close(); sc.close()
+
+
 # ------------------------------------------------------------------------------------------------ frame issue variants
 @pytest.mark.parametrize("which,W,H,hbao", [("sponza_small", 320, 180, False), ("sponza_small", 203, 117, True), ("helmet", 256, 256, False)])
 def test_fused_deferred_lighting_equals_the_chain(request, gpu_ctx, rt, R, sio, A, which, W, H, hbao):

@@ -182,8 +182,9 @@ def main():
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
-    ap.add_argument("--pipelines", type=int, default=2,
-                    help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical). "
+    ap.add_argument("--pipelines", type=int, default=0,
+                    help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical; "
+                         "0 = the library's choice: 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels). "
                          "With more than one, launches of different bands overlap and stretch each other: the per-kernel times then price launches "
                          "that share the GPU; --pipelines 1 times every kernel alone (profiles/ holds both)")
     ap.add_argument("--spp-per-gather", type=int, default=64,
@@ -217,7 +218,7 @@ def main():
     importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
-    ctx.set_pathtrace_pipelines(max(1, min(args.pipelines, 8)))
+    ctx.set_pathtrace_pipelines(max(0, min(args.pipelines, 8)))
     scene = ctx.create_scene(packed)
     info = scene.info()
     # load-time precompute, as the reference does once per scene / sun change (FScene::UpdateDynamicSky at
@@ -326,16 +327,16 @@ def main():
             "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
-                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": max(1, min(args.pipelines, 8)),
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": int(prof.pipelines),
                        "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": dominant, "kernel_ms": round(kernel_ms, 4), "kernel_launches_per_step": dom_launches / args.steps,
-                         "kernel_timing": ("HIP events on each pipeline's stream; %d pipelines overlap, so a launch shares the GPU with the other band's "
-                                           "kernels while it is timed (sum of kernel_ms_per_step > ms_per_step); --pipelines 1 times kernels alone" % args.pipelines)
-                                          if args.pipelines > 1 else "HIP events on the launch stream, one pipeline: every kernel has the GPU to itself",
+                         "kernel_timing": ("HIP events on each pipeline's stream; %d pipelines overlap, so a launch shares the GPU with the other bands' "
+                                           "kernels while it is timed (sum of kernel_ms_per_step > ms_per_step); --pipelines 1 times kernels alone" % prof.pipelines)
+                                          if prof.pipelines > 1 else "HIP events on the launch stream, one pipeline: every kernel has the GPU to itself",
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX,
                          "whole_call": {"ms": round(call_ms, 4), "algorithmic_bytes": int(frame_alg_bytes),
@@ -350,7 +351,7 @@ def main():
                     tj = json.load(f)
                 entry = tj.get("kernels", {}).get(dominant)
                 default_workload = args.scene == "sponza" and [W, H] == [3840, 2160] and not args.no_direct_lighting and args.viewmode == 0
-                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == max(1, min(args.pipelines, 8)):
+                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == int(prof.pipelines):
                     out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tj.get("source")
                     # the traversal kernels are VALU-issue bound: instructions per launch x 4 cycles per wave64

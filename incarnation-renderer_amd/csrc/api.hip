@@ -228,7 +228,10 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 // A pipeline owns a band of 8-pixel tile rows (equal shares; a frame of fewer tile rows than pipelines uses fewer).
 static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, hipStream_t stream) {
     const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u;
-    const int pipes = (int)std::max(1u, std::min<uint32_t>((uint32_t)ctx->wfPipesWanted, tilesY / 4u));      // >= 4 tile rows each
+    // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
+    // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
+    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : ((uint64_t)W * localRows >= 1500000ull ? 2u : 4u);
+    const int pipes = (int)std::max(1u, std::min<uint32_t>(wanted, tilesY / 4u));      // >= 4 tile rows each
     ctx->wfPipes = pipes;
     for (int i = 1; i < pipes; ++i) if (!ctx->wfStreams[i]) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->wfStreams[i], hipStreamNonBlocking));
@@ -622,7 +625,7 @@ int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info)
 int incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (pipelines > (uint32_t)kMaxPipes) return fail(INCR_ERR_INVALID_ARGUMENT, "at most %d pipelines", kMaxPipes);
-    ctx->wfPipesWanted = pipelines ? (int)pipelines : INCR_WF_PIPELINES_DEFAULT;
+    ctx->wfPipesWanted = (int)pipelines;                                  // 0 = chosen per call from the number of paths
     return INCR_OK;
 }
 
@@ -648,6 +651,7 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
         for (int k = 0; k < 20; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++; }
     }
     out->frames = (uint32_t)ctx->profFrames;
+    out->pipelines = ctx->profPipes.empty() ? 0u : (uint32_t)ctx->profPipes.back();
     ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }

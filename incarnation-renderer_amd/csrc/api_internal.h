@@ -20,7 +20,7 @@ int incr_fail(int code, const char* fmt, ...);      // stores the thread's incr_
                                  "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 #ifndef INCR_WF_PIPELINES_DEFAULT
-#define INCR_WF_PIPELINES_DEFAULT 2
+#define INCR_WF_PIPELINES_DEFAULT 0      /* 0 = by size (api.hip ensure_wf_workspace) */
 #endif
 struct incr_context {
     int device;
@@ -32,7 +32,7 @@ struct incr_context {
     incr::WfBuffers wf[8];    // path-state workspace of the wavefront path tracer, one set per pipeline (pathtrace_wf.hip), grown on demand
     uint32_t wfTileRow[9];    // tile rows [wfTileRow[i], wfTileRow[i + 1]) belong to pipeline i
     int wfPipes;              // pipelines of the current frame
-    int wfPipesWanted;        // INCR_WF_PIPELINES (default 2)
+    int wfPipesWanted;        // INCR_WF_PIPELINES / incr_set_pathtrace_pipelines; 0 = by size
     hipStream_t wfStreams[8]; // [0] is filled per call with the caller's stream; the others are library-owned
     hipEvent_t wfFork, wfJoin[8];
     void* wfBlock;            // one allocation behind wf

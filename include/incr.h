@@ -138,7 +138,8 @@ int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_str
  * Not in the reference: how a path-traced frame is issued.  The frame is cut into `pipelines` bands of 8-pixel tile rows, each
  * with its own path-state buffers and its own (library-owned) stream; the bands fork from `stream` and join it again inside
  * incr_pathtrace, so callers see one stream-ordered call.  Results are bit-identical for every count (1..8; 0 = the
- * default, 2, or the INCR_WF_PIPELINES environment variable read at incr_initialize).  One pipeline leaves the GPU waiting
+ * default: chosen per call from the number of paths -- 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels --
+ * or the INCR_WF_PIPELINES environment variable read at incr_initialize).  One pipeline leaves the GPU waiting
  * for the longest rays of each of the eight traversal kernels of a frame; with two the other band's kernels run meanwhile.
  */
 int  incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines);
@@ -153,6 +154,7 @@ typedef struct incr_pathtrace_profile {
     double generate_ms, extend_ms, shade_ms, shadow_gen_ms, shadow_ms, accumulate_ms;   /* summed over all recorded calls */
     uint32_t launches[5];            /* extend, shade, shadow_gen, shadow, accumulate launches that did work */
     uint32_t frames;                 /* recorded incr_pathtrace calls */
+    uint32_t pipelines;              /* pipelines of the last recorded call */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);
 int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);

@@ -333,6 +333,51 @@ static void wave_model_overlap(const char* name, const Trace& tr, size_t nWaves,
            cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0), 100 * stalls / (iters * 64));
 }
 
+// policy 4 (sorted workgroup): the 256 rays of a workgroup live in LDS; every iteration the rays on a node step are handed to the
+// first waves and the rays on a triangle step to the last ones, so a wave runs one kind of step (the wave on the boundary both);
+// waves that get no ray skip the iteration.  cX = what a wave pays for fetching / storing ray state and building the next lists.
+static void wave_model_sorted(const char* name, const Trace& tr, size_t nBlocks, const WaveModel& M, float cX) {
+    const size_t nRays = tr.start.size();
+    struct Lane { bool live = false; uint32_t pos = 0, end = 0; uint32_t trisLeft = 0; };
+    struct Block { Lane l[256]; size_t next = 0, end = 0; bool dry = false, done = false; };
+    std::vector<Block> blocks(nBlocks);
+    size_t cursor = 0; double cost = 0, iters = 0, steps = 0;
+    size_t alive = nBlocks;
+    while (alive) {
+        for (Block& w : blocks) {
+            if (w.done) continue;
+            int live = 0; for (auto& L : w.l) live += L.live;
+            if (!w.dry && (256 - live >= M.refill || live == 0)) {
+                for (auto& L : w.l) {
+                    if (L.live) continue;
+                    if (w.next >= w.end) { if (cursor >= nRays) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)M.chunk, nRays); cursor = w.end; }
+                    const size_t r = w.next++;
+                    L.live = true; L.pos = tr.start[r]; L.end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); L.trisLeft = 0;
+                    if (L.pos == L.end) L.live = false; else ++live;
+                }
+            }
+            if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+            int nN = 0, nT = 0;
+            for (auto& L : w.l) if (L.live) { if (L.trisLeft) ++nT; else ++nN; }
+            // waves: items [0, nN) node, [nN, nN + nT) tri, 64 per wave
+            const int total = nN + nT, nWaves = (total + 63) / 64;
+            for (int wv = 0; wv < nWaves; ++wv) {
+                const int lo = wv * 64, hi = std::min(lo + 64, total);
+                const bool hasN = lo < nN, hasT = hi > nN;
+                cost += M.cC + cX + (hasN ? M.cN : 0.f) + (hasT ? M.cT : 0.f);
+            }
+            iters += 1;
+            for (auto& L : w.l) {
+                if (!L.live) continue;
+                if (L.trisLeft) --L.trisLeft; else L.trisLeft = tr.tris[L.pos++];
+                ++steps;
+                if (!L.trisLeft && L.pos >= L.end) L.live = false;
+            }
+        }
+    }
+    printf("  %-16s sorted workgroup, exchange %3.0f refill %3d: cost/step %6.1f  block iters %.3gM\n", name, cX, M.refill, cost / steps, iters / 1e6);
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static float rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (float)((rng_state >> 40) * (1.0 / 16777216.0)); }
 
@@ -442,7 +487,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                     wave_model(S.n, *S.t, nW, {0, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 0});
                     for (float bias : {0.5f, 1.f, 2.f}) wave_model(S.n, *S.t, nW, {1, S.chunk, S.refill, S.cC, S.cN, S.cT, bias, 0});
                     for (int thr : {8, 16, 24}) wave_model(S.n, *S.t, nW, {2, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr});
-                    for (int Q : {2, 4}) for (int thr : {24, 32, 40}) for (float must : {1.f, 8.f, 16.f}) wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT + 30.f, must, thr}, Q);
+                    for (float cX : {40.f, 80.f, 120.f}) for (int rf : {32, 64}) wave_model_sorted(S.n, *S.t, std::max<size_t>(1, nW / 4), {4, S.chunk * 4, rf, S.cC, S.cN, S.cT, 1.f, 0}, cX);
                 }
             }
         }

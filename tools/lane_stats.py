@@ -1,6 +1,6 @@
 """Developer tool (GPU box): rebuilds the path-tracing kernels with -DINCR_WF_LANE_STATS, renders Sponza-stat frames and prints
 where the lanes of the persistent traversal waves go (node steps / triangle steps / idle, steady state against the drain after
-the cursor ran dry).  usage: python tools/lane_stats.py [--res 3840x2160] [--frames 2]   (restores the normal build afterwards)"""
+the cursor ran dry).  "extend" covers bounces 1-3: the camera rays go through the packet kernel, which has no idle lanes to count.  usage: python tools/lane_stats.py [--res 3840x2160] [--frames 2]   (restores the normal build afterwards)"""
 import argparse, ctypes as C, importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -271,6 +271,15 @@ def test_full_size_properties_4k(gpu_ctx, rt, sio, synth, A, ob):
     assert (got[np.isfinite(want) & (want < 0)] == 0).all()                 # R11G11B10 has no sign: negative radiance stores 0
     fin = np.isfinite(want) & (want < 60000) & (want >= 0)
     assert (got[fin] <= want[fin]).all() and (want[fin] - got[fin] <= np.maximum(want[fin] * 2.0 ** -5, 2e-6)).all()
+    # the way the frame is issued does not change a bit of it: one pipeline / the default two / four, at the bench's own size
+    for pipelines in (1, 4):
+        gpu_ctx.set_pathtrace_pipelines(pipelines)
+        gpu_ctx.clear(pt.history, pt.rows * W * 4); gpu_ctx.clear(pt.stats, C.sizeof(A.RayStats))
+        pt.render(view, 1); e = pt.read()
+        np.testing.assert_array_equal(a["target"], e["target"])
+        np.testing.assert_array_equal(a["history"], e["history"])
+        assert stats_tuple(a["stats"]) == stats_tuple(e["stats"])
+    gpu_ctx.set_pathtrace_pipelines(0)
     # a 64x64 crop of the 4K frame against the oracle (global pixel indices key the sampler)
     ys, xs = np.mgrid[1000:1064, 1900:1964]
     d = rt.make_pathtrace_desc(view, W, H, 1)

@@ -58,7 +58,7 @@ static constexpr int kWfBlock = 256;
 template <int N> using WfStack = LaneStackT<N, kWfBlock, false, true>;        // any-hit (shadow) traversal
 template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         // closest-hit traversal: keyed, drops groups beyond the best hit
 // Hottest nodes kept in LDS per workgroup (80 B each), sized so that stack + copy still give the kernels' workgroups per CU
-// out of 160 KB: extend 7 / 6 / 6 / 4 / 3 workgroups, shadow 8 / 8 / 8 / 8 / 6 at N = 8 / 10 / 12 / 16 / 24.
+// out of 160 KB: extend 7 / 6 / 6 / 4 / 3 workgroups, shadow 7 / 7 / 7 / 7 / 6 at N = 8 / 10 / 12 / 16 / 24.
 #ifndef INCR_EXTEND_TOP
 #define INCR_EXTEND_TOP 80
 #endif
@@ -66,7 +66,7 @@ template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         /
 #define INCR_SHADOW_TOP 144
 #endif
 #ifndef INCR_SHADOW_WAVES
-#define INCR_SHADOW_WAVES 8
+#define INCR_SHADOW_WAVES 7     // the overlapped step (pt_traverse.h trav_any_step2) keeps a node and a triangle in flight: 72 VGPRs; at 8 waves (64) it spills 28 B and loses (shadow 9.4 ms against 7.9)
 #endif
 #ifndef INCR_EXTEND_TOP10
 #define INCR_EXTEND_TOP10 24
@@ -280,7 +280,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
     WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
     bool active = false; uint32_t slot = 0;
-    TravClosest T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
+    TravClosest2 T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f); T.triBase1 = 0; T.triMask1 = 0;
     uint32_t rays = 0;
     LANE_STATS(LaneStats ls;)
     // (The software-pipelined form of wf_shadow_kernel -- loads issued by the refill, rays started after the step, hits stored
@@ -296,13 +296,14 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
                 const float4 o = ext[(size_t)item * 2], d = ext[(size_t)item * 2 + 1];
                 slot = item;
                 trav_closest_begin(T, {o.x, o.y, o.z}, {d.x, d.y, d.z}, 0.001f, 10000.0f);     // TMin / TMax of TraceRay (common.hlsli:49-50,119-120)
+                T.triBase1 = 0; T.triMask1 = 0;
                 st.reset();
                 active = true; rays++;
             }
         }
         if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
-        if (active && trav_closest_step(P, st, T)) {
+        if (active && trav_closest_step2(P, st, T)) {           // node step and triangle step in one iteration (pt_traverse.h)
             B.hit[slot] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
                                  : make_uint4(kMissTri, 0u, 0u, 0u);
             active = false;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
 // ISSUES its two queue loads, the step of the lanes still tracing runs, and the new rays start after it -- their HBM
 // latency hides behind the step's fetch instead of stalling 40 busy lanes; results of finished lanes are written by the
 // next refill, all of them with one instruction.
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAVES : (N <= 16 ? 8 : 6)) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WAVES : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
@@ -741,7 +742,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAV
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0, nextIndex = 0;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-    TravAny T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f);
+    TravAny2 T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f); T.triBase1 = 0; T.triMask1 = 0;
     LANE_STATS(LaneStats ls;)
     for (;;) {
         const unsigned long long act = __ballot(active);
@@ -753,12 +754,13 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_SHADOW_WAV
             if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; nextIndex = item; pending = true; }
         }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
-        if (active && trav_any_step(P, st, T)) { occludedDone = T.occluded; active = false; }
+        if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; active = false; }      // node step and triangle step in one iteration
         if (pending) {
             pending = false;
             rayIndex = nextIndex;
             if (__float_as_uint(qa.w) != 0xffffffffu) {
                 trav_any_begin(T, {qa.x, qa.y, qa.z}, {qb.x, qb.y, qb.z}, 0.1f, 1000.f);     // lighting/common.hlsli:96-100
+                T.haveCur = true; T.triBase1 = 0; T.triMask1 = 0;
                 st.reset();
                 active = true;
             }
@@ -878,7 +880,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 10u ? 10 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24)));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv == 8 ? (uint32_t)INCR_SHADOW_WAVES : (sv <= 16 ? 8u : 6u);
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
     uint32_t total[8], blocksAll[8], blocksExtend[8];
     for (int i = 0; i < numPipes; ++i) {

@@ -370,11 +370,11 @@ template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravCl
 
 // TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES): closest hit
 template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
-    TravClosest T;
-    trav_closest_begin(T, o, d, tmin, tmax);
-    T.haveCur = false;                   // the root is fetched by the first step
+    TravClosest2 T;
+    trav_closest_begin(T, o, d, tmin, tmax);          // haveCur: the root is the first node to visit
+    T.triBase1 = 0; T.triMask1 = 0;
     st.reset();
-    while (!trav_closest_step(P, st, T)) {}
+    while (!trav_closest_step2(P, st, T)) {}
     if (T.found) { hit->t = T.best; hit->u = T.bu; hit->v = T.bv; hit->tri = T.bestTri; }
     return T.found;
 }
@@ -457,10 +457,11 @@ template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& 
 // RayQuery<CULL_BACK_FACING> + one Proceed(): occluded iff any front-facing triangle lies in (tmin, tmax)
 // (lighting/common.hlsli:102-115, 161-174).
 template <class ST> DI bool trace_any(const PtParams& P, ST& st, f3 o, f3 d, float tmin, float tmax) {
-    TravAny T;
+    TravAny2 T;
     trav_any_begin(T, o, d, tmin, tmax);
+    T.haveCur = true; T.triBase1 = 0; T.triMask1 = 0;
     st.reset();
-    while (!trav_any_step(P, st, T)) {}
+    while (!trav_any_step2(P, st, T)) {}
     return T.occluded;
 }
 

@@ -21,10 +21,11 @@
 // the GPU while one band's traversal kernel drains its longest rays.
 //
 // The persistent traversal kernels refill lanes (Aila & Laine 2009, adapted to 64-wide waves): a wave owns a chunk of rays taken
-// from a device-wide cursor; every loop iteration each lane does ONE traversal step (one 8-wide node or one leaf triangle); lanes
+// from a device-wide cursor; every loop iteration each lane tests one 8-wide node and / or one pending leaf triangle; lanes
 // whose ray is done are handed the next rays of the chunk as soon as enough lanes are idle.  Every wave reaches the exit (cursor
 // exhausted and no lane active), so the grid always drains.  They are VALU-ISSUE bound (profiles/r02_pmc_summary*.txt: issue
-// cycles = elapsed cycles, 33-42 % of the lanes useful: a node step and a triangle step are different code).
+// cycles = elapsed cycles, 43-51 % of the lanes useful: a node step and a triangle step are different code, which is why a lane
+// makes both in one iteration whenever it can -- pt_traverse.h trav_closest_step2 / trav_any_step2).
 //
 // The float operations per pixel and their order are exactly those of the reference HLSL; only the schedule differs.
 //

@@ -5,10 +5,11 @@
 // Stand-in for the fixed-function DXR traversal: TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES)
 // closest hit with the ahsMain alpha test on non-opaque geometry, and RayQuery + one Proceed() for shadow rays.
 //
-// Traversal is a RESUMABLE STATE MACHINE with exactly ONE memory round trip per step: a lane either tests one
-// 8-wide node (5 x dwordx4) or ONE pending triangle of the last node (3 x dwordx4); the loads are issued from a
-// mode-selected address before any branching.  Measured on MI355X: with per-leaf / per-triangle loops inside the
-// step, a wave paid up to ~10 serialised round trips per iteration (~8000 cycles per step, waves 70 % waiting).
+// Traversal is a RESUMABLE STATE MACHINE with exactly ONE memory round trip per step: the loads of a step are issued
+// together before any branching.  Measured on MI355X: with per-leaf / per-triangle loops inside the step, a wave paid
+// up to ~10 serialised round trips per iteration (~8000 cycles per step, waves 70 % waiting).  Two generations of the
+// step live here: trav_*_step tests one 8-wide node (5 x dwordx4) OR one pending triangle of the last node (3 x
+// dwordx4); trav_*_step2 (what the kernels use) tests one node AND one queued triangle in the same step.
 #pragma once
 #include "pt_device.h"
 

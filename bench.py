@@ -6,7 +6,7 @@ Metric (BASELINE.json): Mray/s (+ ms/frame) at 4K, 1 spp, Sponza, path tracer.  
 (Sponza.bin is absent from the reference checkout) accumulated into the
 R11G11B10F history, exactly what RenderJob::PathTracing::Execute does per displayed frame.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or alone -- it then starts its N ranks itself)
 
 N > 1 shards the framebuffer in interleaved 8-row blocks (one process per GPU, scene replicated) and
 gathers the HDR history to every rank with one RCCL all_gather per frame (strong scaling: the frame is fixed).
@@ -169,6 +169,103 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
             "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, rendezvous on
+    127.0.0.1), before this process has touched the GPU, and wait for them.  Rank 0's stdout is the parent's (the ONE JSON line);
+    the first non-zero exit code is propagated and the remaining ranks are stopped (a dead peer would leave them in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+
+    def forward():      # rank 0's JSON line -> stdout; anything else a library printed on its stdout (gloo's connection banner) -> stderr
+        for line in procs[0].stdout:
+            (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+            sys.stdout.flush()
+    import threading
+    fw = threading.Thread(target=forward, daemon=True)
+    fw.start()
+    code = 0
+    live = list(procs)
+    while live and code == 0:
+        time.sleep(0.05)
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            live.remove(pr)
+            if rc != 0:
+                code = rc
+                break
+    if code != 0:
+        for pr in live:
+            pr.terminate()
+        deadline = time.time() + 10
+        for pr in live:
+            try:
+                pr.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+    fw.join(timeout=5)
+    return code if code >= 0 else 1
+
+
+def dry_run(args, rank, world):
+    """--dry-run (CPU, gloo): the rank choreography of the real run -- rendezvous, the shard arithmetic, barrier-bracketed timing
+    with the max over ranks, one gather of the per-rank history shards per step, rank 0's single JSON line -- with no render
+    work in it.  Exists so that the launch path (`--gpus N` with and without a launcher) is testable without a GPU."""
+    import torch
+    import torch.distributed as dist
+    W, H = (int(v) for v in args.res.lower().split("x"))
+    if world > 1:
+        dist.init_process_group(backend=args.backend)
+    if args.fail_rank == rank:
+        raise RuntimeError("--fail-rank %d: injected failure" % rank)
+    block = 8
+    blocks = (H + block - 1) // block
+    rows = ((blocks - rank + world - 1) // world) * block if world > 1 else H      # interleaved 8-row blocks, as incr_shard_local_rows (padding rows included)
+    rows_max = ((blocks + world - 1) // world) * block if world > 1 else H
+    history = torch.full((rows_max, W), rank, dtype=torch.int32)
+    gathered = torch.zeros((world * rows_max, W), dtype=torch.int32) if world > 1 else None      # gloo wants the concatenated shape
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, history)
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    px = torch.tensor([rows * W], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(px, op=dist.ReduceOp.SUM)
+        assert all(int(gathered[r * rows_max, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "Mray/s", "value": 0.0, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(tt.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run of the rank choreography (no render work)", "resolution": [W, H], "backend": args.backend,
+                                     "local_rows_sum": int(px.item()) // W}}), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,15 +287,27 @@ def main():
     ap.add_argument("--spp-per-gather", type=int, default=64,
                     help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
                          "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank choreography (rendezvous, barriers, gather, the JSON line) without render work")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run): this rank raises after the rendezvous")
     args = ap.parse_args()
 
-    import torch
+    # `python bench.py --gpus N` as the driver invokes it (no launcher): this process becomes the launcher -- BEFORE anything
+    # touches the GPU (no torch.cuda call, no rt.Context yet; a process that has initialised the GPU must not re-exec) -- and the
+    # N ranks are fresh child processes.  Under torch.distributed.run WORLD_SIZE is already set and this branch is not taken.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without a launcher)" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("--backend gloo is for --dry-run only: the render path runs on the GPU over RCCL")
+    import torch
     A = importlib.import_module(PKG + ".ctypes_api")
     sio = importlib.import_module(PKG + ".scene_io")
     rt = importlib.import_module(PKG + ".runtime")
@@ -211,7 +320,7 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend=args.backend, device_id=dev)
 
     W, H = (int(v) for v in args.res.lower().split("x"))
     packed = build_scene(args.scene, args.texture_size)

@@ -390,6 +390,85 @@ static void print_stats(const char* name, const Stats& s) {
 }
 } // namespace
 
+// policy 5 (per-wave ray pool): R rays of a wave live in LDS (state + stack); every iteration the rays that can make a node step
+// are compacted onto the 64 lanes (first 64 in slot order starting at a rotating offset), then the rays with a queued triangle
+// (queue of Q entries per ray, as the overlapped step).  cX = list building + state load / store per phase that runs.
+static void wave_model_pool(const char* name, const Trace& tr, size_t nWaves, const WaveModel& M, int R, int Q, float cX, int triThr) {
+    const size_t nRays = tr.start.size();
+    struct Ray { bool live = false; uint32_t pos = 0, end = 0; uint32_t q[8]; int qn = 0; };
+    struct Wave { std::vector<Ray> l; size_t next = 0, end = 0; bool dry = false, done = false; int rot = 0; };
+    std::vector<Wave> waves(nWaves); for (auto& w : waves) w.l.resize(R);
+    size_t cursor = 0; double cost = 0, iters = 0, steps = 0, nodeLanes = 0, triLanes = 0, nodeIters = 0, triIters = 0;
+    size_t alive = nWaves;
+    while (alive) {
+        for (Wave& w : waves) {
+            if (w.done) continue;
+            int live = 0; for (auto& L : w.l) live += L.live;
+            if (!w.dry && (R - live >= M.refill || live == 0)) {
+                for (auto& L : w.l) {
+                    if (L.live) continue;
+                    if (w.next >= w.end) { if (cursor >= nRays) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)M.chunk, nRays); cursor = w.end; }
+                    const size_t r = w.next++;
+                    L.live = true; L.pos = tr.start[r]; L.end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); L.qn = 0;
+                    if (L.pos == L.end) L.live = false; else ++live;
+                }
+            }
+            if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+            // tri phase first (state after it feeds the node phase's queue test)
+            int nT = 0, must = 0, nNwant = 0;
+            for (auto& L : w.l) if (L.live) { if (L.qn) { ++nT; if (!(L.pos < L.end && L.qn < Q)) ++must; } if (L.pos < L.end && L.qn < Q) ++nNwant; }
+            const bool doT = nT > 0 && (nT >= triThr || must > 0 || nNwant == 0);
+            int doneT = 0;
+            if (doT) {
+                for (int i = 0; i < R && doneT < 64; ++i) { Ray& L = w.l[(i + w.rot) % R]; if (!L.live || !L.qn) continue; ++doneT; ++steps; if (--L.q[0] == 0) { for (int k = 1; k < L.qn; ++k) L.q[k - 1] = L.q[k]; --L.qn; } if (L.pos >= L.end && L.qn == 0) L.live = false; }
+            }
+            int doneN = 0;
+            for (int i = 0; i < R && doneN < 64; ++i) { Ray& L = w.l[(i + w.rot) % R]; if (!L.live || !(L.pos < L.end && L.qn < Q)) continue; ++doneN; ++steps; const uint32_t t = tr.tris[L.pos++]; if (t) L.q[L.qn++] = t; if (L.pos >= L.end && L.qn == 0) L.live = false; }
+            w.rot = (w.rot + 17) % R;
+            cost += M.cC + (doneN ? M.cN + cX : 0.f) + (doneT ? M.cT + cX : 0.f); iters++;
+            if (doneN) { nodeIters++; nodeLanes += doneN; } if (doneT) { triIters++; triLanes += doneT; }
+        }
+    }
+    printf("  %-8s pool R %3d Q %d cX %3.0f triThr %2d refill %2d: cost/step %6.2f  iters %.3gM  node iters %.0f%% @ %.1f lanes, tri iters %.0f%% @ %.1f lanes\n", name, R, Q, cX, triThr, M.refill,
+           cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0));
+}
+// policy 6 (two rays per lane, in registers): a lane's node step goes to whichever of its two rays can make one, likewise its
+// triangle step; cX = the selects per phase.
+static void wave_model_dual(const char* name, const Trace& tr, size_t nWaves, const WaveModel& M, int K, int Q, float cX) {
+    const size_t nRays = tr.start.size();
+    struct Ray { bool live = false; uint32_t pos = 0, end = 0; uint32_t q[8]; int qn = 0; };
+    struct Wave { std::vector<Ray> l; size_t next = 0, end = 0; bool dry = false, done = false; };
+    const int R = 64 * K;
+    std::vector<Wave> waves(nWaves); for (auto& w : waves) w.l.resize(R);
+    size_t cursor = 0; double cost = 0, iters = 0, steps = 0, nodeLanes = 0, triLanes = 0, nodeIters = 0, triIters = 0;
+    size_t alive = nWaves;
+    while (alive) {
+        for (Wave& w : waves) {
+            if (w.done) continue;
+            int live = 0; for (auto& L : w.l) live += L.live;
+            if (!w.dry && (R - live >= M.refill || live == 0)) {
+                for (auto& L : w.l) {
+                    if (L.live) continue;
+                    if (w.next >= w.end) { if (cursor >= nRays) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)M.chunk, nRays); cursor = w.end; }
+                    const size_t r = w.next++;
+                    L.live = true; L.pos = tr.start[r]; L.end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); L.qn = 0;
+                    if (L.pos == L.end) L.live = false; else ++live;
+                }
+            }
+            if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+            int doneT = 0, doneN = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                for (int k = 0; k < K; ++k) { Ray& L = w.l[lane * K + k]; if (!L.live || !L.qn) continue; ++doneT; ++steps; if (--L.q[0] == 0) { for (int i = 1; i < L.qn; ++i) L.q[i - 1] = L.q[i]; --L.qn; } if (L.pos >= L.end && L.qn == 0) L.live = false; break; }
+                for (int k = 0; k < K; ++k) { Ray& L = w.l[lane * K + k]; if (!L.live || !(L.pos < L.end && L.qn < Q)) continue; ++doneN; ++steps; const uint32_t t = tr.tris[L.pos++]; if (t) L.q[L.qn++] = t; if (L.pos >= L.end && L.qn == 0) L.live = false; break; }
+            }
+            cost += M.cC + (doneN ? M.cN + cX : 0.f) + (doneT ? M.cT + cX : 0.f); iters++;
+            if (doneN) { nodeIters++; nodeLanes += doneN; } if (doneT) { triIters++; triLanes += doneT; }
+        }
+    }
+    printf("  %-8s dual K %d Q %d cX %3.0f refill %2d: cost/step %6.2f  iters %.3gM  node iters %.0f%% @ %.1f lanes, tri iters %.0f%% @ %.1f lanes\n", name, K, Q, cX, M.refill,
+           cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0));
+}
+
 extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, right, up, look */, float tanHalfFovY, float aspect, int W, int H) {
     HostScene hs; copy_scene_desc(*desc, hs);
     const char* why = "";
@@ -487,6 +566,12 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                     wave_model(S.n, *S.t, nW, {0, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 0});
                     for (float bias : {0.5f, 1.f, 2.f}) wave_model(S.n, *S.t, nW, {1, S.chunk, S.refill, S.cC, S.cN, S.cT, bias, 0});
                     for (int thr : {8, 16, 24}) wave_model(S.n, *S.t, nW, {2, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr});
+                    wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 1}, 2);
+                    if (getenv("X_THR")) for (int Q : {2, 3, 4}) for (int thr : {1, 16, 24, 32, 40, 48}) wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr}, Q);
+                    if (getenv("X_POOL")) {
+                        for (int R : {96, 128, 192}) for (float cX : {20.f, 40.f}) for (int tt : {1, 24, 40}) wave_model_pool(S.n, *S.t, std::max<size_t>(1, nW * 64 / R), {5, S.chunk, 16, S.cC, S.cN, S.cT, 1.f, 0}, R, 2, cX, tt);
+                        for (int K : {2, 3}) for (float cX : {15.f, 25.f}) wave_model_dual(S.n, *S.t, std::max<size_t>(1, nW / K), {6, S.chunk, 16, S.cC, S.cN, S.cT, 1.f, 0}, K, 2, cX);
+                    }
                     for (float cX : {40.f, 80.f, 120.f}) for (int rf : {32, 64}) wave_model_sorted(S.n, *S.t, std::max<size_t>(1, nW / 4), {4, S.chunk * 4, rf, S.cC, S.cN, S.cT, 1.f, 0}, cX);
                 }
             }

@@ -24,6 +24,8 @@ extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriOb
 extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
                                           const float* srgbLut, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
+extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
+extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
@@ -269,7 +271,7 @@ extern "C" {
 int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
+    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMaterialTexels, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
                     sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
@@ -279,6 +281,7 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
 }
 
 int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene** out) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!desc || !out) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
@@ -373,8 +376,34 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
             level = next;
         }
     }
-    // The chains above are row-major (what the generators write and incr_scene_texture_download returns); the samplers read a TILED copy
-    sc->linearTextures = texs;
+    // Interleaved level-0 texels per material for the path tracer's chsMain (device_types.h MaterialTexels), from the row-major level 0
+    std::vector<MaterialTexels> mtex(desc->num_materials, MaterialTexels{nullptr, 0u, 0u, 0u, 0u});
+    const bool fuseMaterials = !(getenv("INCR_MATERIAL_TEXELS") && atoi(getenv("INCR_MATERIAL_TEXELS")) == 0);      // A/B hook
+    for (uint32_t mi = 0; mi < desc->num_materials && !rc && fuseMaterials; ++mi) {
+        const int32_t bt = desc->materials[mi].baseColorTextureIndex, nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
+        if (bt < 0 || nt < 0 || mt < 0) continue;
+        const DeviceTexture& Bc = texs[(size_t)bt]; const DeviceTexture& N = texs[(size_t)nt]; const DeviceTexture& M = texs[(size_t)mt];
+        if (Bc.width != N.width || Bc.width != M.width || Bc.height != N.height || Bc.height != M.height) continue;
+        if (N.format != INCR_TEX_RG_SNORM || M.format != INCR_TEX_BGRA8_SWIZZLE_RG || (Bc.format != INCR_TEX_RGBA8_SRGB && Bc.format != INCR_TEX_RGBA8_UNORM)) continue;
+        bool shared = false;          // materials that bind the same three textures share one interleaved image
+        for (uint32_t mj = 0; mj < mi && !shared; ++mj)
+            if (mtex[mj].texels && desc->materials[mj].baseColorTextureIndex == bt && desc->materials[mj].normalTextureIndex == nt && desc->materials[mj].metallicRoughnessTextureIndex == mt) { mtex[mi] = mtex[mj]; shared = true; }
+        if (shared) continue;
+        const uint64_t n = material_texel_count(Bc.width, Bc.height);
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, n * 8);
+        if (e == hipSuccess) e = hipMemset(d, 0, n * 8);
+        if (e == hipSuccess) e = incr_launch_material_texels((const uint32_t*)Bc.texels, (const uint32_t*)N.texels, (const uint32_t*)M.texels, Bc.width, Bc.height, d, nullptr);
+        if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "material texel interleave failed: %s", hipGetErrorString(e)); break; }
+        sc->dTexels.push_back(d);
+        sc->textureBytes += n * 8;
+        mtex[mi] = MaterialTexels{d, Bc.width, Bc.height, Bc.format, 0u};
+    }
+    if (!rc) rc = upload_vec(&sc->dMaterialTexels, mtex.data(), mtex.size());
+    // The chains above are row-major (what the generators write); the samplers read a TILED copy.  The row-major chains are freed
+    // afterwards (incr_scene_texture_download de-tiles on demand): a texture is resident once, not twice.
+    std::vector<void*> linear(desc->num_textures, nullptr);
+    for (uint32_t i = 0; i < desc->num_textures && i < texs.size(); ++i) linear[i] = (void*)texs[i].texels;
     for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
         DeviceTexture& T = texs[i];
         size_t tiledWords = 0;
@@ -395,6 +424,15 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         T.texels = (const uint8_t*)d;
     }
     if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
+    if (!rc) for (void* lp : linear) {           // the tiled copies are complete: drop the row-major chains
+        if (!lp) continue;
+        for (void*& q : sc->dTexels) if (q == lp) { (void)hipFree(q); q = nullptr; break; }
+    }
+    if (!rc) for (uint32_t i = 0; i < desc->num_textures; ++i) {
+        size_t chainTexels = 0;
+        for (uint32_t l = 0; l < texs[i].pad[1]; ++l) chainTexels += (size_t)level_dim(texs[i].width, l) * level_dim(texs[i].height, l);
+        sc->textureBytes -= chainTexels * 4;
+    }
     sc->hostTextures = texs;
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
     if (!rc) rc = incr_raster_scene_upload(sc);
@@ -405,6 +443,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
 
 int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_transforms, const uint32_t* mesh_visibility,
                     const incr_matrix* root_transform, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc) return fail(INCR_ERR_INVALID_ARGUMENT, "scene is NULL");
     bool dirty = false;
@@ -441,19 +480,33 @@ int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_di
 
 int incr_scene_texture_info(incr_context* ctx, const incr_scene* sc, uint32_t ti, uint32_t* width, uint32_t* height, uint32_t* num_mips, uint64_t* chain_texels) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
-    if (!sc || ti >= sc->linearTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");
-    const DeviceTexture& t = sc->linearTextures[ti];
+    if (!sc || ti >= sc->hostTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");
+    const DeviceTexture& t = sc->hostTextures[ti];
     uint64_t n = 0; uint32_t w = t.width, h = t.height;
     for (uint32_t l = 0; l < t.pad[1]; ++l) { n += (uint64_t)w * h; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
     if (width) *width = t.width; if (height) *height = t.height; if (num_mips) *num_mips = t.pad[1]; if (chain_texels) *chain_texels = n;
     return INCR_OK;
 }
+// The row-major chain (level 0 first), de-tiled on demand from the storage the samplers read
 int incr_scene_texture_download(incr_context* ctx, const incr_scene* sc, uint32_t ti, void* dst, uint64_t bytes) {
     uint64_t n = 0;
     int rc = incr_scene_texture_info(ctx, sc, ti, nullptr, nullptr, nullptr, &n);
     if (rc) return rc;
     if (!dst || bytes != n * 4) return fail(INCR_ERR_INVALID_ARGUMENT, "destination must hold the whole chain (%llu bytes)", (unsigned long long)(n * 4));
-    HIP_TRY(hipMemcpy(dst, sc->linearTextures[ti].texels, bytes, hipMemcpyDeviceToHost));      // the row-major chain
+    const DeviceTexture& t = sc->hostTextures[ti];
+    void* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, n * 4));
+    const uint32_t* src = (const uint32_t*)t.texels; uint32_t* out = (uint32_t*)tmp;
+    uint32_t w = t.width, h = t.height;
+    hipError_t e = hipSuccess;
+    for (uint32_t l = 0; l < t.pad[1] && e == hipSuccess; ++l) {
+        e = incr_launch_mip_untile(src, w, h, out, nullptr);
+        src += texel_level_words(w, h); out += (size_t)w * h;
+        w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+    }
+    if (e == hipSuccess) e = hipMemcpy(dst, tmp, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(INCR_ERR_HIP, "texture download failed: %s", hipGetErrorString(e));
     return INCR_OK;
 }
 
@@ -523,6 +576,7 @@ void incr_sky_sun_terms(const float s[3], float t, const incr_perez_distribution
 extern "C" {
 
 int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     if (!d->res_x || !d->res_y) return fail(INCR_ERR_INVALID_ARGUMENT, "zero resolution");
@@ -587,7 +641,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P) {
     memset(&P, 0, sizeof P);
     P.nodes = sc->dNodes; P.tris = sc->dTris; P.shade = sc->dShade;
-    P.materials = sc->dMaterials; P.textures = sc->dTextures; P.srgbLut = ctx->srgbLut;
+    P.materials = sc->dMaterials; P.textures = sc->dTextures; P.materialTexels = sc->dMaterialTexels; P.srgbLut = ctx->srgbLut;
     P.meshLocalToWorld = sc->dMeshLocalToWorld;
     P.globalLights = sc->dGlobalLights; P.lightIndices = sc->dLightIndices; P.lightTransforms = sc->dLightTransforms;
     P.resolvedLights = (const float4*)sc->dResolvedLights;
@@ -598,6 +652,7 @@ static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtP
 
 int incr_trace_rays(incr_context* ctx, const incr_scene* sc, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                     int any_hit, uint32_t* out_ids, float* out_tuv, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc || (n && (!origins || !dirs || !out_ids || !out_tuv))) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     PtParams P; fill_scene_params(ctx, sc, P);
@@ -657,6 +712,7 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
 }
 
 int incr_tonemap(incr_context* ctx, const incr_tonemap_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->hdr_r11g11b10 || !d->ldr_rgba8) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(incr_launch_tonemap((const uint32_t*)d->hdr_r11g11b10, (uint32_t*)d->ldr_rgba8, (size_t)d->res_x * d->rows, (int)d->exposure, d->viewmode, (hipStream_t)stream));
@@ -665,6 +721,7 @@ int incr_tonemap(incr_context* ctx, const incr_tonemap_desc* d, incr_stream stre
 
 int incr_unshard(incr_context* ctx, void* dst, const void* src, uint32_t res_x, uint32_t res_y, uint32_t row_block_height,
                  uint32_t num_shards, uint32_t texel_bytes, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!dst || !src || !row_block_height || !num_shards || texel_bytes % 4) return fail(INCR_ERR_INVALID_ARGUMENT, "bad unshard arguments");
     incr_shard sh = {row_block_height, 0, num_shards};

@@ -19,6 +19,13 @@ int incr_fail(int code, const char* fmt, ...);      // stores the thread's incr_
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? INCR_ERR_OUT_OF_MEMORY : INCR_ERR_HIP, \
                                  "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// ---------------------------------------------------------------------------------------------- profiler ranges
+// The reference wraps every pass in a scoped PIX / Tracy event (inc/profiling.h:10-12 SCOPED_COMMAND_LIST_EVENT); here every C-ABI
+// pass call is a roctx range named after its entry point: `rocprofv3 --marker-trace --kernel-trace` groups a frame's kernels by pass.
+#include <rocprofiler-sdk-roctx/roctx.h>
+struct IncrRange { explicit IncrRange(const char* name) { (void)roctxRangePushA(name); } ~IncrRange() { (void)roctxRangePop(); } };
+#define INCR_RANGE() IncrRange incr_range_(__func__)
+
 #ifndef INCR_WF_PIPELINES_DEFAULT
 #define INCR_WF_PIPELINES_DEFAULT 0      /* 0 = by size (api.hip ensure_wf_workspace) */
 #endif
@@ -59,7 +66,7 @@ struct incr_scene {
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
     std::vector<void*> dTexels;
     std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers of the TILED chains + mip counts)
-    std::vector<incr::DeviceTexture> linearTextures;   // the same with the row-major chains (generation, introspection)
+    incr::MaterialTexels* dMaterialTexels = nullptr;   // per material: interleaved level-0 texels of its three main textures (device_types.h)
     uint64_t textureBytes = 0;
     incr::LightGrid grid;
     uint32_t* dGridOffsets = nullptr; uint32_t* dGridLights = nullptr;

@@ -128,6 +128,7 @@ uint64_t incr_mip_chain_texels(uint32_t width, uint32_t height, uint32_t num_mip
 }
 
 int incr_prefilter_normal_roughness(incr_context* ctx, const incr_prefilter_normal_roughness_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->normalmap || !d->metallic_roughness || !d->out_normalmap || !d->out_metallic_roughness)
         return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");

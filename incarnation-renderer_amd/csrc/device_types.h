@@ -78,7 +78,7 @@ struct DeviceTexture {      // 32 B
 // levels one after the other (a level occupies ceil(w / 8) * ceil(h / 4) whole tiles).  A bilinear footprint (2 x 2 texels) then
 // touches 1.4 lines on average instead of the 2 a row-major image costs (its two rows are a whole image row apart) -- the shading
 // kernel's incoherent bounce hits were bound by exactly those line fetches (12 texels of 4 bytes per hit, 42 % L2 misses).
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define INCR_HD __host__ __device__ inline
 #else
 #define INCR_HD inline
@@ -86,5 +86,21 @@ struct DeviceTexture {      // 32 B
 INCR_HD uint32_t texel_tiles_x(uint32_t w) { return (w + 7u) >> 3; }
 INCR_HD uint32_t texel_level_words(uint32_t w, uint32_t h) { return texel_tiles_x(w) * ((h + 3u) >> 2) * 32u; }      // texels of a level incl. tile padding
 INCR_HD uint32_t texel_tile_index(uint32_t x, uint32_t y, uint32_t w) { return ((y >> 2) * texel_tiles_x(w) + (x >> 3)) * 32u + ((y & 3u) << 3) + (x & 7u); }
+
+// Level 0 of a material's base-colour, normal and metallic-roughness textures INTERLEAVED texel by texel (8 bytes: RGBA8 base colour,
+// RG8 normal, {B, G} of the metallic-roughness texel), when the three share one size -- glTF materials nearly always do.  The path
+// tracer's chsMain samples all three at the same uv with SampleLevel(.., 0) (material/common.hlsli:28-71): one bilinear footprint
+// then costs 4 loads of 8 bytes out of 4 x 4-texel tiles of 128 bytes (1.56 cache lines on average) instead of 12 loads out of three
+// textures (3 x 1.4 lines), and the tap arithmetic runs once.  Same texel bytes, same decode, same filter arithmetic: results are
+// bit-identical to sampling the three textures one by one.  texels == NULL: the material is sampled texture by texture.
+struct MaterialTexels {
+    const void* texels;       // uint2 per texel, tiles of 4 x 4 (material_texel_index)
+    uint32_t width, height;
+    uint32_t baseFormat;      // INCR_TEX_* of the base-colour texture (normal = RG_SNORM, metallic-roughness = BGRA8_SWIZZLE_RG by construction)
+    uint32_t pad;
+};
+INCR_HD uint32_t material_tiles_x(uint32_t w) { return (w + 3u) >> 2; }
+INCR_HD uint64_t material_texel_count(uint32_t w, uint32_t h) { return (uint64_t)material_tiles_x(w) * ((h + 3u) >> 2) * 16u; }
+INCR_HD uint32_t material_texel_index(uint32_t x, uint32_t y, uint32_t w) { return ((y >> 2) * material_tiles_x(w) + (x >> 2)) * 16u + ((y & 3u) << 2) + (x & 3u); }
 
 } // namespace incr

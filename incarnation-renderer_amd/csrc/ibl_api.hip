@@ -29,6 +29,7 @@ extern "C" {
 
 int incr_update_dynamic_sky(incr_context* ctx, const incr_scene* scene, uint32_t envmap_resolution, float turbidity, int32_t storage_rounding,
                             incr_stream stream, incr_sky_ibl** inout_ibl) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!scene || !inout_ibl) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
     const uint32_t N = envmap_resolution;
@@ -85,6 +86,7 @@ int incr_sky_ibl_destroy(incr_context* ctx, incr_sky_ibl* ibl) {
 }
 
 int incr_generate_env_brdf(incr_context* ctx, uint32_t width, uint32_t height, int32_t storage_rounding, void* out_rg16f, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!out_rg16f || !width || !height) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL output or zero size");
     HIP_TRY(incr_launch_env_brdf((uint32_t*)out_rg16f, width, height, 1024, storage_rounding, (hipStream_t)stream));   // renderer.cpp:218

@@ -470,7 +470,9 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 Bt = mul_dir(Bt, localToWorld);
                 const f3 Ntbn = N;
                 const f2 uv = uv0 + bx * (uv1 - uv0) + by * (uv2 - uv0);
-                MatProps matInfo = EvaluateMaterialProperties(P.materials[materialIndex], P.textures, P.srgbLut, uv);
+                const MaterialTexels mtx = P.materialTexels[materialIndex];
+                MatProps matInfo = mtx.texels ? EvaluateMaterialPropertiesInterleaved(P.materials[materialIndex], mtx, P.textures, P.srgbLut, uv)
+                                              : EvaluateMaterialProperties(P.materials[materialIndex], P.textures, P.srgbLut, uv);
                 bool done = false;
                 if (P.viewmode == 1) matInfo.basecolor = mk3(0.5f);
                 else if (P.viewmode == 2) { color = {matInfo.roughness, matInfo.roughness, matInfo.roughness, matInfo.roughness}; done = true; }

@@ -466,6 +466,50 @@ DI f4 level0_finish(const Level0Tap& a, const float* __restrict__ srgbLut, uint3
     r.w = (t00.w * wx0 + t10.w * fx) * wy0 + (t01.w * wx0 + t11.w * fx) * fy;
     return r;
 }
+// The interleaved form (device_types.h MaterialTexels): ONE tap computation and four 8-byte loads for the base colour, the normal and the
+// metallic-roughness sample of a hit.  Texel bytes, decode and filter arithmetic are those of level0_tap / level0_finish channel by
+// channel, so the result equals the texture-by-texture path bit for bit (tests/test_gpu_round3.py).
+DI MatProps EvaluateMaterialPropertiesInterleaved(const incr_material& mat, const MaterialTexels mt, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {
+    const int W = (int)mt.width, H = (int)mt.height;
+    float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
+    if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
+    if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
+    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f, wx0 = 1.f - fx, wy0 = 1.f - fy;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+    const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
+    const uint2* __restrict__ px = (const uint2*)mt.texels;
+    const uint2 c00 = px[material_texel_index((uint32_t)x0, (uint32_t)y0, (uint32_t)W)], c10 = px[material_texel_index((uint32_t)x1, (uint32_t)y0, (uint32_t)W)];
+    const uint2 c01 = px[material_texel_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W)], c11 = px[material_texel_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W)];
+    auto lerp4 = [&](float a, float b, float c, float d) { return (a * wx0 + b * fx) * wy0 + (c * wx0 + d * fx) * fy; };
+    MatProps o;
+    o.emissive = {mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    if (mat.emissiveTextureIndex != -1) { f4 e = SampleLevel0(textures, lut, mat.emissiveTextureIndex, uv); o.emissive = o.emissive * mk3(e.x, e.y, e.z); }
+    {
+        const f4 t00 = decode_texel(lut, mt.baseFormat, c00.x), t10 = decode_texel(lut, mt.baseFormat, c10.x), t01 = decode_texel(lut, mt.baseFormat, c01.x), t11 = decode_texel(lut, mt.baseFormat, c11.x);
+        const f3 b = {lerp4(t00.x, t10.x, t01.x, t11.x), lerp4(t00.y, t10.y, t01.y, t11.y), lerp4(t00.z, t10.z, t01.z, t11.z)};
+        o.basecolor = mk3(mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]) * b;
+        o.opacity = lerp4(t00.w, t10.w, t01.w, t11.w);
+    }
+    const float inv255 = 1.f / 255.f;
+    {   // INCR_TEX_RG_SNORM: 2 * c / 255 - 1 on the R and G bytes (decode_texel)
+        auto sn = [&](uint32_t w, int k) { return 2.f * ((float)((w >> (8 * k)) & 0xffu) * inv255) - 1.f; };
+        const f2 nxy = {lerp4(sn(c00.y, 0), sn(c10.y, 0), sn(c01.y, 0), sn(c11.y, 0)), lerp4(sn(c00.y, 1), sn(c10.y, 1), sn(c01.y, 1), sn(c11.y, 1))};
+        o.bHasNormalmap = true;
+        o.normalmap = {nxy.x, nxy.y, sqrtf(1.f - dot(nxy, nxy))};
+    }
+    {   // INCR_TEX_BGRA8_SWIZZLE_RG: metal = B / 255, roughness = G / 255 (stored as bytes 2 and 3 of the second word)
+        auto un = [&](uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu) * inv255; };
+        o.metallic = lerp4(un(c00.y, 2), un(c10.y, 2), un(c01.y, 2), un(c11.y, 2));
+        o.roughness = lerp4(un(c00.y, 3), un(c10.y, 3), un(c01.y, 3), un(c11.y, 3));
+    }
+    o.aoblend = mat.aoStrength;
+    o.ao = 1.f;
+    if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(textures, lut, mat.aoTextureIndex, uv).x;
+    return o;
+}
 DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv) {
     const int idx[3] = {mat.baseColorTextureIndex, mat.normalTextureIndex, mat.metallicRoughnessTextureIndex};
     DeviceTexture t[3];

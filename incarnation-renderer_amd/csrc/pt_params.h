@@ -21,6 +21,7 @@ struct PtParams {
     const TriShade* __restrict__ shade;
     const incr_material* __restrict__ materials;
     const DeviceTexture* __restrict__ textures;
+    const MaterialTexels* __restrict__ materialTexels;   // per material: interleaved level-0 texels (device_types.h), texels == NULL where not built
     const float* __restrict__ srgbLut;
     const float* __restrict__ meshLocalToWorld;    // 16 floats per mesh: mul(meshTransform, sceneRotation)
     const incr_light* __restrict__ globalLights;

@@ -306,6 +306,7 @@ extern "C" {
 
 // ---------------------------------------------------------------------------------------------- batch culling
 int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -324,6 +325,7 @@ int incr_batch_cull(incr_context* ctx, const incr_batch_cull_desc* d, incr_strea
 
 // ---------------------------------------------------------------------------------------------- light culling
 int incr_light_cull(incr_context* ctx, const incr_light_cull_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -363,6 +365,7 @@ int incr_visibility_get_stats(incr_context* ctx, uint32_t out_counters[4]) {
 }
 
 int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -389,6 +392,7 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
 
 // ---------------------------------------------------------------------------------------------- G-buffer
 int incr_gbuffer(incr_context* ctx, const incr_gbuffer_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -427,6 +431,7 @@ static int fill_sky(const incr_sky_lighting_desc* d, SkyParams& P) {
     return INCR_OK;
 }
 int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     SkyParams P;
@@ -438,6 +443,7 @@ int incr_sky_lighting(incr_context* ctx, const incr_sky_lighting_desc* d, incr_s
 
 // ---------------------------------------------------------------------------------------------- decals
 int incr_gbuffer_decals(incr_context* ctx, const incr_gbuffer_decals_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -472,6 +478,7 @@ int incr_gbuffer_decals(incr_context* ctx, const incr_gbuffer_decals_desc* d, in
 
 // ---------------------------------------------------------------------------------------------- forward lighting
 int incr_forward_lighting(incr_context* ctx, const incr_forward_lighting_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -519,6 +526,7 @@ int incr_forward_lighting(incr_context* ctx, const incr_forward_lighting_desc* d
 
 // ---------------------------------------------------------------------------------------------- HBAO
 int incr_hbao(incr_context* ctx, const incr_hbao_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -548,6 +556,7 @@ static int fill_direct(incr_context* ctx, const incr_direct_lighting_desc* d, Di
     return INCR_OK;
 }
 int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     DirectParams P;
@@ -574,6 +583,7 @@ static int fill_clustered(incr_context* ctx, const incr_clustered_lighting_desc*
     return INCR_OK;
 }
 int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     ClusteredParams P;
@@ -585,6 +595,7 @@ int incr_clustered_lighting(incr_context* ctx, const incr_clustered_lighting_des
 
 // sky + sun + clustered lights in one kernel (raster.hip deferred_lighting_kernel); bit-identical to the three calls in that order
 int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     if (!d->sky && !d->direct && !d->clustered) return INCR_OK;
@@ -609,6 +620,7 @@ int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc*
 
 // ---------------------------------------------------------------------------------------------- dynamic sky background
 int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->scene) return fail(INCR_ERR_INVALID_ARGUMENT, "desc or scene is NULL");
     int rc = check_view(d->view);
@@ -627,6 +639,7 @@ int incr_dynamic_sky(incr_context* ctx, const incr_dynamic_sky_desc* d, incr_str
 }
 
 int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     int rc = check_view(d->view);
@@ -644,6 +657,7 @@ int incr_environmentmap(incr_context* ctx, const incr_environmentmap_desc* d, in
 }
 
 int incr_debug_visualization(incr_context* ctx, const incr_debug_viz_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     int rc = check_view(d->view);
@@ -669,6 +683,7 @@ int incr_debug_visualization(incr_context* ctx, const incr_debug_viz_desc* d, in
 
 // ---------------------------------------------------------------------------------------------- TAA
 int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* d, incr_stream stream) {
+    INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d) return fail(INCR_ERR_INVALID_ARGUMENT, "desc is NULL");
     int rc = check_view(d->view);

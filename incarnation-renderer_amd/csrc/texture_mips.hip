@@ -60,8 +60,33 @@ __global__ __launch_bounds__(256) void mip_tile_kernel(const uint32_t* __restric
     dst[texel_tile_index(x, y, w)] = src[(size_t)y * w + x];
 }
 
+// the inverse, for incr_scene_texture_download: the row-major chains are freed once the tiled copy exists
+__global__ __launch_bounds__(256) void mip_untile_kernel(const uint32_t* __restrict__ src, uint32_t w, uint32_t h, uint32_t* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    dst[(size_t)y * w + x] = src[texel_tile_index(x, y, w)];
+}
+
+// level 0 of a material's three main textures, interleaved (device_types.h MaterialTexels)
+__global__ __launch_bounds__(256) void material_texels_kernel(const uint32_t* __restrict__ base, const uint32_t* __restrict__ normal, const uint32_t* __restrict__ mr,
+                                                              uint32_t w, uint32_t h, uint2* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * w + x;
+    const uint32_t n = normal[i], m = mr[i];
+    dst[material_texel_index(x, y, w)] = make_uint2(base[i], (n & 0xffffu) | (((m >> 16) & 0xffu) << 16) | (((m >> 8) & 0xffu) << 24));      // n.r, n.g, m.b (metal), m.g (roughness)
+}
+
 } // namespace incr
 
+extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::mip_untile_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, src, w, h, dst);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::material_texels_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, base, normal, mr, w, h, (uint2*)dst);
+    return hipGetLastError();
+}
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {
     hipLaunchKernelGGL(incr::mip_tile_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, src, w, h, dst);
     return hipGetLastError();

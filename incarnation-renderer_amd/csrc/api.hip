@@ -513,7 +513,7 @@ int incr_scene_texture_download(incr_context* ctx, const incr_scene* sc, uint32_
 int incr_scene_get_info(incr_context* ctx, const incr_scene* sc, incr_scene_info* info) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc || !info) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
-    info->num_triangles = sc->bvh.tris.size();
+    info->num_triangles = sc->bvh.numTriangles;
     info->num_bvh_nodes = sc->bvh.nodes8.size();
     info->bvh_bytes = sc->bvh.nodes8.size() * sizeof(BvhNode8);
     info->triangle_bytes = sc->bvh.tris.size() * sizeof(TriIsect);
@@ -670,7 +670,7 @@ int incr_scene_validate_host(const incr_scene_desc* desc, incr_scene_info* info)
     const char* err = check_bvh(bvh);
     if (err) return fail(INCR_ERR_INVALID_ARGUMENT, "BVH invariant violated: %s", err);
     memset(info, 0, sizeof *info);
-    info->num_triangles = bvh.tris.size(); info->num_bvh_nodes = bvh.nodes8.size();
+    info->num_triangles = bvh.numTriangles; info->num_bvh_nodes = bvh.nodes8.size();
     info->bvh_bytes = bvh.nodes8.size() * sizeof(BvhNode8); info->triangle_bytes = bvh.tris.size() * sizeof(TriIsect);
     info->shading_bytes = bvh.shade.size() * sizeof(TriShade);
     info->num_instances = bvh.numInstances; info->bvh_max_depth = bvh.maxDepth;

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void bvh_retransform_kernel(uint32_t n, const 
     const float4* sp = (const float4*)(src + i);
     const float4 a = sp[0], b = sp[1], c = sp[2];
     const uint32_t mesh = __float_as_uint(c.y), flags = __float_as_uint(c.z);
+    if (mesh == kTriHole) return;                          // hole slot of a leaf (device_types.h LEAF SLOTS): stays the NaN record it was built as
     const MeshInstanceInfo mi = meshInfo[mesh];
     const float* __restrict__ M = meshLocalToWorld + (size_t)mesh * 16;
     float4 o0, o1, o2;
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(64) void bvh_refit_level_kernel(const uint32_t* __r
             const NodeBox b = boxes[nd.childBase + k];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { bl[a] = b.lo[a]; bh[a] = b.hi[a]; }
-        } else if (nd.meta[k]) {
-            const uint32_t first = nd.triBase + (nd.meta[k] & 31u), cnt = nd.meta[k] >> 5;
+        } else if ((nd.leafTris >> (4 * k)) & 15u) {
+            const uint32_t first = nd.triBase + 4u * (uint32_t)k, cnt = (uint32_t)__popc((nd.leafTris >> (4 * k)) & 15u);
             for (uint32_t t = first; t < first + cnt; ++t) {
                 const TriIsect T = tris[t];
                 const float vx[3] = {T.v0x, T.v0x + T.e1x, T.v0x + T.e2x}, vy[3] = {T.v0y, T.v0y + T.e1y, T.v0y + T.e2y}, vz[3] = {T.v0z, T.v0z + T.e1z, T.v0z + T.e2z};

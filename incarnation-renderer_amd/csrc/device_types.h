@@ -18,9 +18,10 @@ struct alignas(16) BvhNode8 {
     float ox, oy, oz;            // node box minimum
     uint8_t ex, ey, ez, imask;   // per-axis scale exponent (IEEE biased), bit k of imask: child k is an inner node
     uint32_t childBase;          // inner child in slot k is node childBase + k (see SLOT ORDER)
-    uint32_t triBase;            // triangles of the leaf children are stored contiguously from here
-    uint8_t meta[8];             // leaf child: (count << 5) | offset from triBase (count 1..4, offset <= 28); empty: 0;
-                                 // inner: 0, except meta[0] = the node's sort axis (0..2) when slot 0 is inner
+    uint32_t triBase;            // the triangle of bit i of `leafTris` is record triBase + i (see LEAF SLOTS)
+    uint32_t leafTris;           // bit 4 k + j: the leaf child in slot k owns a j-th triangle (count <= 4: the low `count` bits of nibble k);
+                                 // nibbles of inner and empty slots are 0
+    uint8_t sortAxis, pad[3];    // the axis (0..2) the inner children are sorted along (SLOT ORDER)
     uint8_t qlox[8], qloy[8], qloz[8];
     uint8_t qhix[8], qhiy[8], qhiz[8];
 };
@@ -28,6 +29,12 @@ struct alignas(16) BvhNode8 {
 // centre along the node's longest axis (the "sort axis"); leaf children follow, empty slots last.  A traversal stack
 // entry can then name ALL pending inner children of a node in one word: childBase << 9 | reverse << 8 | slot mask --
 // the stack never holds more than one entry per tree level, so it fits LDS for any tree (kMaxBvhDepth).
+// LEAF SLOTS: the leaf child in slot k owns the four triangle records triBase + 4 k .. triBase + 4 k + 3 (triBase is biased by
+// -4 x the number of inner children, modulo 2^32, so that the first leaf's records follow the previous node's), of which the first
+// `count` are triangles and the rest are HOLES (NaN records no ray can hit, flatId 0xffffffff; TriObject::mesh 0xffffffff).  The
+// traversal's "which triangles of this node does the ray have to test" is then a bit operation on the 8-bit child hit mask --
+// every hit bit widened to a nibble, ANDed with leafTris: 8 VALU instructions -- where (count, offset) bytes per child cost a
+// divergent loop over the hit leaves (~14 instructions per round, 3-4 rounds per wave: a tenth of the VALU-bound traversal step).
 static constexpr uint32_t kMaxBvhNodes = 1u << 23;     // childBase must fit 23 bits of a stack entry
 static constexpr uint32_t kMaxBvhDepth = 25;           // deepest tree the traversal kernels carry a stack for (24 entries)
 static_assert(sizeof(BvhNode8) == 80, "node8 must be 5 x 16 bytes");
@@ -36,6 +43,8 @@ static_assert(sizeof(BvhNode8) == 80, "node8 must be 5 x 16 bytes");
 #define INCR_MAX_LEAF_TRIS 4
 #endif
 static constexpr uint32_t kMaxLeafTris = INCR_MAX_LEAF_TRIS;
+static_assert(INCR_MAX_LEAF_TRIS >= 1 && INCR_MAX_LEAF_TRIS <= 4, "a leaf child owns one nibble of BvhNode8::leafTris");
+static constexpr uint32_t kTriHole = 0xffffffffu;      // TriIsect::flatId / TriObject::mesh of a hole record
 
 // Intersection record, leaf order, 48 B (3 x dwordx4).  World-space v0 and edges (Moeller-Trumbore).
 struct alignas(16) TriIsect {

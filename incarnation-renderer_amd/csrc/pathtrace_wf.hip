@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
             for (int k = 0; k < 8; ++k) any |= (__ballot((mine >> k) & 1u) != 0ull) ? (1u << k) : 0u;
             const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
             Node8 U = N; U.hitMask = any; U.imask = imask;
-            U.meta0 = __builtin_amdgcn_readfirstlane(N.meta0); U.meta1 = __builtin_amdgcn_readfirstlane(N.meta1);
+            U.leafTris = __builtin_amdgcn_readfirstlane(N.leafTris); U.sortAxis = __builtin_amdgcn_readfirstlane(N.sortAxis);
             uint32_t triMask = node8_tri_mask(U);
             const uint32_t triBase = __builtin_amdgcn_readfirstlane(N.triBase);
             while (triMask) {
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
                 }
                 const uint32_t rest = inner & ~(1u << nearK);
                 if (rest) {
-                    const uint32_t axis = U.meta0 & 3u;
+                    const uint32_t axis = U.sortAxis;
                     if (sp < kPacketStack) stack[sp++] = stack_entry(childBase, (leadNeg >> axis) & 1u, rest);
                 }
                 cur = childBase + nearK; haveCur = true;

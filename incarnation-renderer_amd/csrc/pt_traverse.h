@@ -114,7 +114,7 @@ struct RaySetup { f3 o, invd; };
 DI RaySetup ray_setup(f3 o, f3 d) { return {o, {1.f / d.x, 1.f / d.y, 1.f / d.z}}; }
 
 struct Node8 {              // decoded header of one node + the hit mask / entry distances of its children
-    uint32_t imask, childBase, triBase, meta0, meta1;
+    uint32_t imask, childBase, triBase, leafTris, sortAxis;
     uint32_t hitMask;       // bit k: the ray interval overlaps child k's (conservative) box
     float tn[8];            // entry distance per child (valid where hitMask is set)
 };
@@ -129,7 +129,7 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     const uint32_t em = __float_as_uint(n0.w);
     N.imask = em >> 24;
     N.childBase = __float_as_uint(n1.x); N.triBase = __float_as_uint(n1.y);
-    N.meta0 = __float_as_uint(n1.z); N.meta1 = __float_as_uint(n1.w);
+    N.leafTris = __float_as_uint(n1.z); N.sortAxis = __float_as_uint(n1.w) & 3u;
     const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float(((em >> 8) & 0xffu) << 23), sz = __uint_as_float(((em >> 16) & 0xffu) << 23);
     const float ax = sx * r.invd.x, ay = sy * r.invd.y, az = sz * r.invd.z;
     const float bx = (n0.x - r.o.x) * r.invd.x, by = (n0.y - r.o.y) * r.invd.y, bz = (n0.z - r.o.z) * r.invd.z;
@@ -159,7 +159,7 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
         N.tn[k] = t0;
         hit |= (t0 <= t1) ? (1u << k) : 0u;
     }
-    // A slot without a child may come out as "hit": it is not an inner node (imask) and its meta byte is 0, so it adds
+    // A slot without a child may come out as "hit": it is not an inner node (imask) and its nibble of leafTris is 0, so it adds
     // neither a node to visit nor a triangle to test -- no separate existence mask is needed (dropping it: +3 % rays/s).
     // (v_pk_fma_f32 for the plane fmas -- child pairs in round 1, the near/far pair of one child in round 2, 24 packed for 48
     // scalar fmas and 5 % fewer VALU instructions in the kernel -- measured -7 % and -9 %: a packed fp32 fma issues no faster
@@ -167,18 +167,17 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     // pairs (1024 + q) for v_fma_mix_f32 -- 24 perms + 48 mixed fmas for 48 converts + 48 fmas: shadow 9.1 -> 9.8 ms.)
     N.hitMask = hit;
 }
-DI uint32_t node8_meta(const Node8& N, uint32_t k) { return ((k < 4u ? N.meta0 : N.meta1) >> (8u * (k & 3u))) & 0xffu; }
 DI uint32_t node8_child(const Node8& N, uint32_t k) { return N.childBase + k; }      // SLOT ORDER: inner children sit in slots 0 .. n-1
-// bit i set <=> triangle triBase + i belongs to a leaf child whose box the ray overlaps
-DI uint32_t node8_tri_mask(const Node8& N) {
-    uint32_t leaves = N.hitMask & ~N.imask, m = 0u;
-    while (leaves) {
-        const uint32_t k = (uint32_t)__builtin_ctz(leaves); leaves &= leaves - 1u;
-        const uint32_t meta = node8_meta(N, k);
-        m |= ((1u << (meta >> 5)) - 1u) << (meta & 31u);
-    }
-    return m;
+// bit i set <=> triangle record triBase + i belongs to a leaf child whose box the ray overlaps (device_types.h LEAF SLOTS): every
+// hit bit widened to its nibble (three shift-or-mask rounds and a multiplication by 15), ANDed with the node's triangle mask.
+// Inner and empty slots have empty nibbles, so their hit bits need no masking.
+DI uint32_t spread_nibbles(uint32_t x) {          // bit k (k < 8) -> bits 4 k .. 4 k + 3
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return (x << 4) - x;
 }
+DI uint32_t node8_tri_mask(const Node8& N) { return spread_nibbles(N.hitMask) & N.leafTris; }
 
 // One fetch per step: 80 bytes at the node, or 48 at the pending triangle (the last two dwordx4 are only issued by lanes on a
 // node step).  Measured on MI355X (tools/microbench/gather_lanes.hip): a divergent dwordx4 gather costs the vector L1 one
@@ -275,7 +274,7 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
             const uint32_t nearK = m1 & 7u;
             const uint32_t rest = inner & ~(1u << nearK);
             if (rest) {
-                const uint32_t axis = N.meta0 & 3u;                  // meta[0] of a node whose slot 0 is inner = its sort axis
+                const uint32_t axis = N.sortAxis;
                 st.push(stack_entry(N.childBase, (T.negDir >> axis) & 1u, rest), __uint_as_float(m2 & ~7u));
             }
             T.cur = N.childBase + nearK; T.curKey = __uint_as_float(m1 & ~7u);
@@ -348,7 +347,7 @@ template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravCl
             const uint32_t nearK = m1 & 7u;
             const uint32_t rest = inner & ~(1u << nearK);
             if (rest) {
-                const uint32_t axis = N.meta0 & 3u;
+                const uint32_t axis = N.sortAxis;
                 st.push(stack_entry(N.childBase, (T.negDir >> axis) & 1u, rest), __uint_as_float(m2 & ~7u));
             }
             T.cur = N.childBase + nearK; T.curKey = __uint_as_float(m1 & ~7u);

@@ -835,7 +835,7 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
         for (int k = 0; k < 8; ++k) any |= (__ballot((mine >> k) & 1u) != 0ull) ? (1u << k) : 0u;
         const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
         Node8 U = N; U.hitMask = any; U.imask = imask;
-        U.meta0 = __builtin_amdgcn_readfirstlane(N.meta0); U.meta1 = __builtin_amdgcn_readfirstlane(N.meta1);
+        U.leafTris = __builtin_amdgcn_readfirstlane(N.leafTris); U.sortAxis = __builtin_amdgcn_readfirstlane(N.sortAxis);
         uint32_t triMask = node8_tri_mask(U);
         const uint32_t triBase = __builtin_amdgcn_readfirstlane(N.triBase);
         while (triMask) {

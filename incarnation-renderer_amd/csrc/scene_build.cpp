@@ -378,10 +378,10 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                 ebits[a] = (uint8_t)e;
             }
             nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
-            nd.triBase = (uint32_t)leafOrder.size();
             nd.childBase = (uint32_t)out.nodes8.size();
             uint32_t numInner = 0;
             for (int k = 0; k < nk; ++k) if (!is_leaf(kids[k])) ++numInner;
+            nd.triBase = (uint32_t)leafOrder.size() - 4u * numInner;          // LEAF SLOTS (device_types.h): the leaf in slot k owns records triBase + 4 k .. + 3
             out.nodes8.resize(out.nodes8.size() + numInner);
             uint32_t innerSlot = 0;
             uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
@@ -397,11 +397,11 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                     qlo[a][k] = (uint8_t)lo; qhi[a][k] = (uint8_t)hi;
                 }
                 if (is_leaf(kids[k])) {
-                    nd.meta[k] = (uint8_t)((c.spanCount << 5) | ((uint32_t)leafOrder.size() - nd.triBase));
-                    for (uint32_t t = c.spanFirst; t < c.spanFirst + c.spanCount; ++t) leafOrder.push_back(b.order[t]);
+                    nd.leafTris |= ((1u << c.spanCount) - 1u) << (4 * k);
+                    for (uint32_t t = 0; t < 4u; ++t) leafOrder.push_back(t < c.spanCount ? b.order[c.spanFirst + t] : kTriHole);
                 } else { nd.imask |= (uint8_t)(1u << k); work8.push_back({kids[k], nd.childBase + innerSlot, it.depth + 1}); ++innerSlot; }
             }
-            if (nd.imask & 1u) nd.meta[0] = (uint8_t)sortAxis;
+            nd.sortAxis = (uint8_t)sortAxis;
             out.nodes8[it.n8] = nd;
         }
     } else {
@@ -454,8 +454,19 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
       for (uint32_t i = 0; i < (uint32_t)nodeDepth.size(); ++i) out.levelNodes[fill[nodeDepth[i] - 1]++] = i; }
 
     // 4. emit triangles + shading records in leaf order
-    out.tris.resize(n); out.shade.resize(n); out.triObj.resize(n);
-    for (size_t i = 0; i < n; ++i) {
+    const size_t slots = leafOrder.size();                 // triangles + holes (device_types.h LEAF SLOTS)
+    out.numTriangles = (uint32_t)n;
+    out.tris.resize(slots); out.shade.resize(slots); out.triObj.resize(slots);
+    for (size_t i = 0; i < slots; ++i) {
+        if (leafOrder[i] == kTriHole) {
+            const float qnan = std::numeric_limits<float>::quiet_NaN();
+            TriObject& ob = out.triObj[i]; memset(&ob, 0, sizeof ob); ob.mesh = kTriHole; ob.flatId = kTriHole;
+            TriIsect& t = out.tris[i];
+            t.v0x = t.v0y = t.v0z = t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = qnan;
+            t.flatId = kTriHole; t.flags = 0; t.pad = 0;
+            memset(&out.shade[i], 0, sizeof(TriShade));
+            continue;
+        }
         const Flat& f = flat[leafOrder[i]];
         TriObject& ob = out.triObj[i];
         ob.p0x = f.obj[0].x; ob.p0y = f.obj[0].y; ob.p0z = f.obj[0].z; ob.p1x = f.obj[1].x; ob.p1y = f.obj[1].y; ob.p1z = f.obj[1].z;
@@ -488,13 +499,19 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
 
 const char* check_bvh(const HostBvh& bvh) {
     static thread_local char msg[160];
-    const size_t n = bvh.tris.size();
+    const size_t n = bvh.tris.size();                       // record slots: triangles + holes
     if (bvh.nodes8.empty()) return "no root node";
     if (bvh.shade.size() != n) return "shading records != triangles";
+    if (bvh.numTriangles > n) return "more triangles than records";
     if (bvh.nodes8.size() > kMaxBvhNodes) return "more nodes than a traversal stack entry can address (2^23)";
     if (bvh.maxDepth > kMaxBvhDepth) return "tree deeper than the traversal stack (25 levels)";
     std::vector<uint8_t> seen(n, 0), seenFlat(n, 0);
-    for (size_t i = 0; i < n; ++i) { if (bvh.tris[i].flatId >= n || seenFlat[bvh.tris[i].flatId]) return "flatId is not a permutation"; seenFlat[bvh.tris[i].flatId] = 1; }
+    size_t holes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (bvh.tris[i].flatId == kTriHole) { ++holes; if (bvh.tris[i].v0x == bvh.tris[i].v0x) return "hole record is not NaN"; continue; }
+        if (bvh.tris[i].flatId >= bvh.numTriangles || seenFlat[bvh.tris[i].flatId]) return "flatId is not a permutation"; seenFlat[bvh.tris[i].flatId] = 1;
+    }
+    if (n - holes != bvh.numTriangles) return "triangle count does not match the records";
     struct Item { uint32_t node; Box parent; bool hasParent; };
     std::vector<Item> st; st.push_back({0u, {}, false});
     std::vector<uint8_t> visited(bvh.nodes8.size(), 0);
@@ -511,15 +528,19 @@ const char* check_bvh(const HostBvh& bvh) {
         const uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; const uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
         uint32_t innerSlot = 0;
         if (nd.imask & (nd.imask + 1u)) return "inner children are not in the lowest slots";
-        if ((nd.imask & 1u) && nd.meta[0] > 2) return "sort axis out of range";
+        if (nd.sortAxis > 2) return "sort axis out of range";
         for (int k = 0; k < 8; ++k) {
-            const bool inner = (nd.imask >> k) & 1u, leaf = !inner && nd.meta[k] != 0;
+            const uint32_t nib = (nd.leafTris >> (4 * k)) & 15u;
+            const bool inner = (nd.imask >> k) & 1u, leaf = !inner && nib != 0;
+            if (inner && nib) return "inner child with triangles";
+            if (nib & (nib + 1u)) return "leaf triangles are not the low bits of their nibble";
             if (!inner && !leaf) continue;
             Box bx;
             for (int a = 0; a < 3; ++a) { bx.lo[a] = org[a] + (float)qlo[a][k] * scale[a]; bx.hi[a] = org[a] + (float)qhi[a][k] * scale[a]; }
             if (leaf) {
-                const uint32_t first = nd.triBase + (nd.meta[k] & 31u), cnt = nd.meta[k] >> 5;
+                const uint32_t first = nd.triBase + 4u * (uint32_t)k, cnt = (uint32_t)__builtin_popcount(nib);
                 if (cnt == 0 || cnt > kMaxLeafTris) return "leaf count out of range";
+                for (uint32_t t = first + cnt; t < first + 4u; ++t) { if (t >= n || bvh.tris[t].flatId != kTriHole) return "leaf slot beyond the count is not a hole"; seen[t] = 1; }
                 for (uint32_t t = first; t < first + cnt; ++t) {
                     if (t >= n) return "leaf range out of bounds";
                     if (seen[t]) return "triangle in two leaves";

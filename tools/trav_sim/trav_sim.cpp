@@ -40,10 +40,10 @@ static void node_test(const BvhNode8& n, const Ray& r, const float invd[3], floa
         if (t0 <= t1) N.hit |= 1u << c;
     }
 }
-static uint32_t tri_mask(const BvhNode8& n, uint32_t hit) {
-    uint32_t leaves = hit & ~n.imask, m = 0;
-    for (int k = 0; k < 8; ++k) if ((leaves >> k) & 1u) { const uint32_t meta = n.meta[k]; m |= ((1u << (meta >> 5)) - 1u) << (meta & 31u); }
-    return m;
+static uint32_t tri_mask(const BvhNode8& n, uint32_t hit) {          // device_types.h LEAF SLOTS: hit bits widened to nibbles
+    uint32_t m = 0;
+    for (int k = 0; k < 8; ++k) if ((hit >> k) & 1u) m |= 15u << (4 * k);
+    return m & n.leafTris;
 }
 static bool tri_isect(const TriIsect& T, const Ray& r, float tmax, float* t) {
     const float e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z}, v0[3] = {T.v0x, T.v0y, T.v0z};
@@ -208,35 +208,10 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
 // Slot order: inner children first (slot k of an inner child <=> node childBase + k), optionally sorted along the
 // node's longest axis by child-box centre (sortAxis[node] is recorded for the reversal trick).
 static void reorder(HostBvh& B, std::vector<uint8_t>& sortAxis, bool sortByAxis) {
+    // the builder emits this order itself since round 2 (scene_build.cpp SLOT ORDER): only the axis table is left to fill
+    (void)sortByAxis;
     sortAxis.assign(B.nodes8.size(), 0);
-    // process parents before children is not required: every swap stays inside one node's contiguous child block
-    for (size_t ni = 0; ni < B.nodes8.size(); ++ni) {
-        BvhNode8 n = B.nodes8[ni];
-        int ax = 0;
-        { const uint8_t e[3] = {n.ex, n.ey, n.ez}; if (e[1] > e[ax]) ax = 1; if (e[2] > e[ax]) ax = 2; }
-        sortAxis[ni] = (uint8_t)ax;
-        const uint8_t* qlo[3] = {n.qlox, n.qloy, n.qloz}; const uint8_t* qhi[3] = {n.qhix, n.qhiy, n.qhiz};
-        struct C { int slot; bool inner, leaf; int key; };
-        C c[8];
-        for (int k = 0; k < 8; ++k) c[k] = {k, (bool)((n.imask >> k) & 1u), n.meta[k] != 0, (int)qlo[ax][k] + (int)qhi[ax][k]};
-        std::stable_sort(c, c + 8, [&](const C& a, const C& b) {
-            const int ca = a.inner ? 0 : a.leaf ? 1 : 2, cb = b.inner ? 0 : b.leaf ? 1 : 2;
-            if (ca != cb) return ca < cb;
-            if (sortByAxis && a.key != b.key) return a.key < b.key;
-            return false;
-        });
-        BvhNode8 m = n; m.imask = 0;
-        std::vector<BvhNode8> kids;
-        for (int k = 0; k < 8; ++k) {
-            const int s = c[k].slot;
-            m.meta[k] = n.meta[s];
-            m.qlox[k] = n.qlox[s]; m.qloy[k] = n.qloy[s]; m.qloz[k] = n.qloz[s];
-            m.qhix[k] = n.qhix[s]; m.qhiy[k] = n.qhiy[s]; m.qhiz[k] = n.qhiz[s];
-            if (c[k].inner) { m.imask |= (uint8_t)(1u << k); kids.push_back(B.nodes8[child_index(n, (uint32_t)s)]); }
-        }
-        for (size_t k = 0; k < kids.size(); ++k) B.nodes8[n.childBase + k] = kids[k];
-        B.nodes8[ni] = m;
-    }
+    for (size_t ni = 0; ni < B.nodes8.size(); ++ni) sortAxis[ni] = B.nodes8[ni].sortAxis;
 }
 
 // ---- wave-scheduling model ---------------------------------------------------------------------------

@@ -285,7 +285,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
     WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
     bool active = false; uint32_t slot = 0;
-    TravClosest2 T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f); T.triBase1 = 0; T.triMask1 = 0;
+    TravClosest2 T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f, 10000.0f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     uint32_t rays = 0;
     LANE_STATS(LaneStats ls;)
     // (The software-pipelined form of wf_shadow_kernel -- loads issued by the refill, rays started after the step, hits stored
@@ -749,7 +749,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0, nextIndex = 0;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-    TravAny2 T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f, 0.f); T.triBase1 = 0; T.triMask1 = 0;
+    TravAny2 T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.1f, 1000.f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     LANE_STATS(LaneStats ls;)
     for (;;) {
         const unsigned long long act = __ballot(active);

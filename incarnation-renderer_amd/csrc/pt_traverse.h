@@ -135,7 +135,7 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     const float bx = (n0.x - r.o.x) * r.invd.x, by = (n0.y - r.o.y) * r.invd.y, bz = (n0.z - r.o.z) * r.invd.z;
     // margins: 0.02 quantum + 2^-22 |b| for the rounding of a, b and the fma, plus the 1 + 4e-7 widening of the far distance
     // (Ize 2013) folded in -- |t| <= 255 |a| + |b| on every plane -- so that no child pays a multiply for it
-    const float mx = 0.0202f * fabsf(ax) + 6.4e-7f * fabsf(bx), my = 0.0202f * fabsf(ay) + 6.4e-7f * fabsf(by), mz = 0.0202f * fabsf(az) + 6.4e-7f * fabsf(bz);
+    const float mx = __builtin_fmaf(fabsf(bx), 6.4e-7f, 0.0202f * fabsf(ax)), my = __builtin_fmaf(fabsf(by), 6.4e-7f, 0.0202f * fabsf(ay)), mz = __builtin_fmaf(fabsf(bz), 6.4e-7f, 0.0202f * fabsf(az));
     const float tmaxW = tmax * 1.0000004f;
     const float bnx = bx - mx, bfx = bx + mx, bny = by - my, bfy = by + my, bnz = bz - mz, bfz = bz + mz;
     // near planes: lo bytes when the direction component is >= 0, hi bytes otherwise

@@ -197,7 +197,8 @@ template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32
             return f;
         }
     }
-    const float4* __restrict__ p = triMask ? (const float4*)(P.tris + triBase + (uint32_t)__builtin_ctz(triMask))
+    const uint32_t ti = triBase + (uint32_t)__builtin_ctz(triMask | 0x80000000u);      // 32-bit sum: triBase is biased modulo 2^32 (device_types.h LEAF SLOTS)
+    const float4* __restrict__ p = triMask ? (const float4*)(P.tris + ti)
                                            : (const float4*)P.nodes + (size_t)cur * 5;
     f.a = p[0]; f.b = p[1]; f.c = p[2];
     if (!triMask) { f.d = p[3]; f.e = p[4]; } else { f.d = f.c; f.e = f.c; }
@@ -423,7 +424,7 @@ template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& 
     const bool wantTri = T.triMask != 0u;
     const bool wantNode = T.haveCur && T.triMask1 == 0u;
     float4 ta, tb, tc;                   // deliberately not initialised: only read under the condition they are loaded under (zeroing cost 12 v_mov per iteration)
-    if (wantTri) { const float4* __restrict__ tp = (const float4*)(P.tris + T.triBase + (uint32_t)__builtin_ctz(T.triMask)); ta = tp[0]; tb = tp[1]; tc = tp[2]; }
+    if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
     Fetch5 f;                            // as above (20 v_mov)
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
     if (wantTri) {

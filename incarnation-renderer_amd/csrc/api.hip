@@ -82,7 +82,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 8u;
     const char* se = getenv("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
     ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
-    memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0;
+    memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0; ctx->wfStage = nullptr; ctx->wfStageBytes = 0;
     // pipelines of a path-traced frame (pathtrace_wf.hip): independent bands of tile rows on concurrent streams
     const char* pe = getenv("INCR_WF_PIPELINES");
     ctx->wfPipesWanted = pe ? std::min(std::max(atoi(pe), 1), kMaxPipes) : INCR_WF_PIPELINES_DEFAULT;
@@ -102,6 +102,7 @@ int incr_teardown(incr_context* ctx) {
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->statStripes) (void)hipFree(ctx->statStripes);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
+    if (ctx->wfStage) (void)hipFree(ctx->wfStage);
     for (int i = 1; i < kMaxPipes; ++i) { if (ctx->wfStreams[i]) (void)hipStreamDestroy(ctx->wfStreams[i]); if (ctx->wfJoin[i]) (void)hipEventDestroy(ctx->wfJoin[i]); }
     if (ctx->wfFork) (void)hipEventDestroy(ctx->wfFork);
     if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
@@ -228,11 +229,11 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned) per pipeline.
 // 272 B of path state + raysPerPath x 48 B of shadow-ray queue per pixel: 5.4 GB at 4K -- 1.9 % of the 288 GB.
 // A pipeline owns a band of 8-pixel tile rows (equal shares; a frame of fewer tile rows than pipelines uses fewer).
-static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, hipStream_t stream) {
-    const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u;
+static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, uint32_t numSamples, hipStream_t stream) {
+    const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u * numSamples;       // samples in flight: the tile rows of one sample after the other
     // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
     // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
-    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : ((uint64_t)W * localRows >= 1500000ull ? 2u : 4u);
+    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u);
     const int pipes = (int)std::max(1u, std::min<uint32_t>(wanted, tilesY / 4u));      // >= 4 tile rows each
     ctx->wfPipes = pipes;
     for (int i = 1; i < pipes; ++i) if (!ctx->wfStreams[i]) {
@@ -622,8 +623,22 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.stats = d->ray_stats;
     P.statStripes = ctx->statStripes;     // the wavefront kernels count through the striped counters
     upload_grid_params(sc, P);
-    int rc = ensure_wf_workspace(ctx, P.W, P.localRows, (hipStream_t)stream);
+    P.numSamples = std::max(d->num_samples, 1u);
+    P.localPixels = P.localRows * P.W;
+    P.divLocalPixels = make_fastdiv(std::max(P.localPixels, 1u));
+    if ((uint64_t)P.localPixels * P.numSamples > 0x7fffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "num_samples %u x %u local pixels overflows the path index", P.numSamples, P.localPixels);
+    int rc = ensure_wf_workspace(ctx, P.W, P.localRows, P.numSamples, (hipStream_t)stream);
     if (rc) return rc;
+    if (P.numSamples > 1u) {        // the samples' parking surface (RGBA16F bits per sample and local pixel), library-owned, grown on demand
+        const uint64_t needStage = (uint64_t)P.localPixels * P.numSamples * 8u;
+        if (ctx->wfStageBytes < needStage) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            if (ctx->wfStage) { HIP_TRY(hipFree(ctx->wfStage)); ctx->wfStage = nullptr; ctx->wfStageBytes = 0; }
+            HIP_TRY(hipMalloc(&ctx->wfStage, needStage));
+            ctx->wfStageBytes = needStage;
+        }
+        P.sampleStage = (uint2*)ctx->wfStage;
+    }
     hipEvent_t* ev = nullptr;
     if (ctx->profiling) {       // one record of kMaxPipes x 22 events per call, whatever the pipeline count
         const size_t perCall = (size_t)kProfEvents * kMaxPipes;

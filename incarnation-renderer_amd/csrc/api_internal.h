@@ -44,6 +44,8 @@ struct incr_context {
     hipEvent_t wfFork, wfJoin[8];
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
+    void* wfStage;            // incr_pathtrace_desc::num_samples > 1: RGBA16F bits per sample in flight and local pixel
+    uint64_t wfStageBytes;
     bool profiling;                                   // incr_profile_begin .. incr_profile_end
     std::vector<hipEvent_t> profEvents;               // 22 per recorded incr_pathtrace call
     size_t profFrames;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void bvh_retransform_kernel(uint32_t n, const 
     }
     float4* dp = (float4*)(tris + i);
     dp[0] = o0; dp[1] = o1; dp[2] = o2;
-    shade[i].instance = mi.instance;
+    shade[__float_as_uint(c.w)].instance = mi.instance;          // shading records are indexed by flattened triangle id
 }
 
 // Smallest biased exponent e with lo + 255 * 2^(e - 127) >= hi in float arithmetic (the builder's rule, scene_build.cpp).

@@ -63,7 +63,9 @@ struct alignas(16) TriObject {
 };
 static_assert(sizeof(TriObject) == 48, "tri source record");
 
-// Shading record, leaf order, 128 B: object-space vertex attributes exactly as the accessor fetchers return them.
+// Shading record, indexed by FLATTENED TRIANGLE ID (TriIsect::flatId -- what a closest-hit query reports), 128 B: object-space vertex
+// attributes exactly as the accessor fetchers return them.  (Not leaf order: the leaf-order arrays carry hole records, and a hit
+// reads one record at random whatever the order.)
 struct alignas(128) TriShade {
     float n[3][3];          // GetFloat3(normalAccessor)   (0 when accessor == -1)
     float t[3][4];          // GetFloat4(tangentAccessor)

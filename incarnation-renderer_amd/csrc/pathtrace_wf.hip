@@ -206,26 +206,28 @@ template <uint32_t kChunk> struct WaveChunk {
 };
 
 // ------------------------------------------------------------------------------------------------ generate
-__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tileBase) {
+__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     for (uint32_t base = blockIdx.x * kWfBlock; base < total; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
         // 8x8 pixel tile per wave: the primary rays of a wave walk the same BVH lines
+        // samples in flight: the tile rows of sample s follow those of sample s - 1 (tilesY rows each)
         const uint32_t tile = (i >> 6) + tileBase, w = i & 63u;
-        const uint32_t px = (tile % tilesX) * 8u + (w & 7u), ly = (tile / tilesX) * 8u + (w >> 3);
+        const uint32_t tyv = tile / tilesX, smp = tyv / tilesY;
+        const uint32_t px = (tile - tyv * tilesX) * 8u + (w & 7u), ly = (tyv - smp * tilesY) * 8u + (w >> 3);
         bool valid = i < total && px < P.W && ly < P.localRows;
         uint32_t pid = 0;
         float4 rayO = make_float4(0.f, 0.f, 0.f, 0.f), rayD = rayO;
         if (valid) {
             const int64_t gy = shard_global_row(P, ly);
-            if (gy < 0) { store_pixel(P, px, ly, {0.f, 0.f, 0.f, 0.f}); valid = false; }     // shard padding row
+            if (gy < 0) { store_pixel(P, px, ly, smp, {0.f, 0.f, 0.f, 0.f}); valid = false; }     // shard padding row
             else {
-                pid = ly * P.W + px;
-                const uint32_t pixelIdx = (uint32_t)gy * P.W + px;
+                pid = smp * P.localPixels + ly * P.W + px;
+                const uint32_t pixelIdx = (uint32_t)gy * P.W + px, sampleIdx = P.sampleIdx + smp;
                 uint32_t raygenSampleSetIdx = 0;      // rgsMain -- pathtracing.hlsl:89-119
-                const f2 subPixelJitter = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
-                const f2 apertureSample = SamplePoint(pixelIdx, P.sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
+                const f2 subPixelJitter = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
+                const f2 apertureSample = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
                 const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
                 rayO = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pid));
                 rayD = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
@@ -272,7 +274,10 @@ extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
 #endif
 
 // ------------------------------------------------------------------------------------------------ extend
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 12 ? 6 : (N <= 16 ? 4 : 3))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+#ifndef INCR_EXTEND_WAVES10
+#define INCR_EXTEND_WAVES10 6
+#endif
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3)))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float s_keys[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kExtend * 5];
@@ -309,7 +314,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
         if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
         if (active && trav_closest_step2(P, st, T)) {           // node step and triangle step in one iteration (pt_traverse.h)
-            B.hit[slot] = T.found ? make_uint4(T.bestTri, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
+            B.hit[slot] = T.found ? make_uint4(T.bestFlat, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
                                  : make_uint4(kMissTri, 0u, 0u, 0u);
             active = false;
         }
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
     if (have) { const float4 ro = B.extA[(size_t)slot * 2], rd = B.extA[(size_t)slot * 2 + 1]; o = {ro.x, ro.y, ro.z}; d = {rd.x, rd.y, rd.z}; }
     const RaySetup rs = ray_setup(o, d);
     const float tmin = 0.001f;                                      // TMin / TMax of TraceRay (common.hlsli:49-50)
-    float best = 10000.0f, bu = 0.f, bv = 0.f; uint32_t bestFlat = 0xffffffffu, bestTri = 0; bool found = false;
+    float best = 10000.0f, bu = 0.f, bv = 0.f; uint32_t bestFlat = 0xffffffffu; bool found = false;
     const uint32_t negDir = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
     const unsigned long long haveMask = __ballot(have);
     if (haveMask != 0ull) {
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
                     const bool better = found ? (t < best || (t == best && flat < bestFlat)) : (t < best);      // as trav_closest_step
                     if (better) {
                         if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
-                        if ((flags & kTriOpaque) || any_hit_accepts(P, ti, u, v)) { found = true; best = t; bestFlat = flat; bestTri = ti; bu = u; bv = v; }
+                        if ((flags & kTriOpaque) || any_hit_accepts(P, flat, u, v)) { found = true; best = t; bestFlat = flat; bu = u; bv = v; }
                     }
                 }
             }
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
             }
         }
     }
-    if (have) B.hit[slot] = found ? make_uint4(bestTri, __float_as_uint(best), __float_as_uint(bu), __float_as_uint(bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
+    if (have) B.hit[slot] = found ? make_uint4(bestFlat, __float_as_uint(best), __float_as_uint(bu), __float_as_uint(bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
     Counters cnt = {have ? 1u : 0u, 0, 0, 0, 0};
     add_counters(P, cnt);
 }
@@ -431,8 +436,9 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
         if (i < count) {
             const float4 ro = extIn[(size_t)i * 2], rd = extIn[(size_t)i * 2 + 1];
             pid = __float_as_uint(ro.w);
-            const uint32_t ly = fast_div(pid, P.divW), px = pid - ly * P.W;
-            const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px;
+            const uint32_t smp = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u, lp = pid - smp * P.localPixels;      // path id = sample * localPixels + local pixel
+            const uint32_t ly = fast_div(lp, P.divW), px = lp - ly * P.W;
+            const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px, sampleIdx = P.sampleIdx + smp;
             const uint4 h = B.hit[i];
             const float4 c4 = stIn[(size_t)i * 2], a4 = stIn[(size_t)i * 2 + 1];
             const f3 rayD = {rd.x, rd.y, rd.z};
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
-                store_pixel(P, px, ly, color);
+                store_pixel(P, px, ly, smp, color);
                 vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
                 *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
             } else {
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 else if (P.viewmode == 4) { color = {matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, 1.f}; done = true; }
                 else if (P.viewmode == 5) { color = {matInfo.emissive.x, matInfo.emissive.y, matInfo.emissive.z, 1.f}; done = true; }
                 if (done) {
-                    store_pixel(P, px, ly, color);
+                    store_pixel(P, px, ly, smp, color);
                     vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
                     *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
                 } else {
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     // wf_shadow_gen_kernel with one lane per (vertex, light) pair: inside this kernel the loop ran to the longest light list
                     // of the wave at 3 waves per SIMD and cost 2.6 of its 6.7 ms per frame)
                     // sky sample :239-244
-                    const f2 us = SamplePoint(pixelIdx, P.sampleIdx, sampleSetIndex, P.divSqrtN, P.divN, P.numPixels);
+                    const f2 us = SamplePoint(pixelIdx, sampleIdx, sampleSetIndex, P.divSqrtN, P.divN, P.numPixels);
                     const f3 skyDir = CosineSampleHemisphere(us);
                     const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
                     const float skyNoL = saturate(dot(N, skyDir));
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
                     if (pathLength < 4) {
                         uint32_t setCopy = sampleSetIndex;
-                        f2 u = SamplePoint(pixelIdx, P.sampleIdx, setCopy, P.divSqrtN, P.divN, P.numPixels);
+                        f2 u = SamplePoint(pixelIdx, sampleIdx, setCopy, P.divSqrtN, P.divN, P.numPixels);
                         f3 L, H;
                         const float t = 0.5f;
                         if (u.x < t) {
@@ -801,7 +807,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
 struct AnyRay2 { f3 o, d, invd; uint32_t cur, triBase, triMask, triBase1, triMask1, index; int sp; bool active, haveCur; };
 struct TopRef { static constexpr bool kTop = true; LdsNodes topNodes; uint32_t topCount; };
 DI void any2_begin(AnyRay2& R, const float4 qa, const float4 qb, uint32_t index) {
-    R.o = {qa.x, qa.y, qa.z}; R.d = {qb.x, qb.y, qb.z}; R.invd = {1.f / qb.x, 1.f / qb.y, 1.f / qb.z};
+    R.o = {qa.x, qa.y, qa.z}; R.d = {qb.x, qb.y, qb.z}; R.invd = ray_setup(R.o, R.d).invd;
     R.cur = 0u; R.triBase = 0u; R.triMask = 0u; R.triBase1 = 0u; R.triMask1 = 0u; R.index = index; R.sp = 0; R.active = true; R.haveCur = true;
 }
 DI void any2_pop_tri(AnyRay2& R) {
@@ -964,9 +970,32 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
         }
-        if (flags & kFlagTerminate) { const uint32_t ly = fast_div(pid, P.divW); store_pixel(P, pid - ly * P.W, ly, color); }
+        if (flags & kFlagTerminate) {
+            const uint32_t smp = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u, lp = pid - smp * P.localPixels;
+            const uint32_t ly = fast_div(lp, P.divW);
+            store_pixel(P, lp - ly * P.W, ly, smp, color);
+        }
         else stOut[(size_t)nextSlot * 2] = make_float4(color.x, color.y, color.z, color.w);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ samples in flight: integrate
+// incr_pathtrace_desc::num_samples > 1: every finished path left its colour (RGBA16F bits, what destUav would hold) in
+// sampleStage[sample][pixel]; one lane per pixel replays pathtrace-integrate.hlsl:16-31 for its samples IN SAMPLE ORDER, each step
+// re-quantised to R11G11B10 in a register as the history surface would have been in memory: the history equals the one that
+// num_samples successive calls leave, bit for bit.  The target keeps the last sample.
+__global__ __launch_bounds__(kWfBlock) void wf_integrate_samples_kernel(const PtParams P) {
+    const uint32_t li = blockIdx.x * kWfBlock + threadIdx.x;
+    if (li >= P.localPixels) return;
+    uint32_t packed = (P.history && P.sampleIdx > 1u) ? P.history[li] : 0u;
+    uint2 last = make_uint2(0u, 0u);
+    for (uint32_t s = 0; s < P.numSamples; ++s) {
+        last = P.sampleStage[(size_t)s * P.localPixels + li];
+        const f3 cur = {f16_bits_to_f32(last.x & 0xffffu), f16_bits_to_f32(last.x >> 16), f16_bits_to_f32(last.y & 0xffffu)};
+        packed = pack_r11g11b10(integrate_sample(P, unpack_r11g11b10(packed), cur, P.sampleIdx + s), P.storageRounding);
+    }
+    if (P.target) *(uint2*)(P.target + (size_t)li * 4) = last;
+    if (P.history) P.history[li] = packed;
 }
 
 } // namespace incr
@@ -1000,14 +1029,17 @@ template <int N> static void launch_shadow2(uint32_t blocks, hipStream_t stream,
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events) {
     using namespace incr;
-    const uint32_t tilesX = (p->W + 7u) / 8u;
+    const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;      // tileRow[] counts rows of all samples in flight: tilesY per sample
     if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
-    if (tileRow[numPipes] == 0) return hipSuccess;
+    if (tileRow[numPipes] == 0) {          // an empty shard: nothing to launch, but a profiled call still owns its event record
+        if (events) for (int k = 0; k < 22 * 8; ++k) (void)hipEventRecord(events[k], streams[0]);
+        return hipSuccess;
+    }
     if (stackEntries > 24u) return hipErrorInvalidValue;
     const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 10u ? 10 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24)));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u)), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
+    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 10 ? (uint32_t)INCR_EXTEND_WAVES10 : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u))), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
     static const int shadowDualEnv = getenv("INCR_WF_SHADOW_DUAL") ? atoi(getenv("INCR_WF_SHADOW_DUAL")) : INCR_SHADOW_DUAL_DEFAULT;      // A/B hook
     const bool shadowDual = shadowDualEnv != 0 && sv <= 12;             // two rays per lane (wf_shadow2_kernel): stacks of both rays in LDS
     const uint32_t blocksShadow = cus * (shadowDual ? (uint32_t)INCR_SHADOW2_WAVES : shadowPerCU);        // the length of the ray queue is only known on the device
@@ -1030,7 +1062,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         if (!total[i]) continue;
         hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
         mark(i, 0);
-        hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tileRow[i] * tilesX); mark(i, 1);
+        hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tilesY, tileRow[i] * tilesX); mark(i, 1);
     }
     int slot = 2;
     for (int bounce = 0; bounce < 4; ++bounce) {
@@ -1056,6 +1088,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     }
     for (int i = 0; i < numPipes; ++i) for (int k = total[i] ? slot : 0; k < 22; ++k) mark(i, k);      // unused slots collapse to zero-length intervals
     for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
+    if (p->numSamples > 1u && p->localPixels) hipLaunchKernelGGL(wf_integrate_samples_kernel, dim3((p->localPixels + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, streams[0], *p);
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);
     return hipGetLastError();
 }

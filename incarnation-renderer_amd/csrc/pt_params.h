@@ -35,6 +35,12 @@ struct PtParams {
     float cameraMatrix[16];
     uint32_t W, H, numPixels, sampleIdx, sqrtSampleCount;
     FastDiv divW, divSqrtN, divN;                  // by W, sqrtSampleCount and sqrtSampleCount^2
+    // samples in flight (incr_pathtrace_desc::num_samples): path id = sample * localPixels + local pixel; sample s of the call is
+    // currentSampleIndex + s.  numSamples > 1: finished paths park their colour in sampleStage[path id] (RGBA16F bits) and
+    // wf_integrate_samples_kernel folds a pixel's samples into the history in sample order
+    uint32_t numSamples, localPixels;
+    FastDiv divLocalPixels;
+    uint2* __restrict__ sampleStage;
     float aperture, focalLength, skyBrightness;
     int32_t directLighting, viewmode;
     incr_perez_distribution perez;

@@ -114,20 +114,24 @@ template <class Table> DI void load_light_resolved(Table table, uint32_t lightIn
     mm[10] = r4.x; mm[12] = r4.y; mm[13] = r4.z; mm[14] = r4.w;
 }
 
-DI void store_pixel(const PtParams& P, uint32_t x, uint32_t ly, f4 c) {
+// destUav[xy] = payload.color (pathtracing.hlsl:118) + the integrate pass on this pixel (pathtrace-integrate.hlsl:16-31).
+// s = the path's sample within the call (0 unless incr_pathtrace_desc::num_samples > 1).
+DI f3 integrate_sample(const PtParams& P, f3 history, f3 cur, uint32_t sampleIdx) {
+    const float n = (float)sampleIdx;
+    if (sampleIdx <= 1) return cur / n;
+    return ((n - 1.f) * history + cur) / n;
+}
+DI void store_pixel(const PtParams& P, uint32_t x, uint32_t ly, uint32_t s, f4 c) {
     const size_t li = (size_t)ly * P.W + x;
     const uint32_t hx = f32_to_f16_bits(c.x, P.storageRounding), hy = f32_to_f16_bits(c.y, P.storageRounding);
     const uint32_t hz = f32_to_f16_bits(c.z, P.storageRounding), hw = f32_to_f16_bits(c.w, P.storageRounding);
-    if (P.target) *(uint2*)(P.target + li * 4) = make_uint2(hx | (hy << 16), hz | (hw << 16));      // destUav[xy] = payload.color (:118)
-    if (P.history) {                                                                                  // pathtrace-integrate.hlsl:16-31
+    if (P.numSamples > 1u) { P.sampleStage[(size_t)s * P.localPixels + li] = make_uint2(hx | (hy << 16), hz | (hw << 16)); return; }      // integrated in sample order later
+    if (P.target) *(uint2*)(P.target + li * 4) = make_uint2(hx | (hy << 16), hz | (hw << 16));
+    if (P.history) {
         const f3 cur = {f16_bits_to_f32(hx), f16_bits_to_f32(hy), f16_bits_to_f32(hz)};
-        const float n = (float)P.sampleIdx;
-        f3 avg;
-        if (P.sampleIdx <= 1) avg = cur / n;
-        else avg = ((n - 1.f) * unpack_r11g11b10(P.history[li]) + cur) / n;
+        const f3 avg = integrate_sample(P, P.sampleIdx <= 1 ? mk3(0.f) : unpack_r11g11b10(P.history[li]), cur, P.sampleIdx);
         P.history[li] = pack_r11g11b10(avg, P.storageRounding);
     }
 }
-
 
 } // namespace incr

@@ -94,8 +94,8 @@ DI bool tri_intersect(const float4 a, const float4 b, const float4 c, f3 o, f3 d
 }
 
 // ahsMain (pathtracing.hlsl:270-302): alpha test of non-opaque geometry
-DI bool any_hit_accepts(const PtParams& P, uint32_t ti, float u, float v) {
-    const TriShade* __restrict__ sh = P.shade + ti;
+DI bool any_hit_accepts(const PtParams& P, uint32_t flat, float u, float v) {
+    const TriShade* __restrict__ sh = P.shade + flat;          // shading records are indexed by flattened triangle id
     const f2 uv0 = {sh->uv[0][0], sh->uv[0][1]}, uv1 = {sh->uv[1][0], sh->uv[1][1]}, uv2 = {sh->uv[2][0], sh->uv[2][1]};
     const f2 uv = uv0 + u * (uv1 - uv0) + v * (uv2 - uv0);
     const int tex = P.materials[sh->materialIndex].baseColorTextureIndex;
@@ -111,7 +111,10 @@ DI bool any_hit_accepts(const PtParams& P, uint32_t ti, float u, float v) {
 // a = scale * invd and b = (origin - o) * invd: ONE fma per plane (these boxes only cull, they never decide a hit,
 // so fused arithmetic is fine here; the exact triangle test stays unfused).
 struct RaySetup { f3 o, invd; };
-DI RaySetup ray_setup(f3 o, f3 d) { return {o, {1.f / d.x, 1.f / d.y, 1.f / d.z}}; }
+// 1 / d by v_rcp_f32 (1 ulp) instead of the exact division (12 instructions per component, 36 per started ray in kernels that are
+// VALU-issue bound): the boxes only cull, and node8_test's margins carry the extra ulp (a and b both scale by 1 + e, |e| <= 2^-23:
+// |dt| <= e (255 |a| + |b|)).  d = 0, denormal or NaN give inf / NaN planes, which the box test ignores (conservative).
+DI RaySetup ray_setup(f3 o, f3 d) { return {o, {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}}; }
 
 struct Node8 {              // decoded header of one node + the hit mask / entry distances of its children
     uint32_t imask, childBase, triBase, leafTris, sortAxis;
@@ -134,8 +137,9 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     const float ax = sx * r.invd.x, ay = sy * r.invd.y, az = sz * r.invd.z;
     const float bx = (n0.x - r.o.x) * r.invd.x, by = (n0.y - r.o.y) * r.invd.y, bz = (n0.z - r.o.z) * r.invd.z;
     // margins: 0.02 quantum + 2^-22 |b| for the rounding of a, b and the fma, plus the 1 + 4e-7 widening of the far distance
-    // (Ize 2013) folded in -- |t| <= 255 |a| + |b| on every plane -- so that no child pays a multiply for it
-    const float mx = __builtin_fmaf(fabsf(bx), 6.4e-7f, 0.0202f * fabsf(ax)), my = __builtin_fmaf(fabsf(by), 6.4e-7f, 0.0202f * fabsf(ay)), mz = __builtin_fmaf(fabsf(bz), 6.4e-7f, 0.0202f * fabsf(az));
+    // (Ize 2013) folded in -- |t| <= 255 |a| + |b| on every plane -- so that no child pays a multiply for it, plus one ulp of
+    // 1 / d (ray_setup: 1.2e-7 (255 |a| + |b|) = 3.1e-5 quantum + 1.2e-7 |b|)
+    const float mx = __builtin_fmaf(fabsf(bx), 7.7e-7f, 0.0203f * fabsf(ax)), my = __builtin_fmaf(fabsf(by), 7.7e-7f, 0.0203f * fabsf(ay)), mz = __builtin_fmaf(fabsf(bz), 7.7e-7f, 0.0203f * fabsf(az));
     const float tmaxW = tmax * 1.0000004f;
     const float bnx = bx - mx, bfx = bx + mx, bny = by - my, bfy = by + my, bnz = bz - mz, bfz = bz + mz;
     // near planes: lo bytes when the direction component is >= 0, hi bytes otherwise
@@ -208,7 +212,7 @@ template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32
 // ---------------------------------------------------------------- closest hit
 struct TravClosest {
     RaySetup rs; f3 d; float tmin, tmax;
-    float best, bu, bv; uint32_t bestFlat, bestTri; bool found;
+    float best, bu, bv; uint32_t bestFlat; bool found;      // bestFlat = the hit's flattened triangle id = its TriShade index (device_types.h)
     uint32_t cur; float curKey;          // next node to visit (valid when haveCur)
     uint32_t triBase, triMask;           // pending triangle tests of the node visited last
     uint32_t negDir;                     // bit a: the ray points down axis a (selects the walk direction through a node's sorted slots)
@@ -219,11 +223,11 @@ struct TravClosest {
 };
 DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax;
-    T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.bestTri = 0; T.found = false;
+    T.best = tmax; T.bu = 0.f; T.bv = 0.f; T.bestFlat = 0xffffffffu; T.found = false;
     T.cur = 0; T.curKey = 0.f; T.haveCur = true; T.triBase = 0; T.triMask = 0;
     T.negDir = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
 }
-// returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestTri hold the result)
+// returns true when the traversal is complete (T.found / T.best / T.bu / T.bv / T.bestFlat hold the result)
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
     const Fetch5 f = fetch_step(P, st, T.cur, T.triBase, T.triMask);
     if (T.triMask) {
@@ -239,7 +243,7 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
             const bool better = T.found ? (t < T.best || (t == T.best && flat < T.bestFlat)) : (t < T.best);
             if (better) {
                 if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
-                if ((flags & kTriOpaque) || any_hit_accepts(P, ti, u, v)) { T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v; }
+                if ((flags & kTriOpaque) || any_hit_accepts(P, flat, u, v)) { T.found = true; T.best = t; T.bestFlat = flat; T.bu = u; T.bv = v; }
             }
         }
         if (T.triMask) return false;
@@ -323,7 +327,7 @@ template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravCl
             const bool better = T.found ? (t < T.best || (t == T.best && flat < T.bestFlat)) : (t < T.best);
             if (better) {
                 if (flags & kTriMirrored) { const float tmp = u; u = v; v = tmp; }
-                if ((flags & kTriOpaque) || any_hit_accepts(P, ti, u, v)) { T.found = true; T.best = t; T.bestFlat = flat; T.bestTri = ti; T.bu = u; T.bv = v; }
+                if ((flags & kTriOpaque) || any_hit_accepts(P, flat, u, v)) { T.found = true; T.best = t; T.bestFlat = flat; T.bu = u; T.bv = v; }
             }
         }
         if (!T.triMask) { T.triBase = T.triBase1; T.triMask = T.triMask1; T.triMask1 = 0u; }
@@ -376,7 +380,7 @@ template <class ST> DI bool trace_closest(const PtParams& P, ST& st, f3 o, f3 d,
     T.triBase1 = 0; T.triMask1 = 0;
     st.reset();
     while (!trav_closest_step2(P, st, T)) {}
-    if (T.found) { hit->t = T.best; hit->u = T.bu; hit->v = T.bv; hit->tri = T.bestTri; }
+    if (T.found) { hit->t = T.best; hit->u = T.bu; hit->v = T.bv; hit->tri = T.bestFlat; }
     return T.found;
 }
 

@@ -456,7 +456,7 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     // 4. emit triangles + shading records in leaf order
     const size_t slots = leafOrder.size();                 // triangles + holes (device_types.h LEAF SLOTS)
     out.numTriangles = (uint32_t)n;
-    out.tris.resize(slots); out.shade.resize(slots); out.triObj.resize(slots);
+    out.tris.resize(slots); out.shade.resize(n); out.triObj.resize(slots);
     for (size_t i = 0; i < slots; ++i) {
         if (leafOrder[i] == kTriHole) {
             const float qnan = std::numeric_limits<float>::quiet_NaN();
@@ -464,7 +464,6 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
             TriIsect& t = out.tris[i];
             t.v0x = t.v0y = t.v0z = t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = qnan;
             t.flatId = kTriHole; t.flags = 0; t.pad = 0;
-            memset(&out.shade[i], 0, sizeof(TriShade));
             continue;
         }
         const Flat& f = flat[leafOrder[i]];
@@ -482,7 +481,7 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         t.e2x = f.e2.x; t.e2y = f.e2.y; t.e2z = f.e2.z;
         t.flatId = leafOrder[i]; t.flags = f.flags; t.pad = 0;
         }
-        TriShade& sh = out.shade[i];
+        TriShade& sh = out.shade[leafOrder[i]];
         const incr_gpu_primitive& prim = s.primitives[f.primGlobal];
         AccessorRef na, ta, ua;
         const bool hn = resolve_accessor(s, prim.normalAccessor, &na), ht = resolve_accessor(s, prim.tangentAccessor, &ta), hu = resolve_accessor(s, prim.uvAccessor, &ua);
@@ -501,7 +500,7 @@ const char* check_bvh(const HostBvh& bvh) {
     static thread_local char msg[160];
     const size_t n = bvh.tris.size();                       // record slots: triangles + holes
     if (bvh.nodes8.empty()) return "no root node";
-    if (bvh.shade.size() != n) return "shading records != triangles";
+    if (bvh.shade.size() != bvh.numTriangles) return "shading records != triangles";
     if (bvh.numTriangles > n) return "more triangles than records";
     if (bvh.nodes8.size() > kMaxBvhNodes) return "more nodes than a traversal stack entry can address (2^23)";
     if (bvh.maxDepth > kMaxBvhDepth) return "tree deeper than the traversal stack (25 levels)";

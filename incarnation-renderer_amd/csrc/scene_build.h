@@ -34,7 +34,7 @@ struct HostScene {
 struct HostBvh {
     std::vector<BvhNode8> nodes8;       // node 0 = root (8-wide, quantised child boxes)
     std::vector<TriIsect> tris;         // leaf order, four record slots per leaf child: triangles + holes (device_types.h LEAF SLOTS)
-    std::vector<TriShade> shade;        // leaf order, same slots
+    std::vector<TriShade> shade;        // indexed by flattened triangle id (numTriangles records)
     uint32_t numTriangles = 0;          // records that are triangles
     std::vector<M44> meshLocalToWorld;  // per mesh: meshTransform * rootTransform (shader: mul(localToWorld, sceneRotation))
     uint32_t numInstances = 0;

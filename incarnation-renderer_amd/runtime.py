@@ -259,7 +259,7 @@ class Scene:
             self.handle = C.c_void_p()
 
 
-def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FConfig, storage_rounding=0, envmap=None):
+def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FConfig, storage_rounding=0, envmap=None, num_samples=1):
     """Fill an incr_pathtrace_desc from FConfig defaults (inc/common.h:6-48) and an FView.
     envmap = (pointer, resolution, levels) of the prefiltered sky cube (ibl.SkyIbl) or None for the analytic stand-in."""
     d = A.PathtraceDesc()
@@ -279,6 +279,7 @@ def make_pathtrace_desc(view, res_x, res_y, sample_index=1, shard=None, cfg=A.FC
     d.turbidity = cfg.Turbidity
     d.sky_brightness = cfg.SkyBrightness
     d.storage_rounding = storage_rounding
+    d.num_samples = num_samples          # samples sample_index .. sample_index + num_samples - 1 as one wavefront (incr.h)
     return d
 
 
@@ -295,8 +296,8 @@ class PathTracer:
         ctx.clear(self.history, self.rows * res_x * 4)
         ctx.clear(self.stats, C.sizeof(A.RayStats))
 
-    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True, envmap=None):
-        d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding, envmap)
+    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True, envmap=None, num_samples=1):
+        d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding, envmap, num_samples)
         d.scene = self.scene.handle
         d.target_rgba16f, d.history_r11g11b10 = self.target, self.history
         d.ray_stats = self.stats if count_rays else None

@@ -132,6 +132,14 @@ typedef struct incr_pathtrace_desc {
      * (what level 0 of that cube approximates; DESIGN.md deviation Q15). */
     const uint32_t* envmap_r11g11b10;
     uint32_t envmap_res, envmap_mips;
+    /* Not in the reference (which renders one sample per displayed frame, renderer.cpp:1681-1699): samples
+     * current_sample_index .. current_sample_index + num_samples - 1 of every pixel traced as ONE wavefront (0 and 1 = one sample).
+     * The history buffer ends up exactly as after num_samples successive calls -- the samples of a pixel are integrated one
+     * after the other in sample order, each step re-quantised to R11G11B10 (pathtrace-integrate.hlsl:16-31) -- and the target
+     * holds the last sample.  What it buys: a 1/8 framebuffer shard with 8 samples in flight launches a full frame's worth of
+     * rays per traversal kernel (8-GPU runs of configs 4 / 5), and a 64-spp frame pays the launch tails 8 times less often. */
+    uint32_t num_samples;
+    uint32_t reserved0;
 } incr_pathtrace_desc;
 int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);
 /*

@@ -55,3 +55,39 @@ def test_texture_download_detiles_the_resident_chain(gpu_ctx, rt, helmet):
         assert (h, w) == img.shape[:2] and mips >= 2
         np.testing.assert_array_equal(chain[: w * h].view(np.uint8).reshape(h, w, 4), img)
     sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ samples in flight
+@pytest.mark.parametrize("scene_name,W,H", [("helmet", 200, 120), ("sponza_small", 256, 144)])
+def test_samples_in_flight_equal_successive_calls(gpu_ctx, rt, sio, A, request, scene_name, W, H):
+    """incr_pathtrace_desc::num_samples = S traces samples n .. n + S - 1 as one wavefront; the R11G11B10 history (a running mean
+    re-quantised at every sample, pathtrace-integrate.hlsl:16-31) and the ray counts must equal S successive calls, the target the
+    last sample's.  16 samples as 1 + 3 + 8 + 4 against 16 single calls; also on a framebuffer shard (2 of 3 ranks, ragged rows)."""
+    packed = request.getfixturevalue(scene_name)
+    sc = gpu_ctx.create_scene(packed)
+    view = sio.FView().reset(packed, aspect=W / H)
+    for shard in (None, A.Shard(8, 1, 3)):
+        a = rt.PathTracer(gpu_ctx, sc, W, H, shard=shard)
+        b = rt.PathTracer(gpu_ctx, sc, W, H, shard=shard)
+        for n in range(1, 17):
+            a.render(view, n)
+        n = 1
+        for S in (1, 3, 8, 4):
+            b.render(view, n, num_samples=S); n += S
+        ra, rb = a.read(), b.read()
+        assert stats_tuple(ra["stats"]) == stats_tuple(rb["stats"])
+        np.testing.assert_array_equal(ra["history"], rb["history"])
+        np.testing.assert_array_equal(ra["target"], rb["target"])
+        assert ra["stats"].camera_rays == 16 * a.rows * W - 16 * _padding_pixels(gpu_ctx, H, shard, a.rows) * W
+        a.close(); b.close()
+    sc.close()
+
+
+def _padding_pixels(ctx, H, shard, rows):
+    """rows of a shard's local frame that lie beyond the frame (the last 8-row block of a ragged frame)"""
+    if shard is None:
+        return 0
+    blocks = (H + 7) // 8
+    mine = [k for k in range(shard.row_block_first, blocks, shard.row_block_stride)]
+    real = sum(min(8, H - 8 * k) for k in mine)
+    return rows - real

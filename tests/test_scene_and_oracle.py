@@ -52,7 +52,7 @@ def test_host_bvh_invariants(rt, A, helmet, sponza_small, synth):
         assert lib.incr_scene_validate_host(C.byref(d), C.byref(info)) == 0, lib.incr_last_error()
         assert info.num_triangles == ntri and ntri // 64 <= info.num_bvh_nodes <= ntri
         slots = info.triangle_bytes // 48                   # four record slots per leaf child: triangles + holes (device_types.h LEAF SLOTS)
-        assert info.triangle_bytes == slots * 48 and info.shading_bytes == slots * 128 and ntri <= slots <= 4 * ntri and slots % 4 == 0
+        assert info.triangle_bytes == slots * 48 and info.shading_bytes == ntri * 128 and ntri <= slots <= 4 * ntri and slots % 4 == 0
         assert info.bvh_bytes == info.num_bvh_nodes * 80
         assert info.bvh_max_depth <= 40
     # a broken desc is rejected with a message instead of being rendered

@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="sponza"); ap.add_argument("--texture-size", type=int, default=1024)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--samples-in-flight", type=int, default=1,
+                    help="incr_pathtrace_desc::num_samples of the SHARD runs (the full frame stays one sample per call): a shard then traces S samples of its "
+                         "pixels as one wavefront; times are per sample")
     a = ap.parse_args()
     import torch  # noqa: F401  (first HIP runtime in the process, as in bench.py)
     A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io")
@@ -27,25 +30,26 @@ def main():
     ctx = rt.Context(0)
     scene = ctx.create_scene(packed)
 
-    def timed(shard):
+    def timed(shard, S=1):
         pt = rt.PathTracer(ctx, scene, W, H, shard=shard)
+        n = 1
         for i in range(a.warmup):
-            pt.render(view, 1 + i, count_rays=False)
+            pt.render(view, n, count_rays=False, num_samples=S); n += S
         ctx.synchronize()
         ctx.clear(pt.stats, C.sizeof(A.RayStats))
         t0 = time.perf_counter()
         for i in range(a.steps):
-            pt.render(view, 1 + a.warmup + i)
+            pt.render(view, n, num_samples=S); n += S
         ctx.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3 / a.steps
-        rays = pt.read()["stats"].total_rays() / a.steps
+        ms = (time.perf_counter() - t0) * 1e3 / (a.steps * S)          # per sample
+        rays = pt.read()["stats"].total_rays() / (a.steps * S)
         # per-kernel HIP-event times of the same frames (a second pass: the events serialise the host side a little)
         ctx.profile_begin()
         for i in range(a.steps):
-            pt.render(view, 1 + a.warmup + a.steps + i)
+            pt.render(view, n, num_samples=S); n += S
         ctx.synchronize()
         p = ctx.profile_end()
-        kernels = {k: round(getattr(p, k + "_ms") / a.steps, 4) for k in ("generate", "extend", "shade", "shadow_gen", "shadow", "accumulate")}
+        kernels = {k: round(getattr(p, k + "_ms") / (a.steps * S), 4) for k in ("generate", "extend", "shade", "shadow_gen", "shadow", "accumulate")}
         pt.close()
         return ms, rays, kernels
 
@@ -53,17 +57,17 @@ def main():
     shard_ms, shard_rays, shard_kernels = [], [], None
     for r in range(a.shards):
         # best of two timings per shard: the shards of a real run share nothing, a hiccup of this process is not theirs
-        ms, rays, kernels = min((timed(A.Shard(8, r, a.shards)) for _ in range(2)), key=lambda t: t[0])
+        ms, rays, kernels = min((timed(A.Shard(8, r, a.shards), a.samples_in_flight) for _ in range(2)), key=lambda t: t[0])
         shard_ms.append(round(ms, 4)); shard_rays.append(int(rays))
         if r == 0:
             shard_kernels = kernels
-    out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps,
+    out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps, "samples_in_flight": a.samples_in_flight,
            "full_frame_ms": round(full_ms, 4), "full_frame_rays": int(full_rays), "shard_ms": shard_ms, "shard_rays": shard_rays,
            "max_shard_ms": max(shard_ms), "sum_shard_ms": round(sum(shard_ms), 4),
            "projected_speedup_compute_only": round(full_ms / max(shard_ms), 3),
            "shard_overhead_vs_full": round(sum(shard_ms) / full_ms, 4),
            "kernel_ms_full_frame": full_kernels, "kernel_ms_shard0": shard_kernels,
-           "note": "one GPU, shards rendered sequentially, best of two timings per shard; excludes the RCCL all_gather (33 MB per gathered 4K frame, once per --spp-per-gather samples)"}
+           "note": "one GPU, shards rendered sequentially, best of two timings per shard; times per sample (a shard call traces samples_in_flight samples as one wavefront); excludes the RCCL all_gather (33 MB per gathered 4K frame, once per --spp-per-gather samples)"}
     line = json.dumps(out)
     print(line, flush=True)
     if a.out:

@@ -287,6 +287,10 @@ def main():
     ap.add_argument("--spp-per-gather", type=int, default=64,
                     help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
                          "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
+    ap.add_argument("--samples-in-flight", type=int, default=0,
+                    help="samples (= steps) a rank traces as ONE wavefront (incr_pathtrace_desc::num_samples; the history is bit-identical to one "
+                         "call per sample).  0 = 1 at N = 1 (a step is then exactly one 1-spp frame, the headline) and 8 at N > 1, where a rank's "
+                         "1/N framebuffer shard alone is too short a ray list to fill the GPU between two launch tails (BASELINE config 4: 64 spp per gathered frame)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank choreography (rendezvous, barriers, gather, the JSON line) without render work")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run): this rank raises after the rendezvous")
@@ -350,8 +354,10 @@ def main():
     full = torch.zeros((H, W), dtype=torch.int32, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev)
 
-    def step(sample_index, e0=None, e1=None, gather=True):
-        d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap)
+    sif = args.samples_in_flight if args.samples_in_flight > 0 else (1 if world == 1 else 8)
+
+    def step(sample_index, e0=None, e1=None, gather=True, num_samples=1):
+        d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap, num_samples=num_samples)
         d.scene = scene.handle
         if args.no_direct_lighting:
             d.direct_lighting = 0
@@ -381,8 +387,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     spg = max(args.spp_per_gather, 1)
-    for i in range(args.steps):
-        step(sample, ev[i][0], ev[i][1], gather=((i + 1) % spg == 0 or i == args.steps - 1)); sample += 1
+    i = calls = 0
+    while i < args.steps:      # the K steps (= K samples of the frame), `sif` of them per incr_pathtrace call, never across a gather
+        S = min(sif, args.steps - i, spg - (i % spg))
+        step(sample, ev[calls][0], ev[calls][1], gather=((i + S) % spg == 0 or i + S == args.steps), num_samples=S)
+        sample += S; i += S; calls += 1
+    ev = ev[:calls]
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_end()
@@ -396,7 +406,7 @@ def main():
     s = stats.cpu().numpy()
     ls = local_stats.cpu().numpy()
     rays = int(s[0] + s[1] + s[2] + s[3]); hits = int(s[4])
-    call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events around the whole incr_pathtrace call
+    call_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps   # HIP events around the whole incr_pathtrace call, per step (sample)
 
     # second half of the metric ("Mray/s + ms/frame"): the raster frame of config 3, outside the timed path-trace region;
     # at N > 1 every rank renders its row band and the TAA bands are all-gathered (sort-first)
@@ -441,7 +451,7 @@ def main():
             "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
-                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": int(prof.pipelines),
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": int(prof.pipelines), "samples_in_flight": sif,
                        "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4)},

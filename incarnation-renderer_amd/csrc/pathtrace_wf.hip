@@ -275,7 +275,7 @@ extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
 
 // ------------------------------------------------------------------------------------------------ extend
 #ifndef INCR_EXTEND_WAVES10
-#define INCR_EXTEND_WAVES10 6
+#define INCR_EXTEND_WAVES10 7      // 10-entry keyed stack: 70 VGPRs since the hit's shading index is its flattened id and 1 / d comes from v_rcp: 7 workgroups of 22.4 KB LDS per CU
 #endif
 template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3)))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];

@@ -624,6 +624,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.statStripes = ctx->statStripes;     // the wavefront kernels count through the striped counters
     upload_grid_params(sc, P);
     P.numSamples = std::max(d->num_samples, 1u);
+    P.hitChain = d->debug_hit_chain;
     P.localPixels = P.localRows * P.W;
     P.divLocalPixels = make_fastdiv(std::max(P.localPixels, 1u));
     if ((uint64_t)P.localPixels * P.numSamples > 0x7fffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "num_samples %u x %u local pixels overflows the path index", P.numSamples, P.localPixels);

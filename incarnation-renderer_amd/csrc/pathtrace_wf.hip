@@ -445,6 +445,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};
             float4* vtx = vertex_of(B, i);
+            if (P.hitChain && h.x == kMissTri) *(uint2*)(P.hitChain + (size_t)lp * 8u + 2u * (uint32_t)bounce) = make_uint2(0xffffffffu, 0xffffffffu);
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 const f4 vt0 = {s2.y, s2.z, s2.w, s3.x}, vt1 = {s3.y, s3.z, s3.w, s4.x}, vt2 = {s4.y, s4.z, s4.w, s5.x};
                 const f2 uv0 = {s5.y, s5.z}, uv1 = {s5.w, s6.x}, uv2 = {s6.y, s6.z};
                 const uint32_t materialIndex = __float_as_uint(s6.w), meshIndex = s7.x;
+                if (P.hitChain) *(uint2*)(P.hitChain + (size_t)lp * 8u + 2u * (uint32_t)bounce) = make_uint2(s7.y << 16 | (s7.z & 0xffffu), s7.w);      // InstanceIndex, GeometryIndex, PrimitiveIndex
                 const float* __restrict__ localToWorld = P.meshLocalToWorld + (size_t)meshIndex * 16;
                 const f3 hitPosition = rayO + hitT * rayD;
                 const f4 packedT = vt0 + bx * (vt1 - vt0) + by * (vt2 - vt0);

@@ -41,6 +41,7 @@ struct PtParams {
     uint32_t numSamples, localPixels;
     FastDiv divLocalPixels;
     uint2* __restrict__ sampleStage;
+    uint32_t* __restrict__ hitChain;           // incr_pathtrace_desc::debug_hit_chain
     float aperture, focalLength, skyBrightness;
     int32_t directLighting, viewmode;
     incr_perez_distribution perez;

@@ -132,6 +132,7 @@ class PathtraceDesc(C.Structure):
         ("ray_stats", C.c_void_p),
         ("envmap_r11g11b10", C.c_void_p), ("envmap_res", C.c_uint32), ("envmap_mips", C.c_uint32),
         ("num_samples", C.c_uint32), ("reserved0", C.c_uint32),
+        ("debug_hit_chain", C.c_void_p),
     ]
 
 

@@ -295,14 +295,26 @@ class PathTracer:
         self.stats = ctx.buffer(C.sizeof(A.RayStats))
         ctx.clear(self.history, self.rows * res_x * 4)
         ctx.clear(self.stats, C.sizeof(A.RayStats))
+        self.chain = None
 
-    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True, envmap=None, num_samples=1):
+    NOT_TRACED = 0xfffffffe      # hit-chain entries of path vertices that were never traced
+
+    def render(self, view, sample_index=1, cfg=A.FConfig, storage_rounding=0, stream=None, count_rays=True, envmap=None, num_samples=1, hit_chain=False):
         d = make_pathtrace_desc(view, self.res_x, self.res_y, sample_index, self.shard, cfg, storage_rounding, envmap, num_samples)
         d.scene = self.scene.handle
         d.target_rgba16f, d.history_r11g11b10 = self.target, self.history
         d.ray_stats = self.stats if count_rays else None
+        if hit_chain:       # incr_pathtrace_desc::debug_hit_chain (test instrumentation): read back with read_chain()
+            if self.chain is None:
+                self.chain = self.ctx.buffer(self.rows * self.res_x * 32)
+            self.ctx.clear(self.chain, self.rows * self.res_x * 32, self.NOT_TRACED, stream)
+            d.debug_hit_chain = self.chain
         self.ctx.pathtrace(d, stream)
         return d
+
+    def read_chain(self):
+        self.ctx.synchronize()
+        return self.ctx.download(self.chain, (self.rows, self.res_x, 4, 2), np.uint32)
 
     def read(self):
         self.ctx.synchronize()
@@ -313,5 +325,5 @@ class PathTracer:
         return dict(target=target, history=history, stats=stats)
 
     def close(self):
-        for p in (self.target, self.history, self.stats):
+        for p in (self.target, self.history, self.stats) + ((self.chain,) if self.chain is not None else ()):
             self.ctx.free(p)

@@ -716,7 +716,8 @@ static Ray GenerateCameraRay(const Frame& f, float2 index, float2 randomSample) 
     return r;
 }
 
-static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t py, RayStats* rs) {
+// chain (optional, 8 words): incr_pathtrace_desc::debug_hit_chain of this pixel
+static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t py, RayStats* rs, uint32_t* chain = nullptr) {
     // rgsMain -- pathtracing.hlsl:89-119
     uint32_t raygenSampleSetIdx = 0;
     const uint32_t pixelIdx = py * f.W + px;
@@ -736,6 +737,7 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         first = false;
         Hit hit;
         if (!trace_closest(s, ray.o, ray.d, ray.tmin, ray.tmax, &hit)) {
+            if (chain) { chain[2 * pathLength] = 0xffffffffu; chain[2 * pathLength + 1] = 0xffffffffu; }
             float3 add;
             if (f.envSkyMode == 0) {                   // msEnvmap -- pathtracing.hlsl:304-309 (EnvSkyMode::HDRI)
                 add = (attenuation * f.skyBrightness) * env_cube_level0(f.envmap, f.envmapRes, f.envmapMips, ray.d);
@@ -750,6 +752,7 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         rs->hits++;
         pathLength += 1;
         const Scene::Tri& T = s.tris[hit.tri];
+        if (chain) { chain[2 * (pathLength - 1)] = T.inst << 16 | (T.geom & 0xffffu); chain[2 * (pathLength - 1) + 1] = T.prim; }
         const uint32_t mesh = s.instMesh[T.inst];
         const incr_gpu_primitive& prim = s.d.primitives[s.primOffset[mesh] + T.geom];       // GetPrimitive
         const Mat4 localToWorld = mat_mul(to_mat4(s.d.mesh_transforms[prim.meshIndex]), f.sceneRotation);
@@ -1093,7 +1096,7 @@ int orc_pathtrace(void* scene, const PtDesc* d, int num_threads, float* float_ta
                 for (uint32_t x = tx * 32; x < std::min(W, tx * 32 + 32); ++x) {
                     const size_t li = (size_t)ly * W + x;
                     float4 c = {0, 0, 0, 0};
-                    if (gy >= 0) c = trace_pixel(s, f, x, (uint32_t)gy, &rs);
+                    if (gy >= 0) c = trace_pixel(s, f, x, (uint32_t)gy, &rs, d->debug_hit_chain ? d->debug_hit_chain + li * 8 : nullptr);
                     if (float_target) { float_target[li * 4] = c.x; float_target[li * 4 + 1] = c.y; float_target[li * 4 + 2] = c.z; float_target[li * 4 + 3] = c.w; }
                     // destUav[xy] = payload.color  -> RGBA16F typed store (:118)
                     uint16_t h[4] = {f32_to_f16(c.x, d->storage_rounding), f32_to_f16(c.y, d->storage_rounding),

@@ -91,3 +91,103 @@ def _padding_pixels(ctx, H, shard, rows):
     mine = [k for k in range(shard.row_block_first, blocks, shard.row_block_stride)]
     real = sum(min(8, H - 8 * k) for k in mine)
     return rows - real
+
+
+# ------------------------------------------------------------------------------------------------ parity evidence, tightened
+def _outliers(g_target, o_target):
+    gt = g_target.view(np.float16).astype(np.float32)
+    ot = o_target.view(np.float16).astype(np.float32)
+    same = (g_target == o_target).all(axis=-1)
+    with np.errstate(invalid="ignore"):
+        rel = np.abs(gt - ot) / np.maximum(np.abs(ot), 1e-3)
+    return ~(same | (rel <= 2.0 ** -7).all(axis=-1))
+
+
+@pytest.mark.parametrize("scene_name,W,H,cap", [("helmet", 512, 512, 0.0005), ("sponza_small", 480, 270, 0.002)])
+def test_pixels_outside_the_tolerance_are_edge_flips(gpu_ctx, rt, sio, ob, request, scene_name, W, H, cap):
+    """The colour tolerance of the path-trace parity tests (2^-7 relative on >= 99.5 % of the pixels) leaves 0.5 % unconstrained.
+    Here every pixel outside 2^-7 must be one whose PATH differs from the oracle's -- some vertex of it hit another triangle, or
+    missed where the other hit (device vs glibc ulps in the sampler's sin / cos / sqrt move a ray across a triangle edge) -- and the
+    share of such pixels is capped at what the kernels deliver (a few 10^-4), not at 5 * 10^-3."""
+    packed = request.getfixturevalue(scene_name)
+    osc = request.getfixturevalue(scene_name + "_oracle")
+    sc = gpu_ctx.create_scene(packed)
+    view = sio.FView().reset(packed, aspect=W / H)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    pt.render(view, 1, hit_chain=True)
+    g = pt.read(); gc = pt.read_chain()
+    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count(), want_chain=True)
+    assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    bad = _outliers(g["target"], o["target"])
+    chain_differs = (gc != o["chain"]).any(axis=(-1, -2))
+    assert gc[..., 0, 0].min() != rt.PathTracer.NOT_TRACED                      # every pixel traced its camera ray
+    assert not (bad & ~chain_differs).any(), "a pixel with the oracle's hit chain is outside the colour tolerance: %d" % int((bad & ~chain_differs).sum())
+    print("%s %dx%d: %d pixels outside 2^-7 (%.5f %%), %d pixels with another hit chain" % (scene_name, W, H, int(bad.sum()), 100 * bad.mean(), int(chain_differs.sum())))
+    assert bad.mean() <= cap, bad.mean()
+    assert chain_differs.mean() <= 4 * cap
+    pt.close(); sc.close()
+
+
+def test_bench_configuration_shaded_strips_4k(gpu_ctx, rt, sio, synth, ob, A):
+    """The bench's exact configuration -- Sponza-stat with 1024^2 textures at 3840x2160, sky cube from the IBL precompute, 65 lights --
+    SHADED, against the oracle: three 8-row strips of the frame (30,720 pixels each, rendered through incr_shard so that the sampler
+    keys on full-frame pixel indices), ray counts equal, colours within 2^-7 except for edge flips."""
+    from conftest import mod
+    W, H = 3840, 2160
+    packed = synth.sponza_stat(texture_size=1024)
+    sc = gpu_ctx.create_scene(packed)
+    ibl = mod("ibl")
+    sky = ibl.SkyIbl(gpu_ctx, sc)
+    gpu_ctx.synchronize()
+    envmap = (sky.info.envmap_r11g11b10, sky.info.cubemap_res, sky.info.num_mips)
+    host_env = np.ascontiguousarray(sky.download()["envmap"])
+    osc = ob.OracleScene(packed)
+    view = sio.FView().reset(packed, aspect=W / H)
+    blocks = (H + 7) // 8
+    total_bad = total = 0
+    for block in (40, 135, 230):                       # upper arcade, nave, floor
+        shard = A.Shard(8, block, blocks)              # exactly one 8-row block
+        pt = rt.PathTracer(gpu_ctx, sc, W, H, shard=shard)
+        assert pt.rows == 8
+        pt.render(view, 1, envmap=envmap, hit_chain=True)
+        g = pt.read(); gc = pt.read_chain()
+        d = rt.make_pathtrace_desc(view, W, H, 1, shard, envmap=(host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips))
+        o = osc.pathtrace(d, num_threads=os.cpu_count(), want_chain=True)
+        assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+        assert g["stats"].light_shadow_rays > 0 and g["stats"].shaded_hits > 8 * W // 2
+        bad = _outliers(g["target"], o["target"])
+        differs = (gc != o["chain"]).any(axis=(-1, -2))
+        assert not (bad & ~differs).any()
+        total_bad += int(bad.sum()); total += bad.size
+        pt.close()
+    print("4K bench configuration, 3 strips: %d of %d pixels outside 2^-7" % (total_bad, total))
+    assert total_bad <= 0.003 * total
+    sky.close(); osc.close(); sc.close()
+
+
+def test_config4_64_samples_accumulation_vs_oracle(gpu_ctx, rt, sio, sponza_small, sponza_small_oracle):
+    """BASELINE config 4 in small: 64 samples (sampleIdx 1 .. 64 of MaxSampleCount 256, Q4) accumulated into the R11G11B10 history, eight
+    samples in flight per call, against 64 oracle passes at 96x54.  A pixel's running mean can differ where one of its 64 paths
+    flipped an edge; the decoded means must stay within a 6-bit mantissa step of each other almost everywhere."""
+    W, H = 96, 54
+    sc = gpu_ctx.create_scene(sponza_small)
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    for n in range(1, 65, 8):
+        pt.render(view, n, num_samples=8)
+    g = pt.read()
+    hist = None
+    rays = 0
+    for n in range(1, 65):
+        o = sponza_small_oracle.pathtrace(rt.make_pathtrace_desc(view, W, H, n), history=hist, num_threads=os.cpu_count())
+        hist = o["history"]; rays += o["stats"].total_rays()
+    assert g["stats"].total_rays() == rays
+    same = (g["history"] == hist)
+    from oracle import binding
+    gh, oh = binding.unpack_r11g11b10(g["history"]), binding.unpack_r11g11b10(hist)
+    with np.errstate(invalid="ignore"):
+        rel = np.abs(gh - oh) / np.maximum(np.abs(oh), 1e-3)
+    close = (rel <= 2.0 ** -4).all(axis=-1)
+    print("64-sample history: %.3f %% bit-identical, %.3f %% within one 5-bit mantissa step" % (100 * same.mean(), 100 * close.mean()))
+    assert same.mean() >= 0.90 and close.mean() >= 0.995
+    pt.close(); sc.close()

@@ -183,3 +183,22 @@ def test_glb_and_data_uri_containers_load_identically(sio, tmp_path):
         n = len(want.buffers[0]) - 32                                   # the loader pads every buffer
         assert np.array_equal(got.buffers[0][:n], want.buffers[0][:n])
         assert bytes(got.materials[0]) == bytes(want.materials[0])
+
+
+def test_oracle_hit_chain_agrees_with_its_ray_queries(helmet_oracle, helmet, sio, rt):
+    """incr_pathtrace_desc::debug_hit_chain (test instrumentation): vertex 0 of every pixel's chain is the closest hit of its camera ray."""
+    W = H = 48
+    view = sio.FView().reset(helmet, aspect=1.0)
+    d = rt.make_pathtrace_desc(view, W, H, 1)
+    r = helmet_oracle.pathtrace(d, num_threads=2, want_chain=True)
+    ys, xs = np.mgrid[0:H, 0:W]
+    o, dr = helmet_oracle.camera_rays(d, xs.ravel(), ys.ravel())
+    ids, _ = helmet_oracle.trace_rays(o, dr, 0.001, 10000.0)
+    c0 = r["chain"][:, :, 0, :].reshape(-1, 2)
+    hit = ids[:, 0] == 1
+    assert hit.any() and (~hit).any()
+    np.testing.assert_array_equal(c0[hit, 0], ids[hit, 1] << 16 | ids[hit, 2])
+    np.testing.assert_array_equal(c0[hit, 1], ids[hit, 3])
+    assert (c0[~hit] == 0xffffffff).all()
+    # vertices beyond the end of a path keep the caller's fill; a miss at vertex 0 ends the path
+    assert (r["chain"][:, :, 1:, :].reshape(-1, 3, 2)[~hit] == 0xfffffffe).all()

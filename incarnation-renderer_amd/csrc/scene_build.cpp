@@ -4,6 +4,7 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cfloat>
 #include <cstdio>
 #include <limits>
@@ -130,9 +131,9 @@ struct Builder {
     }
     static inline float axis_of(const V3& v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
 
-    // depth-capped: past kSahDepth levels the split is the object median along the longest centroid axis, so the
+    // depth-capped: past sahDepth levels the split is the object median along the longest centroid axis, so the
     // recursion (and the tree) stays logarithmic however the SAH behaves on pathological input
-    static constexpr uint32_t kSahDepth = 48;
+    uint32_t sahDepth = 48;
     uint32_t build(uint32_t first, uint32_t count, uint32_t depth = 0) {
         const uint32_t me = (uint32_t)nodes.size();
         nodes.push_back({});
@@ -172,7 +173,7 @@ struct Builder {
         uint32_t mid = first;
         const float leafCost = box_area(bb) * (float)count;
         (void)leafCost;      // the binary tree goes down to single triangles: which subtrees become leaves is the collapse's decision
-        if (depth < kSahDepth && bestAxis >= 0) {
+        if (depth < sahDepth && bestAxis >= 0) {
             const float lo = cb.lo[bestAxis], scale = (float)bins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
             auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
                 int b = (int)((axis_of(cen[t], bestAxis) - lo) * scale); b = std::min(std::max(b, 0), bins - 1);
@@ -286,8 +287,17 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         if (!f.hidden) box_grow(scene, tb[i]);
     }
     { const bool any = n && scene.lo[0] <= scene.hi[0]; for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? scene.lo[a] : 0.f; out.sceneHi[a] = any ? scene.hi[a] : 0.f; } }
+    // The traversal kernels carry one stack entry per tree level (kMaxBvhDepth).  The SAH-optimal collapse below takes at least one
+    // binary level per wide level, so a skewed binary tree (a long strip, a teapot in a stadium) can come out deeper than that:
+    // the build then repeats with the SAH switched off below a shallower binary depth -- object-median splits are balanced,
+    // ceil(log2 n) <= 23 levels for the 2^23 triangles a scene may have, and the wide tree is never deeper than the binary one.
+    std::vector<uint32_t> nodeDepth;
+    std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
+  for (const uint32_t sahDepth : {48u, 12u, 0u}) {
     Builder b(tb, cen);
+    b.sahDepth = sahDepth;
     if (n) b.build(0, (uint32_t)n);
+    nodeDepth.clear(); leafOrder.clear();
 
     // 3. collapse BVH2 -> 8-wide quantised nodes.  Which binary subtrees become the (up to 8) children of a wide node, and which
     //    become leaves of <= kMaxLeafTris triangles, is chosen by dynamic programming over the SAH cost (Ylitie, Karras, Laine
@@ -299,8 +309,6 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     //    same ~300 VALU instructions however many of its slots are in use; the traversal kernels are VALU-bound.
     //    Triangles are laid out in NODE order: the leaf children of one node8 own one contiguous run.
     out.nodes8.clear(); out.maxDepth = 0;
-    std::vector<uint32_t> nodeDepth;
-    std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
     if (n) {
         const size_t n2 = b.nodes.size();
         constexpr float cNode = INCR_BVH_COST_NODE, cTri = INCR_BVH_COST_TRI;
@@ -410,6 +418,11 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         e.ex = e.ey = e.ez = 1;
         out.nodes8.push_back(e);
     }
+
+    uint32_t depthLimit = kMaxBvhDepth;
+    if (const char* e = getenv("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
+    if (out.maxDepth <= depthLimit) break;            // (the median build cannot exceed kMaxBvhDepth: see above)
+  }
 
     // NODE ORDER: best-first by box area -- the root, then repeatedly the children block of the largest node placed so far.
     // Index order then approximates visit frequency (the top three levels take ~40 % of all node visits on Sponza-stat,

@@ -494,11 +494,18 @@ def triangle_soup(seed, ntri, kind="plain", extent=3.0):
     s = sio.PackedScene()
     nv = max(3, ntri // 2 + 3)
     P = rng.uniform(-extent, extent, (nv, 3)).astype(f32)
+    if kind == "progression":      # triangle k sits at x = 1.2^k and is as large as it is far out: the SAH peels one triangle per level (a 60-level binary tree)
+        nv = 3 * ntri
+        x = (f32(1.2) ** np.arange(ntri, dtype=f32)) * f32(1e-3)
+        P = np.zeros((nv, 3), f32)
+        P[0::3] = np.stack([x, -0.2 * x, 0.1 * x], 1); P[1::3] = np.stack([x, 0.3 * x, -0.2 * x], 1); P[2::3] = np.stack([1.1 * x, 0.1 * x, 0.35 * x], 1)
     if kind == "degenerate":
         P[: nv // 2] = P[0]
     elif kind == "flat":
         P[:, 2] = 0.0
     I = rng.integers(0, nv, (ntri, 3)).astype(np.uint32 if kind == "u32" else np.uint16)
+    if kind == "progression":
+        I = np.arange(nv, dtype=np.uint16).reshape(ntri, 3)
     N = rng.normal(size=(nv, 3)).astype(f32); N /= np.linalg.norm(N, axis=1, keepdims=True)
     T4 = np.tile(np.array([1, 0, 0, 1], f32), (nv, 1))
     UV = rng.uniform(0, 1, (nv, 2)).astype(f32)

@@ -202,3 +202,22 @@ def test_oracle_hit_chain_agrees_with_its_ray_queries(helmet_oracle, helmet, sio
     assert (c0[~hit] == 0xffffffff).all()
     # vertices beyond the end of a path keep the caller's fill; a miss at vertex 0 ends the path
     assert (r["chain"][:, :, 1:, :].reshape(-1, 3, 2)[~hit] == 0xfffffffe).all()
+
+
+def test_skewed_scene_builds_within_the_traversal_depth(rt, A, synth, monkeypatch, sponza_small):
+    """A geometric progression of triangles drives the SAH into a 60-level binary tree; the 8-wide tree must still fit the traversal
+    stack (kMaxBvhDepth = 25 levels).  And the builder's fallback -- rebuild with the SAH cut off at a shallower binary depth, down to
+    balanced median splits -- is exercised on an ordinary scene through its test hook."""
+    lib = rt.load()
+    lib.incr_scene_validate_host.restype = C.c_int
+    lib.incr_scene_validate_host.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.SceneInfo)]
+    s = synth.triangle_soup(7, 200, kind="progression")
+    d, info = s.to_desc(), A.SceneInfo()
+    assert lib.incr_scene_validate_host(C.byref(d), C.byref(info)) == 0, lib.incr_last_error()
+    assert info.num_triangles == 200 and info.bvh_max_depth <= 25
+    d, base = sponza_small.to_desc(), A.SceneInfo()
+    assert lib.incr_scene_validate_host(C.byref(d), C.byref(base)) == 0
+    monkeypatch.setenv("INCR_BVH_DEPTH_LIMIT", str(base.bvh_max_depth - 1))
+    forced = A.SceneInfo()
+    assert lib.incr_scene_validate_host(C.byref(d), C.byref(forced)) == 0, lib.incr_last_error()        # check_bvh runs inside: every triangle in exactly one leaf, boxes conservative
+    assert forced.num_triangles == base.num_triangles and forced.num_bvh_nodes != base.num_bvh_nodes     # another tree came out

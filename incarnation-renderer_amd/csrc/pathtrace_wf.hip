@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};
             float4* vtx = vertex_of(B, i);
-            if (P.hitChain && h.x == kMissTri) *(uint2*)(P.hitChain + (size_t)lp * 8u + 2u * (uint32_t)bounce) = make_uint2(0xffffffffu, 0xffffffffu);
+            if (P.hitChain && h.x == kMissTri) { uint32_t* hc = P.hitChain + (size_t)lp * 12u + 3u * (uint32_t)bounce; hc[0] = 0xffffffffu; hc[1] = 0xffffffffu; hc[2] = 0u; }
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 const f4 vt0 = {s2.y, s2.z, s2.w, s3.x}, vt1 = {s3.y, s3.z, s3.w, s4.x}, vt2 = {s4.y, s4.z, s4.w, s5.x};
                 const f2 uv0 = {s5.y, s5.z}, uv1 = {s5.w, s6.x}, uv2 = {s6.y, s6.z};
                 const uint32_t materialIndex = __float_as_uint(s6.w), meshIndex = s7.x;
-                if (P.hitChain) *(uint2*)(P.hitChain + (size_t)lp * 8u + 2u * (uint32_t)bounce) = make_uint2(s7.y << 16 | (s7.z & 0xffffu), s7.w);      // InstanceIndex, GeometryIndex, PrimitiveIndex
+                if (P.hitChain) { uint32_t* hc = P.hitChain + (size_t)lp * 12u + 3u * (uint32_t)bounce; hc[0] = s7.y << 16 | (s7.z & 0xffffu); hc[1] = s7.w; }      // InstanceIndex, GeometryIndex, PrimitiveIndex (word 2: wf_accumulate_kernel)
                 const float* __restrict__ localToWorld = P.meshLocalToWorld + (size_t)meshIndex * 16;
                 const f3 hitPosition = rayO + hitT * rayD;
                 const f4 packedT = vt0 + bx * (vt1 - vt0) + by * (vt2 - vt0);
@@ -930,6 +930,17 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
         const bool skyRequested = vis.w >> 31;
         const uint32_t rayBase = __float_as_uint(v7.w);
         bool skyVisible = skyRequested;
+        uint32_t visWord = 0u;        // debug_hit_chain word 2: which of the vertex's shadow queries came back unoccluded (sum of (loop index + 1) * 0x9E3779B1)
+        if (P.hitChain && !(flags & (kFlagInlineShadow | kFlagManyLights)) && P.directLighting && P.lightCount > 0) {
+            const uint32_t lo = P.gridCellOffsets[cell];
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < kSkySlot; ++k) {
+                const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
+                if (!((w >> (k & 31u)) & 1u)) continue;
+                if (B.rayC[rayBase + rank].w != 0.f) visWord += (P.gridCellLights[lo + k] + 1u) * 0x9E3779B1u;
+                ++rank;
+            }
+        }
         if (!(flags & (kFlagInlineShadow | kFlagManyLights))) {
             // chsMain's light loop (pathtracing.hlsl:230-236) in its order: lights that asked for no ray add exactly attenuation * 0,
             // occluded ones too; the others add the value computed for their ray
@@ -955,6 +966,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
                     const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
                     if ((w >> (k & 31u)) & 1u) { visible = B.rayC[rayBase + rank].w != 0.f; ++rank; }
                 } else if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
+                if (s.needsShadow && visible) visWord += (P.gridCellLights[lo + k] + 1u) * 0x9E3779B1u;
                 if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
                 const f3 r = attenV * radianceOut;
                 color.x += r.x; color.y += r.y; color.z += r.z;
@@ -969,6 +981,10 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
             if (skyVisible) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
+            if (P.hitChain) {
+                const uint32_t smpc = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u;
+                P.hitChain[(size_t)(pid - smpc * P.localPixels) * 12u + 3u * (uint32_t)bounce + 2u] = (visWord & 0x7fffffffu) | (skyVisible ? 0x80000000u : 0u);
+            }
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
         }

@@ -306,15 +306,15 @@ class PathTracer:
         d.ray_stats = self.stats if count_rays else None
         if hit_chain:       # incr_pathtrace_desc::debug_hit_chain (test instrumentation): read back with read_chain()
             if self.chain is None:
-                self.chain = self.ctx.buffer(self.rows * self.res_x * 32)
-            self.ctx.clear(self.chain, self.rows * self.res_x * 32, self.NOT_TRACED, stream)
+                self.chain = self.ctx.buffer(self.rows * self.res_x * 48)
+            self.ctx.clear(self.chain, self.rows * self.res_x * 48, self.NOT_TRACED, stream)
             d.debug_hit_chain = self.chain
         self.ctx.pathtrace(d, stream)
         return d
 
     def read_chain(self):
         self.ctx.synchronize()
-        return self.ctx.download(self.chain, (self.rows, self.res_x, 4, 2), np.uint32)
+        return self.ctx.download(self.chain, (self.rows, self.res_x, 4, 3), np.uint32)
 
     def read(self):
         self.ctx.synchronize()

@@ -140,10 +140,12 @@ typedef struct incr_pathtrace_desc {
      * rays per traversal kernel (8-GPU runs of configs 4 / 5), and a 64-spp frame pays the launch tails 8 times less often. */
     uint32_t num_samples;
     uint32_t reserved0;
-    /* Test instrumentation, optional (NULL = off), device, 8 x uint32 per LOCAL pixel: for path vertex k = 0..3 the closest hit of
-     * the pixel's path as { InstanceIndex() << 16 | GeometryIndex(), PrimitiveIndex() } -- 0xffffffff twice for a miss; entries of
-     * vertices the path never traced keep what the caller cleared them to.  Lets the parity tests show that a pixel outside the
-     * colour tolerance is one whose path took another triangle (an edge flip), not a shading error.  Use with num_samples <= 1. */
+    /* Test instrumentation, optional (NULL = off), device, 12 x uint32 per LOCAL pixel: for path vertex k = 0..3 of the pixel's path
+     * { InstanceIndex() << 16 | GeometryIndex(), PrimitiveIndex(), shadow word } of its closest hit -- 0xffffffff, 0xffffffff, 0 for a
+     * miss; entries of vertices the path never traced keep what the caller cleared them to.  Shadow word: bit 31 = the sky sample's
+     * shadow query was issued and found nothing; bits 0..30 = sum of (light loop index + 1) * 0x9E3779B1 over the lights whose
+     * shadow query was issued and found nothing.  Lets the parity tests show that a pixel outside the colour tolerance is one whose
+     * path took another triangle or whose shadow query flipped (a ray that grazes an edge), not a shading error.  num_samples <= 1. */
     uint32_t* debug_hit_chain;
 } incr_pathtrace_desc;
 int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_stream stream);

@@ -170,7 +170,7 @@ class OracleScene:
 
     def pathtrace(self, desc, history=None, num_threads=1, want_float=False, want_chain=False):
         """Runs DispatchRays + integrate.  Returns dict(target f16 bits, history u32, stats, float, chain).
-        chain (want_chain): incr_pathtrace_desc::debug_hit_chain, [rows, W, 4, 2] u32, 0xfffffffe where a path vertex was never traced."""
+        chain (want_chain): incr_pathtrace_desc::debug_hit_chain, [rows, W, 4, 3] u32, 0xfffffffe where a path vertex was never traced."""
         rows = lib().orc_shard_local_rows(desc.res_y, C.byref(desc.shard))
         W = desc.res_x
         target = np.zeros((rows, W, 4), dtype=np.uint16)
@@ -182,7 +182,7 @@ class OracleScene:
         d.target_rgba16f = target.ctypes.data
         d.history_r11g11b10 = history.ctypes.data
         d.ray_stats = C.addressof(stats)
-        chain = np.full((rows, W, 4, 2), 0xfffffffe, dtype=np.uint32) if want_chain else None
+        chain = np.full((rows, W, 4, 3), 0xfffffffe, dtype=np.uint32) if want_chain else None
         d.debug_hit_chain = chain.ctypes.data if want_chain else None
         rc = lib().orc_pathtrace(self.handle, C.byref(d), num_threads, fl.ctypes.data if want_float else None)
         if rc != 0:

@@ -580,8 +580,9 @@ static bool trace_any(const Scene& s, float3 o, float3 d, float tmin, float tmax
 // ------------------------------------------------------------------------------------------------
 // Lighting -- shaders/lighting/common.hlsli
 // ------------------------------------------------------------------------------------------------
+// visible (optional): set when the light's shadow query was issued and found nothing (the hit-chain instrumentation)
 static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const Mat4& lightTransform, float3 worldPos, float3 basecolor,
-                                float metallic, float roughness, float3 N, float3 V, bool pathTracing, RayStats* rs) {  // :8-143
+                                float metallic, float roughness, float3 N, float3 V, bool pathTracing, RayStats* rs, bool* visible = nullptr) {  // :8-143
     float3 L = {0, 0, 0};
     float3 radianceIn = {0, 0, 0};
     const float3 color = {light.color[0], light.color[1], light.color[2]};
@@ -631,6 +632,7 @@ static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const M
         if (pathTracing || light.type == INCR_LIGHT_DIRECTIONAL) {
             if (rs) rs->lightShadow++;
             if (trace_any(s, worldPos, L, 0.1f, 1000.f)) lightVisibility = 0.f;
+            else if (visible) *visible = true;
         }
         if (lightVisibility > 0.f) {
             float NoV = saturate(dot(N, V));
@@ -651,13 +653,14 @@ static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const M
     return radianceOut;
 }
 
-static float3 GetSkyRadiance(const Scene& s, float3 radianceIn, float3 L, float3 worldPos, const MatProps& matInfo, float3 N, float3 V, RayStats* rs) { // :145-202
+static float3 GetSkyRadiance(const Scene& s, float3 radianceIn, float3 L, float3 worldPos, const MatProps& matInfo, float3 N, float3 V, RayStats* rs, bool* visible = nullptr) { // :145-202
     float3 radianceOut = {0, 0, 0};
     float NoL = saturate(dot(N, L));
     if (NoL > 0.f && (radianceIn.x > 0.f || radianceIn.y > 0.f || radianceIn.z > 0.f)) {
         float lightVisibility = 1.f;
         if (rs) rs->skyShadow++;
         if (trace_any(s, worldPos, L, 0.1f, 1000.f)) lightVisibility = 0.f;
+        else if (visible) *visible = true;
         if (lightVisibility > 0.f) {
             float NoV = dot(N, V);
             float3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
@@ -716,7 +719,7 @@ static Ray GenerateCameraRay(const Frame& f, float2 index, float2 randomSample) 
     return r;
 }
 
-// chain (optional, 8 words): incr_pathtrace_desc::debug_hit_chain of this pixel
+// chain (optional, 12 words): incr_pathtrace_desc::debug_hit_chain of this pixel
 static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t py, RayStats* rs, uint32_t* chain = nullptr) {
     // rgsMain -- pathtracing.hlsl:89-119
     uint32_t raygenSampleSetIdx = 0;
@@ -737,7 +740,7 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         first = false;
         Hit hit;
         if (!trace_closest(s, ray.o, ray.d, ray.tmin, ray.tmax, &hit)) {
-            if (chain) { chain[2 * pathLength] = 0xffffffffu; chain[2 * pathLength + 1] = 0xffffffffu; }
+            if (chain) { chain[3 * pathLength] = 0xffffffffu; chain[3 * pathLength + 1] = 0xffffffffu; chain[3 * pathLength + 2] = 0u; }
             float3 add;
             if (f.envSkyMode == 0) {                   // msEnvmap -- pathtracing.hlsl:304-309 (EnvSkyMode::HDRI)
                 add = (attenuation * f.skyBrightness) * env_cube_level0(f.envmap, f.envmapRes, f.envmapMips, ray.d);
@@ -752,7 +755,8 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         rs->hits++;
         pathLength += 1;
         const Scene::Tri& T = s.tris[hit.tri];
-        if (chain) { chain[2 * (pathLength - 1)] = T.inst << 16 | (T.geom & 0xffffu); chain[2 * (pathLength - 1) + 1] = T.prim; }
+        if (chain) { chain[3 * (pathLength - 1)] = T.inst << 16 | (T.geom & 0xffffu); chain[3 * (pathLength - 1) + 1] = T.prim; }
+        uint32_t visWord = 0u;
         const uint32_t mesh = s.instMesh[T.inst];
         const incr_gpu_primitive& prim = s.d.primitives[s.primOffset[mesh] + T.geom];       // GetPrimitive
         const Mat4 localToWorld = mat_mul(to_mat4(s.d.mesh_transforms[prim.meshIndex]), f.sceneRotation);
@@ -804,7 +808,9 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
                 if ((uint32_t)lightId < s.d.num_global_lights) light = s.d.global_lights[lightId];
                 Mat4 lightTransform{};
                 if ((uint32_t)lightId < s.d.num_scene_lights) lightTransform = to_mat4(s.d.light_transforms[lightId]);
-                float3 r = attenuation * GetDirectRadiance(s, light, lightTransform, hitPosition, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V, true, rs);
+                bool vis = false;
+                float3 r = attenuation * GetDirectRadiance(s, light, lightTransform, hitPosition, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V, true, rs, &vis);
+                if (vis) visWord += ((uint32_t)lightIndex + 1u) * 0x9E3779B1u;
                 color.x += r.x; color.y += r.y; color.z += r.z;
             }
         }
@@ -815,8 +821,10 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
             // (oracle_ibl.h); else Q15: level 0 of that cube ~= 0.04 * Preetham(scene sun dir), evaluated analytically
             float3 radianceIn = f.skyBrightness * (f.envmap ? env_cube_level0(f.envmap, f.envmapRes, f.envmapMips, sampleDir)
                                                             : 0.04f * CalculateSkyRadianceRGB(f.sunEnv, sampleDir, f.perez));
-            float3 r = attenuation * GetSkyRadiance(s, radianceIn, sampleDir, hitPosition, matInfo, N, V, rs);
+            bool skyVis = false;
+            float3 r = attenuation * GetSkyRadiance(s, radianceIn, sampleDir, hitPosition, matInfo, N, V, rs, &skyVis);
             color.x += r.x; color.y += r.y; color.z += r.z;
+            if (chain) chain[3 * (pathLength - 1) + 2] = (visWord & 0x7fffffffu) | (skyVis ? 0x80000000u : 0u);      // which shadow queries of this vertex came back unoccluded
         }
         if (pathLength < 4) {   // MAX_RECURSION_DEPTH
             // GenerateIndirectRadianceRay -- common.hlsli:55-123 (set index taken BY VALUE: Q3)
@@ -1096,7 +1104,7 @@ int orc_pathtrace(void* scene, const PtDesc* d, int num_threads, float* float_ta
                 for (uint32_t x = tx * 32; x < std::min(W, tx * 32 + 32); ++x) {
                     const size_t li = (size_t)ly * W + x;
                     float4 c = {0, 0, 0, 0};
-                    if (gy >= 0) c = trace_pixel(s, f, x, (uint32_t)gy, &rs, d->debug_hit_chain ? d->debug_hit_chain + li * 8 : nullptr);
+                    if (gy >= 0) c = trace_pixel(s, f, x, (uint32_t)gy, &rs, d->debug_hit_chain ? d->debug_hit_chain + li * 12 : nullptr);
                     if (float_target) { float_target[li * 4] = c.x; float_target[li * 4 + 1] = c.y; float_target[li * 4 + 2] = c.z; float_target[li * 4 + 3] = c.w; }
                     // destUav[xy] = payload.color  -> RGBA16F typed store (:118)
                     uint16_t h[4] = {f32_to_f16(c.x, d->storage_rounding), f32_to_f16(c.y, d->storage_rounding),

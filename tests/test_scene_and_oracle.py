@@ -194,14 +194,15 @@ def test_oracle_hit_chain_agrees_with_its_ray_queries(helmet_oracle, helmet, sio
     ys, xs = np.mgrid[0:H, 0:W]
     o, dr = helmet_oracle.camera_rays(d, xs.ravel(), ys.ravel())
     ids, _ = helmet_oracle.trace_rays(o, dr, 0.001, 10000.0)
-    c0 = r["chain"][:, :, 0, :].reshape(-1, 2)
+    c0 = r["chain"][:, :, 0, :2].reshape(-1, 2)
     hit = ids[:, 0] == 1
     assert hit.any() and (~hit).any()
     np.testing.assert_array_equal(c0[hit, 0], ids[hit, 1] << 16 | ids[hit, 2])
     np.testing.assert_array_equal(c0[hit, 1], ids[hit, 3])
     assert (c0[~hit] == 0xffffffff).all()
     # vertices beyond the end of a path keep the caller's fill; a miss at vertex 0 ends the path
-    assert (r["chain"][:, :, 1:, :].reshape(-1, 3, 2)[~hit] == 0xfffffffe).all()
+    assert (r["chain"][:, :, 1:, :].reshape(-1, 3, 3)[~hit] == 0xfffffffe).all()
+    assert (r["chain"][:, :, 0, 2].reshape(-1)[~hit] == 0).all() and (r["chain"][:, :, 0, 2].reshape(-1)[hit] >> 31).any()       # shadow word: some sky samples unoccluded
 
 
 def test_skewed_scene_builds_within_the_traversal_depth(rt, A, synth, monkeypatch, sponza_small):

@@ -103,12 +103,23 @@ def _outliers(g_target, o_target):
     return ~(same | (rel <= 2.0 ** -7).all(axis=-1))
 
 
-@pytest.mark.parametrize("scene_name,W,H,cap", [("helmet", 512, 512, 0.0005), ("sponza_small", 480, 270, 0.002)])
-def test_pixels_outside_the_tolerance_are_edge_flips(gpu_ctx, rt, sio, ob, request, scene_name, W, H, cap):
+def _classify(g_target, o_target, g_chain, o_chain, NOT_TRACED):
+    """outliers of the colour tolerance, pixels whose path or shadow-query outcomes differ, and the number of vertices of every path"""
+    bad = _outliers(g_target, o_target)
+    differs = (g_chain != o_chain).any(axis=(-1, -2))
+    vertices = (g_chain[..., 0] != NOT_TRACED).sum(axis=-1)
+    return bad, differs, vertices
+
+
+@pytest.mark.parametrize("scene_name,W,H,cap", [("helmet", 512, 512, 1e-4), ("sponza_small", 480, 270, 3e-4)])
+def test_pixels_outside_the_tolerance_are_accounted_for(gpu_ctx, rt, sio, ob, request, scene_name, W, H, cap):
     """The colour tolerance of the path-trace parity tests (2^-7 relative on >= 99.5 % of the pixels) leaves 0.5 % unconstrained.
-    Here every pixel outside 2^-7 must be one whose PATH differs from the oracle's -- some vertex of it hit another triangle, or
-    missed where the other hit (device vs glibc ulps in the sampler's sin / cos / sqrt move a ray across a triangle edge) -- and the
-    share of such pixels is capped at what the kernels deliver (a few 10^-4), not at 5 * 10^-3."""
+    Measured (tools/diag_outliers.py): 0 of 262,144 helmet pixels and 11 of 129,600 Sponza-stat pixels are outside 2^-7.  They are of
+    two kinds: paths that took another triangle or whose shadow query flipped (device vs glibc ulps in sin / cos / sqrt move a ray
+    across an edge; visible in the hit chain), and full-length paths over the same triangles whose colour went through three
+    BRDF-sampled bounces (normalize(L + V) of nearly opposite vectors, GGX of a near-mirror lobe: ulp differences amplified to
+    1-20 %).  So: every outlier has another chain OR at least three path vertices, and the share of outliers is capped at 1e-4 / 3e-4
+    instead of 5e-3."""
     packed = request.getfixturevalue(scene_name)
     osc = request.getfixturevalue(scene_name + "_oracle")
     sc = gpu_ctx.create_scene(packed)
@@ -117,24 +128,24 @@ def test_pixels_outside_the_tolerance_are_edge_flips(gpu_ctx, rt, sio, ob, reque
     pt.render(view, 1, hit_chain=True)
     g = pt.read(); gc = pt.read_chain()
     o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count(), want_chain=True)
-    bad = _outliers(g["target"], o["target"])
-    chain_differs = (gc != o["chain"]).any(axis=(-1, -2))
+    bad, differs, vertices = _classify(g["target"], o["target"], gc, o["chain"], rt.PathTracer.NOT_TRACED)
     # ray counts: equal, or off by what the pixels with another path can account for (<= 3 bounce rays + 4 x 66 shadow rays each)
     assert g["stats"].camera_rays == o["stats"].camera_rays == W * H
     for a, b in zip(stats_tuple(g["stats"]), stats_tuple(o["stats"])):
-        assert abs(a - b) <= 70 * int(chain_differs.sum())
-    assert gc[..., 0, 0].min() != rt.PathTracer.NOT_TRACED                      # every pixel traced its camera ray
-    assert not (bad & ~chain_differs).any(), "a pixel with the oracle's hit chain is outside the colour tolerance: %d" % int((bad & ~chain_differs).sum())
-    print("%s %dx%d: %d pixels outside 2^-7 (%.5f %%), %d pixels with another hit chain" % (scene_name, W, H, int(bad.sum()), 100 * bad.mean(), int(chain_differs.sum())))
+        assert abs(a - b) <= 70 * int(differs.sum())
+    assert vertices.min() >= 1                                                   # every pixel traced its camera ray
+    print("%s %dx%d: %d pixels outside 2^-7 (%.5f %%): %d with another chain, %d same chain with >= 3 vertices; %d pixels with another chain in all"
+          % (scene_name, W, H, int(bad.sum()), 100 * bad.mean(), int((bad & differs).sum()), int((bad & ~differs & (vertices >= 3)).sum()), int(differs.sum())))
+    assert not (bad & ~differs & (vertices <= 2)).any(), "a short path over the oracle's triangles is outside the colour tolerance"
     assert bad.mean() <= cap, bad.mean()
-    assert chain_differs.mean() <= 4 * cap
+    assert differs.mean() <= 4 * cap
     pt.close(); sc.close()
 
 
 def test_bench_configuration_shaded_strips_4k(gpu_ctx, rt, sio, synth, ob, A):
     """The bench's exact configuration -- Sponza-stat with 1024^2 textures at 3840x2160, sky cube from the IBL precompute, 65 lights --
     SHADED, against the oracle: three 8-row strips of the frame (30,720 pixels each, rendered through incr_shard so that the sampler
-    keys on full-frame pixel indices), ray counts equal, colours within 2^-7 except for edge flips."""
+    keys on full-frame pixel indices), ray counts equal up to edge flips, colours within 2^-7 except for flips and compounded deep paths (see above)."""
     from conftest import mod
     W, H = 3840, 2160
     packed = synth.sponza_stat(texture_size=1024)
@@ -157,16 +168,15 @@ def test_bench_configuration_shaded_strips_4k(gpu_ctx, rt, sio, synth, ob, A):
         d = rt.make_pathtrace_desc(view, W, H, 1, shard, envmap=(host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips))
         o = osc.pathtrace(d, num_threads=os.cpu_count(), want_chain=True)
         assert g["stats"].light_shadow_rays > 0 and g["stats"].shaded_hits > 8 * W // 2
-        bad = _outliers(g["target"], o["target"])
-        differs = (gc != o["chain"]).any(axis=(-1, -2))
+        bad, differs, vertices = _classify(g["target"], o["target"], gc, o["chain"], rt.PathTracer.NOT_TRACED)
         assert g["stats"].camera_rays == o["stats"].camera_rays == 8 * W
         for a, b in zip(stats_tuple(g["stats"]), stats_tuple(o["stats"])):
             assert abs(a - b) <= 70 * int(differs.sum())
-        assert not (bad & ~differs).any()
+        assert not (bad & ~differs & (vertices <= 2)).any()
         total_bad += int(bad.sum()); total += bad.size
         pt.close()
     print("4K bench configuration, 3 strips: %d of %d pixels outside 2^-7" % (total_bad, total))
-    assert total_bad <= 0.003 * total
+    assert total_bad <= 5e-4 * total
     sky.close(); osc.close(); sc.close()
 
 
@@ -194,5 +204,5 @@ def test_config4_64_samples_accumulation_vs_oracle(gpu_ctx, rt, sio, sponza_smal
         rel = np.abs(gh - oh) / np.maximum(np.abs(oh), 1e-3)
     close = (rel <= 2.0 ** -4).all(axis=-1)
     print("64-sample history: %.3f %% bit-identical, %.3f %% within one 5-bit mantissa step" % (100 * same.mean(), 100 * close.mean()))
-    assert same.mean() >= 0.90 and close.mean() >= 0.995
+    assert same.mean() >= 0.99 and close.mean() >= 0.999
     pt.close(); sc.close()

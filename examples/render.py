@@ -4,6 +4,12 @@
     python examples/render.py --scene helmet --mode pathtrace --spp 64 --res 1024x1024 --out helmet.png
     python examples/render.py --scene sponza --mode raster --frames 16 --res 1920x1080 --hbao --out sponza.png
 
+    python examples/render.py --scene helmet --mode pathtrace --spp 256 --res 1920x1080 --dump-hdr helmet_hdr.npy
+
+--dump-hdr writes the frame's HDR surface as float32 [H, W, 3] (.npy): the R11G11B10_FLOAT path-trace history / TAA accumulation
+decoded exactly (what the tonemap reads).  That is the array to hold against a capture of the reference's own history buffer
+(tools/psnr_capture.py: PSNR on linear HDR clipped to [0, 65504] and on the tonemapped 8-bit image).
+
 Needs an MI355X (there is no CPU fallback); the PNG encoder itself is plain Python (zlib)."""
 import argparse
 import importlib
@@ -49,6 +55,20 @@ def read_png(path):
     return rows[:, 1:].reshape(h, w, 4)
 
 
+def decode_r11g11b10(words):
+    """R11G11B10_FLOAT -> float32 [..., 3]: unsigned, 5-bit exponents (bias 15), 6 / 6 / 5 mantissa bits, denormals, inf / NaN."""
+    w = np.asarray(words, dtype=np.uint32)
+
+    def part(bits, mant_bits):
+        e = (bits >> mant_bits).astype(np.int32); m = (bits & ((1 << mant_bits) - 1)).astype(np.float32)
+        scale = np.float32(1 << mant_bits)
+        normal = np.ldexp(np.float32(1.0) + m / scale, e - 15).astype(np.float32)
+        denorm = np.ldexp(m / scale, -14).astype(np.float32)
+        special = np.where(m == 0, np.float32(np.inf), np.float32(np.nan))
+        return np.where(e == 0, denorm, np.where(e == 31, special, normal)).astype(np.float32)
+    return np.stack([part(w & 0x7ff, 6), part((w >> 11) & 0x7ff, 6), part(w >> 22, 5)], axis=-1)
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--scene", default="helmet", help="helmet | sponza | bistro | path to a .gltf")
@@ -57,6 +77,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="raster: frames rendered (TAA converges over the jitter sequence)")
     ap.add_argument("--hbao", action="store_true"); ap.add_argument("--forward", action="store_true"); ap.add_argument("--viewmode", type=int, default=0)
     ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--out", default="frame.png")
+    ap.add_argument("--dump-hdr", default=None, help="also write the HDR surface the tonemap read as float32 [H, W, 3] .npy")
     a = ap.parse_args()
     A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io"); synth = importlib.import_module(PKG + ".synth")
     rt = importlib.import_module(PKG + ".runtime"); R = importlib.import_module(PKG + ".raster"); ibl = importlib.import_module(PKG + ".ibl")
@@ -89,6 +110,9 @@ def main():
     ldr = hr.download(A.SURFACE_BACK_BUFFER).view(np.uint8).reshape(H, W, 4).copy()
     ldr[..., 3] = 255
     write_png(a.out, ldr)
+    if a.dump_hdr:
+        surf = A.SURFACE_PATHTRACE_HISTORY if a.mode == "pathtrace" else (A.SURFACE_TAA_ACCUMULATION if Cfg.EnableTAA else A.SURFACE_HDR_RASTER)
+        np.save(a.dump_hdr, decode_r11g11b10(hr.download(surf).view(np.uint32).reshape(-1)[: W * H].reshape(H, W)))
     print("%s: %dx%d %s, %d rays traced, %d objects / %d lights culled in the last frame" % (a.out, W, H, a.mode, rays.total_rays(), culled_objects, culled_lights))
     hr.close(); sky.close(); ctx.free(lut); scene.close()
 

@@ -152,10 +152,40 @@ int incr_stream_synchronize(incr_context* ctx, incr_stream stream) {
 
 } // extern "C"
 
+// ---------------------------------------------------------------------------------------------- pinned staging of the update path
+int incr_staging_begin(incr_scene* sc, size_t bytes) {
+    incr_scene::UpdateStaging& g = sc->staging;
+    g.slot ^= 1; g.used = 0;
+    const int k = g.slot;
+    if (!g.done[k]) HIP_TRY(hipEventCreateWithFlags(&g.done[k], hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(g.done[k]));                  // the copies of the update before last: long done in any steady state
+    bytes += 256;
+    if (g.cap[k] < bytes) {
+        if (g.host[k]) { HIP_TRY(hipHostFree(g.host[k])); g.host[k] = nullptr; g.cap[k] = 0; }
+        HIP_TRY(hipHostMalloc((void**)&g.host[k], bytes * 2, hipHostMallocDefault));
+        g.cap[k] = bytes * 2;
+    }
+    return INCR_OK;
+}
+int incr_staging_upload(incr_scene* sc, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    incr_scene::UpdateStaging& g = sc->staging;
+    if (!bytes) return INCR_OK;
+    const size_t at = (g.used + 15) & ~(size_t)15;
+    if (at + bytes > g.cap[g.slot]) return fail(INCR_ERR_INVALID_ARGUMENT, "update staging overflow (%zu + %zu of %zu bytes)", at, bytes, g.cap[g.slot]);
+    memcpy(g.host[g.slot] + at, src, bytes);
+    g.used = at + bytes;
+    HIP_TRY(hipMemcpyAsync(dst, g.host[g.slot] + at, bytes, hipMemcpyHostToDevice, stream));
+    return INCR_OK;
+}
+int incr_staging_end(incr_scene* sc, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(sc->staging.done[sc->staging.slot], stream));
+    return INCR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- scene
 // Light-grid arrays keep their allocation while the new lists fit (incr_update_bvh re-derives the grid on the stream).
-static int upload_light_grid(incr_scene* sc, hipStream_t stream) {
-    build_light_grid(sc->host, sc->bvh, sc->grid);
+static int upload_light_grid(incr_scene* sc, hipStream_t stream, bool staged) {
+    if (!staged) build_light_grid(sc->host, sc->bvh, sc->grid);          // (the update path builds it before it sizes its staging)
     const size_t no = sc->grid.cellOffsets.size(), nl = sc->grid.cellLights.size();
     if (no > sc->gridOffsetsCap || !sc->dGridOffsets) {
         if (sc->dGridOffsets) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(sc->dGridOffsets)); sc->dGridOffsets = nullptr; }
@@ -165,8 +195,13 @@ static int upload_light_grid(incr_scene* sc, hipStream_t stream) {
         if (sc->dGridLights) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(sc->dGridLights)); sc->dGridLights = nullptr; }
         sc->gridLightsCap = nl * 2 + 64; HIP_TRY(hipMalloc((void**)&sc->dGridLights, sc->gridLightsCap * 4));
     }
-    HIP_TRY(hipMemcpyAsync(sc->dGridOffsets, sc->grid.cellOffsets.data(), no * 4, hipMemcpyHostToDevice, stream));
-    if (nl) HIP_TRY(hipMemcpyAsync(sc->dGridLights, sc->grid.cellLights.data(), nl * 4, hipMemcpyHostToDevice, stream));
+    if (staged) {
+        int rc = incr_staging_upload(sc, sc->dGridOffsets, sc->grid.cellOffsets.data(), no * 4, stream);
+        if (!rc) rc = incr_staging_upload(sc, sc->dGridLights, sc->grid.cellLights.data(), nl * 4, stream);
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(sc->dGridOffsets, sc->grid.cellOffsets.data(), no * 4, hipMemcpyHostToDevice));          // scene creation
+    if (nl) HIP_TRY(hipMemcpy(sc->dGridLights, sc->grid.cellLights.data(), nl * 4, hipMemcpyHostToDevice));
     return INCR_OK;
 }
 
@@ -204,7 +239,7 @@ static int upload_bvh(incr_scene* sc) {
     if ((rc = upload_vec(&sc->dMeshInfo, info.data(), info.size()))) return rc;
     if (sc->dNodeBoxes) { (void)hipFree(sc->dNodeBoxes); sc->dNodeBoxes = nullptr; }
     HIP_TRY(hipMalloc(&sc->dNodeBoxes, (sc->bvh.nodes8.size() + 1) * 32));
-    return upload_light_grid(sc, nullptr);
+    return upload_light_grid(sc, nullptr, false);
 }
 
 // pt_params.h FastDiv: magic number and shift for exact division of any 32-bit numerator by d >= 2 (d == 1 is passed through)
@@ -276,6 +311,7 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
                     sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) { if (sc->staging.done[k]) { (void)hipEventSynchronize(sc->staging.done[k]); (void)hipEventDestroy(sc->staging.done[k]); } if (sc->staging.host[k]) (void)hipHostFree(sc->staging.host[k]); }
     incr_raster_scene_free(sc);
     delete sc;
     return INCR_OK;
@@ -459,17 +495,22 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
     // grid), then the re-transform and refit kernels of bvh_update.hip.  No host rebuild, no stream synchronise.
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    std::vector<MeshInstanceInfo>& info = sc->meshInfo;      // scene-lifetime staging for the asynchronous upload
+    std::vector<MeshInstanceInfo>& info = sc->meshInfo;
     refresh_mesh_instances(sc->host, sc->bvh, info);
+    build_light_grid(sc->host, sc->bvh, sc->grid);
+    // every host -> device byte of this update goes through one pinned, double-buffered staging slot (api_internal.h UpdateStaging)
+    int rc = incr_staging_begin(sc, nm * (64 + sizeof(MeshInstanceInfo) + 4) + (sc->grid.cellOffsets.size() + sc->grid.cellLights.size()) * 4 + (size_t)sc->numDecals * 64 + 256);
+    if (rc) return rc;
     if (nm) {
-        HIP_TRY(hipMemcpyAsync(sc->dMeshLocalToWorld, sc->bvh.meshLocalToWorld.data(), nm * 64, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(sc->dMeshInfo, info.data(), nm * sizeof(MeshInstanceInfo), hipMemcpyHostToDevice, st));
+        if ((rc = incr_staging_upload(sc, sc->dMeshLocalToWorld, sc->bvh.meshLocalToWorld.data(), nm * 64, st))) return rc;
+        if ((rc = incr_staging_upload(sc, sc->dMeshInfo, info.data(), nm * sizeof(MeshInstanceInfo), st))) return rc;
     }
     HIP_TRY(incr_launch_bvh_update((uint32_t)sc->bvh.tris.size(), sc->dTriObj, sc->dMeshLocalToWorld, sc->dMeshInfo, sc->dTris, sc->dShade, sc->dNodes,
                                    sc->dLevelNodes, sc->bvh.levelOffsets.data(), (uint32_t)sc->bvh.levelOffsets.size() - 1u, sc->dNodeBoxes, st));
-    int rc = upload_light_grid(sc, st);
+    rc = upload_light_grid(sc, st, true);
     if (!rc) rc = incr_raster_scene_update(sc, st);       // raster side: mesh visibility flags, decal transforms
-    return rc;
+    const int rc2 = incr_staging_end(sc, st);
+    return rc ? rc : rc2;
 }
 
 int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_dir[3]) {

@@ -76,6 +76,10 @@ struct incr_scene {
     // device-side acceleration-structure update (bvh_update.hip)
     incr::TriObject* dTriObj = nullptr; uint32_t* dLevelNodes = nullptr; incr::MeshInstanceInfo* dMeshInfo = nullptr; void* dNodeBoxes = nullptr;
     std::vector<incr::MeshInstanceInfo> meshInfo;
+    // incr_update_bvh's host -> device uploads go through PINNED staging, double-buffered: an asynchronous copy out of pageable
+    // memory either blocks the host until the stream drains or reads a source the next update already rewrites.  A slot is reused
+    // only after the event recorded behind its copies has passed.
+    struct UpdateStaging { uint8_t* host[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}, used = 0; hipEvent_t done[2] = {nullptr, nullptr}; int slot = 0; } staging;
     // raster path (meshlets resolved through the accessor indirection once, at scene creation)
     incr_gpu_meshlet* dMeshlets = nullptr; uint32_t* dPackedTris = nullptr; uint32_t* dMeshVisibility = nullptr;
     float4* dMvPos = nullptr; float2* dMvUv = nullptr; float4* dMvNormal = nullptr; float4* dMvTangent = nullptr;
@@ -110,3 +114,7 @@ int  incr_raster_scene_upload(incr_scene* sc);
 void incr_raster_scene_free(incr_scene* sc);
 // re-upload what the raster passes derive from mesh visibility / the root transform (stream-ordered)
 int  incr_raster_scene_update(incr_scene* sc, hipStream_t stream);
+// pinned staging of incr_update_bvh (api.hip): begin -> any number of uploads -> end (records the slot's event)
+int  incr_staging_begin(incr_scene* sc, size_t bytes);
+int  incr_staging_upload(incr_scene* sc, void* dst, const void* src, size_t bytes, hipStream_t stream);
+int  incr_staging_end(incr_scene* sc, hipStream_t stream);

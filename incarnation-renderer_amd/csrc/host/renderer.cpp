@@ -347,6 +347,7 @@ struct State {
     incr_context* ctx = nullptr;
     RenderJob::Sync jobSync;                                   // s_jobSync
     uint32_t resX = 0, resY = 0;
+    size_t meshletCount = 0;
     uint32_t pathtraceCurrentSampleIndex = 1;                  // s_pathtraceCurrentSampleIndex (renderer.cpp:23)
     Matrix prevViewProjectionTransform{};                      // s_prevViewProjectionTransform
     uint64_t frameIndex = 0;
@@ -358,13 +359,23 @@ struct State {
     FShaderBuffer batchArgsBuffer_Default, batchArgsBuffer_DoubleSided, batchCountsBuffer, culledLightCountBuffer, culledLightListsBuffer, lightGridBuffer;
     FShaderBuffer renderStatsBuffer, rayStatsBuffer;
     std::vector<void*> allocations;
+    // Per-frame transients (renderer.cpp:1385-1515 creates them inside Render; RenderBackend12 recycles them through a pool keyed by
+    // the frame fence, backend-d3d12.cpp:616-789).  Here: stream-ordered allocations (hipMallocAsync from the device's default memory
+    // pool, release threshold raised so that freed blocks stay cached) handed out at the top of Render and returned at its end with
+    // the frame's fence, a HIP event.  A block is handed out again to the SAME stream at once (stream order is the fence) and to
+    // another stream only after its fence has passed; blocks unused for kTransientTrimFrames frames go back to the driver.
+    struct TransientBlock { void* ptr; uint64_t bytes; hipStream_t stream; hipEvent_t fence; uint64_t lastFrame; bool inUse; };
+    std::vector<TransientBlock> transients;
+    uint64_t transientBytes = 0, transientAllocs = 0, transientReuses = 0;
     int lastStatus = INCR_OK;
     // Sort-first multi-GPU: this GPU draws and shades rows [bandY0, bandY1) plus a one-row halo for the TAA
     // neighbourhood, resolves TAA for the band only and leaves gather + tonemap to the caller.  0,0 = the whole frame.
     uint32_t bandY0 = 0, bandY1 = 0;
     FShaderSurface* lastHdr = nullptr;                         // what the tonemap of this frame reads
     // FConfig::UseGraph: the frame's launches are captured, the instantiated graph is updated in place and replayed
-    hipGraphExec_t graphExec = nullptr;
+    hipGraphExec_t graphExec = nullptr;                        // the executable graph of the frame being issued (one of graphExecs)
+    hipGraphExec_t graphExecs[2] = {nullptr, nullptr};         // alternated: an exec is updated in place while the other one may still be running
+    hipEvent_t graphDone[2] = {nullptr, nullptr};              // recorded behind each launch; waited for before that exec is updated again
     hipStream_t captureStream = nullptr;                       // launches are captured here and replayed on the renderer's stream (which may be the null stream)
     uint64_t graphFrames = 0, graphUpdates = 0, graphRebuilds = 0;
     int graphStatus = 0;                                       // 0 = ok / unused, else the HIP error that switched graph replay off
@@ -388,36 +399,92 @@ static int buffer(State& s, FShaderBuffer& b, uint64_t bytes) { b.m_size = bytes
 
 static Matrix identity() { Matrix m{}; m.m[0] = m.m[5] = m.m[10] = m.m[15] = 1.f; return m; }
 
+static constexpr uint64_t kTransientTrimFrames = 64;
+static int transient_acquire(State& s, void** out, uint64_t bytes, hipStream_t stream) {
+    bytes = std::max<uint64_t>((bytes + 3) & ~3ull, 4);
+    for (State::TransientBlock& b : s.transients) {
+        if (b.inUse || b.bytes != bytes) continue;
+        if (b.stream != stream && hipEventQuery(b.fence) != hipSuccess) { (void)hipGetLastError(); continue; }      // another queue: only behind the fence
+        b.inUse = true; b.stream = stream; b.lastFrame = s.frameIndex; *out = b.ptr; s.transientReuses++;
+        return INCR_OK;
+    }
+    State::TransientBlock b{nullptr, bytes, stream, nullptr, s.frameIndex, true};
+    if (hipMallocAsync(&b.ptr, bytes, stream) != hipSuccess) { (void)hipGetLastError(); return INCR_ERR_OUT_OF_MEMORY; }
+    if (hipEventCreateWithFlags(&b.fence, hipEventDisableTiming) != hipSuccess || hipMemsetAsync(b.ptr, 0, bytes, stream) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFreeAsync(b.ptr, stream); if (b.fence) (void)hipEventDestroy(b.fence); return INCR_ERR_HIP;
+    }
+    s.transients.push_back(b); s.transientBytes += bytes; s.transientAllocs++;
+    *out = b.ptr;
+    return INCR_OK;
+}
+// End of the frame: every block handed out this frame goes back with the frame's fence; long-unused blocks are freed (stream-ordered).
+static void transient_release_frame(State& s, hipStream_t stream, bool capturing) {
+    for (size_t i = 0; i < s.transients.size();) {
+        State::TransientBlock& b = s.transients[i];
+        if (b.inUse) { b.inUse = false; if (!capturing) (void)hipEventRecord(b.fence, stream); ++i; continue; }
+        if (s.frameIndex - b.lastFrame > kTransientTrimFrames && !capturing) {
+            (void)hipFreeAsync(b.ptr, b.stream); (void)hipEventDestroy(b.fence); s.transientBytes -= b.bytes;
+            s.transients[i] = s.transients.back(); s.transients.pop_back();
+            continue;
+        }
+        ++i;
+    }
+}
+static int transient_surface(State& s, FShaderSurface& f, uint32_t texelBytes, hipStream_t stream) {
+    f.m_width = s.resX; f.m_height = s.resY; f.m_texelBytes = texelBytes;
+    return transient_acquire(s, &f.m_devicePtr, (uint64_t)s.resX * s.resY * texelBytes, stream);
+}
+static int transient_buffer(State& s, FShaderBuffer& b, uint64_t bytes, hipStream_t stream) { b.m_size = bytes; return transient_acquire(s, &b.m_devicePtr, bytes, stream); }
+
 int Initialize(State& s, incr_context* ctx, incr_stream stream, uint32_t resX, uint32_t resY, size_t meshletCount, const FConfig& c) {
     s.ctx = ctx; s.jobSync.m_ctx = ctx; s.jobSync.m_stream = stream; s.resX = resX; s.resY = resY;
     s.prevViewProjectionTransform = identity();
     for (uint32_t i = 0; i < 16; ++i) { float j[2]; incr_pixel_jitter(i, resX, resY, j); s.pixelJitterValues.push_back({j[0], j[1]}); }   // renderer.cpp:126-131
     int rc = 0;
-    FShaderSurface* four[] = {&s.hdrRasterSceneColor, &s.depthBuffer, &s.visBuffer, &s.gbuffer_basecolor, &s.gbuffer_normals, &s.gbuffer_metallicRoughnessAo,
-                              &s.pathtraceHistoryBuffer, &s.backBuffer};
-    for (FShaderSurface* f : four) if (!rc) rc = surface(s, *f, 4, true);
+    // persistent: the accumulation surfaces (renderer.cpp:96-124 creates them in Initialize), the back buffer, the read-back counters
+    FShaderSurface* kept[] = {&s.pathtraceHistoryBuffer, &s.backBuffer};
+    for (FShaderSurface* f : kept) if (!rc) rc = surface(s, *f, 4, true);
     for (FShaderSurface& f : s.taaAccumulationBuffer) {
         f.m_width = resX; f.m_height = resY; f.m_texelBytes = 4;
         if (!rc) rc = alloc(s, &f.m_devicePtr, (uint64_t)resX * (resY + kBandSlackRows) * 4, true);
     }
-    if (!rc) rc = surface(s, s.hdrRaytraceSceneColor, 8, true);
-    if (!rc) rc = surface(s, s.aoBuffer, 1, true);
-    if (!rc) rc = surface(s, s.bentNormalsBuffer, 4, true);
-    const uint64_t clusters = (uint64_t)c.LightClusterDimX * c.LightClusterDimY * c.LightClusterDimZ;
-    if (!rc) rc = buffer(s, s.batchArgsBuffer_Default, (meshletCount + 1) * sizeof(incr_draw_cmd));
-    if (!rc) rc = buffer(s, s.batchArgsBuffer_DoubleSided, (meshletCount + 1) * sizeof(incr_draw_cmd));
-    if (!rc) rc = buffer(s, s.batchCountsBuffer, 8);
-    if (!rc) rc = buffer(s, s.culledLightCountBuffer, 4);
-    if (!rc) rc = buffer(s, s.culledLightListsBuffer, clusters * c.MaxLightsPerCluster * 4);      // renderer.cpp:1506
-    if (!rc) rc = buffer(s, s.lightGridBuffer, clusters * 8);                                    // renderer.cpp:1515
     if (!rc) rc = buffer(s, s.renderStatsBuffer, sizeof(incr_render_stats));
     if (!rc) rc = buffer(s, s.rayStatsBuffer, sizeof(incr_ray_stats));
+    s.meshletCount = meshletCount;
+    // everything else is a per-frame transient (acquire_frame_transients): keep what the stream-ordered allocator frees cached
+    hipMemPool_t pool = nullptr;
+    int device = 0; (void)hipGetDevice(&device);          // incr_initialize made the context's device current
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) { uint64_t keep = ~0ull; (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep); }
+    else (void)hipGetLastError();
+    return rc;
+}
+
+// renderer.cpp:1385-1515: the frame's transient surfaces and buffers, in the reference's order
+static int acquire_frame_transients(State& s, const FConfig& c, hipStream_t stream) {
+    int rc = 0;
+    FShaderSurface* four[] = {&s.hdrRasterSceneColor, &s.depthBuffer, &s.visBuffer, &s.gbuffer_basecolor, &s.gbuffer_normals, &s.gbuffer_metallicRoughnessAo, &s.bentNormalsBuffer};
+    for (FShaderSurface* f : four) if (!rc) rc = transient_surface(s, *f, 4, stream);
+    if (!rc) rc = transient_surface(s, s.hdrRaytraceSceneColor, 8, stream);
+    if (!rc) rc = transient_surface(s, s.aoBuffer, 1, stream);
+    const uint64_t clusters = (uint64_t)c.LightClusterDimX * c.LightClusterDimY * c.LightClusterDimZ;
+    if (!rc) rc = transient_buffer(s, s.batchArgsBuffer_Default, (s.meshletCount + 1) * sizeof(incr_draw_cmd), stream);
+    if (!rc) rc = transient_buffer(s, s.batchArgsBuffer_DoubleSided, (s.meshletCount + 1) * sizeof(incr_draw_cmd), stream);
+    if (!rc) rc = transient_buffer(s, s.batchCountsBuffer, 8, stream);
+    if (!rc) rc = transient_buffer(s, s.culledLightCountBuffer, 4, stream);
+    if (!rc) rc = transient_buffer(s, s.culledLightListsBuffer, clusters * c.MaxLightsPerCluster * 4, stream);      // renderer.cpp:1506
+    if (!rc) rc = transient_buffer(s, s.lightGridBuffer, clusters * 8, stream);                                    // renderer.cpp:1515
     return rc;
 }
 
 void Teardown(State& s) {
     s.jobSync.SetThreads(0);
-    if (s.graphExec) { (void)hipGraphExecDestroy(s.graphExec); s.graphExec = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (s.graphExecs[i]) { (void)hipGraphExecDestroy(s.graphExecs[i]); s.graphExecs[i] = nullptr; }
+        if (s.graphDone[i]) { (void)hipEventDestroy(s.graphDone[i]); s.graphDone[i] = nullptr; }
+    }
+    s.graphExec = nullptr;
+    for (State::TransientBlock& b : s.transients) { (void)hipFreeAsync(b.ptr, b.stream); (void)hipEventDestroy(b.fence); }
+    s.transients.clear(); s.transientBytes = 0;
     if (s.captureStream) { (void)hipStreamDestroy(s.captureStream); s.captureStream = nullptr; }
     for (void* p : s.allocations) incr_buffer_destroy(s.ctx, p);
     s.allocations.clear();
@@ -454,7 +521,8 @@ int Render(State& s, const FRenderState& renderState) {
     // HIP-graph replay of the raster frame (not in the reference): launches of this frame are captured instead of executed, the
     // instantiated graph of the previous frame takes the new kernel arguments in place (hipGraphExecUpdate) and is launched
     // once.  The first two frames run directly (workspaces grow there); capture needs the launches on one host thread.
-    const bool useGraph = c.UseGraph && !c.PathTrace && s.graphStatus == 0 && s.frameIndex >= 2;
+    // (a profiled frame is issued directly: its per-pass events would otherwise be recorded into the capture)
+    const bool useGraph = c.UseGraph && !c.PathTrace && s.graphStatus == 0 && s.frameIndex >= 2 && !jobSync->m_profile;
     jobSync->SetThreads(useGraph ? 0 : c.RecordThreads);
     const incr_stream frameStream = jobSync->m_stream;
     if (useGraph) {
@@ -465,6 +533,10 @@ int Render(State& s, const FRenderState& renderState) {
         else jobSync->m_stream = (incr_stream)s.captureStream;
     }
     const bool capturing = useGraph && s.graphStatus == 0;
+    // the frame's transients come from the REAL stream (an allocation is not a capturable launch); in steady state every request is
+    // served by the block it had last frame, so a replayed graph keeps its addresses and hipGraphExecUpdate sees unchanged arguments
+    rc = acquire_frame_transients(s, c, (hipStream_t)frameStream);
+    if (rc) { if (capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s.captureStream, &g); if (g) (void)hipGraphDestroy(g); jobSync->m_stream = frameStream; } transient_release_frame(s, (hipStream_t)frameStream, false); return rc; }
 
     job(UpdateTLASPass::Execute(jobSync, scene));                              // :1676
 
@@ -642,15 +714,23 @@ int Render(State& s, const FRenderState& renderState) {
         hipError_t e = hipStreamEndCapture(s.captureStream, &graph);
         jobSync->m_stream = frameStream;
         if (e == hipSuccess && jobSync->m_firstError == INCR_OK) {
-            if (s.graphExec) {
+            // two executable graphs, alternated: the one updated in place here last ran two frames ago, and its launch has finished
+            // (the event behind that launch is waited for) -- an update never touches kernel arguments a running replay still reads
+            const int gi = (int)(s.frameIndex & 1u);
+            hipGraphExec_t& exec = s.graphExecs[gi];
+            if (!s.graphDone[gi]) e = hipEventCreateWithFlags(&s.graphDone[gi], hipEventDisableTiming);
+            else e = hipEventSynchronize(s.graphDone[gi]);
+            if (e == hipSuccess && exec) {
                 hipGraphExecUpdateResult result; hipGraphNode_t errNode = nullptr;
-                e = hipGraphExecUpdate(s.graphExec, graph, &errNode, &result);
+                e = hipGraphExecUpdate(exec, graph, &errNode, &result);
                 if (e == hipSuccess) s.graphUpdates++;
-                else { (void)hipGetLastError(); (void)hipGraphExecDestroy(s.graphExec); s.graphExec = nullptr; e = hipSuccess; }    // topology changed (a pass toggled): rebuild
+                else { (void)hipGetLastError(); (void)hipGraphExecDestroy(exec); exec = nullptr; e = hipSuccess; }    // topology changed (a pass toggled): rebuild
             }
-            if (!s.graphExec) { e = hipGraphInstantiate(&s.graphExec, graph, nullptr, nullptr, 0); if (e == hipSuccess) s.graphRebuilds++; }
-            if (e == hipSuccess) e = hipGraphLaunch(s.graphExec, (hipStream_t)jobSync->m_stream);
+            if (e == hipSuccess && !exec) { e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); if (e == hipSuccess) s.graphRebuilds++; }
+            if (e == hipSuccess) e = hipGraphLaunch(exec, (hipStream_t)jobSync->m_stream);
+            if (e == hipSuccess) e = hipEventRecord(s.graphDone[gi], (hipStream_t)jobSync->m_stream);
             if (e == hipSuccess) s.graphFrames++;
+            s.graphExec = exec;
         }
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {      // the frame is lost for replay: report, and issue every later frame directly
@@ -658,6 +738,7 @@ int Render(State& s, const FRenderState& renderState) {
             if (jobSync->m_firstError == INCR_OK) { jobSync->m_firstError = INCR_ERR_HIP; jobSync->m_firstErrorMessage = std::string("HIP graph replay failed: ") + hipGetErrorString(e); }
         }
     }
+    transient_release_frame(s, (hipStream_t)frameStream, false);      // back to the pool with this frame's fence (recorded on the real stream, behind the frame)
     s.hostSecondsLastFrame = std::chrono::duration<double>(std::chrono::steady_clock::now() - hostT0).count();
     s.frameIndex++;
     s.lastStatus = jobSync->m_firstError;

@@ -186,14 +186,15 @@ static int bake_primitives(const HostScene& h, const std::vector<incr_gpu_primit
 int incr_raster_scene_update(incr_scene* sc, hipStream_t stream) {
     const HostScene& h = sc->host;
     // batch culling and the forward-pass flags read dMeshVisibility; decals were baked with meshTransform * rootTransform
-    if (!h.meshVisibility.empty()) HIP_TRY(hipMemcpyAsync(sc->dMeshVisibility, h.meshVisibility.data(), h.meshVisibility.size() * 4, hipMemcpyHostToDevice, stream));
-    if (sc->numDecals) {
+    // (called inside incr_update_bvh's staging bracket: the sources are copied into the pinned slot before the call returns)
+    int rc = INCR_OK;
+    if (!h.meshVisibility.empty()) rc = incr_staging_upload(sc, sc->dMeshVisibility, h.meshVisibility.data(), h.meshVisibility.size() * 4, stream);
+    if (!rc && sc->numDecals) {
         std::vector<float> l2w((size_t)sc->numDecals * 16);
         for (size_t i = 0; i < sc->numDecals; ++i) { const M44 m = m44_mul(h.decalTransforms[i], h.rootTransform); memcpy(&l2w[i * 16], m.m, 64); }
-        HIP_TRY(hipMemcpyAsync(sc->dDecalLocalToWorld, l2w.data(), l2w.size() * 4, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));      // l2w is a stack-lifetime staging copy (decals are rare; the BVH path above never waits)
+        rc = incr_staging_upload(sc, sc->dDecalLocalToWorld, l2w.data(), l2w.size() * 4, stream);
     }
-    return INCR_OK;
+    return rc;
 }
 
 void incr_raster_scene_free(incr_scene* sc) {

@@ -295,3 +295,15 @@ def test_golden_raster_crop(ob, helmet, sio, R, A):
     covered = g["vis"] != 0xFFFFF000
     assert 0.1 < covered.mean() < 0.9 and (g["depth"][~covered] == 0).all()
     osc.close()
+
+
+def test_example_hdr_decoder_matches_the_oracle(ob):
+    """examples/render.py --dump-hdr decodes R11G11B10_FLOAT in numpy: every bit pattern class against the oracle's decoder."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import render
+    w = np.concatenate([np.random.default_rng(3).integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32),
+                        np.array([0, 0xffffffff, 0x7c0 | (0x7c0 << 11) | (0x3e0 << 22), 1 | (1 << 11) | (1 << 22)], np.uint32)])
+    a, b = render.decode_r11g11b10(w), ob.unpack_r11g11b10(w)
+    fin = np.isfinite(b)
+    assert np.array_equal(a[fin], b[fin]) and (np.isnan(a) == np.isnan(b)).all() and (np.isinf(a) == np.isinf(b)).all()

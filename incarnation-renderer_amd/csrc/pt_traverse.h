@@ -1,15 +1,15 @@
 // pt_traverse.h -- 8-wide quantised BVH traversal with LDS-staged per-lane stacks, ray/triangle test, camera rays.
-// Shared by every path-tracing kernel (pathtrace_wf.hip: production wavefront kernels; pathtrace.hip /
-// pathtrace_wave.hip: single-kernel variants kept for A/B) and by incr_trace_rays.
+// Shared by every kernel that traces: the wavefront path tracer (pathtrace_wf.hip), incr_trace_rays (pt_queries.hip) and the raster
+// passes that issue ray queries (raster.hip: sun shadow packets, HBAO, forward lighting).
 //
 // Stand-in for the fixed-function DXR traversal: TraceRay(RAY_FLAG_CULL_BACK_FACING_TRIANGLES)
 // closest hit with the ahsMain alpha test on non-opaque geometry, and RayQuery + one Proceed() for shadow rays.
 //
 // Traversal is a RESUMABLE STATE MACHINE with exactly ONE memory round trip per step: the loads of a step are issued
 // together before any branching.  Measured on MI355X: with per-leaf / per-triangle loops inside the step, a wave paid
-// up to ~10 serialised round trips per iteration (~8000 cycles per step, waves 70 % waiting).  Two generations of the
-// step live here: trav_*_step tests one 8-wide node (5 x dwordx4) OR one pending triangle of the last node (3 x
-// dwordx4); trav_*_step2 (what the kernels use) tests one node AND one queued triangle in the same step.
+// up to ~10 serialised round trips per iteration (~8000 cycles per step, waves 70 % waiting).  trav_closest_step2 /
+// trav_any_step2 (what every kernel uses) test one 8-wide node (5 x dwordx4) AND one queued triangle (3 x dwordx4) in the same
+// step; trav_closest_step, the first generation (node OR triangle), is kept for the statistics build (tools/trav_stats.py).
 #pragma once
 #include "pt_device.h"
 
@@ -389,38 +389,6 @@ struct TravAny { RaySetup rs; f3 d; float tmin, tmax; uint32_t cur, triBase, tri
 DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
     T.rs = ray_setup(o, d); T.d = d; T.tmin = tmin; T.tmax = tmax; T.cur = 0; T.triBase = 0; T.triMask = 0; T.occluded = false; T.haveCur = false;
 }
-template <class ST> DI bool trav_any_step(const PtParams& P, ST& st, TravAny& T) {
-    const Fetch5 f = fetch_step(P, st, T.cur, T.triBase, T.triMask);
-    if (T.triMask) {
-        T.triMask &= T.triMask - 1u;
-        float t, u, v; uint32_t flat, flags;
-        if (tri_intersect(f.a, f.b, f.c, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; return true; }
-        if (T.triMask) return false;
-    } else {
-        Node8 N;
-        node8_test(f.a, f.b, f.c, f.d, f.e, T.rs, T.tmin, T.tmax, N);
-        T.triBase = N.triBase;
-        T.triMask = node8_tri_mask(N);
-        // inner children in slot order (nearest-first or ray-side-first visit 10 % MORE nodes for shadow rays, tools/trav_sim):
-        // the first is visited next, after this node's triangles (a hit ends the query); the others are one stack entry
-        const uint32_t inner = N.hitMask & N.imask;
-        T.haveCur = inner != 0u;
-        if (inner) {
-            const uint32_t rest = inner & (inner - 1u);
-            if (rest) st.push(stack_entry(N.childBase, false, rest));
-            T.cur = N.childBase + (uint32_t)__builtin_ctz(inner);
-        }
-        if (T.triMask) return false;
-    }
-    if (T.haveCur) { T.haveCur = false; return false; }
-    if (st.sp == 0) return true;
-    uint32_t e = st.top();
-    T.cur = (e >> 9) + (uint32_t)__builtin_ctz(e & 0xffu);
-    e &= e - 1u;                      // the lowest set bit is a slot bit: the mask of a stored entry is never empty
-    if (e & 0xffu) st.setTop(e); else st.drop();
-    return false;
-}
-
 // The same overlap for any-hit queries (wf_shadow_kernel).  A hit ends the query, so a triangle waiting in the queue costs the node
 // steps made while it waits when it turns out to be the occluder -- measured, the fuller lanes win: shadow 8.9 -> 7.9 ms per frame.
 struct TravAny2 : TravAny { uint32_t triBase1, triMask1; };

@@ -373,8 +373,15 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         texs[i].pad[0] = opaque ? 1u : 0u;
         texs[i].pad[1] = mips;
     }
-    // vMF-filtered chains for the normal + metallic-roughness pair of a material (scene.cpp:1157-1320), box chains for the rest
+    // vMF-filtered chains for the normal + metallic-roughness pair of a material (scene.cpp:1157-1320), box chains for the rest.
+    // The pairs are independent: their prefilters run on four streams (a pair's top levels are a few long serial sums,
+    // content_pipeline.hip), one synchronisation at the end.
     std::vector<uint8_t> haveChain(desc->num_textures, 0);
+    struct VmfJob { void* tmpN; void* tmpM; };
+    std::vector<VmfJob> vmfJobs;
+    hipStream_t vmfStreams[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (hipStream_t& st : vmfStreams) if (!rc && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(INCR_ERR_HIP, "stream creation failed");
+    if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "texture upload failed: %s", hipGetErrorString(e)); }      // level 0 is in place before the side streams read it
     for (uint32_t mi = 0; mi < desc->num_materials && !rc; ++mi) {
         const int32_t nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
         if (nt < 0 || mt < 0 || nt == mt || haveChain[(size_t)nt] || haveChain[(size_t)mt]) continue;
@@ -383,24 +390,26 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         if ((N.width >> (N.pad[1] - 1)) << (N.pad[1] - 1) != N.width || (N.height >> (N.pad[1] - 1)) << (N.pad[1] - 1) != N.height) continue;      // 2x2 footprints need even levels
         size_t chainTexels = 0;
         for (uint32_t l = 0; l < N.pad[1]; ++l) chainTexels += (size_t)(N.width >> l) * (N.height >> l);
-        void* tmpN = nullptr; void* tmpM = nullptr;
-        hipError_t e = hipMalloc(&tmpN, chainTexels * 4);
-        if (e == hipSuccess) e = hipMalloc(&tmpM, chainTexels * 4);
+        VmfJob job = {nullptr, nullptr};
+        hipStream_t st = vmfStreams[vmfJobs.size() & 3u];
+        hipError_t e = hipMalloc(&job.tmpN, chainTexels * 4);
+        if (e == hipSuccess) e = hipMalloc(&job.tmpM, chainTexels * 4);
+        vmfJobs.push_back(job);
         if (e == hipSuccess) {
             incr_prefilter_normal_roughness_desc pd = {};
             pd.normalmap = N.texels; pd.metallic_roughness = M.texels; pd.width = N.width; pd.height = N.height; pd.num_mips = N.pad[1];
-            pd.out_normalmap = (uint8_t*)tmpN; pd.out_metallic_roughness = (uint8_t*)tmpM;
+            pd.out_normalmap = (uint8_t*)job.tmpN; pd.out_metallic_roughness = (uint8_t*)job.tmpM;
             pd.reserved = 1;        // exact summation order: the chain equals the oracle's bit for bit
-            rc = incr_prefilter_normal_roughness(ctx, &pd, nullptr);
+            rc = incr_prefilter_normal_roughness(ctx, &pd, (incr_stream)st);
             const size_t first = (size_t)N.width * N.height;
-            if (!rc) e = incr_launch_mip_adopt_vmf((const uint32_t*)tmpN, (const uint32_t*)tmpM, (uint32_t*)N.texels, (uint32_t*)M.texels, first, chainTexels - first, nullptr);
-            if (!rc && e == hipSuccess) e = hipDeviceSynchronize();
+            if (!rc) e = incr_launch_mip_adopt_vmf((const uint32_t*)job.tmpN, (const uint32_t*)job.tmpM, (uint32_t*)N.texels, (uint32_t*)M.texels, first, chainTexels - first, st);
         }
-        if (tmpN) (void)hipFree(tmpN);
-        if (tmpM) (void)hipFree(tmpM);
         if (!rc && e != hipSuccess) rc = fail(INCR_ERR_HIP, "vMF mip chain failed: %s", hipGetErrorString(e));
         haveChain[(size_t)nt] = haveChain[(size_t)mt] = 1;
     }
+    { const hipError_t e = hipDeviceSynchronize(); if (!rc && e != hipSuccess) rc = fail(INCR_ERR_HIP, "vMF mip chain failed: %s", hipGetErrorString(e)); }
+    for (const VmfJob& j : vmfJobs) { if (j.tmpN) (void)hipFree(j.tmpN); if (j.tmpM) (void)hipFree(j.tmpM); }
+    for (hipStream_t st : vmfStreams) if (st) (void)hipStreamDestroy(st);
     for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
         if (haveChain[i]) continue;
         const DeviceTexture& T = texs[i];

@@ -96,18 +96,39 @@ __global__ __launch_bounds__(256) void vmf_level_kernel(const float4* __restrict
 }
 
 // Exact-order variant (incr_prefilter_normal_roughness_desc::reserved = 1): every destination texel walks its 2^k x 2^k footprint of
-// the BASE level with one running sum, y outer / x inner, exactly as the shader (and the oracle) does -- O(texels x levels), but
-// bit-identical chains.  The scene's textures are built with it: the raster passes sample these levels and their G-buffers are
-// compared with the oracle's bit for bit.
-__global__ __launch_bounds__(64) void vmf_level_exact_kernel(const uint32_t* __restrict__ srcN, const uint32_t* __restrict__ srcMR, uint32_t W, uint32_t mip,
-                                                             VmfLevel L, uint32_t* __restrict__ outN, uint32_t* __restrict__ outMR) {
-    const uint32_t x = blockIdx.x * 8u + (threadIdx.x & 7u), y = blockIdx.y * 8u + (threadIdx.x >> 3);
-    if (x >= L.w || y >= L.h) return;
+// the BASE level with ONE running sum, y outer / x inner, exactly as the shader (and the oracle) does -- a float sum cannot be
+// re-associated without changing bits, so a texel of level k is 4^k dependent additions.  What CAN run in parallel does: the vMF
+// vector of every base texel is evaluated once (vmf_base_kernel) instead of once per level, and ONE launch sums all levels, the
+// long footprints first (a 4 x 4 top level of a 1024^2 pair is 16 lanes x 65,536 additions; the lower levels fill the machine
+// meanwhile; several pairs run on parallel streams at scene creation).  Round 2 launched one kernel per level that re-evaluated
+// the base texels inside the loop: 0.8 s per Sponza-stat scene; this form takes a few milliseconds.  The scene's textures are built
+// with it: the raster passes sample these levels and their G-buffers are compared with the oracle's bit for bit.
+__global__ __launch_bounds__(256) void vmf_base_kernel(const uint32_t* __restrict__ srcN, const uint32_t* __restrict__ srcMR, float4* __restrict__ base, uint64_t texels) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < texels) base[i] = vmf_texel(srcN[i], srcMR[i]);
+}
+struct VmfLevels { VmfLevel L[16]; uint32_t first[17]; uint32_t mips; };      // first[k]: threads in front of level k when the levels are walked top-down (first[mips - 1] = 0)
+__global__ __launch_bounds__(64) void vmf_levels_exact_kernel(const float4* __restrict__ base, uint32_t W, VmfLevels V, uint32_t total,
+                                                               uint32_t* __restrict__ outN, uint32_t* __restrict__ outMR) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= total) return;
+    uint32_t mip = V.mips - 1u;
+    while (mip > 1u && t >= V.first[mip - 1u]) --mip;          // top level first: its threads are the longest
+    const VmfLevel L = V.L[mip];
+    const uint32_t local = t - V.first[mip];
+    const uint32_t y = local / L.w, x = local - y * L.w;
     const uint32_t fp = 1u << mip;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t yy = 0; yy < fp; ++yy) {
-        const uint64_t row = (uint64_t)(y * fp + yy) * W + (uint64_t)x * fp;
-        for (uint32_t xx = 0; xx < fp; ++xx) s = add4(s, vmf_texel(srcN[row + xx], srcMR[row + xx]));
+        const float4* __restrict__ row = base + (uint64_t)(y * fp + yy) * W + (uint64_t)x * fp;
+        if (fp >= 8u) {
+            for (uint32_t xx = 0; xx < fp; xx += 8u) {         // eight loads in flight, eight additions in the shader's order
+                const float4 a0 = row[xx], a1 = row[xx + 1], a2 = row[xx + 2], a3 = row[xx + 3], a4 = row[xx + 4], a5 = row[xx + 5], a6 = row[xx + 6], a7 = row[xx + 7];
+                s = add4(s, a0); s = add4(s, a1); s = add4(s, a2); s = add4(s, a3); s = add4(s, a4); s = add4(s, a5); s = add4(s, a6); s = add4(s, a7);
+            }
+        } else {
+            for (uint32_t xx = 0; xx < fp; ++xx) s = add4(s, row[xx]);
+        }
     }
     const uint64_t o = (uint64_t)y * L.w + x;
     vmf_store(s, (float)(fp * fp), outN + L.texelOffset + o, outMR + L.texelOffset + o);
@@ -153,13 +174,18 @@ int incr_prefilter_normal_roughness(incr_context* ctx, const incr_prefilter_norm
     vmf_mip0_kernel<<<dim3((uint32_t)((texels + 255) / 256)), dim3(256), 0, s>>>(srcN, srcMR, outN, outMR, texels);
     HIP_TRY(hipGetLastError());
     if (mips == 1) return INCR_OK;
-    if (d->reserved == 1u) {      // exact order
-        hipError_t e = hipSuccess;
-        for (uint32_t m = 1; m < mips && e == hipSuccess; ++m) {
-            vmf_level_exact_kernel<<<dim3((L[m].w + 7) / 8, (L[m].h + 7) / 8), dim3(64), 0, s>>>(srcN, srcMR, W, m, L[m], outN, outMR);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d->reserved == 1u) {      // exact order; stream-ordered from the scratch allocation to its release: the caller synchronises
+        float4* baseV = nullptr;
+        HIP_TRY(hipMallocAsync((void**)&baseV, texels * sizeof(float4), s));
+        vmf_base_kernel<<<dim3((uint32_t)((texels + 255) / 256)), dim3(256), 0, s>>>(srcN, srcMR, baseV, texels);
+        VmfLevels V; V.mips = mips;
+        uint32_t total = 0;
+        for (uint32_t m = mips; m-- > 1u;) { V.L[m] = L[m]; V.first[m] = total; total += L[m].w * L[m].h; }
+        V.L[0] = L[0]; V.first[0] = total;
+        vmf_levels_exact_kernel<<<dim3((total + 63u) / 64u), dim3(64), 0, s>>>(baseV, W, V, total, outN, outMR);
+        hipError_t e = hipGetLastError();
+        const hipError_t e2 = hipFreeAsync(baseV, s);
+        if (e == hipSuccess) e = e2;
         if (e != hipSuccess) return fail(INCR_ERR_HIP, "prefilter_normal_roughness: %s", hipGetErrorString(e));
         return INCR_OK;
     }

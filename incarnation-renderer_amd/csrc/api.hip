@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libincr_hip.so (include/incr.h): context, resource layer, scene upload and the
 // per-pass entry points.  Host code only; kernels live in pathtrace.hip / raster.hip.
 #include <hip/hip_runtime.h>
+#include <cfloat>
 
 #include <cmath>
 #include <cstdarg>
@@ -20,7 +21,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events);
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
-                                             const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream);
+                                             const uint32_t* ranges, uint32_t numRanges, void* nodeBoxes, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
                                           const float* srgbLut, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
@@ -234,7 +235,11 @@ static int upload_bvh(incr_scene* sc) {
     if ((rc = upload_vec(&sc->dMeshLocalToWorld, (const float*)sc->bvh.meshLocalToWorld.data(), sc->bvh.meshLocalToWorld.size() * 16))) return rc;
     // inputs of the device-side update (bvh_update.hip)
     if ((rc = upload_vec(&sc->dTriObj, sc->bvh.triObj.data(), sc->bvh.triObj.size()))) return rc;
-    if ((rc = upload_vec(&sc->dLevelNodes, sc->bvh.levelNodes.data(), sc->bvh.levelNodes.size()))) return rc;
+    {   // refit order: the static part + room for the dynamic tail (mesh roots + top nodes: at most topCapacity entries)
+        std::vector<uint32_t> order(sc->bvh.refitStaticNodes + sc->bvh.topCapacity, 0u);
+        std::copy(sc->bvh.refitNodes.begin(), sc->bvh.refitNodes.end(), order.begin());
+        if ((rc = upload_vec(&sc->dLevelNodes, order.data(), order.size()))) return rc;
+    }
     std::vector<MeshInstanceInfo> info(sc->host.meshTransforms.size());
     if ((rc = upload_vec(&sc->dMeshInfo, info.data(), info.size()))) return rc;
     if (sc->dNodeBoxes) { (void)hipFree(sc->dNodeBoxes); sc->dNodeBoxes = nullptr; }
@@ -508,14 +513,38 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
     refresh_mesh_instances(sc->host, sc->bvh, info);
     build_light_grid(sc->host, sc->bvh, sc->grid);
     // every host -> device byte of this update goes through one pinned, double-buffered staging slot (api_internal.h UpdateStaging)
-    int rc = incr_staging_begin(sc, nm * (64 + sizeof(MeshInstanceInfo) + 4) + (sc->grid.cellOffsets.size() + sc->grid.cellLights.size()) * 4 + (size_t)sc->numDecals * 64 + 256);
+    int rc = incr_staging_begin(sc, nm * (64 + sizeof(MeshInstanceInfo) + 4) + (sc->grid.cellOffsets.size() + sc->grid.cellLights.size()) * 4 + (size_t)sc->numDecals * 64
+                                    + (size_t)sc->bvh.topCapacity * (sizeof(BvhNode8) + 4) + 1024);
     if (rc) return rc;
     if (nm) {
         if ((rc = incr_staging_upload(sc, sc->dMeshLocalToWorld, sc->bvh.meshLocalToWorld.data(), nm * 64, st))) return rc;
         if ((rc = incr_staging_upload(sc, sc->dMeshInfo, info.data(), nm * sizeof(MeshInstanceInfo), st))) return rc;
     }
+    // the reference rebuilds its TLAS here (update-tlas.inl:24-89): the top tree over the meshes' new boxes (conservative: the eight
+    // corners of every object-space box; the refit below tightens them), a fraction of a millisecond on the host for a thousand meshes
+    {
+        std::vector<float> meshBoxes(nm * 6, 0.f);
+        for (size_t m = 0; m < nm; ++m) {
+            float lo[3] = {1.f, 1.f, 1.f}, hi[3] = {-1.f, -1.f, -1.f};
+            const float* b = sc->bvh.meshObjBox.size() == nm * 6 ? &sc->bvh.meshObjBox[m * 6] : nullptr;
+            if (b && sc->host.meshVisibility[m] && b[0] <= b[3]) {
+                for (int a = 0; a < 3; ++a) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; }
+                for (int c = 0; c < 8; ++c) {
+                    const V3 p = m44_transform_point(v3(b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]), sc->bvh.meshLocalToWorld[m]);
+                    const float q[3] = {p.x, p.y, p.z};
+                    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+                }
+                for (int a = 0; a < 3; ++a) if (!(lo[a] >= -FLT_MAX && hi[a] <= FLT_MAX)) { lo[0] = lo[1] = lo[2] = 1.f; hi[0] = hi[1] = hi[2] = -1.f; break; }
+            }
+            for (int a = 0; a < 3; ++a) { meshBoxes[m * 6 + a] = lo[a]; meshBoxes[m * 6 + 3 + a] = hi[a]; }
+        }
+        rebuild_top_tree(sc->bvh, meshBoxes.data());
+        if ((rc = incr_staging_upload(sc, sc->dNodes, sc->bvh.nodes8.data(), (size_t)sc->bvh.topCapacity * sizeof(BvhNode8), st))) return rc;
+        const size_t dyn = sc->bvh.refitNodes.size() - sc->bvh.refitStaticNodes;
+        if ((rc = incr_staging_upload(sc, sc->dLevelNodes + sc->bvh.refitStaticNodes, sc->bvh.refitNodes.data() + sc->bvh.refitStaticNodes, dyn * 4, st))) return rc;
+    }
     HIP_TRY(incr_launch_bvh_update((uint32_t)sc->bvh.tris.size(), sc->dTriObj, sc->dMeshLocalToWorld, sc->dMeshInfo, sc->dTris, sc->dShade, sc->dNodes,
-                                   sc->dLevelNodes, sc->bvh.levelOffsets.data(), (uint32_t)sc->bvh.levelOffsets.size() - 1u, sc->dNodeBoxes, st));
+                                   sc->dLevelNodes, sc->bvh.refitRanges.data(), (uint32_t)sc->bvh.refitRanges.size() / 2u, sc->dNodeBoxes, st));
     rc = upload_light_grid(sc, st, true);
     if (!rc) rc = incr_raster_scene_update(sc, st);       // raster side: mesh visibility flags, decal transforms
     const int rc2 = incr_staging_end(sc, st);

@@ -137,15 +137,16 @@ __global__ __launch_bounds__(64) void bvh_refit_level_kernel(const uint32_t* __r
 }
 } // namespace incr
 
-// Stream-ordered: re-transform every triangle, then refit level by level, deepest first.  `levelOffsets` is the host copy.
+// Stream-ordered: re-transform every triangle, then refit range by range (scene_build.h refitRanges: children before parents --
+// the meshes' subtrees deepest local level first, the mesh roots, the top tree deepest level first).  `ranges` is the host copy.
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
-                                             incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
-                                             const uint32_t* levelOffsets, uint32_t numLevels, void* nodeBoxes, hipStream_t stream) {
+                                             incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dRefitNodes,
+                                             const uint32_t* ranges, uint32_t numRanges, void* nodeBoxes, hipStream_t stream) {
     using namespace incr;
     if (numTris) hipLaunchKernelGGL(bvh_retransform_kernel, dim3((numTris + 255u) / 256u), dim3(256), 0, stream, numTris, src, meshLocalToWorld, meshInfo, tris, shade);
-    for (uint32_t d = numLevels; d-- > 0;) {
-        const uint32_t first = levelOffsets[d], count = levelOffsets[d + 1] - first;
-        if (count) hipLaunchKernelGGL(bvh_refit_level_kernel, dim3((count + 63u) / 64u), dim3(64), 0, stream, dLevelNodes + first, count, nodes, tris, (NodeBox*)nodeBoxes);
+    for (uint32_t r = 0; r < numRanges; ++r) {
+        const uint32_t first = ranges[2 * r], count = ranges[2 * r + 1];
+        if (count) hipLaunchKernelGGL(bvh_refit_level_kernel, dim3((count + 63u) / 64u), dim3(64), 0, stream, dRefitNodes + first, count, nodes, tris, (NodeBox*)nodeBoxes);
     }
     return hipGetLastError();
 }

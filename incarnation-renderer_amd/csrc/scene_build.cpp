@@ -4,6 +4,8 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <cfloat>
 #include <cstdio>
@@ -125,9 +127,10 @@ struct Builder {
     static constexpr int kBins = 32;
     static constexpr int bins = kBins;
 
-    Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_) : tb(tb_), cen(cen_) {
-        order.resize(tb.size()); std::iota(order.begin(), order.end(), 0u);
-        nodes.reserve(tb.size() ? tb.size() : 1);
+    // over the items [first, first + count) of tb / cen: `order` holds their indices, build(0, count) is the root
+    Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_, uint32_t first, uint32_t count) : tb(tb_), cen(cen_) {
+        order.resize(count); std::iota(order.begin(), order.end(), first);
+        nodes.reserve(count ? 2 * (size_t)count : 1);
     }
     static inline float axis_of(const V3& v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
 
@@ -197,108 +200,18 @@ struct Builder {
         return me;
     }
 };
-} // namespace
 
-void refresh_mesh_instances(const HostScene& s, HostBvh& out, std::vector<MeshInstanceInfo>& info) {
-    const size_t nm = s.meshTransforms.size();
-    out.meshLocalToWorld.resize(nm); info.resize(nm);
-    uint32_t inst = 0;
-    Box world; box_reset(world);
-    for (size_t m = 0; m < nm; ++m) {
-        out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
-        const bool visible = s.meshVisibility[m] != 0;
-        info[m].instance = visible ? inst++ : 0xffffffffu;                 // update-tlas.inl:20-48: one instance per VISIBLE mesh
-        info[m].mirrored = m44_det3(out.meshLocalToWorld[m]) < 0.f ? 1u : 0u;
-        if (visible && out.meshObjBox.size() == nm * 6 && out.meshObjBox[m * 6] <= out.meshObjBox[m * 6 + 3]) {
-            const float* b = &out.meshObjBox[m * 6];
-            for (int c = 0; c < 8; ++c) {
-                const V3 p = m44_transform_point(v3(b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]), out.meshLocalToWorld[m]);
-                const float q[3] = {p.x, p.y, p.z};
-                for (int a = 0; a < 3; ++a) if (q[a] == q[a]) { world.lo[a] = std::min(world.lo[a], q[a]); world.hi[a] = std::max(world.hi[a], q[a]); }
-            }
-        }
-    }
-    out.numInstances = inst;
-    const bool any = world.lo[0] <= world.hi[0];
-    for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? world.lo[a] : 0.f; out.sceneHi[a] = any ? world.hi[a] : 0.f; }
-}
+// ---- 8-wide subtrees ----------------------------------------------------------------------------------------------------------
+// The world-space tree is TWO-LEVEL IN ONE ARRAY: every mesh owns a subtree built once over its own triangles (the reference's BLAS
+// per mesh, scene.cpp:685-772), and a small top tree over the mesh roots (its TLAS, rebuilt every frame by update-tlas.inl:24-89)
+// joins them -- same node format, same traversal, no per-instance ray transform.  When meshes move, their subtrees are re-transformed
+// and refitted on the device (bvh_update.hip) and the top tree is REBUILT from the new mesh boxes (build_top_tree: a thousand boxes,
+// a fraction of a millisecond on the host), so the structure is as good as a fresh build however far the instances travel.
+struct WideTree { std::vector<BvhNode8> nodes; std::vector<uint32_t> depth; std::vector<uint32_t> leafOrder; uint32_t maxDepth = 0; Box box; };
 
-void build_world_bvh(const HostScene& s, HostBvh& out) {
-    // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform).
-    //    Hidden meshes stay in the tree as unhittable (NaN) triangles: incr_update_bvh can then show / hide a mesh by
-    //    re-transforming and refitting on the device, without a rebuild; ids count visible meshes only, as DXR's do.
-    struct Flat { V3 v0, e1, e2; V3 obj[3]; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; bool hidden; };
-    std::vector<Flat> flat;
-    const size_t numMeshes = s.meshTransforms.size();
-    out.meshObjBox.assign(numMeshes * 6, 0.f);
-    for (size_t m = 0; m < numMeshes; ++m) for (int a = 0; a < 3; ++a) { out.meshObjBox[m * 6 + a] = FLT_MAX; out.meshObjBox[m * 6 + 3 + a] = -FLT_MAX; }
-    out.meshLocalToWorld.resize(numMeshes);
-    for (size_t m = 0; m < numMeshes; ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
-    uint32_t inst = 0;
-    for (uint32_t mesh = 0; mesh < (uint32_t)numMeshes; ++mesh) {
-        const bool hidden = !s.meshVisibility[mesh];
-        const M44& l2w = out.meshLocalToWorld[mesh];
-        const bool mirrored = m44_det3(l2w) < 0.f;
-        for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
-            const uint32_t pg = s.primitiveOffset[mesh] + g;
-            const incr_gpu_primitive& prim = s.primitives[pg];
-            const bool opaque = s.materials[(size_t)prim.materialIndex].alphaMode == INCR_ALPHA_OPAQUE;    // scene.cpp:736
-            AccessorRef ia, pa; const bool hi = resolve_accessor(s, prim.indexAccessor, &ia), hp = resolve_accessor(s, prim.positionAccessor, &pa);
-            const uint32_t ntri = (uint32_t)prim.indexCount / 3;
-            for (uint32_t p = 0; p < ntri; ++p) {
-                Flat f;
-                fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
-                V3 v[3];
-                for (int k = 0; k < 3; ++k) {
-                    float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos);
-                    f.obj[k] = v3(pos[0], pos[1], pos[2]);
-                    v[k] = m44_transform_point(f.obj[k], l2w);
-                    for (int a = 0; a < 3; ++a) if (pos[a] == pos[a]) {
-                        out.meshObjBox[mesh * 6 + a] = std::min(out.meshObjBox[mesh * 6 + a], pos[a]);
-                        out.meshObjBox[mesh * 6 + 3 + a] = std::max(out.meshObjBox[mesh * 6 + 3 + a], pos[a]);
-                    }
-                }
-                f.v0 = v[0];
-                f.e1 = (mirrored ? v[2] : v[1]) - v[0];
-                f.e2 = (mirrored ? v[1] : v[2]) - v[0];
-                f.inst = hidden ? 0xffffffffu : inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg; f.hidden = hidden;
-                f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
-                flat.push_back(f);
-            }
-        }
-        if (!hidden) ++inst;
-    }
-    out.numInstances = inst;
-
-    // 2. SAH BVH2
-    const size_t n = flat.size();
-    std::vector<Box> tb(n); std::vector<V3> cen(n);
-    Box scene; box_reset(scene);
-    for (size_t i = 0; i < n; ++i) {
-        const Flat& f = flat[i];
-        const V3 a = f.v0, b = f.v0 + f.e1, c = f.v0 + f.e2;
-        const float xs[3] = {a.x, b.x, c.x}, ys[3] = {a.y, b.y, c.y}, zs[3] = {a.z, b.z, c.z};
-        tb[i].lo[0] = std::min(xs[0], std::min(xs[1], xs[2])); tb[i].hi[0] = std::max(xs[0], std::max(xs[1], xs[2]));
-        tb[i].lo[1] = std::min(ys[0], std::min(ys[1], ys[2])); tb[i].hi[1] = std::max(ys[0], std::max(ys[1], ys[2]));
-        tb[i].lo[2] = std::min(zs[0], std::min(zs[1], zs[2])); tb[i].hi[2] = std::max(zs[0], std::max(zs[1], zs[2]));
-        // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
-        for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
-        cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
-        if (!f.hidden) box_grow(scene, tb[i]);
-    }
-    { const bool any = n && scene.lo[0] <= scene.hi[0]; for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? scene.lo[a] : 0.f; out.sceneHi[a] = any ? scene.hi[a] : 0.f; } }
-    // The traversal kernels carry one stack entry per tree level (kMaxBvhDepth).  The SAH-optimal collapse below takes at least one
-    // binary level per wide level, so a skewed binary tree (a long strip, a teapot in a stadium) can come out deeper than that:
-    // the build then repeats with the SAH switched off below a shallower binary depth -- object-median splits are balanced,
-    // ceil(log2 n) <= 23 levels for the 2^23 triangles a scene may have, and the wide tree is never deeper than the binary one.
-    std::vector<uint32_t> nodeDepth;
-    std::vector<uint32_t> leafOrder; leafOrder.reserve(n);          // leaf-order position -> flattened triangle id
-  for (const uint32_t sahDepth : {48u, 12u, 0u}) {
-    Builder b(tb, cen);
-    b.sahDepth = sahDepth;
-    if (n) b.build(0, (uint32_t)n);
-    nodeDepth.clear(); leafOrder.clear();
-
+// BVH2 `b` (root = node 0 over b.order[0 .. count)) -> 8-wide quantised nodes with local indices
+static void collapse_to_wide(const Builder& b, size_t count, WideTree& W) {
+    W.nodes.clear(); W.depth.clear(); W.leafOrder.clear();
     // 3. collapse BVH2 -> 8-wide quantised nodes.  Which binary subtrees become the (up to 8) children of a wide node, and which
     //    become leaves of <= kMaxLeafTris triangles, is chosen by dynamic programming over the SAH cost (Ylitie, Karras, Laine
     //    2017, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", section 4.1):
@@ -308,8 +221,8 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     //    largest area until a node had 8: on Sponza-stat that left the average node 3.8 children of 8 -- and a node step costs the
     //    same ~300 VALU instructions however many of its slots are in use; the traversal kernels are VALU-bound.
     //    Triangles are laid out in NODE order: the leaf children of one node8 own one contiguous run.
-    out.nodes8.clear(); out.maxDepth = 0;
-    if (n) {
+    W.nodes.clear(); W.maxDepth = 0;
+    if (count) {
         const size_t n2 = b.nodes.size();
         constexpr float cNode = INCR_BVH_COST_NODE, cTri = INCR_BVH_COST_TRI;
         struct Dp { float c[8]; uint8_t split[9]; bool leaf; };      // c[i], i = 1..7; split[j] = k of D(n, j) (j = 2..8), 0 = "use C(n, j - 1)"
@@ -349,13 +262,13 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         };
         struct Item8 { uint32_t n2, n8, depth; };
         std::vector<Item8> work8;
-        out.nodes8.push_back({});
+        W.nodes.push_back({});
         work8.push_back({0u, 0u, 1u});
         while (!work8.empty()) {
             const Item8 it = work8.back(); work8.pop_back();
-            out.maxDepth = std::max(out.maxDepth, it.depth);
-            if (nodeDepth.size() < out.nodes8.size()) nodeDepth.resize(out.nodes8.size(), 0u);
-            nodeDepth[it.n8] = it.depth;
+            W.maxDepth = std::max(W.maxDepth, it.depth);
+            if (W.depth.size() < W.nodes.size()) W.depth.resize(W.nodes.size(), 0u);
+            W.depth[it.n8] = it.depth;
             uint32_t kids[8]; int nk = 0;
             const Node2& root2 = b.nodes[it.n2];
             if (root2.count || (it.n2 == 0 && dp[0].leaf)) kids[nk++] = it.n2;      // degenerate: the whole tree is one leaf
@@ -386,11 +299,11 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                 ebits[a] = (uint8_t)e;
             }
             nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
-            nd.childBase = (uint32_t)out.nodes8.size();
+            nd.childBase = (uint32_t)W.nodes.size();
             uint32_t numInner = 0;
             for (int k = 0; k < nk; ++k) if (!is_leaf(kids[k])) ++numInner;
-            nd.triBase = (uint32_t)leafOrder.size() - 4u * numInner;          // LEAF SLOTS (device_types.h): the leaf in slot k owns records triBase + 4 k .. + 3
-            out.nodes8.resize(out.nodes8.size() + numInner);
+            nd.triBase = (uint32_t)W.leafOrder.size() - 4u * numInner;          // LEAF SLOTS (device_types.h): the leaf in slot k owns records triBase + 4 k .. + 3
+            W.nodes.resize(W.nodes.size() + numInner);
             uint32_t innerSlot = 0;
             uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
             const float org[3] = {nd.ox, nd.oy, nd.oz};
@@ -406,33 +319,31 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                 }
                 if (is_leaf(kids[k])) {
                     nd.leafTris |= ((1u << c.spanCount) - 1u) << (4 * k);
-                    for (uint32_t t = 0; t < 4u; ++t) leafOrder.push_back(t < c.spanCount ? b.order[c.spanFirst + t] : kTriHole);
+                    for (uint32_t t = 0; t < 4u; ++t) W.leafOrder.push_back(t < c.spanCount ? b.order[c.spanFirst + t] : kTriHole);
                 } else { nd.imask |= (uint8_t)(1u << k); work8.push_back({kids[k], nd.childBase + innerSlot, it.depth + 1}); ++innerSlot; }
             }
             nd.sortAxis = (uint8_t)sortAxis;
-            out.nodes8[it.n8] = nd;
+            W.nodes[it.n8] = nd;
         }
     } else {
         BvhNode8 e; memset(&e, 0, sizeof e);
         for (int k = 0; k < 8; ++k) { e.qlox[k] = e.qloy[k] = e.qloz[k] = 255; }
         e.ex = e.ey = e.ez = 1;
-        out.nodes8.push_back(e);
+        W.nodes.push_back(e);
     }
 
-    uint32_t depthLimit = kMaxBvhDepth;
-    if (const char* e = getenv("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
-    if (out.maxDepth <= depthLimit) break;            // (the median build cannot exceed kMaxBvhDepth: see above)
-  }
+}
 
+static void reorder_best_first(WideTree& W) {
     // NODE ORDER: best-first by box area -- the root, then repeatedly the children block of the largest node placed so far.
     // Index order then approximates visit frequency (the top three levels take ~40 % of all node visits on Sponza-stat,
     // tools/trav_sim), so "index < K" names the K hottest nodes: the traversal kernels keep those in LDS (pt_traverse.h).
-    nodeDepth.resize(out.nodes8.size(), 1u);
-    if (n) {
-        const size_t nn = out.nodes8.size();
+    W.depth.resize(W.nodes.size(), 1u);
+    if (W.nodes.size() > 1) {
+        const size_t nn = W.nodes.size();
         std::vector<float> area(nn, 0.f);
         for (size_t i = 0; i < nn; ++i) {
-            const BvhNode8& nd = out.nodes8[i];
+            const BvhNode8& nd = W.nodes[i];
             const uint8_t eb[3] = {nd.ex, nd.ey, nd.ez}; float ext[3];
             for (int a = 0; a < 3; ++a) { uint32_t bits = (uint32_t)eb[a] << 23; float sc; memcpy(&sc, &bits, 4); ext[a] = 255.f * sc; }
             area[i] = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];          // area of the node's quantisation frame: monotone down the tree
@@ -442,7 +353,7 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         uint32_t next = 1; heap.push_back({area[0], 0u});
         while (!heap.empty()) {
             std::pop_heap(heap.begin(), heap.end()); const uint32_t o = heap.back().second; heap.pop_back();
-            const BvhNode8& nd = out.nodes8[o];
+            const BvhNode8& nd = W.nodes[o];
             for (uint32_t k = 0; k < 8; ++k) if ((nd.imask >> k) & 1u) {
                 const uint32_t c = nd.childBase + k;
                 newIndex[c] = next++;
@@ -451,20 +362,303 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         }
         std::vector<BvhNode8> reordered(nn); std::vector<uint32_t> depth2(nn, 1u);
         for (size_t i = 0; i < nn; ++i) {
-            BvhNode8 nd = out.nodes8[i];
+            BvhNode8 nd = W.nodes[i];
             if (nd.imask) nd.childBase = newIndex[nd.childBase];
-            reordered[newIndex[i]] = nd; depth2[newIndex[i]] = nodeDepth[i];
+            reordered[newIndex[i]] = nd; depth2[newIndex[i]] = W.depth[i];
         }
-        out.nodes8.swap(reordered); nodeDepth.swap(depth2);
+        W.nodes.swap(reordered); W.depth.swap(depth2);
     }
-    // node lists by depth (the device refit walks them deepest level first)
-    if (!n) { out.maxDepth = 1; nodeDepth.assign(1, 1u); }
-    out.levelOffsets.assign(out.maxDepth + 1, 0u);
-    for (uint32_t d : nodeDepth) out.levelOffsets[d]++;                     // counts at [depth]
-    for (uint32_t d = 1; d <= out.maxDepth; ++d) out.levelOffsets[d] += out.levelOffsets[d - 1];
-    out.levelNodes.resize(out.nodes8.size());
-    { std::vector<uint32_t> fill(out.levelOffsets.begin(), out.levelOffsets.end() - 1);
-      for (uint32_t i = 0; i < (uint32_t)nodeDepth.size(); ++i) out.levelNodes[fill[nodeDepth[i] - 1]++] = i; }
+}
+
+// A mesh's subtree over the flattened triangles [first, first + count).  The traversal kernels carry one stack entry per tree level
+// (kMaxBvhDepth).  The SAH-optimal collapse takes at least one binary level per wide level, so a skewed binary tree (a long strip, a
+// teapot in a stadium) can come out deeper than its budget: the build then repeats with the SAH switched off below a shallower binary
+// depth -- object-median splits are balanced, ceil(log2 n) <= 23 levels for 2^23 triangles, and the wide tree is never deeper than
+// the binary one.
+static void build_wide_subtree(const std::vector<Box>& tb, const std::vector<V3>& cen, uint32_t first, uint32_t count, uint32_t depthBudget, WideTree& W) {
+    uint32_t depthLimit = depthBudget;
+    if (const char* e = getenv("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
+    box_reset(W.box);
+    for (const uint32_t sahDepth : {48u, 12u, 0u}) {
+        Builder b(tb, cen, first, count);
+        b.sahDepth = sahDepth;
+        if (count) { b.build(0, count); W.box = b.nodes[0].box; }
+        collapse_to_wide(b, count, W);
+        if (W.maxDepth <= depthLimit) break;
+    }
+    reorder_best_first(W);
+}
+
+// origin, exponents and the eight quantised child boxes of a node whose box is `nb` (conservative under the traversal's float decode)
+static void quantise_children(BvhNode8& nd, const Box& nb, const Box* child, int nk) {
+    nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
+    float scale[3]; uint8_t ebits[3];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = std::max(nb.hi[a] - nb.lo[a], 0.f);
+        int e = 1;
+        if (ext > 0.f) { e = (int)std::ceil(std::log2((double)ext / 255.0)) + 127; e = std::min(std::max(e, 1), 254); }
+        for (;;) { uint32_t bits = (uint32_t)e << 23; float sc; memcpy(&sc, &bits, 4); if (nb.lo[a] + 255.f * sc >= nb.hi[a] || e >= 254) { scale[a] = sc; break; } ++e; }
+        ebits[a] = (uint8_t)e;
+    }
+    nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+    uint8_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz}; uint8_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
+    const float org[3] = {nd.ox, nd.oy, nd.oz};
+    for (int k = 0; k < 8; ++k) {
+        const bool empty = k >= nk || !(child[k].lo[0] <= child[k].hi[0] && child[k].lo[1] <= child[k].hi[1] && child[k].lo[2] <= child[k].hi[2]);
+        for (int a = 0; a < 3; ++a) {
+            if (empty) { qlo[a][k] = 255; qhi[a][k] = 0; continue; }           // nothing to hit below: inverted box
+            int lo = (int)std::floor((child[k].lo[a] - org[a]) / scale[a]), hi = (int)std::ceil((child[k].hi[a] - org[a]) / scale[a]);
+            lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+            while (lo > 0 && org[a] + (float)lo * scale[a] > child[k].lo[a]) --lo;
+            while (hi < 255 && org[a] + (float)hi * scale[a] < child[k].hi[a]) ++hi;
+            qlo[a][k] = (uint8_t)lo; qhi[a][k] = (uint8_t)hi;
+        }
+    }
+}
+} // namespace
+
+// The TOP REGION nodes8[0 .. topCapacity): the top tree over the meshes' boxes (binned SAH over the boxes, children opened by area
+// until a node has eight) with ONE COPY OF EVERY MESH ROOT as its leaves-that-are-inner-nodes, children of a node contiguous (SLOT
+// ORDER), the root at index 0.  meshBoxes: 6 floats per mesh (lo.xyz, hi.xyz; lo > hi = nothing to hit).  Also rewrites the dynamic
+// tail of the refit order (mesh roots, then top nodes deepest first) and maxDepth.  Called at scene creation (exact boxes) and by
+// incr_update_bvh (conservative boxes of the moved meshes: the device refit that follows tightens every box).
+void rebuild_top_tree(HostBvh& out, const float* meshBoxes) {
+    const size_t numMeshes = out.meshRoot.size();
+    std::vector<uint32_t> items;
+    for (size_t m = 0; m < numMeshes; ++m) if (out.meshHasTris[m]) items.push_back((uint32_t)m);
+    std::fill(out.nodes8.begin(), out.nodes8.begin() + out.topCapacity, BvhNode8{});
+    std::vector<uint32_t> depth(out.topCapacity, 0u);
+    std::vector<uint32_t> roots, tops;            // region indices
+    uint32_t used = 1;
+    auto box_of = [&](uint32_t m) { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = meshBoxes[m * 6 + a]; b.hi[a] = meshBoxes[m * 6 + 3 + a]; } return b; };
+    if (items.empty()) {
+        BvhNode8 e; memset(&e, 0, sizeof e);
+        for (int k = 0; k < 8; ++k) { e.qlox[k] = e.qloy[k] = e.qloz[k] = 255; }
+        e.ex = e.ey = e.ez = 1;
+        out.nodes8[0] = e; depth[0] = 1; tops.push_back(0);
+    } else if (items.size() == 1) {
+        out.nodes8[0] = out.meshRoot[items[0]]; depth[0] = 1; roots.push_back(0); out.meshRootIndex[items[0]] = 0;
+    } else {
+        std::vector<Box> tb(items.size()); std::vector<V3> cen(items.size());
+        Box all; box_reset(all);
+        for (size_t i = 0; i < items.size(); ++i) { tb[i] = box_of(items[i]); if (tb[i].lo[0] <= tb[i].hi[0]) box_grow(all, tb[i]); }
+        for (size_t i = 0; i < items.size(); ++i) {
+            if (!(tb[i].lo[0] <= tb[i].hi[0] && tb[i].lo[1] <= tb[i].hi[1] && tb[i].lo[2] <= tb[i].hi[2])) {      // hidden / empty mesh: a point where it disturbs the SAH least
+                for (int a = 0; a < 3; ++a) tb[i].lo[a] = tb[i].hi[a] = all.lo[0] <= all.hi[0] ? 0.5f * (all.lo[a] + all.hi[a]) : 0.f;
+            }
+            cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
+        }
+        for (const uint32_t sahDepth : {48u, 0u}) {
+            Builder b(tb, cen, 0u, (uint32_t)items.size());
+            b.sahDepth = sahDepth;
+            b.build(0, (uint32_t)items.size());
+            std::fill(depth.begin(), depth.end(), 0u); roots.clear(); tops.clear(); used = 1;
+            struct Item { uint32_t n2, at, depth; };
+            std::vector<Item> work; work.push_back({0u, 0u, 1u});
+            uint32_t topDepth = 0;
+            while (!work.empty()) {
+                const Item it = work.back(); work.pop_back();
+                const Node2& x = b.nodes[it.n2];
+                uint32_t kids[8]; int nk = 0;
+                kids[nk++] = x.left; kids[nk++] = x.right;
+                while (nk < 8) {                       // open the largest inner child until the node has eight
+                    int best = -1; float bestA = -1.f;
+                    for (int k = 0; k < nk; ++k) if (!b.nodes[kids[k]].count) { const float A = box_area(b.nodes[kids[k]].box); if (A > bestA) { bestA = A; best = k; } }
+                    if (best < 0) break;
+                    const Node2& c = b.nodes[kids[best]];
+                    kids[best] = c.left; kids[nk++] = c.right;
+                }
+                int sortAxis = 0;
+                for (int a = 1; a < 3; ++a) if (x.box.hi[a] - x.box.lo[a] > x.box.hi[sortAxis] - x.box.lo[sortAxis]) sortAxis = a;
+                std::stable_sort(kids, kids + nk, [&](uint32_t p, uint32_t q) {
+                    const Box& bp = b.nodes[p].box; const Box& bq = b.nodes[q].box;
+                    return bp.lo[sortAxis] + bp.hi[sortAxis] < bq.lo[sortAxis] + bq.hi[sortAxis];
+                });
+                BvhNode8 nd; memset(&nd, 0, sizeof nd);
+                Box cb[8];
+                for (int k = 0; k < nk; ++k) { cb[k] = b.nodes[kids[k]].box; if (b.nodes[kids[k]].count) cb[k] = box_of(items[b.order[b.nodes[kids[k]].first]]); }      // a mesh's own box (empty for a hidden mesh)
+                quantise_children(nd, x.box, cb, nk);
+                nd.imask = (uint8_t)((1u << nk) - 1u); nd.sortAxis = (uint8_t)sortAxis; nd.childBase = used;
+                used += (uint32_t)nk;
+                for (int k = 0; k < nk; ++k) {
+                    const Node2& c = b.nodes[kids[k]];
+                    const uint32_t at = nd.childBase + (uint32_t)k;
+                    depth[at] = it.depth + 1;
+                    if (c.count) { const uint32_t m = items[b.order[c.first]]; out.nodes8[at] = out.meshRoot[m]; out.meshRootIndex[m] = at; roots.push_back(at); }
+                    else work.push_back({kids[k], at, it.depth + 1});
+                }
+                out.nodes8[it.at] = nd; depth[it.at] = it.depth; tops.push_back(it.at);
+                topDepth = std::max(topDepth, it.depth);
+            }
+            if (topDepth <= 8u) break;             // (median splits over <= 2^23 meshes: <= 23 binary levels, <= 8 levels of eight)
+        }
+    }
+    out.topCount = used;
+    // dynamic tail of the refit order + the tree's depth
+    out.refitNodes.resize(out.refitStaticNodes); out.refitRanges.resize(2 * (size_t)out.refitStaticRanges);
+    out.maxDepth = 1;
+    if (!roots.empty()) { out.refitRanges.push_back((uint32_t)out.refitNodes.size()); out.refitRanges.push_back((uint32_t)roots.size()); out.refitNodes.insert(out.refitNodes.end(), roots.begin(), roots.end()); }
+    for (size_t m = 0; m < numMeshes; ++m) if (out.meshHasTris[m]) out.maxDepth = std::max(out.maxDepth, depth[out.meshRootIndex[m]] + out.meshLocalDepth[m] - 1u);
+    uint32_t maxTop = 0; for (uint32_t t : tops) maxTop = std::max(maxTop, depth[t]);
+    out.maxDepth = std::max(out.maxDepth, maxTop);
+    for (uint32_t d = maxTop; d >= 1u; --d) {
+        const uint32_t first = (uint32_t)out.refitNodes.size();
+        for (uint32_t t : tops) if (depth[t] == d) out.refitNodes.push_back(t);
+        if (out.refitNodes.size() > first) { out.refitRanges.push_back(first); out.refitRanges.push_back((uint32_t)out.refitNodes.size() - first); }
+    }
+}
+
+void refresh_mesh_instances(const HostScene& s, HostBvh& out, std::vector<MeshInstanceInfo>& info) {
+    const size_t nm = s.meshTransforms.size();
+    out.meshLocalToWorld.resize(nm); info.resize(nm);
+    uint32_t inst = 0;
+    Box world; box_reset(world);
+    for (size_t m = 0; m < nm; ++m) {
+        out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+        const bool visible = s.meshVisibility[m] != 0;
+        info[m].instance = visible ? inst++ : 0xffffffffu;                 // update-tlas.inl:20-48: one instance per VISIBLE mesh
+        info[m].mirrored = m44_det3(out.meshLocalToWorld[m]) < 0.f ? 1u : 0u;
+        if (visible && out.meshObjBox.size() == nm * 6 && out.meshObjBox[m * 6] <= out.meshObjBox[m * 6 + 3]) {
+            const float* b = &out.meshObjBox[m * 6];
+            for (int c = 0; c < 8; ++c) {
+                const V3 p = m44_transform_point(v3(b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]), out.meshLocalToWorld[m]);
+                const float q[3] = {p.x, p.y, p.z};
+                for (int a = 0; a < 3; ++a) if (q[a] == q[a]) { world.lo[a] = std::min(world.lo[a], q[a]); world.hi[a] = std::max(world.hi[a], q[a]); }
+            }
+        }
+    }
+    out.numInstances = inst;
+    const bool any = world.lo[0] <= world.hi[0];
+    for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? world.lo[a] : 0.f; out.sceneHi[a] = any ? world.hi[a] : 0.f; }
+}
+
+void build_world_bvh(const HostScene& s, HostBvh& out) {
+    // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform).
+    //    Hidden meshes stay in the tree as unhittable (NaN) triangles: incr_update_bvh can then show / hide a mesh by
+    //    re-transforming and refitting on the device, without a rebuild; ids count visible meshes only, as DXR's do.
+    struct Flat { V3 v0, e1, e2; V3 obj[3]; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; bool hidden; };
+    std::vector<Flat> flat;
+    const size_t numMeshes = s.meshTransforms.size();
+    out.meshObjBox.assign(numMeshes * 6, 0.f);
+    for (size_t m = 0; m < numMeshes; ++m) for (int a = 0; a < 3; ++a) { out.meshObjBox[m * 6 + a] = FLT_MAX; out.meshObjBox[m * 6 + 3 + a] = -FLT_MAX; }
+    out.meshLocalToWorld.resize(numMeshes);
+    for (size_t m = 0; m < numMeshes; ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
+    uint32_t inst = 0;
+    std::vector<uint32_t> meshFirst(numMeshes + 1, 0u);          // flattened triangles of mesh m: [meshFirst[m], meshFirst[m + 1])
+    for (uint32_t mesh = 0; mesh < (uint32_t)numMeshes; ++mesh) {
+        meshFirst[mesh] = (uint32_t)flat.size();
+        const bool hidden = !s.meshVisibility[mesh];
+        const M44& l2w = out.meshLocalToWorld[mesh];
+        const bool mirrored = m44_det3(l2w) < 0.f;
+        for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
+            const uint32_t pg = s.primitiveOffset[mesh] + g;
+            const incr_gpu_primitive& prim = s.primitives[pg];
+            const bool opaque = s.materials[(size_t)prim.materialIndex].alphaMode == INCR_ALPHA_OPAQUE;    // scene.cpp:736
+            AccessorRef ia, pa; const bool hi = resolve_accessor(s, prim.indexAccessor, &ia), hp = resolve_accessor(s, prim.positionAccessor, &pa);
+            const uint32_t ntri = (uint32_t)prim.indexCount / 3;
+            for (uint32_t p = 0; p < ntri; ++p) {
+                Flat f;
+                fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
+                V3 v[3];
+                for (int k = 0; k < 3; ++k) {
+                    float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos);
+                    f.obj[k] = v3(pos[0], pos[1], pos[2]);
+                    v[k] = m44_transform_point(f.obj[k], l2w);
+                    for (int a = 0; a < 3; ++a) if (pos[a] == pos[a]) {
+                        out.meshObjBox[mesh * 6 + a] = std::min(out.meshObjBox[mesh * 6 + a], pos[a]);
+                        out.meshObjBox[mesh * 6 + 3 + a] = std::max(out.meshObjBox[mesh * 6 + 3 + a], pos[a]);
+                    }
+                }
+                f.v0 = v[0];
+                f.e1 = (mirrored ? v[2] : v[1]) - v[0];
+                f.e2 = (mirrored ? v[1] : v[2]) - v[0];
+                f.inst = hidden ? 0xffffffffu : inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg; f.hidden = hidden;
+                f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
+                flat.push_back(f);
+            }
+        }
+        if (!hidden) ++inst;
+    }
+    out.numInstances = inst;
+    meshFirst[numMeshes] = (uint32_t)flat.size();
+
+    // triangle boxes
+    const size_t n = flat.size();
+    std::vector<Box> tb(n); std::vector<V3> cen(n);
+    Box scene; box_reset(scene);
+    for (size_t i = 0; i < n; ++i) {
+        const Flat& f = flat[i];
+        const V3 a = f.v0, b = f.v0 + f.e1, c = f.v0 + f.e2;
+        const float xs[3] = {a.x, b.x, c.x}, ys[3] = {a.y, b.y, c.y}, zs[3] = {a.z, b.z, c.z};
+        tb[i].lo[0] = std::min(xs[0], std::min(xs[1], xs[2])); tb[i].hi[0] = std::max(xs[0], std::max(xs[1], xs[2]));
+        tb[i].lo[1] = std::min(ys[0], std::min(ys[1], ys[2])); tb[i].hi[1] = std::max(ys[0], std::max(ys[1], ys[2]));
+        tb[i].lo[2] = std::min(zs[0], std::min(zs[1], zs[2])); tb[i].hi[2] = std::max(zs[0], std::max(zs[1], zs[2]));
+        // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
+        for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
+        cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
+        if (!f.hidden) box_grow(scene, tb[i]);
+    }
+    { const bool any = n && scene.lo[0] <= scene.hi[0]; for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? scene.lo[a] : 0.f; out.sceneHi[a] = any ? scene.hi[a] : 0.f; } }
+    // 2. one 8-wide subtree per mesh over its run of the flattened triangles (the reference's BLAS per mesh), built in parallel
+    std::vector<WideTree> sub(numMeshes);
+    {
+        std::vector<uint32_t> todo;
+        for (uint32_t m = 0; m < (uint32_t)numMeshes; ++m) if (meshFirst[m + 1] > meshFirst[m]) todo.push_back(m);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= todo.size()) break;
+                const uint32_t m = todo[i];
+                build_wide_subtree(tb, cen, meshFirst[m], meshFirst[m + 1] - meshFirst[m], kMaxBvhDepth - 8u, sub[m]);
+            }
+        };
+        const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32), todo.size());
+        if (nThreads <= 1) worker();
+        else { std::vector<std::thread> th; for (size_t t = 0; t < nThreads; ++t) th.emplace_back(worker); for (std::thread& t : th) t.join(); }
+    }
+    // 3. one node array: the TOP REGION (top tree + a copy of every mesh root, rebuild_top_tree) in front, then the subtrees below
+    //    their roots, mesh after mesh; triangle record slots in the same order.
+    out.meshRoot.assign(numMeshes, BvhNode8{}); out.meshHasTris.assign(numMeshes, 0); out.meshRootIndex.assign(numMeshes, 0u); out.meshLocalDepth.assign(numMeshes, 1u);
+    uint32_t numItems = 0;
+    for (size_t m = 0; m < numMeshes; ++m) if (meshFirst[m + 1] > meshFirst[m]) { out.meshHasTris[m] = 1; ++numItems; }
+    out.topCapacity = 2u * numItems + 2u;
+    std::vector<uint32_t> leafOrder; leafOrder.reserve(n + n / 2);          // leaf-order position -> flattened triangle id (holes: kTriHole)
+    out.nodes8.assign(out.topCapacity, BvhNode8{});
+    std::vector<uint32_t> blockStart(numMeshes, 0u);
+    uint32_t maxLocal = 1;
+    for (size_t m = 0; m < numMeshes; ++m) {
+        if (!out.meshHasTris[m]) continue;
+        const WideTree& W = sub[m];
+        blockStart[m] = (uint32_t)out.nodes8.size();
+        const uint32_t slotOffset = (uint32_t)leafOrder.size();
+        auto fix = [&](BvhNode8 nd) { if (nd.imask) nd.childBase = blockStart[m] + nd.childBase - 1u; nd.triBase += slotOffset; return nd; };      // (a node's children have local indices >= 1)
+        out.meshRoot[m] = fix(W.nodes[0]);
+        for (size_t i = 1; i < W.nodes.size(); ++i) out.nodes8.push_back(fix(W.nodes[i]));
+        leafOrder.insert(leafOrder.end(), W.leafOrder.begin(), W.leafOrder.end());
+        out.meshLocalDepth[m] = std::max(W.maxDepth, 1u);
+        maxLocal = std::max(maxLocal, out.meshLocalDepth[m]);
+    }
+    // refit order, static part: the subtrees below the roots, deepest local level first (children before parents)
+    out.refitNodes.clear(); out.refitRanges.clear();
+    for (uint32_t d = maxLocal; d >= 2u; --d) {
+        const uint32_t first = (uint32_t)out.refitNodes.size();
+        for (size_t m = 0; m < numMeshes; ++m) {
+            if (!out.meshHasTris[m]) continue;
+            const WideTree& W = sub[m];
+            for (size_t i = 1; i < W.nodes.size(); ++i) if (W.depth[i] == d) out.refitNodes.push_back(blockStart[m] + (uint32_t)i - 1u);
+        }
+        if (out.refitNodes.size() > first) { out.refitRanges.push_back(first); out.refitRanges.push_back((uint32_t)out.refitNodes.size() - first); }
+    }
+    out.refitStaticNodes = (uint32_t)out.refitNodes.size(); out.refitStaticRanges = (uint32_t)out.refitRanges.size() / 2u;
+    {
+        std::vector<float> meshBoxes(numMeshes * 6, 0.f);
+        for (size_t m = 0; m < numMeshes; ++m) for (int a = 0; a < 3; ++a) {
+            const bool any = out.meshHasTris[m] && !s.meshVisibility[m] ? false : out.meshHasTris[m] != 0;
+            meshBoxes[m * 6 + a] = any ? sub[m].box.lo[a] : 1.f; meshBoxes[m * 6 + 3 + a] = any ? sub[m].box.hi[a] : -1.f;
+        }
+        rebuild_top_tree(out, meshBoxes.data());
+    }
 
     // 4. emit triangles + shading records in leaf order
     const size_t slots = leafOrder.size();                 // triangles + holes (device_types.h LEAF SLOTS)
@@ -574,7 +768,8 @@ const char* check_bvh(const HostBvh& bvh) {
         (void)it.parent; (void)it.hasParent;
     }
     for (size_t i = 0; i < n; ++i) if (!seen[i]) return "triangle not referenced by any leaf";
-    for (size_t i = 0; i < visited.size(); ++i) if (!visited[i]) return "unreachable node";
+    for (size_t i = bvh.topCapacity; i < visited.size(); ++i) if (!visited[i]) return "unreachable node";          // (the top region keeps spare slots for rebuild_top_tree)
+    for (size_t i = 0; i < bvh.topCount && i < visited.size(); ++i) if (!visited[i]) return "unreachable node in the top region";
     return nullptr;
 }
 

@@ -42,8 +42,17 @@ struct HostBvh {
     float sceneLo[3], sceneHi[3];
     // ---- inputs of the device-side update (bvh_update.hip: re-transform + refit, UpdateTLASPass stand-in) ----
     std::vector<TriObject> triObj;      // leaf order: object-space vertices + mesh / flags / flattened id
-    std::vector<uint32_t> levelNodes;   // node indices sorted by depth (root first)
-    std::vector<uint32_t> levelOffsets; // levelNodes[levelOffsets[d] .. levelOffsets[d + 1]) = the nodes of depth d + 1
+    // two-level layout (scene_build.cpp): nodes8[0 .. topCapacity) is the TOP REGION -- the top tree over the meshes and one copy of
+    // every mesh root, rewritten by rebuild_top_tree -- and the meshes' subtrees below their roots follow and never move
+    uint32_t topCapacity = 0, topCount = 0;
+    std::vector<BvhNode8> meshRoot;          // per mesh: its root node with global child / triangle indices (the top region holds the live copy)
+    std::vector<uint8_t> meshHasTris;
+    std::vector<uint32_t> meshRootIndex;     // where the mesh's root copy sits in the top region
+    std::vector<uint32_t> meshLocalDepth;    // levels of the mesh's subtree, root included
+    // device refit order (bvh_update.hip): node indices, children before parents -- the static part (subtrees below the roots, deepest
+    // local level first) and the dynamic tail (mesh roots, then top nodes deepest first); refitRanges = (first, count) pairs in launch order
+    std::vector<uint32_t> refitNodes, refitRanges;
+    uint32_t refitStaticNodes = 0, refitStaticRanges = 0;
     std::vector<float> meshObjBox;      // 6 floats per mesh: object-space bounds of its positions (lo.xyz, hi.xyz); lo > hi when empty
 };
 
@@ -51,6 +60,8 @@ struct HostBvh {
 struct MeshInstanceInfo { uint32_t instance, mirrored; };
 // recompute meshLocalToWorld, the instance numbering and a conservative world box from the host scene's current transforms / visibility
 void refresh_mesh_instances(const HostScene& s, HostBvh& bvh, std::vector<MeshInstanceInfo>& info);
+// the top tree over the meshes' boxes (6 floats per mesh: lo.xyz, hi.xyz; lo > hi = nothing to hit) into nodes8[0 .. topCapacity)
+void rebuild_top_tree(HostBvh& bvh, const float* meshBoxes);
 
 // World-space light grid for the path tracer's next-event estimation.  A cell lists (ascending loop index) every
 // light of the chsMain light loop (pathtracing.hlsl:230-236) that can contribute a NON-ZERO radiance somewhere in

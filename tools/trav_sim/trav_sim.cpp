@@ -530,7 +530,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             if (cfg == 2 && variant == 2) {
                 for (int w = 0; w < 2; ++w) { double tot = 0, acc = 0; for (int d = 0; d < 32; ++d) tot += g_visitsByDepth[w][d];
                     printf("  %s node visits by depth (cumulative share):", w ? "any-hit" : "closest"); for (int d = 1; d < 12; ++d) { acc += g_visitsByDepth[w][d]; printf(" d%d %.3f", d, acc / tot); } printf("\n"); }
-                printf("  nodes per level:"); for (size_t d = 0; d + 1 < B.levelOffsets.size(); ++d) printf(" %u", B.levelOffsets[d + 1] - B.levelOffsets[d]); printf("\n");
+
             }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
             if (model) {

@@ -321,7 +321,7 @@ def _bounding_sphere(pos):
     return np.array([c[0], c[1], c[2], r], dtype=f32)
 
 
-def load_gltf(path, load_images=True, max_texture_size=None):
+def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False):
     """glTF 2.0 loader -> PackedScene: .gltf (external or `data:` buffers and images) and binary .glb (embedded BIN chunk,
     bufferView images) -- the two containers tinygltf's LoadASCIIFromFile / LoadBinaryFromFile accept (scene.cpp:113-130)."""
     import base64
@@ -443,6 +443,36 @@ def load_gltf(path, load_images=True, max_texture_size=None):
 
     RH2LH = mat_identity(); RH2LH[2, 2] = f32(-1)
 
+    # MeshUtils::FixupMeshes (mesh-utils.cpp:560-638): a primitive whose material has a normal map but which ships no TANGENT gets
+    # MikkTSpace tangents (incr_generate_tangents, csrc/mikktspace_gen.cpp) in a new buffer / view / accessor, as the reference appends
+    # them to the model.  ignore_tangents: treat every primitive as if it shipped none (tests).
+    generated = {}
+
+    def fixup_tangents(mesh_index, prim_index, p, at):
+        key = (mesh_index, prim_index)
+        if key in generated:
+            return generated[key]
+        acc = -1 if ignore_tangents else at.get("TANGENT", -1)
+        mat_i = p.get("material", 0)
+        needs = acc == -1 and mat_i < len(g.get("materials", [])) and "normalTexture" in g["materials"][mat_i]      # material.normalTexture.index != -1 (:576)
+        if needs and "NORMAL" in at and "TEXCOORD_0" in at and "indices" in p:
+            from . import runtime as _rt
+            nv = int(g["accessors"][at["POSITION"]]["count"])
+            pos = np.ascontiguousarray(s.accessor_array(at["POSITION"], np.float32, 3, nv))
+            nrm = np.ascontiguousarray(s.accessor_array(at["NORMAL"], np.float32, 3, nv))
+            uv = np.ascontiguousarray(s.accessor_array(at["TEXCOORD_0"], np.float32, 2, nv))
+            ia = g["accessors"][p["indices"]]
+            idt = {5121: np.uint8, 5123: np.uint16, 5125: np.uint32}[ia["componentType"]]
+            idx = np.ascontiguousarray(s.accessor_array(p["indices"], idt, 1, ia["count"]).astype(np.uint32).reshape(-1, 3))
+            out = np.zeros((nv, 4), np.float32)
+            _rt.check(_rt.load().incr_generate_tangents(pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data, idx.ctypes.data, nv, idx.shape[0], out.ctypes.data))
+            s.buffers.append(np.concatenate([out.view(np.uint8).reshape(-1), np.zeros(32, np.uint8)]))
+            s.buffer_views.append((len(s.buffers) - 1, 0, nv * 16))
+            s.accessors.append((len(s.buffer_views) - 1, 0, 16))
+            acc = len(s.accessors) - 1
+        generated[key] = acc
+        return acc
+
     def load_node(ni, parent):
         n = g["nodes"][ni]
         t = mat_identity()
@@ -462,12 +492,12 @@ def load_gltf(path, load_images=True, max_texture_size=None):
         if "mesh" in n:
             mesh = g["meshes"][n["mesh"]]
             prims = []
-            for p in mesh["primitives"]:
+            for pi, p in enumerate(mesh["primitives"]):
                 at = p["attributes"]
                 pos_acc = g["accessors"][at["POSITION"]]
                 pos = s.accessor_array(at["POSITION"], np.float32, 3, pos_acc["count"])
                 prims.append(dict(index=p["indices"], position=at["POSITION"], uv=at.get("TEXCOORD_0", -1),
-                                  normal=at.get("NORMAL", -1), tangent=at.get("TANGENT", -1), material=p.get("material", 0),
+                                  normal=at.get("NORMAL", -1), tangent=fixup_tangents(n["mesh"], pi, p, at), material=p.get("material", 0),
                                   index_count=g["accessors"][p["indices"]]["count"], vertex_count=int(pos_acc["count"]), sphere=_bounding_sphere(pos)))
             if mesh.get("name", "").startswith("decal"):          # scene.cpp:281: decal meshes live in their own entity list
                 s.decal_primitives.extend((p, world) for p in prims)

@@ -214,6 +214,15 @@ int  incr_unshard(incr_context* ctx, void* dst_full, const void* src_gathered, u
  * direct lighting -> clustered lighting -> TAA resolve -> tonemap.  All surfaces are linear res_x*res_y arrays in HBM.
  * ===================================================================================================== */
 
+/*
+ * MeshUtils::FixupMeshes (src/mesh-utils.cpp:560-638): tangents for a primitive whose material has a normal map and whose attributes
+ * lack TANGENT -- MikkTSpace's genTangSpaceDefault (triangles, angular threshold 180 degrees) through callbacks that read POSITION /
+ * NORMAL / TEXCOORD_0 by index and store float4(tangent, sign) at the indexed vertex (:28-112: of the faces around a vertex the last
+ * in face order decides).  Host function.  positions / normals: vertex_count x 3 floats, uvs: vertex_count x 2, indices:
+ * triangle_count x 3 (widened to 32 bits); out_tangents: vertex_count x 4 floats (0 where no face references the vertex).
+ */
+int      incr_generate_tangents(const float* positions, const float* normals, const float* uvs, const uint32_t* indices,
+                                uint32_t vertex_count, uint32_t triangle_count, float* out_tangents);
 /* MeshUtils::Meshletize (src/mesh-utils.cpp:640-835) as called by FScene::GenerateMeshlets (src/scene.cpp:503-560):
  * HOST-side load-time utility.  positions: vertex_count records of `position_stride_bytes` (>= 12) starting with xyz.
  * The returned set holds FGpuMeshlet ranges + bounding spheres (accessor/mesh/material fields are -1 for the caller to

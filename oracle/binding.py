@@ -190,6 +190,19 @@ class OracleScene:
         return dict(target=target, history=history, stats=stats, float=fl, chain=chain)
 
 
+def generate_tangents(pos, nrm, uv, idx):
+    """oracle_mikkt.cpp: MikkTSpace genTangSpaceDefault + the reference's SetTSpaceBasic.  pos/nrm [n,3] f32, uv [n,2] f32, idx [t,3] u32 -> [n,4] f32"""
+    L = lib()
+    L.orc_generate_tangents.restype = C.c_int
+    L.orc_generate_tangents.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_void_p]
+    pos = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(nrm, np.float32); uv = np.ascontiguousarray(uv, np.float32); idx = np.ascontiguousarray(idx, np.uint32)
+    out = np.zeros((pos.shape[0], 4), np.float32)
+    rc = L.orc_generate_tangents(pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data, idx.ctypes.data, pos.shape[0], idx.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_generate_tangents failed: %d" % rc)
+    return out
+
+
 # ---- raster half ----------------------------------------------------------------------------------------
 def pixel_jitter(frame_index, res_x, res_y):
     out = (C.c_float * 2)()

@@ -255,3 +255,23 @@ def test_update_bvh_rebuilds_the_top_tree_for_scattered_instances(gpu_ctx, rt, s
     print("scattered instances: %.3f ms per frame after incr_update_bvh, %.3f ms on a fresh scene" % (tu * 1e3, tf * 1e3))
     assert tu <= 1.10 * tf
     sc.close(); fresh.close()
+
+
+# ------------------------------------------------------------------------------------------------ generated tangents
+def test_helmet_without_tangents_renders_like_the_oracle(gpu_ctx, rt, sio, ob):
+    """MeshUtils::FixupMeshes path end to end: the helmet loaded with its TANGENT accessor ignored (MikkTSpace tangents generated by
+    the library), path traced on the GPU and by the oracle."""
+    from conftest import ROOT
+    packed = sio.load_gltf(os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf"), ignore_tangents=True)
+    W = H = 256
+    view = sio.FView().reset(packed, aspect=1.0)
+    sc = gpu_ctx.create_scene(packed)
+    pt = rt.PathTracer(gpu_ctx, sc, W, H)
+    pt.render(view, 1)
+    g = pt.read()
+    osc = ob.OracleScene(packed)
+    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count())
+    assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    ok, same = pixel_agreement(g["target"], o["target"])
+    assert ok >= 0.9995 and same >= 0.98, (ok, same)
+    osc.close(); pt.close(); sc.close()

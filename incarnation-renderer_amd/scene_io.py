@@ -321,7 +321,7 @@ def _bounding_sphere(pos):
     return np.array([c[0], c[1], c[2], r], dtype=f32)
 
 
-def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False):
+def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False, use_content_cache=False):
     """glTF 2.0 loader -> PackedScene: .gltf (external or `data:` buffers and images) and binary .glb (embedded BIN chunk,
     bufferView images) -- the two containers tinygltf's LoadASCIIFromFile / LoadBinaryFromFile accept (scene.cpp:113-130)."""
     import base64
@@ -376,6 +376,7 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
 
     # materials (FScene::LoadMaterial)
     image_cache = {}
+    content_cache_stats = {"hits": 0, "misses": 0}
 
     def image_rgba(image_index):
         if image_index not in image_cache:
@@ -385,10 +386,30 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
             else:                                              # embedded: the encoded file sits in a bufferView
                 bi, bo, bl = s.buffer_views[im["bufferView"]]
                 data = s.buffers[bi][bo:bo + bl].tobytes()
+            # Content cache (scene.cpp:13-89 LoadImageCallback / GetContentCachePath, FConfig::UseContentCache): the reference keeps the
+            # processed image next to the model under .content-cache/ and skips the decode when it is there.  Here the cached form is
+            # the decoded RGBA8 array (.npy), keyed by the encoded bytes' hash and the size limit -- a stale entry cannot be picked up.
+            cached = None
+            if use_content_cache:
+                import hashlib
+                cdir = os.path.join(os.path.dirname(os.path.abspath(path)), ".content-cache")
+                stem = os.path.splitext(os.path.basename(im["uri"]))[0] if "uri" in im and not im["uri"].startswith("data:") else "image%d" % image_index
+                cached = os.path.join(cdir, "%s.%s.%s.npy" % (stem, hashlib.sha256(data).hexdigest()[:16], max_texture_size or "full"))
+                if os.path.exists(cached):
+                    image_cache[image_index] = np.load(cached)
+                    content_cache_stats["hits"] += 1
+                    return image_cache[image_index]
             img = Image.open(io.BytesIO(data)).convert("RGBA")    # "Source Images are always 4 channel 8bpp" (scene.cpp:1167)
             if max_texture_size and max(img.size) > max_texture_size:
                 img = img.resize((max_texture_size, max_texture_size), Image.BOX)
             image_cache[image_index] = np.asarray(img, dtype=np.uint8).copy()
+            if cached:
+                os.makedirs(os.path.dirname(cached), exist_ok=True)
+                tmp = cached + ".tmp%d" % os.getpid()
+                with open(tmp, "wb") as f:
+                    np.save(f, image_cache[image_index])
+                os.replace(tmp, cached)
+                content_cache_stats["misses"] += 1
         return image_cache[image_index]
 
     tex_cache = {}
@@ -516,4 +537,5 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
         for ni in sc["nodes"]:
             load_node(ni, RH2LH)
     s.finalize_sun_light()
+    s.content_cache_stats = content_cache_stats        # hits / misses of this load (use_content_cache)
     return s

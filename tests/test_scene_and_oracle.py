@@ -222,3 +222,23 @@ def test_skewed_scene_builds_within_the_traversal_depth(rt, A, synth, monkeypatc
     forced = A.SceneInfo()
     assert lib.incr_scene_validate_host(C.byref(d), C.byref(forced)) == 0, lib.incr_last_error()        # check_bvh runs inside: every triangle in exactly one leaf, boxes conservative
     assert forced.num_triangles == base.num_triangles and forced.num_bvh_nodes != base.num_bvh_nodes     # another tree came out
+
+
+def test_content_cache_round_trip(sio, tmp_path):
+    """FConfig::UseContentCache (scene.cpp:13-89): the second load of a model takes its images from <model dir>/.content-cache and
+    packs the same bytes; another size limit is another cache entry."""
+    import shutil
+    src = os.path.join(ROOT, "assets", "damaged-helmet")
+    dst = tmp_path / "helmet"
+    shutil.copytree(src, dst)
+    path = str(dst / "DamagedHelmet.gltf")
+    a = sio.load_gltf(path, max_texture_size=64, use_content_cache=True)
+    assert a.content_cache_stats == {"hits": 0, "misses": 5} and len(os.listdir(dst / ".content-cache")) == 5
+    b = sio.load_gltf(path, max_texture_size=64, use_content_cache=True)
+    assert b.content_cache_stats == {"hits": 5, "misses": 0}
+    for (ia, fa), (ib, fb) in zip(a.textures, b.textures):
+        assert fa == fb and np.array_equal(ia, ib)
+    c = sio.load_gltf(path, max_texture_size=32, use_content_cache=True)
+    assert c.content_cache_stats["misses"] == 5 and len(os.listdir(dst / ".content-cache")) == 10
+    plain = sio.load_gltf(path, max_texture_size=64)
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(a.textures, plain.textures))

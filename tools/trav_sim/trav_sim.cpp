@@ -157,6 +157,55 @@ static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, co
 
 // ---- any hit ----------------------------------------------------------------------------------------
 // variant 0: one entry per overlapped inner child (round 1).  variant 1: one group entry per node.
+static std::vector<uint8_t> g_areaOrder;      // per node: its 8 slots by descending child-box area (any-hit experiment)
+static void build_area_order(const HostBvh& B) {
+    g_areaOrder.assign(B.nodes8.size() * 8, 0);
+    for (size_t i = 0; i < B.nodes8.size(); ++i) {
+        const BvhNode8& n = B.nodes8[i];
+        float sc[3]; const uint8_t eb[3] = {n.ex, n.ey, n.ez};
+        for (int a = 0; a < 3; ++a) { uint32_t bits = (uint32_t)eb[a] << 23; memcpy(&sc[a], &bits, 4); }
+        float area[8]; int ord[8];
+        for (int k = 0; k < 8; ++k) {
+            const float dx = ((int)n.qhix[k] - (int)n.qlox[k]) * sc[0], dy = ((int)n.qhiy[k] - (int)n.qloy[k]) * sc[1], dz = ((int)n.qhiz[k] - (int)n.qloz[k]) * sc[2];
+            area[k] = (dx < 0 || dy < 0 || dz < 0) ? -1.f : dx * dy + dy * dz + dz * dx; ord[k] = k;
+        }
+        std::stable_sort(ord, ord + 8, [&](int a, int b) { return area[a] > area[b]; });
+        for (int k = 0; k < 8; ++k) g_areaOrder[i * 8 + k] = (uint8_t)ord[k];
+    }
+}
+static bool anyhit_area(const HostBvh& B, const Ray& r, Stats& S) {
+    const float invd[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]};
+    uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;      // (node whose children wait, mask)
+    uint32_t cur = 0; bool have = true, occluded = false;
+    for (;;) {
+        if (!have) {
+            if (st.empty()) break;
+            auto& e = st.back();
+            uint32_t k = 8;
+            for (int j = 0; j < 8; ++j) { const uint32_t c = g_areaOrder[(size_t)e.first * 8 + j]; if ((e.second >> c) & 1u) { k = c; break; } }
+            cur = B.nodes8[e.first].childBase + k; e.second &= ~(1u << k);
+            if (!e.second) st.pop_back();
+        }
+        have = false;
+        const uint32_t me = cur;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes;
+        NodeT N; node_test(n, r, invd, r.tmax, N);
+        uint32_t tm = tri_mask(n, N.hit);
+        while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) occluded = true; }
+        if (occluded) break;
+        uint32_t inner = N.hit & n.imask;
+        if (!inner) continue;
+        uint32_t k0 = 8;
+        for (int j = 0; j < 8; ++j) { const uint32_t c = g_areaOrder[(size_t)me * 8 + j]; if ((inner >> c) & 1u) { k0 = c; break; } }
+        inner &= ~(1u << k0);
+        if (inner) { st.push_back({me, inner}); ++pushes; }
+        cur = n.childBase + k0; have = true;
+        maxDepth = std::max<uint32_t>(maxDepth, st.size());
+    }
+    note(S, nodes, tris, pushes, maxDepth, occluded);
+    return occluded;
+}
 static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const Ray& r, int variant, Stats& S) {
     const float invd[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]};
     uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
@@ -464,6 +513,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
     for (int cfg = fast ? 2 : 0; cfg < 3; ++cfg) {
         HostBvh B = base; std::vector<uint8_t> sortAxis(B.nodes8.size(), 0);
         if (cfg >= 1) reorder(B, sortAxis, cfg == 2);
+        if (getenv("X_AREA")) build_area_order(B);
         if (const char* e = check_bvh(B)) { printf("cfg %d: BVH check failed: %s\n", cfg, e); return 2; }
         printf("slot order %s\n", cfg == 0 ? "as built" : cfg == 1 ? "inner first" : "inner first + sorted along longest axis");
         const int nv = cfg == 0 ? 1 : 4;
@@ -502,6 +552,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                         Ray s; for (int k = 0; k < 3; ++k) { s.o[k] = p[k]; s.d[k] = d[k]; } s.tmin = 0.1f; s.tmax = tmax;
                         g_trace = model ? &trS : nullptr;
                         anyhit(B, sortAxis, s, (fast || model) ? 1 : variant, ss);
+                        if (getenv("X_AREA")) { g_trace = nullptr; anyhit_area(B, s, ss0); }
                         g_trace = nullptr;
                     };
                     if (sun[0] * n[0] + sun[1] * n[1] + sun[2] * n[2] > 0.f) shadow(sun, 1000.f);
@@ -533,6 +584,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
 
             }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
+            if (getenv("X_AREA")) print_stats("any-hit, area order", ss0);
             if (model) {
                 struct { const char* n; const Trace* t; size_t perWave; int chunk, refill; float cC, cN, cT; } sets[3] = {
                     {"primary", &trP, 1150, 64, 16, 100, 300, 150}, {"bounce", &trB, 700, 64, 16, 100, 300, 150}, {"shadow", &trS, 1700, 128, 12, 80, 260, 110}};

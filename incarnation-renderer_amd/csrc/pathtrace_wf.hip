@@ -252,10 +252,6 @@ struct LaneStats {
         const uint32_t n = (uint32_t)__popcll(__ballot(active && !triMask)), t = (uint32_t)__popcll(__ballot(active && triMask));
         it++; live += n + t; node += n; tri += t; if (exhausted) { drainIt++; drainLive += n + t; } if (!n || !t) pure++;
     }
-    DI void step2(uint32_t liveRays, bool nodeLane, bool triLane, bool exhausted) {        // two rays per lane: live = rays (<= 128)
-        const uint32_t n = (uint32_t)__popcll(__ballot(nodeLane)), t = (uint32_t)__popcll(__ballot(triLane));
-        it++; live += liveRays; node += n; tri += t; if (exhausted) { drainIt++; drainLive += liveRays; } if (!n || !t) pure++;
-    }
     DI void flush(int k) {
         if ((threadIdx.x & 63u) == 0) {
             const uint32_t v[8] = {it, live, node, tri, drainIt, drainLive, refills, pure};
@@ -786,123 +782,6 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
     LANE_STATS(ls.flush(1);)
 }
 
-// ------------------------------------------------------------------------------------------------ shadow rays, two rays per lane
-// The any-hit kernel above is VALU-issue bound with about half of its lanes useful (profiles/r02_pmc_summary*.txt): the node step and
-// the triangle step are different code, each runs with the lanes that happen to need it, and 14 of a wave's 64 lanes hold no ray
-// (refill threshold, the drain of a launch).  Here every lane carries TWO rays in registers (A and B, each with its own LDS stack):
-// per iteration the lane's node step goes to whichever of its rays can make one and its triangle step to whichever has a triangle
-// queued (the preference alternates, so neither ray starves), i.e. the same instruction stream -- plus ~35 selects -- retires the
-// steps of 128 rays instead of 64 (tools/trav_sim wave_model_dual: -13 ... -16 % instructions per step for shadow rays).
-// An occluded ray zeroes its visibility word at once; refills alternate between the two sets (the emptier one first).
-#ifndef INCR_SHADOW2_WAVES
-#define INCR_SHADOW2_WAVES 5
-#endif
-#ifndef INCR_SHADOW_DUAL_DEFAULT
-#define INCR_SHADOW_DUAL_DEFAULT 0
-#endif
-#ifndef INCR_SHADOW2_REFILL
-#define INCR_SHADOW2_REFILL 16
-#endif
-#ifndef INCR_SHADOW2_TOP
-#define INCR_SHADOW2_TOP 120
-#endif
-struct AnyRay2 { f3 o, d, invd; uint32_t cur, triBase, triMask, triBase1, triMask1, index; int sp; bool active, haveCur; };
-struct TopRef { static constexpr bool kTop = true; LdsNodes topNodes; uint32_t topCount; };
-DI void any2_begin(AnyRay2& R, const float4 qa, const float4 qb, uint32_t index) {
-    R.o = {qa.x, qa.y, qa.z}; R.d = {qb.x, qb.y, qb.z}; R.invd = ray_setup(R.o, R.d).invd;
-    R.cur = 0u; R.triBase = 0u; R.triMask = 0u; R.triBase1 = 0u; R.triMask1 = 0u; R.index = index; R.sp = 0; R.active = true; R.haveCur = true;
-}
-DI void any2_pop_tri(AnyRay2& R) {
-    R.triMask &= R.triMask - 1u;
-    if (!R.triMask) { R.triBase = R.triBase1; R.triMask = R.triMask1; R.triMask1 = 0u; }
-}
-DI void any2_push_tris(AnyRay2& R, uint32_t triBase, uint32_t tm) {
-    if (!R.triMask) { R.triBase = triBase; R.triMask = tm; } else { R.triBase1 = triBase; R.triMask1 = tm; }
-}
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 12 ? INCR_SHADOW2_WAVES : 3) void wf_shadow2_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    typedef __attribute__((address_space(3))) uint32_t* LdsU32;
-    __shared__ uint32_t s_stack[2 * N * kWfBlock];
-    __shared__ float4 s_top[INCR_SHADOW2_TOP * 5];
-    const LdsU32 stA = (LdsU32)(s_stack + threadIdx.x), stB = (LdsU32)(s_stack + N * kWfBlock + threadIdx.x);
-    TopRef top; top.topNodes = (LdsNodes)s_top; top.topCount = load_top_nodes(P, s_top, (uint32_t)INCR_SHADOW2_TOP);
-    const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
-    uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
-    WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
-    const float4 z4 = make_float4(0.f, 0.f, 1.f, 0.f);
-    AnyRay2 A, Bq; any2_begin(A, z4, z4, 0u); any2_begin(Bq, z4, z4, 0u); A.active = false; Bq.active = false;
-    bool pending = false, pendToA = true, flip = false;
-    uint32_t nextIndex = 0;
-    float4 qa = z4, qb = z4;
-    const float tmin = 0.1f, tmax = 1000.f;                                // lighting/common.hlsli:96-100
-    LANE_STATS(LaneStats ls;)
-    for (;;) {
-        const unsigned long long actA = __ballot(A.active), actB = __ballot(Bq.active);
-        const uint32_t idleA = 64u - (uint32_t)__popcll(actA), idleB = 64u - (uint32_t)__popcll(actB);
-        if (!chunk.exhausted && (idleA + idleB >= (uint32_t)INCR_SHADOW2_REFILL || (actA | actB) == 0ull)) {
-            LANE_STATS(ls.refills++;)
-            pendToA = idleA >= idleB;                                       // wave-uniform: the emptier set takes the rays
-            const uint32_t item = chunk.take(pendToA ? !A.active : !Bq.active, cursor, total);
-            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; nextIndex = item; pending = true; }
-        }
-        // ---- which ray of the lane takes the triangle step, which the node step
-        const bool wtA = A.active && A.triMask != 0u, wtB = Bq.active && Bq.triMask != 0u;
-        const bool wnA = A.active && A.haveCur && A.triMask1 == 0u, wnB = Bq.active && Bq.haveCur && Bq.triMask1 == 0u;
-        const bool tA = wtA && (flip || !wtB), tB = wtB && !tA;
-        const bool nA = wnA && (!flip || !wnB), nB = wnB && !nA;
-        flip = !flip;
-        LANE_STATS(ls.step2((uint32_t)__popcll(actA) + (uint32_t)__popcll(actB), nA || nB, tA || tB, chunk.exhausted);)
-        // ---- both fetches first
-        float4 ta, tb, tc;                   // not initialised on purpose (pt_traverse.h trav_any_step2)
-        if (tA || tB) {
-            const uint32_t ti = (tA ? A.triBase : Bq.triBase) + (uint32_t)__builtin_ctz(tA ? A.triMask : Bq.triMask);
-            const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2];
-        }
-        Fetch5 f;
-        if (nA || nB) f = fetch_step(P, top, nA ? A.cur : Bq.cur, 0u, 0u);
-        // ---- one queued triangle
-        if (tA || tB) {
-            const f3 o = tA ? A.o : Bq.o, d = tA ? A.d : Bq.d;
-            float t, u, v; uint32_t flat, flags;
-            if (tri_intersect(ta, tb, tc, o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) {
-                ((float*)(B.rayC + (tA ? A.index : Bq.index)))[3] = 0.f;      // occluded: the query is complete (one Proceed(), common.hlsli:105-115)
-                if (tA) A.active = false; else Bq.active = false;
-            } else if (tA) any2_pop_tri(A); else any2_pop_tri(Bq);
-        }
-        // ---- one node
-        if (nA || nB) {
-            RaySetup rs; rs.o = nA ? A.o : Bq.o; rs.invd = nA ? A.invd : Bq.invd;
-            Node8 Nn;
-            node8_test(f.a, f.b, f.c, f.d, f.e, rs, tmin, tmax, Nn);
-            const uint32_t tm = node8_tri_mask(Nn);
-            if (tm) { if (nA) any2_push_tris(A, Nn.triBase, tm); else any2_push_tris(Bq, Nn.triBase, tm); }
-            const uint32_t inner = Nn.hitMask & Nn.imask;
-            int sp = nA ? A.sp : Bq.sp;
-            const LdsU32 st = nA ? stA : stB;
-            uint32_t cur = 0u; bool have = inner != 0u;
-            if (inner) {                                                     // inner children in slot order (pt_traverse.h trav_any_step)
-                const uint32_t rest = inner & (inner - 1u);
-                if (rest && sp < N) { st[sp * kWfBlock] = stack_entry(Nn.childBase, false, rest); ++sp; }
-                cur = Nn.childBase + (uint32_t)__builtin_ctz(inner);
-            } else if (sp > 0) {
-                uint32_t e = st[(sp - 1) * kWfBlock];
-                cur = (e >> 9) + (uint32_t)__builtin_ctz(e & 0xffu);
-                e &= e - 1u;
-                if (e & 0xffu) st[(sp - 1) * kWfBlock] = e; else --sp;
-                have = true;
-            }
-            if (nA) { A.cur = cur; A.haveCur = have; A.sp = sp; } else { Bq.cur = cur; Bq.haveCur = have; Bq.sp = sp; }
-        }
-        if (A.active && !A.haveCur && A.triMask == 0u) A.active = false;       // unoccluded: the record keeps its 1
-        if (Bq.active && !Bq.haveCur && Bq.triMask == 0u) Bq.active = false;
-        if (pending) {
-            pending = false;
-            if (__float_as_uint(qa.w) != 0xffffffffu) { if (pendToA) any2_begin(A, qa, qb, nextIndex); else any2_begin(Bq, qa, qb, nextIndex); }
-        }
-        if (__ballot(A.active || Bq.active) == 0ull && chunk.exhausted) break;
-    }
-    LANE_STATS(ls.flush(1);)
-}
-
 // ------------------------------------------------------------------------------------------------ accumulate
 __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
     const uint32_t count = B.counters[bounce];
@@ -1032,9 +911,6 @@ template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, 
 template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
     hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
 }
-template <int N> static void launch_shadow2(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
-    hipLaunchKernelGGL(wf_shadow2_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
-}
 } // namespace incr
 
 // One frame = `numPipes` independent PIPELINES: pipeline i owns the tile rows [tileRow[i], tileRow[i + 1]) of the (local) frame, its own
@@ -1058,9 +934,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
     const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 10 ? (uint32_t)INCR_EXTEND_WAVES10 : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u))), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
-    static const int shadowDualEnv = getenv("INCR_WF_SHADOW_DUAL") ? atoi(getenv("INCR_WF_SHADOW_DUAL")) : INCR_SHADOW_DUAL_DEFAULT;      // A/B hook
-    const bool shadowDual = shadowDualEnv != 0 && sv <= 12;             // two rays per lane (wf_shadow2_kernel): stacks of both rays in LDS
-    const uint32_t blocksShadow = cus * (shadowDual ? (uint32_t)INCR_SHADOW2_WAVES : shadowPerCU);        // the length of the ray queue is only known on the device
+    const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
     uint32_t total[8], blocksAll[8], blocksExtend[8];
     for (int i = 0; i < numPipes; ++i) {
         total[i] = (tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
@@ -1097,8 +971,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
             hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 2);
-            if (shadowDual) { if (sv == 8) launch_shadow2<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow2<10>(blocksShadow, st, *p, b, bounce); else launch_shadow2<12>(blocksShadow, st, *p, b, bounce); }
-            else if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
+            if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
             mark(i, slot + 3);
             hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);
         }

@@ -255,17 +255,66 @@ DI float decode_small_float(uint32_t v, int mant_bits, uint32_t sign) {
     else r = ldexpf((float)(m | (1u << mant_bits)), (int)e - 15 - mant_bits);
     return sign ? -r : r;
 }
-DI uint32_t f32_to_f16_bits(float f, int rounding) { uint32_t s; uint32_t v = encode_small_float(f, 10, true, rounding, &s); return (s << 15) | v; }
-DI float f16_bits_to_f32(uint32_t h) { return decode_small_float(h & 0x7fffu, 10, (h >> 15) & 1u); }
-DI uint32_t pack_r11g11b10(f3 c, int rounding) {
+// The same conversions on the hardware's own converters (INCR_FAST_SMALL_FLOAT, default): the default store rounding of every typed
+// UAV here is round-toward-zero (D3D11.3 3.2.3.3), which is exactly v_cvt_pkrtz_f16_f32 -- overflow to the largest finite value,
+// denormals kept (f16 denormals are enabled on gfx950), +-inf kept -- and an R11 / R10 channel is the f16 pattern with its low 4 / 5
+// mantissa bits cut off (truncating twice = truncating once), negative values store 0, NaN the all-ones pattern as encode_small_float
+// does.  Decoding is v_cvt_f32_f16 on the widened pattern.  One instruction where the generic code spends 10 (decode) to 35 (encode) per
+// channel: the TAA resolve decodes 13 texels per pixel, the lighting chain re-quantises three times, a cube tap decodes 12 channels.
+// Bit-identical to the generic functions on every input (tests/test_gpu_round3.py::test_small_float_codec_matches_the_generic_one);
+// nearest-even stores (storage_rounding = 1) keep the generic path.
+#ifndef INCR_FAST_SMALL_FLOAT
+#define INCR_FAST_SMALL_FLOAT 1
+#endif
+typedef _Float16 incr_h2 __attribute__((ext_vector_type(2)));
+DI uint32_t pkrtz_bits(float a, float b) { const incr_h2 h = __builtin_bit_cast(incr_h2, __builtin_amdgcn_cvt_pkrtz(a, b)); return __builtin_bit_cast(uint32_t, h); }
+DI float f16_pattern_to_f32(uint32_t h16) { const unsigned short u = (unsigned short)h16; return (float)__builtin_bit_cast(_Float16, u); }
+DI uint32_t f32_to_f16_bits_generic(float f, int rounding) { uint32_t s; uint32_t v = encode_small_float(f, 10, true, rounding, &s); return (s << 15) | v; }
+DI uint32_t f32_to_f16_bits(float f, int rounding) {
+#if INCR_FAST_SMALL_FLOAT
+    if (rounding == 0) {
+        const uint32_t h = pkrtz_bits(f, 0.f) & 0xffffu;
+        return f != f ? ((__float_as_uint(f) >> 16) & 0x8000u) | 0x7fffu : h;
+    }
+#endif
+    return f32_to_f16_bits_generic(f, rounding);
+}
+DI float f16_bits_to_f32(uint32_t h) {
+#if INCR_FAST_SMALL_FLOAT
+    return f16_pattern_to_f32(h & 0xffffu);
+#else
+    return decode_small_float(h & 0x7fffu, 10, (h >> 15) & 1u);
+#endif
+}
+DI uint32_t pack_r11g11b10_generic(f3 c, int rounding) {
     uint32_t s;
     uint32_t r = encode_small_float(c.x, 6, false, rounding, &s);
     uint32_t g = encode_small_float(c.y, 6, false, rounding, &s);
     uint32_t b = encode_small_float(c.z, 5, false, rounding, &s);
     return r | (g << 11) | (b << 22);
 }
-DI f3 unpack_r11g11b10(uint32_t p) {
+DI uint32_t unsigned_small_from_f16(uint32_t h16, float f, int drop) {      // one R11 (drop 4) / R10 (drop 5) channel from the truncated f16 pattern of f
+    if (f != f) return (0x7fffu >> drop);
+    return (h16 & 0x8000u) ? 0u : (h16 >> drop);
+}
+DI uint32_t pack_r11g11b10(f3 c, int rounding) {
+#if INCR_FAST_SMALL_FLOAT
+    if (rounding == 0) {
+        const uint32_t xy = pkrtz_bits(c.x, c.y), z = pkrtz_bits(c.z, 0.f);
+        return unsigned_small_from_f16(xy & 0xffffu, c.x, 4) | (unsigned_small_from_f16(xy >> 16, c.y, 4) << 11) | (unsigned_small_from_f16(z & 0xffffu, c.z, 5) << 22);
+    }
+#endif
+    return pack_r11g11b10_generic(c, rounding);
+}
+DI f3 unpack_r11g11b10_generic(uint32_t p) {
     return {decode_small_float(p & 0x7ffu, 6, 0), decode_small_float((p >> 11) & 0x7ffu, 6, 0), decode_small_float(p >> 22, 5, 0)};
+}
+DI f3 unpack_r11g11b10(uint32_t p) {
+#if INCR_FAST_SMALL_FLOAT
+    return {f16_pattern_to_f32((p & 0x7ffu) << 4), f16_pattern_to_f32(((p >> 11) & 0x7ffu) << 4), f16_pattern_to_f32((p >> 22) << 5)};
+#else
+    return unpack_r11g11b10_generic(p);
+#endif
 }
 
 // ---------------------------------------------------------------- texture unit stand-in (bilinear, wrap, mip 0)

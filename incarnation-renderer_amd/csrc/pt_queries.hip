@@ -38,6 +38,28 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const PtParams P, ui
     tuv[(size_t)i * 3] = r.x; tuv[(size_t)i * 3 + 1] = r.y; tuv[(size_t)i * 3 + 2] = r.z;
 }
 
+// Self-test of the hardware small-float codec (pt_device.h INCR_FAST_SMALL_FLOAT) against the generic bit-level functions, over EVERY
+// float32 pattern (encode) and every storage pattern (decode).  out[0..3] = mismatches of f32 -> f16, f32 -> R11 / R10 channels,
+// f16 -> f32, R11G11B10 -> f32 x 3 (two NaNs count as equal whatever their payload).
+__global__ __launch_bounds__(256) void codec_selftest_kernel(unsigned long long* __restrict__ out) {
+    unsigned long long bad[4] = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = (uint32_t)i;
+        const float f = __uint_as_float(u);
+        if (f32_to_f16_bits(f, 0) != f32_to_f16_bits_generic(f, 0)) bad[0]++;
+        if (pack_r11g11b10({f, f, f}, 0) != pack_r11g11b10_generic({f, f, f}, 0)) bad[1]++;
+        if (u < 0x10000u) {
+            const float a = f16_bits_to_f32(u), b = decode_small_float(u & 0x7fffu, 10, (u >> 15) & 1u);
+            if (!(__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b))) bad[2]++;
+        }
+        const f3 a = unpack_r11g11b10(u), b = unpack_r11g11b10_generic(u);
+        const bool same = (__float_as_uint(a.x) == __float_as_uint(b.x) || (a.x != a.x && b.x != b.x)) && (__float_as_uint(a.y) == __float_as_uint(b.y) || (a.y != a.y && b.y != b.y)) &&
+                          (__float_as_uint(a.z) == __float_as_uint(b.z) || (a.z != a.z && b.z != b.z));
+        if (!same) bad[3]++;
+    }
+    for (int k = 0; k < 4; ++k) if (bad[k]) atomicAdd(out + k, bad[k]);
+}
+
 // TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode (tonemap_texel, pt_device.h).
 // Streaming: 16 B in, 16 B out per lane (four texels) -- with one texel per lane the pass ran at 0.59 TB/s.
 __global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
@@ -95,5 +117,10 @@ extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint
     if (!total) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(incr::unshard_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, W, H, h, numShards, localRows, texelBytes);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t incr_launch_codec_selftest(unsigned long long* out4, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::codec_selftest_kernel, dim3(256 * 64), dim3(256), 0, stream, out4);
     return hipGetLastError();
 }

@@ -188,6 +188,15 @@ typedef struct incr_tonemap_desc {
 int  incr_tonemap(incr_context* ctx, const incr_tonemap_desc* desc, incr_stream stream);
 
 /*
+ * Self-test (not in the reference): the typed-UAV stores and loads of the render targets (R16G16B16A16_FLOAT, R11G11B10_FLOAT; D3D11.3
+ * functional spec 3.2.3.3: round toward zero) run on the hardware's converters; this compares them with the bit-level reference
+ * functions over every float32 pattern and every storage pattern.  out_mismatches[0..3] = f32 -> f16, f32 -> R11 / R10, f16 -> f32,
+ * R11G11B10 -> f32; all zero on a correct build.  Blocks for about a second.
+ */
+int  incr_selftest_small_float(incr_context* ctx, uint64_t out_mismatches[4]);
+
+
+/*
  * Inline ray queries against the scene's acceleration structure: the stand-in for DXR TraceRay / RayQuery
  * (call sites: shaders/raytracing/pathtracing.hlsl:117,265; shaders/lighting/common.hlsli:102-115).
  * All rays use RAY_FLAG_CULL_BACK_FACING_TRIANGLES like every call site of the reference.

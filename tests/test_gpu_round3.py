@@ -275,3 +275,13 @@ def test_helmet_without_tangents_renders_like_the_oracle(gpu_ctx, rt, sio, ob):
     ok, same = pixel_agreement(g["target"], o["target"])
     assert ok >= 0.9995 and same >= 0.98, (ok, same)
     osc.close(); pt.close(); sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ typed-UAV codec
+def test_small_float_codec_matches_the_generic_one(gpu_ctx, rt):
+    """The RGBA16F / R11G11B10F stores and loads run on v_cvt_pkrtz_f16_f32 / v_cvt_f32_f16 (pt_device.h INCR_FAST_SMALL_FLOAT).  Against the
+    bit-level functions -- the ones the oracle restates (D3D11.3 3.2.3.3 round-toward-zero stores) -- over EVERY float32 pattern and every
+    storage pattern: no mismatch."""
+    out = (C.c_uint64 * 4)()
+    rt.check(gpu_ctx.lib.incr_selftest_small_float(gpu_ctx.handle, out))
+    assert list(out) == [0, 0, 0, 0], list(out)

@@ -104,6 +104,9 @@ bool validate_scene(const HostScene& s, const char** why) {
 #ifndef INCR_BVH_COST_NODE
 #define INCR_BVH_COST_NODE 1.0f
 #endif
+#ifndef INCR_LIGHT_GRID_CELLS
+#define INCR_LIGHT_GRID_CELLS 64
+#endif
 #ifndef INCR_BVH_COST_TRI
 #define INCR_BVH_COST_TRI 1.0f
 #endif
@@ -777,21 +780,31 @@ void build_light_grid(const HostScene& s, const HostBvh& bvh, LightGrid& g) {
     float ext[3], maxExt = 0.f;
     for (int a = 0; a < 3; ++a) { ext[a] = std::max(bvh.sceneHi[a] - bvh.sceneLo[a], 0.f); maxExt = std::max(maxExt, ext[a]); }
     if (!(maxExt > 0.f) || !(maxExt < FLT_MAX)) maxExt = 1.f;
-    const float cell = maxExt / 24.f;
+    // 64 cells along the longest axis (24 until round 3): a cell lists the lights whose range sphere touches it, so the candidates a
+    // vertex walks in wf_shadow_gen_kernel exceed its true lights by the cell's diagonal -- with 4 m ranges in a 30 m atrium, 2.0 x at 1.25 m
+    // cells and 1.3 x at 0.47 m.  Lists are exact either way (a skipped light contributes exactly 0).
+    float cell = maxExt / (float)INCR_LIGHT_GRID_CELLS;
     const float pad = 1e-4f * maxExt;
+    for (;;) {       // at most 2^18 cells
+        double cells = 1.0;
+        for (int a = 0; a < 3; ++a) cells *= std::min(96.0, std::max(1.0, std::ceil((double)ext[a] / cell)));
+        if (cells <= 262144.0) break;
+        cell *= 1.26f;
+    }
     for (int a = 0; a < 3; ++a) {
-        g.dim[a] = (uint32_t)std::min(32.f, std::max(1.f, std::ceil(ext[a] / cell)));
+        g.dim[a] = (uint32_t)std::min(96.f, std::max(1.f, std::ceil(ext[a] / cell)));
         g.lo[a] = bvh.sceneLo[a] - pad;
         const float size = (ext[a] + 2.f * pad) / (float)g.dim[a];
         g.invCell[a] = size > 0.f ? 1.f / size : 0.f;
     }
     const uint32_t numCells = g.dim[0] * g.dim[1] * g.dim[2];
     const int lightCount = (int)s.globalLights.size();                          // path-tracing.inl:198
-    std::vector<std::vector<uint32_t>> lists(numCells + 1);
-    for (int li = 0; li < lightCount; ++li) {
-        lists[numCells].push_back((uint32_t)li);
+    // two passes over (light, touched cells): count, prefix, fill -- ascending light order inside every cell, no per-cell allocations
+    g.cellOffsets.assign(numCells + 2, 0);
+    auto for_each_cell_of_light = [&](int li, auto&& visit) {
+        visit(numCells);                                                         // the catch-all cell lists every light
         const int lightId = (size_t)li < s.lightIndices.size() ? s.lightIndices[(size_t)li] : 0;
-        if (lightId < 0 || (size_t)lightId >= s.globalLights.size()) continue;   // zero light: never contributes
+        if (lightId < 0 || (size_t)lightId >= s.globalLights.size()) return;     // zero light: never contributes
         const incr_light& L = s.globalLights[(size_t)lightId];
         const bool haveT = (size_t)lightId < s.lightTransforms.size();
         float pos[3] = {0.f, 0.f, 0.f};
@@ -800,10 +813,18 @@ void build_light_grid(const HostScene& s, const HostBvh& bvh, LightGrid& g) {
         float radius = 0.f;
         if (L.type == INCR_LIGHT_DIRECTIONAL) everywhere = true;
         else if (L.type == INCR_LIGHT_POINT) { if (L.range > 0.f) radius = L.range * 1.001f + pad; else everywhere = true; }
-        else if (L.type == INCR_LIGHT_SPOT) { if (L.range > 0.f) continue; everywhere = true; }
-        else continue;                                                           // Sphere/Disk/Rect: radianceIn stays 0
+        else if (L.type == INCR_LIGHT_SPOT) { if (L.range > 0.f) return; everywhere = true; }
+        else return;                                                             // Sphere/Disk/Rect: radianceIn stays 0
         if (!(radius == radius) || !(pos[0] == pos[0] && pos[1] == pos[1] && pos[2] == pos[2])) everywhere = true;   // NaN data: be conservative
-        for (uint32_t z = 0; z < g.dim[2]; ++z) for (uint32_t y = 0; y < g.dim[1]; ++y) for (uint32_t x = 0; x < g.dim[0]; ++x) {
+        // only the cells the range sphere's bounding box touches are candidates (the grid is rebuilt by every incr_update_bvh)
+        uint32_t c0[3] = {0u, 0u, 0u}, c1[3] = {g.dim[0] - 1u, g.dim[1] - 1u, g.dim[2] - 1u};
+        if (!everywhere) for (int a = 0; a < 3; ++a) {
+            const float lo = (pos[a] - radius - 2.f * pad - g.lo[a]) * g.invCell[a] - 1.f, hi = (pos[a] + radius + 2.f * pad - g.lo[a]) * g.invCell[a] + 1.f;
+            if (!(lo == lo) || !(hi == hi)) continue;
+            c0[a] = (uint32_t)std::min(std::max(lo, 0.f), (float)(g.dim[a] - 1u));
+            c1[a] = (uint32_t)std::min(std::max(hi, 0.f), (float)(g.dim[a] - 1u));
+        }
+        for (uint32_t z = c0[2]; z <= c1[2]; ++z) for (uint32_t y = c0[1]; y <= c1[1]; ++y) for (uint32_t x = c0[0]; x <= c1[0]; ++x) {
             bool overlap = everywhere;
             if (!overlap) {
                 const uint32_t c[3] = {x, y, z};
@@ -816,13 +837,14 @@ void build_light_grid(const HostScene& s, const HostBvh& bvh, LightGrid& g) {
                 }
                 overlap = d2 <= radius * radius;
             }
-            if (overlap) lists[(z * g.dim[1] + y) * g.dim[0] + x].push_back((uint32_t)li);
+            if (overlap) visit((z * g.dim[1] + y) * g.dim[0] + x);
         }
-    }
-    g.cellOffsets.assign(numCells + 2, 0);
-    g.cellLights.clear();
-    for (uint32_t c = 0; c <= numCells; ++c) { g.cellOffsets[c] = (uint32_t)g.cellLights.size(); g.cellLights.insert(g.cellLights.end(), lists[c].begin(), lists[c].end()); }
-    g.cellOffsets[numCells + 1] = (uint32_t)g.cellLights.size();
+    };
+    for (int li = 0; li < lightCount; ++li) for_each_cell_of_light(li, [&](uint32_t c) { g.cellOffsets[c + 1]++; });
+    for (uint32_t c = 0; c <= numCells; ++c) g.cellOffsets[c + 1] += g.cellOffsets[c];
+    g.cellLights.assign(g.cellOffsets[numCells + 1], 0u);
+    std::vector<uint32_t> fill(g.cellOffsets.begin(), g.cellOffsets.end() - 1);
+    for (int li = 0; li < lightCount; ++li) for_each_cell_of_light(li, [&](uint32_t c) { g.cellLights[fill[c]++] = (uint32_t)li; });
 }
 
 } // namespace incr

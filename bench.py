@@ -161,8 +161,8 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     alg = float(W) * H * RASTER_B_PX
     return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world,
             "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
-            "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA"
-                        % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1])),
+            "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA, material sampler anisotropic x%d"
+                        % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1]), int(packed.max_anisotropy) or 16),
             "passes": "batch_cull, light_cull, visibility, gbuffer, deferred_lighting (sky + sun + clustered fused), dynamic_sky, taa_resolve (+ tonemap fused)",
             "per_pass": per_pass, "host_us_per_frame": round(host_s * 1e6, 1),
             "sun_shadow_rays_per_frame": int(rays), "algorithmic_bytes_per_frame": int(alg),
@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
+    ap.add_argument("--max-anisotropy", type=int, default=0, help="raster leg: MaxAnisotropy of the material sampler (0 = the reference's 16; 1 = isotropic trilinear, a diagnostic)")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical; "
@@ -328,6 +329,7 @@ def main():
 
     W, H = (int(v) for v in args.res.lower().split("x"))
     packed = build_scene(args.scene, args.texture_size)
+    packed.max_anisotropy = args.max_anisotropy
     importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)

@@ -364,10 +364,15 @@ DI f4 SampleLevel0(const DeviceTexture* __restrict__ textures, const float* __re
 }
 
 // ---- Sample(s, uv) of the raster passes (material/common.hlsli:6-8 TEX_SAMPLE = Sample outside PATH_TRACING) ----
-// Pinned texture-unit rules: isotropic LOD = log2 of the longer screen-space derivative in texels
-// (D3D11.3 functional spec 7.18.11), the logarithm by exponent + a degree-4 polynomial in the mantissa (|error| < 1.2e-4, the same
-// float operations on host and device), LOD clamped to the chain, its fraction truncated to 8 bits, trilinear = lerp of two
-// bilinear taps.  The reference's sampler is anisotropic (g_anisoSampler); anisotropic footprints are not reproduced.
+// Pinned texture-unit rules.  The reference's sampler is g_anisoSampler = FILTER_ANISOTROPIC with the root
+// signature's default MaxAnisotropy 16 (gbuffer-compute.hlsl:20, visibility-pass.hlsl:11, gbuffer-raster.hlsl:11; d3dx12_root_signature.h:277).
+// D3D leaves the footprint to the implementation; this one is the public textbook form (Vulkan 1.3 spec "Texel Anisotropic
+// Filtering"): rho_max / rho_min = the longer / shorter screen-space derivative in texels, N = min(ceil(rho_max / rho_min), MaxAnisotropy)
+// trilinear taps at uv + longer derivative * (i / (N + 1) - 1/2), i = 1 .. N, averaged, each at LOD = log2(rho_max / min(rho_max / rho_min,
+// MaxAnisotropy)).  No square root is taken: N is the smallest n with n^2 rho_min^2 >= rho_max^2 and the LOD is half the logarithm of
+// max(rho_min^2, rho_max^2 / MaxAnisotropy^2) -- the same float operations on host and device.  MaxAnisotropy 1 is the isotropic rule
+// of D3D11.3 functional spec 7.18.11 (LOD of the longer derivative, one tap).  The logarithm: exponent + a degree-4 polynomial in
+// the mantissa (|error| < 1.2e-4); LOD clamped to the chain, its fraction truncated to 8 bits, trilinear = lerp of two bilinear taps.
 DI float pinned_log2(float x) {         // x > 0, finite, normal
     const uint32_t b = __float_as_uint(x);
     const float e = (float)((int)(b >> 23) - 127);
@@ -375,31 +380,43 @@ DI float pinned_log2(float x) {         // x > 0, finite, normal
     const float p = 1.4425331354141235f + t * (-0.7161056399345398f + t * (0.4395408034324646f + t * (-0.2250901162624359f + t * 0.05923847481608391f)));
     return e + t * p;
 }
-DI float texture_lod(const DeviceTexture& t, f2 ddx, f2 ddy) {
+struct Footprint { float lod; uint32_t taps; f2 axis; };      // axis: the longer derivative, in uv units (the line the taps lie on)
+DI Footprint texture_footprint(const DeviceTexture& t, f2 ddx, f2 ddy, uint32_t maxAniso) {
     const float W = (float)t.width, H = (float)t.height;
     const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
-    const float m = fmaxf(ax * ax + ay * ay, bx * bx + by * by);          // squared length of the longer derivative, in texels
-    if (!(m >= 1.17549435e-38f) || !(m <= 3.0e38f)) return 0.f;            // zero, denormal, NaN or infinite footprint: level 0
-    return 0.5f * pinned_log2(m);
+    const float lx = ax * ax + ay * ay, ly = bx * bx + by * by;          // squared lengths of the two derivatives, in texels
+    const bool xMajor = lx >= ly;
+    const float major = xMajor ? lx : ly, minor = xMajor ? ly : lx;
+    Footprint f; f.lod = 0.f; f.taps = 1u; f.axis = xMajor ? ddx : ddy;
+    if (!(major >= 1.17549435e-38f) || !(major <= 3.0e38f)) return f;     // zero, denormal, NaN or infinite footprint: level 0, one tap
+    uint32_t n = 1u;
+    while (n < maxAniso && (float)(n * n) * minor < major) ++n;
+    f.taps = n;
+    const float m = fmaxf(minor, major / (float)(maxAniso * maxAniso));   // squared minor axis after the ratio clamp
+    if (m >= 1.17549435e-38f) f.lod = 0.5f * pinned_log2(m);
+    return f;
 }
-DI f4 SampleGrad(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv, f2 ddx, f2 ddy) {
-    const DeviceTexture t = textures[texIndex];
+DI float tap_offset(uint32_t i, uint32_t n) { return (float)i / (float)(n + 1u) - 0.5f; }      // i = 1 .. n
+// The two levels a trilinear tap reads, resolved ONCE per Sample (every tap of an anisotropic line reads the same two): word offset
+// and size of level floor(lod) and of the next one; without a second level to blend with (fraction 0 or end of the chain) level 1
+// repeats level 0, so that the taps' loads stay unconditional.
+struct LevelPair { uint32_t off0, off1; int W0, H0, W1, H1; float frac; bool two; };
+DI LevelPair level_pair(const DeviceTexture& t, float lod) {
     const uint32_t numMips = t.pad[1] ? t.pad[1] : 1u;
-    float lod = texture_lod(t, ddx, ddy);
     lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
     const float l0f = floorf(lod);
-    const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
+    LevelPair L;
+    L.frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
     const uint32_t l0 = (uint32_t)l0f;
-    const f4 a = SampleBilinearLevel(t, srgbLut, l0, uv);
-    if (frac == 0.f || l0 + 1u >= numMips) return a;
-    const f4 b = SampleBilinearLevel(t, srgbLut, l0 + 1u, uv);
-    return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac};
+    L.two = !(L.frac == 0.f || l0 + 1u >= numMips);
+    int W = (int)t.width, H = (int)t.height;
+    uint32_t off = 0;
+    for (uint32_t l = 0; l < l0; ++l) { off += texel_level_words((uint32_t)W, (uint32_t)H); W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
+    L.off0 = off; L.W0 = W; L.H0 = H;
+    L.off1 = L.two ? off + texel_level_words((uint32_t)W, (uint32_t)H) : off;
+    L.W1 = L.two ? (W > 1 ? W >> 1 : 1) : W; L.H1 = L.two ? (H > 1 ? H >> 1 : 1) : H;
+    return L;
 }
-
-// SampleGrad(...).w with ONE memory round trip: the addresses of the four texels of both trilinear levels are formed first and the
-// eight loads issued together, where SampleGrad's two SampleBilinearLevel calls sit behind a branch on the LOD fraction.  Same
-// arithmetic for the alpha channel (UNORM alpha: a / 255 for the formats that carry one, 1 otherwise), bit for bit.  For the
-// alpha test of the visibility scan (raster.hip fragment), a per-lane serial loop whose cost is its dependent round trips.
 struct BilinearTap { uint32_t i00, i10, i01, i11; float fx, fy; };
 DI BilinearTap bilinear_tap(int W, int H, size_t off, f2 uv) {
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
@@ -416,36 +433,85 @@ DI BilinearTap bilinear_tap(int W, int H, size_t off, f2 uv) {
     t.i01 = o + texel_tile_index((uint32_t)x0, (uint32_t)y1, (uint32_t)W); t.i11 = o + texel_tile_index((uint32_t)x1, (uint32_t)y1, (uint32_t)W);
     return t;
 }
-DI float texel_alpha(uint32_t format, uint32_t rgba) {
-    return (format == INCR_TEX_RG_SNORM || format == INCR_TEX_BGRA8_SWIZZLE_RG) ? 1.f : (float)(rgba >> 24) * (1.f / 255.f);
-}
-DI float bilinear_alpha(const BilinearTap& t, uint32_t format, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+DI f4 bilinear_blend(const BilinearTap& t, const float* __restrict__ srgbLut, uint32_t format, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+    const f4 t00 = decode_texel(srgbLut, format, c00), t10 = decode_texel(srgbLut, format, c10);
+    const f4 t01 = decode_texel(srgbLut, format, c01), t11 = decode_texel(srgbLut, format, c11);
     const float wx0 = 1.f - t.fx, wy0 = 1.f - t.fy;
-    return (texel_alpha(format, c00) * wx0 + texel_alpha(format, c10) * t.fx) * wy0 + (texel_alpha(format, c01) * wx0 + texel_alpha(format, c11) * t.fx) * t.fy;
+    f4 r;
+    r.x = (t00.x * wx0 + t10.x * t.fx) * wy0 + (t01.x * wx0 + t11.x * t.fx) * t.fy;
+    r.y = (t00.y * wx0 + t10.y * t.fx) * wy0 + (t01.y * wx0 + t11.y * t.fx) * t.fy;
+    r.z = (t00.z * wx0 + t10.z * t.fx) * wy0 + (t01.z * wx0 + t11.z * t.fx) * t.fy;
+    r.w = (t00.w * wx0 + t10.w * t.fx) * wy0 + (t01.w * wx0 + t11.w * t.fx) * t.fy;
+    return r;
 }
-DI float SampleGradAlpha(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy) {
-    const uint32_t numMips = t.pad[1] ? t.pad[1] : 1u;
-    float lod = texture_lod(t, ddx, ddy);
-    lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
-    const float l0f = floorf(lod);
-    const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
-    const uint32_t l0 = (uint32_t)l0f;
-    const bool two = !(frac == 0.f || l0 + 1u >= numMips);
-    int W = (int)t.width, H = (int)t.height;
-    size_t off = 0;
-    for (uint32_t l = 0; l < l0; ++l) { off += texel_level_words((uint32_t)W, (uint32_t)H); W = W > 1 ? W >> 1 : 1; H = H > 1 ? H >> 1 : 1; }
-    const BilinearTap ta = bilinear_tap(W, H, off, uv);
-    // the second level's taps fall back to the first level's when there is no second level to blend with: the loads stay unconditional
-    const size_t off1 = two ? off + texel_level_words((uint32_t)W, (uint32_t)H) : off;
-    const int W1 = two ? (W > 1 ? W >> 1 : 1) : W, H1 = two ? (H > 1 ? H >> 1 : 1) : H;
-    const BilinearTap tb = bilinear_tap(W1, H1, off1, uv);
+// One trilinear tap = SampleBilinearLevel on both levels + the lerp.  (Fetching both levels' texels together, and two taps per round
+// with sixteen loads in flight, was measured: the G-buffer kernel went from 72 to 130 VGPRs and from 0.94 to 1.33 ms.)
+DI f4 bilinear_at(const DeviceTexture& t, const float* __restrict__ srgbLut, int W, int H, uint32_t off, f2 uv) {
+    const BilinearTap k = bilinear_tap(W, H, off, uv);
     const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
-    const uint32_t a00 = px[ta.i00], a10 = px[ta.i10], a01 = px[ta.i01], a11 = px[ta.i11];
-    const uint32_t b00 = px[tb.i00], b10 = px[tb.i10], b01 = px[tb.i01], b11 = px[tb.i11];
-    const float a = bilinear_alpha(ta, t.format, a00, a10, a01, a11);
-    if (!two) return a;
-    const float b = bilinear_alpha(tb, t.format, b00, b10, b01, b11);
-    return a + (b - a) * frac;
+    const uint32_t c00 = px[k.i00], c10 = px[k.i10], c01 = px[k.i01], c11 = px[k.i11];
+    return bilinear_blend(k, srgbLut, t.format, c00, c10, c01, c11);
+}
+DI f4 trilinear_at(const DeviceTexture& t, const float* __restrict__ srgbLut, const LevelPair& L, f2 uv) {
+    const f4 a = bilinear_at(t, srgbLut, L.W0, L.H0, L.off0, uv);
+    if (!L.two) return a;
+    const f4 b = bilinear_at(t, srgbLut, L.W1, L.H1, L.off1, uv);
+    return {a.x + (b.x - a.x) * L.frac, a.y + (b.y - a.y) * L.frac, a.z + (b.z - a.z) * L.frac, a.w + (b.w - a.w) * L.frac};
+}
+DI f4 SampleGrad(const DeviceTexture* __restrict__ textures, const float* __restrict__ srgbLut, int texIndex, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
+    const DeviceTexture t = textures[texIndex];
+    const Footprint fp = texture_footprint(t, ddx, ddy, maxAniso);
+    const LevelPair L = level_pair(t, fp.lod);
+    if (fp.taps == 1u) return trilinear_at(t, srgbLut, L, uv);
+    f4 sum = {0.f, 0.f, 0.f, 0.f};                       // the line of taps, summed in tap order
+    for (uint32_t i = 1u; i <= fp.taps; ++i) {
+        const float o = tap_offset(i, fp.taps);
+        const f4 c = trilinear_at(t, srgbLut, L, {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o});
+        sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+    }
+    const float n = (float)fp.taps;
+    return {sum.x / n, sum.y / n, sum.z / n, sum.w / n};
+}
+
+// SampleGrad(...).w for the alpha test of the visibility scan (raster.hip fragment), a per-lane serial loop whose cost is its dependent
+// round trips: the same taps, the same arithmetic on the alpha channel alone (UNORM alpha: a / 255 for the formats that carry one,
+// 1 otherwise), bit for bit.
+DI bool format_has_alpha(uint32_t format) { return !(format == INCR_TEX_RG_SNORM || format == INCR_TEX_BGRA8_SWIZZLE_RG); }
+DI float texel_alpha(uint32_t rgba) { return (float)(rgba >> 24) * (1.f / 255.f); }          // of a format that carries alpha (decode_texel's .w)
+DI float bilinear_alpha(const BilinearTap& t, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+    const float wx0 = 1.f - t.fx, wy0 = 1.f - t.fy;
+    return (texel_alpha(c00) * wx0 + texel_alpha(c10) * t.fx) * wy0 + (texel_alpha(c01) * wx0 + texel_alpha(c11) * t.fx) * t.fy;
+}
+// one tap's alpha: the eight texels of both levels are fetched together (one memory round trip per tap in a per-lane serial loop)
+DI float trilinear_alpha_at(const DeviceTexture& t, const LevelPair& L, f2 uv) {
+    const BilinearTap ka = bilinear_tap(L.W0, L.H0, L.off0, uv), kb = bilinear_tap(L.W1, L.H1, L.off1, uv);
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t a00 = px[ka.i00], a10 = px[ka.i10], a01 = px[ka.i01], a11 = px[ka.i11];
+    const uint32_t b00 = px[kb.i00], b10 = px[kb.i10], b01 = px[kb.i01], b11 = px[kb.i11];
+    const float a = bilinear_alpha(ka, a00, a10, a01, a11);
+    if (!L.two) return a;
+    const float b = bilinear_alpha(kb, b00, b10, b01, b11);
+    return a + (b - a) * L.frac;
+}
+// clip(Sample(..).w - 0.5): true when the fragment survives.  Along an anisotropic line the decision is often known before the last
+// tap and the loop stops there -- without changing it: every tap's alpha is >= 0 (convex weights of non-negative texels, and
+// a + (b - a) frac >= 0 for frac < 1), so a partial sum >= n / 2 (exact in float for n <= 16) keeps fl(sum / n) >= 0.5 by the
+// monotonicity of the rounded sum and division; and no tap exceeds 1 by more than a few ulp, so a partial sum that cannot reach
+// 0.49999 n even if every remaining tap read 1.00001 ends below 0.5.
+DI bool AlphaTestGrad(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
+    if (!format_has_alpha(t.format)) return true;          // every texel decodes to alpha 1: any filter of ones stays above 0.5
+    const Footprint fp = texture_footprint(t, ddx, ddy, maxAniso);
+    const LevelPair L = level_pair(t, fp.lod);
+    if (fp.taps == 1u) return !(trilinear_alpha_at(t, L, uv) - 0.5f < 0.f);
+    const float n = (float)fp.taps;
+    float sum = 0.f;
+    for (uint32_t i = 1u; i <= fp.taps; ++i) {
+        const float o = tap_offset(i, fp.taps);
+        sum += trilinear_alpha_at(t, L, {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o});
+        if (sum >= 0.5f * n) return true;
+        if (sum + (float)(fp.taps - i) * 1.00001f < 0.49999f * n) return false;
+    }
+    return !(sum / n - 0.5f < 0.f);
 }
 
 // material/common.hlsli:10-115
@@ -600,8 +666,62 @@ DI MatProps EvaluateMaterialProperties(const incr_material& mat, const DeviceTex
     if (mat.aoTextureIndex != -1) o.ao = SampleLevel0(textures, lut, mat.aoTextureIndex, uv).x;
     return o;
 }
-DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy) {   // raster: Sample
-    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleGrad(textures, lut, tex, st, ddx, ddy); });
+// Sample(g_anisoSampler, uv) of a material's textures.  Base colour, normal and metallic-roughness maps nearly always share one size:
+// their footprints, levels, tap positions, texel indices and bilinear weights are then the same numbers, computed once per tap for
+// the three (the G-buffer kernel is VALU-bound on exactly this address arithmetic: 2 x ~60 instructions per trilinear tap and texture,
+// up to 16 taps); each texture still sees SampleGrad's arithmetic operation for operation.
+struct JointSamples { f4 base, normal, mr; };
+// FB / FN / FM: the three formats as compile-time constants (the usual sRGB base colour + SNORM normals + swizzled metallic-roughness), or
+// -1 = read the descriptor's: the per-texel format switch of decode_texel then folds away, and with it the channels nobody reads
+template <int F> DI f4 bilinear_from(const DeviceTexture& t, const float* __restrict__ lut, const BilinearTap& k) {
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t c00 = px[k.i00], c10 = px[k.i10], c01 = px[k.i01], c11 = px[k.i11];
+    return bilinear_blend(k, lut, F < 0 ? t.format : (uint32_t)F, c00, c10, c01, c11);
+}
+DI f4 lerp_levels(f4 a, f4 b, float frac) { return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac}; }
+template <int FB, int FN, int FM>
+DI JointSamples SampleGradJointT(const DeviceTexture& tb, const DeviceTexture& tn, const DeviceTexture& tm, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
+    const Footprint fp = texture_footprint(tb, ddx, ddy, maxAniso);
+    const LevelPair L = level_pair(tb, fp.lod);
+    JointSamples s; s.base = {0.f, 0.f, 0.f, 0.f}; s.normal = s.base; s.mr = s.base;
+    for (uint32_t i = 1u; i <= fp.taps; ++i) {
+        const float o = fp.taps == 1u ? 0.f : tap_offset(i, fp.taps);
+        f2 st = uv;
+        if (fp.taps != 1u) st = {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o};
+        const BilinearTap ka = bilinear_tap(L.W0, L.H0, L.off0, st);
+        f4 cb = bilinear_from<FB>(tb, lut, ka), cn = bilinear_from<FN>(tn, lut, ka), cm = bilinear_from<FM>(tm, lut, ka);
+        if (L.two) {
+            const BilinearTap kb = bilinear_tap(L.W1, L.H1, L.off1, st);
+            cb = lerp_levels(cb, bilinear_from<FB>(tb, lut, kb), L.frac); cn = lerp_levels(cn, bilinear_from<FN>(tn, lut, kb), L.frac); cm = lerp_levels(cm, bilinear_from<FM>(tm, lut, kb), L.frac);
+        }
+        if (fp.taps == 1u) { s.base = cb; s.normal = cn; s.mr = cm; return s; }
+        s.base.x += cb.x; s.base.y += cb.y; s.base.z += cb.z; s.base.w += cb.w;
+        s.normal.x += cn.x; s.normal.y += cn.y; s.normal.z += cn.z; s.normal.w += cn.w;
+        s.mr.x += cm.x; s.mr.y += cm.y; s.mr.z += cm.z; s.mr.w += cm.w;
+    }
+    const float n = (float)fp.taps;
+    s.base = {s.base.x / n, s.base.y / n, s.base.z / n, s.base.w / n};
+    s.normal = {s.normal.x / n, s.normal.y / n, s.normal.z / n, s.normal.w / n};
+    s.mr = {s.mr.x / n, s.mr.y / n, s.mr.z / n, s.mr.w / n};
+    return s;
+}
+DI JointSamples SampleGradJoint(const DeviceTexture& tb, const DeviceTexture& tn, const DeviceTexture& tm, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
+    if (tb.format == INCR_TEX_RGBA8_SRGB && tn.format == INCR_TEX_RG_SNORM && tm.format == INCR_TEX_BGRA8_SWIZZLE_RG)
+        return SampleGradJointT<INCR_TEX_RGBA8_SRGB, INCR_TEX_RG_SNORM, INCR_TEX_BGRA8_SWIZZLE_RG>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
+    return SampleGradJointT<-1, -1, -1>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
+}
+DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {   // raster: Sample
+    const int ib = mat.baseColorTextureIndex, in = mat.normalTextureIndex, im = mat.metallicRoughnessTextureIndex;
+    if (ib != -1 && in != -1 && im != -1) {
+        const DeviceTexture tb = textures[ib], tn = textures[in], tm = textures[im];
+        if (tb.width == tn.width && tb.width == tm.width && tb.height == tn.height && tb.height == tm.height && tb.pad[1] == tn.pad[1] && tb.pad[1] == tm.pad[1]) {
+            const JointSamples js = SampleGradJoint(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
+            return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) {
+                return tex == ib ? js.base : (tex == in ? js.normal : (tex == im ? js.mr : SampleGrad(textures, lut, tex, st, ddx, ddy, maxAniso)));
+            });
+        }
+    }
+    return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) { return SampleGrad(textures, lut, tex, st, ddx, ddy, maxAniso); });
 }
 
 // exp(x) for x <= 0 with a fixed evaluation (HLSL leaves exp's precision open; the vMF prefilter's exp feeds UNORM8 texels that

@@ -231,8 +231,7 @@ DI void trav_closest_begin(TravClosest& T, f3 o, f3 d, float tmin, float tmax) {
 template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClosest& T) {
     const Fetch5 f = fetch_step(P, st, T.cur, T.triBase, T.triMask);
     if (T.triMask) {
-        // ---- one pending triangle ----
-        const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask);
+        // ---- one pending triangle (fetch_step read the record of the lowest set bit) ----
         T.triMask &= T.triMask - 1u;
 #ifdef INCR_TRAV_STATS
         T.nTris++;

@@ -321,8 +321,7 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
         // trilinear levels are fetched together
         const f3 lam = bary_eval(st.bs, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
         const UvGrad g = quad_uv_gradient(st.bs, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
-        const float opacity = SampleGradAlpha(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy);
-        if (opacity - 0.5f < 0.f) return;
+        if (!AlphaTestGrad(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy, P.S.maxAnisotropy)) return;
     }
     atomicMax(dst, v);
 }
@@ -558,7 +557,7 @@ DI bool qw_next(QueueWalk& q, uint32_t* __restrict__ cursor, uint32_t n, uint32_
     *out = q.cur; q.cur += step;
     return true;
 }
-__global__ __launch_bounds__(256) void vis_scan_kernel(const VisParams P) {
+__global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
     QueueWalk q;
@@ -610,7 +609,12 @@ __global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long lo
 
 // ---------------------------------------------------------------------------------------------- G-buffer
 // gbuffer-compute.hlsl:157-253 (USING_MESHLETS); 16x16 thread groups there, 64x4 pixel blocks here (one wave = one row run)
-__global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
+__global__ __launch_bounds__(256, 4) void gbuffer_kernel(const GBufferParams P) {
+    // the sRGB decode table in LDS: a trilinear tap of a base-colour map looks 24 values up, as many instructions on the vector memory
+    // pipeline (which bounds this kernel) as its texel loads
+    __shared__ float s_srgbLut[256];
+    s_srgbLut[threadIdx.x] = P.S.srgbLut[threadIdx.x];
+    __syncthreads();
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.y1) return;
     const size_t i = (size_t)y * P.W + x;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void gbuffer_kernel(const GBufferParams P) {
     const f3 B = normalize(cross(N, T) * tanW0);
     const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
     const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
-    const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
+    const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, s_srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
     if (mi.bHasNormalmap) {
         const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)meshIndex * 16;
         const f3 l0 = {L[0], L[1], L[2]}, l1 = {L[4], L[5], L[6]}, l2 = {L[8], L[9], L[10]};
@@ -1038,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
             const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
             const incr_material mat = P.S.materials[d.materialIndex];
             const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
-            const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy);
+            const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy);
             bool done = true;
             if (P.viewmode == 2) out = mk3(p.roughness);                             // ps_main :95-105 (`#if VIWEMODE == 1` never fires)
             else if (P.viewmode == 3) out = mk3(p.metallic);
@@ -1081,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
                         }
                     }
                     float transmission = mat.transmissionFactor;                     // material/common.hlsli:83-88
-                    if (mat.transmissionTextureIndex != -1) transmission *= SampleGrad(P.S.textures, P.S.srgbLut, mat.transmissionTextureIndex, UV, gr.ddx, gr.ddy).x;
+                    if (mat.transmissionTextureIndex != -1) transmission *= SampleGrad(P.S.textures, P.S.srgbLut, mat.transmissionTextureIndex, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy).x;
                     if (P.diffuseIbl && P.sh9) {                                     // :149-165
                         const f3 albedo = ((1.f - p.metallic) * (1.f - transmission)) * p.basecolor;
                         const f3 shDiffuse = (albedo * K_INV_PI) * ShIrradiance(N, P.sh9);
@@ -1194,7 +1198,7 @@ DI void decal_fragment(const DecalParams& P, const SubTriRec& r, uint32_t px, ui
     const f3 lam = bary_eval(bs, pixel_ndc(px, py, (float)P.W, (float)P.H));
     const incr_material mat = P.S.materials[d.materialIndex];
     const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], px, py, (float)P.W, (float)P.H);
-    const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy);
+    const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy, P.S.maxAnisotropy);
     const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
     f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
     if (p.bHasNormalmap) {

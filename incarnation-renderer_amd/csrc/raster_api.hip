@@ -214,6 +214,7 @@ void fill_raster_scene(const incr_context* ctx, const incr_scene* sc, RasterScen
     S.mvPos = sc->dMvPos; S.mvUv = sc->dMvUv; S.mvNormal = sc->dMvNormal; S.mvTangent = sc->dMvTangent;
     S.meshLocalToWorld = sc->dMeshLocalToWorld; S.materials = sc->dMaterials; S.textures = sc->dTextures; S.srgbLut = ctx->srgbLut;
     S.numMeshlets = (uint32_t)sc->host.meshlets.size(); S.numMeshes = (uint32_t)sc->host.meshTransforms.size();
+    S.maxAnisotropy = sc->host.maxAnisotropy;
 }
 // FConfig::UseMeshlets == false.  The order key of the visibility pass keeps bit 31 for the draw list, so the primitive
 // id has 11 bits there (EncodePrimitiveVisibility itself has 12, encoding.hlsli:8-11).

@@ -25,6 +25,7 @@ struct RasterScene {
     const DeviceTexture* __restrict__ textures;
     const float* __restrict__ srgbLut;
     uint32_t numMeshlets, numMeshes;
+    uint32_t maxAnisotropy;                   // g_anisoSampler's MaxAnisotropy (incr_scene_desc::max_anisotropy; 16 as the reference's root signatures)
 };
 
 // The primitive (non-meshlet) path, FConfig::UseMeshlets == false: per-primitive index / vertex arrays resolved out of the

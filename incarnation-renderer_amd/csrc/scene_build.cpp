@@ -41,6 +41,7 @@ void copy_scene_desc(const incr_scene_desc& d, HostScene& s) {
     for (uint32_t i = 0; i < d.num_scene_lights; ++i) s.lightTransforms[i] = m44_from(d.light_transforms[i]);
     s.rootTransform = m44_from(d.root_transform);
     memcpy(s.sunDir, d.sun_dir, 12);
+    s.maxAnisotropy = d.max_anisotropy ? d.max_anisotropy : 16u;
     s.decalPrimitives.clear(); s.decalTransforms.clear();
     if (d.num_decal_primitives && d.decal_primitives && d.decal_transforms) {
         s.decalPrimitives.assign(d.decal_primitives, d.decal_primitives + d.num_decal_primitives);
@@ -84,6 +85,7 @@ static void fetch_floats(const AccessorRef* r, uint32_t index, int ncomp, float*
 bool validate_scene(const HostScene& s, const char** why) {
     static thread_local char msg[160];
     *why = msg;
+    if (s.maxAnisotropy < 1u || s.maxAnisotropy > 16u) { snprintf(msg, sizeof msg, "max_anisotropy %u: D3D12_REQ_MAXANISOTROPY is 16", s.maxAnisotropy); return false; }
     if (s.primitiveOffset.back() != s.primitives.size()) { snprintf(msg, sizeof msg, "sum(primitive_counts)=%u != num_primitives=%zu", s.primitiveOffset.back(), s.primitives.size()); return false; }
     for (size_t i = 0; i < s.primitives.size(); ++i) {
         const incr_gpu_primitive& p = s.primitives[i];

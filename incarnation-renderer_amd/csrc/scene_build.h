@@ -26,6 +26,7 @@ struct HostScene {
     std::vector<M44> lightTransforms;
     M44 rootTransform;
     float sunDir[3];
+    uint32_t maxAnisotropy;          // incr_scene_desc::max_anisotropy, 0 resolved to 16
     // FScene::m_sceneMeshDecals: drawn by the decal G-buffer pass only (not in `primitives`, not in the BVH)
     std::vector<incr_gpu_primitive> decalPrimitives;
     std::vector<M44> decalTransforms;      // per decal primitive

@@ -92,7 +92,7 @@ class SceneDesc(C.Structure):
         ("num_scene_lights", C.c_uint32), ("light_indices", C.POINTER(C.c_int32)),
         ("light_transforms", C.POINTER(Matrix)),
         ("root_transform", Matrix),
-        ("sun_dir", c_float3), ("reserved", C.c_uint32),
+        ("sun_dir", c_float3), ("max_anisotropy", C.c_uint32),
         ("num_decal_primitives", C.c_uint32), ("decal_primitives", C.POINTER(GpuPrimitive)), ("decal_transforms", C.POINTER(Matrix)),
     ]
 

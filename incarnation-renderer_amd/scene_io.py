@@ -191,6 +191,7 @@ class PackedScene:
         self.cameras = []
         self.root_transform = mat_identity()
         self.sun_dir = sun_direction_from_time_of_day()
+        self.max_anisotropy = 0      # MaxAnisotropy of the raster passes' sampler: 0 = the reference's 16, 1 = isotropic trilinear
         self.meshlets = None         # filled by meshlet generation: (GpuMeshlet array, vertex indices, packed triangles)
         self._keep = []
         self._desc = None
@@ -289,6 +290,7 @@ class PackedScene:
         d.root_transform = to_matrix(self.root_transform)
         for i in range(3):
             d.sun_dir[i] = float(self.sun_dir[i])
+        d.max_anisotropy = int(self.max_anisotropy)
         if self.decal_primitives:
             dps = []
             for p, _ in self.decal_primitives:

@@ -170,7 +170,8 @@ typedef struct incr_scene_desc {
                                           const incr_matrix* light_transforms;  /* per SCENE light (renderer.cpp:1540-1558) */
     incr_matrix root_transform;           /* FScene::m_rootTransform == shader `sceneRotation` */
     float    sun_dir[3];                  /* FScene::m_sunDir from time of day (scene.cpp:1594-1655); feeds the dynamic-sky environment */
-    uint32_t reserved;
+    uint32_t max_anisotropy;              /* MaxAnisotropy of the raster passes' g_anisoSampler: 0 = 16, the default of the reference's static
+                                           * samplers (gbuffer-compute.hlsl:20, d3dx12_root_signature.h:277); 1 = isotropic trilinear; at most 16 */
     /* FScene::m_sceneMeshDecals (scene.cpp:281: meshes whose name starts with "decal"): kept out of the packed primitives
      * and the BVH, drawn only by the decal G-buffer pass (incr_gbuffer_decals).  Accessors / materials index the arrays above. */
     uint32_t num_decal_primitives;        const incr_gpu_primitive* decal_primitives;   /* in draw order: mesh, then primitive */

@@ -223,6 +223,7 @@ struct Scene {
     // mip chains of the textures (levels packed, level 0 first), built at scene creation: see build_texture_mips()
     std::vector<std::vector<uint32_t>> texChain;
     std::vector<uint32_t> texMips;
+    uint32_t maxAnisotropy = 16;           // incr_scene_desc::max_anisotropy (0 = 16)
 };
 
 static inline bool acc_valid(const Scene& s, int accessorIndex) { return accessorIndex >= 0 && (uint32_t)accessorIndex < s.d.num_accessors; }
@@ -304,9 +305,15 @@ static float4 SampleBilinearLevel(const Scene& s, int texIndex, uint32_t level, 
 static float4 SampleLevel0(const Scene& s, int texIndex, float2 uv) { return SampleBilinearLevel(s, texIndex, 0u, uv); }
 
 // ---- Sample(s, uv) of the raster passes (material/common.hlsli:6-8: TEX_SAMPLE = Sample outside PATH_TRACING) ----
-// Pinned: isotropic LOD = log2 of the longer screen-space UV derivative in texels (D3D11.3 functional spec
-// 7.18.11) with the logarithm evaluated as exponent + a degree-4 polynomial of the mantissa, clamped to the chain, fraction
-// truncated to 8 bits, trilinear lerp of two bilinear taps.  The reference's anisotropic sampler is not reproduced.
+// g_anisoSampler: FILTER_ANISOTROPIC, MaxAnisotropy = the root-signature default 16 (gbuffer-compute.hlsl:20, visibility-pass.hlsl:11,
+// gbuffer-raster.hlsl:11; ext/d3d12 d3dx12_root_signature.h:277).  D3D leaves the anisotropic footprint to the GPU; pinned here
+//  as the textbook line of taps (Vulkan 1.3 spec, "Texel Anisotropic Filtering"): with rho_max, rho_min the lengths
+// of the longer / shorter screen-space UV derivative in texels,
+//     N = min(ceil(rho_max / rho_min), MaxAnisotropy),  lod = log2(rho_max / min(rho_max / rho_min, MaxAnisotropy)),
+//     colour = 1/N * sum_{i=1..N} trilinear(uv + longer derivative * (i / (N + 1) - 1/2), lod).
+// Evaluated on SQUARED lengths so that no square root has to agree between machines; the logarithm is exponent + a degree-4
+// polynomial of the mantissa; lod clamped to the chain, fraction truncated to 8 bits, trilinear = lerp of two bilinear taps.
+// MaxAnisotropy = 1 degenerates to the isotropic rule of the D3D11.3 functional spec 7.18.11.
 static float pinned_log2(float x) {
     uint32_t b; memcpy(&b, &x, 4);
     const float e = (float)((int)(b >> 23) - 127);
@@ -315,16 +322,26 @@ static float pinned_log2(float x) {
     const float p = 1.4425331354141235f + t * (-0.7161056399345398f + t * (0.4395408034324646f + t * (-0.2250901162624359f + t * 0.05923847481608391f)));
     return e + t * p;
 }
-static float texture_lod(const incr_texture_desc& t, float2 ddx, float2 ddy) {
+struct AnisoLine { float lod; uint32_t taps; float2 along; };
+static AnisoLine aniso_line(const incr_texture_desc& t, float2 ddx, float2 ddy, uint32_t maxAnisotropy) {
     const float W = (float)t.width, H = (float)t.height;
     const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
-    const float m = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
-    if (!(m >= 1.17549435e-38f) || !(m <= 3.0e38f)) return 0.f;
-    return 0.5f * pinned_log2(m);
+    const float lenX2 = ax * ax + ay * ay, lenY2 = bx * bx + by * by;
+    AnisoLine r;
+    float rhoMax2, rhoMin2;
+    if (lenX2 >= lenY2) { rhoMax2 = lenX2; rhoMin2 = lenY2; r.along = ddx; } else { rhoMax2 = lenY2; rhoMin2 = lenX2; r.along = ddy; }
+    r.lod = 0.f; r.taps = 1;
+    if (!(rhoMax2 >= 1.17549435e-38f) || !(rhoMax2 <= 3.0e38f)) return r;           // no usable footprint: level 0, one tap
+    for (uint32_t n = 1; n < maxAnisotropy; ++n) {                                    // ceil(rho_max / rho_min) without the root
+        if (!((float)(n * n) * rhoMin2 < rhoMax2)) break;
+        r.taps = n + 1;
+    }
+    const float clampedMin2 = fmaxf(rhoMin2, rhoMax2 / (float)(maxAnisotropy * maxAnisotropy));
+    if (clampedMin2 >= 1.17549435e-38f) r.lod = 0.5f * pinned_log2(clampedMin2);
+    return r;
 }
-static float4 SampleGrad(const Scene& s, int texIndex, float2 uv, float2 ddx, float2 ddy) {
+static float4 sample_trilinear(const Scene& s, int texIndex, float lod, float2 uv) {
     const uint32_t numMips = s.texMips[(size_t)texIndex];
-    float lod = texture_lod(s.d.textures[texIndex], ddx, ddy);
     lod = fminf(fmaxf(lod, 0.f), (float)(numMips - 1u));
     const float l0f = floorf(lod);
     const float frac = floorf((lod - l0f) * 256.f) * (1.f / 256.f);
@@ -333,6 +350,18 @@ static float4 SampleGrad(const Scene& s, int texIndex, float2 uv, float2 ddx, fl
     if (frac == 0.f || l0 + 1u >= numMips) return a;
     const float4 b = SampleBilinearLevel(s, texIndex, l0 + 1u, uv);
     return {a.x + (b.x - a.x) * frac, a.y + (b.y - a.y) * frac, a.z + (b.z - a.z) * frac, a.w + (b.w - a.w) * frac};
+}
+static float4 SampleGrad(const Scene& s, int texIndex, float2 uv, float2 ddx, float2 ddy) {
+    const AnisoLine line = aniso_line(s.d.textures[texIndex], ddx, ddy, s.maxAnisotropy);
+    if (line.taps == 1) return sample_trilinear(s, texIndex, line.lod, uv);
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = 1; i <= line.taps; ++i) {
+        const float where = (float)i / (float)(line.taps + 1u) - 0.5f;
+        const float4 c = sample_trilinear(s, texIndex, line.lod, {uv.x + line.along.x * where, uv.y + line.along.y * where});
+        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+    }
+    const float n = (float)line.taps;
+    return {acc.x / n, acc.y / n, acc.z / n, acc.w / n};
 }
 
 // shaders/material/common.hlsli:10-115 (fields the hot path reads)
@@ -935,6 +964,7 @@ static uint32_t srgb_encode_nearest(const float* lut, float v) {
 static void build_texture_mips(Scene& s) {
     const uint32_t nt = s.d.num_textures;
     s.texChain.assign(nt, {}); s.texMips.assign(nt, 1u);
+    s.maxAnisotropy = s.d.max_anisotropy ? std::min(s.d.max_anisotropy, 16u) : 16u;
     auto dim = [](uint32_t d, uint32_t l) { return std::max(d >> l, 1u); };
     for (uint32_t i = 0; i < nt; ++i) {
         const incr_texture_desc& t = s.d.textures[i];

@@ -1,0 +1,58 @@
+// Issue cost of candidate instructions for the BVH slab test on gfx950, in cycles per wave64 instruction: one workgroup of W waves per
+// SIMD-set runs N back-to-back independent instances of the instruction between two s_memtime stamps.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/issue_rate tools/microbench/issue_rate.hip && gpurun_out/issue_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define REP4(x) x x x x
+#define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
+#define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
+template <int OP> __global__ void k(uint64_t* out, float* sink) {
+    float a = threadIdx.x * 0.5f, b = 1.0001f, c = 0.3f, d = 0.7f, e = 0.1f;
+    uint32_t u = threadIdx.x * 2654435761u, v = 0x01020304u, w = 7u, x = 9u;
+    const uint64_t cond = 0x5555aaaa5555aaaaull ^ (uint64_t)(uintptr_t)out;
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 64; ++i) {
+        if (OP == 0) { REP64(asm volatile("v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %3, %1, %2, %3\n v_fma_f32 %4, %1, %2, %4\n v_fma_f32 %5, %1, %2, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(d));) }
+        if (OP == 1) { REP64(asm volatile("v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4" : "=v"(a), "=v"(c), "=v"(d), "=v"(e) : "v"(v));) }
+        if (OP == 2) { REP64(asm volatile("v_dot2_f32_f16 %0, %4, %5, %0\n v_dot2_f32_f16 %1, %4, %5, %1\n v_dot2_f32_f16 %2, %4, %5, %2\n v_dot2_f32_f16 %3, %4, %5, %3" : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(v), "v"(w));) }
+        if (OP == 3) { REP64(asm volatile("v_dot2_i32_i16 %0, %4, %5, %0\n v_dot2_i32_i16 %1, %4, %5, %1\n v_dot2_i32_i16 %2, %4, %5, %2\n v_dot2_i32_i16 %3, %4, %5, %3" : "+v"(u), "+v"(x), "+v"(w), "+v"(v) : "v"(v), "v"(w));) }
+        if (OP == 4) { REP64(asm volatile("v_pk_mad_i16 %0, %4, %5, %0\n v_pk_mad_i16 %1, %4, %5, %1\n v_pk_mad_i16 %2, %4, %5, %2\n v_pk_mad_i16 %3, %4, %5, %3" : "+v"(u), "+v"(x), "+v"(w), "+v"(v) : "v"(v), "v"(w));) }
+        if (OP == 5) { REP64(asm volatile("v_perm_b32 %0, %4, %5, %6\n v_perm_b32 %1, %4, %5, %6\n v_perm_b32 %2, %4, %5, %6\n v_perm_b32 %3, %4, %5, %6" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(v), "v"(w), "v"(x));) }
+        if (OP == 6) { REP64(asm volatile("v_fma_mix_f32 %0, %4, %5, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel_hi:[1,0,0]" : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(v), "v"(b));) }
+        if (OP == 7) { REP64(asm volatile("v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5" : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(b));) }
+        if (OP == 8) { REP64(asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1" : "+v"(*(double*)&u), "+v"(*(double*)&w) : "v"(*(double*)&a), "v"(*(double*)&c));) }
+        if (OP == 9) { REP64(asm volatile("v_pk_max_i16 %0, %0, %4\n v_pk_min_i16 %1, %1, %4\n v_pk_max_i16 %2, %2, %4\n v_pk_min_i16 %3, %3, %4" : "+v"(u), "+v"(x), "+v"(w), "+v"(v) : "v"(v));) }
+        if (OP == 10) { REP64(asm volatile("v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %4, %5, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %4, %5, %6" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b), "s"(cond));) }
+        if (OP == 11) { REP64(asm volatile("v_cmp_lt_f32 vcc, %4, %5\n v_cndmask_b32 %0, %4, %5, vcc\n v_cmp_gt_f32 vcc, %4, %5\n v_cndmask_b32 %1, %4, %5, vcc" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b) : "vcc");) }
+        if (OP == 12) { REP64(asm volatile("v_cmp_lt_f32 %6, %4, %5\n v_cmp_gt_f32 %7, %4, %5\n v_cmp_le_f32 %6, %4, %5\n v_cmp_ge_f32 %7, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b), "s"(cond), "s"(cond));) }
+        if (OP == 13) { REP64(asm volatile("v_med3_f32 %0, %0, %4, %5\n v_min3_f32 %1, %1, %4, %5\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(b));) }
+        if (OP == 14) { REP64(asm volatile("v_lshlrev_b32 %0, 3, %4\n v_and_b32 %1, %4, %5\n v_bfe_u32 %2, %4, 8, 8\n v_add_u32 %3, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
+    sink[threadIdx.x + blockIdx.x * blockDim.x] = a + c + d + e + (float)(u + x + w + v);
+}
+template <int OP> static void run(const char* name, int perIter) {
+    uint64_t* out; float* sink;
+    hipMalloc(&out, 8 * 65536); hipMalloc(&sink, 4 * 1024 * 1024);
+    for (int wavesPerSimd : {1, 2, 4}) {
+        const int threads = 256 * wavesPerSimd;          // one workgroup on one CU: wavesPerSimd waves on each of its 4 SIMDs
+        const int blocks = 1;
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, out, sink);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, out, sink);
+        hipDeviceSynchronize();
+        static uint64_t h[65536]; hipMemcpy(h, out, 8 * (size_t)(threads / 64), hipMemcpyDeviceToHost);
+        double sum = 0; const int nw = threads / 64; for (int i = 0; i < nw; ++i) sum += (double)h[i];
+        const double instr = 64.0 * 64 * perIter;
+        printf("%-22s %d wave(s)/SIMD: %.2f cycles per instruction per wave  (=> %.2f per SIMD slot)\n", name, wavesPerSimd, sum / nw / instr, sum / nw / instr / wavesPerSimd);
+    }
+    hipFree(out); hipFree(sink);
+}
+int main() {
+    run<0>("v_fma_f32", 4); run<1>("v_cvt_f32_ubyteN", 4); run<2>("v_dot2_f32_f16", 4); run<3>("v_dot2_i32_i16", 4); run<4>("v_pk_mad_i16", 4);
+    run<5>("v_perm_b32", 4); run<6>("v_fma_mix_f32", 4); run<7>("v_max3_f32", 4); run<8>("v_pk_fma_f32", 2); run<9>("v_pk_max/min_i16", 4); run<10>("v_cndmask_b32 (sgpr)", 4); run<11>("v_cmp+v_cndmask vcc", 4); run<12>("v_cmp_f32 -> sgpr", 4); run<13>("med3/min3/max/min", 4); run<14>("shift/and/bfe/add", 4);
+    return 0;
+}

@@ -27,7 +27,7 @@ with open("$OUT/summary.txt", "w") as o:
         line = "%-36s %-32s per-launch %.6g  (launches %d)" % (kn, cn, v / n, n)
         print(line); o.write(line + "\n")
 # HBM traffic per launch of every path-tracing kernel, stamped with the hash of the kernel sources it was measured on:
-# bench.py attaches `roofline.traffic` only when the stamp matches the sources it runs (profiles/hbm_traffic_latest.json)
+# bench.py attaches roofline.traffic only when the stamp matches the sources it runs (profiles/hbm_traffic_latest.json)
 import json, sys
 sys.path.insert(0, "$GRAFT_REPO_ROOT")
 import bench

@@ -92,6 +92,36 @@ def cpu_baseline(packed, view, res, seconds_hint, envmap=None):
 RASTER_B_PX = 133
 
 
+class _Collectives:
+    """The path's collectives.  Over RCCL they run on the device tensors as they are.  In the one-GPU rehearsal of the N > 1 path
+    (--share-gpu: every rank renders on GPU 0, torch.distributed over gloo) the same calls stage through the host: the rank
+    choreography, the shard / band arithmetic and every buffer shape are the ones the RCCL run uses, only the transport differs."""
+
+    def __init__(self, dist, torch, staged):
+        self.dist, self.torch, self.staged = dist, torch, staged
+        self.ReduceOp = dist.ReduceOp
+
+    def all_gather_into_tensor(self, out, inp):
+        if not self.staged:
+            return self.dist.all_gather_into_tensor(out, inp)
+        host = self.torch.empty(out.numel(), dtype=out.dtype)          # gloo wants the concatenation as one flat tensor
+        self.dist.all_gather_into_tensor(host, inp.cpu().contiguous().view(-1))
+        out.copy_(host.view(out.shape))
+
+    def all_reduce(self, t, op):
+        if not self.staged:
+            return self.dist.all_reduce(t, op=op)
+        host = t.cpu()
+        self.dist.all_reduce(host, op=op)
+        t.copy_(host)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def destroy_process_group(self):
+        self.dist.destroy_process_group()
+
+
 class _DeviceWords:
     """CUDA array interface over a raw device pointer: lets torch.distributed collectives run on a library-owned surface."""
 
@@ -115,10 +145,18 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
         if world > 1:
             ptr = rr.surface_ptr(A.SURFACE_TAA_ACCUMULATION)
             if ptr not in tensors:
-                tensors[ptr] = torch.as_tensor(_DeviceWords(ptr, world * rows * W), device=dev)
-            full = tensors[ptr]
-            band = full[rank * rows * W:(rank + 1) * rows * W].clone()
-            dist.all_gather_into_tensor(full, band)
+                tensors[ptr] = torch.as_tensor(_DeviceWords(ptr, H * W), device=dev)
+            surface = tensors[ptr]
+            if world * rows == H:            # equal bands: gather straight into the surface
+                band = surface[rank * rows * W:(rank + 1) * rows * W].clone()
+                dist.all_gather_into_tensor(surface, band)
+            else:                            # the last band is shorter: gather padded bands, copy the frame's rows back
+                band = torch.zeros(rows * W, dtype=surface.dtype, device=dev)
+                mine = surface[rank * rows * W:min((rank + 1) * rows, H) * W]
+                band[:mine.numel()] = mine
+                padded = tensors.setdefault("padded", torch.empty(world * rows * W, dtype=surface.dtype, device=dev))
+                dist.all_gather_into_tensor(padded, band)
+                surface.copy_(padded[:H * W])
             if rank == 0:
                 rr.tonemap()
 
@@ -136,7 +174,7 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, dist.ReduceOp.MAX)
     ms = float(tt.item()) / steps * 1e3
     # per-pass GPU time of one more frame (events on the submission stream) and the algorithmic bytes each pass moves per pixel
     # (SURVEY.md 8d): visibility 8 (id + depth written), G-buffer 4 + 16, fused lighting 16 read + 8 colour rw (unfused: 3 x 24),
@@ -293,6 +331,8 @@ def main():
                          "call per sample).  0 = 1 at N = 1 (a step is then exactly one 1-spp frame, the headline) and 8 at N > 1, where a rank's "
                          "1/N framebuffer shard alone is too short a ray list to fill the GPU between two launch tails (BASELINE config 4: 64 spp per gathered frame)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 path on ONE GPU: every rank renders on GPU 0 and the collectives go over gloo through the host "
+                                                             "(with --backend gloo; the numbers are not a scaling measurement and the JSON line says so)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank choreography (rendezvous, barriers, gather, the JSON line) without render work")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run): this rank raises after the rendezvous")
     args = ap.parse_args()
@@ -310,8 +350,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without a launcher)" % (args.gpus, world, args.gpus))
     if args.dry_run:
         return dry_run(args, rank, world)
-    if args.backend != "nccl":
-        raise SystemExit("--backend gloo is for --dry-run only: the render path runs on the GPU over RCCL")
+    if (args.backend != "nccl") != bool(args.share_gpu):
+        raise SystemExit("--backend gloo goes with --dry-run (no render work) or with --share-gpu (all ranks on GPU 0); the measured path runs over RCCL, one GPU per rank")
     import torch
     A = importlib.import_module(PKG + ".ctypes_api")
     sio = importlib.import_module(PKG + ".scene_io")
@@ -319,13 +359,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group(backend=args.backend, device_id=dev)
+        if args.share_gpu:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend=args.backend, device_id=dev)
+        dist = _Collectives(dist_mod, torch, staged=bool(args.share_gpu))
 
     W, H = (int(v) for v in args.res.lower().split("x"))
     packed = build_scene(args.scene, args.texture_size)
@@ -402,8 +447,8 @@ def main():
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     local_stats = stats.clone()
     if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt, dist.ReduceOp.MAX)
+        dist.all_reduce(stats, dist.ReduceOp.SUM)
     dt = float(tt.item())
     s = stats.cpu().numpy()
     ls = local_stats.cpu().numpy()
@@ -456,7 +501,8 @@ def main():
                        "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": int(prof.pipelines), "samples_in_flight": sif,
                        "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
-                       "ms_per_frame": round(dt / args.steps * 1e3, 4)},
+                       "ms_per_frame": round(dt / args.steps * 1e3, 4),
+                       **({"rehearsal": "--share-gpu: %d ranks on ONE GPU, collectives over gloo through the host -- exercises the N > 1 code path, measures nothing" % world} if args.share_gpu else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": dominant, "kernel_ms": round(kernel_ms, 4), "kernel_launches_per_step": dom_launches / args.steps,

@@ -317,6 +317,7 @@ def main():
     ap.add_argument("--no-direct-lighting", action="store_true", help="diagnostic: DIRECT_LIGHTING=0 (not the headline workload)")
     ap.add_argument("--viewmode", type=int, default=0, help="diagnostic: FConfig::Viewmode")
     ap.add_argument("--max-anisotropy", type=int, default=0, help="raster leg: MaxAnisotropy of the material sampler (0 = the reference's 16; 1 = isotropic trilinear, a diagnostic)")
+    ap.add_argument("--block-compress", action="store_true", help="diagnostic: hand the textures over as BC3 / BC5 chains (bc.py's encoder) instead of RGBA8")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical; "
@@ -375,6 +376,8 @@ def main():
     W, H = (int(v) for v in args.res.lower().split("x"))
     packed = build_scene(args.scene, args.texture_size)
     packed.max_anisotropy = args.max_anisotropy
+    if args.block_compress:
+        packed.compress_textures()
     importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
@@ -498,7 +501,7 @@ def main():
             "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
-                       "lights": len(packed.global_lights), "texture_size": args.texture_size, "pipelines": int(prof.pipelines), "samples_in_flight": sif,
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size, **({"textures": "block-compressed chains (BC3 / BC5)"} if args.block_compress else {}), "pipelines": int(prof.pipelines), "samples_in_flight": sif,
                        "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4),

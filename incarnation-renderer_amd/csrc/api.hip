@@ -25,6 +25,7 @@ extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriOb
 extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format,
                                           const float* srgbLut, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
+extern "C" hipError_t incr_launch_bc_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
@@ -357,9 +358,57 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     std::vector<DeviceTexture> texs(desc->num_textures);
     auto mip_levels = [](uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 4 && h >= 4) { ++n; w >>= 1; h >>= 1; } return n ? n : 1u; };      // scene.cpp:1072-1081
     auto level_dim = [](uint32_t d, uint32_t l) { return std::max(d >> l, 1u); };
+    std::vector<uint8_t> haveChain(desc->num_textures, 0);
     for (uint32_t i = 0; i < desc->num_textures && !rc; ++i) {
         const incr_texture_desc& t = desc->textures[i];
-        if (!t.texels || !t.width || !t.height || t.format > INCR_TEX_BGRA8_SWIZZLE_RG) { rc = fail(INCR_ERR_INVALID_ARGUMENT, "texture %u invalid", i); break; }
+        if (!t.texels || !t.width || !t.height || t.format > INCR_TEX_BC5_SNORM) { rc = fail(INCR_ERR_INVALID_ARGUMENT, "texture %u invalid", i); break; }
+        if (t.format >= INCR_TEX_BC3_SRGB) {
+            // A block-compressed chain (what the reference uploads after DirectX::Compress): every level is decoded into the row-major
+            // words of the chain buffer (texture_mips.hip bc_decode_kernel); nothing is generated or filtered for such a texture.
+            uint32_t full = 1; while ((t.width >> full) || (t.height >> full)) ++full;            // levels down to 1 x 1
+            if (!t.mip_levels || t.mip_levels > full) { rc = fail(INCR_ERR_INVALID_ARGUMENT, "texture %u: %u mip levels for a %u x %u block-compressed chain", i, t.mip_levels, t.width, t.height); break; }
+            const size_t blockBytes = t.format == INCR_TEX_BC4_UNORM ? 8 : 16;
+            size_t chainTexels = 0, chainBlocks = 0;
+            for (uint32_t l = 0; l < t.mip_levels; ++l) {
+                const uint32_t w = level_dim(t.width, l), h = level_dim(t.height, l);
+                chainTexels += (size_t)w * h; chainBlocks += (size_t)((w + 3) / 4) * ((h + 3) / 4);
+            }
+            void* d = nullptr; void* blocks = nullptr;
+            hipError_t e = hipMalloc(&d, chainTexels * 4);
+            if (e == hipSuccess) e = hipMalloc(&blocks, chainBlocks * blockBytes);
+            if (e == hipSuccess) e = hipMemcpy(blocks, t.texels, chainBlocks * blockBytes, hipMemcpyHostToDevice);
+            const uint8_t* src = (const uint8_t*)blocks; uint32_t* dst = (uint32_t*)d;
+            for (uint32_t l = 0; l < t.mip_levels && e == hipSuccess; ++l) {
+                const uint32_t w = level_dim(t.width, l), h = level_dim(t.height, l);
+                e = incr_launch_bc_decode(src, w, h, t.format, dst, nullptr);
+                src += (size_t)((w + 3) / 4) * ((h + 3) / 4) * blockBytes; dst += (size_t)w * h;
+            }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (blocks) (void)hipFree(blocks);
+            if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "block-compressed texture decode failed: %s", hipGetErrorString(e)); break; }
+            sc->dTexels.push_back(d);
+            sc->textureBytes += chainTexels * 4;
+            texs[i].texels = (const uint8_t*)d; texs[i].width = t.width; texs[i].height = t.height;
+            texs[i].format = t.format == INCR_TEX_BC3_SRGB ? (uint32_t)INCR_TEX_RGBA8_SRGB : (t.format == INCR_TEX_BC5_SNORM ? (uint32_t)INCR_TEX_RG16S_OVER_4445 : (uint32_t)INCR_TEX_RG16_OVER_8925);
+            texs[i].pad[0] = texs[i].pad[2] = 0; texs[i].pad[1] = t.mip_levels;
+            if (t.format == INCR_TEX_BC3_SRGB) {          // pad[0]: every alpha of level 0 decodes to 255 (both endpoints 255, or only indices that select a 255)
+                const size_t n0 = (size_t)((t.width + 3) / 4) * ((t.height + 3) / 4);
+                bool opaque = true;
+                for (size_t b = 0; b < n0 && opaque; ++b) {
+                    const uint8_t* blk = t.texels + b * 16;
+                    if (blk[0] == 255 && blk[1] == 255) continue;
+                    uint64_t bits = 0; for (int k = 0; k < 6; ++k) bits |= (uint64_t)blk[2 + k] << (8 * k);
+                    for (int px = 0; px < 16 && opaque; ++px) {
+                        const uint32_t idx = (uint32_t)(bits >> (3 * px)) & 7u;
+                        const bool is255 = (idx == 0 && blk[0] == 255) || (idx == 1 && blk[1] == 255) || (idx == 7 && blk[0] <= blk[1]);
+                        opaque = is255;
+                    }
+                }
+                texs[i].pad[0] = opaque ? 1u : 0u;
+            }
+            haveChain[i] = 1;
+            continue;
+        }
         const size_t bytes = (size_t)t.width * t.height * 4;
         const uint32_t mips = mip_levels(t.width, t.height);
         size_t chainTexels = 0;
@@ -382,7 +431,6 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     // vMF-filtered chains for the normal + metallic-roughness pair of a material (scene.cpp:1157-1320), box chains for the rest.
     // The pairs are independent: their prefilters run on four streams (a pair's top levels are a few long serial sums,
     // content_pipeline.hip), one synchronisation at the end.
-    std::vector<uint8_t> haveChain(desc->num_textures, 0);
     struct VmfJob { void* tmpN; void* tmpM; };
     std::vector<VmfJob> vmfJobs;
     hipStream_t vmfStreams[4] = {nullptr, nullptr, nullptr, nullptr};

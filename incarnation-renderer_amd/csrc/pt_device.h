@@ -325,6 +325,9 @@ DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t 
     case INCR_TEX_RGBA8_SRGB:       return {srgbLut[r], srgbLut[g], srgbLut[b], (float)a * inv255};
     case INCR_TEX_RG_SNORM:         return {2.f * ((float)r * inv255) - 1.f, 2.f * ((float)g * inv255) - 1.f, 0.f, 1.f};
     case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)b * inv255, (float)g * inv255, 0.f, 1.f};
+    // decoded BC4 / BC5 blocks (texture_mips.hip bc_decode_kernel): the palette entry's exact numerator over 35 x 255, or 35 x 127 signed
+    case INCR_TEX_RG16_OVER_8925:   return {(float)(rgba & 0xffffu) / 8925.f, (float)(rgba >> 16) / 8925.f, 0.f, 1.f};
+    case INCR_TEX_RG16S_OVER_4445:  return {(float)(int16_t)(rgba & 0xffffu) / 4445.f, (float)(int16_t)(rgba >> 16) / 4445.f, 0.f, 1.f};
     default:                        return {(float)r * inv255, (float)g * inv255, (float)b * inv255, (float)a * inv255};
     }
 }
@@ -476,7 +479,7 @@ DI f4 SampleGrad(const DeviceTexture* __restrict__ textures, const float* __rest
 // SampleGrad(...).w for the alpha test of the visibility scan (raster.hip fragment), a per-lane serial loop whose cost is its dependent
 // round trips: the same taps, the same arithmetic on the alpha channel alone (UNORM alpha: a / 255 for the formats that carry one,
 // 1 otherwise), bit for bit.
-DI bool format_has_alpha(uint32_t format) { return !(format == INCR_TEX_RG_SNORM || format == INCR_TEX_BGRA8_SWIZZLE_RG); }
+DI bool format_has_alpha(uint32_t format) { return format == INCR_TEX_RGBA8_UNORM || format == INCR_TEX_RGBA8_SRGB; }
 DI float texel_alpha(uint32_t rgba) { return (float)(rgba >> 24) * (1.f / 255.f); }          // of a format that carries alpha (decode_texel's .w)
 DI float bilinear_alpha(const BilinearTap& t, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
     const float wx0 = 1.f - t.fx, wy0 = 1.f - t.fy;
@@ -708,6 +711,8 @@ DI JointSamples SampleGradJointT(const DeviceTexture& tb, const DeviceTexture& t
 DI JointSamples SampleGradJoint(const DeviceTexture& tb, const DeviceTexture& tn, const DeviceTexture& tm, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
     if (tb.format == INCR_TEX_RGBA8_SRGB && tn.format == INCR_TEX_RG_SNORM && tm.format == INCR_TEX_BGRA8_SWIZZLE_RG)
         return SampleGradJointT<INCR_TEX_RGBA8_SRGB, INCR_TEX_RG_SNORM, INCR_TEX_BGRA8_SWIZZLE_RG>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
+    if (tb.format == INCR_TEX_RGBA8_SRGB && tn.format == INCR_TEX_RG16S_OVER_4445 && tm.format == INCR_TEX_RG16_OVER_8925)          // the same three slots handed over block-compressed
+        return SampleGradJointT<INCR_TEX_RGBA8_SRGB, INCR_TEX_RG16S_OVER_4445, INCR_TEX_RG16_OVER_8925>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
     return SampleGradJointT<-1, -1, -1>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
 }
 DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {   // raster: Sample

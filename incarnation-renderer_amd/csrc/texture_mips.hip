@@ -79,6 +79,65 @@ __global__ __launch_bounds__(256) void material_texels_kernel(const uint32_t* __
 
 } // namespace incr
 
+namespace incr {
+// ---- block-compressed chains handed over by the integrator (incr_types.h formats 4-7): decoded ONCE, at scene creation, into the words
+// the samplers read.  The decode is fixed by the format (D3D11.3 functional spec 19.5: BC1 colour block, BC4 block); what a texture
+// unit keeps of the palette's precision is pinned:
+//   BC3 -> RGBA8 as the texture caches of current GPUs expand BC1-3: colour endpoints 5:6:5 widened by bit replication, the two
+//          interpolants (2 a + b) / 3 and (a + 2 b) / 3 rounded to nearest (+ 1 before the division); alpha = the BC4 palette rounded
+//          to 8 bits ((n + 17) / 35).  The result is a plain INCR_TEX_RGBA8_SRGB texture.
+//   BC4 / BC5 -> EXACT: every palette entry of an 8-bit-endpoint block is a multiple of 1/35 of an endpoint step ((7 - k) e0 + k e1) / 7
+//          or ((5 - k) e0 + k e1) / 5, so the texel stores the integer numerator n over 35 x 255 = 8925 (UNORM) or 35 x 127 = 4445
+//          (SNORM; -128 reads as -127) in 16 bits per channel and the sampler divides (INCR_TEX_RG16_OVER_8925 / INCR_TEX_RG16S_OVER_4445).
+__device__ __forceinline__ int32_t bc4_numerator(const uint8_t* __restrict__ block, uint32_t texel, bool snorm) {      // palette value x 35
+    int32_t e0 = block[0], e1 = block[1];
+    if (snorm) { e0 = (int8_t)block[0]; e1 = (int8_t)block[1]; e0 = e0 < -127 ? -127 : e0; e1 = e1 < -127 ? -127 : e1; }
+    uint64_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bits |= (uint64_t)block[2 + k] << (8 * k);
+    const int32_t i = (int32_t)((bits >> (3u * texel)) & 7u);
+    if (i == 0) return e0 * 35;
+    if (i == 1) return e1 * 35;
+    if (e0 > e1) return ((8 - i) * e0 + (i - 1) * e1) * 5;             // six interpolants in sevenths
+    if (i < 6) return ((6 - i) * e0 + (i - 1) * e1) * 7;               // four interpolants in fifths
+    const int32_t one = snorm ? 127 * 35 : 255 * 35;
+    return i == 6 ? (snorm ? -one : 0) : one;
+}
+__global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t* __restrict__ blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const uint32_t bw = (w + 3u) >> 2, texel = (y & 3u) * 4u + (x & 3u);
+    const size_t bi = (size_t)(y >> 2) * bw + (x >> 2);
+    uint32_t word;
+    if (format == INCR_TEX_BC4_UNORM) {
+        word = (uint32_t)bc4_numerator(blocks + bi * 8, texel, false);
+    } else if (format == INCR_TEX_BC5_UNORM) {
+        word = (uint32_t)bc4_numerator(blocks + bi * 16, texel, false) | ((uint32_t)bc4_numerator(blocks + bi * 16 + 8, texel, false) << 16);
+    } else if (format == INCR_TEX_BC5_SNORM) {
+        word = ((uint32_t)bc4_numerator(blocks + bi * 16, texel, true) & 0xffffu) | ((uint32_t)bc4_numerator(blocks + bi * 16 + 8, texel, true) << 16);
+    } else {                                                              // INCR_TEX_BC3_SRGB: alpha block, then colour block
+        const uint8_t* __restrict__ b = blocks + bi * 16;
+        const uint32_t a = (uint32_t)(bc4_numerator(b, texel, false) + 17) / 35u;
+        const uint32_t c0 = b[8] | ((uint32_t)b[9] << 8), c1 = b[10] | ((uint32_t)b[11] << 8);
+        const uint32_t idx = ((b[12] | ((uint32_t)b[13] << 8) | ((uint32_t)b[14] << 16) | ((uint32_t)b[15] << 24)) >> (2u * texel)) & 3u;
+        auto widen = [](uint32_t c, uint32_t* r, uint32_t* g, uint32_t* bl) {
+            const uint32_t r5 = (c >> 11) & 31u, g6 = (c >> 5) & 63u, b5 = c & 31u;
+            *r = (r5 << 3) | (r5 >> 2); *g = (g6 << 2) | (g6 >> 4); *bl = (b5 << 3) | (b5 >> 2);
+        };
+        uint32_t r0, g0, b0, r1, g1, b1;
+        widen(c0, &r0, &g0, &b0); widen(c1, &r1, &g1, &b1);
+        uint32_t r, g, bl;
+        if (idx == 0u) { r = r0; g = g0; bl = b0; }
+        else if (idx == 1u) { r = r1; g = g1; bl = b1; }
+        else if (idx == 2u) { r = (2u * r0 + r1 + 1u) / 3u; g = (2u * g0 + g1 + 1u) / 3u; bl = (2u * b0 + b1 + 1u) / 3u; }
+        else { r = (r0 + 2u * r1 + 1u) / 3u; g = (g0 + 2u * g1 + 1u) / 3u; bl = (b0 + 2u * b1 + 1u) / 3u; }
+        word = r | (g << 8) | (bl << 16) | (a << 24);
+    }
+    dst[(size_t)y * w + x] = word;
+}
+
+} // namespace incr
+
 extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {
     hipLaunchKernelGGL(incr::mip_untile_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, src, w, h, dst);
     return hipGetLastError();
@@ -99,5 +158,9 @@ extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream) {
     if (!count) return hipSuccess;
     hipLaunchKernelGGL(incr::mip_adopt_vmf_kernel, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, vmfN, vmfMR, dstN, dstMR, first, count);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_bc_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::bc_decode_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, blocks, w, h, format, dst);
     return hipGetLastError();
 }

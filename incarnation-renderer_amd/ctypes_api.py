@@ -66,13 +66,14 @@ class LightGridData(C.Structure):
 
 
 TEX_RGBA8_UNORM, TEX_RGBA8_SRGB, TEX_RG_SNORM, TEX_BGRA8_SWIZZLE_RG = 0, 1, 2, 3
+TEX_BC3_SRGB, TEX_BC4_UNORM, TEX_BC5_UNORM, TEX_BC5_SNORM, TEX_RG16_OVER_8925, TEX_RG16S_OVER_4445 = 4, 5, 6, 7, 8, 9
 ALPHA_OPAQUE, ALPHA_MASKED, ALPHA_BLEND = 0, 1, 2
 LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT = 0, 1, 2
 
 
 class TextureDesc(C.Structure):
     _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("mip_levels", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

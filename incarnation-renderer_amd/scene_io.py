@@ -205,6 +205,21 @@ class PackedScene:
         self.textures.append((np.ascontiguousarray(rgba8, dtype=np.uint8), int(fmt)))
         return len(self.textures) - 1
 
+    def add_texture_bc(self, image):
+        """A block-compressed mip chain (bc.BcImage: what the reference uploads after DirectX::Compress) in place of RGBA8 texels."""
+        self.textures.append((image, int(image.format)))
+        return len(self.textures) - 1
+
+    def compress_textures(self):
+        """Replace every RGBA8 texture by a block-compressed chain of the format the reference picks for its slot (scene.cpp:902-904,
+        932-933, 1162-1163): sRGB -> BC3_UNORM_SRGB, normals -> BC5_SNORM, metallic-roughness -> BC5_UNORM, the rest -> BC4_UNORM.  The
+        encoder is bc.py's range fit, not DirectXTex's: this produces VALID compressed input, not the reference's bytes."""
+        from . import bc
+        to_bc = {A.TEX_RGBA8_SRGB: A.TEX_BC3_SRGB, A.TEX_RG_SNORM: A.TEX_BC5_SNORM, A.TEX_BGRA8_SWIZZLE_RG: A.TEX_BC5_UNORM, A.TEX_RGBA8_UNORM: A.TEX_BC4_UNORM}
+        self.textures = [(bc.compress(img, to_bc[fmt]), to_bc[fmt]) if fmt in to_bc else (img, fmt) for img, fmt in self.textures]
+        self._desc = None
+        return self
+
     def accessor_array(self, accessor_index, dtype, ncomp, count):
         """Read `count` elements through the accessor indirection (host-side helper)."""
         view_i, a_off, stride = self.accessors[accessor_index]
@@ -267,7 +282,11 @@ class PackedScene:
         texs = []
         for img, fmt in self.textures:
             t = A.TextureDesc()
-            t.texels = img.ctypes.data
+            if hasattr(img, "blocks"):           # bc.BcImage: the compressed chain goes over as it is
+                t.texels = img.blocks.ctypes.data
+                t.mip_levels = img.mip_levels
+            else:
+                t.texels = img.ctypes.data
             t.height, t.width = img.shape[0], img.shape[1]
             t.format = fmt
             texs.append(t)

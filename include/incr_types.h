@@ -129,23 +129,36 @@ typedef struct incr_light_grid_data { uint32_t offset; uint32_t count; } incr_li
 
 /*
  * Texture table entry.  The reference block-compresses textures with DirectXTex
- * (scene.cpp:889-933); BC encoding is a closed third-party step, so this
- * boundary takes the *uncompressed* RGBA8 texels the reference feeds to the
- * compressor, plus the channel interpretation the chosen DXGI format implies:
+ * (scene.cpp:889-933, 1072-1100, 1157-1420: mip chain, then DirectX::Compress).  The ENCODER is a closed third-party step,
+ * so the boundary takes either
+ *   - the *uncompressed* RGBA8 texels the reference feeds to the compressor, plus the channel interpretation the chosen DXGI
+ *     format implies (formats 0-3; the library builds the mip chain and the vMF-filtered normal / roughness levels itself), or
+ *   - the COMPRESSED mip chain the reference uploads (formats 4-7: what `compressedScratch` / the content cache's .dds hold):
+ *     `texels` = the blocks of level 0, 1, ... `mip_levels - 1` back to back (ceil(w/4) x ceil(h/4) blocks per level, row-major;
+ *     16 bytes per block, 8 for BC4), decoded by the library as the texture unit does; nothing is
+ *     generated or filtered for such a texture.
  */
 enum {
     INCR_TEX_RGBA8_UNORM      = 0, /* R8G8B8A8_UNORM -> BC4/BC5_UNORM: value = c/255                          */
     INCR_TEX_RGBA8_SRGB       = 1, /* R8G8B8A8_UNORM_SRGB -> BC3_UNORM_SRGB: rgb sRGB-decoded per texel, a linear */
     INCR_TEX_RG_SNORM         = 2, /* R8G8B8A8_UNORM -> BC5_SNORM (normal maps): value = 2*c/255 - 1             */
-    INCR_TEX_BGRA8_SWIZZLE_RG = 3  /* metal/rough: sampled .r = texel.b (metal), .g = texel.g (roughness)
+    INCR_TEX_BGRA8_SWIZZLE_RG = 3, /* metal/rough: sampled .r = texel.b (metal), .g = texel.g (roughness)
                                       (scene.cpp:932 B8G8R8A8 swizzle; prefilter-normal-roughness.hlsl:41 `.bgra`) */
+    INCR_TEX_BC3_SRGB         = 4, /* DXGI_FORMAT_BC3_UNORM_SRGB blocks: base colour, emissive (scene.cpp:902-903)        */
+    INCR_TEX_BC4_UNORM        = 5, /* DXGI_FORMAT_BC4_UNORM blocks: AO, transmission, clearcoat (scene.cpp:904, 948, 971) */
+    INCR_TEX_BC5_UNORM        = 6, /* DXGI_FORMAT_BC5_UNORM blocks: .r = metal, .g = roughness (scene.cpp:1163)           */
+    INCR_TEX_BC5_SNORM        = 7, /* DXGI_FORMAT_BC5_SNORM blocks: normal maps (scene.cpp:1162)                          */
+    /* what the samplers see after decode (never passed in): two 16-bit numerators per texel, value = n / 8925 or n / 4445 */
+    INCR_TEX_RG16_OVER_8925   = 8,
+    INCR_TEX_RG16S_OVER_4445  = 9
 };
 typedef struct incr_texture_desc {
-    const uint8_t* texels;   /* width*height*4 bytes, row-major, top row first, RGBA order as decoded from the image */
+    const uint8_t* texels;   /* formats 0-3: width*height*4 bytes, row-major, top row first, RGBA order as decoded from the image;
+                                formats 4-7: the compressed mip chain (above) */
     uint32_t width;
     uint32_t height;
-    uint32_t format;         /* INCR_TEX_* */
-    uint32_t reserved;
+    uint32_t format;         /* INCR_TEX_* (0-7) */
+    uint32_t mip_levels;     /* formats 4-7: levels in `texels` (>= 1); ignored for formats 0-3 */
 } incr_texture_desc;
 
 /*

@@ -223,6 +223,7 @@ struct Scene {
     // mip chains of the textures (levels packed, level 0 first), built at scene creation: see build_texture_mips()
     std::vector<std::vector<uint32_t>> texChain;
     std::vector<uint32_t> texMips;
+    std::vector<uint32_t> texFormat;       // what the sampler decodes: the desc's format, or what a block-compressed chain was expanded to
     uint32_t maxAnisotropy = 16;           // incr_scene_desc::max_anisotropy (0 = 16)
 };
 
@@ -274,6 +275,9 @@ static float4 decode_texel_word(const Scene& s, uint32_t format, uint32_t c) {
     case INCR_TEX_RGBA8_SRGB:       return {s.srgb_lut[p[0]], s.srgb_lut[p[1]], s.srgb_lut[p[2]], (float)p[3] * inv255};
     case INCR_TEX_RG_SNORM:         return {2.f * ((float)p[0] * inv255) - 1.f, 2.f * ((float)p[1] * inv255) - 1.f, 0.f, 1.f};
     case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)p[2] * inv255, (float)p[1] * inv255, 0.f, 1.f};
+    // expanded BC4 / BC5 texels (expand_bc_chain below): two 16-bit numerators over 35 x 255, or signed over 35 x 127
+    case INCR_TEX_RG16_OVER_8925:   return {(float)(c & 0xffffu) / 8925.f, (float)(c >> 16) / 8925.f, 0.f, 1.f};
+    case INCR_TEX_RG16S_OVER_4445:  return {(float)(int16_t)(c & 0xffffu) / 4445.f, (float)(int16_t)(c >> 16) / 4445.f, 0.f, 1.f};
     default:                        return {(float)p[0] * inv255, (float)p[1] * inv255, (float)p[2] * inv255, (float)p[3] * inv255};
     }
 }
@@ -292,8 +296,9 @@ static float4 SampleBilinearLevel(const Scene& s, int texIndex, uint32_t level, 
     float fx = x - x0f, fy = y - y0f;
     int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
     int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
-    float4 t00 = decode_texel_word(s, t.format, px[(size_t)y0 * W + x0]), t10 = decode_texel_word(s, t.format, px[(size_t)y0 * W + x1]);
-    float4 t01 = decode_texel_word(s, t.format, px[(size_t)y1 * W + x0]), t11 = decode_texel_word(s, t.format, px[(size_t)y1 * W + x1]);
+    const uint32_t fmt = s.texFormat[(size_t)texIndex];
+    float4 t00 = decode_texel_word(s, fmt, px[(size_t)y0 * W + x0]), t10 = decode_texel_word(s, fmt, px[(size_t)y0 * W + x1]);
+    float4 t01 = decode_texel_word(s, fmt, px[(size_t)y1 * W + x0]), t11 = decode_texel_word(s, fmt, px[(size_t)y1 * W + x1]);
     float wx0 = 1.f - fx, wy0 = 1.f - fy;
     float4 r;
     r.x = (t00.x * wx0 + t10.x * fx) * wy0 + (t01.x * wx0 + t11.x * fx) * fy;
@@ -961,13 +966,86 @@ static uint32_t srgb_encode_nearest(const float* lut, float v) {
     if (lo < 255u && (lut[lo + 1u] - v) < (v - lut[lo])) ++lo;
     return lo;
 }
+// ---- block-compressed chains at the boundary (incr_types.h formats 4-7): what the reference uploads after DirectX::Compress
+// (scene.cpp:1100, 1401).  The block layouts are those of the D3D11.3 functional spec 19.5 (BC1 colour block inside BC3; BC4 blocks for
+// BC3's alpha and for each channel of BC5).  Pinned: a BC4 / BC5 texel keeps its palette entry EXACTLY, as the
+// numerator over 7 x 5 x 255 (x 127 signed); a BC3 texel becomes 8 bits per channel, interpolants rounded to nearest.
+struct Bc4Palette { int32_t times35[8]; };          // the eight values of one BC4 block, each multiplied by 35
+static Bc4Palette bc4_palette(const uint8_t* block, bool snorm) {
+    int32_t a = block[0], b = block[1];
+    if (snorm) { a = (int8_t)block[0]; b = (int8_t)block[1]; a = std::max(a, -127); b = std::max(b, -127); }
+    Bc4Palette p;
+    p.times35[0] = 35 * a; p.times35[1] = 35 * b;
+    if (a > b) {
+        for (int k = 1; k <= 6; ++k) p.times35[1 + k] = 5 * ((7 - k) * a + k * b);          // (7 - k) / 7 a + k / 7 b
+    } else {
+        for (int k = 1; k <= 4; ++k) p.times35[1 + k] = 7 * ((5 - k) * a + k * b);          // (5 - k) / 5 a + k / 5 b
+        p.times35[6] = snorm ? -35 * 127 : 0;
+        p.times35[7] = snorm ? 35 * 127 : 35 * 255;
+    }
+    return p;
+}
+static uint32_t bc4_selector(const uint8_t* block, uint32_t texel) {                        // 3 bits per texel, little-endian, after the two endpoints
+    uint64_t v = 0; for (int k = 5; k >= 0; --k) v = (v << 8) | block[2 + k];
+    return (uint32_t)((v >> (3 * texel)) & 7u);
+}
+static void expand_bc_level(const uint8_t* blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* out) {
+    const uint32_t bw = (w + 3) / 4, bytes = format == INCR_TEX_BC4_UNORM ? 8 : 16;
+    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {
+        const uint8_t* blk = blocks + ((size_t)(y / 4) * bw + x / 4) * bytes;
+        const uint32_t texel = (y % 4) * 4 + x % 4;
+        uint32_t word = 0;
+        if (format == INCR_TEX_BC3_SRGB) {
+            const uint32_t alpha = (uint32_t)(bc4_palette(blk, false).times35[bc4_selector(blk, texel)] + 17) / 35u;
+            const uint32_t e[2] = {(uint32_t)blk[8] | ((uint32_t)blk[9] << 8), (uint32_t)blk[10] | ((uint32_t)blk[11] << 8)};
+            uint32_t rgb[2][3];
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t r5 = e[k] >> 11, g6 = (e[k] >> 5) & 63u, b5 = e[k] & 31u;
+                rgb[k][0] = (r5 << 3) | (r5 >> 2); rgb[k][1] = (g6 << 2) | (g6 >> 4); rgb[k][2] = (b5 << 3) | (b5 >> 2);
+            }
+            const uint32_t selectors = (uint32_t)blk[12] | ((uint32_t)blk[13] << 8) | ((uint32_t)blk[14] << 16) | ((uint32_t)blk[15] << 24);
+            const uint32_t sel = (selectors >> (2 * texel)) & 3u;
+            word = alpha << 24;
+            for (int ch = 0; ch < 3; ++ch) {
+                uint32_t v;
+                switch (sel) {
+                case 0: v = rgb[0][ch]; break;
+                case 1: v = rgb[1][ch]; break;
+                case 2: v = (2 * rgb[0][ch] + rgb[1][ch] + 1) / 3; break;          // BC3's colour block is always in four-colour mode
+                default: v = (rgb[0][ch] + 2 * rgb[1][ch] + 1) / 3; break;
+                }
+                word |= v << (8 * ch);
+            }
+        } else {
+            const bool snorm = format == INCR_TEX_BC5_SNORM;
+            const int32_t r = bc4_palette(blk, snorm).times35[bc4_selector(blk, texel)];
+            const int32_t g = format == INCR_TEX_BC4_UNORM ? 0 : bc4_palette(blk + 8, snorm).times35[bc4_selector(blk + 8, texel)];
+            word = ((uint32_t)r & 0xffffu) | ((uint32_t)g << 16);
+        }
+        out[(size_t)y * w + x] = word;
+    }
+}
 static void build_texture_mips(Scene& s) {
     const uint32_t nt = s.d.num_textures;
-    s.texChain.assign(nt, {}); s.texMips.assign(nt, 1u);
+    s.texChain.assign(nt, {}); s.texMips.assign(nt, 1u); s.texFormat.assign(nt, 0u);
     s.maxAnisotropy = s.d.max_anisotropy ? std::min(s.d.max_anisotropy, 16u) : 16u;
     auto dim = [](uint32_t d, uint32_t l) { return std::max(d >> l, 1u); };
     for (uint32_t i = 0; i < nt; ++i) {
         const incr_texture_desc& t = s.d.textures[i];
+        s.texFormat[i] = t.format;
+        if (t.format >= INCR_TEX_BC3_SRGB && t.format <= INCR_TEX_BC5_SNORM) {          // a compressed chain: expanded level by level, nothing generated
+            s.texMips[i] = t.mip_levels ? t.mip_levels : 1u;
+            s.texFormat[i] = t.format == INCR_TEX_BC3_SRGB ? (uint32_t)INCR_TEX_RGBA8_SRGB : (t.format == INCR_TEX_BC5_SNORM ? (uint32_t)INCR_TEX_RG16S_OVER_4445 : (uint32_t)INCR_TEX_RG16_OVER_8925);
+            size_t texels = 0; for (uint32_t l = 0; l < s.texMips[i]; ++l) texels += (size_t)dim(t.width, l) * dim(t.height, l);
+            s.texChain[i].assign(texels, 0u);
+            const uint8_t* src = t.texels; uint32_t* dst = s.texChain[i].data();
+            for (uint32_t l = 0; l < s.texMips[i]; ++l) {
+                const uint32_t w = dim(t.width, l), h = dim(t.height, l);
+                expand_bc_level(src, w, h, t.format, dst);
+                src += (size_t)((w + 3) / 4) * ((h + 3) / 4) * (t.format == INCR_TEX_BC4_UNORM ? 8 : 16); dst += (size_t)w * h;
+            }
+            continue;
+        }
         uint32_t n = 0; for (uint32_t w = t.width, h = t.height; w >= 4 && h >= 4; w >>= 1, h >>= 1) ++n;
         s.texMips[i] = n ? n : 1u;
         size_t texels = 0; for (uint32_t l = 0; l < s.texMips[i]; ++l) texels += (size_t)dim(t.width, l) * dim(t.height, l);
@@ -975,6 +1053,7 @@ static void build_texture_mips(Scene& s) {
         memcpy(s.texChain[i].data(), t.texels, (size_t)t.width * t.height * 4);
     }
     std::vector<uint8_t> have(nt, 0);
+    for (uint32_t i = 0; i < nt; ++i) have[i] = s.d.textures[i].format >= INCR_TEX_BC3_SRGB ? 1 : 0;
     for (uint32_t mi = 0; mi < s.d.num_materials; ++mi) {
         const int32_t a = s.d.materials[mi].normalTextureIndex, b = s.d.materials[mi].metallicRoughnessTextureIndex;
         if (a < 0 || b < 0 || a == b || (uint32_t)a >= nt || (uint32_t)b >= nt || have[(size_t)a] || have[(size_t)b]) continue;

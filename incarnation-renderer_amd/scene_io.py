@@ -342,7 +342,7 @@ def _bounding_sphere(pos):
     return np.array([c[0], c[1], c[2], r], dtype=f32)
 
 
-def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False, use_content_cache=False):
+def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False, use_content_cache=False, texture_cache_dir=None):
     """glTF 2.0 loader -> PackedScene: .gltf (external or `data:` buffers and images) and binary .glb (embedded BIN chunk,
     bufferView images) -- the two containers tinygltf's LoadASCIIFromFile / LoadBinaryFromFile accept (scene.cpp:113-130)."""
     import base64
@@ -441,6 +441,18 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
         src = g["textures"][texture_ref["index"]]["source"]
         key = (src, fmt)
         if key not in tex_cache:
+            # The reference's texture cache (scene.cpp:1046-1070, 1103-1115: `<cache>/<image stem>.dds`, the block-compressed mip chain
+            # DirectX::Compress wrote): when such a file exists and holds the format this slot compresses to, ITS blocks are handed over
+            # -- the texels the reference's GPU samples -- instead of the decoded image.
+            uri = g["images"][src].get("uri", "")
+            dds = os.path.join(texture_cache_dir, os.path.splitext(os.path.basename(uri))[0] + ".dds") if texture_cache_dir and uri and not uri.startswith("data:") else None
+            if dds and os.path.exists(dds):
+                from . import bc
+                image = bc.read_dds(dds)
+                slot_format = {A.TEX_RGBA8_SRGB: A.TEX_BC3_SRGB, A.TEX_RG_SNORM: A.TEX_BC5_SNORM, A.TEX_BGRA8_SWIZZLE_RG: A.TEX_BC5_UNORM, A.TEX_RGBA8_UNORM: A.TEX_BC4_UNORM}[fmt]
+                if image.format == slot_format:
+                    tex_cache[key] = s.add_texture_bc(image)
+                    return tex_cache[key]
             tex_cache[key] = s.add_texture(image_rgba(src), fmt)
         return tex_cache[key]
 

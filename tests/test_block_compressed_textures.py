@@ -184,3 +184,28 @@ def test_gpu_frames_on_compressed_textures_match_the_oracle(gpu_ctx, rt, ob, syn
     ok, same = pixel_agreement(got["target"], want["target"])
     assert ok >= 0.995 and same >= 0.95, (ok, same)
     pt.close(); osc.close(); gs.close()
+
+
+def test_loader_takes_the_reference_texture_cache(tmp_path, sio, A, bc, helmet):
+    """`<cache>/<image stem>.dds` (what the reference's LoadTexture leaves behind, scene.cpp:1103-1115) replaces the decoded image when it
+    holds the format the slot compresses to; other files are ignored."""
+    import json
+    from conftest import ROOT
+    path = os.path.join(ROOT, "assets/damaged-helmet/DamagedHelmet.gltf")
+    g = json.load(open(path))
+    m = helmet.materials[0]
+    small = lambda ti: np.ascontiguousarray(helmet.textures[ti][0][::32, ::32])          # 64 x 64 stand-ins: any valid chain will do
+    stem = lambda ti: os.path.splitext(os.path.basename(g["images"][g["textures"][ti]["source"]]["uri"]))[0]
+    gl = g["materials"][0]
+    base_t, normal_t, mr_t = gl["pbrMetallicRoughness"]["baseColorTexture"]["index"], gl["normalTexture"]["index"], gl["pbrMetallicRoughness"]["metallicRoughnessTexture"]["index"]
+    bc.write_dds(os.path.join(tmp_path, stem(base_t) + ".dds"), bc.compress(small(m.baseColorTextureIndex), A.TEX_BC3_SRGB))
+    bc.write_dds(os.path.join(tmp_path, stem(normal_t) + ".dds"), bc.compress(small(m.normalTextureIndex), A.TEX_BC5_SNORM))
+    bc.write_dds(os.path.join(tmp_path, stem(mr_t) + ".dds"), bc.compress(small(m.metallicRoughnessTextureIndex), A.TEX_BC4_UNORM))      # wrong format for the slot
+    s = sio.load_gltf(path, texture_cache_dir=str(tmp_path))
+    m2 = s.materials[0]
+    assert s.textures[m2.baseColorTextureIndex][1] == A.TEX_BC3_SRGB and s.textures[m2.baseColorTextureIndex][0].width == 64
+    assert s.textures[m2.normalTextureIndex][1] == A.TEX_BC5_SNORM
+    assert s.textures[m2.metallicRoughnessTextureIndex][1] == A.TEX_BGRA8_SWIZZLE_RG and s.textures[m2.metallicRoughnessTextureIndex][0].shape[0] == 2048
+    assert s.textures[m2.emissiveTextureIndex][1] == A.TEX_RGBA8_SRGB
+    d = s.to_desc()
+    assert d.textures[m2.baseColorTextureIndex].mip_levels == 5 and d.textures[m2.normalTextureIndex].format == A.TEX_BC5_SNORM

@@ -9,6 +9,11 @@
 
 namespace incr {
 
+// Children per node that the builder fills and the traversal tests.  8 is the product; 4 and 6 exist for the A/B measurement of narrower
+// trees under the VALU bound: same 80-byte node, the upper slots stay empty.
+#ifndef INCR_BVH_WIDTH
+#define INCR_BVH_WIDTH 8
+#endif
 // 8-wide BVH node with child boxes quantised to 8 bits relative to the node's own box (after Ylitie, Karras, Laine:
 // "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017), 80 B = 5 x dwordx4 per lane
 // for 8 children (the 4-wide float node costs 7 loads for 4 children).  Traversal on MI355X is bound by dependent

@@ -152,7 +152,7 @@ DI void node8_test(const float4 n0, const float4 n1, const float4 n2, const floa
     const uint32_t nz0 = pz ? qloz0 : qhiz0, nz1 = pz ? qloz1 : qhiz1, fz0 = pz ? qhiz0 : qloz0, fz1 = pz ? qhiz1 : qloz1;
     uint32_t hit = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < INCR_BVH_WIDTH; ++k) {
         const int j = k & 3;
         const uint32_t nxp = k < 4 ? nx0 : nx1, nyp = k < 4 ? ny0 : ny1, nzp = k < 4 ? nz0 : nz1;
         const uint32_t fxp = k < 4 ? fx0 : fx1, fyp = k < 4 ? fy0 : fy1, fzp = k < 4 ? fz0 : fz1;
@@ -269,7 +269,7 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
             // node step against 46 -- and the traversal kernels are VALU-bound.)
             uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < INCR_BVH_WIDTH; ++k) {
                 const uint32_t fill = (uint32_t)__builtin_amdgcn_sbfe((int)~inner, (uint32_t)k, 1u);      // 0 or ~0
                 const uint32_t key = ((__float_as_uint(N.tn[k]) & ~7u) | (uint32_t)k) | fill;
                 m2 = umed3(m1, m2, key);
@@ -342,7 +342,7 @@ template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravCl
         if (inner) {
             uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < INCR_BVH_WIDTH; ++k) {
                 const uint32_t fill = (uint32_t)__builtin_amdgcn_sbfe((int)~inner, (uint32_t)k, 1u);
                 const uint32_t key = ((__float_as_uint(N.tn[k]) & ~7u) | (uint32_t)k) | fill;
                 m2 = umed3(m1, m2, key);

@@ -229,8 +229,11 @@ static void collapse_to_wide(const Builder& b, size_t count, WideTree& W) {
     W.nodes.clear(); W.maxDepth = 0;
     if (count) {
         const size_t n2 = b.nodes.size();
-        constexpr float cNode = INCR_BVH_COST_NODE, cTri = INCR_BVH_COST_TRI;
-        struct Dp { float c[8]; uint8_t split[9]; bool leaf; };      // c[i], i = 1..7; split[j] = k of D(n, j) (j = 2..8), 0 = "use C(n, j - 1)"
+        // INCR_BVH_WIDTH (device_types.h): children per node the traversal tests, 8 unless an A/B build narrows the tree; a narrower node's
+        // step is cheaper (the slab tests are 0.65 of it)
+        constexpr int WIDTH = INCR_BVH_WIDTH;
+        constexpr float cNode = INCR_BVH_COST_NODE * (0.35f + 0.65f * (float)WIDTH / 8.f), cTri = INCR_BVH_COST_TRI;
+        struct Dp { float c[8]; uint8_t split[9]; uint8_t wideSplit; bool leaf; };      // wideSplit = k of D(n, WIDTH), the node's own children (split[WIDTH] may be cleared below)      // c[i], i = 1..7; split[j] = k of D(n, j) (j = 2..8), 0 = "use C(n, j - 1)"
         std::vector<Dp> dp(n2);
         for (size_t i = n2; i-- > 0;) {                              // children come after their parent in `nodes`: reverse order is bottom-up
             const Node2& nd2 = b.nodes[i]; Dp& d = dp[i];
@@ -238,7 +241,7 @@ static void collapse_to_wide(const Builder& b, size_t count, WideTree& W) {
             if (!(A >= 0.f)) A = 0.f;                                // NaN boxes
             A = std::min(A, 1e28f);                                  // keeps every sum of costs finite (<= 2^23 triangles)
             const float leafC = nd2.spanCount <= kMaxLeafTris ? A * (float)nd2.spanCount * cTri : FLT_MAX;
-            memset(d.split, 0, sizeof d.split);
+            memset(d.split, 0, sizeof d.split); d.wideSplit = 0;
             if (nd2.count) { d.leaf = true; for (int k = 1; k < 8; ++k) d.c[k] = leafC; continue; }
             const Dp& L = dp[nd2.left]; const Dp& R = dp[nd2.right];
             float D[9];
@@ -247,7 +250,8 @@ static void collapse_to_wide(const Builder& b, size_t count, WideTree& W) {
                 for (int k = 1; k < j; ++k) { if (k > 7 || j - k > 7) continue; const float c = L.c[k] + R.c[j - k]; if (c < bestC) { bestC = c; bestK = k; } }
                 D[j] = bestC; d.split[j] = (uint8_t)bestK;
             }
-            const float wide = A * cNode + D[8];
+            const float wide = A * cNode + D[WIDTH];
+            d.wideSplit = d.split[WIDTH];
             d.leaf = nd2.spanCount <= kMaxLeafTris && leafC <= wide;
             d.c[1] = std::min(leafC, wide);
             for (int j = 2; j < 8; ++j) { if (D[j] < d.c[j - 1]) d.c[j] = D[j]; else { d.c[j] = d.c[j - 1]; d.split[j] = 0; } }
@@ -277,7 +281,7 @@ static void collapse_to_wide(const Builder& b, size_t count, WideTree& W) {
             uint32_t kids[8]; int nk = 0;
             const Node2& root2 = b.nodes[it.n2];
             if (root2.count || (it.n2 == 0 && dp[0].leaf)) kids[nk++] = it.n2;      // degenerate: the whole tree is one leaf
-            else { const int k = dp[it.n2].split[8]; collect(root2.left, k, kids, nk); collect(root2.right, 8 - k, kids, nk); }
+            else { const int k = dp[it.n2].wideSplit; collect(root2.left, k, kids, nk); collect(root2.right, WIDTH - k, kids, nk); }
             auto is_leaf = [&](uint32_t x) { return dp[x].leaf; };
             BvhNode8 nd; memset(&nd, 0, sizeof nd);
             const Box& nb = b.nodes[it.n2].box;
@@ -466,7 +470,7 @@ void rebuild_top_tree(HostBvh& out, const float* meshBoxes) {
                 const Node2& x = b.nodes[it.n2];
                 uint32_t kids[8]; int nk = 0;
                 kids[nk++] = x.left; kids[nk++] = x.right;
-                while (nk < 8) {                       // open the largest inner child until the node has eight
+                while (nk < INCR_BVH_WIDTH) {          // open the largest inner child until the node has eight
                     int best = -1; float bestA = -1.f;
                     for (int k = 0; k < nk; ++k) if (!b.nodes[kids[k]].count) { const float A = box_area(b.nodes[kids[k]].box); if (A > bestA) { bestA = A; best = k; } }
                     if (best < 0) break;

@@ -180,8 +180,19 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     # (SURVEY.md 8d): visibility 8 (id + depth written), G-buffer 4 + 16, fused lighting 16 read + 8 colour rw (unfused: 3 x 24),
     # dynamic sky 4 + 4, TAA 12 + 4 (+ 4 LDR when the tonemap is fused), tonemap 4 + 4
     per_pass = None
+    iso_ms = None
     if world == 1:
         rr.set_profiling(True); rr.render(view); times = rr.pass_times(); rr.set_profiling(False)
+        if (int(packed.max_anisotropy) or 16) != 1:          # the same frame through the isotropic sampler of rounds 1-2, for comparison with their records
+            rt_mod = importlib.import_module(PKG + ".runtime")
+            rt_mod.check(ctx.lib.incr_scene_set_max_anisotropy(ctx.handle, scene.handle, 1))
+            for _ in range(2):
+                frame()
+            barrier(); t1 = time.perf_counter()
+            for _ in range(steps):
+                frame()
+            barrier(); iso_ms = (time.perf_counter() - t1) / steps * 1e3
+            rt_mod.check(ctx.lib.incr_scene_set_max_anisotropy(ctx.handle, scene.handle, int(packed.max_anisotropy)))
         bpp = {"visibility": 8, "gbuffer": 20, "deferred_lighting": 24, "sky_lighting": 24, "direct_lighting": 24, "clustered_lighting": 24,
                "dynamic_sky": 8, "environmentmap": 8, "taa_resolve": 20, "tonemap": 8, "hbao": 13}
         per_pass = {}
@@ -197,7 +208,7 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     rays = A.RayStats.from_buffer_copy(raw.tobytes()).light_shadow_rays // (steps + warmup)
     rr.close()
     alg = float(W) * H * RASTER_B_PX
-    return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world,
+    return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world, **({"ms_per_frame_isotropic_sampler": round(iso_ms, 4)} if iso_ms is not None else {}),
             "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
             "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA, material sampler anisotropic x%d"
                         % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1]), int(packed.max_anisotropy) or 16),

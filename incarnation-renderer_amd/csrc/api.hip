@@ -607,6 +607,14 @@ int incr_scene_set_sun_dir(incr_context* ctx, incr_scene* sc, const float sun_di
     return INCR_OK;
 }
 
+int incr_scene_set_max_anisotropy(incr_context* ctx, incr_scene* sc, uint32_t max_anisotropy) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!sc) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (max_anisotropy > 16u) return fail(INCR_ERR_INVALID_ARGUMENT, "max_anisotropy %u: D3D12_REQ_MAXANISOTROPY is 16", max_anisotropy);
+    sc->host.maxAnisotropy = max_anisotropy ? max_anisotropy : 16u;
+    return INCR_OK;
+}
+
 int incr_scene_texture_info(incr_context* ctx, const incr_scene* sc, uint32_t ti, uint32_t* width, uint32_t* height, uint32_t* num_mips, uint64_t* chain_texels) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!sc || ti >= sc->hostTextures.size()) return fail(INCR_ERR_INVALID_ARGUMENT, "texture index out of range");

@@ -88,7 +88,7 @@ namespace incr {
 //          to 8 bits ((n + 17) / 35).  The result is a plain INCR_TEX_RGBA8_SRGB texture.
 //   BC4 / BC5 -> EXACT: every palette entry of an 8-bit-endpoint block is a multiple of 1/35 of an endpoint step ((7 - k) e0 + k e1) / 7
 //          or ((5 - k) e0 + k e1) / 5, so the texel stores the integer numerator n over 35 x 255 = 8925 (UNORM) or 35 x 127 = 4445
-//          (SNORM; -128 reads as -127) in 16 bits per channel and the sampler divides (INCR_TEX_RG16_OVER_8925 / INCR_TEX_RG16S_OVER_4445).
+//          (SNORM; -128 reads as -127) in 16 bits per channel and the sampler scales it back (INCR_TEX_RG16_OVER_8925 / INCR_TEX_RG16S_OVER_4445, pt_device.h decode_texel).
 __device__ __forceinline__ int32_t bc4_numerator(const uint8_t* __restrict__ block, uint32_t texel, bool snorm) {      // palette value x 35
     int32_t e0 = block[0], e1 = block[1];
     if (snorm) { e0 = (int8_t)block[0]; e1 = (int8_t)block[1]; e0 = e0 < -127 ? -127 : e0; e1 = e1 < -127 ? -127 : e1; }

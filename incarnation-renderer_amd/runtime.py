@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(CSRC, "libincr_hip.so")
 EXPORTS = [
     "incr_initialize", "incr_teardown", "incr_last_error", "incr_version", "incr_device_count",
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
-    "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir",
+    "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir", "incr_scene_set_max_anisotropy",
     "incr_scene_get_info", "incr_scene_texture_info", "incr_scene_texture_download", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
     "incr_trace_rays", "incr_selftest_small_float", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines",
     # raster path
@@ -80,6 +80,7 @@ def load():
     L.incr_scene_destroy.restype = C.c_int; L.incr_scene_destroy.argtypes = [vp, vp]
     L.incr_update_bvh.restype = C.c_int; L.incr_update_bvh.argtypes = [vp, vp, vp, vp, vp, vp]
     L.incr_scene_set_sun_dir.restype = C.c_int; L.incr_scene_set_sun_dir.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.incr_scene_set_max_anisotropy.restype = C.c_int; L.incr_scene_set_max_anisotropy.argtypes = [vp, vp, u32]
     L.incr_scene_texture_info.restype = C.c_int
     L.incr_scene_texture_info.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
     L.incr_scene_texture_download.restype = C.c_int; L.incr_scene_texture_download.argtypes = [vp, vp, u32, vp, u64]

@@ -64,6 +64,8 @@ int  incr_update_bvh(incr_context* ctx, incr_scene* scene, const incr_matrix* me
                      const uint32_t* mesh_visibility, const incr_matrix* root_transform, incr_stream stream);
 /* FScene::m_sunDir (scene.cpp:1594-1655 UpdateSunDirection) -- feeds the dynamic-sky environment. */
 int  incr_scene_set_sun_dir(incr_context* ctx, incr_scene* scene, const float sun_dir[3]);
+/* MaxAnisotropy of the raster passes' material sampler (incr_scene_desc::max_anisotropy) for the frames issued from now on: 1 .. 16, 0 = 16. */
+int  incr_scene_set_max_anisotropy(incr_context* ctx, incr_scene* scene, uint32_t max_anisotropy);
 /* The device-resident mip chain of scene texture `texture_index` (all levels, level 0 first; level l is max(w >> l, 1) x
  * max(h >> l, 1) RGBA8 texels): sizes, and a copy to host memory (tests compare it with the oracle's chain). */
 int  incr_scene_texture_info(incr_context* ctx, const incr_scene* scene, uint32_t texture_index, uint32_t* width, uint32_t* height,

@@ -148,7 +148,7 @@ enum {
     INCR_TEX_BC4_UNORM        = 5, /* DXGI_FORMAT_BC4_UNORM blocks: AO, transmission, clearcoat (scene.cpp:904, 948, 971) */
     INCR_TEX_BC5_UNORM        = 6, /* DXGI_FORMAT_BC5_UNORM blocks: .r = metal, .g = roughness (scene.cpp:1163)           */
     INCR_TEX_BC5_SNORM        = 7, /* DXGI_FORMAT_BC5_SNORM blocks: normal maps (scene.cpp:1162)                          */
-    /* what the samplers see after decode (never passed in): two 16-bit numerators per texel, value = n / 8925 or n / 4445 */
+    /* what the samplers see after decode (never passed in): two 16-bit numerators per texel, value = n x float(1 / 8925) or n x float(1 / 4445) */
     INCR_TEX_RG16_OVER_8925   = 8,
     INCR_TEX_RG16S_OVER_4445  = 9
 };

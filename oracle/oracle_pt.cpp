@@ -276,8 +276,9 @@ static float4 decode_texel_word(const Scene& s, uint32_t format, uint32_t c) {
     case INCR_TEX_RG_SNORM:         return {2.f * ((float)p[0] * inv255) - 1.f, 2.f * ((float)p[1] * inv255) - 1.f, 0.f, 1.f};
     case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)p[2] * inv255, (float)p[1] * inv255, 0.f, 1.f};
     // expanded BC4 / BC5 texels (expand_bc_chain below): two 16-bit numerators over 35 x 255, or signed over 35 x 127
-    case INCR_TEX_RG16_OVER_8925:   return {(float)(c & 0xffffu) / 8925.f, (float)(c >> 16) / 8925.f, 0.f, 1.f};
-    case INCR_TEX_RG16S_OVER_4445:  return {(float)(int16_t)(c & 0xffffu) / 4445.f, (float)(int16_t)(c >> 16) / 4445.f, 0.f, 1.f};
+    //   (value = numerator x the float nearest 1 / 8925 resp. 1 / 4445: the end points come out as exactly 0, 1 and -1)
+    case INCR_TEX_RG16_OVER_8925:   { const float r = 1.f / 8925.f; return {(float)(c & 0xffffu) * r, (float)(c >> 16) * r, 0.f, 1.f}; }
+    case INCR_TEX_RG16S_OVER_4445:  { const float r = 1.f / 4445.f; return {(float)(int16_t)(c & 0xffffu) * r, (float)(int16_t)(c >> 16) * r, 0.f, 1.f}; }
     default:                        return {(float)p[0] * inv255, (float)p[1] * inv255, (float)p[2] * inv255, (float)p[3] * inv255};
     }
 }

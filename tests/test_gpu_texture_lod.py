@@ -110,3 +110,28 @@ def test_sample_grad_matches_oracle_pointwise(gpu_ctx, rt, R, sio, synth, A, ob)
     w, h, mips, chain = gs.texture_chain(0)
     assert (w, h, mips) == (2048, 2048, 10)
     osc.close(); gs.close()
+
+
+def test_max_anisotropy_setter_equals_a_scene_created_with_it(gpu_ctx, rt, R, sio, synth, A):
+    """incr_scene_set_max_anisotropy switches the material sampler of later frames: 1 = the isotropic rule, and the floor scene's grazing
+    part really depends on it."""
+    W, H = 320, 180
+    s = _floor_scene(synth, sio, R, A)
+    view = sio.FView().reset(s, aspect=W / H)
+
+    class Cfg(A.FConfig):
+        EnableTAA = False
+    frames = {}
+    for created_with in (0, 1):
+        s.max_anisotropy = created_with; s._desc = None
+        gs = gpu_ctx.create_scene(s)
+        (vc, g), = gpu_frame(rt, R, gpu_ctx, gs, view, W, H, Cfg, frames=1)
+        frames[created_with] = g["gbuffer_basecolor"].copy()
+        if created_with == 0:
+            rt.check(gpu_ctx.lib.incr_scene_set_max_anisotropy(gpu_ctx.handle, gs.handle, 1))
+            (vc, g), = gpu_frame(rt, R, gpu_ctx, gs, view, W, H, Cfg, frames=1)
+            switched = g["gbuffer_basecolor"].copy()
+            assert gpu_ctx.lib.incr_scene_set_max_anisotropy(gpu_ctx.handle, gs.handle, 17) != 0
+        gs.close()
+    np.testing.assert_array_equal(switched, frames[1])
+    assert (frames[0] != frames[1]).mean() > 0.05

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="raster: frames rendered (TAA converges over the jitter sequence)")
     ap.add_argument("--hbao", action="store_true"); ap.add_argument("--forward", action="store_true"); ap.add_argument("--viewmode", type=int, default=0)
     ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--out", default="frame.png")
+    ap.add_argument("--max-anisotropy", type=int, default=0, help="raster: MaxAnisotropy of the material sampler (0 = the reference's 16, 1 = isotropic)")
+    ap.add_argument("--block-compress", action="store_true", help="hand the textures over as block-compressed chains (bc.py's encoder)")
     ap.add_argument("--dump-hdr", default=None, help="also write the HDR surface the tonemap read as float32 [H, W, 3] .npy")
     a = ap.parse_args()
     A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io"); synth = importlib.import_module(PKG + ".synth")
@@ -90,6 +92,9 @@ def main():
         packed = synth.bistro_scale(texture_size=min(a.texture_size, 256))
     else:
         packed = sio.load_gltf(a.scene)
+    packed.max_anisotropy = a.max_anisotropy
+    if a.block_compress:
+        packed.compress_textures()
     R.generate_meshlets(packed)
 
     class Cfg(A.FConfig):

@@ -55,6 +55,50 @@ def read_png(path):
     return rows[:, 1:].reshape(h, w, 4)
 
 
+def write_exr(path, rgb):
+    """rgb: (H, W, 3) float32 -> OpenEXR 2.0 scan-line file, uncompressed, three FLOAT channels (the format a DX12 capture of the
+    reference's HDR target would be exchanged in: `tools/psnr_capture.py` reads both this and .npy)."""
+    img = np.ascontiguousarray(rgb, dtype="<f4")
+    h, w = img.shape[:2]
+
+    def attr(name, kind, data):
+        return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chans = b"".join(n + b"\0" + struct.pack("<iBxxxii", 2, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"      # FLOAT, pLinear 0, sampling 1 x 1
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = (attr("channels", "chlist", chans) + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box)
+              + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0))
+              + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    line_bytes = 3 * w * 4
+    first = 8 + len(header) + 8 * h
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 20000630, 2) + header)
+        f.write(struct.pack("<%dQ" % h, *[first + y * (8 + line_bytes) for y in range(h)]))
+        for y in range(h):
+            f.write(struct.pack("<ii", y, line_bytes) + img[y, :, 2].tobytes() + img[y, :, 1].tobytes() + img[y, :, 0].tobytes())      # channels in alphabetical order
+
+
+def read_exr(path):
+    """Inverse of write_exr for uncompressed scan-line files with FLOAT B, G, R channels."""
+    raw = open(path, "rb").read()
+    assert struct.unpack_from("<II", raw, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        e = raw.index(b"\0", pos); name = raw[pos:e].decode(); pos = e + 1
+        e = raw.index(b"\0", pos); pos = e + 1
+        n = struct.unpack_from("<i", raw, pos)[0]; attrs[name] = raw[pos + 4:pos + 4 + n]; pos += 4 + n
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    assert attrs["compression"] == b"\0" and attrs["channels"].startswith(b"B\0")
+    offsets = struct.unpack_from("<%dQ" % h, raw, pos)
+    out = np.zeros((h, w, 3), np.float32)
+    for o in offsets:
+        y, n = struct.unpack_from("<ii", raw, o)
+        row = np.frombuffer(raw, "<f4", count=3 * w, offset=o + 8).reshape(3, w)
+        out[y - y0] = row[::-1].T
+    return out
+
+
 def decode_r11g11b10(words):
     """R11G11B10_FLOAT -> float32 [..., 3]: unsigned, 5-bit exponents (bias 15), 6 / 6 / 5 mantissa bits, denormals, inf / NaN."""
     w = np.asarray(words, dtype=np.uint32)
@@ -79,7 +123,7 @@ def main():
     ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--out", default="frame.png")
     ap.add_argument("--max-anisotropy", type=int, default=0, help="raster: MaxAnisotropy of the material sampler (0 = the reference's 16, 1 = isotropic)")
     ap.add_argument("--block-compress", action="store_true", help="hand the textures over as block-compressed chains (bc.py's encoder)")
-    ap.add_argument("--dump-hdr", default=None, help="also write the HDR surface the tonemap read as float32 [H, W, 3] .npy")
+    ap.add_argument("--dump-hdr", default=None, help="also write the HDR surface the tonemap read as float32 [H, W, 3]: .npy, or OpenEXR when the name ends in .exr")
     a = ap.parse_args()
     A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io"); synth = importlib.import_module(PKG + ".synth")
     rt = importlib.import_module(PKG + ".runtime"); R = importlib.import_module(PKG + ".raster"); ibl = importlib.import_module(PKG + ".ibl")
@@ -117,7 +161,11 @@ def main():
     write_png(a.out, ldr)
     if a.dump_hdr:
         surf = A.SURFACE_PATHTRACE_HISTORY if a.mode == "pathtrace" else (A.SURFACE_TAA_ACCUMULATION if Cfg.EnableTAA else A.SURFACE_HDR_RASTER)
-        np.save(a.dump_hdr, decode_r11g11b10(hr.download(surf).view(np.uint32).reshape(-1)[: W * H].reshape(H, W)))
+        hdr = decode_r11g11b10(hr.download(surf).view(np.uint32).reshape(-1)[: W * H].reshape(H, W))
+        if a.dump_hdr.lower().endswith(".exr"):
+            write_exr(a.dump_hdr, hdr)
+        else:
+            np.save(a.dump_hdr, hdr)
     print("%s: %dx%d %s, %d rays traced, %d objects / %d lights culled in the last frame" % (a.out, W, H, a.mode, rays.total_rays(), culled_objects, culled_lights))
     hr.close(); sky.close(); ctx.free(lut); scene.close()
 

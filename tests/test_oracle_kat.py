@@ -307,3 +307,21 @@ def test_example_hdr_decoder_matches_the_oracle(ob):
     a, b = render.decode_r11g11b10(w), ob.unpack_r11g11b10(w)
     fin = np.isfinite(b)
     assert np.array_equal(a[fin], b[fin]) and (np.isnan(a) == np.isnan(b)).all() and (np.isinf(a) == np.isinf(b)).all()
+
+
+def test_example_exr_writer_round_trip(tmp_path):
+    """examples/render.py --dump-hdr x.exr: an uncompressed scan-line OpenEXR (magic 20000630, version 2, channels B G R FLOAT); the
+    reader of tools/psnr_capture.py gets the array back bit for bit, specials included."""
+    import struct, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import render
+    rng = np.random.default_rng(4)
+    img = rng.uniform(0, 60000, (7, 13, 3)).astype(np.float32)
+    img[0, 0] = [0.0, np.inf, 1e-30]; img[6, 12] = [np.nan, 65504.0, 1.0]
+    p = os.path.join(tmp_path, "t.exr")
+    render.write_exr(p, img)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<II", raw, 0) == (20000630, 2) and b"channels\0chlist\0" in raw[:64] and b"compression\0compression\0\1\0\0\0\0" in raw
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1 + 8 * 7 + 7 * (8 + 13 * 12)
+    back = render.read_exr(p)
+    np.testing.assert_array_equal(back.view(np.uint32), img.view(np.uint32))

@@ -1,5 +1,5 @@
 """PSNR of a rendered HDR frame against a capture of the reference (SURVEY.md 8c "external ground truth", 8d "Image quality"):
-both float32 [H, W, 3] arrays (.npy, or raw little-endian float32 with --res WxH) in linear radiance -- ours from
+both float32 [H, W, 3] arrays (.npy, uncompressed OpenEXR, or raw little-endian float32 with --res WxH) in linear radiance -- ours from
 `examples/render.py --dump-hdr`, the capture from a dump of the reference's pathtraceHistoryBuffer / TAA accumulation surface.
 Prints the PSNR on linear HDR clipped to [0, 65504] and on the tonemapped 8-bit image (Exposure(ev100) . ACES, tonemap.hlsl:30-59).
 
@@ -13,6 +13,11 @@ import numpy as np
 def load(path, res):
     if path.endswith(".npy"):
         return np.load(path).astype(np.float32)
+    if path.lower().endswith(".exr"):          # uncompressed scan-line OpenEXR with FLOAT R, G, B (examples/render.py --dump-hdr x.exr writes it)
+        import os, sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+        import render
+        return render.read_exr(path)
     w, h = (int(v) for v in res.lower().split("x"))
     return np.fromfile(path, dtype="<f4").reshape(h, w, -1)[..., :3]
 

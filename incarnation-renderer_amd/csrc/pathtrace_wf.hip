@@ -206,38 +206,39 @@ template <uint32_t kChunk> struct WaveChunk {
 };
 
 // ------------------------------------------------------------------------------------------------ generate
+// rgsMain's ray for list item i (pathtracing.hlsl:89-119): 8x8 pixel tile per wave -- the primary rays of a wave walk the same BVH lines;
+// samples in flight: the tile rows of sample s follow those of sample s - 1 (tilesY rows each).  false: no ray (outside the frame, or a
+// shard's padding row, whose pixel is cleared here).
+DI bool generate_lane(const PtParams& P, uint32_t i, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase, float4* rayO, float4* rayD) {
+    const uint32_t tile = (i >> 6) + tileBase, w = i & 63u;
+    const uint32_t tyv = tile / tilesX, smp = tyv / tilesY;
+    const uint32_t px = (tile - tyv * tilesX) * 8u + (w & 7u), ly = (tyv - smp * tilesY) * 8u + (w >> 3);
+    *rayO = make_float4(0.f, 0.f, 0.f, 0.f); *rayD = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (!(i < total && px < P.W && ly < P.localRows)) return false;
+    const int64_t gy = shard_global_row(P, ly);
+    if (gy < 0) { store_pixel(P, px, ly, smp, {0.f, 0.f, 0.f, 0.f}); return false; }     // shard padding row
+    const uint32_t pid = smp * P.localPixels + ly * P.W + px;
+    const uint32_t pixelIdx = (uint32_t)gy * P.W + px, sampleIdx = P.sampleIdx + smp;
+    uint32_t raygenSampleSetIdx = 0;
+    const f2 subPixelJitter = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
+    const f2 apertureSample = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
+    const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
+    *rayO = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pid));
+    *rayD = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
+    return true;
+}
+DI void store_primary(const WfBuffers& B, uint32_t slot, float4 rayO, float4 rayD) {
+    B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD;
+    B.stA[(size_t)slot * 2] = make_float4(0.f, 0.f, 0.f, 0.f); B.stA[(size_t)slot * 2 + 1] = make_float4(1.f, 1.f, 1.f, 0.f);      // payload.color, payload.attenuation
+}
 __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     for (uint32_t base = blockIdx.x * kWfBlock; base < total; base += gridDim.x * kWfBlock) {
-        const uint32_t i = base + threadIdx.x;
-        // 8x8 pixel tile per wave: the primary rays of a wave walk the same BVH lines
-        // samples in flight: the tile rows of sample s follow those of sample s - 1 (tilesY rows each)
-        const uint32_t tile = (i >> 6) + tileBase, w = i & 63u;
-        const uint32_t tyv = tile / tilesX, smp = tyv / tilesY;
-        const uint32_t px = (tile - tyv * tilesX) * 8u + (w & 7u), ly = (tyv - smp * tilesY) * 8u + (w >> 3);
-        bool valid = i < total && px < P.W && ly < P.localRows;
-        uint32_t pid = 0;
-        float4 rayO = make_float4(0.f, 0.f, 0.f, 0.f), rayD = rayO;
-        if (valid) {
-            const int64_t gy = shard_global_row(P, ly);
-            if (gy < 0) { store_pixel(P, px, ly, smp, {0.f, 0.f, 0.f, 0.f}); valid = false; }     // shard padding row
-            else {
-                pid = smp * P.localPixels + ly * P.W + px;
-                const uint32_t pixelIdx = (uint32_t)gy * P.W + px, sampleIdx = P.sampleIdx + smp;
-                uint32_t raygenSampleSetIdx = 0;      // rgsMain -- pathtracing.hlsl:89-119
-                const f2 subPixelJitter = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
-                const f2 apertureSample = SamplePoint(pixelIdx, sampleIdx, raygenSampleSetIdx, P.divSqrtN, P.divN, P.numPixels);
-                const Ray ray = GenerateCameraRay(P, {(float)px + subPixelJitter.x, (float)(uint32_t)gy + subPixelJitter.y}, apertureSample);
-                rayO = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pid));
-                rayD = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
-            }
-        }
+        float4 rayO, rayD;
+        const bool valid = generate_lane(P, base + threadIdx.x, total, tilesX, tilesY, tileBase, &rayO, &rayD);
         const uint32_t slot = block_append(valid, B.counters + 0, s_waveCount, &s_base);
-        if (valid) {
-            B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD;
-            B.stA[(size_t)slot * 2] = make_float4(0.f, 0.f, 0.f, 0.f); B.stA[(size_t)slot * 2 + 1] = make_float4(1.f, 1.f, 1.f, 0.f);      // payload.color, payload.attenuation
-        }
+        if (valid) store_primary(B, slot, rayO, rayD);
     }
 }
 
@@ -331,14 +332,8 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
 // boxes a ray overlaps cannot be hit by it.  Children are taken in the first live lane's near-to-far order; a node is entered when
 // any live ray overlaps it closer than that ray's best hit.
 static constexpr int kPacketStack = 32;              // one entry per tree level (kMaxBvhDepth = 25)
-__global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtParams P, const WfBuffers B) {
-    __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
-    uint32_t* stack = s_stack + (threadIdx.x >> 6) * kPacketStack;
-    const uint32_t total = B.counters[0];
-    const uint32_t slot = blockIdx.x * kWfBlock + threadIdx.x;
-    const bool have = slot < total;
-    f3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
-    if (have) { const float4 ro = B.extA[(size_t)slot * 2], rd = B.extA[(size_t)slot * 2 + 1]; o = {ro.x, ro.y, ro.z}; d = {rd.x, rd.y, rd.z}; }
+struct PacketHit { bool found; float best, bu, bv; uint32_t bestFlat; };
+DI PacketHit packet_closest(const PtParams& P, uint32_t* stack, bool have, f3 o, f3 d) {
     const RaySetup rs = ray_setup(o, d);
     const float tmin = 0.001f;                                      // TMin / TMax of TraceRay (common.hlsli:49-50)
     float best = 10000.0f, bu = 0.f, bv = 0.f; uint32_t bestFlat = 0xffffffffu; bool found = false;
@@ -407,7 +402,35 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtP
             }
         }
     }
-    if (have) B.hit[slot] = found ? make_uint4(bestFlat, __float_as_uint(best), __float_as_uint(bu), __float_as_uint(bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
+    return {found, best, bu, bv, bestFlat};
+}
+DI uint4 hit_record(const PacketHit& h) {
+    return h.found ? make_uint4(h.bestFlat, __float_as_uint(h.best), __float_as_uint(h.bu), __float_as_uint(h.bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
+}
+__global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtParams P, const WfBuffers B) {
+    __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
+    const uint32_t total = B.counters[0];
+    const uint32_t slot = blockIdx.x * kWfBlock + threadIdx.x;
+    const bool have = slot < total;
+    f3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
+    if (have) { const float4 ro = B.extA[(size_t)slot * 2], rd = B.extA[(size_t)slot * 2 + 1]; o = {ro.x, ro.y, ro.z}; d = {rd.x, rd.y, rd.z}; }
+    const PacketHit h = packet_closest(P, s_stack + (threadIdx.x >> 6) * kPacketStack, have, o, d);
+    if (have) B.hit[slot] = hit_record(h);
+    Counters cnt = {have ? 1u : 0u, 0, 0, 0, 0};
+    add_counters(P, cnt);
+}
+// wf_generate_kernel + wf_extend_packet_kernel in one: a lane makes its camera ray, the wave traces its tile as a packet, and only then are
+// the ray, the payload's start values and the hit appended to bounce 0's list -- the separate generate pass wrote 96 B per pixel that the
+// packet kernel read straight back (0.38 ms of a 4K frame); here those stores leave a kernel that is bound by its vector ALU.
+__global__ __launch_bounds__(kWfBlock, 6) void wf_primary_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
+    __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
+    __shared__ uint32_t s_waveCount[kWfBlock / 64];
+    __shared__ uint32_t s_base;
+    float4 rayO, rayD;
+    const bool have = generate_lane(P, blockIdx.x * kWfBlock + threadIdx.x, total, tilesX, tilesY, tileBase, &rayO, &rayD);
+    const PacketHit h = packet_closest(P, s_stack + (threadIdx.x >> 6) * kPacketStack, have, {rayO.x, rayO.y, rayO.z}, {rayD.x, rayD.y, rayD.z});
+    const uint32_t slot = block_append(have, B.counters + 0, s_waveCount, &s_base);
+    if (have) { store_primary(B, slot, rayO, rayD); B.hit[slot] = hit_record(h); }
     Counters cnt = {have ? 1u : 0u, 0, 0, 0, 0};
     add_counters(P, cnt);
 }
@@ -948,20 +971,23 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
     }
     static const bool packetPrimary = !(getenv("INCR_WF_PACKET_PRIMARY") && atoi(getenv("INCR_WF_PACKET_PRIMARY")) == 0);      // A/B hook
+    static const bool fusedPrimary = packetPrimary && !(getenv("INCR_WF_FUSED_PRIMARY") && atoi(getenv("INCR_WF_FUSED_PRIMARY")) == 0);      // A/B hook: generate inside the packet kernel
     auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
         hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
         mark(i, 0);
-        hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tilesY, tileRow[i] * tilesX); mark(i, 1);
+        if (!fusedPrimary) hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tilesY, tileRow[i] * tilesX);
+        mark(i, 1);            // (with the fused primary kernel the "generate" interval is empty and "extend" of bounce 0 holds both)
     }
     int slot = 2;
     for (int bounce = 0; bounce < 4; ++bounce) {
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (bounce == 0 && packetPrimary) hipLaunchKernelGGL(wf_extend_packet_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b);
+            if (bounce == 0 && fusedPrimary) hipLaunchKernelGGL(wf_primary_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, total[i], tilesX, tilesY, tileRow[i] * tilesX);
+            else if (bounce == 0 && packetPrimary) hipLaunchKernelGGL(wf_extend_packet_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b);
             else if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 1);

@@ -229,7 +229,7 @@ DI bool generate_lane(const PtParams& P, uint32_t i, uint32_t total, uint32_t ti
 }
 DI void store_primary(const WfBuffers& B, uint32_t slot, float4 rayO, float4 rayD) {
     B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD;
-    B.stA[(size_t)slot * 2] = make_float4(0.f, 0.f, 0.f, 0.f); B.stA[(size_t)slot * 2 + 1] = make_float4(1.f, 1.f, 1.f, 0.f);      // payload.color, payload.attenuation
+    // (payload.color = 0 and payload.attenuation = 1 of a camera ray are not stored: wf_shade_kernel knows them at bounce 0)
 }
 __global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
@@ -459,7 +459,8 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             const uint32_t ly = fast_div(lp, P.divW), px = lp - ly * P.W;
             const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px, sampleIdx = P.sampleIdx + smp;
             const uint4 h = B.hit[i];
-            const float4 c4 = stIn[(size_t)i * 2], a4 = stIn[(size_t)i * 2 + 1];
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = make_float4(1.f, 1.f, 1.f, 0.f);      // rgsMain's payload (pathtracing.hlsl:110-114): colour 0, attenuation 1
+            if (bounce > 0) { c4 = stIn[(size_t)i * 2]; a4 = stIn[(size_t)i * 2 + 1]; }
             const f3 rayD = {rd.x, rd.y, rd.z};
             color = {c4.x, c4.y, c4.z, c4.w};
             f3 attenuation = {a4.x, a4.y, a4.z};

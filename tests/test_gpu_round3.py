@@ -291,24 +291,27 @@ def test_small_float_codec_matches_the_generic_one(gpu_ctx, rt):
     assert list(out) == [0, 0, 0, 0], list(out)
 
 
-def test_bench_two_ranks_rehearsal_on_one_gpu():
-    """`python bench.py --gpus 2` end to end with render work: the N > 1 branch of bench.py (its own rank processes, interleaved
+@pytest.mark.parametrize("ranks,res", [(2, "640x360"), (3, "640x368")])
+def test_bench_ranks_rehearsal_on_one_gpu(ranks, res):
+    """`python bench.py --gpus N` end to end with render work: the N > 1 branch of bench.py (its own rank processes, interleaved
     8-row shards, the history gather + incr_unshard, 8 samples in flight, the raster row bands + the TAA band gather, the
-    max-over-ranks clock, the one JSON line) on the one GPU there is -- both ranks on GPU 0, collectives over gloo (--share-gpu).
-    The RCCL transport itself needs a second GPU; everything above it runs here."""
+    max-over-ranks clock, the one JSON line) on the one GPU there is -- all ranks on GPU 0, collectives over gloo (--share-gpu).
+    Three ranks over 368 rows: 46 row blocks and 123-row raster bands, neither a multiple of the rank count (ragged shards, the padded
+    band gather).  The RCCL transport itself needs a second GPU; everything above it runs here."""
     import json, os, subprocess, sys
     from conftest import ROOT
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "10", "--warmup", "1",
-           "--res", "640x360", "--texture-size", "64", "--no-cpu-baseline", "--spp-per-gather", "4"]
+    W, H = (int(v) for v in res.split("x"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--share-gpu", "--steps", "10", "--warmup", "1",
+           "--res", res, "--texture-size", "64", "--no-cpu-baseline", "--spp-per-gather", "4"]
     env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["n_gpus"] == ranks and d["steps"] == 10 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["samples_in_flight"] == 8 and "rehearsal" in d["config"] and "RCCL" in d["config"]["sharding"]
-    # both ranks' rays are in the total: a 640x360 frame sends 230,400 camera rays per sample
-    assert d["config"]["rays_per_step"] > 2 * 230400
+    # every rank's rays are in the total: the frame sends W x H camera rays per sample, whatever the split
+    assert d["config"]["rays_per_step"] > 2 * W * H
     ra = d["raster"]
-    assert "error" not in ra and ra["n_gpus"] == 2 and ra["ms_per_frame"] > 0 and "row bands" in ra["sharding"]
+    assert "error" not in ra and ra["n_gpus"] == ranks and ra["ms_per_frame"] > 0 and "row bands" in ra["sharding"]

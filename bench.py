@@ -483,8 +483,9 @@ def main():
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
-        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 20 launches (4 x extend / shade / shadow_gen / shadow /
-        # accumulate; bounce 0's extend makes the camera rays itself, so the "generate" interval is empty unless INCR_WF_FUSED_PRIMARY=0);
+        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 16 launches (4 x extend / shade / shadow / accumulate; bounce 0's extend
+        # makes the camera rays itself and shade sets its vertices' shadow rays up, so the "generate" and "shadow_gen" intervals are
+        # empty unless INCR_WF_FUSED_PRIMARY=0 / INCR_WF_FUSED_SHADOW_GEN=0);
         # the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
         # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
         per_kernel = {"incr::wf_generate_kernel": (prof.generate_ms, max(prof.frames, 1), rows * W * 64.0 * args.steps),

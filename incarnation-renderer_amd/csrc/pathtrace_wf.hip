@@ -435,10 +435,167 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_primary_kernel(const PtParams 
     add_counters(P, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------ shadow-ray set-up (called by shade, below)
+#ifndef INCR_WF_FUSE_SHADOW_GEN
+#define INCR_WF_FUSE_SHADOW_GEN 1          // 0: wf_shade_kernel carries neither the set-up code nor its 38 KB of LDS (A/B builds)
+#endif
+DI uint32_t nth_set_bit(uint32_t word, uint32_t j) {          // position of the j-th (0-based) set bit of `word`
+    uint32_t pos = 0u;
+#pragma unroll
+    for (uint32_t sft = 16u; sft > 0u; sft >>= 1) {
+        const uint32_t c = (uint32_t)__popc((word >> pos) & ((1u << sft) - 1u));
+        if (j >= c) { j -= c; pos += sft; }
+    }
+    return pos;
+}
+// The shared-memory scratch of the ray set-up (one workgroup = 256 list slots).
+struct ShadowGenLds {
+    uint32_t prefix[kWfBlock + 1];
+    uint32_t waveTotal[kWfBlock / 64];
+    uint32_t pid[kWfBlock];
+    uint4 mask[kWfBlock];
+    float4 pos[kWfBlock], sky[kWfBlock], nrm[kWfBlock], col[kWfBlock], att[kWfBlock];
+    float2 vyz[kWfBlock];
+    float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
+    uint32_t base;
+};
+// What a lane brings for its list slot: the vertex wf_shade_kernel made (or nothing: a miss, a slot past the list's end).
+struct ShadowGenVertex {
+    bool have; uint32_t cellLo, cellHi; uint4 req;
+    float4 pos /* .w = cellLo */, sky, nrm /* .w = roughness */, col /* basecolor, metallic */, att /* attenuation at the vertex, incoming ray direction .x */;
+    float2 vyz /* incoming ray direction .yz */;
+};
+DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          // visible after the next __syncthreads
+    if ((uint32_t)P.lightCount <= kGenLdsLights) for (uint32_t k = threadIdx.x; k < (uint32_t)P.lightCount * 5u; k += kWfBlock) S.lights[k] = P.resolvedLights[k];
+}
+// The ray set-up of one workgroup's 256 list slots (every thread of the workgroup must call it: it synchronises).  `pid` = the lane's
+// list slot.  Run by wf_shade_kernel on the vertices it has just made (the fused form: they are still in registers) or by
+// wf_shadow_gen_kernel on vertices read back from the records.
+DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, ShadowGenLds& S, uint32_t pid, const ShadowGenVertex& V) {
+    uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint32_t* const s_pid = S.pid; uint4* const s_mask = S.mask;
+    float4* const s_pos = S.pos; float4* const s_sky = S.sky; float4* const s_nrm = S.nrm; float4* const s_col = S.col; float4* const s_att = S.att;
+    float2* const s_vyz = S.vyz; float4* const s_lights = S.lights; uint32_t& s_base = S.base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
+    auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
+        if (ldsLights) load_light_resolved((const float4*)s_lights, li, light, mm); else load_light_resolved(P.resolvedLights, li, light, mm);
+    };
+    __syncthreads();          // the scratch may still be read by the workgroup's previous call (wf_shade_kernel's slot loop); also publishes S.lights
+    const bool haveVtx = V.have; const uint32_t cellLo = V.cellLo, cellHi = V.cellHi; uint4 req = V.req;
+    const float4 vpos = V.pos, vsky = V.sky, vnrm = V.nrm, vcol = V.col, vatt = V.att; const float2 vyz = V.vyz;
+    // ---- phase 1: which lights of its cell does every vertex need a shadow ray to?  One lane per (vertex, candidate light) pair:
+    //      GetDirectRadiance's NoL > 0 && any(radianceIn > 0) (lighting/common.hlsli:84-95), the request bit set in LDS
+    const uint32_t cand = haveVtx ? (cellHi - cellLo) : 0u;
+    {
+        uint32_t incl = cand;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+        if (lane == 63u) s_waveTotal[wave] = incl;
+        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
+        __syncthreads();
+        uint32_t waveBase = 0, totalCand = 0;
+#pragma unroll
+        for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; totalCand += c; }
+        s_prefix[tid] = waveBase + incl - cand;
+        if (tid == 0) s_prefix[kWfBlock] = totalCand;
+        __syncthreads();
+        uint32_t lightShadow = 0;
+        for (uint32_t c = tid; c < totalCand; c += kWfBlock) {
+            uint32_t lo = 0u, hi = kWfBlock;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= c) lo = mid; else hi = mid; }
+            const uint32_t k = c - s_prefix[lo];
+            const float4 v0 = s_pos[lo], n4 = s_nrm[lo];
+            incr_light light; float lm[16];
+            fetch_light(P.gridCellLights[__float_as_uint(v0.w) + k], light, lm);
+            if (light_setup(light, lm, true, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
+                ++lightShadow;
+                if (k < kSkySlot) atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
+            }
+        }
+        Counters cnt = {0, 0, 0, lightShadow, 0};
+        add_counters(P, cnt);
+        __syncthreads();
+        req = s_mask[tid];
+        if (haveVtx && cand) {      // the complete request mask goes back to the vertex record (accumulate counts the rays with it)
+            *(uint4*)(vertex_of(B, pid) + 5) = req;
+            if (cand > kSkySlot) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagManyLights)); }
+        }
+    }
+    const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
+    // ---- phase 2: the rays.  Exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+    __syncthreads();
+    if (lane == 63u) s_waveTotal[wave] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
+    __syncthreads();
+    s_prefix[tid] = waveBase + incl - n;
+    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
+    __syncthreads();
+    if (total == 0u) return;
+    const uint32_t base = s_base;
+    if (base + total > B.rayCap || base + total < base) {
+        // queue full: these vertices are traced by accumulate; the part of the claimed range that lies inside the queue
+        // is filled with null rays so that the traversal kernel never reads an unwritten record
+        if (n) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagInlineShadow)); }
+        for (uint32_t r = tid; r < total && base + r < B.rayCap; r += kWfBlock) {
+            B.rayQ[(size_t)(base + r) * 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+            B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(0.f, 0.f, 1.f, 0.f);
+        }
+        return;
+    }
+    if (n) ((uint32_t*)(vertex_of(B, pid) + 7))[3] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
+    for (uint32_t r = tid; r < total; r += kWfBlock) {
+        // owner vertex: the last v with s_prefix[v] <= r
+        uint32_t lo = 0u, hi = kWfBlock;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= r) lo = mid; else hi = mid; }
+        uint32_t j = r - s_prefix[lo];
+        const uint4 m = s_mask[lo];
+        const uint32_t vp = s_pid[lo];
+        uint32_t word = m.x, wbase = 0u;
+        const uint32_t c0 = (uint32_t)__popc(m.x), c1 = (uint32_t)__popc(m.y), c2 = (uint32_t)__popc(m.z);
+        if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
+        const uint32_t slot = wbase + nth_set_bit(word, j);
+        const float4 v0 = s_pos[lo];
+        const f3 origin = {v0.x, v0.y, v0.z};
+        f3 L, contribution = {0.f, 0.f, 0.f};
+        if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; L = {v4.x, v4.y, v4.z}; }      // the sky term itself is evaluated by accumulate
+        else {
+            // chsMain's light loop body for this (vertex, light): GetDirectRadiance with lightVisibility = 1 (lighting/common.hlsli:8-143),
+            // times the path attenuation -- evaluated HERE, one lane per ray, instead of once more per cell light in accumulate
+            const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
+            incr_light light; float lm[16];
+            fetch_light(li, light, lm);
+            const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
+            const f3 N = {n4.x, n4.y, n4.z};
+            const LightSample ls = light_setup(light, lm, true, origin, N);
+            L = ls.L;
+            const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
+            const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
+            contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
+        }
+        B.rayQ[(size_t)(base + r) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
+        B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
+        B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ shade
-__global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce) {
+__global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce, int fuseShadowGen) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
+    // fuseShadowGen: the shadow-ray set-up of this workgroup's vertices (shadow_gen_block) runs here, on the values still in registers,
+    // instead of in wf_shadow_gen_kernel, which read 112 B of every vertex record back
+#if INCR_WF_FUSE_SHADOW_GEN
+    __shared__ ShadowGenLds s_gen;
+    if (fuseShadowGen) shadow_gen_load_lights(P, s_gen);
+#endif
     Counters cnt = {0, 0, 0, 0, 0};
     const uint32_t count = B.counters[bounce];
     const float4* __restrict__ extIn = (bounce & 1) ? B.extB : B.extA;
@@ -449,6 +606,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
     for (uint32_t base = blockIdx.x * kWfBlock; base < count; base += gridDim.x * kWfBlock) {
         const uint32_t i = base + threadIdx.x;
         bool cont = false, haveVertex = false;
+        ShadowGenVertex SV = {};
         uint32_t pid = 0;
         float4 nextO = make_float4(0.f, 0.f, 0.f, 0.f), nextD = nextO, nextA = nextO;
         f4 color = {0.f, 0.f, 0.f, 0.f};
@@ -585,11 +743,22 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, __uint_as_float(pid));
                     *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, req3);              // the sky request; shadow_gen adds the lights'
                     vtx[7] = make_float4(rayD.x, rayD.y, rayD.z, 0.f);              // accumulate / shadow_gen need V = -rayD of the INCOMING ray
+                    if (fuseShadowGen) {
+                        SV.have = true; SV.req = make_uint4(0u, 0u, 0u, req3);
+                        if (P.directLighting && P.lightCount > 0) { SV.cellLo = P.gridCellOffsets[cell]; SV.cellHi = P.gridCellOffsets[cell + 1]; }
+                        SV.pos = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(SV.cellLo));
+                        SV.sky = make_float4(skyDir.x, skyDir.y, skyDir.z, 0.f); SV.nrm = make_float4(N.x, N.y, N.z, matInfo.roughness);
+                        SV.col = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, matInfo.metallic);
+                        SV.att = make_float4(attenV.x, attenV.y, attenV.z, rayD.x); SV.vyz = make_float2(rayD.y, rayD.z);
+                    }
                 }
             }
         }
         // (Ordering the block's continuation rays by direction octant -- a wave of the next extend launch then holds one or two octants
         // instead of eight -- was measured and dropped: extend 11.9 -> 11.8 ms per frame, the next bounce's shade 6.65 -> 6.9 ms.)
+#if INCR_WF_FUSE_SHADOW_GEN
+        if (fuseShadowGen) shadow_gen_block(P, B, bounce, s_gen, i, SV);
+#endif
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
         // the continuation ray and its attenuation go to the next bounce's list; its colour is written there by accumulate, once the
         // lights of this vertex are in
@@ -609,155 +778,30 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
 // Queue capacity is a soft limit (rayCap = 8 rays per path, four to five times what the light grid asks for on the
 // bench scenes): a workgroup whose rays do not fit flags its vertices kFlagInlineShadow and accumulate traces those
 // requests itself -- slower, same result, nothing is dropped.
-DI uint32_t nth_set_bit(uint32_t word, uint32_t j) {          // position of the j-th (0-based) set bit of `word`
-    uint32_t pos = 0u;
-#pragma unroll
-    for (uint32_t sft = 16u; sft > 0u; sft >>= 1) {
-        const uint32_t c = (uint32_t)__popc((word >> pos) & ((1u << sft) - 1u));
-        if (j >= c) { j -= c; pos += sft; }
-    }
-    return pos;
-}
 
 __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    __shared__ uint32_t s_prefix[kWfBlock + 1];
-    __shared__ uint32_t s_waveTotal[kWfBlock / 64];
-    __shared__ uint32_t s_pid[kWfBlock];
-    __shared__ uint4 s_mask[kWfBlock];
-    __shared__ float4 s_pos[kWfBlock], s_sky[kWfBlock], s_nrm[kWfBlock], s_col[kWfBlock], s_att[kWfBlock];
-    __shared__ float2 s_vyz[kWfBlock];
-    __shared__ float4 s_lights[kGenLdsLights * 5];                            // the resolved light table (pt_shade.h), when the scene's lights fit
-    __shared__ uint32_t s_base;
+    __shared__ ShadowGenLds S;
     const uint32_t count = B.counters[bounce];
     if (blockIdx.x * kWfBlock >= count) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
-    if (ldsLights) for (uint32_t k = tid; k < (uint32_t)P.lightCount * 5u; k += kWfBlock) s_lights[k] = P.resolvedLights[k];      // visible after the first __syncthreads below
-    auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
-        if (ldsLights) load_light_resolved((const float4*)s_lights, li, light, mm); else load_light_resolved(P.resolvedLights, li, light, mm);
-    };
-    const uint32_t i = blockIdx.x * kWfBlock + tid;
-    uint32_t pid = 0, cellLo = 0, cellHi = 0; bool haveVtx = false; uint4 req = make_uint4(0u, 0u, 0u, 0u);
-    // what a ray needs of its vertex goes to LDS once per vertex (position + first light-list entry of its cell, sky direction, the
-    // BRDF inputs): the rays of a vertex are spread over many lanes, and each used to walk vertex -> cell -> list offset itself
-    float4 vpos = make_float4(0.f, 0.f, 0.f, 0.f), vsky = vpos, vnrm = vpos, vcol = vpos, vatt = vpos; float2 vyz = make_float2(0.f, 0.f);
+    shadow_gen_load_lights(P, S);
+    const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
+    ShadowGenVertex V = {};
     if (i < count) {
-        pid = i;                                                                  // "path" = list slot in this kernel
         const float4* vtx = vertex_of(B, i);
         const float4 v2 = vtx[2];
         if (!(__float_as_uint(v2.w) & kFlagSkip)) {                               // a shaded hit (misses and debug views carry no vertex)
-            haveVtx = true;
-            req = *(const uint4*)(vtx + 5);
+            V.have = true;
+            V.req = *(const uint4*)(vtx + 5);
             const float4 v0 = vtx[0], v3 = vtx[3], v7 = vtx[7];
-            vsky = vtx[4]; vnrm = vtx[1];
-            if (P.directLighting && P.lightCount > 0) { const uint32_t cell = __float_as_uint(v3.w); cellLo = P.gridCellOffsets[cell]; cellHi = P.gridCellOffsets[cell + 1]; }
-            vpos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(cellLo));
-            vcol = make_float4(v2.x, v2.y, v2.z, v0.w);                        // basecolor, metallic
-            vatt = make_float4(v3.x, v3.y, v3.z, v7.x);                        // attenuation at the vertex, incoming ray direction .x
-            vyz = make_float2(v7.y, v7.z);                                     // incoming ray direction .yz
+            V.sky = vtx[4]; V.nrm = vtx[1];
+            if (P.directLighting && P.lightCount > 0) { const uint32_t cell = __float_as_uint(v3.w); V.cellLo = P.gridCellOffsets[cell]; V.cellHi = P.gridCellOffsets[cell + 1]; }
+            V.pos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(V.cellLo));
+            V.col = make_float4(v2.x, v2.y, v2.z, v0.w);                       // basecolor, metallic
+            V.att = make_float4(v3.x, v3.y, v3.z, v7.x);                       // attenuation at the vertex, incoming ray direction .x
+            V.vyz = make_float2(v7.y, v7.z);                                   // incoming ray direction .yz
         }
     }
-    // ---- phase 1: which lights of its cell does every vertex need a shadow ray to?  One lane per (vertex, candidate light) pair:
-    //      GetDirectRadiance's NoL > 0 && any(radianceIn > 0) (lighting/common.hlsli:84-95), the request bit set in LDS
-    const uint32_t cand = haveVtx ? (cellHi - cellLo) : 0u;
-    {
-        uint32_t incl = cand;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
-        if (lane == 63u) s_waveTotal[wave] = incl;
-        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
-        __syncthreads();
-        uint32_t waveBase = 0, totalCand = 0;
-#pragma unroll
-        for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; totalCand += c; }
-        s_prefix[tid] = waveBase + incl - cand;
-        if (tid == 0) s_prefix[kWfBlock] = totalCand;
-        __syncthreads();
-        uint32_t lightShadow = 0;
-        for (uint32_t c = tid; c < totalCand; c += kWfBlock) {
-            uint32_t lo = 0u, hi = kWfBlock;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= c) lo = mid; else hi = mid; }
-            const uint32_t k = c - s_prefix[lo];
-            const float4 v0 = s_pos[lo], n4 = s_nrm[lo];
-            incr_light light; float lm[16];
-            fetch_light(P.gridCellLights[__float_as_uint(v0.w) + k], light, lm);
-            if (light_setup(light, lm, true, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
-                ++lightShadow;
-                if (k < kSkySlot) atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
-            }
-        }
-        Counters cnt = {0, 0, 0, lightShadow, 0};
-        add_counters(P, cnt);
-        __syncthreads();
-        req = s_mask[tid];
-        if (haveVtx && cand) {      // the complete request mask goes back to the vertex record (accumulate counts the rays with it)
-            *(uint4*)(vertex_of(B, pid) + 5) = req;
-            if (cand > kSkySlot) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagManyLights)); }
-        }
-    }
-    const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
-    // ---- phase 2: the rays.  Exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
-    uint32_t incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
-    __syncthreads();
-    if (lane == 63u) s_waveTotal[wave] = incl;
-    __syncthreads();
-    uint32_t waveBase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
-    __syncthreads();
-    s_prefix[tid] = waveBase + incl - n;
-    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
-    __syncthreads();
-    if (total == 0u) return;
-    const uint32_t base = s_base;
-    if (base + total > B.rayCap || base + total < base) {
-        // queue full: these vertices are traced by accumulate; the part of the claimed range that lies inside the queue
-        // is filled with null rays so that the traversal kernel never reads an unwritten record
-        if (n) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagInlineShadow)); }
-        for (uint32_t r = tid; r < total && base + r < B.rayCap; r += kWfBlock) {
-            B.rayQ[(size_t)(base + r) * 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-            B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(0.f, 0.f, 1.f, 0.f);
-        }
-        return;
-    }
-    if (n) ((uint32_t*)(vertex_of(B, pid) + 7))[3] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
-    for (uint32_t r = tid; r < total; r += kWfBlock) {
-        // owner vertex: the last v with s_prefix[v] <= r
-        uint32_t lo = 0u, hi = kWfBlock;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= r) lo = mid; else hi = mid; }
-        uint32_t j = r - s_prefix[lo];
-        const uint4 m = s_mask[lo];
-        const uint32_t vp = s_pid[lo];
-        uint32_t word = m.x, wbase = 0u;
-        const uint32_t c0 = (uint32_t)__popc(m.x), c1 = (uint32_t)__popc(m.y), c2 = (uint32_t)__popc(m.z);
-        if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
-        const uint32_t slot = wbase + nth_set_bit(word, j);
-        const float4 v0 = s_pos[lo];
-        const f3 origin = {v0.x, v0.y, v0.z};
-        f3 L, contribution = {0.f, 0.f, 0.f};
-        if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; L = {v4.x, v4.y, v4.z}; }      // the sky term itself is evaluated by accumulate
-        else {
-            // chsMain's light loop body for this (vertex, light): GetDirectRadiance with lightVisibility = 1 (lighting/common.hlsli:8-143),
-            // times the path attenuation -- evaluated HERE, one lane per ray, instead of once more per cell light in accumulate
-            const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
-            incr_light light; float lm[16];
-            fetch_light(li, light, lm);
-            const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
-            const f3 N = {n4.x, n4.y, n4.z};
-            const LightSample ls = light_setup(light, lm, true, origin, N);
-            L = ls.L;
-            const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
-            const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
-            contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
-        }
-        B.rayQ[(size_t)(base + r) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
-        B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
-        B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
-    }
+    shadow_gen_block(P, B, bounce, S, i, V);
 }
 
 // Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray zeroes the
@@ -972,6 +1016,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
     }
     static const bool packetPrimary = !(getenv("INCR_WF_PACKET_PRIMARY") && atoi(getenv("INCR_WF_PACKET_PRIMARY")) == 0);      // A/B hook
+    static const bool fusedShadowGen = INCR_WF_FUSE_SHADOW_GEN && !(getenv("INCR_WF_FUSED_SHADOW_GEN") && atoi(getenv("INCR_WF_FUSED_SHADOW_GEN")) == 0);      // A/B hook: the shadow-ray set-up inside wf_shade_kernel
+    const int fuseGen = (fusedShadowGen && p->viewmode < 2) ? 1 : 0;
     static const bool fusedPrimary = packetPrimary && !(getenv("INCR_WF_FUSED_PRIMARY") && atoi(getenv("INCR_WF_FUSED_PRIMARY")) == 0);      // A/B hook: generate inside the packet kernel
     auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
@@ -991,13 +1037,14 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             else if (bounce == 0 && packetPrimary) hipLaunchKernelGGL(wf_extend_packet_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b);
             else if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
             mark(i, slot);
-            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 1);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen); mark(i, slot + 1);
         }
         if (p->viewmode >= 2) { slot += 2; break; }            // VIEWMODE >= 2 paths end at the first hit
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 2);
+            if (!fuseGen) hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce);
+            mark(i, slot + 2);
             if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
             mark(i, slot + 3);
             hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);

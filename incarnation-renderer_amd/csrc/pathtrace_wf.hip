@@ -85,7 +85,7 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
 }
 static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved records shadow_gen keeps in LDS (10 KB)
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
-static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u;
+static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
 // Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
 // items: 44.9 / 44.5 / 45.5 / 46.3 / 51.4 / 55.0 / 58.6 -- with 8192 persistent waves a 512-item chunk is a quarter of a
@@ -116,11 +116,15 @@ static constexpr int kCursorBase = 16, kRayCountBase = 32;
 // lives at the ray's slot.  Every kernel of a bounce walks the list in order, so all of these are coalesced streams; in round 1
 // they were arrays indexed by pixel id, which the list order follows only in bounce 0 (shade ran 1.8x slower per hit on bounces
 // 1-3).  Only the final pixel store is a scatter.
-// vertex record: 8 float4 per list slot
-//   [0] hitPos.xyz, metallic   [1] N.xyz, roughness   [2] basecolor.xyz, flags   [3] attenuation at the vertex .xyz, cell
-//   [4] skyDir.xyz, path id    [5] request mask (4 x u32): the shadow rays shade asks for
-//   [6] payload.color .xyz so far, slot of the continuation ray in the next bounce's list (0xffffffff: the path ends here)
-//   [7] incoming ray direction .xyz, index of the vertex's first queued shadow ray (written by shadow_gen)
+// vertex record: 8 float4 per list slot.  The first three are all wf_accumulate_kernel reads of a vertex whose shadow rays went through
+// the queue (the usual case: every ray's radiance is in its rayC record); the other five are written and read only when something has
+// to be re-evaluated per vertex (flags kFlagInlineShadow / kFlagManyLights / kFlagFullRecord, or the stand-alone wf_shadow_gen_kernel).
+//   [kVColor] payload.color .xyz so far, slot of the continuation ray in the next bounce's list (0xffffffff: the path ends here)
+//   [kVMask]  request mask (4 x u32): the shadow rays of this vertex, bit 127 = the sky sample
+//   [kVMeta]  flags, path id, index of the vertex's first queued shadow ray, light-grid cell
+//   [kVPos] hitPos.xyz, metallic   [kVNrm] N.xyz, roughness   [kVBase] basecolor.xyz, incoming ray direction .x
+//   [kVAtt] attenuation at the vertex .xyz, incoming ray direction .y   [kVSky] skyDir.xyz, incoming ray direction .z
+enum : int { kVColor = 0, kVMask = 1, kVMeta = 2, kVPos = 3, kVNrm = 4, kVBase = 5, kVAtt = 6, kVSky = 7 };
 DI float4* vertex_of(const WfBuffers& B, uint32_t slot) { return B.vertex + (size_t)slot * 8; }
 
 DI void add_counters(const PtParams& P, const Counters& cnt) {
@@ -471,7 +475,10 @@ DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          //
 // The ray set-up of one workgroup's 256 list slots (every thread of the workgroup must call it: it synchronises).  `pid` = the lane's
 // list slot.  Run by wf_shade_kernel on the vertices it has just made (the fused form: they are still in registers) or by
 // wf_shadow_gen_kernel on vertices read back from the records.
-DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, ShadowGenLds& S, uint32_t pid, const ShadowGenVertex& V) {
+// Returns what the caller files in the lane's vertex record: the complete request mask, kFlagManyLights / kFlagInlineShadow, and the index of
+// the vertex's first queued ray.
+struct ShadowGenResult { uint4 req; uint32_t flags, rayBase; };
+DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, ShadowGenLds& S, uint32_t pid, const ShadowGenVertex& V) {
     uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint32_t* const s_pid = S.pid; uint4* const s_mask = S.mask;
     float4* const s_pos = S.pos; float4* const s_sky = S.sky; float4* const s_nrm = S.nrm; float4* const s_col = S.col; float4* const s_att = S.att;
     float2* const s_vyz = S.vyz; float4* const s_lights = S.lights; uint32_t& s_base = S.base;
@@ -482,6 +489,7 @@ DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, Shad
     };
     __syncthreads();          // the scratch may still be read by the workgroup's previous call (wf_shade_kernel's slot loop); also publishes S.lights
     const bool haveVtx = V.have; const uint32_t cellLo = V.cellLo, cellHi = V.cellHi; uint4 req = V.req;
+    ShadowGenResult out = {req, 0u, 0u};
     const float4 vpos = V.pos, vsky = V.sky, vnrm = V.nrm, vcol = V.col, vatt = V.att; const float2 vyz = V.vyz;
     // ---- phase 1: which lights of its cell does every vertex need a shadow ray to?  One lane per (vertex, candidate light) pair:
     //      GetDirectRadiance's NoL > 0 && any(radianceIn > 0) (lighting/common.hlsli:84-95), the request bit set in LDS
@@ -516,12 +524,10 @@ DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, Shad
         Counters cnt = {0, 0, 0, lightShadow, 0};
         add_counters(P, cnt);
         __syncthreads();
-        req = s_mask[tid];
-        if (haveVtx && cand) {      // the complete request mask goes back to the vertex record (accumulate counts the rays with it)
-            *(uint4*)(vertex_of(B, pid) + 5) = req;
-            if (cand > kSkySlot) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagManyLights)); }
-        }
+        req = s_mask[tid];          // the complete request mask (accumulate counts the rays with it)
+        if (haveVtx && cand > kSkySlot) out.flags |= kFlagManyLights;
     }
+    out.req = req;
     const uint32_t n = (uint32_t)(__popc(req.x) + __popc(req.y) + __popc(req.z) + __popc(req.w));
     // ---- phase 2: the rays.  Exclusive scan of n over the workgroup: wave scan by shuffles, then the four wave totals
     uint32_t incl = n;
@@ -537,19 +543,19 @@ DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, Shad
     s_prefix[tid] = waveBase + incl - n;
     if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
     __syncthreads();
-    if (total == 0u) return;
+    if (total == 0u) return out;
     const uint32_t base = s_base;
     if (base + total > B.rayCap || base + total < base) {
         // queue full: these vertices are traced by accumulate; the part of the claimed range that lies inside the queue
         // is filled with null rays so that the traversal kernel never reads an unwritten record
-        if (n) { float4* v2 = vertex_of(B, pid) + 2; const float4 v = *v2; *v2 = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(v.w) | kFlagInlineShadow)); }
+        if (n) out.flags |= kFlagInlineShadow;
         for (uint32_t r = tid; r < total && base + r < B.rayCap; r += kWfBlock) {
             B.rayQ[(size_t)(base + r) * 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
             B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(0.f, 0.f, 1.f, 0.f);
         }
-        return;
+        return out;
     }
-    if (n) ((uint32_t*)(vertex_of(B, pid) + 7))[3] = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
+    if (n) out.rayBase = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
     for (uint32_t r = tid; r < total; r += kWfBlock) {
         // owner vertex: the last v with s_prefix[v] <= r
         uint32_t lo = 0u, hi = kWfBlock;
@@ -565,8 +571,18 @@ DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, Shad
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
         f3 L, contribution = {0.f, 0.f, 0.f};
-        if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; L = {v4.x, v4.y, v4.z}; }      // the sky term itself is evaluated by accumulate
-        else {
+        if (slot == kSkySlot) {
+            // chsMain's sky sample (pathtracing.hlsl:239-244): GetSkyRadiance with lightVisibility = 1 (lighting/common.hlsli:145-202) over the
+            // pdf, times the path attenuation -- evaluated HERE like the lights', so that accumulate only sums
+            const float4 v4 = s_sky[lo], n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
+            L = {v4.x, v4.y, v4.z};
+            const f3 N = {n4.x, n4.y, n4.z};
+            MatProps matInfo = {};
+            matInfo.basecolor = mk3(c4.x, c4.y, c4.z); matInfo.metallic = c4.w; matInfo.roughness = n4.w;
+            const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, L);
+            const f3 radianceOut = sky_shade(skyRadianceIn, L, saturate(dot(N, L)), matInfo, N, -mk3(a4.w, vyz2.x, vyz2.y));
+            contribution = mk3(a4.x, a4.y, a4.z) * (radianceOut / CosineHemispherePdf(L.z));
+        } else {
             // chsMain's light loop body for this (vertex, light): GetDirectRadiance with lightVisibility = 1 (lighting/common.hlsli:8-143),
             // times the path attenuation -- evaluated HERE, one lane per ray, instead of once more per cell light in accumulate
             const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
@@ -584,6 +600,7 @@ DI void shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, Shad
         B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
         B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
     }
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
         const uint32_t i = base + threadIdx.x;
         bool cont = false, haveVertex = false;
         ShadowGenVertex SV = {};
-        uint32_t pid = 0;
+        uint32_t pid = 0, vflags = 0u, vcell = 0u;
         float4 nextO = make_float4(0.f, 0.f, 0.f, 0.f), nextD = nextO, nextA = nextO;
         f4 color = {0.f, 0.f, 0.f, 0.f};
         if (i < count) {
@@ -628,8 +645,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 const f3 add = sky_miss_add(P, attenuation, rayD);
                 color.x += add.x; color.y += add.y; color.z += add.z;
                 store_pixel(P, px, ly, smp, color);
-                vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
-                *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
+                vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
             } else {
                 const f3 rayO = {ro.x, ro.y, ro.z};
                 const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
@@ -667,8 +683,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 else if (P.viewmode == 5) { color = {matInfo.emissive.x, matInfo.emissive.y, matInfo.emissive.z, 1.f}; done = true; }
                 if (done) {
                     store_pixel(P, px, ly, smp, color);
-                    vtx[2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kFlagSkip));
-                    *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, 0u);
+                    vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
                 } else {
                     const f3 add = attenuation * matInfo.emissive * 20000;
                     color.x += add.x; color.y += add.y; color.z += add.z;
@@ -736,34 +751,42 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     }
                     if (!cont) flags |= kFlagTerminate;
                     haveVertex = true;
-                    vtx[0] = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, matInfo.metallic);
-                    vtx[1] = make_float4(N.x, N.y, N.z, matInfo.roughness);
-                    vtx[2] = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, __uint_as_float(flags));
-                    vtx[3] = make_float4(attenV.x, attenV.y, attenV.z, __uint_as_float(cell));
-                    vtx[4] = make_float4(skyDir.x, skyDir.y, skyDir.z, __uint_as_float(pid));
-                    *(uint4*)(vtx + 5) = make_uint4(0u, 0u, 0u, req3);              // the sky request; shadow_gen adds the lights'
-                    vtx[7] = make_float4(rayD.x, rayD.y, rayD.z, 0.f);              // accumulate / shadow_gen need V = -rayD of the INCOMING ray
-                    if (fuseShadowGen) {
-                        SV.have = true; SV.req = make_uint4(0u, 0u, 0u, req3);
-                        if (P.directLighting && P.lightCount > 0) { SV.cellLo = P.gridCellOffsets[cell]; SV.cellHi = P.gridCellOffsets[cell + 1]; }
-                        SV.pos = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(SV.cellLo));
-                        SV.sky = make_float4(skyDir.x, skyDir.y, skyDir.z, 0.f); SV.nrm = make_float4(N.x, N.y, N.z, matInfo.roughness);
-                        SV.col = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, matInfo.metallic);
-                        SV.att = make_float4(attenV.x, attenV.y, attenV.z, rayD.x); SV.vyz = make_float2(rayD.y, rayD.z);
-                    }
+                    // the vertex: its fields stay in registers for the shadow-ray set-up below; the record gets them there
+                    vflags = flags; vcell = cell;
+                    if (!finiteAtt || !(CosineHemispherePdf(skyDir.z) > 0.f)) vflags |= kFlagFullRecord;      // the sky term is not "+ 0" when unrequested or occluded: accumulate re-evaluates it
+                    SV.have = true; SV.req = make_uint4(0u, 0u, 0u, req3);
+                    if (P.directLighting && P.lightCount > 0) { SV.cellLo = P.gridCellOffsets[cell]; SV.cellHi = P.gridCellOffsets[cell + 1]; }
+                    SV.pos = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(SV.cellLo));
+                    SV.sky = make_float4(skyDir.x, skyDir.y, skyDir.z, 0.f); SV.nrm = make_float4(N.x, N.y, N.z, matInfo.roughness);
+                    SV.col = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, matInfo.metallic);
+                    SV.att = make_float4(attenV.x, attenV.y, attenV.z, rayD.x); SV.vyz = make_float2(rayD.y, rayD.z);
                 }
             }
         }
         // (Ordering the block's continuation rays by direction octant -- a wave of the next extend launch then holds one or two octants
         // instead of eight -- was measured and dropped: extend 11.9 -> 11.8 ms per frame, the next bounce's shade 6.65 -> 6.9 ms.)
+        ShadowGenResult sg = {SV.req, 0u, 0u};
 #if INCR_WF_FUSE_SHADOW_GEN
-        if (fuseShadowGen) shadow_gen_block(P, B, bounce, s_gen, i, SV);
+        if (fuseShadowGen) sg = shadow_gen_block(P, B, bounce, s_gen, i, SV);
 #endif
+        if (haveVertex) {
+            float4* vtx = vertex_of(B, i);
+            const uint32_t f = vflags | sg.flags;
+            *(uint4*)(vtx + kVMask) = sg.req;
+            *(uint4*)(vtx + kVMeta) = make_uint4(f, pid, sg.rayBase, vcell);
+            if (!fuseShadowGen || (f & (kFlagInlineShadow | kFlagManyLights | kFlagFullRecord))) {       // someone re-evaluates this vertex: the rest of the record
+                vtx[kVPos] = make_float4(SV.pos.x, SV.pos.y, SV.pos.z, SV.col.w);
+                vtx[kVNrm] = SV.nrm;
+                vtx[kVBase] = make_float4(SV.col.x, SV.col.y, SV.col.z, SV.att.w);
+                vtx[kVAtt] = make_float4(SV.att.x, SV.att.y, SV.att.z, SV.vyz.x);
+                vtx[kVSky] = make_float4(SV.sky.x, SV.sky.y, SV.sky.z, SV.vyz.y);
+            }
+        }
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
         // the continuation ray and its attenuation go to the next bounce's list; its colour is written there by accumulate, once the
         // lights of this vertex are in
         if (cont) { extOut[(size_t)slot * 2] = nextO; extOut[(size_t)slot * 2 + 1] = nextD; stOut[(size_t)slot * 2 + 1] = nextA; }
-        if (haveVertex) vertex_of(B, i)[6] = make_float4(color.x, color.y, color.z, __uint_as_float(cont ? slot : 0xffffffffu));
+        if (haveVertex) vertex_of(B, i)[kVColor] = make_float4(color.x, color.y, color.z, __uint_as_float(cont ? slot : 0xffffffffu));
     }
     add_counters(P, cnt);
 }
@@ -786,22 +809,29 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
     shadow_gen_load_lights(P, S);
     const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
     ShadowGenVertex V = {};
+    uint4 meta = make_uint4(kFlagSkip, 0u, 0u, 0u);
     if (i < count) {
         const float4* vtx = vertex_of(B, i);
-        const float4 v2 = vtx[2];
-        if (!(__float_as_uint(v2.w) & kFlagSkip)) {                               // a shaded hit (misses and debug views carry no vertex)
+        meta = *(const uint4*)(vtx + kVMeta);
+        if (!(meta.x & kFlagSkip)) {                                              // a shaded hit (misses and debug views carry no vertex)
             V.have = true;
-            V.req = *(const uint4*)(vtx + 5);
-            const float4 v0 = vtx[0], v3 = vtx[3], v7 = vtx[7];
-            V.sky = vtx[4]; V.nrm = vtx[1];
-            if (P.directLighting && P.lightCount > 0) { const uint32_t cell = __float_as_uint(v3.w); V.cellLo = P.gridCellOffsets[cell]; V.cellHi = P.gridCellOffsets[cell + 1]; }
+            V.req = *(const uint4*)(vtx + kVMask);
+            const float4 v0 = vtx[kVPos], vb = vtx[kVBase], va = vtx[kVAtt], vs = vtx[kVSky];
+            V.nrm = vtx[kVNrm];
+            if (P.directLighting && P.lightCount > 0) { V.cellLo = P.gridCellOffsets[meta.w]; V.cellHi = P.gridCellOffsets[meta.w + 1]; }
             V.pos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(V.cellLo));
-            V.col = make_float4(v2.x, v2.y, v2.z, v0.w);                       // basecolor, metallic
-            V.att = make_float4(v3.x, v3.y, v3.z, v7.x);                       // attenuation at the vertex, incoming ray direction .x
-            V.vyz = make_float2(v7.y, v7.z);                                   // incoming ray direction .yz
+            V.sky = make_float4(vs.x, vs.y, vs.z, 0.f);
+            V.col = make_float4(vb.x, vb.y, vb.z, v0.w);                       // basecolor, metallic
+            V.att = make_float4(va.x, va.y, va.z, vb.w);                       // attenuation at the vertex, incoming ray direction .x
+            V.vyz = make_float2(va.w, vs.w);                                   // incoming ray direction .yz
         }
     }
-    shadow_gen_block(P, B, bounce, S, i, V);
+    const ShadowGenResult r = shadow_gen_block(P, B, bounce, S, i, V);
+    if (V.have) {
+        float4* vtx = vertex_of(B, i);
+        *(uint4*)(vtx + kVMask) = r.req;
+        *(uint4*)(vtx + kVMeta) = make_uint4(meta.x | r.flags, meta.y, r.rayBase, meta.w);
+    }
 }
 
 // Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray zeroes the
@@ -856,28 +886,21 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
     float4* stOut = (bounce & 1) ? B.stA : B.stB;
     for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
         const float4* vtx = vertex_of(B, i);
-        const float4 v2 = vtx[2];
-        const uint32_t flags = __float_as_uint(v2.w);
+        const uint4 meta = *(const uint4*)(vtx + kVMeta);
+        const uint32_t flags = meta.x;
         if (flags & kFlagSkip) continue;
-        const bool inlineShadow = flags & kFlagInlineShadow;
-        const float4 v0 = vtx[0], v1 = vtx[1], v3 = vtx[3], v4 = vtx[4];
-        const uint4 vis = *(const uint4*)(vtx + 5);
-        const float4 v6 = vtx[6], v7 = vtx[7];
-        const uint32_t pid = __float_as_uint(v4.w), nextSlot = __float_as_uint(v6.w);
+        const float4 v6 = vtx[kVColor];
+        const uint4 vis = *(const uint4*)(vtx + kVMask);
+        const uint32_t pid = meta.y, rayBase = meta.z, cell = meta.w, nextSlot = __float_as_uint(v6.w);
         f4 color = {v6.x, v6.y, v6.z, 0.f};                       // payload.color.w is 0 on every path that reaches a light loop
-        const f3 hitPosition = {v0.x, v0.y, v0.z}, N = {v1.x, v1.y, v1.z}, basecolor = {v2.x, v2.y, v2.z}, attenV = {v3.x, v3.y, v3.z};
-        const f3 skyDir = {v4.x, v4.y, v4.z};
-        const f3 V = -mk3(v7.x, v7.y, v7.z);
-        MatProps matInfo = {};
-        matInfo.basecolor = basecolor; matInfo.metallic = v0.w; matInfo.roughness = v1.w;
-        const uint32_t cell = __float_as_uint(v3.w);
         // the vertex's queued rays: [rayBase, rayBase + popc(request mask)) in ascending slot order, the sky ray (slot 127) last;
-        // each record carries attenuation * GetDirectRadiance of its light (wf_shadow_gen_kernel) and the visibility the shadow kernel left
+        // each record carries attenuation * GetDirectRadiance of its light -- for the sky ray attenuation * GetSkyRadiance / pdf
+        // (shadow_gen_block) -- and the visibility the shadow kernel left
         const uint32_t requested = (uint32_t)(__popc(vis.x) + __popc(vis.y) + __popc(vis.z) + __popc(vis.w));
         const bool skyRequested = vis.w >> 31;
-        const uint32_t rayBase = __float_as_uint(v7.w);
         bool skyVisible = skyRequested;
         uint32_t visWord = 0u;        // debug_hit_chain word 2: which of the vertex's shadow queries came back unoccluded (sum of (loop index + 1) * 0x9E3779B1)
+        const bool perVertex = flags & (kFlagInlineShadow | kFlagManyLights | kFlagFullRecord);
         if (P.hitChain && !(flags & (kFlagInlineShadow | kFlagManyLights)) && P.directLighting && P.lightCount > 0) {
             const uint32_t lo = P.gridCellOffsets[cell];
             uint32_t rank = 0;
@@ -888,52 +911,66 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
                 ++rank;
             }
         }
-        if (!(flags & (kFlagInlineShadow | kFlagManyLights))) {
-            // chsMain's light loop (pathtracing.hlsl:230-236) in its order: lights that asked for no ray add exactly attenuation * 0,
-            // occluded ones too; the others add the value computed for their ray
+        if (!perVertex) {
+            // chsMain's light loop (pathtracing.hlsl:230-236) and sky sample (:239-244) in their order: lights that asked for no ray add
+            // exactly attenuation * 0, occluded ones too, and so does a sky sample that is unrequested or occluded (finite attenuation and
+            // pdf > 0: wf_shade_kernel flags the vertices where that does not hold); the others add the value computed for their ray
             const uint32_t lights = requested - (skyRequested ? 1u : 0u);
             for (uint32_t r = 0; r < lights; ++r) {
                 const float4 c = B.rayC[rayBase + r];
                 if (c.w != 0.f) { color.x += c.x; color.y += c.y; color.z += c.z; }
             }
-            if (skyRequested) skyVisible = B.rayC[rayBase + lights].w != 0.f;
-        } else if (P.directLighting && P.lightCount > 0) {
-            // slow path: the ray queue was full for this vertex (every request is traced here), or its cell lists more than 127 lights
-            // (the first 127 went through the queue, the rest is traced here)
-            const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
-            const uint32_t n = hi - lo;
-            uint32_t rank = 0;
-            for (uint32_t k = 0; k < n; ++k) {
-                incr_light light; const float* m; bool haveT;
-                load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
-                const LightSample s = light_setup(light, m, haveT, hitPosition, N);
-                f3 radianceOut = {0.f, 0.f, 0.f};
-                bool visible = false;
-                if (k < kSkySlot && !inlineShadow) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
-                    const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
-                    if ((w >> (k & 31u)) & 1u) { visible = B.rayC[rayBase + rank].w != 0.f; ++rank; }
-                } else if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
-                if (s.needsShadow && visible) visWord += (P.gridCellLights[lo + k] + 1u) * 0x9E3779B1u;
-                if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
-                const f3 r = attenV * radianceOut;
-                color.x += r.x; color.y += r.y; color.z += r.z;
+            if (skyRequested) {
+                const float4 c = B.rayC[rayBase + lights];
+                skyVisible = c.w != 0.f;
+                if (skyVisible) { color.x += c.x; color.y += c.y; color.z += c.z; }
+            }
+        } else {
+            // per-vertex evaluation out of the full record: the ray queue was full for this vertex (every request is traced here), its cell
+            // lists more than 127 lights (the first 127 went through the queue, the rest is traced here), or "+ 0" is not exact for it
+            const bool inlineShadow = flags & kFlagInlineShadow;
+            const float4 v0 = vtx[kVPos], v1 = vtx[kVNrm], vb = vtx[kVBase], va = vtx[kVAtt], vs = vtx[kVSky];
+            const f3 hitPosition = {v0.x, v0.y, v0.z}, N = {v1.x, v1.y, v1.z}, basecolor = {vb.x, vb.y, vb.z}, attenV = {va.x, va.y, va.z};
+            const f3 skyDir = {vs.x, vs.y, vs.z};
+            const f3 V = -mk3(vb.w, va.w, vs.w);
+            MatProps matInfo = {};
+            matInfo.basecolor = basecolor; matInfo.metallic = v0.w; matInfo.roughness = v1.w;
+            if (P.directLighting && P.lightCount > 0) {
+                const uint32_t lo = P.gridCellOffsets[cell], hi = P.gridCellOffsets[cell + 1];
+                const uint32_t n = hi - lo;
+                uint32_t rank = 0;
+                if (flags & (kFlagInlineShadow | kFlagManyLights)) visWord = 0u;
+                for (uint32_t k = 0; k < n; ++k) {
+                    incr_light light; const float* m; bool haveT;
+                    load_light(P, (int)P.gridCellLights[lo + k], light, m, haveT);
+                    const LightSample s = light_setup(light, m, haveT, hitPosition, N);
+                    f3 radianceOut = {0.f, 0.f, 0.f};
+                    bool visible = false;
+                    if (k < kSkySlot && !inlineShadow) {          // selects, not words[k >> 5]: a dynamically indexed array would live in scratch
+                        const uint32_t w = k < 32u ? vis.x : (k < 64u ? vis.y : (k < 96u ? vis.z : vis.w));
+                        if ((w >> (k & 31u)) & 1u) { visible = B.rayC[rayBase + rank].w != 0.f; ++rank; }
+                    } else if (s.needsShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; visible = !trace_any(P, ps, hitPosition, s.L, 0.1f, 1000.f); }
+                    if ((flags & (kFlagInlineShadow | kFlagManyLights)) && s.needsShadow && visible) visWord += (P.gridCellLights[lo + k] + 1u) * 0x9E3779B1u;
+                    if (s.needsShadow && visible) radianceOut = light_shade(s, matInfo.basecolor, matInfo.metallic, matInfo.roughness, N, V);
+                    const f3 r = attenV * radianceOut;
+                    color.x += r.x; color.y += r.y; color.z += r.z;
+                }
             }
             if (skyRequested) {
                 if (inlineShadow) { PrivStackT<kStackLds> ps; ps.sp = 0; skyVisible = !trace_any(P, ps, hitPosition, skyDir, 0.1f, 1000.f); }
                 else skyVisible = B.rayC[rayBase + requested - 1u].w != 0.f;
             }
-        }
-        {   // sky sample (pathtracing.hlsl:239-244 + lighting/common.hlsli:145-202)
+            // sky sample (pathtracing.hlsl:239-244 + lighting/common.hlsli:145-202)
             const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
             const float skyNoL = saturate(dot(N, skyDir));
             f3 radianceOut = {0.f, 0.f, 0.f};
             if (skyVisible) radianceOut = sky_shade(skyRadianceIn, skyDir, skyNoL, matInfo, N, V);
-            if (P.hitChain) {
-                const uint32_t smpc = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u;
-                P.hitChain[(size_t)(pid - smpc * P.localPixels) * 12u + 3u * (uint32_t)bounce + 2u] = (visWord & 0x7fffffffu) | (skyVisible ? 0x80000000u : 0u);
-            }
             const f3 r = attenV * (radianceOut / CosineHemispherePdf(skyDir.z));
             color.x += r.x; color.y += r.y; color.z += r.z;
+        }
+        if (P.hitChain) {
+            const uint32_t smpc = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u;
+            P.hitChain[(size_t)(pid - smpc * P.localPixels) * 12u + 3u * (uint32_t)bounce + 2u] = (visWord & 0x7fffffffu) | (skyVisible ? 0x80000000u : 0u);
         }
         if (flags & kFlagTerminate) {
             const uint32_t smp = P.numSamples > 1u ? fast_div(pid, P.divLocalPixels) : 0u, lp = pid - smp * P.localPixels;

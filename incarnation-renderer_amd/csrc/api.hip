@@ -302,7 +302,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
         WfBuffers& w = ctx->wf[i];
         w.counters = (uint32_t*)p; p += 4096;
         w.extA = (float4*)p; p += n[i] * 32; w.extB = (float4*)p; p += n[i] * 32; w.stA = (float4*)p; p += n[i] * 32; w.stB = (float4*)p; p += n[i] * 32;
-        w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 128;
+        w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 48; w.vertexFull = (float4*)p; p += n[i] * 80;
         w.rayQ = (float4*)p; p += (rayCap[i] + 1) * 32; w.rayC = (float4*)p; p += (rayCap[i] + 1) * 16; w.rayCap = (uint32_t)rayCap[i];
         w.numPaths = (uint32_t)n[i];
     }

@@ -116,16 +116,19 @@ static constexpr int kCursorBase = 16, kRayCountBase = 32;
 // lives at the ray's slot.  Every kernel of a bounce walks the list in order, so all of these are coalesced streams; in round 1
 // they were arrays indexed by pixel id, which the list order follows only in bounce 0 (shade ran 1.8x slower per hit on bounces
 // 1-3).  Only the final pixel store is a scatter.
-// vertex record: 8 float4 per list slot.  The first three are all wf_accumulate_kernel reads of a vertex whose shadow rays went through
-// the queue (the usual case: every ray's radiance is in its rayC record); the other five are written and read only when something has
-// to be re-evaluated per vertex (flags kFlagInlineShadow / kFlagManyLights / kFlagFullRecord, or the stand-alone wf_shadow_gen_kernel).
+// vertex record, in two arrays.  B.vertex, 3 float4 per list slot, is all wf_accumulate_kernel reads of a vertex whose shadow rays went
+// through the queue (the usual case: every ray's radiance is in its rayC record):
 //   [kVColor] payload.color .xyz so far, slot of the continuation ray in the next bounce's list (0xffffffff: the path ends here)
 //   [kVMask]  request mask (4 x u32): the shadow rays of this vertex, bit 127 = the sky sample
 //   [kVMeta]  flags, path id, index of the vertex's first queued shadow ray, light-grid cell
-//   [kVPos] hitPos.xyz, metallic   [kVNrm] N.xyz, roughness   [kVBase] basecolor.xyz, incoming ray direction .x
-//   [kVAtt] attenuation at the vertex .xyz, incoming ray direction .y   [kVSky] skyDir.xyz, incoming ray direction .z
-enum : int { kVColor = 0, kVMask = 1, kVMeta = 2, kVPos = 3, kVNrm = 4, kVBase = 5, kVAtt = 6, kVSky = 7 };
-DI float4* vertex_of(const WfBuffers& B, uint32_t slot) { return B.vertex + (size_t)slot * 8; }
+// B.vertexFull, 5 float4 per list slot, is written and read only when something has to be re-evaluated per vertex (flags
+// kFlagInlineShadow / kFlagManyLights / kFlagFullRecord, or the stand-alone wf_shadow_gen_kernel):
+//   [kFPos] hitPos.xyz, metallic   [kFNrm] N.xyz, roughness   [kFBase] basecolor.xyz, incoming ray direction .x
+//   [kFAtt] attenuation at the vertex .xyz, incoming ray direction .y   [kFSky] skyDir.xyz, incoming ray direction .z
+enum : int { kVColor = 0, kVMask = 1, kVMeta = 2 };
+enum : int { kFPos = 0, kFNrm = 1, kFBase = 2, kFAtt = 3, kFSky = 4 };
+DI float4* vertex_of(const WfBuffers& B, uint32_t slot) { return B.vertex + (size_t)slot * 3; }
+DI float4* vertex_full_of(const WfBuffers& B, uint32_t slot) { return B.vertexFull + (size_t)slot * 5; }
 
 DI void add_counters(const PtParams& P, const Counters& cnt) {
     if (!P.stats) return;
@@ -775,11 +778,12 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             *(uint4*)(vtx + kVMask) = sg.req;
             *(uint4*)(vtx + kVMeta) = make_uint4(f, pid, sg.rayBase, vcell);
             if (!fuseShadowGen || (f & (kFlagInlineShadow | kFlagManyLights | kFlagFullRecord))) {       // someone re-evaluates this vertex: the rest of the record
-                vtx[kVPos] = make_float4(SV.pos.x, SV.pos.y, SV.pos.z, SV.col.w);
-                vtx[kVNrm] = SV.nrm;
-                vtx[kVBase] = make_float4(SV.col.x, SV.col.y, SV.col.z, SV.att.w);
-                vtx[kVAtt] = make_float4(SV.att.x, SV.att.y, SV.att.z, SV.vyz.x);
-                vtx[kVSky] = make_float4(SV.sky.x, SV.sky.y, SV.sky.z, SV.vyz.y);
+                float4* full = vertex_full_of(B, i);
+                full[kFPos] = make_float4(SV.pos.x, SV.pos.y, SV.pos.z, SV.col.w);
+                full[kFNrm] = SV.nrm;
+                full[kFBase] = make_float4(SV.col.x, SV.col.y, SV.col.z, SV.att.w);
+                full[kFAtt] = make_float4(SV.att.x, SV.att.y, SV.att.z, SV.vyz.x);
+                full[kFSky] = make_float4(SV.sky.x, SV.sky.y, SV.sky.z, SV.vyz.y);
             }
         }
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
@@ -816,8 +820,9 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
         if (!(meta.x & kFlagSkip)) {                                              // a shaded hit (misses and debug views carry no vertex)
             V.have = true;
             V.req = *(const uint4*)(vtx + kVMask);
-            const float4 v0 = vtx[kVPos], vb = vtx[kVBase], va = vtx[kVAtt], vs = vtx[kVSky];
-            V.nrm = vtx[kVNrm];
+            const float4* full = vertex_full_of(B, i);
+            const float4 v0 = full[kFPos], vb = full[kFBase], va = full[kFAtt], vs = full[kFSky];
+            V.nrm = full[kFNrm];
             if (P.directLighting && P.lightCount > 0) { V.cellLo = P.gridCellOffsets[meta.w]; V.cellHi = P.gridCellOffsets[meta.w + 1]; }
             V.pos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(V.cellLo));
             V.sky = make_float4(vs.x, vs.y, vs.z, 0.f);
@@ -929,7 +934,8 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             // per-vertex evaluation out of the full record: the ray queue was full for this vertex (every request is traced here), its cell
             // lists more than 127 lights (the first 127 went through the queue, the rest is traced here), or "+ 0" is not exact for it
             const bool inlineShadow = flags & kFlagInlineShadow;
-            const float4 v0 = vtx[kVPos], v1 = vtx[kVNrm], vb = vtx[kVBase], va = vtx[kVAtt], vs = vtx[kVSky];
+            const float4* full = vertex_full_of(B, i);
+            const float4 v0 = full[kFPos], v1 = full[kFNrm], vb = full[kFBase], va = full[kFAtt], vs = full[kFSky];
             const f3 hitPosition = {v0.x, v0.y, v0.z}, N = {v1.x, v1.y, v1.z}, basecolor = {vb.x, vb.y, vb.z}, attenV = {va.x, va.y, va.z};
             const f3 skyDir = {vs.x, vs.y, vs.z};
             const f3 V = -mk3(vb.w, va.w, vs.w);

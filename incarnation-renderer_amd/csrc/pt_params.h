@@ -70,7 +70,8 @@ struct WfBuffers {
     float4* stA;         // state travelling with the rays of the even bounces, 2 x float4: {payload.color} {payload.attenuation.xyz, 0}
     float4* stB;
     uint4*  hit;         // per list slot of the current bounce: {leaf-order triangle, t, u, v}
-    float4* vertex;      // 8 x float4 per list slot of the current bounce: see pathtrace_wf.hip
+    float4* vertex;      // 3 x float4 per list slot of the current bounce: what accumulate reads of a vertex (pathtrace_wf.hip "vertex record")
+    float4* vertexFull;  // 5 x float4 per list slot: the rest of the record, written only for the vertices that are re-evaluated
     uint32_t* counters;  // 64 words: list lengths, traversal cursors, shadow-ray counts (pathtrace_wf.hip kCursorBase / kRayCountBase)
     float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, vertex slot} {direction.xyz, request slot}
     float4* rayC;        // per queued ray: {attenuation * radiance of its light, 1 = unoccluded / 0 = occluded}

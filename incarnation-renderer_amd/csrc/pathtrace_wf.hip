@@ -461,7 +461,7 @@ struct ShadowGenLds {
     uint32_t waveTotal[kWfBlock / 64];
     uint32_t pid[kWfBlock];
     uint4 mask[kWfBlock];
-    float4 pos[kWfBlock], sky[kWfBlock], nrm[kWfBlock], col[kWfBlock], att[kWfBlock];
+    float4 pos[kWfBlock], sky[kWfBlock], nrm[kWfBlock], col[kWfBlock], att[kWfBlock], skyRad[kWfBlock];
     float2 vyz[kWfBlock];
     float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
     uint32_t base;
@@ -470,6 +470,7 @@ struct ShadowGenLds {
 struct ShadowGenVertex {
     bool have; uint32_t cellLo, cellHi; uint4 req;
     float4 pos /* .w = cellLo */, sky, nrm /* .w = roughness */, col /* basecolor, metallic */, att /* attenuation at the vertex, incoming ray direction .x */;
+    float4 skyRad /* skyBrightness x the environment's radiance along sky.xyz (the caller has it from the request test) */;
     float2 vyz /* incoming ray direction .yz */;
 };
 DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          // visible after the next __syncthreads
@@ -484,7 +485,7 @@ struct ShadowGenResult { uint4 req; uint32_t flags, rayBase; };
 DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, ShadowGenLds& S, uint32_t pid, const ShadowGenVertex& V) {
     uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint32_t* const s_pid = S.pid; uint4* const s_mask = S.mask;
     float4* const s_pos = S.pos; float4* const s_sky = S.sky; float4* const s_nrm = S.nrm; float4* const s_col = S.col; float4* const s_att = S.att;
-    float2* const s_vyz = S.vyz; float4* const s_lights = S.lights; uint32_t& s_base = S.base;
+    float2* const s_vyz = S.vyz; float4* const s_lights = S.lights; uint32_t& s_base = S.base; float4* const s_skyRad = S.skyRad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
     auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
@@ -502,7 +503,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
         if (lane == 63u) s_waveTotal[wave] = incl;
-        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz;
+        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz; s_skyRad[tid] = V.skyRad;
         __syncthreads();
         uint32_t waveBase = 0, totalCand = 0;
 #pragma unroll
@@ -582,7 +583,8 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const f3 N = {n4.x, n4.y, n4.z};
             MatProps matInfo = {};
             matInfo.basecolor = mk3(c4.x, c4.y, c4.z); matInfo.metallic = c4.w; matInfo.roughness = n4.w;
-            const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, L);
+            const float4 sr = s_skyRad[lo];
+            const f3 skyRadianceIn = {sr.x, sr.y, sr.z};
             const f3 radianceOut = sky_shade(skyRadianceIn, L, saturate(dot(N, L)), matInfo, N, -mk3(a4.w, vyz2.x, vyz2.y));
             contribution = mk3(a4.x, a4.y, a4.z) * (radianceOut / CosineHemispherePdf(L.z));
         } else {
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     if (P.directLighting && P.lightCount > 0) { SV.cellLo = P.gridCellOffsets[cell]; SV.cellHi = P.gridCellOffsets[cell + 1]; }
                     SV.pos = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(SV.cellLo));
                     SV.sky = make_float4(skyDir.x, skyDir.y, skyDir.z, 0.f); SV.nrm = make_float4(N.x, N.y, N.z, matInfo.roughness);
+                    SV.skyRad = make_float4(skyRadianceIn.x, skyRadianceIn.y, skyRadianceIn.z, 0.f);
                     SV.col = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, matInfo.metallic);
                     SV.att = make_float4(attenV.x, attenV.y, attenV.z, rayD.x); SV.vyz = make_float2(rayD.y, rayD.z);
                 }
@@ -826,6 +829,8 @@ __global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams 
             if (P.directLighting && P.lightCount > 0) { V.cellLo = P.gridCellOffsets[meta.w]; V.cellHi = P.gridCellOffsets[meta.w + 1]; }
             V.pos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(V.cellLo));
             V.sky = make_float4(vs.x, vs.y, vs.z, 0.f);
+            const f3 sr = P.skyBrightness * sky_env_radiance(P, mk3(vs.x, vs.y, vs.z));
+            V.skyRad = make_float4(sr.x, sr.y, sr.z, 0.f);
             V.col = make_float4(vb.x, vb.y, vb.z, v0.w);                       // basecolor, metallic
             V.att = make_float4(va.x, va.y, va.z, vb.w);                       // attenuation at the vertex, incoming ray direction .x
             V.vyz = make_float2(va.w, vs.w);                                   // incoming ray direction .yz

@@ -5,17 +5,20 @@
 // 288 GB of HBM3E at ~8 TB/s, so the per-path state lives in HBM (272 B + 8 x 48 B of shadow-ray queue per pixel)
 // and the work is cut into lean kernels that each do one thing at high occupancy:
 //
-//   generate   rgsMain: camera ray per pixel (8x8 pixel tiles per wave), ray queue of bounce 0
 //   per bounce b = 0..3, over the ray list L_b (everything a kernel touches is indexed by LIST SLOT: coalesced streams):
-//     extend     closest hit (TraceRay stand-in).  b = 0: the camera rays of a tile as ONE PACKET (wf_extend_packet_kernel);
-//                b > 0: persistent waves, one ray per lane, lane refill                              [traversal only]
+//     extend     closest hit (TraceRay stand-in).  b = 0: wf_primary_kernel -- rgsMain's camera ray per pixel (8x8 pixel tiles per
+//                wave) and the tile traced as ONE PACKET, then appended to L_0;  b > 0: persistent waves, one ray per lane,
+//                lane refill                                                                          [traversal only]
 //     shade      miss: msDynamicSky + store.  hit: chsMain without its light loop -- surface, material, emissive, sky sample
-//                direction, BRDF-sampled continuation ray appended to L_{b+1}                       [no traversal]
-//     shadow_gen the light loop's candidates: one lane per (vertex, light of the vertex's grid cell) decides whether a shadow
-//                ray is needed (request mask), then one lane per RAY writes the queue record and the light's radiance  [no traversal]
+//                direction, BRDF-sampled continuation ray appended to L_{b+1}; then, per workgroup, the light loop's candidates
+//                (shadow_gen_block): one lane per (vertex, light of the vertex's grid cell) decides whether a shadow ray is
+//                needed (request mask), and one lane per RAY writes the queue record and the light's -- or the sky sample's --
+//                radiance along it                                                                    [no traversal]
 //     shadow     RayQuery stand-in: traces the queued rays, zeroes the visibility word of occluded ones [traversal only]
-//     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER over the records left visible, then the sky sample; finished
+//     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER over the records left visible, the sky sample's last; finished
 //                paths are stored + integrated                                                        [no traversal]
+//   (wf_generate_kernel + wf_extend_packet_kernel and wf_shadow_gen_kernel are the unfused forms of the first two, kept behind
+//   INCR_WF_FUSED_PRIMARY=0 / INCR_WF_FUSED_SHADOW_GEN=0 for A/B runs.)
 //
 // A frame is issued as two PIPELINES (bands of tile rows on their own streams, launcher below): the other band's kernels fill
 // the GPU while one band's traversal kernel drains its longest rays.

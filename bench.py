@@ -439,8 +439,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     sample = 1
-    for _ in range(args.warmup):
-        step(sample); sample += 1
+    # warm-up in the SAME call shape as the timed steps (`sif` samples per call): the library sizes its path-state workspace by the samples
+    # in flight, and the first call of a shape allocates it
+    w = 0
+    while w < args.warmup:
+        S = min(sif, max(args.steps, 1))
+        step(sample, num_samples=S); sample += S; w += S
     barrier()
     stats.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

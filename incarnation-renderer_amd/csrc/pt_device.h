@@ -42,7 +42,7 @@ DI f4 operator*(float s, f4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
 DI float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DI float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-DI f3 normalize(f3 v) { float l = sqrtf(dot(v, v)); return {v.x / l, v.y / l, v.z / l}; }
+DI f3 normalize(f3 v) { const float r = 1.f / sqrtf(dot(v, v)); return {v.x * r, v.y * r, v.z * r}; }      // HLSL normalize = x * rsqrt(dot(x, x)) (DXIL: Dot3, Rsqrt, FMul), rsqrt pinned to 1 / sqrt: DESIGN.md section 3
 DI float hmax(float a, float b) { return fmaxf(a, b); }
 DI float hmin(float a, float b) { return fminf(a, b); }
 DI float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }

@@ -48,8 +48,10 @@ static inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 static inline float3 cross(float3 a, float3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-// HLSL normalize(v): v / sqrt(dot(v,v))  (pinned as divide-by-length)
-static inline float3 normalize(float3 v) { float l = sqrtf(dot(v, v)); return {v.x / l, v.y / l, v.z / l}; }
+// HLSL normalize(v).  DXC lowers the intrinsic to dot + Rsqrt + FMul (x * rsqrt(dot(x, x))); D3D leaves rsqrt's last bit to the GPU, so
+// it is pinned to the correctly rounded sqrt and reciprocal: v * (1 / sqrt(dot(v, v))).  (Rounds 1-2 pinned v / sqrt(dot(v, v)): three
+// divisions where the shader has three multiplies.)
+static inline float3 normalize(float3 v) { const float r = 1.f / sqrtf(dot(v, v)); return {v.x * r, v.y * r, v.z * r}; }
 // HLSL max/min return the non-NaN operand; saturate(NaN) = 0.
 static inline float hmax(float a, float b) { return fmaxf(a, b); }
 static inline float hmin(float a, float b) { return fminf(a, b); }

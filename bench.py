@@ -129,7 +129,7 @@ class _DeviceWords:
         self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
 
-def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, torch, dist, rank, world, dev, ibl_inputs):
+def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, torch, dist, rank, world, dev, ibl_inputs, collective=False, checksums=False):
     """ms/frame of the visibility-buffer raster + clustered deferred frame (batch cull .. tonemap), inputs resident in HBM.
     world > 1: every rank renders its row band; one RCCL all_gather of the TAA bands per frame; rank 0 tonemaps."""
     R = importlib.import_module(PKG + ".raster")
@@ -137,12 +137,13 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     rr = R.HostRenderer(ctx, scene, W, H, stream=stream_handle, ibl=ibl_inputs)      # C++ Renderer::Render (csrc/host/renderer.cpp)
     rows = (H + world - 1) // world
     tensors = {}
-    if world > 1:
+    collective = collective or world > 1
+    if collective:
         rr.set_band(rank * rows, min((rank + 1) * rows, H))
 
     def frame():
         rr.render(view)
-        if world > 1:
+        if collective:
             ptr = rr.surface_ptr(A.SURFACE_TAA_ACCUMULATION)
             if ptr not in tensors:
                 tensors[ptr] = torch.as_tensor(_DeviceWords(ptr, H * W), device=dev)
@@ -161,7 +162,7 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
                 rr.tonemap()
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -173,9 +174,13 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
         frame()
     barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collective:
         dist.all_reduce(tt, dist.ReduceOp.MAX)
     ms = float(tt.item()) / steps * 1e3
+    taa_crc = None
+    if checksums:
+        import zlib
+        taa_crc = zlib.crc32(ctx.download(rr.surface_ptr(A.SURFACE_TAA_ACCUMULATION), (H * W,), np.uint32).tobytes())
     # per-pass GPU time of one more frame (events on the submission stream) and the algorithmic bytes each pass moves per pixel
     # (SURVEY.md 8d): visibility 8 (id + depth written), G-buffer 4 + 16, fused lighting 16 read + 8 colour rw (unfused: 3 x 24),
     # dynamic sky 4 + 4, TAA 12 + 4 (+ 4 LDR when the tonemap is fused), tonemap 4 + 4
@@ -209,13 +214,14 @@ def raster_leg(ctx, scene, packed, view, W, H, steps, warmup, stream_handle, tor
     rr.close()
     alg = float(W) * H * RASTER_B_PX
     return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "n_gpus": world, **({"ms_per_frame_isotropic_sampler": round(iso_ms, 4)} if iso_ms is not None else {}),
-            "sharding": "none" if world == 1 else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
+            "sharding": "none" if not collective else "sort-first row bands of %d rows + RCCL all_gather of the TAA bands" % rows,
             "workload": "visibility-buffer raster + clustered deferred shading, %dx%d, %d meshlets (%d + %d drawn), SH9 + split-sum specular sky lighting, 1 sun shadow ray/pixel, dynamic sky, TAA, material sampler anisotropic x%d"
                         % (W, H, packed.num_meshlets, int(counts[0]), int(counts[1]), int(packed.max_anisotropy) or 16),
             "passes": "batch_cull, light_cull, visibility, gbuffer, deferred_lighting (sky + sun + clustered fused), dynamic_sky, taa_resolve (+ tonemap fused)",
             "per_pass": per_pass, "host_us_per_frame": round(host_s * 1e6, 1),
             "sun_shadow_rays_per_frame": int(rays), "algorithmic_bytes_per_frame": int(alg),
-            "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 2), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            **({"taa_accumulation_crc32": taa_crc} if taa_crc is not None else {})}
 
 
 def spawn_ranks(n, argv):
@@ -345,6 +351,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 path on ONE GPU: every rank renders on GPU 0 and the collectives go over gloo through the host "
                                                              "(with --backend gloo; the numbers are not a scaling measurement and the JSON line says so)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: run the N > 1 code path at world size 1 over RCCL -- init_process_group('nccl', device_id), the 8-row-block shard descriptor, "
+                         "all_gather_into_tensor of the history + incr_unshard per gathered frame, the TAA band gather on the library-owned surface, "
+                         "destroy_process_group.  Results equal the plain run bit for bit (--checksums); proves the transport branch on one GPU")
+    ap.add_argument("--checksums", action="store_true", help="add CRC-32s of the final history (and of the raster leg's TAA accumulation surface) to the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank choreography (rendezvous, barriers, gather, the JSON line) without render work")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run): this rank raises after the rendezvous")
     args = ap.parse_args()
@@ -376,10 +387,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if args.force_collectives and (world != 1 or args.share_gpu):
+        raise SystemExit("--force-collectives is the one-rank run of the N > 1 path: use it with --gpus 1")
+    collective = world > 1 or args.force_collectives      # the framebuffer goes through the shard / gather / unshard path
+    if collective:
         import torch.distributed as dist_mod
         if args.share_gpu:
             dist_mod.init_process_group(backend="gloo")
+        elif world == 1 and "MASTER_ADDR" not in os.environ:      # no launcher: a rendezvous of one on the loopback
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            dist_mod.init_process_group(backend=args.backend, device_id=dev, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
         else:
             dist_mod.init_process_group(backend=args.backend, device_id=dev)
         dist = _Collectives(dist_mod, torch, staged=bool(args.share_gpu))
@@ -406,16 +426,16 @@ def main():
     envmap = (sky.info.envmap_r11g11b10, sky.info.cubemap_res, sky.info.num_mips)
     ibl_inputs = importlib.import_module(PKG + ".raster").IblInputs.from_sky(sky, env_brdf, (512, 512))
 
-    shard = A.Shard(0, 0, 1) if world == 1 else A.Shard(8, rank, world)
+    shard = A.Shard(8, rank, world) if collective else A.Shard(0, 0, 1)
     rows = ctx.lib.incr_shard_local_rows(H, C.byref(shard))
     target = torch.zeros((rows, W, 4), dtype=torch.int16, device=dev)        # RGBA16F bits
     history = torch.zeros((rows, W), dtype=torch.int32, device=dev)          # R11G11B10F bits
     stats = torch.zeros(8, dtype=torch.int64, device=dev)
-    gathered = torch.zeros((world, rows, W), dtype=torch.int32, device=dev) if world > 1 else None
-    full = torch.zeros((H, W), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.zeros((world, rows, W), dtype=torch.int32, device=dev) if collective else None
+    full = torch.zeros((H, W), dtype=torch.int32, device=dev) if collective else None
     stream = torch.cuda.current_stream(dev)
 
-    sif = args.samples_in_flight if args.samples_in_flight > 0 else (1 if world == 1 else 8)
+    sif = args.samples_in_flight if args.samples_in_flight > 0 else (8 if world > 1 else 1)
 
     def step(sample_index, e0=None, e1=None, gather=True, num_samples=1):
         d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap, num_samples=num_samples)
@@ -429,12 +449,12 @@ def main():
         ctx.pathtrace(d, stream.cuda_stream)
         if e1 is not None:
             e1.record(stream)
-        if world > 1 and gather:   # the one exchange step of the path: gather disjoint framebuffer shards (final HDR of the accumulation)
+        if collective and gather:   # the one exchange step of the path: gather disjoint framebuffer shards (final HDR of the accumulation)
             dist.all_gather_into_tensor(gathered, history)
             ctx.unshard(full.data_ptr(), gathered.data_ptr(), W, H, shard.row_block_height, world, 4, stream.cuda_stream)
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -464,7 +484,7 @@ def main():
     # max over ranks of the wall time, sum over ranks of the rays traced
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     local_stats = stats.clone()
-    if world > 1:
+    if collective:
         dist.all_reduce(tt, dist.ReduceOp.MAX)
         dist.all_reduce(stats, dist.ReduceOp.SUM)
     dt = float(tt.item())
@@ -478,10 +498,11 @@ def main():
     raster_out = None
     if not args.no_raster:
         try:
-            raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs)
+            raster_out = raster_leg(ctx, scene, packed, view, W, H, args.steps, args.warmup, stream.cuda_stream, torch, dist, rank, world, dev, ibl_inputs,
+                                    collective=collective, checksums=args.checksums)
             raster_out["sky_ibl_precompute_ms"] = round(t_ibl * 1e3, 2)      # once per scene / sun change, not per frame
         except Exception as e:      # the headline (path trace) line must survive a failure of the secondary leg
-            if world > 1:           # ... but not at N > 1: the leg contains collectives, a rank that skipped them would hang the others
+            if collective:          # ... but not at N > 1: the leg contains collectives, a rank that skipped them would hang the others
                 raise
             raster_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -524,7 +545,7 @@ def main():
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
                        "lights": len(packed.global_lights), "texture_size": args.texture_size, **({"textures": "block-compressed chains (BC3 / BC5)"} if args.block_compress else {}), "pipelines": int(prof.pipelines), "samples_in_flight": sif,
-                       "sharding": "none" if world == 1 else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
+                       "sharding": "none" if not collective else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4),
                        **({"rehearsal": "--share-gpu: %d ranks on ONE GPU, collectives over gloo through the host -- exercises the N > 1 code path, measures nothing" % world} if args.share_gpu else {})},
@@ -564,6 +585,13 @@ def main():
                     out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources, another workload or another pipeline count: not attached"
             except Exception:
                 pass
+        if args.force_collectives:
+            out["config"]["force_collectives"] = ("world size 1 over %s: init_process_group(device_id), all_gather_into_tensor of the history shard + incr_unshard, "
+                                                  "the TAA band gather on the library-owned surface, all_reduce of time and ray counts, destroy_process_group" % args.backend)
+        if args.checksums:
+            import zlib
+            final = (full if collective else history[:H]).cpu().numpy()
+            out["config"]["history_crc32"] = zlib.crc32(np.ascontiguousarray(final).tobytes())
         if raster_out is not None:
             out["raster"] = raster_out
         if world == 1 and not args.no_cpu_baseline:
@@ -573,7 +601,7 @@ def main():
                                                envmap=(host_env.ctypes.data, sky.info.cubemap_res, sky.info.num_mips))
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

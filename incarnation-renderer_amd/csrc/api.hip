@@ -2,6 +2,7 @@
 // per-pass entry points.  Host code only; kernels live in pathtrace.hip / raster.hip.
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -42,6 +43,29 @@ int incr_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
+// ---------------------------------------------------------------------------------------------- profiler ranges (api_internal.h)
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* want = getenv("INCR_ROCTX");
+        const bool on = want ? atoi(want) != 0 : getenv("ROCP_TOOL_LIBRARIES") != nullptr;      // rocprofv3 exports its tool library list to the profiled process
+        if (!on) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;                                                                          // no profiler SDK on this machine: ranges stay no-ops
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+}
+void incr_roctx_push(const char* name) { const Roctx& r = roctx(); if (r.push) (void)r.push(name); }
+void incr_roctx_pop() { const Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+
 static constexpr int kProfEvents = 22;      // per pipeline of a recorded incr_pathtrace call: start + generate + 4 x (extend, shade, shadow_gen, shadow, accumulate)
 static constexpr int kMaxPipes = 8;
 
@@ -391,16 +415,25 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
             texs[i].texels = (const uint8_t*)d; texs[i].width = t.width; texs[i].height = t.height;
             texs[i].format = t.format == INCR_TEX_BC3_SRGB ? (uint32_t)INCR_TEX_RGBA8_SRGB : (t.format == INCR_TEX_BC5_SNORM ? (uint32_t)INCR_TEX_RG16S_OVER_4445 : (uint32_t)INCR_TEX_RG16_OVER_8925);
             texs[i].pad[0] = texs[i].pad[2] = 0; texs[i].pad[1] = t.mip_levels;
-            if (t.format == INCR_TEX_BC3_SRGB) {          // pad[0]: every alpha of level 0 decodes to 255 (both endpoints 255, or only indices that select a 255)
-                const size_t n0 = (size_t)((t.width + 3) / 4) * ((t.height + 3) / 4);
+            if (t.format == INCR_TEX_BC3_SRGB) {
+                // pad[0]: every alpha of EVERY level decodes to 255 (the raster passes then drop the alpha clip).  A handed-in chain's lower
+                // levels are independent blocks, so all of them are inspected.  Palette of a BC4 alpha block (D3D11.3 functional spec 19.5.4):
+                // index 0 / 1 = the endpoints; a0 > a1: six interpolants; a0 <= a1: four interpolants, index 6 = 0, index 7 = 255 -- so a block
+                // with both endpoints 255 is in the second mode and index 6 still selects 0.
+                size_t nBlocks = 0;
+                for (uint32_t l = 0; l < t.mip_levels; ++l) nBlocks += (size_t)((level_dim(t.width, l) + 3) / 4) * ((level_dim(t.height, l) + 3) / 4);
                 bool opaque = true;
-                for (size_t b = 0; b < n0 && opaque; ++b) {
+                for (size_t b = 0; b < nBlocks && opaque; ++b) {
                     const uint8_t* blk = t.texels + b * 16;
-                    if (blk[0] == 255 && blk[1] == 255) continue;
+                    const uint32_t a0 = blk[0], a1 = blk[1];
                     uint64_t bits = 0; for (int k = 0; k < 6; ++k) bits |= (uint64_t)blk[2 + k] << (8 * k);
                     for (int px = 0; px < 16 && opaque; ++px) {
                         const uint32_t idx = (uint32_t)(bits >> (3 * px)) & 7u;
-                        const bool is255 = (idx == 0 && blk[0] == 255) || (idx == 1 && blk[1] == 255) || (idx == 7 && blk[0] <= blk[1]);
+                        bool is255;
+                        if (idx == 0) is255 = a0 == 255;
+                        else if (idx == 1) is255 = a1 == 255;
+                        else if (a0 > a1) is255 = false;                                       // interpolants between 255 and something smaller
+                        else is255 = idx == 7 || (idx < 6 && a0 == 255);                          // a0 <= a1: a0 == 255 means a1 == 255 too, interpolants 255; index 6 = 0
                         opaque = is255;
                     }
                 }
@@ -554,8 +587,10 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
         for (size_t i = 0; i < nm; ++i) if (sc->host.meshVisibility[i] != mesh_visibility[i]) { sc->host.meshVisibility[i] = mesh_visibility[i]; dirty = true; }
     if (root_transform && memcmp(sc->host.rootTransform.m, root_transform->m, 64)) { sc->host.rootTransform = m44_from(*root_transform); dirty = true; }
     if (!dirty) return INCR_OK;          // the reference rebuilds its TLAS every frame; ours only when an input changed
-    // Everything below is ordered on the caller's stream: small uploads (per-mesh matrices and instance ids, the light
-    // grid), then the re-transform and refit kernels of bvh_update.hip.  No host rebuild, no stream synchronise.
+    // The device work below is ordered on the caller's stream: small uploads (per-mesh matrices and instance ids, the rebuilt top
+    // tree, the light grid), then the re-transform and refit kernels of bvh_update.hip.  The CALL itself does host work -- the top
+    // tree and the light grid are rebuilt on the host, and taking a staging slot may wait for the slot's previous use
+    // (hipEventSynchronize) or grow it (hipHostMalloc) -- so it must not be issued on a capturing stream.
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     std::vector<MeshInstanceInfo>& info = sc->meshInfo;
@@ -565,6 +600,9 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
     int rc = incr_staging_begin(sc, nm * (64 + sizeof(MeshInstanceInfo) + 4) + (sc->grid.cellOffsets.size() + sc->grid.cellLights.size()) * 4 + (size_t)sc->numDecals * 64
                                     + (size_t)sc->bvh.topCapacity * (sizeof(BvhNode8) + 4) + 1024);
     if (rc) return rc;
+    // whatever happens below, the slot's event is recorded behind the copies already enqueued: a slot without it could be rewritten
+    // by the next update while a hipMemcpyAsync still reads it
+    struct StagingGuard { incr_scene* sc; hipStream_t st; bool armed = true; ~StagingGuard() { if (armed) (void)incr_staging_end(sc, st); } } guard{sc, st};
     if (nm) {
         if ((rc = incr_staging_upload(sc, sc->dMeshLocalToWorld, sc->bvh.meshLocalToWorld.data(), nm * 64, st))) return rc;
         if ((rc = incr_staging_upload(sc, sc->dMeshInfo, info.data(), nm * sizeof(MeshInstanceInfo), st))) return rc;
@@ -596,6 +634,7 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
                                    sc->dLevelNodes, sc->bvh.refitRanges.data(), (uint32_t)sc->bvh.refitRanges.size() / 2u, sc->dNodeBoxes, st));
     rc = upload_light_grid(sc, st, true);
     if (!rc) rc = incr_raster_scene_update(sc, st);       // raster side: mesh visibility flags, decal transforms
+    guard.armed = false;
     const int rc2 = incr_staging_end(sc, st);
     return rc ? rc : rc2;
 }
@@ -722,6 +761,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     if (d->env_sky_mode == 0 && !d->envmap_r11g11b10) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode 0 (HDRI) needs envmap_r11g11b10: the miss shader samples the cube");
     if (d->viewmode < 0 || d->viewmode > 5) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d unsupported (0..5)", d->viewmode);
     if (d->max_sample_count < 1) return fail(INCR_ERR_INVALID_ARGUMENT, "max_sample_count must be >= 1");
+    if (d->debug_hit_chain && d->num_samples > 1u) return fail(INCR_ERR_INVALID_ARGUMENT, "debug_hit_chain holds one chain per local pixel: num_samples must be <= 1 (got %u)", d->num_samples);
     if (d->shard.row_block_height && !d->shard.row_block_stride) return fail(INCR_ERR_INVALID_ARGUMENT, "row_block_stride must be >= 1");
     const incr_scene* sc = d->scene;
     PtParams P; fill_scene_params(ctx, sc, P);

@@ -22,8 +22,12 @@ int incr_fail(int code, const char* fmt, ...);      // stores the thread's incr_
 // ---------------------------------------------------------------------------------------------- profiler ranges
 // The reference wraps every pass in a scoped PIX / Tracy event (inc/profiling.h:10-12 SCOPED_COMMAND_LIST_EVENT); here every C-ABI
 // pass call is a roctx range named after its entry point: `rocprofv3 --marker-trace --kernel-trace` groups a frame's kernels by pass.
-#include <rocprofiler-sdk-roctx/roctx.h>
-struct IncrRange { explicit IncrRange(const char* name) { (void)roctxRangePushA(name); } ~IncrRange() { (void)roctxRangePop(); } };
+// The library does NOT link the profiler SDK: librocprofiler-sdk-roctx.so is looked up with dlopen on the first range, and only when a
+// profiler is attached (rocprofv3 sets ROCP_TOOL_LIBRARIES) or INCR_ROCTX=1 asks for it; otherwise -- a runtime-only ROCm install, an
+// ordinary run of the renderer or the bench -- a range is one predictable branch (api.hip incr_roctx_*).
+void incr_roctx_push(const char* name);
+void incr_roctx_pop();
+struct IncrRange { explicit IncrRange(const char* name) { incr_roctx_push(name); } ~IncrRange() { incr_roctx_pop(); } };
 #define INCR_RANGE() IncrRange incr_range_(__func__)
 
 #ifndef INCR_WF_PIPELINES_DEFAULT

@@ -17,8 +17,8 @@
 //     shadow     RayQuery stand-in: traces the queued rays, zeroes the visibility word of occluded ones [traversal only]
 //     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER over the records left visible, the sky sample's last; finished
 //                paths are stored + integrated                                                        [no traversal]
-//   (wf_generate_kernel + wf_extend_packet_kernel and wf_shadow_gen_kernel are the unfused forms of the first two, kept behind
-//   INCR_WF_FUSED_PRIMARY=0 / INCR_WF_FUSED_SHADOW_GEN=0 for A/B runs.)
+//   (Rounds 1-3 also carried the unfused forms -- wf_generate_kernel + wf_extend_packet_kernel, wf_shadow_gen_kernel -- behind environment
+//   hooks for A/B runs; they were removed in round 4: commit 9a57a74 / 3220d1d hold them with their measurements.)
 //
 // A frame is issued as two PIPELINES (bands of tile rows on their own streams, launcher below): the other band's kernels fill
 // the GPU while one band's traversal kernel drains its longest rays.
@@ -125,7 +125,7 @@ static constexpr int kCursorBase = 16, kRayCountBase = 32;
 //   [kVMask]  request mask (4 x u32): the shadow rays of this vertex, bit 127 = the sky sample
 //   [kVMeta]  flags, path id, index of the vertex's first queued shadow ray, light-grid cell
 // B.vertexFull, 5 float4 per list slot, is written and read only when something has to be re-evaluated per vertex (flags
-// kFlagInlineShadow / kFlagManyLights / kFlagFullRecord, or the stand-alone wf_shadow_gen_kernel):
+// kFlagInlineShadow / kFlagManyLights / kFlagFullRecord):
 //   [kFPos] hitPos.xyz, metallic   [kFNrm] N.xyz, roughness   [kFBase] basecolor.xyz, incoming ray direction .x
 //   [kFAtt] attenuation at the vertex .xyz, incoming ray direction .y   [kFSky] skyDir.xyz, incoming ray direction .z
 enum : int { kVColor = 0, kVMask = 1, kVMeta = 2 };
@@ -241,17 +241,6 @@ DI void store_primary(const WfBuffers& B, uint32_t slot, float4 rayO, float4 ray
     B.extA[(size_t)slot * 2] = rayO; B.extA[(size_t)slot * 2 + 1] = rayD;
     // (payload.color = 0 and payload.attenuation = 1 of a camera ray are not stored: wf_shade_kernel knows them at bounce 0)
 }
-__global__ __launch_bounds__(kWfBlock) void wf_generate_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
-    __shared__ uint32_t s_waveCount[kWfBlock / 64];
-    __shared__ uint32_t s_base;
-    for (uint32_t base = blockIdx.x * kWfBlock; base < total; base += gridDim.x * kWfBlock) {
-        float4 rayO, rayD;
-        const bool valid = generate_lane(P, base + threadIdx.x, total, tilesX, tilesY, tileBase, &rayO, &rayD);
-        const uint32_t slot = block_append(valid, B.counters + 0, s_waveCount, &s_base);
-        if (valid) store_primary(B, slot, rayO, rayD);
-    }
-}
-
 #ifdef INCR_WF_LANE_STATS
 // Developer build only (tools/lane_stats.py): where the lanes of the traversal waves go.  Per kernel (0 extend, 1 shadow) 8 words:
 // iterations, live lanes, lanes on a node step, lanes on a triangle step, iterations after the cursor ran dry, live lanes in those,
@@ -332,7 +321,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
 }
 
 // ------------------------------------------------------------------------------------------------ extend, camera rays
-// Bounce 0 only.  The 64 camera rays of a wave are an 8 x 8 pixel tile (wf_generate_kernel) -- lens samples 0.01 apart, directions
+// Bounce 0 only.  The 64 camera rays of a wave are an 8 x 8 pixel tile (generate_lane) -- lens samples 0.01 apart, directions
 // a pixel apart -- so they walk the tree as ONE PACKET: node index, stack, leaf and triangle loops and the 80 / 48-byte fetches are
 // wave-uniform (scalar registers and scalar loads), and every lane tests ITS ray against the eight boxes / the triangle, with all
 // lanes useful.  The lane-per-ray state machine above spends two thirds of its vector instructions on lanes that are idle or on
@@ -417,21 +406,9 @@ DI PacketHit packet_closest(const PtParams& P, uint32_t* stack, bool have, f3 o,
 DI uint4 hit_record(const PacketHit& h) {
     return h.found ? make_uint4(h.bestFlat, __float_as_uint(h.best), __float_as_uint(h.bu), __float_as_uint(h.bv)) : make_uint4(kMissTri, 0u, 0u, 0u);
 }
-__global__ __launch_bounds__(kWfBlock, 6) void wf_extend_packet_kernel(const PtParams P, const WfBuffers B) {
-    __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
-    const uint32_t total = B.counters[0];
-    const uint32_t slot = blockIdx.x * kWfBlock + threadIdx.x;
-    const bool have = slot < total;
-    f3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
-    if (have) { const float4 ro = B.extA[(size_t)slot * 2], rd = B.extA[(size_t)slot * 2 + 1]; o = {ro.x, ro.y, ro.z}; d = {rd.x, rd.y, rd.z}; }
-    const PacketHit h = packet_closest(P, s_stack + (threadIdx.x >> 6) * kPacketStack, have, o, d);
-    if (have) B.hit[slot] = hit_record(h);
-    Counters cnt = {have ? 1u : 0u, 0, 0, 0, 0};
-    add_counters(P, cnt);
-}
-// wf_generate_kernel + wf_extend_packet_kernel in one: a lane makes its camera ray, the wave traces its tile as a packet, and only then are
-// the ray, the payload's start values and the hit appended to bounce 0's list -- the separate generate pass wrote 96 B per pixel that the
-// packet kernel read straight back (0.38 ms of a 4K frame); here those stores leave a kernel that is bound by its vector ALU.
+// Camera-ray generation and the packet traversal in one: a lane makes its camera ray, the wave traces its tile as a packet, and only then are
+// the ray and the hit appended to bounce 0's list -- a separate generate pass (rounds 1-2) wrote 96 B per pixel that the packet kernel read
+// straight back (0.38 ms of a 4K frame); here those stores leave a kernel that is bound by its vector ALU.
 __global__ __launch_bounds__(kWfBlock, 6) void wf_primary_kernel(const PtParams P, const WfBuffers B, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase) {
     __shared__ uint32_t s_stack[(kWfBlock / 64) * kPacketStack];
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
@@ -446,9 +423,6 @@ __global__ __launch_bounds__(kWfBlock, 6) void wf_primary_kernel(const PtParams 
 }
 
 // ------------------------------------------------------------------------------------------------ shadow-ray set-up (called by shade, below)
-#ifndef INCR_WF_FUSE_SHADOW_GEN
-#define INCR_WF_FUSE_SHADOW_GEN 1          // 0: wf_shade_kernel carries neither the set-up code nor its 38 KB of LDS (A/B builds)
-#endif
 DI uint32_t nth_set_bit(uint32_t word, uint32_t j) {          // position of the j-th (0-based) set bit of `word`
     uint32_t pos = 0u;
 #pragma unroll
@@ -480,8 +454,8 @@ DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          //
     if ((uint32_t)P.lightCount <= kGenLdsLights) for (uint32_t k = threadIdx.x; k < (uint32_t)P.lightCount * 5u; k += kWfBlock) S.lights[k] = P.resolvedLights[k];
 }
 // The ray set-up of one workgroup's 256 list slots (every thread of the workgroup must call it: it synchronises).  `pid` = the lane's
-// list slot.  Run by wf_shade_kernel on the vertices it has just made (the fused form: they are still in registers) or by
-// wf_shadow_gen_kernel on vertices read back from the records.
+// list slot.  Run by wf_shade_kernel on the vertices it has just made (they are still in registers; rounds 1-2 had a kernel of its own
+// that read 112 B of every vertex record back).
 // Returns what the caller files in the lane's vertex record: the complete request mask, kFlagManyLights / kFlagInlineShadow, and the index of
 // the vertex's first queued ray.
 struct ShadowGenResult { uint4 req; uint32_t flags, rayBase; };
@@ -616,11 +590,9 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     // fuseShadowGen: the shadow-ray set-up of this workgroup's vertices (shadow_gen_block) runs here, on the values still in registers,
-    // instead of in wf_shadow_gen_kernel, which read 112 B of every vertex record back
-#if INCR_WF_FUSE_SHADOW_GEN
+    // (0 only for the debug views, which make no vertices)
     __shared__ ShadowGenLds s_gen;
     if (fuseShadowGen) shadow_gen_load_lights(P, s_gen);
-#endif
     Counters cnt = {0, 0, 0, 0, 0};
     const uint32_t count = B.counters[bounce];
     const float4* __restrict__ extIn = (bounce & 1) ? B.extB : B.extA;
@@ -710,7 +682,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     uint32_t cell = light_cell(P, hitPosition);
                     if (!finiteAtt) cell = numCells;                      // the catch-all cell lists every light
                     // (which lights of the cell need a shadow ray -- chsMain's loop over the lights, pathtracing.hlsl:230-236 -- is decided by
-                    // wf_shadow_gen_kernel with one lane per (vertex, light) pair: inside this kernel the loop ran to the longest light list
+                    // shadow_gen_block with one lane per (vertex, light) pair: inside the per-hit code the loop ran to the longest light list
                     // of the wave at 3 waves per SIMD and cost 2.6 of its 6.7 ms per frame)
                     // sky sample :239-244
                     const f2 us = SamplePoint(pixelIdx, sampleIdx, sampleSetIndex, P.divSqrtN, P.divN, P.numPixels);
@@ -775,9 +747,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
         // (Ordering the block's continuation rays by direction octant -- a wave of the next extend launch then holds one or two octants
         // instead of eight -- was measured and dropped: extend 11.9 -> 11.8 ms per frame, the next bounce's shade 6.65 -> 6.9 ms.)
         ShadowGenResult sg = {SV.req, 0u, 0u};
-#if INCR_WF_FUSE_SHADOW_GEN
         if (fuseShadowGen) sg = shadow_gen_block(P, B, bounce, s_gen, i, SV);
-#endif
         if (haveVertex) {
             float4* vtx = vertex_of(B, i);
             const uint32_t f = vflags | sg.flags;
@@ -811,41 +781,6 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
 // Queue capacity is a soft limit (rayCap = 8 rays per path, four to five times what the light grid asks for on the
 // bench scenes): a workgroup whose rays do not fit flags its vertices kFlagInlineShadow and accumulate traces those
 // requests itself -- slower, same result, nothing is dropped.
-
-__global__ __launch_bounds__(kWfBlock) void wf_shadow_gen_kernel(const PtParams P, const WfBuffers B, int bounce) {
-    __shared__ ShadowGenLds S;
-    const uint32_t count = B.counters[bounce];
-    if (blockIdx.x * kWfBlock >= count) return;
-    shadow_gen_load_lights(P, S);
-    const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
-    ShadowGenVertex V = {};
-    uint4 meta = make_uint4(kFlagSkip, 0u, 0u, 0u);
-    if (i < count) {
-        const float4* vtx = vertex_of(B, i);
-        meta = *(const uint4*)(vtx + kVMeta);
-        if (!(meta.x & kFlagSkip)) {                                              // a shaded hit (misses and debug views carry no vertex)
-            V.have = true;
-            V.req = *(const uint4*)(vtx + kVMask);
-            const float4* full = vertex_full_of(B, i);
-            const float4 v0 = full[kFPos], vb = full[kFBase], va = full[kFAtt], vs = full[kFSky];
-            V.nrm = full[kFNrm];
-            if (P.directLighting && P.lightCount > 0) { V.cellLo = P.gridCellOffsets[meta.w]; V.cellHi = P.gridCellOffsets[meta.w + 1]; }
-            V.pos = make_float4(v0.x, v0.y, v0.z, __uint_as_float(V.cellLo));
-            V.sky = make_float4(vs.x, vs.y, vs.z, 0.f);
-            const f3 sr = P.skyBrightness * sky_env_radiance(P, mk3(vs.x, vs.y, vs.z));
-            V.skyRad = make_float4(sr.x, sr.y, sr.z, 0.f);
-            V.col = make_float4(vb.x, vb.y, vb.z, v0.w);                       // basecolor, metallic
-            V.att = make_float4(va.x, va.y, va.z, vb.w);                       // attenuation at the vertex, incoming ray direction .x
-            V.vyz = make_float2(va.w, vs.w);                                   // incoming ray direction .yz
-        }
-    }
-    const ShadowGenResult r = shadow_gen_block(P, B, bounce, S, i, V);
-    if (V.have) {
-        float4* vtx = vertex_of(B, i);
-        *(uint4*)(vtx + kVMask) = r.req;
-        *(uint4*)(vtx + kVMeta) = make_uint4(meta.x | r.flags, meta.y, r.rayBase, meta.w);
-    }
-}
 
 // Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray zeroes the
 // visibility word of its own record (a plain 4-byte store; unoccluded rays -- the majority of the light rays -- write nothing).
@@ -1066,26 +1001,21 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         (void)hipEventRecord(fork, streams[0]);
         for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
     }
-    static const bool packetPrimary = !(getenv("INCR_WF_PACKET_PRIMARY") && atoi(getenv("INCR_WF_PACKET_PRIMARY")) == 0);      // A/B hook
-    static const bool fusedShadowGen = INCR_WF_FUSE_SHADOW_GEN && !(getenv("INCR_WF_FUSED_SHADOW_GEN") && atoi(getenv("INCR_WF_FUSED_SHADOW_GEN")) == 0);      // A/B hook: the shadow-ray set-up inside wf_shade_kernel
-    const int fuseGen = (fusedShadowGen && p->viewmode < 2) ? 1 : 0;
-    static const bool fusedPrimary = packetPrimary && !(getenv("INCR_WF_FUSED_PRIMARY") && atoi(getenv("INCR_WF_FUSED_PRIMARY")) == 0);      // A/B hook: generate inside the packet kernel
+    const int fuseGen = p->viewmode < 2 ? 1 : 0;          // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; debug views make no vertices
     auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
         hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
         mark(i, 0);
-        if (!fusedPrimary) hipLaunchKernelGGL(wf_generate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], total[i], tilesX, tilesY, tileRow[i] * tilesX);
-        mark(i, 1);            // (with the fused primary kernel the "generate" interval is empty and "extend" of bounce 0 holds both)
+        mark(i, 1);            // (the "generate" interval of rounds 1-2 is empty: "extend" of bounce 0 = wf_primary_kernel holds both)
     }
     int slot = 2;
     for (int bounce = 0; bounce < 4; ++bounce) {
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (bounce == 0 && fusedPrimary) hipLaunchKernelGGL(wf_primary_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, total[i], tilesX, tilesY, tileRow[i] * tilesX);
-            else if (bounce == 0 && packetPrimary) hipLaunchKernelGGL(wf_extend_packet_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b);
+            if (bounce == 0) hipLaunchKernelGGL(wf_primary_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, total[i], tilesX, tilesY, tileRow[i] * tilesX);
             else if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen); mark(i, slot + 1);
@@ -1094,8 +1024,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (!fuseGen) hipLaunchKernelGGL(wf_shadow_gen_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce);
-            mark(i, slot + 2);
+            mark(i, slot + 2);            // (the "shadow_gen" interval of rounds 1-2 is empty: the set-up runs inside wf_shade_kernel)
             if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
             mark(i, slot + 3);
             hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);

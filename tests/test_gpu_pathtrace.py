@@ -140,15 +140,11 @@ def test_sponza_small_lights_and_alpha_mask(gpu_ctx, rt, sio, sponza_small, spon
     W, H = 320, 180
     view = sio.FView().reset(sponza_small, aspect=W / H)
     pt = rt.PathTracer(gpu_ctx, sponza_small_gpu, W, H)
-    pt.render(view, 5)
-    g = pt.read()
-    o = sponza_small_oracle.pathtrace(rt.make_pathtrace_desc(view, W, H, 5), num_threads=os.cpu_count())
-    gs, os_ = np.array(stats_tuple(g["stats"]), dtype=np.float64), np.array(stats_tuple(o["stats"]), dtype=np.float64)
-    assert gs[0] == os_[0] == W * H
-    assert (np.abs(gs - os_) <= 2e-3 * os_).all(), (gs, os_)          # a flipped edge pixel changes the ray count of its path
+    from parity_helpers import accounted_parity
+    # every pixel outside 2^-7 is a path over other triangles / with a flipped shadow query, or a path of >= 3 vertices (parity_helpers.py)
+    g, o, _ = accounted_parity(rt, pt, sponza_small_oracle, view, W, H, 5, cap=5e-4, label="sponza_small lights + alpha mask")
+    assert g["stats"].camera_rays == W * H
     assert g["stats"].light_shadow_rays > W * H                         # the light loop really ran
-    ok, same = pixel_agreement(g["target"], o["target"])
-    assert ok >= 0.99, (ok, same)
     # masked (alpha-tested) rays: closest-hit identity against the oracle on rays aimed through the plants
     rng = np.random.default_rng(99)
     n = 100_000

@@ -91,12 +91,8 @@ def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob):
     Ws, Hs = 160, 90
     vs = sio.FView().reset(s, aspect=Ws / Hs)
     pts = rt.PathTracer(gpu_ctx, sc, Ws, Hs)
-    pts.render(vs, 3); g = pts.read()
-    o = osc.pathtrace(rt.make_pathtrace_desc(vs, Ws, Hs, 3), num_threads=os.cpu_count())
-    gs, os_ = np.array(stats_tuple(g["stats"]), dtype=np.float64), np.array(stats_tuple(o["stats"]), dtype=np.float64)
-    assert (np.abs(gs - os_) <= 3e-3 * np.maximum(os_, 1)).all(), (gs, os_)
-    ok, same = pixel_agreement(g["target"], o["target"])
-    assert ok >= 0.99, (ok, same)
+    from parity_helpers import accounted_parity
+    accounted_parity(rt, pts, osc, vs, Ws, Hs, 3, cap=7e-4, label="config 5 window (Bistro-scale)", min_outliers_allowed=4)
     pts.close()
     # raster frame + TAA at 4K: two frames, second reprojects the first; bands of ids are plausible and the history converges
     class Cfg(A.FConfig):
@@ -134,13 +130,9 @@ def test_spot_lights_path_tracer(gpu_ctx, rt, sio, A, ob, sponza_spots):
     osc = ob.OracleScene(sponza_spots)
     view = sio.FView().reset(sponza_spots, aspect=W / H)
     pt = rt.PathTracer(gpu_ctx, sc, W, H)
-    pt.render(view, 2); g = pt.read()
-    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 2), num_threads=os.cpu_count())
-    gs, os_ = np.array(stats_tuple(g["stats"]), dtype=np.float64), np.array(stats_tuple(o["stats"]), dtype=np.float64)
-    assert gs[0] == os_[0] == W * H
-    assert (np.abs(gs - os_) <= 2e-3 * os_).all(), (gs, os_)
-    ok, same = pixel_agreement(g["target"], o["target"])
-    assert ok >= 0.99, (ok, same)
+    from parity_helpers import accounted_parity
+    g, o, _ = accounted_parity(rt, pt, osc, view, W, H, 2, cap=5e-4, label="spot lights")
+    assert g["stats"].camera_rays == W * H
     # the spots are really evaluated: more light shadow rays than the rig without them ...
     base = copy.copy(sponza_spots)
     n0 = len(sponza_spots.global_lights) - 8
@@ -269,9 +261,8 @@ def test_update_bvh_matches_fresh_scene(gpu_ctx, rt, R, sio, synth, A, ob):
     u, f = pu.read(), pf.read()
     assert stats_tuple(u["stats"]) == stats_tuple(f["stats"])
     np.testing.assert_array_equal(u["target"], f["target"])
-    o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1), num_threads=os.cpu_count())
-    ok, same = pixel_agreement(u["target"], o["target"])
-    assert ok >= 0.99, (ok, same)
+    from parity_helpers import accounted_parity
+    accounted_parity(rt, pu, osc, view, W, H, 1, cap=5e-4, label="after incr_update_bvh", min_outliers_allowed=4)
     pu.close(); pf.close()
     # raster frame: hidden mesh culled, decal / mesh transforms follow the root transform -- identical surfaces
     (_, gu), = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, A.FConfig, frames=1)
@@ -364,14 +355,15 @@ def test_ragged_frames_packets_and_pipelines(gpu_ctx, rt, sio, ob, sponza_small,
     view = sio.FView().reset(sponza_small, aspect=W / H)
     sc = gpu_ctx.create_scene(sponza_small)
     pt = rt.PathTracer(gpu_ctx, sc, W, H)
-    pt.render(view, 2)
-    g = pt.read()
-    o = ob.OracleScene(sponza_small).pathtrace(rt.make_pathtrace_desc(view, W, H, 2), num_threads=os.cpu_count())
-    assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    from parity_helpers import accounted_parity
+    # one pixel in a thousand may sit outside 2^-7 -- and only as a path of >= 3 vertices or one whose hit chain / shadow word differs
+    # from the oracle's (parity_helpers.py); a shading error on a short path fails whatever its share
+    osc = ob.OracleScene(sponza_small)
+    g, o, bad = accounted_parity(rt, pt, osc, view, W, H, 2, cap=1e-3, label="ragged frame")
     assert g["stats"].camera_rays == W * H
-    ok, same = pixel_agreement(g["target"], o["target"])
-    assert ok >= 1.0 - int(0.001 * W * H + 0.5) / (W * H), (ok, same)          # one pixel in a thousand may sit outside 2^-7 (a deep path behind an ill-conditioned BRDF term)
-    pt.close(); sc.close()
+    if not bad.any():
+        assert stats_tuple(g["stats"]) == stats_tuple(o["stats"])
+    osc.close(); pt.close(); sc.close()
 
 
 # ------------------------------------------------------------------------------------------------ frame issue variants

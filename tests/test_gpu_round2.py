@@ -92,7 +92,7 @@ def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob):
     vs = sio.FView().reset(s, aspect=Ws / Hs)
     pts = rt.PathTracer(gpu_ctx, sc, Ws, Hs)
     from parity_helpers import accounted_parity
-    accounted_parity(rt, pts, osc, vs, Ws, Hs, 3, cap=7e-4, label="config 5 window (Bistro-scale)", min_outliers_allowed=4)
+    accounted_parity(rt, pts, osc, vs, Ws, Hs, 3, cap=3e-4, label="config 5 window (Bistro-scale)", min_outliers_allowed=4)
     pts.close()
     # raster frame + TAA at 4K: two frames, second reprojects the first; bands of ids are plausible and the history converges
     class Cfg(A.FConfig):
@@ -131,7 +131,7 @@ def test_spot_lights_path_tracer(gpu_ctx, rt, sio, A, ob, sponza_spots):
     view = sio.FView().reset(sponza_spots, aspect=W / H)
     pt = rt.PathTracer(gpu_ctx, sc, W, H)
     from parity_helpers import accounted_parity
-    g, o, _ = accounted_parity(rt, pt, osc, view, W, H, 2, cap=5e-4, label="spot lights")
+    g, o, _ = accounted_parity(rt, pt, osc, view, W, H, 2, cap=2e-4, label="spot lights")
     assert g["stats"].camera_rays == W * H
     # the spots are really evaluated: more light shadow rays than the rig without them ...
     base = copy.copy(sponza_spots)
@@ -262,7 +262,7 @@ def test_update_bvh_matches_fresh_scene(gpu_ctx, rt, R, sio, synth, A, ob):
     assert stats_tuple(u["stats"]) == stats_tuple(f["stats"])
     np.testing.assert_array_equal(u["target"], f["target"])
     from parity_helpers import accounted_parity
-    accounted_parity(rt, pu, osc, view, W, H, 1, cap=5e-4, label="after incr_update_bvh", min_outliers_allowed=4)
+    accounted_parity(rt, pu, osc, view, W, H, 1, cap=3e-4, label="after incr_update_bvh", min_outliers_allowed=4)
     pu.close(); pf.close()
     # raster frame: hidden mesh culled, decal / mesh transforms follow the root transform -- identical surfaces
     (_, gu), = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, A.FConfig, frames=1)

@@ -206,6 +206,7 @@ static bool anyhit_area(const HostBvh& B, const Ray& r, Stats& S) {
     note(S, nodes, tris, pushes, maxDepth, occluded);
     return occluded;
 }
+static uint32_t g_occTri = 0xffffffffu;
 static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const Ray& r, int variant, Stats& S) {
     const float invd[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]};
     uint32_t nodes = 0, tris = 0, pushes = 0, maxDepth = 0;
@@ -231,7 +232,7 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
         NodeT N; node_test(n, r, invd, r.tmax, N);
         uint32_t tm = tri_mask(n, N.hit);
         const uint32_t trisBefore = tris;
-        while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) occluded = true; }
+        while (tm && !occluded) { const uint32_t ti = n.triBase + (uint32_t)__builtin_ctz(tm); tm &= tm - 1u; ++tris; float t; if (tri_isect(B.tris[ti], r, r.tmax, &t)) { occluded = true; g_occTri = ti; } }
         if (g_trace) g_trace->tris.push_back((uint8_t)(tris - trisBefore));
         if (occluded) break;
         uint32_t inner = N.hit & n.imask;
@@ -355,6 +356,64 @@ static void wave_model_overlap(const char* name, const Trace& tr, size_t nWaves,
     }
     printf("  %-16s overlap Q %d thr %2d must %2.0f: cost/step %6.1f  iters %.3gM  node iters %.0f%% @ %.1f lanes, tri iters %.0f%% @ %.1f lanes, stalled lane-iters %.1f%%\n", name, Q, M.thr, M.bias,
            cost / steps, iters / 1e6, 100 * nodeIters / iters, nodeLanes / std::max(nodeIters, 1.0), 100 * triIters / iters, triLanes / std::max(triIters, 1.0), 100 * stalls / (iters * 64));
+}
+
+// policy 7 (drain spill): the overlapped step of policy 3, but a wave whose cursor has run dry and that holds fewer than `spillAt` live
+// rays WRITES THEIR STATE OUT (cS instructions) and leaves; the spilled rays of all waves are then continued by a second launch whose
+// waves start full (64 spilled rays each, refilled from the spill list like a ray list, cR instructions per refill on top of cC).
+// Levels > 1 spill again from the resume launch.  Answers: how many wave iterations does the drain of a persistent launch cost, and how
+// many of them does compaction across waves give back?
+struct SpillRay { uint32_t pos, end; uint32_t q[8]; int qn; };
+static void wave_model_spill(const char* name, const Trace& tr, size_t nWaves, const WaveModel& M, int Q, int spillAt, int levels, float cS, float cR) {
+    const size_t nRays = tr.start.size();
+    std::vector<SpillRay> in(nRays);
+    for (size_t r = 0; r < nRays; ++r) { in[r].pos = tr.start[r]; in[r].end = r + 1 < nRays ? tr.start[r + 1] : (uint32_t)tr.tris.size(); in[r].qn = 0; }
+    double cost = 0, iters = 0, steps = 0, drainIters = 0, drainLive = 0; size_t spilledTotal = 0;
+    for (int level = 0; level <= levels && !in.empty(); ++level) {
+        std::vector<SpillRay> out;
+        struct Lane { bool live = false; SpillRay r; };
+        struct Wave { Lane l[64]; size_t next = 0, end = 0; bool dry = false, done = false; };
+        const size_t nW = level == 0 ? nWaves : std::min(nWaves, (in.size() + 63) / 64);
+        std::vector<Wave> waves(nW);
+        size_t cursor = 0, alive = nW;
+        const int chunk = level == 0 ? M.chunk : 64;
+        const bool maySpill = level < levels;
+        while (alive) {
+            for (Wave& w : waves) {
+                if (w.done) continue;
+                int live = 0; for (auto& L : w.l) live += L.live;
+                if (!w.dry && (64 - live >= M.refill || live == 0)) {
+                    if (level > 0) cost += cR;
+                    for (auto& L : w.l) {
+                        if (L.live) continue;
+                        if (w.next >= w.end) { if (cursor >= in.size()) { w.dry = true; break; } w.next = cursor; w.end = std::min(cursor + (size_t)chunk, in.size()); cursor = w.end; }
+                        L.r = in[w.next++]; L.live = !(L.r.pos >= L.r.end && L.r.qn == 0);
+                        if (L.live) ++live;
+                    }
+                }
+                if (live == 0) { if (w.dry) { w.done = true; --alive; } continue; }
+                if (w.dry && maySpill && live < spillAt) {
+                    for (auto& L : w.l) if (L.live) { out.push_back(L.r); L.live = false; }
+                    cost += cS; w.done = true; --alive; continue;
+                }
+                int nN = 0, nT = 0;
+                for (auto& L : w.l) if (L.live) { if (L.r.pos < L.r.end && L.r.qn < Q) ++nN; if (L.r.qn) ++nT; }
+                cost += M.cC + (nN ? M.cN : 0.f) + (nT ? M.cT : 0.f); iters++;
+                if (w.dry) { drainIters++; drainLive += live; }
+                for (auto& L : w.l) {
+                    if (!L.live) continue;
+                    const bool canNode = L.r.pos < L.r.end && L.r.qn < Q;
+                    if (L.r.qn) { ++steps; if (--L.r.q[0] == 0) { for (int i = 1; i < L.r.qn; ++i) L.r.q[i - 1] = L.r.q[i]; --L.r.qn; } }
+                    if (canNode) { ++steps; const uint32_t t = tr.tris[L.r.pos++]; if (t) L.r.q[L.r.qn++] = t; }
+                    if (L.r.pos >= L.r.end && L.r.qn == 0) L.live = false;
+                }
+            }
+        }
+        spilledTotal += out.size();
+        in.swap(out);
+    }
+    printf("  %-8s spill at < %2d live, %d level(s), cS %3.0f cR %3.0f: cost/step %6.2f  iters %.4gM  drain iters %.1f%% @ %.1f live  spilled rays %.2f%%\n", name, spillAt, levels, cS, cR,
+           cost / steps, iters / 1e6, 100 * drainIters / iters, drainLive / std::max(drainIters, 1.0), 100.0 * spilledTotal / nRays);
 }
 
 // policy 4 (sorted workgroup): the 256 rays of a workgroup live in LDS; every iteration the rays on a node step are handed to the
@@ -522,7 +581,9 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             if (cfg == 1 && v >= 2) continue;            // reversal needs the sorted order
             if (fast && v != 2) continue;
             rng_state = 0x9E3779B97F4A7C15ull;
-            Stats sp, sb, ss, ss0;
+            Stats sp, sb, ss, ss0, ssOcc;
+            const bool occCache = getenv("X_OCC") != nullptr;
+            std::vector<uint32_t> occTri(3 * 256, 0xffffffffu); double occStat[3][3] = {};
             Trace trP, trB, trS; const bool model = cfg == 2 && variant == 2;
             g_nodeDepth.clear(); memset(g_visitsByDepth, 0, sizeof g_visitsByDepth);
             if (cfg == 2 && variant == 2) { g_nodeDepth.assign(B.nodes8.size(), 0); std::vector<std::pair<uint32_t,uint8_t>> q; q.push_back({0u, 1}); while (!q.empty()) { auto [ni, d] = q.back(); q.pop_back(); g_nodeDepth[ni] = d; for (int k = 0; k < 8; ++k) if ((B.nodes8[ni].imask >> k) & 1u) q.push_back({B.nodes8[ni].childBase + (uint32_t)k, (uint8_t)(d + 1)}); } }
@@ -548,20 +609,29 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                     for (int k = 0; k < 3; ++k) n[k] *= nl;
                     float p[3]; for (int k = 0; k < 3; ++k) p[k] = r.o[k] + h.t * r.d[k];
                     // shadow rays: sun, in-range point lights, one cosine sky sample
-                    auto shadow = [&](const float d[3], float tmax) {
+                    auto shadow = [&](const float d[3], float tmax, int lightKey = -1) {
                         Ray s; for (int k = 0; k < 3; ++k) { s.o[k] = p[k]; s.d[k] = d[k]; } s.tmin = 0.1f; s.tmax = tmax;
+                        if (occCache && lightKey >= 0) {          // X_OCC: last-occluder cache per light (and per bounce), rays in pixel order
+                            uint32_t& c = occTri[(size_t)bounce * 256 + (size_t)lightKey];
+                            occStat[bounce][0]++;
+                            float tt; if (c != 0xffffffffu && tri_isect(B.tris[c], s, s.tmax, &tt)) { occStat[bounce][1]++; return; }
+                            g_occTri = 0xffffffffu;
+                            const bool o = anyhit(B, sortAxis, s, 1, ssOcc);
+                            if (o) { c = g_occTri; occStat[bounce][2]++; }
+                            return;
+                        }
                         g_trace = model ? &trS : nullptr;
                         anyhit(B, sortAxis, s, (fast || model) ? 1 : variant, ss);
                         if (getenv("X_AREA")) { g_trace = nullptr; anyhit_area(B, s, ss0); }
                         g_trace = nullptr;
                     };
-                    if (sun[0] * n[0] + sun[1] * n[1] + sun[2] * n[2] > 0.f) shadow(sun, 1000.f);
+                    if (sun[0] * n[0] + sun[1] * n[1] + sun[2] * n[2] > 0.f) shadow(sun, 1000.f, 0);
                     for (const PL& L : pls) {
                         float d[3] = {L.p[0] - p[0], L.p[1] - p[1], L.p[2] - p[2]};
                         const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                         if (dist >= L.range) continue;
                         for (int k = 0; k < 3; ++k) d[k] /= dist;
-                        if (d[0] * n[0] + d[1] * n[1] + d[2] * n[2] > 0.f) shadow(d, 1000.f);     // the reference traces to TMax 1000
+                        if (d[0] * n[0] + d[1] * n[1] + d[2] * n[2] > 0.f) shadow(d, 1000.f, 1 + (int)(&L - pls.data()));     // the reference traces to TMax 1000
                     }
                     // cosine direction about n
                     float t1[3] = {fabsf(n[0]) > 0.5f ? 0.f : 1.f, fabsf(n[0]) > 0.5f ? 1.f : 0.f, 0.f};
@@ -584,6 +654,8 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
 
             }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);
+            if (occCache) { print_stats("any-hit light rays behind the occluder cache", ssOcc);
+                for (int b = 0; b < 3; ++b) printf("  occluder cache, bounce %d: light rays %.0f  cache hits %.3f  occluded by traversal %.3f\n", b, occStat[b][0], occStat[b][1] / std::max(occStat[b][0], 1.0), occStat[b][2] / std::max(occStat[b][0], 1.0)); }
             if (getenv("X_AREA")) print_stats("any-hit, area order", ss0);
             if (model) {
                 struct { const char* n; const Trace* t; size_t perWave; int chunk, refill; float cC, cN, cT; } sets[3] = {
@@ -595,6 +667,10 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
                     for (int thr : {8, 16, 24}) wave_model(S.n, *S.t, nW, {2, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr});
                     wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 1}, 2);
                     if (getenv("X_THR")) for (int Q : {2, 3, 4}) for (int thr : {1, 16, 24, 32, 40, 48}) wave_model_overlap(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, thr}, Q);
+                    if (getenv("X_SPILL")) {
+                        wave_model_spill(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 1}, 2, 0, 0, 0.f, 0.f);
+                        for (int lv : {1, 2}) for (int at : {16, 24, 32, 40, 48}) wave_model_spill(S.n, *S.t, nW, {3, S.chunk, S.refill, S.cC, S.cN, S.cT, 1.f, 1}, 2, at, lv, 150.f, 150.f);
+                    }
                     if (getenv("X_POOL")) {
                         for (int R : {96, 128, 192}) for (float cX : {20.f, 40.f}) for (int tt : {1, 24, 40}) wave_model_pool(S.n, *S.t, std::max<size_t>(1, nW * 64 / R), {5, S.chunk, 16, S.cC, S.cN, S.cT, 1.f, 0}, R, 2, cX, tt);
                         for (int K : {2, 3}) for (float cX : {15.f, 25.f}) wave_model_dual(S.n, *S.t, std::max<size_t>(1, nW / K), {6, S.chunk, 16, S.cC, S.cN, S.cT, 1.f, 0}, K, 2, cX);

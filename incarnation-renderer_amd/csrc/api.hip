@@ -759,7 +759,9 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     if ((uint64_t)d->res_x * d->res_y > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "resolution overflows the 32-bit pixel index of the sampler");
     if (d->env_sky_mode != 0 && d->env_sky_mode != 1) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode %d unsupported (0 = HDRI cube, 1 = dynamic sky)", d->env_sky_mode);
     if (d->env_sky_mode == 0 && !d->envmap_r11g11b10) return fail(INCR_ERR_INVALID_ARGUMENT, "env_sky_mode 0 (HDRI) needs envmap_r11g11b10: the miss shader samples the cube");
-    if (d->viewmode < 0 || d->viewmode > 5) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d unsupported (0..5)", d->viewmode);
+    // FConfig::Viewmode compiles pathtracing.hlsl with any VIEWMODE (path-tracing.inl:31-35): 1 lighting only, 2-5 material channels at the
+    // first hit, 7 a mirror bounce at the first hit; 0, 6 (NaN check: a tonemap-side view) and 8-13 are named by no #if: the normal path
+    if (d->viewmode < 0 || d->viewmode > 13) return fail(INCR_ERR_INVALID_ARGUMENT, "viewmode %d unsupported (0..13)", d->viewmode);
     if (d->max_sample_count < 1) return fail(INCR_ERR_INVALID_ARGUMENT, "max_sample_count must be >= 1");
     if (d->debug_hit_chain && d->num_samples > 1u) return fail(INCR_ERR_INVALID_ARGUMENT, "debug_hit_chain holds one chain per local pixel: num_samples must be <= 1 (got %u)", d->num_samples);
     if (d->shard.row_block_height && !d->shard.row_block_stride) return fail(INCR_ERR_INVALID_ARGUMENT, "row_block_stride must be >= 1");

@@ -1,6 +1,7 @@
 // ibl_device.h -- device-side texture-unit stand-ins for the environment maps: packed mip chains of R11G11B10_FLOAT
 // lat-long textures and cube maps, sampled with the pinned rules of DESIGN.md section 3 (2D: bilinear + WRAP; cube: D3D
-// face table, bilinear inside the face, trilinear c0 (1 - f) + c1 f).  Same arithmetic as oracle/oracle_ibl.h.
+// face table, bilinear with taps across face edges taken from the adjacent face (seamless), trilinear c0 (1 - f) + c1 f).  Same
+// arithmetic as oracle/oracle_ibl.h.
 #pragma once
 #include "pt_device.h"
 
@@ -35,19 +36,72 @@ DI void cube_face_uv(f3 d, uint32_t* face, float* u, float* v) {
     else                      { ma = az; if (d.z >= 0.f) { *face = 4; sc = d.x; tc = -d.y; } else { *face = 5; sc = -d.x; tc = -d.y; } }
     *u = (sc / ma + 1.f) * 0.5f; *v = (tc / ma + 1.f) * 0.5f;
 }
+// SEAMLESS cube filtering (D3D11.3 functional spec, TextureCube edge handling: a linear tap that falls off a face is taken from the
+// adjacent face; every TextureCube.Sample / SampleLevel of the reference goes through it -- pathtracing.hlsl:243, 308, sky-lighting.hlsl:123,
+// envmap.hlsl:47, prefilter.hlsl's taps).  cube_unfold: texel (x, y) of `face`, one step outside the face on exactly ONE side, -> the
+// texel across that edge, in exact integer arithmetic: texel centres in doubled cube coordinates (a = 2x + 1 - n in the face plane, +-n
+// along the major axis); the component that left the cube is pulled back onto its face (+-n) and the old major component moves half a
+// texel in (+-(n - 1)).  At a cube CORNER three faces meet and the fourth tap of the 2 x 2 footprint does not exist: it is the
+// average of the other three (the rule GL 4.x recommends and D3D hardware follows; pinned: sum in tap order, times float(1 / 3)).
+DI void cube_unfold(uint32_t n, uint32_t* face, int* x, int* y) {
+    const int N = (int)n, M = N - 1, a = 2 * *x + 1 - N, b = 2 * *y + 1 - N;
+    int px, py, pz;
+    switch (*face) {                                 // (sc, tc, ma) -> position on the cube, as cube_face_uv
+        case 0: px = N; py = -b; pz = -a; break;
+        case 1: px = -N; py = -b; pz = a; break;
+        case 2: px = a; py = N; pz = b; break;
+        case 3: px = a; py = -N; pz = -b; break;
+        case 4: px = a; py = -b; pz = N; break;
+        default: px = -a; py = -b; pz = -N; break;
+    }
+    const uint32_t major = *face >> 1;
+    const bool ox = major != 0u && (px > N || px < -N), oy = major != 1u && (py > N || py < -N);      // else z left the cube
+    if (major == 0u) px = px > 0 ? M : -M; else if (major == 1u) py = py > 0 ? M : -M; else pz = pz > 0 ? M : -M;
+    uint32_t f;
+    if (ox) { f = px < 0 ? 1u : 0u; px = px < 0 ? -N : N; }
+    else if (oy) { f = py < 0 ? 3u : 2u; py = py < 0 ? -N : N; }
+    else { f = pz < 0 ? 5u : 4u; pz = pz < 0 ? -N : N; }
+    int a2, b2;
+    switch (f) {
+        case 0: a2 = -pz; b2 = -py; break;
+        case 1: a2 = pz; b2 = -py; break;
+        case 2: a2 = px; b2 = pz; break;
+        case 3: a2 = px; b2 = -pz; break;
+        case 4: a2 = px; b2 = -py; break;
+        default: a2 = -px; b2 = -py; break;
+    }
+    *face = f; *x = (a2 + M) >> 1; *y = (b2 + M) >> 1;
+}
+DI f3 cube_texel(const uint32_t* __restrict__ level0, uint32_t n, uint32_t face, int x, int y) {      // (x, y) off the face on at most one side
+    if (x < 0 || y < 0 || x >= (int)n || y >= (int)n) cube_unfold(n, &face, &x, &y);
+    return unpack_r11g11b10(level0[((size_t)face * n + (uint32_t)y) * n + (uint32_t)x]);
+}
 DI f3 cube_sample_level(const CubeChain& c, f3 dir, uint32_t level) {
     uint32_t face; float u, v;
     cube_face_uv(dir, &face, &u, &v);
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
     const uint32_t n = mip_dim(c.N, level);
-    const uint32_t* __restrict__ img = c.data + mip_offset_cube(c.N, level) + (size_t)face * n * n;
-    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
-    x = fminf(fmaxf(x, 0.f), (float)(n - 1)); y = fminf(fmaxf(y, 0.f), (float)(n - 1));
+    const uint32_t* __restrict__ lvl = c.data + mip_offset_cube(c.N, level);
+    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;                  // u, v in [0, 1]: x, y in [-0.5, n - 0.5]
     const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = min(x0 + 1, n - 1), y1 = min(y0 + 1, n - 1);
-    const f3 t00 = unpack_r11g11b10(img[(size_t)y0 * n + x0]), t10 = unpack_r11g11b10(img[(size_t)y0 * n + x1]);
-    const f3 t01 = unpack_r11g11b10(img[(size_t)y1 * n + x0]), t11 = unpack_r11g11b10(img[(size_t)y1 * n + x1]);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;             // x0 in [-1, n - 1], x1 in [0, n]
+    f3 t00, t10, t01, t11;
+    if (x0 >= 0 && y0 >= 0 && x1 < (int)n && y1 < (int)n) {                         // the footprint lies inside the face
+        const uint32_t* __restrict__ img = lvl + (size_t)face * n * n;
+        t00 = unpack_r11g11b10(img[(size_t)y0 * n + x0]); t10 = unpack_r11g11b10(img[(size_t)y0 * n + x1]);
+        t01 = unpack_r11g11b10(img[(size_t)y1 * n + x0]); t11 = unpack_r11g11b10(img[(size_t)y1 * n + x1]);
+    } else {
+        const bool xl = x0 < 0, xh = x1 >= (int)n, yl = y0 < 0, yh = y1 >= (int)n;
+        const bool m00 = xl && yl, m10 = xh && yl, m01 = xl && yh, m11 = xh && yh;   // the tap beyond a cube corner (at most one)
+        const f3 zero = {0.f, 0.f, 0.f};
+        t00 = m00 ? zero : cube_texel(lvl, n, face, x0, y0); t10 = m10 ? zero : cube_texel(lvl, n, face, x1, y0);
+        t01 = m01 ? zero : cube_texel(lvl, n, face, x0, y1); t11 = m11 ? zero : cube_texel(lvl, n, face, x1, y1);
+        if (m00 || m10 || m01 || m11) {
+            const f3 avg = (((t00 + t10) + t01) + t11) * 0.333333343f;
+            if (m00) t00 = avg; else if (m10) t10 = avg; else if (m01) t01 = avg; else t11 = avg;
+        }
+    }
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
 }

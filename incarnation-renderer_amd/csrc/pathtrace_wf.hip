@@ -632,7 +632,8 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                 // chsMain -- pathtracing.hlsl:121-268
                 cnt.hits++;
                 const int pathLength = bounce + 1;
-                uint32_t sampleSetIndex = (uint32_t)bounce;               // one SamplePoint per earlier hit (Q3)
+                // one SamplePoint per earlier hit (Q3) -- except the mirror vertex of VIEWMODE 7 (below), which consumes none
+                uint32_t sampleSetIndex = (uint32_t)bounce - ((P.viewmode == 7 && bounce > 0) ? 1u : 0u);
                 const float4* __restrict__ sp = (const float4*)(P.shade + h.x);
                 const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
                 const uint4 s7 = *(const uint4*)(sp + 7);
@@ -674,6 +675,15 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     }
                     const f3 V = -rayD;
                     const f3 attenV = attenuation;
+                    if (P.viewmode == 7 && pathLength < 2) {
+                        // VIEWMODE 7, Reflections (pathtracing.hlsl:212-224): the first hit sends one mirror ray with the same payload and returns --
+                        // no lights, no sky sample, no attenuation test.  The vertex carries an empty request mask: accumulate hands the colour on.
+                        const f3 Rm = normalize(reflect(-V, N));
+                        nextO = make_float4(hitPosition.x, hitPosition.y, hitPosition.z, __uint_as_float(pid));
+                        nextD = make_float4(Rm.x, Rm.y, Rm.z, 0.f);
+                        nextA = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.f);
+                        cont = true; haveVertex = true; vflags = 0u; vcell = 0u;
+                    } else {
                     // ---- enumerate the shadow rays of this vertex as a request mask ----
                     uint32_t req3 = 0u;
                     uint32_t flags = 0u;
@@ -741,6 +751,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     SV.skyRad = make_float4(skyRadianceIn.x, skyRadianceIn.y, skyRadianceIn.z, 0.f);
                     SV.col = make_float4(matInfo.basecolor.x, matInfo.basecolor.y, matInfo.basecolor.z, matInfo.metallic);
                     SV.att = make_float4(attenV.x, attenV.y, attenV.z, rayD.x); SV.vyz = make_float2(rayD.y, rayD.z);
+                    }
                 }
             }
         }
@@ -1001,7 +1012,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         (void)hipEventRecord(fork, streams[0]);
         for (int i = 1; i < numPipes; ++i) (void)hipStreamWaitEvent(streams[i], fork, 0);
     }
-    const int fuseGen = p->viewmode < 2 ? 1 : 0;          // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; debug views make no vertices
+    const bool firstHitOnly = p->viewmode >= 2 && p->viewmode <= 5;      // VIEWMODE 2-5 return at the first hit (pathtracing.hlsl:184-196); every other mode is a full path
+    const int fuseGen = firstHitOnly ? 0 : 1;             // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; the material views make no vertices
     auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
@@ -1020,7 +1032,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen); mark(i, slot + 1);
         }
-        if (p->viewmode >= 2) { slot += 2; break; }            // VIEWMODE >= 2 paths end at the first hit
+        if (firstHitOnly) { slot += 2; break; }
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];

@@ -269,7 +269,7 @@ struct SubTri {
     int32_t bias[3];                     // 0 for top/left edges, -1 otherwise (D3D fill rule)
     double area;                         // 1 / (twice the signed screen area), in double
     float z0, dz1, dz2;
-    uint32_t key;
+    uint32_t key, list;                  // visibility id (Encode{Meshlet,Primitive}Visibility) and the draw list that drew it (0 default, 1 double-sided)
     int32_t alphaTex;                    // base-colour texture to alpha-test against, -1 = none
     BarySetup bs;                        // interpolant set-up of the ORIGINAL triangle's clip-space vertices (alpha-tested triangles only)
     DeviceTexture tex;                   // descriptor of alphaTex, fetched once per triangle
@@ -310,7 +310,9 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
     float depth = (st.z0 + l1 * st.dz1) + l2 * st.dz2;
     if (!(depth >= 0.f)) return;
     if (depth > 1.f) depth = 1.f;
-    const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(st.key + 1u);
+    // depth || draw list || id + 1: a depth in [0, 1] is a bit pattern below 2^30 (1.0f = 0x3F800000), the list bit decides equal depths
+    // between the two draw lists, and the id keeps all of its 32 bits (EncodePrimitiveVisibility uses every one: 12 + 20)
+    const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 34) | ((unsigned long long)st.list << 33) | ((unsigned long long)st.key + 1ull);
     unsigned long long* dst = P.packed + (size_t)py * P.W + px;
     if (st.alphaTex >= 0) {                                        // ps_meshlet_main: clip(opacity - 0.5)
         // values only grow: a fragment that loses now loses for good -- worth a load before the texture sample (fetching the surface
@@ -372,7 +374,7 @@ DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriRec r = P.recs[idx];
     const ScreenVert v0 = {r.X0, r.Y0, r.z0}, v1 = {r.X1, r.Y1, r.z1}, v2 = {r.X2, r.Y2, r.z2};
     if (!setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, st)) return false;
-    st->key = r.key; st->alphaTex = r.alphaTex;
+    st->key = r.key; st->list = r.pad; st->alphaTex = r.alphaTex;
     if (r.alphaTex >= 0) vq_load_alpha(P, idx, st);
     return true;
 }
@@ -381,7 +383,7 @@ DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
 // bounding-box size.  MUST be called by all 64 lanes (queue slots are allocated with ballots: one atomic per wave and
 // queue instead of one per triangle -- 930 K same-address atomics cost 9 ms on the Bistro-scale scene).
 DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float4 c0, const float4 c1, const float4 c2,
-                      const float2 uvA, const float2 uvB, const float2 uvC, uint32_t key, int32_t alphaTex, bool cullBack) {
+                      const float2 uvA, const float2 uvB, const float2 uvC, uint32_t key, uint32_t list, int32_t alphaTex, bool cullBack) {
     const float Wf = (float)P.W, Hf = (float)P.H;
     const ClipVert cv[3] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
     ClipVert poly[4]; int np = 0;
@@ -427,7 +429,7 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
         if (!have) continue;
         SubTriRec r;
         r.X0 = v0.X; r.Y0 = v0.Y; r.X1 = v1.X; r.Y1 = v1.Y; r.X2 = v2.X; r.Y2 = v2.Y; r.z0 = v0.z; r.z1 = v1.z; r.z2 = v2.z;
-        r.key = key; r.alphaTex = alphaTex; r.pad = 0;
+        r.key = key; r.alphaTex = alphaTex; r.pad = list;
         P.recs[idx] = r;
         if (alphaTex >= 0) {
             SubTriAlpha al;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(kVisWaves * 64) void vis_setup_kernel(const VisPara
             const float4 c0 = s_clip[wave][li[0]], c1 = s_clip[wave][li[1]], c2 = s_clip[wave][li[2]];
             float2 uvA = make_float2(0.f, 0.f), uvB = uvA, uvC = uvA;
             if (alphaTex >= 0) { uvA = P.S.mvUv[m.vertexBegin + li[0]]; uvB = P.S.mvUv[m.vertexBegin + li[1]]; uvC = P.S.mvUv[m.vertexBegin + li[2]]; }
-            emit_triangle(P, lane, valid, c0, c1, c2, uvA, uvB, uvC, (list << 31) | ((cmd.id << 7) | tri), alphaTex, list == 0);
+            emit_triangle(P, lane, valid, c0, c1, c2, uvA, uvB, uvC, (cmd.id << 7) | tri, list, alphaTex, list == 0);
         }
         __builtin_amdgcn_wave_barrier();                         // s_clip[wave] is rewritten by the next job
     }
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(256) void vis_setup_prim_kernel(const VisParams P) 
             c[k] = make_float4(cc.x, cc.y, cc.z, cc.w);
             uv[k] = alphaTex >= 0 ? R.pvUv[d.vertexBase + vi] : make_float2(0.f, 0.f);
         }
-        // the forward pass draws primitive by primitive in scene order: no list bit in the depth-tie order key
-        emit_triangle(P, lane, valid, c[0], c[1], c[2], uv[0], uv[1], uv[2], ((P.forward ? 0u : list) << 31) | ((prim << 20) | tri), alphaTex, list == 0);
+        // the forward pass draws primitive by primitive in scene order: no list bit in the depth-tie order
+        emit_triangle(P, lane, valid, c[0], c[1], c[2], uv[0], uv[1], uv[2], (prim << 20) | tri, P.forward ? 0u : list, alphaTex, list == 0);
     }
 }
 // forward-pass.inl:68-179: every primitive of every visible mesh is drawn; CullMode NONE for double-sided materials
@@ -592,8 +594,8 @@ __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
 // packed depth|key -> R32_UINT visibility + D32 depth (clears: 0xFFFFF000 and 0, visibility-pass.inl:68-74)
 // 16 B in (two depth|key words), 8 + 8 B out per lane; `first` is even and n is rounded up by the launcher's padding rule
 __global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long long* __restrict__ packed, uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
-    auto id_of = [](unsigned long long v) { return v == 0 ? 0xFFFFF000u : (((uint32_t)v - 1u) & 0x7fffffffu); };
-    auto z_of = [](unsigned long long v) { return v == 0 ? 0.f : __uint_as_float((uint32_t)(v >> 32)); };
+    auto id_of = [](unsigned long long v) { return v == 0 ? 0xFFFFF000u : (uint32_t)((v & 0x1ffffffffull) - 1ull); };
+    auto z_of = [](unsigned long long v) { return v == 0 ? 0.f : __uint_as_float((uint32_t)(v >> 34)); };
     const bool wide = ((((uintptr_t)packed) & 15u) | (((uintptr_t)vis) & 7u) | (((uintptr_t)depth) & 7u)) == 0;
     const size_t pairs = wide ? n / 2 : 0;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < pairs; q += (size_t)gridDim.x * blockDim.x) {

@@ -216,11 +216,11 @@ void fill_raster_scene(const incr_context* ctx, const incr_scene* sc, RasterScen
     S.numMeshlets = (uint32_t)sc->host.meshlets.size(); S.numMeshes = (uint32_t)sc->host.meshTransforms.size();
     S.maxAnisotropy = sc->host.maxAnisotropy;
 }
-// FConfig::UseMeshlets == false.  The order key of the visibility pass keeps bit 31 for the draw list, so the primitive
-// id has 11 bits there (EncodePrimitiveVisibility itself has 12, encoding.hlsli:8-11).
+// FConfig::UseMeshlets == false.  EncodePrimitiveVisibility keeps 12 bits of primitive id (encoding.hlsli:4-11): 4,096 primitives, of which the
+// last one shares its id range with the clear value 0xFFFFF000 (visibility-pass.inl:68-74) from triangle 0xFF000 on -- in the reference too.
 int fill_raster_prims(const incr_scene* sc, uint32_t* primFlags, RasterPrims& R) {
     const size_t n = sc->host.primitives.size();
-    if (n >= 2048) return fail(INCR_ERR_INVALID_ARGUMENT, "%zu primitives: the primitive path holds at most 2047 (use meshlets)", n);
+    if (n > 4096) return fail(INCR_ERR_INVALID_ARGUMENT, "%zu primitives: EncodePrimitiveVisibility holds at most 4096 (use meshlets)", n);
     R.draws = sc->dPrimDraws; R.indices = sc->dPrimIndices;
     R.pvPos = sc->dPvPos; R.pvUv = sc->dPvUv; R.pvNormal = sc->dPvNormal; R.pvTangent = sc->dPvTangent;
     R.chunkPrim = sc->dChunkPrim; R.chunkFirstTri = sc->dChunkFirstTri; R.primFlags = primFlags;

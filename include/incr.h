@@ -123,7 +123,7 @@ typedef struct incr_pathtrace_desc {
     float    camera_focal_length;    /* FConfig::Pathtracing_CameraFocalLength (7)                               */
     int32_t  env_sky_mode;           /* FConfig::EnvSkyMode: 1 = dynamic sky (msDynamicSky); 0 = envmap (unsupported first cut) */
     int32_t  direct_lighting;        /* FConfig::EnableDirectLighting -> DIRECT_LIGHTING macro                   */
-    int32_t  viewmode;               /* FConfig::Viewmode -> VIEWMODE macro (0..5)                               */
+    int32_t  viewmode;               /* FConfig::Viewmode -> VIEWMODE macro (0..13; 1 lighting only, 2-5 first-hit material views, 7 mirror bounce, others = the normal path) */
     float    turbidity;              /* FConfig::Turbidity (2)                                                   */
     float    sky_brightness;         /* FConfig::SkyBrightness (25000)                                           */
     int32_t  storage_rounding;       /* 0 = round-toward-zero typed-UAV stores (D3D11.3 spec 3.2.3.3), 1 = nearest-even */
@@ -333,7 +333,7 @@ typedef struct incr_visibility_desc {
     uint32_t* vis_buffer;              /* device, res_x*res_y R32_UINT */
     float*    depth_buffer;            /* device, res_x*res_y D32_FLOAT */
     int32_t   use_primitives;          /* !FConfig::UseMeshlets: vs_primitive_main / ps_primitive_main, vis = primitiveId << 20 | triangle
-                                          (at most 2047 primitives: the depth-tie order key keeps one bit for the draw list) */
+                                          (at most 4096 primitives: the 12 bits of EncodePrimitiveVisibility, encoding.hlsli:4-11) */
 } incr_visibility_desc;
 int incr_visibility(incr_context* ctx, const incr_visibility_desc* desc, incr_stream stream);
 /* Introspection for the bench: work-queue counters of the last incr_visibility call (synchronises the device):
@@ -467,7 +467,7 @@ int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc*
  * clip(opacity - 0.5), depth GREATER_EQUAL with writes) and shades in the pixel shader: emissive * 20000 + every scene light
  * (sun with a ray-traced shadow) + SH9 diffuse + split-sum specular IBL.  Here: primitive visibility in scene order into a
  * library-owned id surface, then one shading kernel.  Viewmode 2..5 and 7 return material channels / reflections as the
- * shader does (its LightingOnly branch is dead code: `#if VIWEMODE == 1`).  At most 2047 primitives. */
+ * shader does (its LightingOnly branch is dead code: `#if VIWEMODE == 1`).  At most 4096 primitives. */
 typedef struct incr_forward_lighting_desc {
     const incr_scene* scene;
     const incr_view_constants* view;

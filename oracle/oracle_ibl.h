@@ -5,8 +5,8 @@
 //
 // Pinned texture-unit rules: 2D bilinear with WRAP addressing on both axes, texel centre +0.5, float weights,
 // (t00 wx0 + t10 fx) wy0 + (t01 wx0 + t11 fx) fy; "MIP_POINT" with an integer level reads exactly that level.  Cube maps:
-// face = major axis (x before y before z on ties), D3D (sc, tc, ma) table, bilinear INSIDE the face with coordinates
-// clamped to the face (no cross-face filtering: a deviation from D3D's seamless cube filtering), trilinear =
+// face = major axis (x before y before z on ties), D3D (sc, tc, ma) table, bilinear with SEAMLESS edges (taps beyond a face edge come
+// from the adjacent face, the tap beyond a cube corner is the mean of the other three: D3D11.3 TextureCube edge handling), trilinear =
 // c0 (1 - f) + c1 f between the two nearest levels, level clamped to [0, mips - 1].
 // Surfaces are R11G11B10_FLOAT (radiance) / RGBA32F (SH) / R16G16_FLOAT (BRDF LUT), stores as `rounding` says.
 #pragma once
@@ -40,21 +40,66 @@ static void cube_face_uv(float3 d, uint32_t* face, float* u, float* v) {
     else                      { ma = az; if (d.z >= 0.f) { *face = 4; sc = d.x; tc = -d.y; } else { *face = 5; sc = -d.x; tc = -d.y; } }
     *u = (sc / ma + 1.f) * 0.5f; *v = (tc / ma + 1.f) * 0.5f;
 }
+// D3D11.3 TextureCube edge handling: a linear tap beyond a face edge comes from the adjacent face.  Restated geometrically: the texel
+// centre as a point on the cube surface in doubled integer coordinates (face plane at +-n along the major axis, centres at odd
+// offsets 2 i + 1 - n inside it); a centre one step beyond an edge has one in-plane coordinate of magnitude n + 1: fold it over the
+// edge -- that coordinate becomes +-n (the new face's plane), the former major coordinate +-(n - 1) (the first texel row of the new
+// face) -- and read the new face's (sc, tc) back.  The tap beyond a CORNER has no texel: average of the footprint's other three.
+static void cube_fold_over_edge(uint32_t n, uint32_t* face, int* x, int* y) {
+    const int N = (int)n;
+    const int sc2 = 2 * *x + 1 - N, tc2 = 2 * *y + 1 - N;
+    int p[3];
+    switch (*face) {
+        case 0: p[0] = N;  p[1] = -tc2; p[2] = -sc2; break;      // +X: sc = -z, tc = -y
+        case 1: p[0] = -N; p[1] = -tc2; p[2] = sc2;  break;      // -X: sc = +z, tc = -y
+        case 2: p[0] = sc2; p[1] = N;  p[2] = tc2;  break;       // +Y: sc = +x, tc = +z
+        case 3: p[0] = sc2; p[1] = -N; p[2] = -tc2; break;       // -Y: sc = +x, tc = -z
+        case 4: p[0] = sc2; p[1] = -tc2; p[2] = N;  break;       // +Z: sc = +x, tc = -y
+        default: p[0] = -sc2; p[1] = -tc2; p[2] = -N; break;     // -Z: sc = -x, tc = -y
+    }
+    const int major = (int)(*face >> 1);
+    int over = -1;
+    for (int k = 0; k < 3; ++k) if (k != major && std::abs(p[k]) > N) over = k;
+    p[major] = p[major] > 0 ? N - 1 : -(N - 1);
+    p[over] = p[over] > 0 ? N : -N;
+    const uint32_t nf = (uint32_t)over * 2u + (p[over] < 0 ? 1u : 0u);
+    int s2, t2;
+    switch (nf) {
+        case 0: s2 = -p[2]; t2 = -p[1]; break;
+        case 1: s2 = p[2];  t2 = -p[1]; break;
+        case 2: s2 = p[0];  t2 = p[2];  break;
+        case 3: s2 = p[0];  t2 = -p[2]; break;
+        case 4: s2 = p[0];  t2 = -p[1]; break;
+        default: s2 = -p[0]; t2 = -p[1]; break;
+    }
+    *face = nf; *x = (s2 + N - 1) / 2; *y = (t2 + N - 1) / 2;
+}
 static float3 cube_sample_level(const CubeChain& c, float3 dir, uint32_t level) {
     uint32_t face; float u, v;
     cube_face_uv(dir, &face, &u, &v);
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
     const uint32_t n = std::max(c.N >> level, 1u);
-    const uint32_t* img = c.data + mip_offset_cube(c.N, level) + (size_t)face * n * n;
-    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
-    x = fminf(fmaxf(x, 0.f), (float)(n - 1)); y = fminf(fmaxf(y, 0.f), (float)(n - 1));
+    const uint32_t* lvl = c.data + mip_offset_cube(c.N, level);
+    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
     const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = std::min(x0 + 1, n - 1), y1 = std::min(y0 + 1, n - 1);
-    const float3 t00 = unpack_r11g11b10(img[(size_t)y0 * n + x0]), t10 = unpack_r11g11b10(img[(size_t)y0 * n + x1]);
-    const float3 t01 = unpack_r11g11b10(img[(size_t)y1 * n + x0]), t11 = unpack_r11g11b10(img[(size_t)y1 * n + x1]);
+    const int xs[2] = {(int)x0f, (int)x0f + 1}, ys[2] = {(int)y0f, (int)y0f + 1};
+    float3 t[2][2]; bool missing[2][2]; bool anyMissing = false;
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
+        const bool offX = xs[i] < 0 || xs[i] >= (int)n, offY = ys[j] < 0 || ys[j] >= (int)n;
+        missing[j][i] = offX && offY; anyMissing = anyMissing || missing[j][i];
+        t[j][i] = float3{0.f, 0.f, 0.f};
+        if (missing[j][i]) continue;
+        uint32_t f = face; int tx = xs[i], ty = ys[j];
+        if (offX || offY) cube_fold_over_edge(n, &f, &tx, &ty);
+        t[j][i] = unpack_r11g11b10(lvl[((size_t)f * n + (uint32_t)ty) * n + (uint32_t)tx]);
+    }
+    if (anyMissing) {
+        const float3 avg = (((t[0][0] + t[0][1]) + t[1][0]) + t[1][1]) * 0.333333343f;
+        for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) if (missing[j][i]) t[j][i] = avg;
+    }
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
-    return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
+    return (t[0][0] * wx0 + t[0][1] * fx) * wy0 + (t[1][0] * wx0 + t[1][1] * fx) * fy;
 }
 static float3 env_cube_level0(const uint32_t* data, uint32_t N, uint32_t mips, float3 dir) { return cube_sample_level({N, mips, data}, dir, 0u); }
 static float3 cube_sample_trilinear(const CubeChain& c, float3 dir, float level) {

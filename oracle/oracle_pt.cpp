@@ -835,6 +835,14 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
         }
         float3 V = -ray.d;
 
+        if (f.viewmode == 7 && pathLength < 2) {         // VIEWMODE 7, Reflections -- pathtracing.hlsl:212-224: the first hit sends ONE mirror ray with
+            // the same payload (colour, attenuation, path length; no SamplePoint is consumed: the sample set index stays) and returns --
+            // no lights, no sky sample at this vertex, no test of the attenuation
+            if (chain) chain[3 * (pathLength - 1) + 2] = 0u;
+            ray.o = hitPosition; ray.d = normalize(reflect(-V, N)); ray.tmin = k_rayOffset; ray.tmax = 10000.0f;
+            continue;
+        }
+
         if (f.directLighting) {
             for (int lightIndex = 0; lightIndex < f.lightCount; ++lightIndex) {
                 // D3D robust buffer access: out-of-range loads return 0

@@ -223,7 +223,7 @@ static inline void meshlet_tri_verts(const Scene& s, const incr_gpu_meshlet& m, 
 
 struct RasterTarget { uint32_t W, H, y0, y1; std::vector<uint64_t> packed; };
 
-static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t key,
+static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, ScreenVert v1, ScreenVert v2, bool cullBack, uint32_t key, uint32_t list,
                           const incr_material& mat, const float4 p[3], const float2 uv[3]) {
     int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
     if (area == 0) return;
@@ -254,7 +254,10 @@ static void raster_subtri(const Scene& s, RasterTarget& rt, ScreenVert v0, Scree
                 const float opacity = SampleGrad(s, mat.baseColorTextureIndex, interp2(uv[0], uv[1], uv[2], lam), g.ddx, g.ddy).w;
                 if (opacity - 0.5f < 0.f) continue;
             }
-            const uint64_t v = ((uint64_t)f2u(depth) << 32) | (uint64_t)(key + 1u);
+            // GREATER_EQUAL in draw order (default list, then double-sided list; ascending id inside a list): the survivor of a pixel is the
+            // maximum of (depth, list, id).  One 64-bit word: depth in [0, 1] has a bit pattern below 2^30, one bit of list, 33 bits of id + 1
+            // (the id keeps all 32 bits: EncodePrimitiveVisibility is 12 + 20)
+            const uint64_t v = ((uint64_t)f2u(depth) << 34) | ((uint64_t)list << 33) | ((uint64_t)key + 1u);
             uint64_t& dst = rt.packed[(size_t)py * rt.W + px];
             if (v > dst) dst = v;
         }
@@ -290,7 +293,8 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
                 }
                 // forward pass (forward-pass.inl:68-179): one draw per primitive in scene order, cull mode from the material
                 const bool cullBack = forward ? !mat.doubleSided : list == 0;
-                const uint32_t key = ((forward ? 0u : (uint32_t)list) << 31) | (usePrims ? ((objectId << 20) | tri) : ((objectId << 7) | tri));
+                const uint32_t key = usePrims ? ((objectId << 20) | tri) : ((objectId << 7) | tri);      // Encode{Primitive,Meshlet}Visibility, encoding.hlsli:4-28
+                const uint32_t listBit = forward ? 0u : (uint32_t)list;
                 // near-plane clip (z <= w)
                 bool in[3]; int nin = 0;
                 for (int k = 0; k < 3; ++k) { in[k] = (cv[k].w - cv[k].z) >= 0.f; nin += in[k]; }
@@ -305,15 +309,15 @@ static void visibility_pass(const Scene& s, const incr_view_constants& vc, const
                 ScreenVert sv[4]; bool ok = true;
                 for (int k = 0; k < np; ++k) ok = ok && to_screen(poly[k], W, H, &sv[k]);
                 if (!ok) continue;
-                raster_subtri(s, rt, sv[0], sv[1], sv[2], cullBack, key, mat, p, uv);
-                if (np == 4) raster_subtri(s, rt, sv[0], sv[2], sv[3], cullBack, key, mat, p, uv);
+                raster_subtri(s, rt, sv[0], sv[1], sv[2], cullBack, key, listBit, mat, p, uv);
+                if (np == 4) raster_subtri(s, rt, sv[0], sv[2], sv[3], cullBack, key, listBit, mat, p, uv);
             }
         }
     }
     for (size_t i = (size_t)rt.y0 * rt.W; i < (size_t)rt.y1 * rt.W; ++i) {       // only the scissor rows are cleared and written
         const uint64_t v = rt.packed[i];
         if (v == 0) { vis[i] = 0xFFFFF000u; depthOut[i] = 0.f; }
-        else { vis[i] = ((uint32_t)v - 1u) & 0x7fffffffu; depthOut[i] = u2f((uint32_t)(v >> 32)); }
+        else { vis[i] = (uint32_t)((v & 0x1ffffffffull) - 1u); depthOut[i] = u2f((uint32_t)(v >> 34)); }
     }
 }
 

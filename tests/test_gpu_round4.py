@@ -96,3 +96,97 @@ def test_raster_4k_bench_configuration_bands_vs_oracle(gpu_ctx, rt, R, sio, synt
         rr.close(); sky.close(); gpu_ctx.free(lut)
     finally:
         osc.close(); gscene.close()
+
+
+# ------------------------------------------------------------------------------------------------ path-tracer view modes 6-13
+def test_pathtrace_viewmode_7_mirror_bounce_vs_oracle(gpu_ctx, rt, sio, A, sponza_small, sponza_small_oracle, helmet, helmet_oracle):
+    """VIEWMODE 7, Reflections (pathtracing.hlsl:212-224): the first hit sends one mirror ray normalize(reflect(-V, N)) with the same payload and
+    returns -- no light loop, no sky sample, no SamplePoint at that vertex; from the second hit on the path is the normal one.  Against the
+    oracle with every outlier accounted for; the first vertex requests no shadow ray (its shadow word is 0) and every first hit continues."""
+    from parity_helpers import accounted_parity, NOT_TRACED
+
+    class Reflections(A.FConfig):
+        Viewmode = 7
+    for scene, osc, W, H, cap in ((sponza_small, sponza_small_oracle, 320, 180, 4e-4), (helmet, helmet_oracle, 256, 256, 2e-4)):
+        view = sio.FView().reset(scene, aspect=W / H)
+        sc = gpu_ctx.create_scene(scene)
+        pt = rt.PathTracer(gpu_ctx, sc, W, H)
+        g, o, _ = accounted_parity(rt, pt, osc, view, W, H, 3, cap=cap, label="viewmode 7", cfg=Reflections, min_outliers_allowed=3)
+        chain = pt.read_chain()
+        hit0 = (chain[..., 0, 0] != 0xffffffff) & (chain[..., 0, 0] != NOT_TRACED)
+        assert hit0.mean() > 0.3
+        assert (chain[..., 0, 2][hit0] == 0).all()                                  # no shadow query at the mirror vertex
+        assert (chain[..., 1, 0][hit0] != NOT_TRACED).all()                         # the mirror ray is always traced
+        assert g["stats"].bounce_rays >= int(hit0.sum())
+        # the normal mode's image differs (lights and sky at the first vertex)
+        pt.render(view, 3); n = pt.read()
+        assert not np.array_equal(n["target"], g["target"])
+        pt.close(); sc.close()
+
+
+@pytest.mark.parametrize("viewmode", [6, 8, 10, 13])
+def test_pathtrace_viewmodes_without_a_shader_branch_are_the_normal_path(gpu_ctx, rt, sio, A, sponza_small, viewmode):
+    """pathtracing.hlsl names VIEWMODE 1-5 and 7 only: compiled with 6 (NaN check, a tonemap-side view) or 8-13 (raster debug views) it is
+    the normal path tracer (path-tracing.inl:31-35 passes any FConfig::Viewmode).  Bit-identical target, history and ray counts."""
+    from parity_helpers import stats_tuple
+    W, H = 200, 112
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    sc = gpu_ctx.create_scene(sponza_small)
+
+    class Cfg(A.FConfig):
+        Viewmode = viewmode
+    a = rt.PathTracer(gpu_ctx, sc, W, H); b = rt.PathTracer(gpu_ctx, sc, W, H)
+    for n in (1, 2):
+        a.render(view, n); b.render(view, n, cfg=Cfg)
+    ra, rb = a.read(), b.read()
+    assert stats_tuple(ra["stats"]) == stats_tuple(rb["stats"]) and ra["stats"].light_shadow_rays > 0
+    np.testing.assert_array_equal(ra["target"], rb["target"]); np.testing.assert_array_equal(ra["history"], rb["history"])
+    with pytest.raises(rt.IncrError):
+        b.render(view, 1, cfg=type("Bad", (A.FConfig,), {"Viewmode": 14}))
+    a.close(); b.close(); sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ primitive path beyond 2,047 primitives
+def test_primitive_path_uses_all_12_bits_of_primitive_id(gpu_ctx, rt, R, sio, synth, ob, A):
+    """EncodePrimitiveVisibility keeps 12 bits of primitive id (encoding.hlsli:4-11).  Rounds 1-3 spent one of them on the draw-list order
+    of equal depths; the list bit now lives beside the depth in the 64-bit depth || list || id word.  A scene of 3,601 primitives (one per mesh)
+    through FConfig::UseMeshlets = false: ids, depth and G-buffers bit-exact against the oracle, ids above 2,047 on screen; 4,097 are refused."""
+    from test_gpu_raster import gpu_frame
+    from test_raster_host_and_oracle import run_oracle_frame
+
+    class Prims(A.FConfig):
+        UseMeshlets = False
+    scene = synth.bistro_scale(num_instances=3600, tris_per_mesh=64, num_materials=12, texture_size=8)
+    assert sum(len(p) for p in scene.mesh_primitives) == 3601
+    R.generate_meshlets(scene)                       # sizes the draw lists (one entry per meshlet >= one per primitive)
+    W, H = 384, 216
+    view = sio.FView()                                  # above the street, looking down the grid: thousands of props on screen
+    view.position = np.array([0, 45, -110], dtype=np.float32); view.look = np.array([0, -0.45, 1], dtype=np.float32); view.right = np.array([1, 0, 0], dtype=np.float32)
+    view.update_view_transform()
+    view.projection_transform = sio.reverse_z_infinite_perspective_fov_lh(0.8, W / H, A.FConfig.CameraNearPlane)
+    gscene = gpu_ctx.create_scene(scene)
+    osc = ob.OracleScene(scene)
+    try:
+        (vc, g), = gpu_frame(rt, R, gpu_ctx, gscene, view, W, H, Prims, frames=1)
+        _, hs = run_oracle_frame(ob, R, A, scene, osc, view, W, H, cfg=Prims)
+        o = hs.arr
+        np.testing.assert_array_equal(g["counts"], o["counts"])
+        np.testing.assert_array_equal(g["vis"], o["vis"])
+        np.testing.assert_array_equal(g["depth"].view(np.uint32), o["depth"].view(np.uint32))
+        for name in ("gbuffer_basecolor", "gbuffer_normals", "gbuffer_mra"):
+            np.testing.assert_array_equal(g[name], o[name], err_msg=name)
+        covered = g["vis"] != 0xFFFFF000
+        prim = g["vis"][covered] >> 20
+        print("primitive ids on screen: %d distinct, max %d, %.1f %% of the covered pixels above 2047" % (len(np.unique(prim)), prim.max(), 100 * (prim > 2047).mean()))
+        assert prim.max() == 3600 and len(np.unique(prim)) > 2000 and ((prim > 2047) & (prim < 3600)).mean() > 0.3
+    finally:
+        osc.close(); gscene.close()
+    big = synth.bistro_scale(num_instances=4096, tris_per_mesh=8, num_materials=4, texture_size=8)          # 4,097 primitives
+    gs2 = gpu_ctx.create_scene(big)
+    try:
+        rr = R.RasterRenderer(gpu_ctx, gs2, 64, 36, Prims)
+        with pytest.raises(rt.IncrError):
+            rr.render(sio.FView().reset(big, aspect=64 / 36))
+        rr.close()
+    finally:
+        gs2.close()

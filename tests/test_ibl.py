@@ -3,6 +3,7 @@ The chain goes through sinf/cosf/expf/tanf/acosf/atan2f/log2f, which differ in t
 math library, so radiance surfaces are compared within one R11G11B10 storage step (2^-5 relative on blue, 2^-6 on red /
 green) instead of bit for bit; everything that is pure arithmetic on given inputs is compared exactly."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -345,3 +346,146 @@ def test_gpu_hdri_sky_mode(rt, R, ob, A, sio, gpu_ctx, helmet, helmet_oracle):
         pt.close(); pt1.close(); sky.close()
     finally:
         gscene.close()
+
+
+# ------------------------------------------------------------------------------------------------ seamless cube filtering (round 4)
+def _random_cube(res, seed):
+    """a packed cube chain (levels res .. 1) of random high-contrast R11G11B10 texels"""
+    rng = np.random.default_rng(seed)
+    n, parts = res, []
+    while n >= 1:
+        # 11/11/10-bit floats with exponents 12..17: values between 2^-3 and 4
+        e = rng.integers(12, 18, (6 * n * n, 3), dtype=np.uint32)
+        m = rng.integers(0, 32, (6 * n * n, 3), dtype=np.uint32)
+        parts.append((e[:, 0] << 6 | m[:, 0]) | (e[:, 1] << 6 | m[:, 1]) << 11 | (e[:, 2] << 5 | (m[:, 2] & 31)) << 22)
+        n >>= 1
+    return np.ascontiguousarray(np.concatenate(parts).astype(np.uint32))
+
+
+def _cube_point(face, sc, tc):
+    """cube_face_uv inverted: the point of the cube surface with face coordinates (sc, tc) in [-1, 1]"""
+    return np.array([(1, -tc, -sc), (-1, -tc, sc), (sc, 1, tc), (sc, -1, -tc), (sc, -tc, 1), (-sc, -tc, -1)][face], dtype=np.float64)
+
+
+def _sample(ob, flat, res, mips, d, level=0.0):
+    out = (C.c_float * 3)()
+    ob.lib().orc_cube_sample(flat.ctypes.data, res, mips, (C.c_float * 3)(*[float(np.float32(v)) for v in d]), float(level), out)
+    return np.array(out[:], dtype=np.float64)
+
+
+def test_oracle_cube_filtering_is_seamless(ob):
+    """D3D11.3 TextureCube edge handling (consumers: pathtracing.hlsl:243, 308; sky-lighting.hlsl:123; envmap.hlsl:47): a bilinear tap beyond a
+    face edge comes from the adjacent face.  Checked against an INDEPENDENT adjacency: the neighbour of an edge texel is the texel of another
+    face whose centre is nearest (in 3-D) to the point one texel step beyond the edge.  On the edge itself, level with a texel centre, the
+    sample must be the mean of the two texels either side; approaching an edge from its two faces gives the same value; at a cube corner
+    the sample is the mean of the three corner texels (the missing fourth tap = mean of the other three)."""
+    res, mips = 8, 4
+    flat = _random_cube(res, 7)
+    lv0 = ob.unpack_r11g11b10(levels_cube(flat, res)[0]).astype(np.float64)              # [6, n, n, 3]
+    n = res
+    # all texel centres of the cube, for the brute-force neighbour search
+    centres = np.array([_cube_point(f, (2 * x + 1 - n) / n, (2 * y + 1 - n) / n) for f in range(6) for y in range(n) for x in range(n)])
+    index = [(f, y, x) for f in range(6) for y in range(n) for x in range(n)]
+    checked = 0
+    for f in range(6):
+        for side in range(4):                       # x beyond n-1, x beyond 0, y beyond n-1, y beyond 0
+            for k in range(n):
+                x, y = ((n - 1, k), (0, k), (k, n - 1), (k, 0))[side]
+                dx, dy = ((1, 0), (-1, 0), (0, 1), (0, -1))[side]
+                beyond = _cube_point(f, (2 * (x + dx) + 1 - n) / n, (2 * (y + dy) + 1 - n) / n)
+                dist = np.linalg.norm(centres - beyond, axis=1)
+                dist[[i for i, (ff, _, _) in enumerate(index) if ff == f]] = np.inf
+                nf, ny, nx = index[int(np.argmin(dist))]
+                # the direction of the edge point level with the texel centre
+                sc, tc = (2 * x + 1 - n) / n + dx / n, (2 * y + 1 - n) / n + dy / n
+                got = _sample(ob, flat, res, mips, _cube_point(f, sc, tc))
+                want = 0.5 * lv0[f, y, x] + 0.5 * lv0[nf, ny, nx]
+                np.testing.assert_allclose(got, want, rtol=2e-6, err_msg="face %d side %d texel %d: neighbour (%d, %d, %d)" % (f, side, k, nf, nx, ny))
+                checked += 1
+    assert checked == 6 * 4 * n
+    # continuity: the same edge point approached from either face
+    rng = np.random.default_rng(3)
+    for f in range(6):
+        for side in range(4):
+            for _ in range(8):
+                t = rng.uniform(-0.98, 0.98)
+                sc, tc = ((1.0, t), (-1.0, t), (t, 1.0), (t, -1.0))[side]
+                p = _cube_point(f, sc, tc)
+                inward = _cube_point(f, 0.0, 0.0)                       # the face centre: moving towards it stays on face f
+                a = _sample(ob, flat, res, mips, p + 1e-4 * (inward - p))
+                axis = int(np.argmax(np.abs(inward)))
+                q = p.copy(); q[axis] *= (1 - 1e-4)                      # shrinking the major component: the neighbouring face becomes the major one
+                b = _sample(ob, flat, res, mips, q)
+                assert np.abs(a - b).max() <= 2e-3 * max(a.max(), b.max()), (f, side, t, a, b)
+    # corners: mean of the three corner texels, on every level
+    for lvl, nn in enumerate((8, 4, 2, 1)):
+        lv = ob.unpack_r11g11b10(levels_cube(flat, res)[lvl]).astype(np.float64)
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    got = _sample(ob, flat, res, mips, (sx, sy, sz), level=lvl)
+                    three = []
+                    for f in range(6):
+                        for (yy, xx) in ((0, 0), (0, nn - 1), (nn - 1, 0), (nn - 1, nn - 1)):
+                            c = _cube_point(f, (2 * xx + 1 - nn) / nn, (2 * yy + 1 - nn) / nn)
+                            if np.sign(c[0]) == sx and np.sign(c[1]) == sy and np.sign(c[2]) == sz and (nn > 1 or True):
+                                if nn == 1:
+                                    continue
+                                three.append(lv[f, yy, xx])
+                    if nn == 1:          # 1 x 1 faces: the three faces that meet at the corner
+                        three = [lv[0 if sx > 0 else 1, 0, 0], lv[2 if sy > 0 else 3, 0, 0], lv[4 if sz > 0 else 5, 0, 0]]
+                    assert len(three) == 3
+                    np.testing.assert_allclose(got, np.mean(three, axis=0), rtol=3e-6, err_msg="corner (%d, %d, %d) level %d" % (sx, sy, sz, lvl))
+
+
+@pytest.mark.gpu
+def test_gpu_cube_edges_and_corners_equal_the_oracle(rt, R, ob, A, sio, gpu_ctx):
+    """The device sampler on every edge and corner of a random cube: EnvSkyMode 0 background (envmap.hlsl:47 -> cube level 0) of an empty
+    scene seen from the origin towards each of the 8 cube corners (a corner view holds the three edges that meet there) and the 6 face
+    centres, bit for bit against the oracle's pass; the path tracer's msEnvmap (pathtracing.hlsl:308) on the same views."""
+    res, mips = 8, 4
+    flat = _random_cube(res, 11)
+    dev = gpu_ctx.buffer(flat.nbytes); gpu_ctx.upload(dev, flat)
+
+    class Hdri(A.FConfig):
+        EnvSkyMode = 0
+        EnableTAA = False
+    s = sio.PackedScene()
+    gscene = gpu_ctx.create_scene(s)
+    osc = ob.OracleScene(s)
+    W = H = 96
+    try:
+        looks = [(sx, sy, sz) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] + [(1, 0, 0), (-1, 0, 0), (0, 1, 0.001), (0, -1, 0.001), (0, 0, 1), (0, 0, -1)]
+        for look in looks:
+            view = sio.FView()
+            view.position = np.zeros(3, dtype=np.float32)
+            view.look = np.array(look, dtype=np.float32)
+            view.right = np.cross(np.array([0.0, 1.0, 0.0]), view.look).astype(np.float32)
+            view.update_view_transform()
+            view.projection_transform = sio.reverse_z_infinite_perspective_fov_lh(1.2, 1.0, A.FConfig.CameraNearPlane)
+            rr = R.RasterRenderer(gpu_ctx, gscene, W, H, Hdri); rr.ibl = R.IblInputs(None, dev, res, mips)
+            vc = rr.render(view); gpu_ctx.synchronize()
+            hs = ob.HostSurfaces(W, H, 0, 16 * 9 * 24, 64)
+            for name, d in R.build_descs(None, s, vc, hs.ptr, 0, Hdri, ibl=R.IblInputs(None, flat.ctypes.data, res, mips)):
+                ob.run_pass(osc, name, d)
+            color = rr.surf.download("color")
+            np.testing.assert_array_equal(color, hs.arr["color"], err_msg="look %s" % (look,))
+            assert len(np.unique(color)) > 50                           # texels of several faces, filtered
+            rr.close()
+            pt = rt.PathTracer(gpu_ctx, gscene, W, H)
+            pt.render(view, 1, cfg=Hdri, envmap=(dev, res, mips)); g = pt.read()
+            o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1, cfg=Hdri, envmap=(flat.ctypes.data, res, mips)), num_threads=8)
+            np.testing.assert_array_equal(g["target"], o["target"], err_msg="msEnvmap, look %s" % (look,))
+            pt.close()
+    finally:
+        gpu_ctx.free(dev); osc.close(); gscene.close()
+
+
+def test_golden_sky_ibl(ob, sky16):
+    """tests/golden/sky_ibl_16.npz (tools/make_golden.py): the oracle's FScene::UpdateDynamicSky products at 16^2 -- lat-long chain, source
+    cube, prefiltered cube (1024 trilinear cube taps per texel, many across face edges) and SH9 -- reproduce bit for bit."""
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests/golden/sky_ibl_16.npz"))
+    for k in ("latlong", "source_cube", "envmap"):
+        np.testing.assert_array_equal(sky16[k], g[k], err_msg=k)
+    np.testing.assert_array_equal(sky16["sh9"].view(np.uint32), g["sh9"].view(np.uint32))

@@ -242,3 +242,26 @@ def test_content_cache_round_trip(sio, tmp_path):
     assert c.content_cache_stats["misses"] == 5 and len(os.listdir(dst / ".content-cache")) == 10
     plain = sio.load_gltf(path, max_texture_size=64)
     assert all(np.array_equal(x[0], y[0]) for x, y in zip(a.textures, plain.textures))
+
+
+def test_oracle_viewmode_7_mirror_bounce(ob, rt, sio, A, helmet, helmet_oracle):
+    """VIEWMODE 7 (pathtracing.hlsl:212-224) in the oracle: the first hit traces no shadow ray (its shadow word is 0) and always continues
+    with one mirror ray; later vertices are ordinary.  VIEWMODE 6 and 8-13 have no branch in the shader: the normal path."""
+    W = H = 48
+    view = sio.FView().reset(helmet, aspect=1.0)
+    NOT_TRACED = 0xfffffffe
+
+    def run(vm):
+        cfg = type("Cfg", (A.FConfig,), {"Viewmode": vm})
+        return helmet_oracle.pathtrace(rt.make_pathtrace_desc(view, W, H, 2, cfg=cfg), num_threads=os.cpu_count() or 1, want_chain=True)
+    n, r = run(0), run(7)
+    hit0 = (r["chain"][..., 0, 0] != 0xffffffff) & (r["chain"][..., 0, 0] != NOT_TRACED)
+    assert hit0.sum() > 200
+    np.testing.assert_array_equal(r["chain"][..., 0, :2], n["chain"][..., 0, :2])          # same camera rays, same first hits
+    assert (r["chain"][..., 0, 2][hit0] == 0).all() and (n["chain"][..., 0, 2][hit0] != 0).any()
+    assert (r["chain"][..., 1, 0][hit0] != NOT_TRACED).all()
+    assert r["stats"].bounce_rays >= int(hit0.sum()) and r["stats"].sky_shadow_rays < n["stats"].sky_shadow_rays
+    assert not np.array_equal(r["target"], n["target"])
+    for vm in (6, 8, 13):
+        o = run(vm)
+        np.testing.assert_array_equal(o["target"], n["target"]); np.testing.assert_array_equal(o["chain"], n["chain"])

@@ -134,4 +134,9 @@ for name, dsc in R.build_descs(None, s, vcr, hs.ptr, 0, NoTaa):
     ob.run_pass(osc, name, dsc)
 np.savez_compressed(os.path.join(G, "helmet_raster_64.npz"), vis=hs.arr["vis"], depth=hs.arr["depth"], g0=hs.arr["gbuffer_basecolor"],
                     g1=hs.arr["gbuffer_normals"], g2=hs.arr["gbuffer_mra"], color=hs.arr["color"], counts=hs.arr["counts"])
+
+# ---- sky / IBL precompute at 16^2 (FScene::UpdateDynamicSky): lat-long chain, source cube, GGX-prefiltered cube (its taps cross face
+#      edges: seamless cube filtering), SH9
+sky = ob.update_dynamic_sky((0.35, 0.8, 0.48), 2.0, resolution=16)
+np.savez_compressed(os.path.join(G, "sky_ibl_16.npz"), latlong=sky["latlong"], source_cube=sky["source_cube"], envmap=sky["envmap"], sh9=sky["sh9"])
 print("golden written:", sorted(os.listdir(G)))

@@ -88,6 +88,8 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
 }
 static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved records shadow_gen keeps in LDS (10 KB)
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
+static constexpr uint32_t kGenOrderCap = 2048;         // rays of one workgroup (256 vertices) that the light-major order handles; beyond that the vertex-major order stays
+static constexpr uint32_t kGenBins = kGenLdsLights + 4; // one bin per scene light (when they fit the LDS table) + the sky samples by direction quadrant
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
 // Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
@@ -111,6 +113,14 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
 static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;
 static constexpr uint32_t kMissTri = 0xffffffffu;
+#ifndef INCR_WF_LIGHT_MAJOR
+#define INCR_WF_LIGHT_MAJOR 0      // 0: the vertex-major queue order of rounds 1-3 (A/B builds)
+#endif
+static constexpr bool kWfLightMajor = INCR_WF_LIGHT_MAJOR != 0;
+#ifndef INCR_WF_OCC_CACHE
+#define INCR_WF_OCC_CACHE 0        // a shadow lane tests the triangle that occluded its previous ray first (A/B builds: 0)
+#endif
+static constexpr bool kWfOccCache = INCR_WF_OCC_CACHE != 0;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
 static constexpr int kCursorBase = 16, kRayCountBase = 32;
 
@@ -442,6 +452,11 @@ struct ShadowGenLds {
     float2 vyz[kWfBlock];
     float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
     uint32_t base;
+    // LIGHT-MAJOR queue order (round 4): a workgroup's rays are written light by light -- bin = the light's index in the scene, four more for the sky
+    // samples by direction quadrant -- instead of vertex by vertex: the 64 rays of a shadow wave then converge on one light from neighbouring
+    // origins (bounce 0: the pixels of four 8 x 8 tiles).  info[r] = owner vertex | request slot << 8 | bin << 15 | rank in the bin << 23.
+    uint32_t info[kGenOrderCap];
+    uint32_t bin[kGenBins + 1];
 };
 // What a lane brings for its list slot: the vertex wf_shade_kernel made (or nothing: a miss, a slot past the list's end).
 struct ShadowGenVertex {
@@ -536,19 +551,52 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
         }
         return out;
     }
-    if (n) out.rayBase = base + s_prefix[tid];                                  // the vertex's rays are [rayBase, rayBase + popc(mask)), ascending slot
-    for (uint32_t r = tid; r < total; r += kWfBlock) {
-        // owner vertex: the last v with s_prefix[v] <= r
+    if (n) out.rayBase = base + s_prefix[tid];                                  // the vertex's RECORDS (rayC) are [rayBase, rayBase + popc(mask)), ascending slot
+    // Which ray is record r?  Owner vertex = the last v with s_prefix[v] <= r, request slot = the (r - s_prefix[v])-th set bit of its mask.
+    auto decode = [&](uint32_t r, uint32_t* owner, uint32_t* slotOut) {
         uint32_t lo = 0u, hi = kWfBlock;
 #pragma unroll
         for (int it = 0; it < 8; ++it) { const uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= r) lo = mid; else hi = mid; }
         uint32_t j = r - s_prefix[lo];
         const uint4 m = s_mask[lo];
-        const uint32_t vp = s_pid[lo];
         uint32_t word = m.x, wbase = 0u;
         const uint32_t c0 = (uint32_t)__popc(m.x), c1 = (uint32_t)__popc(m.y), c2 = (uint32_t)__popc(m.z);
         if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
-        const uint32_t slot = wbase + nth_set_bit(word, j);
+        *owner = lo; *slotOut = wbase + nth_set_bit(word, j);
+    };
+    // ---- queue order.  The RECORD of a ray (rayC: its radiance and visibility, what accumulate sums in chsMain's loop order) stays at base + r,
+    //      vertex-major; its QUEUE entry (rayQ: what the traversal kernel walks) goes to base + order(r) and names the record in direction.w.
+    const bool reorder = kWfLightMajor && ldsLights && total <= kGenOrderCap;
+    if (reorder) {
+        for (uint32_t b = tid; b <= kGenBins; b += kWfBlock) S.bin[b] = 0u;
+        __syncthreads();
+        for (uint32_t r = tid; r < total; r += kWfBlock) {
+            uint32_t lo, slot; decode(r, &lo, &slot);
+            uint32_t bin;
+            if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; bin = kGenLdsLights + (v4.x < 0.f ? 1u : 0u) + (v4.y < 0.f ? 2u : 0u); }
+            else bin = P.gridCellLights[__float_as_uint(s_pos[lo].w) + slot];
+            const uint32_t rank = atomicAdd(&S.bin[bin], 1u);                  // < 512: a vertex asks for a light at most once, 256 vertices
+            S.info[r] = lo | (slot << 8) | (bin << 15) | (rank << 23);
+        }
+        __syncthreads();
+        if (wave == 0u) {          // exclusive scan of the bin counts: three bins per lane, wave scan, write back
+            uint32_t c[3], sum = 0u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const uint32_t b = lane * 3u + (uint32_t)k; c[k] = b < kGenBins ? S.bin[b] : 0u; sum += c[k]; }
+            uint32_t incl2 = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl2, off, 64); if (lane >= (uint32_t)off) incl2 += v; }
+            uint32_t run = incl2 - sum;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const uint32_t b = lane * 3u + (uint32_t)k; if (b < kGenBins) S.bin[b] = run; run += c[k]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t r = tid; r < total; r += kWfBlock) {
+        uint32_t lo, slot, dest = r;
+        if (reorder) { const uint32_t e = S.info[r]; lo = e & 0xffu; slot = (e >> 8) & 0x7fu; dest = S.bin[(e >> 15) & 0xffu] + (e >> 23); }
+        else decode(r, &lo, &slot);
+        const uint32_t vp = s_pid[lo];
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
         f3 L, contribution = {0.f, 0.f, 0.f};
@@ -578,8 +626,8 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
             contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
         }
-        B.rayQ[(size_t)(base + r) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
-        B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(slot));
+        B.rayQ[(size_t)(base + dest) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
+        B.rayQ[(size_t)(base + dest) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(base + r));      // .w: the ray's record
         B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
     }
     return out;
@@ -808,7 +856,8 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
-    uint32_t rayIndex = 0, nextIndex = 0;
+    uint32_t rayIndex = 0;
+    uint32_t lastOcc = 0xffffffffu;      // occluder cache: the triangle record that ended this lane's previous occluded ray
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
     TravAny2 T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.1f, 1000.f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     LANE_STATS(LaneStats ls;)
@@ -817,18 +866,22 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
         const uint32_t idle = 64u - (uint32_t)__popcll(act);
         if (!chunk.exhausted && (idle >= kShadowRefill || act == 0ull)) {
             LANE_STATS(ls.refills++;)
-            if (occludedDone) { ((float*)(B.rayC + rayIndex))[3] = 0.f; occludedDone = false; }
+            if (occludedDone) { ((float*)(B.rayC + rayIndex))[3] = 0.f; occludedDone = false; }          // rayIndex = the ray's RECORD (direction.w of its queue entry)
             const uint32_t item = chunk.take(!active, cursor, total);
-            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; nextIndex = item; pending = true; }
+            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; pending = true; }
         }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
-        if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; active = false; }      // node step and triangle step in one iteration
+        if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; if (kWfOccCache && T.occluded) lastOcc = T.hitTri; active = false; }      // node step and triangle step in one iteration
         if (pending) {
             pending = false;
-            rayIndex = nextIndex;
+            rayIndex = __float_as_uint(qb.w);
             if (__float_as_uint(qa.w) != 0xffffffffu) {
                 trav_any_begin(T, {qa.x, qa.y, qa.z}, {qb.x, qb.y, qb.z}, 0.1f, 1000.f);     // lighting/common.hlsli:96-100
                 T.haveCur = true; T.triBase1 = 0; T.triMask1 = 0;
+                // occluder cache: any front-facing triangle in the interval occludes (lighting/common.hlsli:102-115: order-independent), so the
+                // triangle that stopped the lane's previous ray -- with the light-major queue order a ray to the same light from a neighbouring
+                // origin -- is tested first, in the triangle slot of the root's node step (the overlapped step runs both): no extra iteration
+                if (kWfOccCache && lastOcc != 0xffffffffu) { T.triBase = lastOcc; T.triMask = 1u; }
                 st.reset();
                 active = true;
             }

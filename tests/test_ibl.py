@@ -475,7 +475,12 @@ def test_gpu_cube_edges_and_corners_equal_the_oracle(rt, R, ob, A, sio, gpu_ctx)
             pt = rt.PathTracer(gpu_ctx, gscene, W, H)
             pt.render(view, 1, cfg=Hdri, envmap=(dev, res, mips)); g = pt.read()
             o = osc.pathtrace(rt.make_pathtrace_desc(view, W, H, 1, cfg=Hdri, envmap=(flat.ctypes.data, res, mips)), num_threads=8)
-            np.testing.assert_array_equal(g["target"], o["target"], err_msg="msEnvmap, look %s" % (look,))
+            # the camera ray goes through sin / cos (lens sample): a direction may differ by an ulp between device and host, the filtered cube
+            # value with it -- continuous across texel and face boundaries now, so every pixel stays within the colour tolerance
+            gt = g["target"].view(np.float16).astype(np.float32); ot = o["target"].view(np.float16).astype(np.float32)
+            same = (g["target"] == o["target"]).all(axis=-1)
+            assert same.mean() > 0.999, (look, same.mean())
+            assert (np.abs(gt - ot) <= 2.0 ** -7 * np.maximum(np.abs(ot), 1e-3)).all(), "msEnvmap, look %s" % (look,)
             pt.close()
     finally:
         gpu_ctx.free(dev); osc.close(); gscene.close()

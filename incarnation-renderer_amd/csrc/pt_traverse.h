@@ -71,24 +71,37 @@ struct PrivStackT {
 using LaneStack = LaneStackT<kStackLds, kBlock>;
 DI uint32_t stack_entry(uint32_t childBase, bool reverse, uint32_t slotMask) { return childBase << 9 | (reverse ? 0x100u : 0u) | slotMask; }
 
-// Moeller-Trumbore on the stored (v0, e1, e2); every operation unfused and in a pinned order: t, u, v are part of
+// Moeller-Trumbore on the stored (v0, e1, e2); every operation unfused and in a pinned order: the hit predicate and t, u, v are part of
 // the parity contract (bit-exact against the CPU oracle).  a, b, c = the three dwordx4 of a TriIsect record.
-DI bool tri_intersect(const float4 a, const float4 b, const float4 c, f3 o, f3 d, float tmin, float tmax,
-                      float* t, float* u, float* v, uint32_t* flatId, uint32_t* flags) {
+// The PREDICATE "the ray hits the triangle inside (tmin, tmax)" is evaluated on the UNSCALED numerators (round 4; rounds 1-3 divided first):
+//     det = e1 . (d x e2) > 0          (RAY_FLAG_CULL_BACK_FACING_TRIANGLES)
+//     U = (o - v0) . (d x e2),  V = d . ((o - v0) x e1),  T = e2 . ((o - v0) x e1)
+//     0 <= U <= det,  0 <= V,  U + V <= det,  tmin det < T < tmax det
+// -- the same triangle up to the last ulp of its edges, and what a shadow query needs is only this: an any-hit test costs no division
+// (~12 instructions of the ~62 of a triangle step in kernels that are VALU-issue bound).  A closest-hit query divides once the
+// predicate holds: t = T / det, u = U / det, v = V / det as products with the correctly rounded 1 / det, the values of rounds 1-3.
+DI bool tri_hit(const float4 a, const float4 b, const float4 c, f3 o, f3 d, float tmin, float tmax, float* det, float* U, float* V, float* Tn) {
     const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
     const f3 pv = cross(d, e2);
-    const float det = dot(e1, pv);
-    if (!(det > 0.f)) return false;                       // RAY_FLAG_CULL_BACK_FACING_TRIANGLES
-    const float inv = 1.f / det;
+    const float dt = dot(e1, pv);
+    if (!(dt > 0.f)) return false;
     const f3 sv = o - v0;
-    const float uu = dot(sv, pv) * inv;
-    if (!(uu >= 0.f && uu <= 1.f)) return false;
+    const float uu = dot(sv, pv);
+    if (!(uu >= 0.f && uu <= dt)) return false;
     const f3 q = cross(sv, e1);
-    const float vv = dot(d, q) * inv;
-    if (!(vv >= 0.f && uu + vv <= 1.f)) return false;
-    const float tt = dot(e2, q) * inv;
-    if (!(tt > tmin && tt < tmax)) return false;
-    *t = tt; *u = uu; *v = vv;
+    const float vv = dot(d, q);
+    if (!(vv >= 0.f && uu + vv <= dt)) return false;
+    const float tt = dot(e2, q);
+    if (!(tt > tmin * dt && tt < tmax * dt)) return false;
+    *det = dt; *U = uu; *V = vv; *Tn = tt;
+    return true;
+}
+DI bool tri_intersect(const float4 a, const float4 b, const float4 c, f3 o, f3 d, float tmin, float tmax,
+                      float* t, float* u, float* v, uint32_t* flatId, uint32_t* flags) {
+    float det, U, V, Tn;
+    if (!tri_hit(a, b, c, o, d, tmin, tmax, &det, &U, &V, &Tn)) return false;
+    const float inv = 1.f / det;
+    *t = Tn * inv; *u = U * inv; *v = V * inv;
     *flatId = __float_as_uint(c.y); *flags = __float_as_uint(c.z);
     return true;
 }
@@ -401,8 +414,8 @@ template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& 
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
     if (wantTri) {
         T.triMask &= T.triMask - 1u;
-        float t, u, v; uint32_t flat, flags;
-        if (tri_intersect(ta, tb, tc, T.rs.o, T.d, T.tmin, T.tmax, &t, &u, &v, &flat, &flags)) { T.occluded = true; T.hitTri = ti; return true; }
+        float det, U, V, Tn;
+        if (tri_hit(ta, tb, tc, T.rs.o, T.d, T.tmin, T.tmax, &det, &U, &V, &Tn)) { T.occluded = true; T.hitTri = ti; return true; }
         if (!T.triMask) { T.triBase = T.triBase1; T.triMask = T.triMask1; T.triMask1 = 0u; }
     }
     if (wantNode) {

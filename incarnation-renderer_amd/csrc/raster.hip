@@ -849,8 +849,8 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
             triMask &= triMask - 1u;
             const float4* __restrict__ tp = (const float4*)(P.tris + ti);
             const float4 a = tp[0], b = tp[1], c = tp[2];
-            float t, u, v; uint32_t flat, flags;
-            if (alive && tri_intersect(a, b, c, rs.o, d, tmin, tmax, &t, &u, &v, &flat, &flags)) { occluded = true; alive = false; }
+            float det, U, V, Tn;
+            if (alive && tri_hit(a, b, c, rs.o, d, tmin, tmax, &det, &U, &V, &Tn)) { occluded = true; alive = false; }
             if (__ballot(alive) == 0ull) break;
         }
         const uint32_t inner = any & imask;

@@ -422,25 +422,29 @@ static MatProps EvaluateMaterialPropertiesGrad(const Scene& s, const incr_materi
 //    i.e. det = dot(e1, cross(d, e2)) > 0 with object-space vertex order; when the instance transform
 //    mirrors (det3 < 0, e.g. the RH2LH root) v1 and v2 are swapped in the flattened triangle and the
 //    barycentrics swapped back on hit.
-//  * ray/triangle: Moeller-Trumbore on (v0, e1, e2), interval tmin < t < tmax, closest hit with
+//  * ray/triangle: Moeller-Trumbore on (v0, e1, e2), interval tmin det < T < tmax det (see tri_intersect), closest hit with
 //    ties broken towards the smaller flattened triangle id (traversal-order independent).
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; uint32_t tri; };
 
+// The hit predicate is pinned on the UNSCALED Moeller-Trumbore numerators (no division decides a hit: round 4; rounds 1-3 compared the
+// quotients): front-facing, 0 <= U <= det, 0 <= V, U + V <= det, tmin det < T < tmax det.  t, u, v of an accepted hit are the
+// numerators times the correctly rounded reciprocal of det.  DXR leaves the watertightness of the test to the implementation; this
+// is one such choice, shared by the closest-hit and the any-hit queries.
 static inline bool tri_intersect(const Scene::Tri& T, float3 o, float3 d, float tmin, float tmax, float* t, float* u, float* v) {
     float3 p = cross(d, T.e2);
     float det = dot(T.e1, p);
     if (!(det > 0.f)) return false;                 // RAY_FLAG_CULL_BACK_FACING_TRIANGLES (and degenerate)
-    float inv = 1.f / det;
     float3 sv = o - T.v0;
-    float uu = dot(sv, p) * inv;
-    if (!(uu >= 0.f && uu <= 1.f)) return false;
+    float un = dot(sv, p);
+    if (!(un >= 0.f && un <= det)) return false;
     float3 q = cross(sv, T.e1);
-    float vv = dot(d, q) * inv;
-    if (!(vv >= 0.f && uu + vv <= 1.f)) return false;
-    float tt = dot(T.e2, q) * inv;
-    if (!(tt > tmin && tt < tmax)) return false;
-    *t = tt; *u = uu; *v = vv;
+    float vn = dot(d, q);
+    if (!(vn >= 0.f && un + vn <= det)) return false;
+    float tn = dot(T.e2, q);
+    if (!(tn > tmin * det && tn < tmax * det)) return false;
+    float inv = 1.f / det;
+    *t = tn * inv; *u = un * inv; *v = vn * inv;
     return true;
 }
 static inline bool box_intersect(const Scene::Node& n, float3 o, float3 invd, float tmin, float tmax) {

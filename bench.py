@@ -341,6 +341,9 @@ def main():
                          "0 = the library's choice: 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels). "
                          "With more than one, launches of different bands overlap and stretch each other: the per-kernel times then price launches "
                          "that share the GPU; --pipelines 1 times every kernel alone (profiles/ holds both)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="bounce overlap (incr_set_pathtrace_overlap: the closest-hit launch of bounce b + 1 runs beside the any-hit launch of bounce b on a side "
+                         "stream); auto = the library's default (on), except with --pipelines 1, whose purpose is to time every kernel alone")
     ap.add_argument("--spp-per-gather", type=int, default=64,
                     help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
                          "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
@@ -413,6 +416,8 @@ def main():
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
     ctx.set_pathtrace_pipelines(max(0, min(args.pipelines, 8)))
+    if args.overlap != "auto" or args.pipelines == 1:
+        ctx.set_pathtrace_overlap(args.overlap == "on")
     scene = ctx.create_scene(packed)
     info = scene.info()
     # load-time precompute, as the reference does once per scene / sun change (FScene::UpdateDynamicSky at
@@ -526,7 +531,7 @@ def main():
         # Between those two the overlapped intervals are within a few per cent of each other and trade places from run to run, while alone
         # the any-hit kernel is the longer one (7.6 vs 7.0 ms per frame) because it traces more rays: with pipelines > 1 the one that moves
         # more algorithmic bytes is taken -- a choice that does not flip with timing noise.
-        if prof.pipelines <= 1:
+        if prof.pipelines <= 1 and not prof.overlap:
             dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
         else:
             dominant = max(("incr::wf_extend_kernel", "incr::wf_shadow_kernel"), key=lambda k: per_kernel[k][2])
@@ -544,7 +549,7 @@ def main():
             "config": {"workload": "path trace %s %dx%d 1 spp/step (BASELINE config 4 scene: deterministic Sponza-stat, 262,267 tris, 65 lights)"
                                    % (args.scene, W, H) if args.scene == "sponza" else "path trace %s %dx%d 1 spp/step" % (args.scene, W, H),
                        "scene": args.scene, "resolution": [W, H], "spp_per_step": 1, "triangles": int(info.num_triangles),
-                       "lights": len(packed.global_lights), "texture_size": args.texture_size, **({"textures": "block-compressed chains (BC3 / BC5)"} if args.block_compress else {}), "pipelines": int(prof.pipelines), "samples_in_flight": sif,
+                       "lights": len(packed.global_lights), "texture_size": args.texture_size, **({"textures": "block-compressed chains (BC3 / BC5)"} if args.block_compress else {}), "pipelines": int(prof.pipelines), "bounce_overlap": bool(prof.overlap), "samples_in_flight": sif,
                        "sharding": "none" if not collective else "interleaved 8-row blocks + RCCL all_gather of the R11G11B10F history every %d samples and after the last step" % spg,
                        "rays_per_step": rays // args.steps, "shaded_hits_per_step": hits // args.steps,
                        "ms_per_frame": round(dt / args.steps * 1e3, 4),
@@ -555,7 +560,7 @@ def main():
                          "kernel_timing": ("HIP events on each pipeline's stream; %d pipelines overlap, so a launch shares the GPU with the other bands' "
                                            "kernels while it is timed (sum of kernel_ms_per_step > ms_per_step; the streaming kernels' intervals are mostly waiting for CUs, "
                                            "so the dominant kernel is picked among the two traversal kernels); --pipelines 1 times kernels alone" % prof.pipelines)
-                                          if prof.pipelines > 1 else "HIP events on the launch stream, one pipeline: every kernel has the GPU to itself",
+                                          if (prof.pipelines > 1 or prof.overlap) else "HIP events on the launch stream, one pipeline, no bounce overlap: every kernel has the GPU to itself",
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX,
                          "whole_call": {"ms": round(call_ms, 4), "algorithmic_bytes": int(frame_alg_bytes),
@@ -570,7 +575,7 @@ def main():
                     tj = json.load(f)
                 entry = tj.get("kernels", {}).get(dominant)
                 default_workload = args.scene == "sponza" and [W, H] == [3840, 2160] and not args.no_direct_lighting and args.viewmode == 0
-                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == int(prof.pipelines):
+                if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == int(prof.pipelines) and bool(tj.get("bounce_overlap", False)) == bool(prof.overlap):
                     out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tj.get("source")
                     # the traversal kernels are VALU-issue bound: instructions per launch x 4 cycles per wave64

@@ -19,7 +19,8 @@
 using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
-                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events);
+                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap);
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
                                              const uint32_t* ranges, uint32_t numRanges, void* nodeBoxes, hipStream_t stream);
@@ -66,7 +67,7 @@ const Roctx& roctx() { static const Roctx r; return r; }
 void incr_roctx_push(const char* name) { const Roctx& r = roctx(); if (r.push) (void)r.push(name); }
 void incr_roctx_pop() { const Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
 
-static constexpr int kProfEvents = 22;      // per pipeline of a recorded incr_pathtrace call: start + generate + 4 x (extend, shade, shadow_gen, shadow, accumulate)
+static constexpr int kProfEvents = kWfProfEvents;      // per pipeline of a recorded incr_pathtrace call (pt_params.h)
 static constexpr int kMaxPipes = 8;
 
 static void fill_scene_params(const incr_context* ctx, const incr_scene* sc, PtParams& P);
@@ -115,6 +116,8 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     ctx->wfPipesWanted = pe ? std::min(std::max(atoi(pe), 1), kMaxPipes) : INCR_WF_PIPELINES_DEFAULT;
     ctx->wfPipes = 1; memset(ctx->wfTileRow, 0, sizeof ctx->wfTileRow);
     memset(ctx->wfStreams, 0, sizeof ctx->wfStreams); memset(ctx->wfJoin, 0, sizeof ctx->wfJoin);
+    memset(ctx->wfSideStreams, 0, sizeof ctx->wfSideStreams); memset(ctx->wfBounceFork, 0, sizeof ctx->wfBounceFork); memset(ctx->wfBounceJoin, 0, sizeof ctx->wfBounceJoin);
+    { const char* ov = getenv("INCR_WF_OVERLAP"); ctx->wfOverlap = ov ? atoi(ov) != 0 : true; }          // bounce overlap (pathtrace_wf.hip launcher), incr_set_pathtrace_overlap
     HIP_TRY(hipEventCreateWithFlags(&ctx->wfFork, hipEventDisableTiming));      // the pipelines' own streams are created on first use
     ctx->profiling = false; ctx->profFrames = 0;
     ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
@@ -131,6 +134,8 @@ int incr_teardown(incr_context* ctx) {
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->wfStage) (void)hipFree(ctx->wfStage);
     for (int i = 1; i < kMaxPipes; ++i) { if (ctx->wfStreams[i]) (void)hipStreamDestroy(ctx->wfStreams[i]); if (ctx->wfJoin[i]) (void)hipEventDestroy(ctx->wfJoin[i]); }
+    for (int i = 0; i < kMaxPipes; ++i) if (ctx->wfSideStreams[i]) (void)hipStreamDestroy(ctx->wfSideStreams[i]);
+    for (int i = 0; i < kMaxPipes * 4; ++i) { if (ctx->wfBounceFork[i]) (void)hipEventDestroy(ctx->wfBounceFork[i]); if (ctx->wfBounceJoin[i]) (void)hipEventDestroy(ctx->wfBounceJoin[i]); }
     if (ctx->wfFork) (void)hipEventDestroy(ctx->wfFork);
     if (ctx->rasterBlock) (void)hipFree(ctx->rasterBlock);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
@@ -299,12 +304,19 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
     const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u * numSamples;       // samples in flight: the tile rows of one sample after the other
     // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
     // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
-    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u);
+    // With bounce overlap every pipeline owns two streams and the runtime multiplexes more than four streams onto its hardware queues (helmet
+    // 1080p: 1.10 ms with two pipelines, 1.46 with three, 2.16 with four): two pipelines whatever the size (a 1/8 shard of 4K, 8 samples
+    // in flight: 2.39 ms per sample with four pipelines and no overlap, 2.30 with two and overlap; gpurun_out/r4_ab_overlap.txt -> profiles/).
+    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : (ctx->wfOverlap ? 2u : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u));
     const int pipes = (int)std::max(1u, std::min<uint32_t>(wanted, tilesY / 4u));      // >= 4 tile rows each
     ctx->wfPipes = pipes;
     for (int i = 1; i < pipes; ++i) if (!ctx->wfStreams[i]) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->wfStreams[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ctx->wfJoin[i], hipEventDisableTiming));
+    }
+    if (ctx->wfOverlap) for (int i = 0; i < pipes; ++i) if (!ctx->wfSideStreams[i]) {          // bounce overlap: a side stream + a fork / join event pair per bounce
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->wfSideStreams[i], hipStreamNonBlocking));
+        for (int b = 0; b < 4; ++b) { HIP_TRY(hipEventCreateWithFlags(&ctx->wfBounceFork[i * 4 + b], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->wfBounceJoin[i * 4 + b], hipEventDisableTiming)); }
     }
     uint64_t n[kMaxPipes], rayCap[kMaxPipes], need = 0;
     for (int i = 0; i <= pipes; ++i) ctx->wfTileRow[i] = (uint32_t)((uint64_t)tilesY * i / pipes);
@@ -317,6 +329,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         for (int i = 1; i < kMaxPipes; ++i) if (ctx->wfStreams[i]) HIP_TRY(hipStreamSynchronize(ctx->wfStreams[i]));
+        for (int i = 0; i < kMaxPipes; ++i) if (ctx->wfSideStreams[i]) HIP_TRY(hipStreamSynchronize(ctx->wfSideStreams[i]));
         if (ctx->wfBlock) { HIP_TRY(hipFree(ctx->wfBlock)); ctx->wfBlock = nullptr; ctx->wfBytes = 0; }
         HIP_TRY(hipMalloc(&ctx->wfBlock, need));
         ctx->wfBytes = need;
@@ -823,12 +836,13 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
         const size_t perCall = (size_t)kProfEvents * kMaxPipes;
         while (ctx->profEvents.size() < (ctx->profFrames + 1) * perCall) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->profEvents.push_back(e); }
         ev = ctx->profEvents.data() + ctx->profFrames * perCall;
-        ctx->profPipes.push_back(ctx->wfPipes);
+        ctx->profPipes.push_back(ctx->wfPipes | (ctx->wfOverlap ? 0x100 : 0));
         ctx->profFrames++;
     }
     const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
     ctx->wfStreams[0] = (hipStream_t)stream;
-    HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev));
+    HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev,
+                                     ctx->wfSideStreams, ctx->wfBounceFork, ctx->wfBounceJoin, ctx->wfOverlap ? 1 : 0));
     return INCR_OK;
 }
 
@@ -878,6 +892,12 @@ int incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines) {
     return INCR_OK;
 }
 
+int incr_set_pathtrace_overlap(incr_context* ctx, int32_t enable) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    ctx->wfOverlap = enable != 0;
+    return INCR_OK;
+}
+
 int incr_profile_begin(incr_context* ctx) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     ctx->profiling = true; ctx->profFrames = 0; ctx->profPipes.clear();
@@ -893,14 +913,23 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     double* cls[5] = {&out->extend_ms, &out->shade_ms, &out->shadow_gen_ms, &out->shadow_ms, &out->accumulate_ms};
     // every pipeline's kernels are timed on the pipeline's own stream; with more than one pipeline the intervals of different
     // pipelines overlap in time, so the per-kernel sums can exceed the frame's wall time (they price the kernels, not the frame)
-    for (size_t f = 0; f < ctx->profFrames; ++f) for (int pipe = 0; pipe < ctx->profPipes[f]; ++pipe) {
+    for (size_t f = 0; f < ctx->profFrames; ++f) for (int pipe = 0; pipe < (ctx->profPipes[f] & 0xff); ++pipe) {
         hipEvent_t* ev = ctx->profEvents.data() + (f * kMaxPipes + pipe) * kProfEvents;
+        const bool overlapped = (ctx->profPipes[f] & 0x100) != 0;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); out->generate_ms += ms;
-        for (int k = 0; k < 20; ++k) { HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k])); *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++; }
+        for (int k = 0; k < 20; ++k) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k]));
+            if (overlapped && k % 5 == 0 && k > 0) {          // bounce overlap: on the pipeline's stream this interval is only the WAIT for the side stream's extend launch
+                out->extend_wait_ms += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, ev[22 + 2 * (k / 5 - 1)], ev[23 + 2 * (k / 5 - 1)]));
+            }
+            *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++;
+        }
     }
     out->frames = (uint32_t)ctx->profFrames;
-    out->pipelines = ctx->profPipes.empty() ? 0u : (uint32_t)ctx->profPipes.back();
+    out->pipelines = ctx->profPipes.empty() ? 0u : (uint32_t)(ctx->profPipes.back() & 0xff);
+    out->overlap = ctx->profPipes.empty() ? 0u : (uint32_t)((ctx->profPipes.back() >> 8) & 1);
     ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }

@@ -46,6 +46,9 @@ struct incr_context {
     int wfPipesWanted;        // INCR_WF_PIPELINES / incr_set_pathtrace_pipelines; 0 = by size
     hipStream_t wfStreams[8]; // [0] is filled per call with the caller's stream; the others are library-owned
     hipEvent_t wfFork, wfJoin[8];
+    bool wfOverlap;           // bounce overlap: extend(b + 1) beside shadow(b) on the pipeline's side stream (INCR_WF_OVERLAP, incr_set_pathtrace_overlap)
+    hipStream_t wfSideStreams[8];                     // library-owned, created on first use
+    hipEvent_t wfBounceFork[32], wfBounceJoin[32];    // [pipeline * 4 + bounce]
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
     void* wfStage;            // incr_pathtrace_desc::num_samples > 1: RGBA16F bits per sample in flight and local pixel

@@ -287,12 +287,15 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float s_keys[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kExtend * 5];
+    const uint32_t total = B.counters[bounce];
+    // a workgroup whose first wave has no static chunk has none at all (WaveChunk::init_static) and never takes one from the cursor: it leaves
+    // before copying the top nodes -- a short list (a small frame, a late bounce) is then a short launch
+    if (blockIdx.x * (kWfBlock / 64) * kExtendChunk >= total) return;
     WfStackK<N> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
     st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kExtend));
     // the rays of this bounce: a flat queue in list order (origin + path id, direction), written by generate / shade -- a refill
     // is two coalesced loads, not a path id and two gathers behind it
     const float4* __restrict__ ext = (bounce & 1) ? B.extB : B.extA;
-    const uint32_t total = B.counters[bounce];
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
     WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
     bool active = false; uint32_t slot = 0;
@@ -850,9 +853,10 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
 template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WAVES : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
+    const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
+    if (blockIdx.x * (kWfBlock / 64) * kShadowChunk >= total) return;          // no static chunk for any wave of this workgroup (see wf_extend_kernel)
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
     st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kShadow));
-    const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
@@ -1037,14 +1041,24 @@ template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, 
 // rays -- a ray is a chain of ~30 (max > 150) dependent fetch + test steps, ~2 us each once its wave runs alone -- and with one
 // pipeline the whole GPU waits for that tail 8 times per frame; with two, the other pipeline's kernels fill the machine meanwhile.
 // The effect grows as the frame shrinks (a 1/8 framebuffer shard of an 8-GPU run: profiles/r02_shard_emulation.json).
-// `events` (optional, 22 per pipeline): recorded on the pipeline's stream before its first kernel and after every kernel.
+//
+// BOUNCE OVERLAP (round 4, `overlap`): inside a pipeline the shadow rays of bounce b and the continuation rays of bounce b + 1 are both
+// made by wf_shade_kernel(b) and do not depend on each other -- chsMain traces them one after the other only because it is written as a
+// recursion.  wf_extend_kernel(b + 1) therefore runs on the pipeline's SIDE stream beside wf_shadow_kernel(b) + wf_accumulate_kernel(b):
+//     shade(b) -> { shadow(b) -> accumulate(b)  ||  extend(b + 1) } -> shade(b + 1)
+// (accumulate(b) writes the colour that travels with the ray of bounce b + 1, which only shade(b + 1) reads; extend(b + 1) writes the hit
+// records of its own list.)  A frame of few rays is a chain of launches each as long as its longest ray (helmet 1080p: seven traversal
+// launches of 110-140 us in a 1.39 ms frame, profiles/r04_small_frame_trace.txt): the chain loses three links.  On a large frame the
+// extend launch fills the drain of the shadow launch.  Results do not depend on it (same kernels, same inputs).
+// `events` (optional, kWfProfEvents per pipeline): see pt_params.h.
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
-                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events) {
+                                               hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;      // tileRow[] counts rows of all samples in flight: tilesY per sample
     if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
     if (tileRow[numPipes] == 0) {          // an empty shard: nothing to launch, but a profiled call still owns its event record
-        if (events) for (int k = 0; k < 22 * 8; ++k) (void)hipEventRecord(events[k], streams[0]);
+        if (events) for (int k = 0; k < kWfProfEvents * 8; ++k) (void)hipEventRecord(events[k], streams[0]);
         return hipSuccess;
     }
     if (stackEntries > 24u) return hipErrorInvalidValue;
@@ -1067,7 +1081,12 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     }
     const bool firstHitOnly = p->viewmode >= 2 && p->viewmode <= 5;      // VIEWMODE 2-5 return at the first hit (pathtracing.hlsl:184-196); every other mode is a full path
     const int fuseGen = firstHitOnly ? 0 : 1;             // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; the material views make no vertices
-    auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * 22 + slot], streams[i]); };
+    const bool side = overlap && sideStreams && bounceFork && bounceJoin && !firstHitOnly;
+    auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * kWfProfEvents + slot], streams[i]); };
+    auto extend = [&](int i, int bounce, hipStream_t st) {
+        const WfBuffers& b = pipes[i];
+        if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+    };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
@@ -1081,7 +1100,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
             if (bounce == 0) hipLaunchKernelGGL(wf_primary_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, total[i], tilesX, tilesY, tileRow[i] * tilesX);
-            else if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+            else if (side) (void)hipStreamWaitEvent(st, bounceJoin[i * 4 + bounce - 1], 0);      // this bounce's extend ran beside the previous bounce's shadow rays
+            else extend(i, bounce, st);
             mark(i, slot);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen); mark(i, slot + 1);
         }
@@ -1089,6 +1109,14 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
+            if (side && bounce < 3) {
+                (void)hipEventRecord(bounceFork[i * 4 + bounce], st);
+                (void)hipStreamWaitEvent(sideStreams[i], bounceFork[i * 4 + bounce], 0);
+                if (events) (void)hipEventRecord(events[i * kWfProfEvents + 22 + 2 * bounce], sideStreams[i]);
+                extend(i, bounce + 1, sideStreams[i]);
+                if (events) (void)hipEventRecord(events[i * kWfProfEvents + 23 + 2 * bounce], sideStreams[i]);
+                (void)hipEventRecord(bounceJoin[i * 4 + bounce], sideStreams[i]);
+            }
             mark(i, slot + 2);            // (the "shadow_gen" interval of rounds 1-2 is empty: the set-up runs inside wf_shade_kernel)
             if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
             mark(i, slot + 3);
@@ -1097,6 +1125,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         slot += 5;
     }
     for (int i = 0; i < numPipes; ++i) for (int k = total[i] ? slot : 0; k < 22; ++k) mark(i, k);      // unused slots collapse to zero-length intervals
+    if (events) for (int i = 0; i < numPipes; ++i) if (!side || !total[i]) for (int k = 22; k < kWfProfEvents; ++k) mark(i, k);      // no side launches: zero-length
     for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
     if (p->numSamples > 1u && p->localPixels) hipLaunchKernelGGL(wf_integrate_samples_kernel, dim3((p->localPixels + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, streams[0], *p);
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);

@@ -63,6 +63,11 @@ struct PtParams {
     unsigned long long* statStripes;          // raster passes: 64 striped ray counters (16 words apart), folded into `stats` afterwards
 };
 
+// HIP events per pipeline of a recorded incr_pathtrace call (incr_profile_begin): [0] start, [1] after the (empty) generate interval, then per bounce
+// extend / shade / shadow_gen / shadow / accumulate on the pipeline's stream; [22 + 2 j], [23 + 2 j] around the extend launch of bounce j + 1
+// on the pipeline's SIDE stream when it runs beside the shadow launch of bounce j (pathtrace_wf.hip "bounce overlap")
+static constexpr int kWfProfEvents = 28;
+
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).
 struct WfBuffers {
     float4* extA;        // rays of the even bounces, list order, 2 x float4 per ray: {origin.xyz, path id} {direction.xyz, 0}

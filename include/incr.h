@@ -160,6 +160,13 @@ int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_str
  * for the longest rays of each of the eight traversal kernels of a frame; with two the other band's kernels run meanwhile.
  */
 int  incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines);
+/*
+ * Not in the reference: bounce overlap.  chsMain traces a vertex's shadow rays and then its continuation ray because it is a recursion; both
+ * are made by the same shading step and neither depends on the other, so inside a pipeline the closest-hit launch of bounce b + 1 runs on a
+ * side stream beside the any-hit launch (+ the summation) of bounce b.  Results are bit-identical.  Default on (INCR_WF_OVERLAP=0 at
+ * incr_initialize or enable = 0 turn it off: every launch of a pipeline then runs alone, which is what per-kernel timing wants).
+ */
+int  incr_set_pathtrace_overlap(incr_context* ctx, int32_t enable);
 
 /*
  * Per-kernel timing of the path tracer (stands in for the reference's PIX/Tracy GPU zones, inc/profiling.h:10-12):
@@ -172,6 +179,10 @@ typedef struct incr_pathtrace_profile {
     uint32_t launches[5];            /* extend, shade, shadow_gen, shadow, accumulate launches that did work */
     uint32_t frames;                 /* recorded incr_pathtrace calls */
     uint32_t pipelines;              /* pipelines of the last recorded call */
+    uint32_t overlap;                /* 1: the last recorded call ran with bounce overlap (below): extend_ms then sums the launches as timed on the side
+                                        streams, where they share the GPU with the shadow launch of the bounce before */
+    uint32_t reserved0;
+    double   extend_wait_ms;         /* bounce overlap: what the pipelines' own streams still waited for those extend launches */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);
 int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);

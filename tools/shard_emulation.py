@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--samples-in-flight", type=int, default=1,
                     help="incr_pathtrace_desc::num_samples of the SHARD runs (the full frame stays one sample per call): a shard then traces S samples of its "
                          "pixels as one wavefront; times are per sample")
+    ap.add_argument("--pipelines", type=int, default=0, help="incr_set_pathtrace_pipelines (0 = the library's choice by size)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], help="incr_set_pathtrace_overlap (auto = the library's default)")
+    ap.add_argument("--shard-list", default="", help="comma-separated shard indices to time instead of all (a quick A/B)")
     a = ap.parse_args()
     import torch  # noqa: F401  (first HIP runtime in the process, as in bench.py)
     A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io")
@@ -29,6 +32,9 @@ def main():
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(0)
     scene = ctx.create_scene(packed)
+    ctx.set_pathtrace_pipelines(a.pipelines)
+    if a.overlap != "auto":
+        ctx.set_pathtrace_overlap(a.overlap == "on")
 
     def timed(shard, S=1):
         pt = rt.PathTracer(ctx, scene, W, H, shard=shard)
@@ -55,13 +61,13 @@ def main():
 
     full_ms, full_rays, full_kernels = timed(None)
     shard_ms, shard_rays, shard_kernels = [], [], None
-    for r in range(a.shards):
+    for r in ([int(v) for v in a.shard_list.split(",")] if a.shard_list else range(a.shards)):
         # best of two timings per shard: the shards of a real run share nothing, a hiccup of this process is not theirs
         ms, rays, kernels = min((timed(A.Shard(8, r, a.shards), a.samples_in_flight) for _ in range(2)), key=lambda t: t[0])
         shard_ms.append(round(ms, 4)); shard_rays.append(int(rays))
-        if r == 0:
+        if shard_kernels is None:
             shard_kernels = kernels
-    out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps, "samples_in_flight": a.samples_in_flight,
+    out = {"tool": "shard_emulation", "scene": a.scene, "resolution": [W, H], "shards": a.shards, "steps": a.steps, "samples_in_flight": a.samples_in_flight, "pipelines": a.pipelines, "overlap": a.overlap,
            "full_frame_ms": round(full_ms, 4), "full_frame_rays": int(full_rays), "shard_ms": shard_ms, "shard_rays": shard_rays,
            "max_shard_ms": max(shard_ms), "sum_shard_ms": round(sum(shard_ms), 4),
            "projected_speedup_compute_only": round(full_ms / max(shard_ms), 3),

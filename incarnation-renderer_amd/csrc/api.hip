@@ -34,6 +34,7 @@ extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_codec_selftest(unsigned long long* out4, hipStream_t stream);
+extern "C" hipError_t incr_launch_rcp_selftest(unsigned long long* out2, hipStream_t stream);
 extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
 extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
                                           uint32_t localRows, uint32_t texelBytes, hipStream_t stream);
@@ -945,6 +946,20 @@ int incr_selftest_small_float(incr_context* ctx, uint64_t out_mismatches[4]) {
     if (e == hipSuccess) e = hipMemcpy(out_mismatches, d, 32, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(INCR_ERR_HIP, "small-float self-test failed: %s", hipGetErrorString(e));
+    return INCR_OK;
+}
+
+int incr_selftest_reciprocal(incr_context* ctx, uint64_t out_mismatches[3]) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (!out_mismatches) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 24));
+    hipError_t e = hipMemset(d, 0, 24);
+    if (e == hipSuccess) e = incr_launch_rcp_selftest(d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_mismatches, d, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(INCR_ERR_HIP, "reciprocal self-test failed: %s", hipGetErrorString(e));
     return INCR_OK;
 }
 

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                         const float NoV = hmax(dot(N, V), 0.001f);
                         const float NoH = hmax(dot(N, H), 0.001f);
                         const float VoH = hmax(dot(V, H), 0.001f);
-                        const float pdf = t * CosineHemispherePdf(NoL) + (1.f - t) * GGXPdf(NoH, matInfo.roughness) / (4.f * VoH);
+                        const float pdf = t * CosineHemispherePdf(NoL) + QDIV((1.f - t) * GGXPdf(NoH, matInfo.roughness), 4.f * VoH);
                         const f3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
                         const f3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
                         const float D = GGX(NoH, matInfo.roughness);

@@ -19,15 +19,46 @@ struct f4 { float x, y, z, w; };
 
 #define DI __device__ __forceinline__
 
+// Division.  HLSL's a / b is DXIL FDiv, which GPUs lower to a reciprocal and a multiplication; INCR_DIV selects how it is evaluated here:
+//   0  IEEE a / b (v_div_scale x 2, v_rcp, 6 fused ops, v_div_fmas, v_div_fixup: 11 instructions, 14 issue slots)
+//   1  a * rcp(b) with rcp(b) the CORRECTLY ROUNDED reciprocal: v_rcp_f32 (1 ulp) + two Newton steps in fused arithmetic (Markstein) + v_div_fixup
+//      for zero / infinity / NaN -- 6 instructions + the multiplication
+//   2  a * rcp(b) with one Newton step (faithful, correctly rounded in all but ~2^-22 of the cases), 3 instructions + the multiplication
+#ifndef INCR_DIV
+#define INCR_DIV 1          // pinned in the oracle as a * (1.f / b) (oracle_math.h): 1 reproduces it bit for bit; 0 and 2 are A/B builds
+#endif
+DI float rcp_cr(float x) {
+#if INCR_DIV == 2
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e0 = __builtin_fmaf(-x, y0, 1.f);
+    return __builtin_fmaf(y0, e0, y0);
+#else
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e0 = __builtin_fmaf(-x, y0, 1.f);
+    const float y1 = __builtin_fmaf(y0, e0, y0);
+    const float e1 = __builtin_fmaf(-x, y1, 1.f);
+    const float y2 = __builtin_fmaf(y1, e1, y1);
+    return __builtin_amdgcn_div_fixupf(y2, x, 1.f);
+#endif
+}
+#if INCR_DIV == 0
+#define QDIV(a, b) ((a) / (b))
+#else
+#define QDIV(a, b) ((a) * rcp_cr(b))
+#endif
 DI f3 mk3(float x, float y, float z) { return {x, y, z}; }
 DI f3 mk3(float s) { return {s, s, s}; }
 DI f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 DI f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 DI f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-DI f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+DI f3 operator/(f3 a, f3 b) { return {QDIV(a.x, b.x), QDIV(a.y, b.y), QDIV(a.z, b.z)}; }
 DI f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 DI f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+#if INCR_DIV == 0
 DI f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+#else
+DI f3 operator/(f3 a, float s) { const float r = rcp_cr(s); return {a.x * r, a.y * r, a.z * r}; }
+#endif
 DI f3 operator+(float s, f3 a) { return {s + a.x, s + a.y, s + a.z}; }
 DI f3 operator+(f3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
 DI f3 operator-(float s, f3 a) { return {s - a.x, s - a.y, s - a.z}; }
@@ -42,7 +73,7 @@ DI f4 operator*(float s, f4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
 DI float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DI float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-DI f3 normalize(f3 v) { const float r = 1.f / sqrtf(dot(v, v)); return {v.x * r, v.y * r, v.z * r}; }      // HLSL normalize = x * rsqrt(dot(x, x)) (DXIL: Dot3, Rsqrt, FMul), rsqrt pinned to 1 / sqrt: DESIGN.md section 3
+DI f3 normalize(f3 v) { const float r = QDIV(1.f, sqrtf(dot(v, v))); return {v.x * r, v.y * r, v.z * r}; }      // HLSL normalize = x * rsqrt(dot(x, x)) (DXIL: Dot3, Rsqrt, FMul), rsqrt pinned to 1 / sqrt: DESIGN.md section 3
 DI float hmax(float a, float b) { return fmaxf(a, b); }
 DI float hmin(float a, float b) { return fminf(a, b); }
 DI float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
@@ -111,7 +142,7 @@ DI f2 CorrelatedMultiJitteredSampling(uint32_t sampleIdx, const FastDiv& dn, con
     uint32_t sy = CMJ_Permute(row, dn, pattern * 0x02e5be93);
     float jx = CMJ_RandFloat(sampleIdx, pattern * 0x967a889b);
     float jy = CMJ_RandFloat(sampleIdx, pattern * 0x368cc8b7);
-    return {((float)sx + ((float)sy + jx) / (float)ny) / (float)nx, ((float)sampleIdx + jy) / (float)N};
+    return {QDIV((float)sx + QDIV((float)sy + jx, (float)ny), (float)nx), QDIV((float)sampleIdx + jy, (float)N)};
 }
 // raytracing/common.hlsli:8-14
 DI f2 SamplePoint(uint32_t pixelIdx, uint32_t sampleIdx, uint32_t& setIdx, const FastDiv& divSqrtN, const FastDiv& divN, uint32_t numPixels) {
@@ -129,8 +160,8 @@ DI f2 ConcentricSampleDisk(f2 u) {                        // uniform-sampling.hl
     f2 o = {2.f * u.x - 1.f, 2.f * u.y - 1.f};
     if (o.x == 0.f && o.y == 0.f) return {0.f, 0.f};
     float theta, r;
-    if (fabsf(o.x) > fabsf(o.y)) { r = o.x; theta = K_PI_OVER_4 * (o.y / o.x); }
-    else { r = o.y; theta = K_PI_OVER_2 - K_PI_OVER_4 * (o.x / o.y); }
+    if (fabsf(o.x) > fabsf(o.y)) { r = o.x; theta = K_PI_OVER_4 * QDIV(o.y, o.x); }
+    else { r = o.y; theta = K_PI_OVER_2 - K_PI_OVER_4 * QDIV(o.x, o.y); }
     return {r * cosf(theta), r * sinf(theta)};
 }
 DI f3 CosineSampleHemisphere(f2 u) {                      // :61-66
@@ -147,12 +178,12 @@ DI float GGX(float NoH, float Roughness) {                // bxdf-sampling.hlsli
     float NoH2 = NoH * NoH;
     float denom = (NoH2 * (a2 - 1.f) + 1.f);
     denom = K_PI * denom * denom;
-    return a2 / hmax(denom, 0.0001f);
+    return QDIV(a2, hmax(denom, 0.0001f));
 }
 DI f3 SampleGGX(f2 u, float roughness) {                  // :29-42
     float a = roughness * roughness;
     float Phi = 2 * K_PI * u.x;
-    float CosTheta = sqrtf((1.f - u.y) / (1.f + (a * a - 1.f) * u.y));
+    float CosTheta = sqrtf(QDIV(1.f - u.y, 1.f + (a * a - 1.f) * u.y));
     float SinTheta = sqrtf(1.f - CosTheta * CosTheta);
     return {SinTheta * sinf(Phi), SinTheta * cosf(Phi), CosTheta};
 }
@@ -162,10 +193,10 @@ DI float G_SmithGGXCorrelated(float NoV, float NoL, float roughness) {   // pbr.
     float a2 = roughness * roughness;
     float GGXV = NoL * sqrtf(NoV * NoV * (1.0f - a2) + a2);
     float GGXL = NoV * sqrtf(NoL * NoL * (1.0f - a2) + a2);
-    return 0.5f / hmax(GGXV + GGXL, 0.00001f);
+    return QDIV(0.5f, hmax(GGXV + GGXL, 0.00001f));
 }
 DI f3 F_Schlick(float u, f3 f0) { float f = pow5(1.0f - u); return f + f0 * (1.0f - f); }
-DI float G_SchlickGGX(float u, float k) { return u / (u * (1.f - k) + k); }
+DI float G_SchlickGGX(float u, float k) { return QDIV(u, u * (1.f - k) + k); }
 DI float G_Smith_Direct(float NoV, float NoL, float roughness) {
     float a2 = roughness * roughness;
     float k = (a2 + 1) * (a2 + 1) / 8.f;

@@ -60,6 +60,29 @@ __global__ __launch_bounds__(256) void codec_selftest_kernel(unsigned long long*
     for (int k = 0; k < 4; ++k) if (bad[k]) atomicAdd(out + k, bad[k]);
 }
 
+// Self-test of rcp_cr (pt_device.h: the reciprocal behind every pinned shader division a * rcp(b)) against the IEEE quotient 1.f / x over EVERY
+// float32 pattern.  out[0] = patterns with x and 1 / x both NORMAL numbers (2^-126 <= |x| <= 2^126) where the two differ, out[1] = of those, the
+// ones further than one ulp apart, out[2] = differing patterns outside that domain (denormal x or denormal quotient: v_rcp_f32 flushes them;
+// no shader denominator lives there), two NaNs counting as equal.
+__global__ __launch_bounds__(256) void rcp_selftest_kernel(unsigned long long* __restrict__ out) {
+    unsigned long long bad = 0, far = 0, outside = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = rcp_cr(x), b = 1.f / x;
+        const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+        if (ua == ub || (a != a && b != b)) continue;
+        const uint32_t e = ((uint32_t)i >> 23) & 0xffu;
+        const bool domain = e >= 1u && (e < 253u || (e == 253u && ((uint32_t)i & 0x7fffffu) == 0u));      // |x| in [2^-126, 2^126]
+        if (!domain) { outside++; continue; }
+        bad++;
+        const uint32_t d = ua > ub ? ua - ub : ub - ua;
+        if (d > 1u) far++;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (far) atomicAdd(out + 1, far);
+    if (outside) atomicAdd(out + 2, outside);
+}
+
 // TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode (tonemap_texel, pt_device.h).
 // Streaming: 16 B in, 16 B out per lane (four texels) -- with one texel per lane the pass ran at 0.59 TB/s.
 __global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
@@ -120,6 +143,10 @@ extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint
     return hipGetLastError();
 }
 
+extern "C" hipError_t incr_launch_rcp_selftest(unsigned long long* out2, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::rcp_selftest_kernel, dim3(256 * 64), dim3(256), 0, stream, out2);
+    return hipGetLastError();
+}
 extern "C" hipError_t incr_launch_codec_selftest(unsigned long long* out4, hipStream_t stream) {
     hipLaunchKernelGGL(incr::codec_selftest_kernel, dim3(256 * 64), dim3(256), 0, stream, out4);
     return hipGetLastError();

@@ -29,8 +29,8 @@ DI LightSample light_setup(const incr_light& light, const float* __restrict__ m,
         const float distance = sqrtf(distanceSquared);
         s.L = lightVec / distance;
         float radialAttenuation;
-        if (light.range > 0.f) radialAttenuation = hmax(hmin(1.f, 1.f - pow4(distance / light.range)), 0.f) / distanceSquared;
-        else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        if (light.range > 0.f) radialAttenuation = QDIV(hmax(hmin(1.f, 1.f - pow4(QDIV(distance, light.range))), 0.f), distanceSquared);
+        else radialAttenuation = QDIV(1.f, hmax(distanceSquared, 0.0001f));
         s.radianceIn = 10000 * light.intensity * color * radialAttenuation;
     } else if (light.type == INCR_LIGHT_SPOT) {
         const f3 spotPosition = {mm[12], mm[13], mm[14]};
@@ -44,7 +44,7 @@ DI LightSample light_setup(const incr_light& light, const float* __restrict__ m,
         const float cosineOuterAngle = cosf(light.spotAngles[1]);
         if (cd > cosineOuterAngle) {
             const float cosineInnerAngle = cosf(light.spotAngles[0]);
-            const float lightAngleScale = 1.f / hmax(0.001f, cosineInnerAngle - cosineOuterAngle);
+            const float lightAngleScale = QDIV(1.f, hmax(0.001f, cosineInnerAngle - cosineOuterAngle));
             const float lightAngleOffset = -cosineOuterAngle * lightAngleScale;
             angularAttenuation = saturate(cd * lightAngleScale + lightAngleOffset);
             angularAttenuation *= angularAttenuation;
@@ -52,7 +52,7 @@ DI LightSample light_setup(const incr_light& light, const float* __restrict__ m,
         float radialAttenuation = 0.f;
         if (angularAttenuation > 0.f) {
             if (light.range > 0.f) { /* Q9: shadowed redeclaration at common.hlsli:73 leaves 0 */ }
-            else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+            else radialAttenuation = QDIV(1.f, hmax(distanceSquared, 0.0001f));
         }
         s.radianceIn = 10000 * light.intensity * color * angularAttenuation * radialAttenuation;
     }

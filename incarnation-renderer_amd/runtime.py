@@ -21,7 +21,7 @@ EXPORTS = [
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir", "incr_scene_set_max_anisotropy",
     "incr_scene_get_info", "incr_scene_texture_info", "incr_scene_texture_download", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
-    "incr_trace_rays", "incr_selftest_small_float", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines", "incr_set_pathtrace_overlap",
+    "incr_trace_rays", "incr_selftest_small_float", "incr_selftest_reciprocal", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines", "incr_set_pathtrace_overlap",
     # raster path
     "incr_generate_tangents", "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",

@@ -207,6 +207,14 @@ int  incr_tonemap(incr_context* ctx, const incr_tonemap_desc* desc, incr_stream 
  * R11G11B10 -> f32; all zero on a correct build.  Blocks for about a second.
  */
 int  incr_selftest_small_float(incr_context* ctx, uint64_t out_mismatches[4]);
+/*
+ * Self-test (not in the reference): shader divisions are evaluated as a * rcp(b) (HLSL a / b = DXIL FDiv, which GPUs lower to a reciprocal and a
+ * multiplication) with rcp the CORRECTLY ROUNDED reciprocal -- on the device v_rcp_f32 + two fused Newton steps + v_div_fixup (csrc/pt_device.h rcp_cr),
+ * in the CPU oracle 1.f / b.  This compares the device reciprocal with the IEEE quotient 1.f / x over every float32 pattern: out_mismatches[0] =
+ * patterns with x and 1 / x both normal numbers (2^-126 <= |x| <= 2^126) where they differ, [1] = of those, by more than one ulp, [2] = differing
+ * patterns outside that domain (the hardware reciprocal flushes denormals; no shader denominator lives there).  Blocks for about a second.
+ */
+int  incr_selftest_reciprocal(incr_context* ctx, uint64_t out_mismatches[3]);
 
 
 /*

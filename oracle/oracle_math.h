@@ -24,10 +24,16 @@ static inline float3 f3(float s) { return {s, s, s}; }
 static inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static inline float3 operator*(float3 a, float3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-static inline float3 operator/(float3 a, float3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+// DIVISION in shader arithmetic is pinned as a * rcp(b) with rcp the correctly rounded reciprocal (round 4): HLSL's a / b is DXIL FDiv, which
+// GPUs lower to a reciprocal and a multiplication -- never to an IEEE division -- and a vector divided by a scalar to ONE reciprocal.  Sites:
+// the float3 operators below, SamplePoint, ConcentricSampleDisk, GGX, SampleGGX, G_SmithGGXCorrelated, G_SchlickGGX, the light attenuation
+// terms and the BRDF-sampling pdf (oracle_pt.cpp).  Everything else (geometry, texture addressing, the raster set-up) keeps the IEEE quotient.
+static inline float rcp(float x) { return 1.f / x; }
+static inline float qdiv(float a, float b) { return a * rcp(b); }
+static inline float3 operator/(float3 a, float3 b) { return {qdiv(a.x, b.x), qdiv(a.y, b.y), qdiv(a.z, b.z)}; }
 static inline float3 operator*(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 static inline float3 operator*(float s, float3 a) { return {s * a.x, s * a.y, s * a.z}; }
-static inline float3 operator/(float3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+static inline float3 operator/(float3 a, float s) { const float r = rcp(s); return {a.x * r, a.y * r, a.z * r}; }
 static inline float3 operator+(float3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
 static inline float3 operator+(float s, float3 a) { return {s + a.x, s + a.y, s + a.z}; }
 static inline float3 operator-(float s, float3 a) { return {s - a.x, s - a.y, s - a.z}; }

@@ -57,7 +57,7 @@ static float2 CorrelatedMultiJitteredSampling(uint32_t sampleIdx, uint32_t nx, u
     uint32_t sy = CMJ_Permute(sampleIdx / nx, ny, pattern * 0x02e5be93);
     float jx = CMJ_RandFloat(sampleIdx, pattern * 0x967a889b);
     float jy = CMJ_RandFloat(sampleIdx, pattern * 0x368cc8b7);
-    return {((float)sx + ((float)sy + jx) / (float)ny) / (float)nx, ((float)sampleIdx + jy) / (float)N};
+    return {qdiv((float)sx + qdiv((float)sy + jx, (float)ny), (float)nx), qdiv((float)sampleIdx + jy, (float)N)};
 }
 // shaders/raytracing/common.hlsli:8-14
 static float2 SamplePoint(uint32_t pixelIdx, uint32_t sampleIdx, uint32_t& setIdx, uint32_t sqrtSampleCount, uint32_t numPixels) {
@@ -86,8 +86,8 @@ static float2 ConcentricSampleDisk(float2 u) {
     float2 uOffset = {2.f * u.x - 1.f, 2.f * u.y - 1.f};
     if (uOffset.x == 0.f && uOffset.y == 0.f) return {0.f, 0.f};
     float theta, r;
-    if (fabsf(uOffset.x) > fabsf(uOffset.y)) { r = uOffset.x; theta = k_PiOver4 * (uOffset.y / uOffset.x); }
-    else { r = uOffset.y; theta = k_PiOver2 - k_PiOver4 * (uOffset.x / uOffset.y); }
+    if (fabsf(uOffset.x) > fabsf(uOffset.y)) { r = uOffset.x; theta = k_PiOver4 * qdiv(uOffset.y, uOffset.x); }
+    else { r = uOffset.y; theta = k_PiOver2 - k_PiOver4 * qdiv(uOffset.x, uOffset.y); }
     return {r * cosf(theta), r * sinf(theta)};
 }
 // :61-66
@@ -107,12 +107,12 @@ static float GGX(float NoH, float Roughness) {
     float nom = a2;
     float denom = (NoH2 * (a2 - 1.f) + 1.f);
     denom = k_Pi * denom * denom;
-    return nom / hmax(denom, 0.0001f);
+    return qdiv(nom, hmax(denom, 0.0001f));
 }
 static float3 SampleGGX(float2 u, float roughness) {
     float a = roughness * roughness;
     float Phi = 2 * k_Pi * u.x;
-    float CosTheta = sqrtf((1.f - u.y) / (1.f + (a * a - 1.f) * u.y));
+    float CosTheta = sqrtf(qdiv(1.f - u.y, 1.f + (a * a - 1.f) * u.y));
     float SinTheta = sqrtf(1.f - CosTheta * CosTheta);
     // Polar2Cartesian(sint, cost, phi, Tangent)  shaders/common/math.hlsli:56-64
     return {SinTheta * sinf(Phi), SinTheta * cosf(Phi), CosTheta};
@@ -124,13 +124,13 @@ static float G_SmithGGXCorrelated(float NoV, float NoL, float roughness) {     /
     float a2 = roughness * roughness;
     float GGXV = NoL * sqrtf(NoV * NoV * (1.0f - a2) + a2);
     float GGXL = NoV * sqrtf(NoL * NoL * (1.0f - a2) + a2);
-    return 0.5f / hmax(GGXV + GGXL, 0.00001f);
+    return qdiv(0.5f, hmax(GGXV + GGXL, 0.00001f));
 }
 static float3 F_Schlick(float u, float3 f0) {                                  // :22-26
     float f = pow5(1.0f - u);
     return f + f0 * (1.0f - f);
 }
-static float G_SchlickGGX(float u, float k) { return u / (u * (1.f - k) + k); } // :37-40
+static float G_SchlickGGX(float u, float k) { return qdiv(u, u * (1.f - k) + k); } // :37-40
 static float G_Smith_Direct(float NoV, float NoL, float roughness) {           // :43-50
     float a2 = roughness * roughness;
     float k = (a2 + 1) * (a2 + 1) / 8.f;
@@ -637,8 +637,8 @@ static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const M
         float distance = sqrtf(distanceSquared);
         L = lightVec / distance;
         float radialAttenuation;
-        if (light.range > 0.f) radialAttenuation = hmax(hmin(1.f, 1.f - pow4(distance / light.range)), 0.f) / distanceSquared;
-        else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+        if (light.range > 0.f) radialAttenuation = qdiv(hmax(hmin(1.f, 1.f - pow4(qdiv(distance, light.range))), 0.f), distanceSquared);
+        else radialAttenuation = qdiv(1.f, hmax(distanceSquared, 0.0001f));
         radianceIn = 10000 * light.intensity * color * radialAttenuation;
     } else if (light.type == INCR_LIGHT_SPOT) {
         float3 spotPosition = {m[12], m[13], m[14]};
@@ -652,7 +652,7 @@ static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const M
         float cosineOuterAngle = cosf(light.spotAngles[1]);
         if (cd > cosineOuterAngle) {
             float cosineInnerAngle = cosf(light.spotAngles[0]);
-            float lightAngleScale = 1.f / hmax(0.001f, cosineInnerAngle - cosineOuterAngle);
+            float lightAngleScale = qdiv(1.f, hmax(0.001f, cosineInnerAngle - cosineOuterAngle));
             float lightAngleOffset = -cosineOuterAngle * lightAngleScale;
             angularAttenuation = saturate(cd * lightAngleScale + lightAngleOffset);
             angularAttenuation *= angularAttenuation;
@@ -660,7 +660,7 @@ static float3 GetDirectRadiance(const Scene& s, const incr_light& light, const M
         float radialAttenuation = 0.f;
         if (angularAttenuation > 0.f) {
             if (light.range > 0.f) { /* Q9: inner-scope redeclaration at :73 leaves the outer value 0 */ }
-            else radialAttenuation = 1.f / hmax(distanceSquared, 0.0001f);
+            else radialAttenuation = qdiv(1.f, hmax(distanceSquared, 0.0001f));
         }
         radianceIn = 10000 * light.intensity * color * angularAttenuation * radialAttenuation;
     }
@@ -897,7 +897,7 @@ static float4 trace_pixel(const Scene& s, const Frame& f, uint32_t px, uint32_t 
             float NoV = hmax(dot(N, V), 0.001f);
             float NoH = hmax(dot(N, H), 0.001f);
             float VoH = hmax(dot(V, H), 0.001f);
-            float pdf = t * CosineHemispherePdf(NoL) + (1.f - t) * GGXPdf(NoH, matInfo.roughness) / (4.f * VoH);
+            float pdf = t * CosineHemispherePdf(NoL) + qdiv((1.f - t) * GGXPdf(NoH, matInfo.roughness), 4.f * VoH);
             float3 F0 = matInfo.metallic * matInfo.basecolor + (1.f - matInfo.metallic) * 0.04f;
             float3 albedo = (1.f - matInfo.metallic) * matInfo.basecolor;
             float D = GGX(NoH, matInfo.roughness);

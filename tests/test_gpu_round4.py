@@ -223,3 +223,17 @@ def test_bounce_overlap_is_bit_identical(gpu_ctx, rt, sio, A, request, scene_nam
     finally:
         gpu_ctx.set_pathtrace_pipelines(0); gpu_ctx.set_pathtrace_overlap(True)
         sc.close()
+
+
+# ------------------------------------------------------------------------------------------------ pinned shader division
+def test_device_reciprocal_is_the_correctly_rounded_one(gpu_ctx):
+    """Shader divisions are a * rcp(b) with rcp correctly rounded (oracle: 1.f / b; device: v_rcp_f32 + two fused Newton steps + v_div_fixup,
+    pt_device.h rcp_cr).  Over all 2^32 float patterns the device reciprocal must equal the IEEE quotient except on a vanishing set (Markstein's
+    sequence can miss by one ulp when the mantissa of x is all ones, and where the quotient is denormal), never by more than one ulp."""
+    import ctypes as C
+    out = (C.c_uint64 * 3)()
+    gpu_ctx.lib.incr_selftest_reciprocal.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert gpu_ctx.lib.incr_selftest_reciprocal(gpu_ctx.handle, out) == 0
+    print("rcp_cr vs 1.f / x: %d of the patterns with x and 1 / x normal differ, %d of them by more than one ulp; %d differ outside that domain" % (out[0], out[1], out[2]))
+    assert out[1] == 0
+    assert out[0] <= 2 ** 32 * 1e-5

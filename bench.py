@@ -498,6 +498,35 @@ def main():
     rays = int(s[0] + s[1] + s[2] + s[3]); hits = int(s[4])
     call_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps   # HIP events around the whole incr_pathtrace call, per step (sample)
 
+    # The same kernels timed ALONE (one pipeline, no bounce overlap: every launch has the GPU to itself), a few extra steps outside the timed
+    # region: the record then carries both the shared-GPU interval of the dominant kernel and its stand-alone one (roofline.alone)
+    alone = None
+    if world == 1 and not collective and (int(prof.pipelines) > 1 or prof.overlap):
+        ctx.set_pathtrace_pipelines(1); ctx.set_pathtrace_overlap(False)
+        stats_a = torch.zeros(8, dtype=torch.int64, device=dev)
+        hist_a = history.clone()                                      # the timed accumulation stays what the K steps left
+        n_alone = max(2, min(4, args.steps))
+
+        def step_alone(si):
+            d = rt.make_pathtrace_desc(view, W, H, si, shard, envmap=envmap)
+            d.scene = scene.handle
+            if args.no_direct_lighting:
+                d.direct_lighting = 0
+            d.viewmode = args.viewmode
+            d.target_rgba16f, d.history_r11g11b10, d.ray_stats = target.data_ptr(), hist_a.data_ptr(), stats_a.data_ptr()
+            ctx.pathtrace(d, stream.cuda_stream)
+        step_alone(sample); torch.cuda.synchronize(dev); stats_a.zero_()
+        ctx.profile_begin()
+        for k in range(n_alone):
+            step_alone(sample + 1 + k)
+        torch.cuda.synchronize(dev)
+        alone = (ctx.profile_end(), stats_a.cpu().numpy(), n_alone)
+        ctx.set_pathtrace_pipelines(max(0, min(args.pipelines, 8)))
+        if args.overlap != "auto":
+            ctx.set_pathtrace_overlap(args.overlap == "on")
+        else:
+            ctx.set_pathtrace_overlap(True)
+
     # second half of the metric ("Mray/s + ms/frame"): the raster frame of config 3, outside the timed path-trace region;
     # at N > 1 every rank renders its row band and the TAA bands are all-gathered (sort-first)
     raster_out = None
@@ -513,9 +542,8 @@ def main():
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
-        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 16 launches (4 x extend / shade / shadow / accumulate; bounce 0's extend
-        # makes the camera rays itself and shade sets its vertices' shadow rays up, so the "generate" and "shadow_gen" intervals are
-        # empty unless INCR_WF_FUSED_PRIMARY=0 / INCR_WF_FUSED_SHADOW_GEN=0);
+        # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 16 launches per pipeline (4 x extend / shade / shadow / accumulate; bounce 0's
+        # extend makes the camera rays itself and shade sets its vertices' shadow rays up: the "generate" and "shadow_gen" intervals of rounds 1-2 are empty);
         # the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
         # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
         per_kernel = {"incr::wf_generate_kernel": (prof.generate_ms, max(prof.frames, 1), rows * W * 64.0 * args.steps),
@@ -567,6 +595,20 @@ def main():
                                         "achieved": round(frame_alg_bytes / (call_ms * 1e-3) / 1e9, 2)},
                          "kernel_ms_per_step": {k.split("::")[1]: round(v[0] / args.steps, 4) for k, v in per_kernel.items()}},
         }
+        if alone is not None:
+            pa, sa, na = alone
+            alone_kernel = {"incr::wf_extend_kernel": (pa.extend_ms, max(pa.launches[0], 1), float(sa[0] + sa[1]) * b_ray),
+                            "incr::wf_shade_kernel": (pa.shade_ms, max(pa.launches[1], 1), float(sa[4]) * B_HIT),
+                            "incr::wf_shadow_kernel": (pa.shadow_ms, max(pa.launches[3], 1), float(sa[2] + sa[3]) * b_ray),
+                            "incr::wf_accumulate_kernel": (pa.accumulate_ms, max(pa.launches[4], 1), float(sa[4]) * 128.0 + rows * W * B_PX * na)}
+            a_ms, a_launches, a_bytes = alone_kernel[dominant]
+            if a_ms > 0:
+                a_kernel_ms = a_ms / a_launches
+                a_ach = a_bytes / a_launches / (a_kernel_ms * 1e-3) / 1e9
+                out["roofline"]["alone"] = {"kernel_ms": round(a_kernel_ms, 4), "algorithmic_bytes_per_launch": int(a_bytes / a_launches), "achieved": round(a_ach, 2),
+                                            "frac": round(a_ach / HBM_PEAK_GBS, 5), "launches_per_step": a_launches / na, "steps": na,
+                                            "kernel_ms_per_step": {k.split("::")[1]: round(v[0] / na, 4) for k, v in alone_kernel.items()},
+                                            "note": "%d extra steps outside the timed region with one pipeline and no bounce overlap: every launch has the GPU to itself (a launch then covers the whole frame)" % na}
         # measured HBM bytes of the dominant kernel: only from a PMC run (tools/pmc.sh) of THESE kernel sources on this workload
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         if os.path.exists(traffic_file):

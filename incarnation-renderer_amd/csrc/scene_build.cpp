@@ -4,7 +4,9 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <cstdlib>
 #include <cfloat>
@@ -124,7 +126,7 @@ static inline float box_area(const Box& b) {
 struct Node2 { Box box; uint32_t left, right, first, count; uint32_t spanFirst, spanCount; };   // count > 0: leaf over order[first .. first+count); span*: the subtree's run of `order` (every node)
 
 struct Builder {
-    const std::vector<Box>& tb; const std::vector<V3>& cen;
+    const Box* tb; const V3* cen;
     std::vector<uint32_t> order;
     std::vector<Node2> nodes;
     // 32 bins: 1 % fewer node visits than 16 on Sponza-stat; traversal cost 0.5 / 2, leaf limits 2 / 3 and splitting pairs all
@@ -133,7 +135,7 @@ struct Builder {
     static constexpr int bins = kBins;
 
     // over the items [first, first + count) of tb / cen: `order` holds their indices, build(0, count) is the root
-    Builder(const std::vector<Box>& tb_, const std::vector<V3>& cen_, uint32_t first, uint32_t count) : tb(tb_), cen(cen_) {
+    Builder(const Box* tb_, const V3* cen_, uint32_t first, uint32_t count) : tb(tb_), cen(cen_) {
         order.resize(count); std::iota(order.begin(), order.end(), first);
         nodes.reserve(count ? 2 * (size_t)count : 1);
     }
@@ -384,7 +386,7 @@ static void reorder_best_first(WideTree& W) {
 // teapot in a stadium) can come out deeper than its budget: the build then repeats with the SAH switched off below a shallower binary
 // depth -- object-median splits are balanced, ceil(log2 n) <= 23 levels for 2^23 triangles, and the wide tree is never deeper than
 // the binary one.
-static void build_wide_subtree(const std::vector<Box>& tb, const std::vector<V3>& cen, uint32_t first, uint32_t count, uint32_t depthBudget, WideTree& W) {
+static void build_wide_subtree(const Box* tb, const V3* cen, uint32_t first, uint32_t count, uint32_t depthBudget, WideTree& W) {
     uint32_t depthLimit = depthBudget;
     if (const char* e = getenv("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
     box_reset(W.box);
@@ -458,7 +460,7 @@ void rebuild_top_tree(HostBvh& out, const float* meshBoxes) {
             cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
         }
         for (const uint32_t sahDepth : {48u, 0u}) {
-            Builder b(tb, cen, 0u, (uint32_t)items.size());
+            Builder b(tb.data(), cen.data(), 0u, (uint32_t)items.size());
             b.sahDepth = sahDepth;
             b.build(0, (uint32_t)items.size());
             std::fill(depth.begin(), depth.end(), 0u); roots.clear(); tops.clear(); used = 1;
@@ -541,73 +543,110 @@ void refresh_mesh_instances(const HostScene& s, HostBvh& out, std::vector<MeshIn
     for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? world.lo[a] : 0.f; out.sceneHi[a] = any ? world.hi[a] : 0.f; }
 }
 
+namespace {
+// Work sharing for the load-time loops below: `count` items in chunks of `grain`, handed out by an atomic cursor to up to 64 host threads
+// (the reference builds its acceleration structures on the GPU, scene.cpp:747-843; here the build is host work spread over the cores)
+template <class F> void parallel_for(size_t count, size_t grain, F&& fn) {
+    const size_t chunks = (count + grain - 1) / std::max<size_t>(grain, 1);
+    const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64), chunks);
+    std::atomic<size_t> next{0};
+    auto worker = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= chunks) break; fn(c * grain, std::min(count, (c + 1) * grain)); } };
+    if (nThreads <= 1) { worker(); return; }
+    std::vector<std::thread> th; for (size_t t = 0; t < nThreads; ++t) th.emplace_back(worker);
+    for (std::thread& t : th) t.join();
+}
+struct StageTimer {          // INCR_SCENE_TIMING=1: wall time of the stages of build_world_bvh on stderr (tools/scene_create_time.py)
+    const bool on = getenv("INCR_SCENE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  build_world_bvh %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+};
+}
 void build_world_bvh(const HostScene& s, HostBvh& out) {
+    StageTimer timer;
     // 1. flatten (update-tlas.inl:20-48: one instance per VISIBLE mesh, transform = meshTransform * rootTransform).
     //    Hidden meshes stay in the tree as unhittable (NaN) triangles: incr_update_bvh can then show / hide a mesh by
     //    re-transforming and refitting on the device, without a rebuild; ids count visible meshes only, as DXR's do.
     struct Flat { V3 v0, e1, e2; V3 obj[3]; uint32_t inst, geom, prim, flags, mesh, primGlobal; uint32_t idx[3]; bool hidden; };
-    std::vector<Flat> flat;
+    RecordVec<Flat> flat;
     const size_t numMeshes = s.meshTransforms.size();
     out.meshObjBox.assign(numMeshes * 6, 0.f);
     for (size_t m = 0; m < numMeshes; ++m) for (int a = 0; a < 3; ++a) { out.meshObjBox[m * 6 + a] = FLT_MAX; out.meshObjBox[m * 6 + 3 + a] = -FLT_MAX; }
     out.meshLocalToWorld.resize(numMeshes);
     for (size_t m = 0; m < numMeshes; ++m) out.meshLocalToWorld[m] = m44_mul(s.meshTransforms[m], s.rootTransform);
-    uint32_t inst = 0;
     std::vector<uint32_t> meshFirst(numMeshes + 1, 0u);          // flattened triangles of mesh m: [meshFirst[m], meshFirst[m + 1])
+    std::vector<uint32_t> meshInst(numMeshes, 0xffffffffu);
+    uint32_t inst = 0;
     for (uint32_t mesh = 0; mesh < (uint32_t)numMeshes; ++mesh) {
-        meshFirst[mesh] = (uint32_t)flat.size();
-        const bool hidden = !s.meshVisibility[mesh];
-        const M44& l2w = out.meshLocalToWorld[mesh];
-        const bool mirrored = m44_det3(l2w) < 0.f;
-        for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
-            const uint32_t pg = s.primitiveOffset[mesh] + g;
-            const incr_gpu_primitive& prim = s.primitives[pg];
-            const bool opaque = s.materials[(size_t)prim.materialIndex].alphaMode == INCR_ALPHA_OPAQUE;    // scene.cpp:736
-            AccessorRef ia, pa; const bool hi = resolve_accessor(s, prim.indexAccessor, &ia), hp = resolve_accessor(s, prim.positionAccessor, &pa);
-            const uint32_t ntri = (uint32_t)prim.indexCount / 3;
-            for (uint32_t p = 0; p < ntri; ++p) {
-                Flat f;
-                fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
-                V3 v[3];
-                for (int k = 0; k < 3; ++k) {
-                    float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos);
-                    f.obj[k] = v3(pos[0], pos[1], pos[2]);
-                    v[k] = m44_transform_point(f.obj[k], l2w);
-                    for (int a = 0; a < 3; ++a) if (pos[a] == pos[a]) {
-                        out.meshObjBox[mesh * 6 + a] = std::min(out.meshObjBox[mesh * 6 + a], pos[a]);
-                        out.meshObjBox[mesh * 6 + 3 + a] = std::max(out.meshObjBox[mesh * 6 + 3 + a], pos[a]);
-                    }
-                }
-                f.v0 = v[0];
-                f.e1 = (mirrored ? v[2] : v[1]) - v[0];
-                f.e2 = (mirrored ? v[1] : v[2]) - v[0];
-                f.inst = hidden ? 0xffffffffu : inst; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg; f.hidden = hidden;
-                f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
-                flat.push_back(f);
-            }
-        }
-        if (!hidden) ++inst;
+        uint32_t ntri = 0;
+        for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) ntri += (uint32_t)s.primitives[s.primitiveOffset[mesh] + g].indexCount / 3;
+        meshFirst[mesh + 1] = meshFirst[mesh] + ntri;
+        if (s.meshVisibility[mesh]) meshInst[mesh] = inst++;
     }
     out.numInstances = inst;
-    meshFirst[numMeshes] = (uint32_t)flat.size();
+    flat.resize(meshFirst[numMeshes]);
+    parallel_for(numMeshes, 1, [&](size_t m0, size_t m1) {
+        for (uint32_t mesh = (uint32_t)m0; mesh < (uint32_t)m1; ++mesh) {
+            size_t w = meshFirst[mesh];
+            const bool hidden = !s.meshVisibility[mesh];
+            const M44& l2w = out.meshLocalToWorld[mesh];
+            const bool mirrored = m44_det3(l2w) < 0.f;
+            for (uint32_t g = 0; g < s.primitiveCounts[mesh]; ++g) {
+                const uint32_t pg = s.primitiveOffset[mesh] + g;
+                const incr_gpu_primitive& prim = s.primitives[pg];
+                const bool opaque = s.materials[(size_t)prim.materialIndex].alphaMode == INCR_ALPHA_OPAQUE;    // scene.cpp:736
+                AccessorRef ia, pa; const bool hi = resolve_accessor(s, prim.indexAccessor, &ia), hp = resolve_accessor(s, prim.positionAccessor, &pa);
+                const uint32_t ntri = (uint32_t)prim.indexCount / 3;
+                for (uint32_t p = 0; p < ntri; ++p) {
+                    Flat& f = flat[w++];
+                    fetch_uint3(hi ? &ia : nullptr, p * 3, f.idx);
+                    V3 v[3];
+                    for (int k = 0; k < 3; ++k) {
+                        float pos[3]; fetch_floats(hp ? &pa : nullptr, f.idx[k], 3, pos);
+                        f.obj[k] = v3(pos[0], pos[1], pos[2]);
+                        v[k] = m44_transform_point(f.obj[k], l2w);
+                        for (int a = 0; a < 3; ++a) if (pos[a] == pos[a]) {
+                            out.meshObjBox[mesh * 6 + a] = std::min(out.meshObjBox[mesh * 6 + a], pos[a]);
+                            out.meshObjBox[mesh * 6 + 3 + a] = std::max(out.meshObjBox[mesh * 6 + 3 + a], pos[a]);
+                        }
+                    }
+                    f.v0 = v[0];
+                    f.e1 = (mirrored ? v[2] : v[1]) - v[0];
+                    f.e2 = (mirrored ? v[1] : v[2]) - v[0];
+                    f.inst = hidden ? 0xffffffffu : meshInst[mesh]; f.geom = g; f.prim = p; f.mesh = mesh; f.primGlobal = pg; f.hidden = hidden;
+                    f.flags = (opaque ? kTriOpaque : 0u) | (mirrored ? kTriMirrored : 0u);
+                }
+            }
+        }
+    });
+    timer.lap("flatten");
 
     // triangle boxes
     const size_t n = flat.size();
-    std::vector<Box> tb(n); std::vector<V3> cen(n);
+    RecordVec<Box> tbv(n); RecordVec<V3> cenv(n);
+    Box* const tb = tbv.data(); V3* const cen = cenv.data();
     Box scene; box_reset(scene);
-    for (size_t i = 0; i < n; ++i) {
-        const Flat& f = flat[i];
-        const V3 a = f.v0, b = f.v0 + f.e1, c = f.v0 + f.e2;
-        const float xs[3] = {a.x, b.x, c.x}, ys[3] = {a.y, b.y, c.y}, zs[3] = {a.z, b.z, c.z};
-        tb[i].lo[0] = std::min(xs[0], std::min(xs[1], xs[2])); tb[i].hi[0] = std::max(xs[0], std::max(xs[1], xs[2]));
-        tb[i].lo[1] = std::min(ys[0], std::min(ys[1], ys[2])); tb[i].hi[1] = std::max(ys[0], std::max(ys[1], ys[2]));
-        tb[i].lo[2] = std::min(zs[0], std::min(zs[1], zs[2])); tb[i].hi[2] = std::max(zs[0], std::max(zs[1], zs[2]));
-        // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
-        for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
-        cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
-        if (!f.hidden) box_grow(scene, tb[i]);
+    {
+        std::mutex sceneLock;
+        parallel_for(n, 65536, [&](size_t i0, size_t i1) {
+            Box part; box_reset(part);
+            for (size_t i = i0; i < i1; ++i) {
+                const Flat& f = flat[i];
+                const V3 a = f.v0, b = f.v0 + f.e1, c = f.v0 + f.e2;
+                const float xs[3] = {a.x, b.x, c.x}, ys[3] = {a.y, b.y, c.y}, zs[3] = {a.z, b.z, c.z};
+                tb[i].lo[0] = std::min(xs[0], std::min(xs[1], xs[2])); tb[i].hi[0] = std::max(xs[0], std::max(xs[1], xs[2]));
+                tb[i].lo[1] = std::min(ys[0], std::min(ys[1], ys[2])); tb[i].hi[1] = std::max(ys[0], std::max(ys[1], ys[2]));
+                tb[i].lo[2] = std::min(zs[0], std::min(zs[1], zs[2])); tb[i].hi[2] = std::max(zs[0], std::max(zs[1], zs[2]));
+                // NaN / inf vertices: give the triangle an empty box so it can never be hit but keeps its slot
+                for (int k = 0; k < 3; ++k) if (!(tb[i].lo[k] >= -FLT_MAX && tb[i].hi[k] <= FLT_MAX)) { tb[i].lo[0] = tb[i].lo[1] = tb[i].lo[2] = 0.f; tb[i].hi[0] = tb[i].hi[1] = tb[i].hi[2] = 0.f; }
+                cen[i] = v3(0.5f * (tb[i].lo[0] + tb[i].hi[0]), 0.5f * (tb[i].lo[1] + tb[i].hi[1]), 0.5f * (tb[i].lo[2] + tb[i].hi[2]));
+                if (!f.hidden) box_grow(part, tb[i]);
+            }
+            std::lock_guard<std::mutex> g(sceneLock);
+            if (part.lo[0] <= part.hi[0]) box_grow(scene, part);          // min / max: the union does not depend on the order of the parts
+        });
     }
     { const bool any = n && scene.lo[0] <= scene.hi[0]; for (int a = 0; a < 3; ++a) { out.sceneLo[a] = any ? scene.lo[a] : 0.f; out.sceneHi[a] = any ? scene.hi[a] : 0.f; } }
+    timer.lap("triangle boxes");
     // 2. one 8-wide subtree per mesh over its run of the flattened triangles (the reference's BLAS per mesh), built in parallel
     std::vector<WideTree> sub(numMeshes);
     {
@@ -622,32 +661,44 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
                 build_wide_subtree(tb, cen, meshFirst[m], meshFirst[m + 1] - meshFirst[m], kMaxBvhDepth - 8u, sub[m]);
             }
         };
-        const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32), todo.size());
+        const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64), todo.size());
         if (nThreads <= 1) worker();
         else { std::vector<std::thread> th; for (size_t t = 0; t < nThreads; ++t) th.emplace_back(worker); for (std::thread& t : th) t.join(); }
     }
+    timer.lap("subtrees (parallel)");
     // 3. one node array: the TOP REGION (top tree + a copy of every mesh root, rebuild_top_tree) in front, then the subtrees below
     //    their roots, mesh after mesh; triangle record slots in the same order.
     out.meshRoot.assign(numMeshes, BvhNode8{}); out.meshHasTris.assign(numMeshes, 0); out.meshRootIndex.assign(numMeshes, 0u); out.meshLocalDepth.assign(numMeshes, 1u);
     uint32_t numItems = 0;
     for (size_t m = 0; m < numMeshes; ++m) if (meshFirst[m + 1] > meshFirst[m]) { out.meshHasTris[m] = 1; ++numItems; }
     out.topCapacity = 2u * numItems + 2u;
-    std::vector<uint32_t> leafOrder; leafOrder.reserve(n + n / 2);          // leaf-order position -> flattened triangle id (holes: kTriHole)
-    out.nodes8.assign(out.topCapacity, BvhNode8{});
-    std::vector<uint32_t> blockStart(numMeshes, 0u);
+    std::vector<uint32_t> leafOrder;          // leaf-order position -> flattened triangle id (holes: kTriHole)
+    std::vector<uint32_t> blockStart(numMeshes, 0u), slotStart(numMeshes, 0u);
     uint32_t maxLocal = 1;
-    for (size_t m = 0; m < numMeshes; ++m) {
-        if (!out.meshHasTris[m]) continue;
-        const WideTree& W = sub[m];
-        blockStart[m] = (uint32_t)out.nodes8.size();
-        const uint32_t slotOffset = (uint32_t)leafOrder.size();
-        auto fix = [&](BvhNode8 nd) { if (nd.imask) nd.childBase = blockStart[m] + nd.childBase - 1u; nd.triBase += slotOffset; return nd; };      // (a node's children have local indices >= 1)
-        out.meshRoot[m] = fix(W.nodes[0]);
-        for (size_t i = 1; i < W.nodes.size(); ++i) out.nodes8.push_back(fix(W.nodes[i]));
-        leafOrder.insert(leafOrder.end(), W.leafOrder.begin(), W.leafOrder.end());
-        out.meshLocalDepth[m] = std::max(W.maxDepth, 1u);
-        maxLocal = std::max(maxLocal, out.meshLocalDepth[m]);
+    {
+        size_t nodesEnd = out.topCapacity, slotsEnd = 0;
+        for (size_t m = 0; m < numMeshes; ++m) {
+            if (!out.meshHasTris[m]) continue;
+            blockStart[m] = (uint32_t)nodesEnd; slotStart[m] = (uint32_t)slotsEnd;
+            nodesEnd += sub[m].nodes.size() - 1; slotsEnd += sub[m].leafOrder.size();
+            out.meshLocalDepth[m] = std::max(sub[m].maxDepth, 1u);
+            maxLocal = std::max(maxLocal, out.meshLocalDepth[m]);
+        }
+        out.nodes8.assign(out.topCapacity, BvhNode8{});
+        out.nodes8.resize(nodesEnd);
+        leafOrder.resize(slotsEnd);
     }
+    parallel_for(numMeshes, 1, [&](size_t m0, size_t m1) {          // every mesh copies its subtree into its own range
+        for (size_t m = m0; m < m1; ++m) {
+            if (!out.meshHasTris[m]) continue;
+            const WideTree& W = sub[m];
+            const uint32_t slotOffset = slotStart[m];
+            auto fix = [&](BvhNode8 nd) { if (nd.imask) nd.childBase = blockStart[m] + nd.childBase - 1u; nd.triBase += slotOffset; return nd; };      // (a node's children have local indices >= 1)
+            out.meshRoot[m] = fix(W.nodes[0]);
+            for (size_t i = 1; i < W.nodes.size(); ++i) out.nodes8[blockStart[m] + i - 1] = fix(W.nodes[i]);
+            std::copy(W.leafOrder.begin(), W.leafOrder.end(), leafOrder.begin() + slotOffset);
+        }
+    });
     // refit order, static part: the subtrees below the roots, deepest local level first (children before parents)
     out.refitNodes.clear(); out.refitRanges.clear();
     for (uint32_t d = maxLocal; d >= 2u; --d) {
@@ -669,11 +720,13 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         rebuild_top_tree(out, meshBoxes.data());
     }
 
+    timer.lap("node array + refit order + top tree");
     // 4. emit triangles + shading records in leaf order
     const size_t slots = leafOrder.size();                 // triangles + holes (device_types.h LEAF SLOTS)
     out.numTriangles = (uint32_t)n;
     out.tris.resize(slots); out.shade.resize(n); out.triObj.resize(slots);
-    for (size_t i = 0; i < slots; ++i) {
+    parallel_for(slots, 32768, [&](size_t s0, size_t s1) {          // every slot writes its own records (shading records: one per flattened id)
+    for (size_t i = s0; i < s1; ++i) {
         if (leafOrder[i] == kTriHole) {
             const float qnan = std::numeric_limits<float>::quiet_NaN();
             TriObject& ob = out.triObj[i]; memset(&ob, 0, sizeof ob); ob.mesh = kTriHole; ob.flatId = kTriHole;
@@ -709,7 +762,10 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
         sh.materialIndex = (uint32_t)prim.materialIndex;
         sh.meshIndex = (uint32_t)prim.meshIndex;
         sh.instance = f.inst; sh.geometry = f.geom; sh.primitive = f.prim;
+    
     }
+    });
+    timer.lap("triangle + shading records");
 }
 
 const char* check_bvh(const HostBvh& bvh) {

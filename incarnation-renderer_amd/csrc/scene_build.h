@@ -3,6 +3,7 @@
 // flattens every visible mesh instance to world space, builds a SAH BVH, collapses it to 8-wide nodes with
 // quantised child boxes and bakes one 128-byte shading record per triangle.
 #pragma once
+#include <memory>
 #include <vector>
 #include "device_types.h"
 #include "host_math.h"
@@ -32,17 +33,27 @@ struct HostScene {
     std::vector<M44> decalTransforms;      // per decal primitive
 };
 
+// std::vector whose resize() leaves new elements UNINITIALISED: the three big record arrays of a scene (0.8 GB on the Bistro-scale scene) are
+// filled slot by slot by parallel workers right after they are sized; value-initialising them first was a serial memset of the lot.
+template <class T> struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using RecordVec = std::vector<T, DefaultInitAllocator<T>>;
+
 struct HostBvh {
     std::vector<BvhNode8> nodes8;       // node 0 = root (8-wide, quantised child boxes)
-    std::vector<TriIsect> tris;         // leaf order, four record slots per leaf child: triangles + holes (device_types.h LEAF SLOTS)
-    std::vector<TriShade> shade;        // indexed by flattened triangle id (numTriangles records)
+    RecordVec<TriIsect> tris;           // leaf order, four record slots per leaf child: triangles + holes (device_types.h LEAF SLOTS)
+    RecordVec<TriShade> shade;          // indexed by flattened triangle id (numTriangles records)
     uint32_t numTriangles = 0;          // records that are triangles
     std::vector<M44> meshLocalToWorld;  // per mesh: meshTransform * rootTransform (shader: mul(localToWorld, sceneRotation))
     uint32_t numInstances = 0;
     uint32_t maxDepth = 0;
     float sceneLo[3], sceneHi[3];
     // ---- inputs of the device-side update (bvh_update.hip: re-transform + refit, UpdateTLASPass stand-in) ----
-    std::vector<TriObject> triObj;      // leaf order: object-space vertices + mesh / flags / flattened id
+    RecordVec<TriObject> triObj;        // leaf order: object-space vertices + mesh / flags / flattened id
     // two-level layout (scene_build.cpp): nodes8[0 .. topCapacity) is the TOP REGION -- the top tree over the meshes and one copy of
     // every mesh root, rewritten by rebuild_top_tree -- and the meshes' subtrees below their roots follow and never move
     uint32_t topCapacity = 0, topCount = 0;

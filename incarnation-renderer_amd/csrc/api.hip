@@ -2,6 +2,7 @@
 // per-pass entry points.  Host code only; kernels live in pathtrace.hip / raster.hip.
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <chrono>
 #include <dlfcn.h>
 
 #include <cmath>
@@ -371,7 +372,10 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     incr_scene* sc = new (std::nothrow) incr_scene();
     if (!sc) return fail(INCR_ERR_OUT_OF_MEMORY, "host allocation failed");
     sc->ctx = ctx;
+    struct Lap { const bool on = getenv("INCR_SCENE_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                 void operator()(const char* what) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  incr_scene_create %-26s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } } lap;
     copy_scene_desc(*desc, sc->host);
+    lap("copy of the desc");
     const char* why = "";
     if (!validate_scene(sc->host, &why)) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "scene desc rejected: %s", why); }
     for (uint32_t i = 0; i < desc->num_materials; ++i) {
@@ -380,13 +384,16 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
                                 m.transmissionTextureIndex, m.clearcoatTextureIndex, m.clearcoatRoughnessTextureIndex, m.clearcoatNormalTextureIndex};
         for (int32_t t : idx) if (t < -1 || t >= (int32_t)desc->num_textures) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "material %u: texture index %d out of range", i, t); }
     }
+    lap("validation");
     build_world_bvh(sc->host, sc->bvh);
+    lap("build_world_bvh");
     if (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes) {
         const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
         delete sc;
         return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes);
     }
     int rc = upload_bvh(sc);
+    lap("upload of the tree");
     if (!rc) rc = upload_vec(&sc->dMaterials, sc->host.materials.data(), sc->host.materials.size());
     if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
     if (!rc) rc = upload_vec(&sc->dLightIndices, sc->host.lightIndices.data(), sc->host.lightIndices.size());
@@ -582,7 +589,9 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     }
     sc->hostTextures = texs;
     if (!rc) rc = upload_vec(&sc->dTextures, texs.data(), texs.size());
+    lap("textures");
     if (!rc) rc = incr_raster_scene_upload(sc);
+    lap("raster-side bake + upload");
     if (rc) { incr_scene_destroy(ctx, sc); return rc; }
     *out = sc;
     return INCR_OK;

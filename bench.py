@@ -338,12 +338,12 @@ def main():
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-frame leg (ms/frame of BASELINE config 3; N = 1 only)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="concurrent bands of tile rows a path-traced frame is issued as (incr_set_pathtrace_pipelines; results are bit-identical; "
-                         "0 = the library's choice: 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels). "
+                         "0 = the library's choice: 1 with the side stream of --overlap, else 2 for a frame and 4 for a framebuffer shard of fewer than 1.5 M pixels). "
                          "With more than one, launches of different bands overlap and stretch each other: the per-kernel times then price launches "
                          "that share the GPU; --pipelines 1 times every kernel alone (profiles/ holds both)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
-                    help="bounce overlap (incr_set_pathtrace_overlap: the closest-hit launch of bounce b + 1 runs beside the any-hit launch of bounce b on a side "
-                         "stream); auto = the library's default (on), except with --pipelines 1, whose purpose is to time every kernel alone")
+                    help="incr_set_pathtrace_overlap: the any-hit launches (and the deferred summation) of a pipeline run on a side stream beside its main chain "
+                         "primary -> shade -> extend -> shade ...; auto = the library's default (on), except with an explicit --pipelines 1, whose purpose is to time every kernel alone")
     ap.add_argument("--spp-per-gather", type=int, default=64,
                     help="N > 1: samples accumulated in each rank's history shard between two RCCL gathers of the HDR buffer "
                          "(BASELINE config 4 = 64 spp per gathered frame, SURVEY.md 8e); the last timed step always gathers")
@@ -585,10 +585,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": dominant, "kernel_ms": round(kernel_ms, 4), "kernel_launches_per_step": dom_launches / args.steps,
-                         "kernel_timing": ("HIP events on each pipeline's stream; %d pipelines overlap, so a launch shares the GPU with the other bands' "
-                                           "kernels while it is timed (sum of kernel_ms_per_step > ms_per_step; the streaming kernels' intervals are mostly waiting for CUs, "
-                                           "so the dominant kernel is picked among the two traversal kernels); --pipelines 1 times kernels alone" % prof.pipelines)
-                                          if (prof.pipelines > 1 or prof.overlap) else "HIP events on the launch stream, one pipeline, no bounce overlap: every kernel has the GPU to itself",
+                         "kernel_timing": ("HIP events around every launch on the stream it is issued on; %d pipeline(s)%s: launches share the GPU while they are timed "
+                                           "(the sum of kernel_ms_per_step exceeds ms_per_step), so the dominant kernel is picked among the two traversal kernels by the bytes they "
+                                           "move; roofline.alone times the same kernel with the GPU to itself" % (prof.pipelines, ", the any-hit launches on a side stream beside the main chain (deferred accumulation)" if prof.overlap else ""))
+                                          if (prof.pipelines > 1 or prof.overlap) else "HIP events around every launch, one pipeline, everything on one stream: every kernel has the GPU to itself",
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "bytes_per_ray": b_ray, "bytes_per_hit": B_HIT, "bytes_per_pixel_sample": B_PX,
                          "whole_call": {"ms": round(call_ms, 4), "algorithmic_bytes": int(frame_alg_bytes),

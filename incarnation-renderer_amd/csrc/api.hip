@@ -109,7 +109,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
     HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
     const char* rc = getenv("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
-    ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 8u;
+    ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 12u;          // one queue for the four bounces of a path (6 rays per path on the bench scene)
     const char* se = getenv("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
     ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0; ctx->wfStage = nullptr; ctx->wfStageBytes = 0;
@@ -300,16 +300,17 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 }
 
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned) per pipeline.
-// 272 B of path state + raysPerPath x 48 B of shadow-ray queue per pixel: 5.4 GB at 4K -- 1.9 % of the 288 GB.
+// 656 B of path state (the vertex records of the four bounces side by side) + raysPerPath x 48 B of shadow-ray queue per pixel: 10.2 GB at 4K -- 3.5 % of the 288 GB.
 // A pipeline owns a band of 8-pixel tile rows (equal shares; a frame of fewer tile rows than pipelines uses fewer).
 static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, uint32_t numSamples, hipStream_t stream) {
     const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u * numSamples;       // samples in flight: the tile rows of one sample after the other
     // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
     // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
-    // With bounce overlap every pipeline owns two streams and the runtime multiplexes more than four streams onto its hardware queues (helmet
-    // 1080p: 1.10 ms with two pipelines, 1.46 with three, 2.16 with four): two pipelines whatever the size (a 1/8 shard of 4K, 8 samples
-    // in flight: 2.39 ms per sample with four pipelines and no overlap, 2.30 with two and overlap; gpurun_out/r4_ab_overlap.txt -> profiles/).
-    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : (ctx->wfOverlap ? 2u : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u));
+    // With the any-hit launches on the side stream (deferred accumulation, pathtrace_wf.hip launcher) ONE pipeline is the fastest issue at every size
+    // measured: 4K 17.90 ms with one pipeline, 18.24 with two (same box, gpurun_out/r4_ab_deferred2.txt -> profiles/); a 1/8 shard of 4K and the helmet at
+    // 1080p are within 1 % either way.  More pipelines also mean more streams than the runtime has hardware queues (helmet 1080p: 1.10 ms with two
+    // pipelines of two streams, 1.46 with three, 2.16 with four).  Without the side stream: two for a frame, four for a framebuffer shard, as in rounds 2-3.
+    const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : (ctx->wfOverlap ? 1u : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u));
     const int pipes = (int)std::max(1u, std::min<uint32_t>(wanted, tilesY / 4u));      // >= 4 tile rows each
     ctx->wfPipes = pipes;
     for (int i = 1; i < pipes; ++i) if (!ctx->wfStreams[i]) {
@@ -326,7 +327,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
         const uint64_t paths = std::max<uint64_t>((uint64_t)(ctx->wfTileRow[i + 1] - ctx->wfTileRow[i]) * tilesX * 64u, 1);
         n[i] = (paths + 255) & ~255ull;
         rayCap[i] = std::min<uint64_t>(n[i] * ctx->raysPerPath, 0xfffffff0ull);
-        need += n[i] * (32 * 4 + 16 + 128) + 4096 + (rayCap[i] + 1) * 48;
+        need += n[i] * (32 * 4 + 16 + 4 * 128) + 4096 + (rayCap[i] + 1) * 48;          // vertex records of the four bounces side by side (deferred accumulation)
     }
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -341,7 +342,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
         WfBuffers& w = ctx->wf[i];
         w.counters = (uint32_t*)p; p += 4096;
         w.extA = (float4*)p; p += n[i] * 32; w.extB = (float4*)p; p += n[i] * 32; w.stA = (float4*)p; p += n[i] * 32; w.stB = (float4*)p; p += n[i] * 32;
-        w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 48; w.vertexFull = (float4*)p; p += n[i] * 80;
+        w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 48 * 4; w.vertexFull = (float4*)p; p += n[i] * 80 * 4;
         w.rayQ = (float4*)p; p += (rayCap[i] + 1) * 32; w.rayC = (float4*)p; p += (rayCap[i] + 1) * 16; w.rayCap = (uint32_t)rayCap[i];
         w.numPaths = (uint32_t)n[i];
     }
@@ -920,21 +921,16 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     memset(out, 0, sizeof *out);
     ctx->profiling = false;
     HIP_TRY(hipDeviceSynchronize());
-    double* cls[5] = {&out->extend_ms, &out->shade_ms, &out->shadow_gen_ms, &out->shadow_ms, &out->accumulate_ms};
     // every pipeline's kernels are timed on the pipeline's own stream; with more than one pipeline the intervals of different
     // pipelines overlap in time, so the per-kernel sums can exceed the frame's wall time (they price the kernels, not the frame)
+    double* kinds[4] = {&out->extend_ms, &out->shade_ms, &out->shadow_ms, &out->accumulate_ms};
+    const int launchSlot[4] = {0, 1, 3, 4};
     for (size_t f = 0; f < ctx->profFrames; ++f) for (int pipe = 0; pipe < (ctx->profPipes[f] & 0xff); ++pipe) {
         hipEvent_t* ev = ctx->profEvents.data() + (f * kMaxPipes + pipe) * kProfEvents;
-        const bool overlapped = (ctx->profPipes[f] & 0x100) != 0;
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); out->generate_ms += ms;
-        for (int k = 0; k < 20; ++k) {
-            HIP_TRY(hipEventElapsedTime(&ms, ev[1 + k], ev[2 + k]));
-            if (overlapped && k % 5 == 0 && k > 0) {          // bounce overlap: on the pipeline's stream this interval is only the WAIT for the side stream's extend launch
-                out->extend_wait_ms += ms;
-                HIP_TRY(hipEventElapsedTime(&ms, ev[22 + 2 * (k / 5 - 1)], ev[23 + 2 * (k / 5 - 1)]));
-            }
-            *cls[k % 5] += ms; if (ms > 0.f) out->launches[k % 5]++;
+        for (int b = 0; b < 4; ++b) for (int k = 0; k < 4; ++k) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[1 + (b * 4 + k) * 2], ev[1 + (b * 4 + k) * 2 + 1]));
+            *kinds[k] += ms; if (ms > 0.f) out->launches[launchSlot[k]]++;
         }
     }
     out->frames = (uint32_t)ctx->profFrames;

@@ -90,7 +90,7 @@ static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved 
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kGenOrderCap = 2048;         // rays of one workgroup (256 vertices) that the light-major order handles; beyond that the vertex-major order stays
 static constexpr uint32_t kGenBins = kGenLdsLights + 4; // one bin per scene light (when they fit the LDS table) + the sky samples by direction quadrant
-static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u;
+static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u, kFlagMiss = 32u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
 // Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
 // items: 44.9 / 44.5 / 45.5 / 46.3 / 51.4 / 55.0 / 58.6 -- with 8192 persistent waves a 512-item chunk is a quarter of a
@@ -122,7 +122,9 @@ static constexpr bool kWfLightMajor = INCR_WF_LIGHT_MAJOR != 0;
 #endif
 static constexpr bool kWfOccCache = INCR_WF_OCC_CACHE != 0;
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
-static constexpr int kCursorBase = 16, kRayCountBase = 32;
+// (round 4: ONE shadow-ray queue for the four bounces -- [32] counts its rays; [40 + b] = its length before the rays of bounce b, [40 + b + 1] after
+//  them, written by wf_snapshot_kernel behind wf_shade_kernel(b): a shadow launch traces the rays of one or several bounces as the range between two snapshots)
+static constexpr int kCursorBase = 16, kRayCountBase = 32, kSnapBase = 40;
 
 // Path state is indexed by LIST SLOT, not by pixel: the rays of a bounce are a flat list (generate / shade append to it), and
 // everything a kernel of that bounce touches -- the ray, the colour / attenuation travelling with it, the hit, the vertex record --
@@ -140,8 +142,11 @@ static constexpr int kCursorBase = 16, kRayCountBase = 32;
 //   [kFAtt] attenuation at the vertex .xyz, incoming ray direction .y   [kFSky] skyDir.xyz, incoming ray direction .z
 enum : int { kVColor = 0, kVMask = 1, kVMeta = 2 };
 enum : int { kFPos = 0, kFNrm = 1, kFBase = 2, kFAtt = 3, kFSky = 4 };
-DI float4* vertex_of(const WfBuffers& B, uint32_t slot) { return B.vertex + (size_t)slot * 3; }
-DI float4* vertex_full_of(const WfBuffers& B, uint32_t slot) { return B.vertexFull + (size_t)slot * 5; }
+// Round 4: the records of the FOUR bounces live side by side (B.vertex + bounce * numPaths * 3): wf_accumulate_kernel(b) runs after the shading of
+// the later bounces (DEFERRED ACCUMULATION, launcher below), so a bounce cannot reuse the previous bounce's records.  [kVColor].xyz is no longer the
+// colour so far but what THIS vertex adds to payload.color before its light loop (attenuation x emissive x 20000; for a miss: the miss shader's term).
+DI float4* vertex_of(const WfBuffers& B, int bounce, uint32_t slot) { return B.vertex + ((size_t)bounce * B.numPaths + slot) * 3; }
+DI float4* vertex_full_of(const WfBuffers& B, int bounce, uint32_t slot) { return B.vertexFull + ((size_t)bounce * B.numPaths + slot) * 5; }
 
 DI void add_counters(const PtParams& P, const Counters& cnt) {
     if (!P.stats) return;
@@ -540,7 +545,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
     for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
     __syncthreads();
     s_prefix[tid] = waveBase + incl - n;
-    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase + bounce, total) : 0u; }
+    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase, total) : 0u; }
     __syncthreads();
     if (total == 0u) return out;
     const uint32_t base = s_base;
@@ -665,18 +670,19 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             const uint32_t ly = fast_div(lp, P.divW), px = lp - ly * P.W;
             const uint32_t pixelIdx = (uint32_t)shard_global_row(P, ly) * P.W + px, sampleIdx = P.sampleIdx + smp;
             const uint4 h = B.hit[i];
-            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = make_float4(1.f, 1.f, 1.f, 0.f);      // rgsMain's payload (pathtracing.hlsl:110-114): colour 0, attenuation 1
-            if (bounce > 0) { c4 = stIn[(size_t)i * 2]; a4 = stIn[(size_t)i * 2 + 1]; }
+            // rgsMain's payload (pathtracing.hlsl:110-114): colour 0, attenuation 1.  The colour does not travel through this kernel any more: what a
+            // vertex adds to it goes into its record and wf_accumulate_kernel -- deferred to the end of the frame -- does every addition in chsMain's order
+            float4 a4 = make_float4(1.f, 1.f, 1.f, 0.f);
+            if (bounce > 0) a4 = stIn[(size_t)i * 2 + 1];
             const f3 rayD = {rd.x, rd.y, rd.z};
-            color = {c4.x, c4.y, c4.z, c4.w};
+            color = {0.f, 0.f, 0.f, 0.f};
             f3 attenuation = {a4.x, a4.y, a4.z};
-            float4* vtx = vertex_of(B, i);
+            float4* vtx = vertex_of(B, bounce, i);
             if (P.hitChain && h.x == kMissTri) { uint32_t* hc = P.hitChain + (size_t)lp * 12u + 3u * (uint32_t)bounce; hc[0] = 0xffffffffu; hc[1] = 0xffffffffu; hc[2] = 0u; }
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
-                color.x += add.x; color.y += add.y; color.z += add.z;
-                store_pixel(P, px, ly, smp, color);
-                vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
+                vtx[kVColor] = make_float4(add.x, add.y, add.z, __uint_as_float(0xffffffffu));      // payload.color += add, then rgsMain stores the pixel: wf_accumulate_kernel
+                *(uint4*)(vtx + kVMeta) = make_uint4(kFlagMiss | kFlagTerminate, pid, 0u, 0u);
             } else {
                 const f3 rayO = {ro.x, ro.y, ro.z};
                 const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
                 } else {
                     const f3 add = attenuation * matInfo.emissive * 20000;
-                    color.x += add.x; color.y += add.y; color.z += add.z;
+                    color = {add.x, add.y, add.z, 0.f};                      // payload.color.xyz += add happens in wf_accumulate_kernel, before the vertex's light loop
                     attenuation = attenuation * saturate(1.f - matInfo.emissive);
                     if (matInfo.bHasNormalmap) {
                         const f3 nm = matInfo.normalmap;
@@ -811,12 +817,12 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
         ShadowGenResult sg = {SV.req, 0u, 0u};
         if (fuseShadowGen) sg = shadow_gen_block(P, B, bounce, s_gen, i, SV);
         if (haveVertex) {
-            float4* vtx = vertex_of(B, i);
+            float4* vtx = vertex_of(B, bounce, i);
             const uint32_t f = vflags | sg.flags;
             *(uint4*)(vtx + kVMask) = sg.req;
             *(uint4*)(vtx + kVMeta) = make_uint4(f, pid, sg.rayBase, vcell);
             if (!fuseShadowGen || (f & (kFlagInlineShadow | kFlagManyLights | kFlagFullRecord))) {       // someone re-evaluates this vertex: the rest of the record
-                float4* full = vertex_full_of(B, i);
+                float4* full = vertex_full_of(B, bounce, i);
                 full[kFPos] = make_float4(SV.pos.x, SV.pos.y, SV.pos.z, SV.col.w);
                 full[kFNrm] = SV.nrm;
                 full[kFBase] = make_float4(SV.col.x, SV.col.y, SV.col.z, SV.att.w);
@@ -825,10 +831,10 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             }
         }
         const uint32_t slot = block_append(cont, liveCounter, s_waveCount, &s_base);
-        // the continuation ray and its attenuation go to the next bounce's list; its colour is written there by accumulate, once the
-        // lights of this vertex are in
+        // the continuation ray and its attenuation go to the next bounce's list; its colour is written there by accumulate(bounce), which runs
+        // after the whole path has been traced
         if (cont) { extOut[(size_t)slot * 2] = nextO; extOut[(size_t)slot * 2 + 1] = nextD; stOut[(size_t)slot * 2 + 1] = nextA; }
-        if (haveVertex) vertex_of(B, i)[kVColor] = make_float4(color.x, color.y, color.z, __uint_as_float(cont ? slot : 0xffffffffu));
+        if (haveVertex) vertex_of(B, bounce, i)[kVColor] = make_float4(color.x, color.y, color.z, __uint_as_float(cont ? slot : 0xffffffffu));
     }
     add_counters(P, cnt);
 }
@@ -850,14 +856,17 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
 // ISSUES its two queue loads, the step of the lanes still tracing runs, and the new rays start after it -- their HBM
 // latency hides behind the step's fetch instead of stalling 40 busy lanes; results of finished lanes are written by the
 // next refill, all of them with one instruction.
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WAVES : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int bounce) {
+// `launch` = the index of this launch within the frame (its cursor); it traces the rays of bounces loBounce .. hiBounce = the queue range between the
+// snapshots [kSnapBase + loBounce, kSnapBase + hiBounce + 1).
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WAVES : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int launch, int loBounce, int hiBounce) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
-    const uint32_t total = min(B.counters[kRayCountBase + bounce], B.rayCap);
+    const uint32_t first = min(B.counters[kSnapBase + loBounce], B.rayCap);
+    const uint32_t total = min(B.counters[kSnapBase + hiBounce + 1], B.rayCap) - first;
     if (blockIdx.x * (kWfBlock / 64) * kShadowChunk >= total) return;          // no static chunk for any wave of this workgroup (see wf_extend_kernel)
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
     st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kShadow));
-    uint32_t* cursor = B.counters + kCursorBase + 2 * bounce + 1;
+    uint32_t* cursor = B.counters + kCursorBase + 2 * launch + 1;
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0;
@@ -872,7 +881,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
             LANE_STATS(ls.refills++;)
             if (occludedDone) { ((float*)(B.rayC + rayIndex))[3] = 0.f; occludedDone = false; }          // rayIndex = the ray's RECORD (direction.w of its queue entry)
             const uint32_t item = chunk.take(!active, cursor, total);
-            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)item * 2]; qb = B.rayQ[(size_t)item * 2 + 1]; pending = true; }
+            if (item != 0xffffffffu) { qa = B.rayQ[(size_t)(first + item) * 2]; qb = B.rayQ[(size_t)(first + item) * 2 + 1]; pending = true; }
         }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
         if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; if (kWfOccCache && T.occluded) lastOcc = T.hitTri; active = false; }      // node step and triangle step in one iteration
@@ -899,16 +908,28 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
 // ------------------------------------------------------------------------------------------------ accumulate
 __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kernel(const PtParams P, const WfBuffers B, int bounce) {
     const uint32_t count = B.counters[bounce];
+    const float4* __restrict__ stIn = (bounce & 1) ? B.stB : B.stA;
     float4* stOut = (bounce & 1) ? B.stA : B.stB;
     for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
-        const float4* vtx = vertex_of(B, i);
+        const float4* vtx = vertex_of(B, bounce, i);
         const uint4 meta = *(const uint4*)(vtx + kVMeta);
         const uint32_t flags = meta.x;
         if (flags & kFlagSkip) continue;
         const float4 v6 = vtx[kVColor];
+        // payload.color as the path brings it to this vertex (rgsMain: 0; later: what accumulate(bounce - 1) left for this slot), plus what the vertex
+        // adds before its light loop -- chsMain's emissive term (pathtracing.hlsl:200), or the miss shader's sky term, after which rgsMain stores the pixel
+        float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bounce > 0) cin = stIn[(size_t)i * 2];
+        if (flags & kFlagMiss) {
+            const uint32_t mpid = meta.y;
+            const uint32_t smp = P.numSamples > 1u ? fast_div(mpid, P.divLocalPixels) : 0u, lp = mpid - smp * P.localPixels;
+            const uint32_t ly = fast_div(lp, P.divW);
+            store_pixel(P, lp - ly * P.W, ly, smp, {cin.x + v6.x, cin.y + v6.y, cin.z + v6.z, cin.w});
+            continue;
+        }
         const uint4 vis = *(const uint4*)(vtx + kVMask);
         const uint32_t pid = meta.y, rayBase = meta.z, cell = meta.w, nextSlot = __float_as_uint(v6.w);
-        f4 color = {v6.x, v6.y, v6.z, 0.f};                       // payload.color.w is 0 on every path that reaches a light loop
+        f4 color = {cin.x + v6.x, cin.y + v6.y, cin.z + v6.z, 0.f};          // payload.color.w is 0 on every path that reaches a light loop
         // the vertex's queued rays: [rayBase, rayBase + popc(request mask)) in ascending slot order, the sky ray (slot 127) last;
         // each record carries attenuation * GetDirectRadiance of its light -- for the sky ray attenuation * GetSkyRadiance / pdf
         // (shadow_gen_block) -- and the visibility the shadow kernel left
@@ -945,7 +966,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
             // per-vertex evaluation out of the full record: the ray queue was full for this vertex (every request is traced here), its cell
             // lists more than 127 lights (the first 127 went through the queue, the rest is traced here), or "+ 0" is not exact for it
             const bool inlineShadow = flags & kFlagInlineShadow;
-            const float4* full = vertex_full_of(B, i);
+            const float4* full = vertex_full_of(B, bounce, i);
             const float4 v0 = full[kFPos], v1 = full[kFNrm], vb = full[kFBase], va = full[kFAtt], vs = full[kFSky];
             const f3 hitPosition = {v0.x, v0.y, v0.z}, N = {v1.x, v1.y, v1.z}, basecolor = {vb.x, vb.y, vb.z}, attenV = {va.x, va.y, va.z};
             const f3 skyDir = {vs.x, vs.y, vs.z};
@@ -1030,8 +1051,12 @@ __global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters
 template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
     hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
 }
-template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
-    hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
+template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int launch, int lo, int hi) {
+    hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, launch, lo, hi);
+}
+// behind wf_shade_kernel(bounce): the shadow-ray queue's length with the rays of bounces 0 .. bounce in it
+__global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int bounce) {
+    if (threadIdx.x == 0) counters[kSnapBase + bounce + 1] = counters[kRayCountBase];
 }
 } // namespace incr
 
@@ -1042,14 +1067,16 @@ template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, 
 // pipeline the whole GPU waits for that tail 8 times per frame; with two, the other pipeline's kernels fill the machine meanwhile.
 // The effect grows as the frame shrinks (a 1/8 framebuffer shard of an 8-GPU run: profiles/r02_shard_emulation.json).
 //
-// BOUNCE OVERLAP (round 4, `overlap`): inside a pipeline the shadow rays of bounce b and the continuation rays of bounce b + 1 are both
-// made by wf_shade_kernel(b) and do not depend on each other -- chsMain traces them one after the other only because it is written as a
-// recursion.  wf_extend_kernel(b + 1) therefore runs on the pipeline's SIDE stream beside wf_shadow_kernel(b) + wf_accumulate_kernel(b):
-//     shade(b) -> { shadow(b) -> accumulate(b)  ||  extend(b + 1) } -> shade(b + 1)
-// (accumulate(b) writes the colour that travels with the ray of bounce b + 1, which only shade(b + 1) reads; extend(b + 1) writes the hit
-// records of its own list.)  A frame of few rays is a chain of launches each as long as its longest ray (helmet 1080p: seven traversal
-// launches of 110-140 us in a 1.39 ms frame, profiles/r04_small_frame_trace.txt): the chain loses three links.  On a large frame the
-// extend launch fills the drain of the shadow launch.  Results do not depend on it (same kernels, same inputs).
+// DEFERRED ACCUMULATION (round 4).  chsMain is a recursion: it traces a vertex's shadow rays, adds their light, then traces the continuation
+// ray.  Nothing a later vertex computes depends on the colour gathered so far -- payload.color is only added to -- so the pipeline's MAIN chain is
+//     primary -> shade(0) -> extend(1) -> shade(1) -> extend(2) -> shade(2) -> extend(3) -> shade(3)
+// and the shadow rays of all four bounces go into ONE queue that the any-hit launches trace as ranges (one launch per bounce group, `shadowAfter`)
+// on the pipeline's SIDE stream, beside the main chain (`overlap`; without it they are issued in place on the main stream: every launch alone).
+// When both are done, wf_accumulate_kernel(0 .. 3) replay payload.color in chsMain's order: colour so far + the vertex's own term + its lights
+// in loop order + its sky sample, bounce after bounce -- the same additions in the same order, so the image is the one of the in-order issue
+// bit for bit.  What it buys: the critical path of a frame loses its four any-hit launches and their drains (a frame of few rays is a chain of
+// launches each as long as its longest ray: helmet 1080p, profiles/r04_small_frame_trace.txt), and on a large frame the any-hit work fills
+// the drains of the closest-hit launches and vice versa.
 // `events` (optional, kWfProfEvents per pipeline): see pt_params.h.
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
@@ -1082,50 +1109,89 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const bool firstHitOnly = p->viewmode >= 2 && p->viewmode <= 5;      // VIEWMODE 2-5 return at the first hit (pathtracing.hlsl:184-196); every other mode is a full path
     const int fuseGen = firstHitOnly ? 0 : 1;             // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; the material views make no vertices
     const bool side = overlap && sideStreams && bounceFork && bounceJoin && !firstHitOnly;
-    auto mark = [&](int i, int slot) { if (events) (void)hipEventRecord(events[i * kWfProfEvents + slot], streams[i]); };
+    // any-hit launches: after which bounces the queue's new rays are traced (INCR_WF_SHADOW_GROUPS = e.g. "0,1,3": the rays of bounces 2 and 3 in one launch)
+    static const uint32_t shadowAfterMask = [] { const char* e = getenv("INCR_WF_SHADOW_GROUPS"); if (!e) return 0xfu; uint32_t m = 8u; for (const char* c = e; *c; ++c) if (*c >= '0' && *c <= '3') m |= 1u << (*c - '0'); return m; }();
+    // accumulate(b) right behind the any-hit launch that traced bounce b's rays (on its stream), or all four at the end of the main stream (A/B: INCR_WF_ACC_SIDE)
+    // Measured on one box (gpurun_out/r4_ab_deferred2.txt -> profiles/): 4K, one pipeline: 17.90 ms at the end, 18.00 behind the launches (the summation competes
+    // with the main chain for the same wave slots); helmet 1080p, a chain of short launches: 1.13 ms at the end, 1.08 behind.  So: by size.
+    static const int accSideEnv = getenv("INCR_WF_ACC_SIDE") ? atoi(getenv("INCR_WF_ACC_SIDE")) : -1;
+    uint64_t allPaths = 0; for (int i = 0; i < numPipes; ++i) allPaths += (uint64_t)(tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
+    const bool accBehindShadow = !side || (accSideEnv >= 0 ? accSideEnv != 0 : allPaths < 3000000ull);
+    bool rec[8][kWfProfEvents] = {};
+    auto ev = [&](int i, int bounce, int kind, int end, hipStream_t st) {          // kind: 0 extend, 1 shade, 2 shadow, 3 accumulate
+        if (!events) return;
+        const int k = 1 + ((bounce * 4 + kind) * 2 + end);
+        (void)hipEventRecord(events[i * kWfProfEvents + k], st); rec[i][k] = true;
+    };
     auto extend = [&](int i, int bounce, hipStream_t st) {
         const WfBuffers& b = pipes[i];
         if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+    };
+    auto shadow = [&](int i, int launch, int lo, int hi, hipStream_t st) {
+        const WfBuffers& b = pipes[i];
+        if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, launch, lo, hi); else launch_shadow<24>(blocksShadow, st, *p, b, launch, lo, hi);
     };
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
         hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
-        mark(i, 0);
-        mark(i, 1);            // (the "generate" interval of rounds 1-2 is empty: "extend" of bounce 0 = wf_primary_kernel holds both)
+        if (events) { (void)hipEventRecord(events[i * kWfProfEvents], streams[i]); rec[i][0] = true; }
     }
-    int slot = 2;
+    int groupLo[8] = {}, launches[8] = {};
+    bool forked[8] = {};
     for (int bounce = 0; bounce < 4; ++bounce) {
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
             hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
+            ev(i, bounce, 0, 0, st);
             if (bounce == 0) hipLaunchKernelGGL(wf_primary_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, total[i], tilesX, tilesY, tileRow[i] * tilesX);
-            else if (side) (void)hipStreamWaitEvent(st, bounceJoin[i * 4 + bounce - 1], 0);      // this bounce's extend ran beside the previous bounce's shadow rays
             else extend(i, bounce, st);
-            mark(i, slot);
-            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen); mark(i, slot + 1);
+            ev(i, bounce, 0, 1, st);
+            ev(i, bounce, 1, 0, st);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen);
+            if (!firstHitOnly) hipLaunchKernelGGL(wf_snapshot_kernel, dim3(1), dim3(64), 0, st, b.counters, bounce);
+            ev(i, bounce, 1, 1, st);
         }
-        if (firstHitOnly) { slot += 2; break; }
+        if (firstHitOnly) break;
+        if (!((shadowAfterMask >> bounce) & 1u) && bounce < 3) continue;
         for (int i = 0; i < numPipes; ++i) {
             if (!total[i]) continue;
-            hipStream_t st = streams[i]; const WfBuffers& b = pipes[i];
-            if (side && bounce < 3) {
-                (void)hipEventRecord(bounceFork[i * 4 + bounce], st);
-                (void)hipStreamWaitEvent(sideStreams[i], bounceFork[i * 4 + bounce], 0);
-                if (events) (void)hipEventRecord(events[i * kWfProfEvents + 22 + 2 * bounce], sideStreams[i]);
-                extend(i, bounce + 1, sideStreams[i]);
-                if (events) (void)hipEventRecord(events[i * kWfProfEvents + 23 + 2 * bounce], sideStreams[i]);
-                (void)hipEventRecord(bounceJoin[i * 4 + bounce], sideStreams[i]);
+            hipStream_t st = streams[i];
+            if (side) {          // the any-hit launch of this bounce group on the side stream, behind the shading that filled its range of the queue
+                st = sideStreams[i];
+                (void)hipEventRecord(bounceFork[i * 4 + bounce], streams[i]);
+                (void)hipStreamWaitEvent(st, bounceFork[i * 4 + bounce], 0);
+                forked[i] = true;
             }
-            mark(i, slot + 2);            // (the "shadow_gen" interval of rounds 1-2 is empty: the set-up runs inside wf_shade_kernel)
-            if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, bounce); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, bounce); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, bounce); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, bounce); else launch_shadow<24>(blocksShadow, st, *p, b, bounce);
-            mark(i, slot + 3);
-            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce); mark(i, slot + 4);
+            ev(i, bounce, 2, 0, st);
+            shadow(i, launches[i]++, groupLo[i], bounce, st);
+            ev(i, bounce, 2, 1, st);
+            // the bounces whose rays are now traced can be summed: accumulate(b) needs the visibility of bounce b's rays and the colour accumulate(b - 1)
+            // left -- both are behind it on this stream
+            for (int b = groupLo[i]; b <= bounce && accBehindShadow; ++b) {
+                ev(i, b, 3, 0, st);
+                hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, pipes[i], b);
+                ev(i, b, 3, 1, st);
+            }
+            groupLo[i] = bounce + 1;
         }
-        slot += 5;
     }
-    for (int i = 0; i < numPipes; ++i) for (int k = total[i] ? slot : 0; k < 22; ++k) mark(i, k);      // unused slots collapse to zero-length intervals
-    if (events) for (int i = 0; i < numPipes; ++i) if (!side || !total[i]) for (int k = 22; k < kWfProfEvents; ++k) mark(i, k);      // no side launches: zero-length
+    {
+        for (int i = 0; i < numPipes; ++i) if (total[i] && forked[i]) { (void)hipEventRecord(bounceJoin[i * 4], sideStreams[i]); (void)hipStreamWaitEvent(streams[i], bounceJoin[i * 4], 0); }
+        if (!firstHitOnly && !accBehindShadow) for (int bounce = 0; bounce < 4; ++bounce) for (int i = 0; i < numPipes; ++i) {
+            if (!total[i]) continue;
+            ev(i, bounce, 3, 0, streams[i]);
+            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], bounce);
+            ev(i, bounce, 3, 1, streams[i]);
+        }
+        if (firstHitOnly) for (int i = 0; i < numPipes; ++i) {          // material views: the camera rays that missed still get their sky
+            if (!total[i]) continue;
+            ev(i, 0, 3, 0, streams[i]);
+            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, streams[i], *p, pipes[i], 0);
+            ev(i, 0, 3, 1, streams[i]);
+        }
+    }
+    if (events) for (int i = 0; i < numPipes; ++i) for (int k = 0; k < kWfProfEvents; ++k) if (!rec[i][k]) (void)hipEventRecord(events[i * kWfProfEvents + k], streams[i]);      // kernels that did not run: zero-length intervals
     for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
     if (p->numSamples > 1u && p->localPixels) hipLaunchKernelGGL(wf_integrate_samples_kernel, dim3((p->localPixels + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, streams[0], *p);
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);

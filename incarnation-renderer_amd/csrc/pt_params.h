@@ -63,10 +63,10 @@ struct PtParams {
     unsigned long long* statStripes;          // raster passes: 64 striped ray counters (16 words apart), folded into `stats` afterwards
 };
 
-// HIP events per pipeline of a recorded incr_pathtrace call (incr_profile_begin): [0] start, [1] after the (empty) generate interval, then per bounce
-// extend / shade / shadow_gen / shadow / accumulate on the pipeline's stream; [22 + 2 j], [23 + 2 j] around the extend launch of bounce j + 1
-// on the pipeline's SIDE stream when it runs beside the shadow launch of bounce j (pathtrace_wf.hip "bounce overlap")
-static constexpr int kWfProfEvents = 28;
+// HIP events per pipeline of a recorded incr_pathtrace call (incr_profile_begin): [0] start, then a (start, end) pair per bounce and kernel kind --
+// [1 + (bounce * 4 + kind) * 2 + end], kind 0 extend (bounce 0: wf_primary_kernel), 1 shade, 2 shadow (the any-hit launch issued after that bounce:
+// it may cover several bounces' rays), 3 accumulate -- each recorded on the stream the kernel is launched on (pathtrace_wf.hip launcher)
+static constexpr int kWfProfEvents = 33;
 
 // Path state of the wavefront (multi-kernel) path tracer, SoA in HBM, one slot per local pixel (pathtrace_wf.hip).
 struct WfBuffers {
@@ -75,10 +75,10 @@ struct WfBuffers {
     float4* stA;         // state travelling with the rays of the even bounces, 2 x float4: {payload.color} {payload.attenuation.xyz, 0}
     float4* stB;
     uint4*  hit;         // per list slot of the current bounce: {leaf-order triangle, t, u, v}
-    float4* vertex;      // 3 x float4 per list slot of the current bounce: what accumulate reads of a vertex (pathtrace_wf.hip "vertex record")
-    float4* vertexFull;  // 5 x float4 per list slot: the rest of the record, written only for the vertices that are re-evaluated
+    float4* vertex;      // 3 x float4 per bounce and list slot ([bounce][slot]): what accumulate reads of a vertex (pathtrace_wf.hip "vertex record")
+    float4* vertexFull;  // 5 x float4 per bounce and list slot: the rest of the record, written only for the vertices that are re-evaluated
     uint32_t* counters;  // 64 words: list lengths, traversal cursors, shadow-ray counts (pathtrace_wf.hip kCursorBase / kRayCountBase)
-    float4* rayQ;        // shadow-ray queue, 2 x float4 per ray: {origin.xyz, vertex slot} {direction.xyz, request slot}
+    float4* rayQ;        // shadow-ray queue (ONE for the four bounces), 2 x float4 per ray: {origin.xyz, vertex slot} {direction.xyz, index of the ray's record}
     float4* rayC;        // per queued ray: {attenuation * radiance of its light, 1 = unoccluded / 0 = occluded}
     uint32_t rayCap;     // rays the queue holds (soft limit: overflowing vertices are traced inside accumulate)
     uint32_t numPaths;

@@ -155,16 +155,19 @@ int  incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* desc, incr_str
  * Not in the reference: how a path-traced frame is issued.  The frame is cut into `pipelines` bands of 8-pixel tile rows, each
  * with its own path-state buffers and its own (library-owned) stream; the bands fork from `stream` and join it again inside
  * incr_pathtrace, so callers see one stream-ordered call.  Results are bit-identical for every count (1..8; 0 = the
- * default: chosen per call from the number of paths -- 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels --
- * or the INCR_WF_PIPELINES environment variable read at incr_initialize).  One pipeline leaves the GPU waiting
+ * default: 1 when the any-hit launches run on a side stream (incr_set_pathtrace_overlap, the default), else chosen per call from the number of
+ * paths -- 2 for a frame, 4 for a framebuffer shard of fewer than 1.5 M pixels -- or the INCR_WF_PIPELINES environment variable read at incr_initialize).  One pipeline leaves the GPU waiting
  * for the longest rays of each of the eight traversal kernels of a frame; with two the other band's kernels run meanwhile.
  */
 int  incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines);
 /*
- * Not in the reference: bounce overlap.  chsMain traces a vertex's shadow rays and then its continuation ray because it is a recursion; both
- * are made by the same shading step and neither depends on the other, so inside a pipeline the closest-hit launch of bounce b + 1 runs on a
- * side stream beside the any-hit launch (+ the summation) of bounce b.  Results are bit-identical.  Default on (INCR_WF_OVERLAP=0 at
- * incr_initialize or enable = 0 turn it off: every launch of a pipeline then runs alone, which is what per-kernel timing wants).
+ * Not in the reference: how the kernels of a pipeline are issued.  chsMain is a recursion -- shadow rays of a vertex, their light, then the continuation
+ * ray -- but nothing a later vertex computes depends on the colour gathered so far (payload.color is only added to).  The library therefore runs a
+ * pipeline's main chain camera rays -> shade -> closest hit -> shade -> ... without the shadow rays in it: they go into one queue, are traced by any-hit
+ * launches on a SIDE stream beside the main chain, and the summation of every vertex (chsMain's additions in chsMain's order, bounce after bounce) is
+ * deferred until they are done.  The image is bit-identical to the in-order issue.  Default on; INCR_WF_OVERLAP=0 at incr_initialize or enable = 0 issue
+ * everything on the pipeline's one stream, any-hit launch and summation right behind the shading of their bounce: every launch then runs alone, which
+ * is what per-kernel timing wants.
  */
 int  incr_set_pathtrace_overlap(incr_context* ctx, int32_t enable);
 
@@ -179,10 +182,10 @@ typedef struct incr_pathtrace_profile {
     uint32_t launches[5];            /* extend, shade, shadow_gen, shadow, accumulate launches that did work */
     uint32_t frames;                 /* recorded incr_pathtrace calls */
     uint32_t pipelines;              /* pipelines of the last recorded call */
-    uint32_t overlap;                /* 1: the last recorded call ran with bounce overlap (below): extend_ms then sums the launches as timed on the side
-                                        streams, where they share the GPU with the shadow launch of the bounce before */
+    uint32_t overlap;                /* 1: the last recorded call ran its any-hit launches on the pipelines' side streams (incr_set_pathtrace_overlap, below): the
+                                        launches of the two streams share the GPU while they are timed */
     uint32_t reserved0;
-    double   extend_wait_ms;         /* bounce overlap: what the pipelines' own streams still waited for those extend launches */
+    double   extend_wait_ms;         /* reserved (0) */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);
 int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);

@@ -9,19 +9,21 @@
 //     extend     closest hit (TraceRay stand-in).  b = 0: wf_primary_kernel -- rgsMain's camera ray per pixel (8x8 pixel tiles per
 //                wave) and the tile traced as ONE PACKET, then appended to L_0;  b > 0: persistent waves, one ray per lane,
 //                lane refill                                                                          [traversal only]
-//     shade      miss: msDynamicSky + store.  hit: chsMain without its light loop -- surface, material, emissive, sky sample
-//                direction, BRDF-sampled continuation ray appended to L_{b+1}; then, per workgroup, the light loop's candidates
+//     shade      miss: msDynamicSky's term into the slot's record.  hit: chsMain without its light loop -- surface, material, emissive, sky
+//                sample direction, BRDF-sampled continuation ray appended to L_{b+1}; then, per workgroup, the light loop's candidates
 //                (shadow_gen_block): one lane per (vertex, light of the vertex's grid cell) decides whether a shadow ray is
 //                needed (request mask), and one lane per RAY writes the queue record and the light's -- or the sky sample's --
 //                radiance along it                                                                    [no traversal]
 //     shadow     RayQuery stand-in: traces the queued rays, zeroes the visibility word of occluded ones [traversal only]
-//     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER over the records left visible, the sky sample's last; finished
-//                paths are stored + integrated                                                        [no traversal]
+//     accumulate chsMain's sum IN THE REFERENCE'S LOOP ORDER: colour so far + the vertex's own term + the records left visible, the sky
+//                sample's last; finished paths are stored + integrated                                  [no traversal]
+//   The MAIN CHAIN of a frame is primary -> shade(0) -> extend(1) -> shade(1) -> ... -> shade(3): nothing on it needs the colour gathered so
+//   far.  The shadow rays of all bounces go into one queue, traced by any-hit launches on a side stream beside the main chain, and the
+//   accumulate kernels run once their rays are in (DEFERRED ACCUMULATION, launcher at the end of this file).
 //   (Rounds 1-3 also carried the unfused forms -- wf_generate_kernel + wf_extend_packet_kernel, wf_shadow_gen_kernel -- behind environment
 //   hooks for A/B runs; they were removed in round 4: commit 9a57a74 / 3220d1d hold them with their measurements.)
 //
-// A frame is issued as two PIPELINES (bands of tile rows on their own streams, launcher below): the other band's kernels fill
-// the GPU while one band's traversal kernel drains its longest rays.
+// A frame can be cut into PIPELINES (bands of tile rows on their own streams); with the side stream one pipeline is the fastest issue.
 //
 // The persistent traversal kernels refill lanes (Aila & Laine 2009, adapted to 64-wide waves): a wave owns a chunk of rays taken
 // from a device-wide cursor; every loop iteration each lane tests one 8-wide node and / or one pending leaf triangle; lanes
@@ -88,8 +90,6 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
 }
 static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved records shadow_gen keeps in LDS (10 KB)
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
-static constexpr uint32_t kGenOrderCap = 2048;         // rays of one workgroup (256 vertices) that the light-major order handles; beyond that the vertex-major order stays
-static constexpr uint32_t kGenBins = kGenLdsLights + 4; // one bin per scene light (when they fit the LDS table) + the sky samples by direction quadrant
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u, kFlagMiss = 32u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
 // Round 1, one setting for both kernels, 4K Sponza-stat, ms per frame for chunks of 32 / 64 / 96 / 128 / 256 / 512 / 1024
@@ -113,14 +113,10 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
 static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;
 static constexpr uint32_t kMissTri = 0xffffffffu;
-#ifndef INCR_WF_LIGHT_MAJOR
-#define INCR_WF_LIGHT_MAJOR 0      // 0: the vertex-major queue order of rounds 1-3 (A/B builds)
-#endif
-static constexpr bool kWfLightMajor = INCR_WF_LIGHT_MAJOR != 0;
-#ifndef INCR_WF_OCC_CACHE
-#define INCR_WF_OCC_CACHE 0        // a shadow lane tests the triangle that occluded its previous ray first (A/B builds: 0)
-#endif
-static constexpr bool kWfOccCache = INCR_WF_OCC_CACHE != 0;
+// (Round 4 measured two ways of changing which rays share a shadow wave and removed both -- commit e325fc1 holds the code, profiles/r04_ab_ray_order.txt
+// the numbers: a LIGHT-MAJOR queue order out of shadow_gen_block (LDS binning by scene light: shadow 7.48 -> 7.55 ms alone, shade + 0.19 ms for the
+// binning: a lane-per-ray wave pays per iteration, not per divergence) and a per-lane OCCLUDER CACHE (the triangle that stopped the lane's previous ray
+// tested first: 7.56 -> 7.82 ms vertex-major, 7.50 -> 7.57 light-major).)
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
 // (round 4: ONE shadow-ray queue for the four bounces -- [32] counts its rays; [40 + b] = its length before the rays of bounce b, [40 + b + 1] after
 //  them, written by wf_snapshot_kernel behind wf_shade_kernel(b): a shadow launch traces the rays of one or several bounces as the range between two snapshots)
@@ -460,11 +456,6 @@ struct ShadowGenLds {
     float2 vyz[kWfBlock];
     float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
     uint32_t base;
-    // LIGHT-MAJOR queue order (round 4): a workgroup's rays are written light by light -- bin = the light's index in the scene, four more for the sky
-    // samples by direction quadrant -- instead of vertex by vertex: the 64 rays of a shadow wave then converge on one light from neighbouring
-    // origins (bounce 0: the pixels of four 8 x 8 tiles).  info[r] = owner vertex | request slot << 8 | bin << 15 | rank in the bin << 23.
-    uint32_t info[kGenOrderCap];
-    uint32_t bin[kGenBins + 1];
 };
 // What a lane brings for its list slot: the vertex wf_shade_kernel made (or nothing: a miss, a slot past the list's end).
 struct ShadowGenVertex {
@@ -572,38 +563,11 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
         if (j >= c0) { j -= c0; word = m.y; wbase = 32u; if (j >= c1) { j -= c1; word = m.z; wbase = 64u; if (j >= c2) { j -= c2; word = m.w; wbase = 96u; } } }
         *owner = lo; *slotOut = wbase + nth_set_bit(word, j);
     };
-    // ---- queue order.  The RECORD of a ray (rayC: its radiance and visibility, what accumulate sums in chsMain's loop order) stays at base + r,
-    //      vertex-major; its QUEUE entry (rayQ: what the traversal kernel walks) goes to base + order(r) and names the record in direction.w.
-    const bool reorder = kWfLightMajor && ldsLights && total <= kGenOrderCap;
-    if (reorder) {
-        for (uint32_t b = tid; b <= kGenBins; b += kWfBlock) S.bin[b] = 0u;
-        __syncthreads();
-        for (uint32_t r = tid; r < total; r += kWfBlock) {
-            uint32_t lo, slot; decode(r, &lo, &slot);
-            uint32_t bin;
-            if (slot == kSkySlot) { const float4 v4 = s_sky[lo]; bin = kGenLdsLights + (v4.x < 0.f ? 1u : 0u) + (v4.y < 0.f ? 2u : 0u); }
-            else bin = P.gridCellLights[__float_as_uint(s_pos[lo].w) + slot];
-            const uint32_t rank = atomicAdd(&S.bin[bin], 1u);                  // < 512: a vertex asks for a light at most once, 256 vertices
-            S.info[r] = lo | (slot << 8) | (bin << 15) | (rank << 23);
-        }
-        __syncthreads();
-        if (wave == 0u) {          // exclusive scan of the bin counts: three bins per lane, wave scan, write back
-            uint32_t c[3], sum = 0u;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { const uint32_t b = lane * 3u + (uint32_t)k; c[k] = b < kGenBins ? S.bin[b] : 0u; sum += c[k]; }
-            uint32_t incl2 = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl2, off, 64); if (lane >= (uint32_t)off) incl2 += v; }
-            uint32_t run = incl2 - sum;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { const uint32_t b = lane * 3u + (uint32_t)k; if (b < kGenBins) S.bin[b] = run; run += c[k]; }
-        }
-        __syncthreads();
-    }
+    // The RECORD of a ray (rayC: its radiance and visibility, what accumulate sums in chsMain's loop order) and its QUEUE entry (rayQ: what the
+    // traversal kernel walks) share the index base + r; the queue entry names the record in direction.w.
     for (uint32_t r = tid; r < total; r += kWfBlock) {
-        uint32_t lo, slot, dest = r;
-        if (reorder) { const uint32_t e = S.info[r]; lo = e & 0xffu; slot = (e >> 8) & 0x7fu; dest = S.bin[(e >> 15) & 0xffu] + (e >> 23); }
-        else decode(r, &lo, &slot);
+        uint32_t lo, slot; const uint32_t dest = r;
+        decode(r, &lo, &slot);
         const uint32_t vp = s_pid[lo];
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
@@ -870,7 +834,6 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0;
-    uint32_t lastOcc = 0xffffffffu;      // occluder cache: the triangle record that ended this lane's previous occluded ray
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
     TravAny2 T; trav_any_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.1f, 1000.f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     LANE_STATS(LaneStats ls;)
@@ -884,17 +847,13 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
             if (item != 0xffffffffu) { qa = B.rayQ[(size_t)(first + item) * 2]; qb = B.rayQ[(size_t)(first + item) * 2 + 1]; pending = true; }
         }
         LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
-        if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; if (kWfOccCache && T.occluded) lastOcc = T.hitTri; active = false; }      // node step and triangle step in one iteration
+        if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; active = false; }      // node step and triangle step in one iteration
         if (pending) {
             pending = false;
             rayIndex = __float_as_uint(qb.w);
             if (__float_as_uint(qa.w) != 0xffffffffu) {
                 trav_any_begin(T, {qa.x, qa.y, qa.z}, {qb.x, qb.y, qb.z}, 0.1f, 1000.f);     // lighting/common.hlsli:96-100
                 T.haveCur = true; T.triBase1 = 0; T.triMask1 = 0;
-                // occluder cache: any front-facing triangle in the interval occludes (lighting/common.hlsli:102-115: order-independent), so the
-                // triangle that stopped the lane's previous ray -- with the light-major queue order a ray to the same light from a neighbouring
-                // origin -- is tested first, in the triangle slot of the root's node step (the overlapped step runs both): no extra iteration
-                if (kWfOccCache && lastOcc != 0xffffffffu) { T.triBase = lastOcc; T.triMask = 1u; }
                 st.reset();
                 active = true;
             }
@@ -1072,9 +1031,9 @@ __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int
 //     primary -> shade(0) -> extend(1) -> shade(1) -> extend(2) -> shade(2) -> extend(3) -> shade(3)
 // and the shadow rays of all four bounces go into ONE queue that the any-hit launches trace as ranges (one launch per bounce group, `shadowAfter`)
 // on the pipeline's SIDE stream, beside the main chain (`overlap`; without it they are issued in place on the main stream: every launch alone).
-// When both are done, wf_accumulate_kernel(0 .. 3) replay payload.color in chsMain's order: colour so far + the vertex's own term + its lights
-// in loop order + its sky sample, bounce after bounce -- the same additions in the same order, so the image is the one of the in-order issue
-// bit for bit.  What it buys: the critical path of a frame loses its four any-hit launches and their drains (a frame of few rays is a chain of
+// wf_accumulate_kernel(0 .. 3) then replay payload.color in chsMain's order: colour so far + the vertex's own term + its lights in loop order + its
+// sky sample, bounce after bounce -- the same additions in the same order, so the image is the one of the in-order issue bit for bit.  They run at the
+// end of the main stream (a large frame) or each right behind the any-hit launch of its bounce on the side stream (a small one), by measurement.  What it buys: the critical path of a frame loses its four any-hit launches and their drains (a frame of few rays is a chain of
 // launches each as long as its longest ray: helmet 1080p, profiles/r04_small_frame_trace.txt), and on a large frame the any-hit work fills
 // the drains of the closest-hit launches and vice versa.
 // `events` (optional, kWfProfEvents per pipeline): see pt_params.h.

@@ -403,19 +403,18 @@ DI void trav_any_begin(TravAny& T, f3 o, f3 d, float tmin, float tmax) {
 }
 // The same overlap for any-hit queries (wf_shadow_kernel).  A hit ends the query, so a triangle waiting in the queue costs the node
 // steps made while it waits when it turns out to be the occluder -- measured, the fuller lanes win: shadow 8.9 -> 7.9 ms per frame.
-struct TravAny2 : TravAny { uint32_t triBase1, triMask1; uint32_t hitTri; /* record index of the occluder (valid when occluded) */ };
+struct TravAny2 : TravAny { uint32_t triBase1, triMask1; };
 template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& T) {
     const bool wantTri = T.triMask != 0u;
     const bool wantNode = T.haveCur && T.triMask1 == 0u;
     float4 ta, tb, tc;                   // deliberately not initialised: only read under the condition they are loaded under (zeroing cost 12 v_mov per iteration)
-    uint32_t ti = 0u;
-    if (wantTri) { ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
+    if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
     Fetch5 f;                            // as above (20 v_mov)
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
     if (wantTri) {
         T.triMask &= T.triMask - 1u;
         float det, U, V, Tn;
-        if (tri_hit(ta, tb, tc, T.rs.o, T.d, T.tmin, T.tmax, &det, &U, &V, &Tn)) { T.occluded = true; T.hitTri = ti; return true; }
+        if (tri_hit(ta, tb, tc, T.rs.o, T.d, T.tmin, T.tmax, &det, &U, &V, &Tn)) { T.occluded = true; return true; }
         if (!T.triMask) { T.triBase = T.triBase1; T.triMask = T.triMask1; T.triMask1 = 0u; }
     }
     if (wantNode) {

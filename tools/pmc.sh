@@ -41,11 +41,12 @@ for kn, d in kernels.items():
     if "FETCH_SIZE_KB_per_launch" in d and "WRITE_SIZE_KB_per_launch" in d:
         d["hbm_bytes_per_launch"] = int(2 * d["FETCH_SIZE_KB_per_launch"] * 1024 + d["WRITE_SIZE_KB_per_launch"] * 1024)
 _args = "$*".split()
-_pipes = int(_args[_args.index("--pipelines") + 1]) if "--pipelines" in _args else 2      # the library's choice for a whole 4K frame
-json.dump({"kernel_source_hash": bench.kernel_source_hash(), "bench_args": "$*", "pipelines": _pipes, "kernels": kernels,
+_pipes = int(_args[_args.index("--pipelines") + 1]) if "--pipelines" in _args else 1      # the library's choice with the any-hit launches on the side stream
+_overlap = (_args[_args.index("--overlap") + 1] == "on") if "--overlap" in _args else ("--pipelines" not in _args or _pipes != 1)      # bench.py: an explicit --pipelines 1 times kernels alone
+json.dump({"kernel_source_hash": bench.kernel_source_hash(), "bench_args": "$*", "pipelines": _pipes, "bounce_overlap": _overlap, "kernels": kernels,
            "source": "tools/pmc.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py $*; bytes = 2 x FETCH_SIZE x 1024 + "
                      "WRITE_SIZE x 1024 (MI355X_MICROARCH.md 'HBM': FETCH_SIZE is in KB and counts 128-B requests as 64 B on gfx950; the factor 2 is "
                      "calibrated for wide streaming reads, so for 80-B node gathers this is an upper estimate); counter collection serialises the launches, so "
-                     "these are per-launch figures of kernels that have the GPU to themselves, a launch = one pipeline's share of the frame"},
+                     "these are per-launch figures of kernels that have the GPU to themselves, a launch = one pipeline's share of the frame (the whole frame with one pipeline)"},
           open("$OUT/hbm_traffic.json", "w"), indent=1)
 PY

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R/incarnation-renderer_amd/csrc && make -s -j16 2>&1 | grep -i error; make -s -C $R/oracle 2>&1 | grep -i error
 cd $R
 if [ "$PART" = a ]; then
-  timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -2 $O/gpu_tests.log
+  timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -2 $O/gpu_tests.log
   timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
   timeout -k 10 200 python bench.py --pipelines 1 --no-raster --no-cpu-baseline > $O/bench_pipelines1.json 2>> $O/bench.err; cut -c1-200 $O/bench_pipelines1.json
   cd /tmp && export TMPDIR=/tmp

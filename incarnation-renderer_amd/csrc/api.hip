@@ -307,7 +307,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
     // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
     // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
     // With the any-hit launches on the side stream (deferred accumulation, pathtrace_wf.hip launcher) ONE pipeline is the fastest issue at every size
-    // measured: 4K 17.90 ms with one pipeline, 18.24 with two (same box, gpurun_out/r4_ab_deferred2.txt -> profiles/); a 1/8 shard of 4K and the helmet at
+    // measured: 4K 17.90 ms with one pipeline, 18.24 with two (same box, profiles/r04_ab_deferred.txt); a 1/8 shard of 4K and the helmet at
     // 1080p are within 1 % either way.  More pipelines also mean more streams than the runtime has hardware queues (helmet 1080p: 1.10 ms with two
     // pipelines of two streams, 1.46 with three, 2.16 with four).  Without the side stream: two for a frame, four for a framebuffer shard, as in rounds 2-3.
     const uint32_t wanted = ctx->wfPipesWanted ? (uint32_t)ctx->wfPipesWanted : (ctx->wfOverlap ? 1u : ((uint64_t)W * localRows * numSamples >= 1500000ull ? 2u : 4u));

@@ -1068,14 +1068,15 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const bool firstHitOnly = p->viewmode >= 2 && p->viewmode <= 5;      // VIEWMODE 2-5 return at the first hit (pathtracing.hlsl:184-196); every other mode is a full path
     const int fuseGen = firstHitOnly ? 0 : 1;             // the shadow-ray set-up of a vertex runs at the end of wf_shade_kernel's workgroup; the material views make no vertices
     const bool side = overlap && sideStreams && bounceFork && bounceJoin && !firstHitOnly;
-    // any-hit launches: after which bounces the queue's new rays are traced (INCR_WF_SHADOW_GROUPS = e.g. "0,1,3": the rays of bounces 2 and 3 in one launch)
-    static const uint32_t shadowAfterMask = [] { const char* e = getenv("INCR_WF_SHADOW_GROUPS"); if (!e) return 0xfu; uint32_t m = 8u; for (const char* c = e; *c; ++c) if (*c >= '0' && *c <= '3') m |= 1u << (*c - '0'); return m; }();
-    // accumulate(b) right behind the any-hit launch that traced bounce b's rays (on its stream), or all four at the end of the main stream (A/B: INCR_WF_ACC_SIDE)
-    // Measured on one box (gpurun_out/r4_ab_deferred2.txt -> profiles/): 4K, one pipeline: 17.90 ms at the end, 18.00 behind the launches (the summation competes
+    // any-hit launches: one per bounce.  (Fewer, longer launches -- the rays of bounces 2 + 3, of 0 + 1 and 2 + 3, or of all four in one -- were measured:
+    // alone, one launch over all 50 M rays takes 6.0 ms against 7.5 for the four, but a launch that waits for several bounces' rays has less of the
+    // main chain left to run beside: 4K frame 17.83 ms per bounce, 18.13 / 18.41 / 18.63 / 18.78 ms for the groupings above, profiles/r04_ab_deferred.txt.)
+    const uint32_t shadowAfterMask = 0xfu;
+    // accumulate(b) right behind the any-hit launch that traced bounce b's rays (on its stream), or all four at the end of the main stream
+    // Measured on one box (profiles/r04_ab_deferred.txt): 4K, one pipeline: 17.90 ms at the end, 18.00 behind the launches (the summation competes
     // with the main chain for the same wave slots); helmet 1080p, a chain of short launches: 1.13 ms at the end, 1.08 behind.  So: by size.
-    static const int accSideEnv = getenv("INCR_WF_ACC_SIDE") ? atoi(getenv("INCR_WF_ACC_SIDE")) : -1;
     uint64_t allPaths = 0; for (int i = 0; i < numPipes; ++i) allPaths += (uint64_t)(tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
-    const bool accBehindShadow = !side || (accSideEnv >= 0 ? accSideEnv != 0 : allPaths < 3000000ull);
+    const bool accBehindShadow = !side || allPaths < 3000000ull;
     bool rec[8][kWfProfEvents] = {};
     auto ev = [&](int i, int bounce, int kind, int end, hipStream_t st) {          // kind: 0 extend, 1 shade, 2 shadow, 3 accumulate
         if (!events) return;

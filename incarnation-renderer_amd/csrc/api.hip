@@ -327,7 +327,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
         const uint64_t paths = std::max<uint64_t>((uint64_t)(ctx->wfTileRow[i + 1] - ctx->wfTileRow[i]) * tilesX * 64u, 1);
         n[i] = (paths + 255) & ~255ull;
         rayCap[i] = std::min<uint64_t>(n[i] * ctx->raysPerPath, 0xfffffff0ull);
-        need += n[i] * (32 * 4 + 16 + 4 * 128) + 4096 + (rayCap[i] + 1) * 48;          // vertex records of the four bounces side by side (deferred accumulation)
+        need += n[i] * (32 * 4 + 16 + 4 * 128) + 65536 + (rayCap[i] + 1) * 48;          // vertex records of the four bounces side by side (deferred accumulation)
     }
     if (ctx->wfBytes < need) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -340,7 +340,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
     uint8_t* p = (uint8_t*)ctx->wfBlock;
     for (int i = 0; i < pipes; ++i) {
         WfBuffers& w = ctx->wf[i];
-        w.counters = (uint32_t*)p; p += 4096;
+        w.counters = (uint32_t*)p; p += 65536;          // 64 words of counters + the striped cursors of the persistent kernels, each on its own cache line
         w.extA = (float4*)p; p += n[i] * 32; w.extB = (float4*)p; p += n[i] * 32; w.stA = (float4*)p; p += n[i] * 32; w.stB = (float4*)p; p += n[i] * 32;
         w.hit = (uint4*)p; p += n[i] * 16; w.vertex = (float4*)p; p += n[i] * 48 * 4; w.vertexFull = (float4*)p; p += n[i] * 80 * 4;
         w.rayQ = (float4*)p; p += (rayCap[i] + 1) * 32; w.rayC = (float4*)p; p += (rayCap[i] + 1) * 16; w.rayCap = (uint32_t)rayCap[i];

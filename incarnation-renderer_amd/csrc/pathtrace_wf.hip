@@ -113,6 +113,12 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
 static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;
 static constexpr uint32_t kMissTri = 0xffffffffu;
+#ifndef INCR_WF_CURSOR_STRIPES
+#define INCR_WF_CURSOR_STRIPES 8      // 1 = one cursor word per launch (rounds 1-3).  The chunk requests of 7,168 waves on ONE word are a queue of same-address atomics: with
+#endif                                // 64-ray any-hit chunks the 4K frame took 21.5 ms on one cursor and 17.7 on eight; at the shipped chunk sizes eight stripes give 17.68 -> 17.55 ms (r04_ab_chunks)
+// striped cursors of the persistent kernels (WaveChunk): counters[kStripeBase + (launch slot * stripes + stripe) * 32], launch slot = bounce for the
+// closest-hit launches, 4 + launch index for the any-hit ones; zeroed by wf_init_counters_kernel
+static constexpr int kStripeBase = 128;
 // (Round 4 measured two ways of changing which rays share a shadow wave and removed both -- commit e325fc1 holds the code, profiles/r04_ab_ray_order.txt
 // the numbers: a LIGHT-MAJOR queue order out of shadow_gen_block (LDS binning by scene light: shadow 7.48 -> 7.55 ms alone, shade + 0.19 ms for the
 // binning: a lane-per-ray wave pays per iteration, not per divergence) and a per-lane OCCLUDER CACHE (the triangle that stopped the lane's previous ray
@@ -190,9 +196,13 @@ DI uint32_t light_cell(const PtParams& P, f3 p) {
 
 // Wave-level work distribution: hands the next items of the wave's chunk to idle lanes (consecutive indices in
 // lane order), taking a new chunk from the device-wide cursor when the current one is used up.
-template <uint32_t kChunk> struct WaveChunk {
+template <uint32_t kChunkDefault> struct WaveChunk {
     uint32_t next, end;     // wave-uniform
     bool exhausted;
+#if INCR_WF_CURSOR_STRIPES > 1
+    uint32_t stripe = blockIdx.x % INCR_WF_CURSOR_STRIPES, tried = 0u;
+#endif
+    uint32_t kChunk = kChunkDefault;      // items per grab: wave-uniform; the closest-hit launches of a large frame take 128 (below), everything else the compile-time size
     // A wave's FIRST chunk is static -- chunk number = its index in the grid -- and the launcher starts the cursors behind
     // that round: the 8192 waves of the grid do not queue on one cursor word for their first item (or just to learn there
     // is nothing left: a wave without a static chunk leaves at once).  Chunks are kChunk items in both rounds, so a short
@@ -210,11 +220,28 @@ template <uint32_t kChunk> struct WaveChunk {
         const unsigned long long m = __ballot(idle);
         if (m == 0ull) return 0xffffffffu;
         if (next >= end && !exhausted) {
+#if INCR_WF_CURSOR_STRIPES > 1
+            // STRIPED cursors: the part of the list behind the static round is cut into INCR_WF_CURSOR_STRIPES contiguous segments, each with a cursor of
+            // its own (on its own cache line); a wave draws from its home segment (workgroup index modulo the stripe count) and moves on to the next
+            // when that one is used up -- the grid's chunk requests no longer queue on one word
+            const uint32_t dynBase = min(gridDim.x * (kWfBlock / 64) * kChunk, total), dynTotal = total - dynBase;
+            const uint32_t segLen = ((dynTotal + INCR_WF_CURSOR_STRIPES * kChunk - 1u) / (INCR_WF_CURSOR_STRIPES * kChunk)) * kChunk;
+            for (;;) {
+                if (tried >= (uint32_t)INCR_WF_CURSOR_STRIPES || segLen == 0u) { exhausted = true; break; }
+                uint32_t b = 0;
+                if ((threadIdx.x & 63u) == 0) b = atomicAdd(cursor + stripe * 32u, kChunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                const uint32_t segBegin = dynBase + stripe * segLen;
+                if (b < segLen && segBegin + b < total) { next = segBegin + b; end = min(min(next + kChunk, segBegin + segLen), total); break; }
+                ++tried; stripe = stripe + 1u == (uint32_t)INCR_WF_CURSOR_STRIPES ? 0u : stripe + 1u;
+            }
+#else
             uint32_t b = 0;
             if ((threadIdx.x & 63u) == 0) b = atomicAdd(cursor, kChunk);
             b = __builtin_amdgcn_readfirstlane(b);
             if (b >= total) exhausted = true;
             else { next = b; end = min(b + kChunk, total); }
+#endif
         }
         if (next >= end) return 0xffffffffu;
         const uint32_t lane = threadIdx.x & 63u;
@@ -284,21 +311,25 @@ extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
 #ifndef INCR_EXTEND_WAVES10
 #define INCR_EXTEND_WAVES10 7      // 10-entry keyed stack: 70 VGPRs since the hit's shading index is its flattened id and 1 / d comes from v_rcp: 7 workgroups of 22.4 KB LDS per CU
 #endif
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3)))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce) {
+template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3)))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce, uint32_t chunkSize) {
     __shared__ uint32_t s_stack[N * kWfBlock];
     __shared__ float s_keys[N * kWfBlock];
     __shared__ float4 s_top[TopNodes<N>::kExtend * 5];
     const uint32_t total = B.counters[bounce];
     // a workgroup whose first wave has no static chunk has none at all (WaveChunk::init_static) and never takes one from the cursor: it leaves
     // before copying the top nodes -- a short list (a small frame, a late bounce) is then a short launch
-    if (blockIdx.x * (kWfBlock / 64) * kExtendChunk >= total) return;
+    if (blockIdx.x * (kWfBlock / 64) * chunkSize >= total) return;
     WfStackK<N> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
     st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kExtend));
     // the rays of this bounce: a flat queue in list order (origin + path id, direction), written by generate / shade -- a refill
     // is two coalesced loads, not a path id and two gathers behind it
     const float4* __restrict__ ext = (bounce & 1) ? B.extB : B.extA;
+#if INCR_WF_CURSOR_STRIPES > 1
+    uint32_t* cursor = B.counters + kStripeBase + bounce * INCR_WF_CURSOR_STRIPES * 32;
+#else
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
-    WaveChunk<kExtendChunk> chunk; chunk.init_static(total);
+#endif
+    WaveChunk<kExtendChunk> chunk; chunk.kChunk = chunkSize; chunk.init_static(total);
     bool active = false; uint32_t slot = 0;
     TravClosest2 T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f, 10000.0f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     uint32_t rays = 0;
@@ -645,8 +676,13 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             if (P.hitChain && h.x == kMissTri) { uint32_t* hc = P.hitChain + (size_t)lp * 12u + 3u * (uint32_t)bounce; hc[0] = 0xffffffffu; hc[1] = 0xffffffffu; hc[2] = 0u; }
             if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
                 const f3 add = sky_miss_add(P, attenuation, rayD);
-                vtx[kVColor] = make_float4(add.x, add.y, add.z, __uint_as_float(0xffffffffu));      // payload.color += add, then rgsMain stores the pixel: wf_accumulate_kernel
-                *(uint4*)(vtx + kVMeta) = make_uint4(kFlagMiss | kFlagTerminate, pid, 0u, 0u);
+                if (bounce == 0) {          // a camera ray that misses: payload.color is still rgsMain's 0, the pixel is 0 + add -- stored here, no record to write and read back
+                    store_pixel(P, px, ly, smp, {0.f + add.x, 0.f + add.y, 0.f + add.z, 0.f});
+                    vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
+                } else {
+                    vtx[kVColor] = make_float4(add.x, add.y, add.z, __uint_as_float(0xffffffffu));      // payload.color += add, then rgsMain stores the pixel: wf_accumulate_kernel
+                    *(uint4*)(vtx + kVMeta) = make_uint4(kFlagMiss | kFlagTerminate, pid, 0u, 0u);
+                }
             } else {
                 const f3 rayO = {ro.x, ro.y, ro.z};
                 const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
@@ -830,7 +866,11 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
     if (blockIdx.x * (kWfBlock / 64) * kShadowChunk >= total) return;          // no static chunk for any wave of this workgroup (see wf_extend_kernel)
     WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
     st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kShadow));
+#if INCR_WF_CURSOR_STRIPES > 1
+    uint32_t* cursor = B.counters + kStripeBase + (4 + launch) * INCR_WF_CURSOR_STRIPES * 32;
+#else
     uint32_t* cursor = B.counters + kCursorBase + 2 * launch + 1;
+#endif
     WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0;
@@ -1006,9 +1046,12 @@ __global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters
     uint32_t v = 0u;
     if (i >= (uint32_t)kCursorBase && i < (uint32_t)kCursorBase + 8u) v = ((i - kCursorBase) & 1u) ? shadowStart : extendStart;   // behind the static first round
     counters[i] = v;
+#if INCR_WF_CURSOR_STRIPES > 1
+    for (uint32_t k = i; k < 8u * INCR_WF_CURSOR_STRIPES; k += 64u) counters[kStripeBase + k * 32u] = 0u;
+#endif
 }
-template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce) {
-    hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce);
+template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce, uint32_t chunk) {
+    hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce, chunk);
 }
 template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int launch, int lo, int hi) {
     hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, launch, lo, hi);
@@ -1053,9 +1096,12 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
     const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 10 ? (uint32_t)INCR_EXTEND_WAVES10 : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u))), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
-    uint32_t total[8], blocksAll[8], blocksExtend[8];
+    uint32_t total[8], blocksAll[8], blocksExtend[8], extendChunk[8];
     for (int i = 0; i < numPipes; ++i) {
         total[i] = (tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
+        // rays a closest-hit wave takes from the cursor at a time: 128 for the long lists of a large frame (fewer same-address atomics on the cursor: 4K frame
+        // 17.74 -> 17.59 ms), 64 for short ones (helmet 1080p: 1.08 ms against 1.14 with 128: a chunk is then too large a share of a wave's work) -- r04_ab_chunks
+        extendChunk[i] = total[i] >= 4000000u ? 2u * kExtendChunk : kExtendChunk;
         // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer
         // (capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms, uncapped 42.7)
         blocksAll[i] = std::max(1u, (total[i] + kWfBlock - 1) / kWfBlock);
@@ -1085,7 +1131,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     };
     auto extend = [&](int i, int bounce, hipStream_t st) {
         const WfBuffers& b = pipes[i];
-        if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce);
+        const uint32_t ck = extendChunk[i];
+        if (sv == 8) launch_extend<8>(blocksExtend[i], st, *p, b, bounce, ck); else if (sv == 10) launch_extend<10>(blocksExtend[i], st, *p, b, bounce, ck); else if (sv == 12) launch_extend<12>(blocksExtend[i], st, *p, b, bounce, ck); else if (sv == 16) launch_extend<16>(blocksExtend[i], st, *p, b, bounce, ck); else launch_extend<24>(blocksExtend[i], st, *p, b, bounce, ck);
     };
     auto shadow = [&](int i, int launch, int lo, int hi, hipStream_t st) {
         const WfBuffers& b = pipes[i];
@@ -1094,7 +1141,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
-        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * kExtendChunk, blocksShadow * (kWfBlock / 64) * kShadowChunk);
+        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * extendChunk[i], blocksShadow * (kWfBlock / 64) * kShadowChunk);
         if (events) { (void)hipEventRecord(events[i * kWfProfEvents], streams[i]); rec[i][0] = true; }
     }
     int groupLo[8] = {}, launches[8] = {};

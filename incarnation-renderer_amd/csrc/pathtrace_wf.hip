@@ -104,11 +104,16 @@ static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow
 #ifndef INCR_SHADOW_CHUNK
 #define INCR_SHADOW_CHUNK 128
 #endif
+#ifndef INCR_EXTEND_CHUNK_LARGE
+#define INCR_EXTEND_CHUNK_LARGE 128      // closest-hit chunk of a pipeline with >= 4 M paths (launcher)
+#endif
+// Round 4, one pipeline with the any-hit launches beside the main chain (r04_ab_chunks: same box, two runs each): extend 16 / shadow 12 idle lanes 17.61-17.65 ms per
+// 4K frame, 12 / 16: 17.43-17.48, 12 / 12: 17.56-17.58, 16 / 16: 17.53-17.62, 12 / 20: 17.58-17.59, 8 / 16: 17.50-17.52.
 #ifndef INCR_EXTEND_REFILL
-#define INCR_EXTEND_REFILL 16
+#define INCR_EXTEND_REFILL 12
 #endif
 #ifndef INCR_SHADOW_REFILL
-#define INCR_SHADOW_REFILL 12
+#define INCR_SHADOW_REFILL 16
 #endif
 static constexpr uint32_t kExtendChunk = INCR_EXTEND_CHUNK, kShadowChunk = INCR_SHADOW_CHUNK;
 static constexpr uint32_t kExtendRefill = INCR_EXTEND_REFILL, kShadowRefill = INCR_SHADOW_REFILL;
@@ -1101,7 +1106,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         total[i] = (tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
         // rays a closest-hit wave takes from the cursor at a time: 128 for the long lists of a large frame (fewer same-address atomics on the cursor: 4K frame
         // 17.74 -> 17.59 ms), 64 for short ones (helmet 1080p: 1.08 ms against 1.14 with 128: a chunk is then too large a share of a wave's work) -- r04_ab_chunks
-        extendChunk[i] = total[i] >= 4000000u ? 2u * kExtendChunk : kExtendChunk;
+        extendChunk[i] = total[i] >= 4000000u ? (uint32_t)INCR_EXTEND_CHUNK_LARGE : kExtendChunk;
         // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer
         // (capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms, uncapped 42.7)
         blocksAll[i] = std::max(1u, (total[i] + kWfBlock - 1) / kWfBlock);

@@ -132,6 +132,11 @@ static constexpr int kStripeBase = 128;
 // (round 4: ONE shadow-ray queue for the four bounces -- [32] counts its rays; [40 + b] = its length before the rays of bounce b, [40 + b + 1] after
 //  them, written by wf_snapshot_kernel behind wf_shade_kernel(b): a shadow launch traces the rays of one or several bounces as the range between two snapshots)
 static constexpr int kCursorBase = 16, kRayCountBase = 32, kSnapBase = 40;
+// The dynamic sky's launch constants (Perez coefficients + the miss shader's sun: 32 floats) live in the counters block as well, written by
+// wf_init_counters_kernel: wf_accumulate_kernel reads them with scalar loads inside its miss branch only, so that they hold no SGPRs on the
+// (far more common) hit side -- as kernel arguments they are preloaded for the whole kernel and spill
+static constexpr int kSkyConstBase = 4096;
+struct WfSkyConsts { incr_perez_distribution perez; SkySun sunMiss; };
 
 // Path state is indexed by LIST SLOT, not by pixel: the rays of a bounce are a flat list (generate / shade append to it), and
 // everything a kernel of that bounce touches -- the ray, the colour / attenuation travelling with it, the hit, the vertex record --
@@ -642,7 +647,10 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-__global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce, int fuseShadowGen) {
+// ENV: the caller passed the sky cube (P.envmap != NULL: bench, the C++ renderer) -- the kernel then carries no Preetham code at all.  The analytic sky's ~35 scalar
+// constants, pre-loaded and spilled to vector-register lanes, cost the kernel 4 % even where no lane ever evaluated it (round 4: SGPR spills 197 -> 134, shade 4.43 ->
+// 4.24 ms per frame alone with the miss shading moved to wf_accumulate_kernel as well).
+template <bool ENV> __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce, int fuseShadowGen) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
     // fuseShadowGen: the shadow-ray set-up of this workgroup's vertices (shadow_gen_block) runs here, on the values still in registers,
@@ -679,15 +687,10 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
             f3 attenuation = {a4.x, a4.y, a4.z};
             float4* vtx = vertex_of(B, bounce, i);
             if (P.hitChain && h.x == kMissTri) { uint32_t* hc = P.hitChain + (size_t)lp * 12u + 3u * (uint32_t)bounce; hc[0] = 0xffffffffu; hc[1] = 0xffffffffu; hc[2] = 0u; }
-            if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319
-                const f3 add = sky_miss_add(P, attenuation, rayD);
-                if (bounce == 0) {          // a camera ray that misses: payload.color is still rgsMain's 0, the pixel is 0 + add -- stored here, no record to write and read back
-                    store_pixel(P, px, ly, smp, {0.f + add.x, 0.f + add.y, 0.f + add.z, 0.f});
-                    vtx[kVMeta] = make_float4(__uint_as_float(kFlagSkip), 0.f, 0.f, 0.f);
-                } else {
-                    vtx[kVColor] = make_float4(add.x, add.y, add.z, __uint_as_float(0xffffffffu));      // payload.color += add, then rgsMain stores the pixel: wf_accumulate_kernel
-                    *(uint4*)(vtx + kVMeta) = make_uint4(kFlagMiss | kFlagTerminate, pid, 0u, 0u);
-                }
+            if (h.x == kMissTri) {   // msEnvmap / msDynamicSky -- pathtracing.hlsl:304-319: evaluated by wf_accumulate_kernel (the analytic sky stays out of this kernel)
+                vtx[kVColor] = make_float4(attenuation.x, attenuation.y, attenuation.z, __uint_as_float(0xffffffffu));
+                vtx[kVMask] = make_float4(rayD.x, rayD.y, rayD.z, 0.f);
+                *(uint4*)(vtx + kVMeta) = make_uint4(kFlagMiss | kFlagTerminate, pid, 0u, 0u);
             } else {
                 const f3 rayO = {ro.x, ro.y, ro.z};
                 const float hitT = __uint_as_float(h.y), bx = __uint_as_float(h.z), by = __uint_as_float(h.w);
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(co
                     // sky sample :239-244
                     const f2 us = SamplePoint(pixelIdx, sampleIdx, sampleSetIndex, P.divSqrtN, P.divN, P.numPixels);
                     const f3 skyDir = CosineSampleHemisphere(us);
-                    const f3 skyRadianceIn = P.skyBrightness * sky_env_radiance(P, skyDir);
+                    const f3 skyRadianceIn = P.skyBrightness * (ENV ? cube_sample_level(CubeChain{P.envmapRes, P.envmapMips, P.envmap}, skyDir, 0u) : sky_env_radiance(P, skyDir));
                     const float skyNoL = saturate(dot(N, skyDir));
                     if (skyNoL > 0.f && (skyRadianceIn.x > 0.f || skyRadianceIn.y > 0.f || skyRadianceIn.z > 0.f)) { req3 |= 0x80000000u; cnt.skyShadow++; }
                     // ---- BRDF-sampled continuation (raytracing/common.hlsli:55-123) ----
@@ -924,11 +927,22 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
         // adds before its light loop -- chsMain's emissive term (pathtracing.hlsl:200), or the miss shader's sky term, after which rgsMain stores the pixel
         float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bounce > 0) cin = stIn[(size_t)i * 2];
-        if (flags & kFlagMiss) {
+        if (flags & kFlagMiss) {          // the miss shader's term (msEnvmap / msDynamicSky, pathtracing.hlsl:304-319) on the attenuation and direction the ray arrived with
             const uint32_t mpid = meta.y;
             const uint32_t smp = P.numSamples > 1u ? fast_div(mpid, P.divLocalPixels) : 0u, lp = mpid - smp * P.localPixels;
             const uint32_t ly = fast_div(lp, P.divW);
-            store_pixel(P, lp - ly * P.W, ly, smp, {cin.x + v6.x, cin.y + v6.y, cin.z + v6.z, cin.w});
+            const float4 md = vtx[kVMask];
+            f3 add;
+            if (P.envSkyMode == 0) add = sky_miss_add(P, mk3(v6.x, v6.y, v6.z), mk3(md.x, md.y, md.z));
+            else {          // sky_miss_add's msDynamicSky arm on the constants wf_init_counters_kernel left in the workspace
+                typedef const __attribute__((address_space(4))) float* ConstFloats;
+                const ConstFloats sc = (ConstFloats)(uintptr_t)(B.counters + kSkyConstBase);
+                WfSkyConsts k;
+#pragma unroll
+                for (uint32_t w = 0; w < sizeof(WfSkyConsts) / 4u; ++w) ((float*)&k)[w] = sc[w];
+                add = mk3(v6.x, v6.y, v6.z) * 1000 * CalculateSkyRadianceRGB(k.sunMiss, mk3(md.x, md.y, md.z), k.perez);
+            }
+            store_pixel(P, lp - ly * P.W, ly, smp, {cin.x + add.x, cin.y + add.y, cin.z + add.z, cin.w});
             continue;
         }
         const uint4 vis = *(const uint4*)(vtx + kVMask);
@@ -1046,8 +1060,9 @@ __global__ __launch_bounds__(kWfBlock) void wf_integrate_samples_kernel(const Pt
 
 // ---- launcher ------------------------------------------------------------------------------------------
 namespace incr {
-__global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters, uint32_t extendStart, uint32_t shadowStart) {
+__global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters, uint32_t extendStart, uint32_t shadowStart, const WfSkyConsts sky) {
     const uint32_t i = threadIdx.x;
+    if (i < sizeof(WfSkyConsts) / 4u) counters[kSkyConstBase + i] = ((const uint32_t*)&sky)[i];
     uint32_t v = 0u;
     if (i >= (uint32_t)kCursorBase && i < (uint32_t)kCursorBase + 8u) v = ((i - kCursorBase) & 1u) ? shadowStart : extendStart;   // behind the static first round
     counters[i] = v;
@@ -1143,10 +1158,12 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         const WfBuffers& b = pipes[i];
         if (sv == 8) launch_shadow<8>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 10) launch_shadow<10>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 12) launch_shadow<12>(blocksShadow, st, *p, b, launch, lo, hi); else if (sv == 16) launch_shadow<16>(blocksShadow, st, *p, b, launch, lo, hi); else launch_shadow<24>(blocksShadow, st, *p, b, launch, lo, hi);
     };
+    WfSkyConsts skyConsts;
+    skyConsts.perez = p->perez; skyConsts.sunMiss = p->sunMiss;
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
-        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * extendChunk[i], blocksShadow * (kWfBlock / 64) * kShadowChunk);
+        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * extendChunk[i], blocksShadow * (kWfBlock / 64) * kShadowChunk, skyConsts);
         if (events) { (void)hipEventRecord(events[i * kWfProfEvents], streams[i]); rec[i][0] = true; }
     }
     int groupLo[8] = {}, launches[8] = {};
@@ -1160,7 +1177,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
             else extend(i, bounce, st);
             ev(i, bounce, 0, 1, st);
             ev(i, bounce, 1, 0, st);
-            hipLaunchKernelGGL(wf_shade_kernel, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen);
+            if (p->envmap) hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen);
+            else hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(blocksAll[i]), dim3(kWfBlock), 0, st, *p, b, bounce, fuseGen);
             if (!firstHitOnly) hipLaunchKernelGGL(wf_snapshot_kernel, dim3(1), dim3(64), 0, st, b.counters, bounce);
             ev(i, bounce, 1, 1, st);
         }

@@ -49,8 +49,10 @@ static constexpr int kWfBlock = 256;
 // Waves per SIMD the shade / accumulate kernels are compiled for (measured at 4K Sponza-stat, ms per frame for
 // 3 / 4 / 5 / 6 / 8 waves: shade 7.5 / 7.5 / 9.5 / 10.8 / 10.9, accumulate 4.6 / 3.8 / 5.0 / 5.3 / 5.9): one more resident
 // wave pays for accumulate; below 128 VGPRs both kernels spill and lose more than the occupancy gives.
+// Round 4: as single-pass kernels (no grid-stride loop for the compiler to hoist ~140 invariants out of) shade needs 117 VGPRs and
+// accumulate 113; shade's scratch was trimmed to 40 KB so that four workgroups fit a CU (3 -> 4 waves: 4K frame 17.13 -> 16.60 ms).
 #ifndef INCR_SHADE_WAVES
-#define INCR_SHADE_WAVES 3
+#define INCR_SHADE_WAVES 4
 #endif
 #ifndef INCR_EXTEND_WAVES
 #define INCR_EXTEND_WAVES 7     // waves per SIMD of the closest-hit kernel with the 8-entry stack: at 8 (64 VGPRs) it spills 28 B inside the step; 12.3 / 11.8 / 12.0 ms per 4K frame at 8 / 7 / 6
@@ -88,7 +90,10 @@ DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) 
     __syncthreads();
     return count;
 }
-static constexpr uint32_t kGenLdsLights = 128;         // lights whose resolved records shadow_gen keeps in LDS (10 KB)
+#ifndef INCR_GEN_LDS_LIGHTS
+#define INCR_GEN_LDS_LIGHTS 128
+#endif
+static constexpr uint32_t kGenLdsLights = INCR_GEN_LDS_LIGHTS;         // lights whose resolved records shadow_gen keeps in LDS (80 B each)
 static constexpr uint32_t kSkySlot = 127;              // bit 127 of the request mask = the sky sample
 static constexpr uint32_t kFlagTerminate = 1u, kFlagSkip = 2u, kFlagInlineShadow = 4u, kFlagManyLights = 8u, kFlagFullRecord = 16u, kFlagMiss = 32u;
 // Items a wave takes from the device-wide cursor at a time, and the number of idle lanes that triggers a refill.
@@ -487,14 +492,13 @@ DI uint32_t nth_set_bit(uint32_t word, uint32_t j) {          // position of the
     }
     return pos;
 }
-// The shared-memory scratch of the ray set-up (one workgroup = 256 list slots).
+// The shared-memory scratch of the ray set-up (one workgroup = 256 list slots).  With wf_shade_kernel's own few words it has to stay within 40 KB:
+// four workgroups per CU (INCR_SHADE_WAVES).
 struct ShadowGenLds {
     uint32_t prefix[kWfBlock + 1];
     uint32_t waveTotal[kWfBlock / 64];
-    uint32_t pid[kWfBlock];
     uint4 mask[kWfBlock];
-    float4 pos[kWfBlock], sky[kWfBlock], nrm[kWfBlock], col[kWfBlock], att[kWfBlock], skyRad[kWfBlock];
-    float2 vyz[kWfBlock];
+    float4 pos[kWfBlock], sky[kWfBlock] /* .w = incoming ray direction .y */, nrm[kWfBlock], col[kWfBlock], att[kWfBlock], skyRad[kWfBlock] /* .w = incoming ray direction .z */;
     float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
     uint32_t base;
 };
@@ -515,9 +519,9 @@ DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          //
 // the vertex's first queued ray.
 struct ShadowGenResult { uint4 req; uint32_t flags, rayBase; };
 DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int bounce, ShadowGenLds& S, uint32_t pid, const ShadowGenVertex& V) {
-    uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint32_t* const s_pid = S.pid; uint4* const s_mask = S.mask;
+    uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint4* const s_mask = S.mask;
     float4* const s_pos = S.pos; float4* const s_sky = S.sky; float4* const s_nrm = S.nrm; float4* const s_col = S.col; float4* const s_att = S.att;
-    float2* const s_vyz = S.vyz; float4* const s_lights = S.lights; uint32_t& s_base = S.base; float4* const s_skyRad = S.skyRad;
+    float4* const s_lights = S.lights; uint32_t& s_base = S.base; float4* const s_skyRad = S.skyRad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
     auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
@@ -535,7 +539,8 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
         if (lane == 63u) s_waveTotal[wave] = incl;
-        s_pid[tid] = pid; s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = vsky; s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt; s_vyz[tid] = vyz; s_skyRad[tid] = V.skyRad;
+        s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = make_float4(vsky.x, vsky.y, vsky.z, vyz.x); s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt;
+        s_skyRad[tid] = make_float4(V.skyRad.x, V.skyRad.y, V.skyRad.z, vyz.y);
         __syncthreads();
         uint32_t waveBase = 0, totalCand = 0;
 #pragma unroll
@@ -609,19 +614,20 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
     for (uint32_t r = tid; r < total; r += kWfBlock) {
         uint32_t lo, slot; const uint32_t dest = r;
         decode(r, &lo, &slot);
-        const uint32_t vp = s_pid[lo];
+        const uint32_t vp = pid - tid + lo;          // the owner's list slot: the workgroup's slots are consecutive
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
         f3 L, contribution = {0.f, 0.f, 0.f};
         if (slot == kSkySlot) {
             // chsMain's sky sample (pathtracing.hlsl:239-244): GetSkyRadiance with lightVisibility = 1 (lighting/common.hlsli:145-202) over the
             // pdf, times the path attenuation -- evaluated HERE like the lights', so that accumulate only sums
-            const float4 v4 = s_sky[lo], n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
+            const float4 v4 = s_sky[lo], n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo];
             L = {v4.x, v4.y, v4.z};
             const f3 N = {n4.x, n4.y, n4.z};
             MatProps matInfo = {};
             matInfo.basecolor = mk3(c4.x, c4.y, c4.z); matInfo.metallic = c4.w; matInfo.roughness = n4.w;
             const float4 sr = s_skyRad[lo];
+            const float2 vyz2 = make_float2(v4.w, sr.w);
             const f3 skyRadianceIn = {sr.x, sr.y, sr.z};
             const f3 radianceOut = sky_shade(skyRadianceIn, L, saturate(dot(N, L)), matInfo, N, -mk3(a4.w, vyz2.x, vyz2.y));
             contribution = mk3(a4.x, a4.y, a4.z) * (radianceOut / CosineHemispherePdf(L.z));
@@ -631,7 +637,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const uint32_t li = P.gridCellLights[__float_as_uint(v0.w) + slot];
             incr_light light; float lm[16];
             fetch_light(li, light, lm);
-            const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = s_vyz[lo];
+            const float4 n4 = s_nrm[lo], c4 = s_col[lo], a4 = s_att[lo]; const float2 vyz2 = make_float2(s_sky[lo].w, s_skyRad[lo].w);
             const f3 N = {n4.x, n4.y, n4.z};
             const LightSample ls = light_setup(light, lm, true, origin, N);
             L = ls.L;
@@ -650,6 +656,9 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
 // ENV: the caller passed the sky cube (P.envmap != NULL: bench, the C++ renderer) -- the kernel then carries no Preetham code at all.  The analytic sky's ~35 scalar
 // constants, pre-loaded and spilled to vector-register lanes, cost the kernel 4 % even where no lane ever evaluated it (round 4: SGPR spills 197 -> 134, shade 4.43 ->
 // 4.24 ms per frame alone with the miss shading moved to wf_accumulate_kernel as well).
+#ifndef INCR_SHADE_LOOP
+#define INCR_SHADE_LOOP 0
+#endif
 template <bool ENV> __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) void wf_shade_kernel(const PtParams P, const WfBuffers B, int bounce, int fuseShadowGen) {
     __shared__ uint32_t s_waveCount[kWfBlock / 64];
     __shared__ uint32_t s_base;
@@ -664,7 +673,14 @@ template <bool ENV> __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) voi
     const float4* __restrict__ stIn = (bounce & 1) ? B.stB : B.stA;
     float4* stOut = (bounce & 1) ? B.stA : B.stB;
     uint32_t* liveCounter = B.counters + bounce + 1;
+    // one pass per workgroup: the launcher's grid covers every path of the pipeline (blocksAll).  A grid-stride loop here has the compiler hoist
+    // ~140 loop-invariant scalars (addresses, launch constants) out of it, which then live in spilled SGPRs for the whole kernel
+#if INCR_SHADE_LOOP
     for (uint32_t base = blockIdx.x * kWfBlock; base < count; base += gridDim.x * kWfBlock) {
+#else
+    const uint32_t base = blockIdx.x * kWfBlock;
+    if (base < count) {
+#endif
         const uint32_t i = base + threadIdx.x;
         bool cont = false, haveVertex = false;
         ShadowGenVertex SV = {};
@@ -917,7 +933,8 @@ __global__ __launch_bounds__(kWfBlock, INCR_ACCUM_WAVES) void wf_accumulate_kern
     const uint32_t count = B.counters[bounce];
     const float4* __restrict__ stIn = (bounce & 1) ? B.stB : B.stA;
     float4* stOut = (bounce & 1) ? B.stA : B.stB;
-    for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i += gridDim.x * kWfBlock) {
+    // one trip (the grid covers every slot, as in wf_shade_kernel): `i = ~0u` ends the loop after its first pass and lets the body keep its `continue`s
+    for (uint32_t i = blockIdx.x * kWfBlock + threadIdx.x; i < count; i = INCR_SHADE_LOOP ? i + gridDim.x * kWfBlock : 0xffffffffu) {
         const float4* vtx = vertex_of(B, bounce, i);
         const uint4 meta = *(const uint4*)(vtx + kVMeta);
         const uint32_t flags = meta.x;

@@ -21,7 +21,7 @@ using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
-                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap);
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement);
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
                                              const uint32_t* ranges, uint32_t numRanges, void* nodeBoxes, hipStream_t stream);
@@ -119,6 +119,7 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     ctx->wfPipes = 1; memset(ctx->wfTileRow, 0, sizeof ctx->wfTileRow);
     memset(ctx->wfStreams, 0, sizeof ctx->wfStreams); memset(ctx->wfJoin, 0, sizeof ctx->wfJoin);
     memset(ctx->wfSideStreams, 0, sizeof ctx->wfSideStreams); memset(ctx->wfBounceFork, 0, sizeof ctx->wfBounceFork); memset(ctx->wfBounceJoin, 0, sizeof ctx->wfBounceJoin);
+    { const char* ap = getenv("INCR_WF_ACC_PLACEMENT"); ctx->wfAccPlacement = ap ? std::min(std::max(atoi(ap), -1), 1) : -1; }
     { const char* ov = getenv("INCR_WF_OVERLAP"); ctx->wfOverlap = ov ? atoi(ov) != 0 : true; }          // bounce overlap (pathtrace_wf.hip launcher), incr_set_pathtrace_overlap
     HIP_TRY(hipEventCreateWithFlags(&ctx->wfFork, hipEventDisableTiming));      // the pipelines' own streams are created on first use
     ctx->profiling = false; ctx->profFrames = 0;
@@ -853,7 +854,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
     ctx->wfStreams[0] = (hipStream_t)stream;
     HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev,
-                                     ctx->wfSideStreams, ctx->wfBounceFork, ctx->wfBounceJoin, ctx->wfOverlap ? 1 : 0));
+                                     ctx->wfSideStreams, ctx->wfBounceFork, ctx->wfBounceJoin, ctx->wfOverlap ? 1 : 0, ctx->wfAccPlacement));
     return INCR_OK;
 }
 

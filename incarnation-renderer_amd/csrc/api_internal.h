@@ -49,6 +49,7 @@ struct incr_context {
     bool wfOverlap;           // bounce overlap: extend(b + 1) beside shadow(b) on the pipeline's side stream (INCR_WF_OVERLAP, incr_set_pathtrace_overlap)
     hipStream_t wfSideStreams[8];                     // library-owned, created on first use
     hipEvent_t wfBounceFork[32], wfBounceJoin[32];    // [pipeline * 4 + bounce]
+    int wfAccPlacement;                               // where wf_accumulate_kernel runs: -1 = by size; 0 the end of the main stream, 1 behind the any-hit launches on the side stream (INCR_WF_ACC_PLACEMENT)
     void* wfBlock;            // one allocation behind wf
     uint64_t wfBytes;
     void* wfStage;            // incr_pathtrace_desc::num_samples > 1: RGBA16F bits per sample in flight and local pixel

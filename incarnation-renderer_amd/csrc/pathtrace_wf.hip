@@ -132,7 +132,10 @@ static constexpr int kStripeBase = 128;
 // (Round 4 measured two ways of changing which rays share a shadow wave and removed both -- commit e325fc1 holds the code, profiles/r04_ab_ray_order.txt
 // the numbers: a LIGHT-MAJOR queue order out of shadow_gen_block (LDS binning by scene light: shadow 7.48 -> 7.55 ms alone, shade + 0.19 ms for the
 // binning: a lane-per-ray wave pays per iteration, not per divergence) and a per-lane OCCLUDER CACHE (the triangle that stopped the lane's previous ray
-// tested first: 7.56 -> 7.82 ms vertex-major, 7.50 -> 7.57 light-major).)
+// tested first: 7.56 -> 7.82 ms vertex-major, 7.50 -> 7.57 light-major).  Also measured and removed: ONE RAY AHEAD PER LANE in wf_shadow_kernel -- the refill hands a lane
+// its next ray while it still traces the current one, and a lane that finishes starts it in the same iteration: 63.8 live lanes in the steady state (53.6), 12.4 M wave
+// iterations per frame (14.3 M) -- and the 4K frame 16.80-16.87 ms against 16.63-16.65, 16.56-16.65 with the refill at 32 used-up lanes: the ray start (three v_rcp_f32,
+// ~15 moves, the visibility store) then runs in nearly every iteration instead of every fifth, and what the fuller lanes save it costs (profiles/r04_ab_lane_fill.txt).)
 // counters: [b] = |L_b| for b = 0..4 ; cursors at [16 + 2b] (extend) and [16 + 2b + 1] (shadow) ; [32 + b] = shadow rays queued in bounce b
 // (round 4: ONE shadow-ray queue for the four bounces -- [32] counts its rays; [40 + b] = its length before the rays of bounce b, [40 + b + 1] after
 //  them, written by wf_snapshot_kernel behind wf_shade_kernel(b): a shadow launch traces the rays of one or several bounces as the range between two snapshots)
@@ -296,14 +299,15 @@ DI void store_primary(const WfBuffers& B, uint32_t slot, float4 rayO, float4 ray
 }
 #ifdef INCR_WF_LANE_STATS
 // Developer build only (tools/lane_stats.py): where the lanes of the traversal waves go.  Per kernel (0 extend, 1 shadow) 8 words:
-// iterations, live lanes, lanes on a node step, lanes on a triangle step, iterations after the cursor ran dry, live lanes in those,
+// iterations, live lanes, lanes taking a node step, lanes taking a triangle step (a lane can take both), iterations after the cursor ran dry, live lanes in those,
 // iterations that ran a refill, iterations in which only one kind of step was present.
 __device__ unsigned long long g_laneStats[16];
 struct LaneStats {
     uint32_t it = 0, live = 0, node = 0, tri = 0, drainIt = 0, drainLive = 0, refills = 0, pure = 0;
-    DI void step(bool active, uint32_t triMask, bool exhausted) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(active && !triMask)), t = (uint32_t)__popcll(__ballot(active && triMask));
-        it++; live += n + t; node += n; tri += t; if (exhausted) { drainIt++; drainLive += n + t; } if (!n || !t) pure++;
+    // node / tri = the lanes that take a node step / a triangle step in this iteration (trav_*_step2: haveCur && !triMask1 / triMask != 0; a lane can take both)
+    DI void step(bool active, bool wantNode, bool wantTri, bool exhausted) {
+        const uint32_t a = (uint32_t)__popcll(__ballot(active)), n = (uint32_t)__popcll(__ballot(active && wantNode)), t = (uint32_t)__popcll(__ballot(active && wantTri));
+        it++; live += a; node += n; tri += t; if (exhausted) { drainIt++; drainLive += a; } if (!n || !t) pure++;
     }
     DI void flush(int k) {
         if ((threadIdx.x & 63u) == 0) {
@@ -368,7 +372,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
             }
         }
         if (__ballot(active) == 0ull) { if (chunk.exhausted) break; else continue; }
-        LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
+        LANE_STATS(ls.step(active, T.haveCur && T.triMask1 == 0u, T.triMask != 0u, chunk.exhausted);)
         if (active && trav_closest_step2(P, st, T)) {           // node step and triangle step in one iteration (pt_traverse.h)
             B.hit[slot] = T.found ? make_uint4(T.bestFlat, __float_as_uint(T.best), __float_as_uint(T.bu), __float_as_uint(T.bv))
                                  : make_uint4(kMissTri, 0u, 0u, 0u);
@@ -910,7 +914,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WA
             const uint32_t item = chunk.take(!active, cursor, total);
             if (item != 0xffffffffu) { qa = B.rayQ[(size_t)(first + item) * 2]; qb = B.rayQ[(size_t)(first + item) * 2 + 1]; pending = true; }
         }
-        LANE_STATS(ls.step(active, T.triMask, chunk.exhausted);)
+        LANE_STATS(ls.step(active, T.haveCur && T.triMask1 == 0u, T.triMask != 0u, chunk.exhausted);)
         if (active && trav_any_step2(P, st, T)) { occludedDone = T.occluded; active = false; }      // node step and triangle step in one iteration
         if (pending) {
             pending = false;
@@ -1119,7 +1123,7 @@ __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int
 // `events` (optional, kWfProfEvents per pipeline): see pt_params.h.
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
-                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap) {
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;      // tileRow[] counts rows of all samples in flight: tilesY per sample
     if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
@@ -1159,7 +1163,12 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     // Measured on one box (profiles/r04_ab_deferred.txt): 4K, one pipeline: 17.90 ms at the end, 18.00 behind the launches (the summation competes
     // with the main chain for the same wave slots); helmet 1080p, a chain of short launches: 1.13 ms at the end, 1.08 behind.  So: by size.
     uint64_t allPaths = 0; for (int i = 0; i < numPipes; ++i) allPaths += (uint64_t)(tileRow[i + 1] - tileRow[i]) * tilesX * 64u;
-    const bool accBehindShadow = !side || allPaths < 3000000ull;
+    // (A third placement -- the summation on a stream of its own, accumulate(b) waiting for the any-hit launch of bounce b by an event and running beside the main chain and
+    // the later any-hit launches -- was built and measured: the four summations do move off the tail of the frame (rocprofv3 timeline: 0.19 ms left after the last any-hit launch
+    // instead of 0.95), and the frame takes what it took, 16.675 against 16.70 ms over six interleaved runs each: the waves the summation occupies are waves the traversal
+    // kernels do not run.  profiles/r04_ab_deferred.txt.)  accPlacement: -1 by size, 0 / 1 forced (INCR_WF_ACC_PLACEMENT).
+    const int placement = !side ? 1 : (accPlacement >= 0 ? std::min(accPlacement, 1) : (allPaths < 3000000ull ? 1 : 0));
+    const bool accBehindShadow = placement == 1;
     bool rec[8][kWfProfEvents] = {};
     auto ev = [&](int i, int bounce, int kind, int end, hipStream_t st) {          // kind: 0 extend, 1 shade, 2 shadow, 3 accumulate
         if (!events) return;

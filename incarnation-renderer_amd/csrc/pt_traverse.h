@@ -322,6 +322,9 @@ template <class ST> DI bool trav_closest_step(const PtParams& P, ST& st, TravClo
 // tested.  Both branches of the loop body then run with more of the wave's lanes: the wave model (tools/trav_sim wave_model_overlap)
 // said -17 ... -21 % instructions per step, the kernel went from 2.26 to 1.95 ms per launch (extend 8.6 -> 7.7 ms per frame).
 struct TravClosest2 : TravClosest { uint32_t triBase1, triMask1; };
+// (GATED TRIANGLE ROUNDS -- the triangle branch of an iteration taken only when at least G lanes of the wave have a triangle waiting, or no lane can take a node step --
+// were measured in round 4: 4K frame 16.69 ms ungated, 17.35 / 17.71 / 18.54 at G = 16 / 24 / 32: the triangles a lane has not tested yet are hits it has not found yet,
+// an any-hit ray that would have ended goes on walking and a closest-hit ray goes on with too large a tmax.  profiles/r04_ab_lane_fill.txt.)
 template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravClosest2& T) {
     const bool wantTri = T.triMask != 0u;
     const bool wantNode = T.haveCur && T.triMask1 == 0u;

@@ -32,7 +32,7 @@ try:
     lib.incr_debug_lane_stats(out)
     for k, name in enumerate(("extend", "shadow")):
         it, live, node, tri, dit, dlive, refills, pure = [out[k * 8 + i] / a.frames for i in range(8)]
-        print("%s: wave-iterations %.3gM  steps %.4gM  live lanes/iter %.1f (node %.1f, tri %.1f)  single-kind iterations %.1f %%" % (name, it / 1e6, live / 1e6, live / it, node / it, tri / it, 100 * pure / it))
+        print("%s: wave-iterations %.3gM  live lane-iterations %.4gM  live lanes/iter %.1f (taking a node step %.1f, a triangle step %.1f)  single-kind iterations %.1f %%" % (name, it / 1e6, live / 1e6, live / it, node / it, tri / it, 100 * pure / it))
         print("   drain (cursor dry): %.1f %% of iterations at %.1f live lanes; steady state %.1f live lanes; refills %.3gM" % (100 * dit / it, dlive / max(dit, 1), (live - dlive) / max(it - dit, 1), refills / 1e6))
 finally:
     build(a.extra)

@@ -13,6 +13,8 @@
 #include <mutex>
 #include <new>
 #include <algorithm>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "api_internal.h"
@@ -387,15 +389,12 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         for (int32_t t : idx) if (t < -1 || t >= (int32_t)desc->num_textures) { delete sc; return fail(INCR_ERR_INVALID_ARGUMENT, "material %u: texture index %d out of range", i, t); }
     }
     lap("validation");
-    build_world_bvh(sc->host, sc->bvh);
-    lap("build_world_bvh");
-    if (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes) {
-        const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
-        delete sc;
-        return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes);
-    }
-    int rc = upload_bvh(sc);
-    lap("upload of the tree");
+    // The acceleration structure is built on the host's cores (scene_build.cpp) WHILE the device builds the texture chains and the raster side is baked: nothing below
+    // reads sc->bvh before the join in front of upload_bvh (round 4: Bistro-scale scene creation 0.41 -> 0.31 s, Sponza-stat 0.29 -> 0.17 s; the stages used to run one after the other)
+    std::chrono::steady_clock::time_point bvhDone;
+    std::thread bvhThread([&] { build_world_bvh(sc->host, sc->bvh); bvhDone = std::chrono::steady_clock::now(); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } bvhJoiner{bvhThread};          // every early return below waits for the builder first
+    int rc = INCR_OK;
     if (!rc) rc = upload_vec(&sc->dMaterials, sc->host.materials.data(), sc->host.materials.size());
     if (!rc) rc = upload_vec(&sc->dGlobalLights, sc->host.globalLights.data(), sc->host.globalLights.size());
     if (!rc) rc = upload_vec(&sc->dLightIndices, sc->host.lightIndices.data(), sc->host.lightIndices.size());
@@ -594,6 +593,16 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     lap("textures");
     if (!rc) rc = incr_raster_scene_upload(sc);
     lap("raster-side bake + upload");
+    bvhThread.join();
+    if (lap.on) fprintf(stderr, "  incr_scene_create %-26s done %.1f ms before the join\n", "build_world_bvh (thread)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bvhDone).count());
+    lap("wait for build_world_bvh");
+    if (!rc && (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes)) {
+        const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
+        incr_scene_destroy(ctx, sc);
+        return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes);
+    }
+    if (!rc) rc = upload_bvh(sc);
+    lap("upload of the tree");
     if (rc) { incr_scene_destroy(ctx, sc); return rc; }
     *out = sc;
     return INCR_OK;

@@ -392,7 +392,8 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     // The acceleration structure is built on the host's cores (scene_build.cpp) WHILE the device builds the texture chains and the raster side is baked: nothing below
     // reads sc->bvh before the join in front of upload_bvh (round 4: Bistro-scale scene creation 0.41 -> 0.31 s, Sponza-stat 0.29 -> 0.17 s; the stages used to run one after the other)
     std::chrono::steady_clock::time_point bvhDone;
-    std::thread bvhThread([&] { build_world_bvh(sc->host, sc->bvh); bvhDone = std::chrono::steady_clock::now(); });
+    bool bvhFailed = false;          // an exception must not leave the thread (std::terminate): the build allocates ~1 GB of records for a Bistro-scale scene
+    std::thread bvhThread([&] { try { build_world_bvh(sc->host, sc->bvh); } catch (...) { bvhFailed = true; } bvhDone = std::chrono::steady_clock::now(); });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } bvhJoiner{bvhThread};          // every early return below waits for the builder first
     int rc = INCR_OK;
     if (!rc) rc = upload_vec(&sc->dMaterials, sc->host.materials.data(), sc->host.materials.size());
@@ -596,6 +597,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     bvhThread.join();
     if (lap.on) fprintf(stderr, "  incr_scene_create %-26s done %.1f ms before the join\n", "build_world_bvh (thread)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bvhDone).count());
     lap("wait for build_world_bvh");
+    if (bvhFailed) { incr_scene_destroy(ctx, sc); return fail(INCR_ERR_OUT_OF_MEMORY, "acceleration-structure build failed (host allocation)"); }
     if (!rc && (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes)) {
         const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
         incr_scene_destroy(ctx, sc);

@@ -815,9 +815,6 @@ extern "C" hipError_t incr_launch_fold_ray_stats(unsigned long long* stripes, in
 // same answer as never testing it, so the result equals trace_any's for every ray.  All 64 lanes must call; `wants` marks the
 // lanes that have a ray.  `stack`: kPacketStack words of LDS per wave.
 static constexpr int kPacketStack = 32;      // one entry per tree level (kMaxBvhDepth = 25)
-#ifndef INCR_PACKET_MOST_RAYS_FIRST
-#define INCR_PACKET_MOST_RAYS_FIRST 1
-#endif
 DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, f3 d, float tmin, float tmax, bool wants) {
     const RaySetup rs = ray_setup(o, d);
     bool alive = wants, occluded = false;
@@ -840,9 +837,8 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
         node8_test(n0, n1, n2, n3, n4, rs, tmin, tmax, N);
         const uint32_t mine = alive ? N.hitMask : 0u;
         uint32_t any = 0u;                                                                 // children some live ray overlaps
-        uint32_t cnt[8];                                                                   // ... and how many of them (scalar: s_bcnt1 of the ballot)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const unsigned long long bk = __ballot((mine >> k) & 1u); cnt[k] = (uint32_t)__popcll(bk); any |= (bk != 0ull) ? (1u << k) : 0u; }
+        for (int k = 0; k < 8; ++k) any |= (__ballot((mine >> k) & 1u) != 0ull) ? (1u << k) : 0u;
         const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
         Node8 U = N; U.hitMask = any; U.imask = imask;
         U.leafTris = __builtin_amdgcn_readfirstlane(N.leafTris); U.sortAxis = __builtin_amdgcn_readfirstlane(N.sortAxis);
@@ -859,17 +855,9 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
         }
         const uint32_t inner = any & imask;
         if (inner) {
-            // an any-hit walk is free in its order: the inner child that MOST live rays overlap goes first (the subtree most likely to end the packet), the others
-            // wait as one group
-            uint32_t firstK = (uint32_t)__builtin_ctz(inner);
-#if INCR_PACKET_MOST_RAYS_FIRST
-            uint32_t bestCnt = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (((inner >> k) & 1u) && cnt[k] > bestCnt) { bestCnt = cnt[k]; firstK = (uint32_t)k; }
-#endif
-            const uint32_t rest = inner & ~(1u << firstK);
+            const uint32_t rest = inner & (inner - 1u);
             if (rest) { if (sp < kPacketStack) stack[sp++] = stack_entry(childBase, false, rest); }
-            cur = childBase + firstK;
+            cur = childBase + (uint32_t)__builtin_ctz(inner);
             haveCur = true;
         }
     }

@@ -429,7 +429,7 @@ DI PacketHit packet_closest(const PtParams& P, uint32_t* stack, bool have, f3 o,
             const uint32_t imask = __builtin_amdgcn_readfirstlane(N.imask), childBase = __builtin_amdgcn_readfirstlane(N.childBase);
             Node8 U = N; U.hitMask = any; U.imask = imask;
             U.leafTris = __builtin_amdgcn_readfirstlane(N.leafTris); U.sortAxis = __builtin_amdgcn_readfirstlane(N.sortAxis);
-            uint32_t triMask = node8_tri_mask(U);
+            uint32_t triMask = node8_tri_mask_uniform(U.hitMask, U.leafTris);
             const uint32_t triBase = __builtin_amdgcn_readfirstlane(N.triBase);
             while (triMask) {
                 const uint32_t ti = triBase + (uint32_t)__builtin_ctz(triMask);

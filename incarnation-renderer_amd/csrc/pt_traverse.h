@@ -192,9 +192,22 @@ DI uint32_t spread_nibbles(uint32_t x) {          // bit k (k < 8) -> bits 4 k .
     x = (x | (x << 12)) & 0x000f000fu;
     x = (x | (x << 6)) & 0x03030303u;
     x = (x | (x << 3)) & 0x11111111u;
-    return (x << 4) - x;
+    // bit 4 k -> nibble k: two shift-ors.  (Written as (x << 4) - x the compiler makes it x * 15 by v_mul_lo_u32, a quarter-rate instruction in every node step.)
+    uint32_t y, r;
+    asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(y) : "v"(x));
+    asm("v_lshl_or_b32 %0, %1, 2, %1" : "=v"(r) : "v"(y));
+    return r;
 }
 DI uint32_t node8_tri_mask(const Node8& N) { return spread_nibbles(N.hitMask) & N.leafTris; }
+// the same for a WAVE-UNIFORM hit mask (the packet walks): plain C, so that the value stays in scalar registers (the inline assembly above would move it to vector ones and
+// with it the packet's triangle loop and its loads)
+DI uint32_t node8_tri_mask_uniform(uint32_t hitMask, uint32_t leafTris) {
+    uint32_t x = hitMask;
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return ((x << 4) - x) & leafTris;
+}
 
 // One fetch per step: 80 bytes at the node, or 48 at the pending triangle (the last two dwordx4 are only issued by lanes on a
 // node step).  Measured on MI355X (tools/microbench/gather_lanes.hip): a divergent dwordx4 gather costs the vector L1 one
@@ -202,12 +215,32 @@ DI uint32_t node8_tri_mask(const Node8& N) { return spread_nibbles(N.hitMask) & 
 // on, the unit this traversal is bound by (idle lanes are nearly free, instructions are not); the same gather out of LDS
 // runs at 461 G records/s.  So the hottest nodes (index < topCount; ~40 % of all node visits for the top three levels of
 // Sponza-stat) are served from a per-workgroup LDS copy when the stack type says so.
+// Record addresses without an integer multiplication: v_mul_lo_u32 and v_mad_u64_u32 (what `base + index * 80` compiles to) are QUARTER-RATE on this part, 16 cycles where a
+// shift-add takes 4, and a traversal iteration made three of them (node from HBM, node from LDS, triangle).  A record's byte offset is built from shift-adds (opaque to the
+// optimiser, which would fold them back into the multiplication) and stays 32-bit -- 2^23 nodes x 80 B and the triangle records fit -- so the loads take the
+// scalar-base + 32-bit-vector-offset form and no 64-bit address arithmetic is left either.
+DI uint32_t node_byte_offset(uint32_t node) { uint32_t r; asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(r) : "v"(node)); return r << 4; }      // node * 80
+DI uint32_t tri_byte_offset(uint32_t tri) { uint32_t r; asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(tri)); return r << 4; }        // tri * 48
+#ifndef INCR_SHIFT_ADDR
+#define INCR_SHIFT_ADDR 1
+#endif
+#if INCR_SHIFT_ADDR
+DI const float4* node_ptr(const PtParams& P, uint32_t node) { return (const float4*)((const char*)P.nodes + (size_t)node_byte_offset(node)); }
+DI const float4* tri_ptr(const PtParams& P, uint32_t tri) { return (const float4*)((const char*)P.tris + (size_t)tri_byte_offset(tri)); }
+#else
+DI const float4* node_ptr(const PtParams& P, uint32_t node) { return (const float4*)P.nodes + (size_t)node * 5; }
+DI const float4* tri_ptr(const PtParams& P, uint32_t tri) { return (const float4*)(P.tris + tri); }
+#endif
 struct Fetch5 { float4 a, b, c, d, e; };
 template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32_t cur, uint32_t triBase, uint32_t triMask) {
     Fetch5 f;
     if constexpr (ST::kTop) {
         if (!triMask && cur < st.topCount) {
+#if INCR_SHIFT_ADDR
+            LdsNodes q = (LdsNodes)((__attribute__((address_space(3))) const char*)st.topNodes + node_byte_offset(cur));
+#else
             LdsNodes q = st.topNodes + cur * 5u;
+#endif
             const incr_v4f a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
             f.a = make_float4(a.x, a.y, a.z, a.w); f.b = make_float4(b.x, b.y, b.z, b.w); f.c = make_float4(c.x, c.y, c.z, c.w);
             f.d = make_float4(d.x, d.y, d.z, d.w); f.e = make_float4(e.x, e.y, e.z, e.w);
@@ -215,8 +248,7 @@ template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32
         }
     }
     const uint32_t ti = triBase + (uint32_t)__builtin_ctz(triMask | 0x80000000u);      // 32-bit sum: triBase is biased modulo 2^32 (device_types.h LEAF SLOTS)
-    const float4* __restrict__ p = triMask ? (const float4*)(P.tris + ti)
-                                           : (const float4*)P.nodes + (size_t)cur * 5;
+    const float4* __restrict__ p = triMask ? tri_ptr(P, ti) : node_ptr(P, cur);
     f.a = p[0]; f.b = p[1]; f.c = p[2];
     if (!triMask) { f.d = p[3]; f.e = p[4]; } else { f.d = f.c; f.e = f.c; }
     return f;
@@ -331,7 +363,7 @@ template <class ST> DI bool trav_closest_step2(const PtParams& P, ST& st, TravCl
     // ---- both fetches first
     float4 ta, tb, tc;                   // deliberately not initialised: only read under the condition they are loaded under (zeroing cost 12 v_mov per iteration)
     uint32_t ti = 0;
-    if (wantTri) { ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }
+    if (wantTri) { ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = tri_ptr(P, ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }
     Fetch5 f;                            // as above (20 v_mov)
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
     // ---- one pending triangle
@@ -411,7 +443,7 @@ template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& 
     const bool wantTri = T.triMask != 0u;
     const bool wantNode = T.haveCur && T.triMask1 == 0u;
     float4 ta, tb, tc;                   // deliberately not initialised: only read under the condition they are loaded under (zeroing cost 12 v_mov per iteration)
-    if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = (const float4*)(P.tris + ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
+    if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = tri_ptr(P, ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
     Fetch5 f;                            // as above (20 v_mov)
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
     if (wantTri) {

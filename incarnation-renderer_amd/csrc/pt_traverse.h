@@ -192,7 +192,7 @@ DI uint32_t spread_nibbles(uint32_t x) {          // bit k (k < 8) -> bits 4 k .
     x = (x | (x << 12)) & 0x000f000fu;
     x = (x | (x << 6)) & 0x03030303u;
     x = (x | (x << 3)) & 0x11111111u;
-    // bit 4 k -> nibble k: two shift-ors.  (Written as (x << 4) - x the compiler makes it x * 15 by v_mul_lo_u32, a quarter-rate instruction in every node step.)
+    // bit 4 k -> nibble k: two shift-ors, inline so that the optimiser cannot fold them into the x * 15 it makes of (x << 4) - x (measured: shadow 7.16 -> 7.05 ms per frame alone)
     uint32_t y, r;
     asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(y) : "v"(x));
     asm("v_lshl_or_b32 %0, %1, 2, %1" : "=v"(r) : "v"(y));
@@ -215,32 +215,22 @@ DI uint32_t node8_tri_mask_uniform(uint32_t hitMask, uint32_t leafTris) {
 // on, the unit this traversal is bound by (idle lanes are nearly free, instructions are not); the same gather out of LDS
 // runs at 461 G records/s.  So the hottest nodes (index < topCount; ~40 % of all node visits for the top three levels of
 // Sponza-stat) are served from a per-workgroup LDS copy when the stack type says so.
-// Record addresses without an integer multiplication: v_mul_lo_u32 and v_mad_u64_u32 (what `base + index * 80` compiles to) are QUARTER-RATE on this part, 16 cycles where a
-// shift-add takes 4, and a traversal iteration made three of them (node from HBM, node from LDS, triangle).  A record's byte offset is built from shift-adds (opaque to the
-// optimiser, which would fold them back into the multiplication) and stays 32-bit -- 2^23 nodes x 80 B and the triangle records fit -- so the loads take the
-// scalar-base + 32-bit-vector-offset form and no 64-bit address arithmetic is left either.
-DI uint32_t node_byte_offset(uint32_t node) { uint32_t r; asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(r) : "v"(node)); return r << 4; }      // node * 80
-DI uint32_t tri_byte_offset(uint32_t tri) { uint32_t r; asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(tri)); return r << 4; }        // tri * 48
-#ifndef INCR_SHIFT_ADDR
-#define INCR_SHIFT_ADDR 1
-#endif
-#if INCR_SHIFT_ADDR
+// Record addresses in 32 bits.  `base + index * 80` as 64-bit arithmetic compiles to v_mad_u64_u32, which issues at HALF rate on gfx950 (5.5 against 2.7 cycles per SIMD slot,
+// tools/microbench/issue_rate.hip; v_mul_lo_u32 is full rate) and leaves a 64-bit address pair in vector registers; a traversal iteration made two of them plus a separate
+// multiplication for the LDS copy of the node.  A record's BYTE OFFSET fits 32 bits (2^23 nodes x 80 B; the triangle records of a scene the 32-bit indices can name): one
+// v_mul_lo_u32, shared by the LDS and the HBM path, and the loads take the scalar-base + 32-bit-vector-offset form (global_load ... v_off, s[base:base+1]).
+DI uint32_t node_byte_offset(uint32_t node) { return node * 80u; }
+DI uint32_t tri_byte_offset(uint32_t tri) { return tri * 48u; }
 DI const float4* node_ptr(const PtParams& P, uint32_t node) { return (const float4*)((const char*)P.nodes + (size_t)node_byte_offset(node)); }
 DI const float4* tri_ptr(const PtParams& P, uint32_t tri) { return (const float4*)((const char*)P.tris + (size_t)tri_byte_offset(tri)); }
-#else
-DI const float4* node_ptr(const PtParams& P, uint32_t node) { return (const float4*)P.nodes + (size_t)node * 5; }
-DI const float4* tri_ptr(const PtParams& P, uint32_t tri) { return (const float4*)(P.tris + tri); }
-#endif
+// (Same box, ms per 4K frame with every kernel alone, shadow / extend: 64-bit addresses 7.36 / 6.93; these 7.05 / 6.89; the offsets as inline shift-adds 7.25 / 6.89:
+//  profiles/r04_ab_lane_fill.txt.)
 struct Fetch5 { float4 a, b, c, d, e; };
 template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32_t cur, uint32_t triBase, uint32_t triMask) {
     Fetch5 f;
     if constexpr (ST::kTop) {
         if (!triMask && cur < st.topCount) {
-#if INCR_SHIFT_ADDR
             LdsNodes q = (LdsNodes)((__attribute__((address_space(3))) const char*)st.topNodes + node_byte_offset(cur));
-#else
-            LdsNodes q = st.topNodes + cur * 5u;
-#endif
             const incr_v4f a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
             f.a = make_float4(a.x, a.y, a.z, a.w); f.b = make_float4(b.x, b.y, b.z, b.w); f.c = make_float4(c.x, c.y, c.z, c.w);
             f.d = make_float4(d.x, d.y, d.z, d.w); f.e = make_float4(e.x, e.y, e.z, e.w);

@@ -30,6 +30,16 @@ template <int OP> __global__ void k(uint64_t* out, float* sink) {
         if (OP == 12) { REP64(asm volatile("v_cmp_lt_f32 %6, %4, %5\n v_cmp_gt_f32 %7, %4, %5\n v_cmp_le_f32 %6, %4, %5\n v_cmp_ge_f32 %7, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b), "s"(cond), "s"(cond));) }
         if (OP == 13) { REP64(asm volatile("v_med3_f32 %0, %0, %4, %5\n v_min3_f32 %1, %1, %4, %5\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(b));) }
         if (OP == 14) { REP64(asm volatile("v_lshlrev_b32 %0, 3, %4\n v_and_b32 %1, %4, %5\n v_bfe_u32 %2, %4, 8, 8\n v_add_u32 %3, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        // round 4: the integer instructions of the traversal loop's bookkeeping (which of them are quarter-rate?)
+        if (OP == 15) { REP64(asm volatile("v_mul_lo_u32 %0, %4, %5\n v_mul_lo_u32 %1, %4, %5\n v_mul_lo_u32 %2, %4, %5\n v_mul_lo_u32 %3, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        if (OP == 16) { REP64(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1" : "+v"(*(double*)&u), "+v"(*(double*)&w) : "v"(a), "v"(b) : "vcc");) }
+        if (OP == 17) { REP64(asm volatile("v_ffbl_b32 %0, %4\n v_ffbh_u32 %1, %4\n v_ffbl_b32 %2, %5\n v_ffbh_u32 %3, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        if (OP == 18) { REP64(asm volatile("v_lshl_add_u32 %0, %4, 2, %5\n v_lshl_or_b32 %1, %4, 2, %5\n v_and_or_b32 %2, %4, %5, %4\n v_med3_u32 %3, %4, %5, %4" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        if (OP == 19) { REP64(asm volatile("v_rcp_f32 %0, %4\n v_rcp_f32 %1, %5\n v_sqrt_f32 %2, %4\n v_rsq_f32 %3, %5" : "=v"(a), "=v"(c), "=v"(d), "=v"(e) : "v"(b), "v"(b));) }
+        if (OP == 20) { REP64(asm volatile("v_lshlrev_b64 %0, 5, %2\n v_lshlrev_b64 %1, 4, %2" : "=v"(*(double*)&u), "=v"(*(double*)&w) : "v"(*(double*)&a));) }
+        if (OP == 21) { REP64(asm volatile("v_bfe_i32 %0, %4, 3, 1\n v_bcnt_u32_b32 %1, %4, %5\n v_mbcnt_lo_u32_b32 %2, %4, %5\n v_cvt_f32_u32 %3, %4" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        if (OP == 22) { REP64(asm volatile("v_mul_hi_u32 %0, %4, %5\n v_mul_u32_u24 %1, %4, %5\n v_mad_u32_u24 %2, %4, %5, %4\n v_mul_hi_u32 %3, %4, %5" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
+        if (OP == 23) { REP64(asm volatile("v_mul_u32_u24 %0, %4, %5\n v_mad_u32_u24 %1, %4, %5, %4\n v_mul_u32_u24 %2, %4, %5\n v_mad_u32_u24 %3, %4, %5, %4" : "=v"(u), "=v"(x), "=v"(w), "=v"(v) : "v"(a), "v"(b));) }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
@@ -54,5 +64,7 @@ template <int OP> static void run(const char* name, int perIter) {
 int main() {
     run<0>("v_fma_f32", 4); run<1>("v_cvt_f32_ubyteN", 4); run<2>("v_dot2_f32_f16", 4); run<3>("v_dot2_i32_i16", 4); run<4>("v_pk_mad_i16", 4);
     run<5>("v_perm_b32", 4); run<6>("v_fma_mix_f32", 4); run<7>("v_max3_f32", 4); run<8>("v_pk_fma_f32", 2); run<9>("v_pk_max/min_i16", 4); run<10>("v_cndmask_b32 (sgpr)", 4); run<11>("v_cmp+v_cndmask vcc", 4); run<12>("v_cmp_f32 -> sgpr", 4); run<13>("med3/min3/max/min", 4); run<14>("shift/and/bfe/add", 4);
+    run<15>("v_mul_lo_u32", 4); run<16>("v_mad_u64_u32", 2); run<17>("v_ffbl/v_ffbh", 4); run<18>("lshl_add/lshl_or/and_or/med3_u32", 4); run<19>("rcp/rcp/sqrt/rsq", 4); run<20>("v_lshlrev_b64", 2);
+    run<21>("bfe_i32/bcnt/mbcnt/cvt_f32_u32", 4); run<22>("mul_hi/mul_u24/mad_u24/mul_hi", 4); run<23>("mul_u32_u24/mad_u32_u24", 4);
     return 0;
 }

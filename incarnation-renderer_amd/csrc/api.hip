@@ -598,10 +598,10 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     if (lap.on) fprintf(stderr, "  incr_scene_create %-26s done %.1f ms before the join\n", "build_world_bvh (thread)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bvhDone).count());
     lap("wait for build_world_bvh");
     if (bvhFailed) { incr_scene_destroy(ctx, sc); return fail(INCR_ERR_OUT_OF_MEMORY, "acceleration-structure build failed (host allocation)"); }
-    if (!rc && (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes)) {
-        const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size();
+    if (!rc && (sc->bvh.maxDepth > kMaxBvhDepth || sc->bvh.nodes8.size() > kMaxBvhNodes || sc->bvh.tris.size() > kMaxTriRecords)) {
+        const uint32_t d = sc->bvh.maxDepth; const size_t nn = sc->bvh.nodes8.size(), nt = sc->bvh.tris.size();
         incr_scene_destroy(ctx, sc);
-        return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes);
+        return fail(INCR_ERR_INVALID_ARGUMENT, "acceleration structure outside the traversal limits: depth %u (max %u), %zu nodes (max %u), %zu triangle records (max %u)", d, kMaxBvhDepth, nn, kMaxBvhNodes, nt, kMaxTriRecords);
     }
     if (!rc) rc = upload_bvh(sc);
     lap("upload of the tree");

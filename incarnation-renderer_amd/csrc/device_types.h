@@ -42,6 +42,7 @@ struct alignas(16) BvhNode8 {
 // divergent loop over the hit leaves (~14 instructions per round, 3-4 rounds per wave: a tenth of the VALU-bound traversal step).
 static constexpr uint32_t kMaxBvhNodes = 1u << 23;     // childBase must fit 23 bits of a stack entry
 static constexpr uint32_t kMaxBvhDepth = 25;           // deepest tree the traversal kernels carry a stack for (24 entries)
+static constexpr uint32_t kMaxTriRecords = 0xffffffffu / 48u;      // the traversal addresses a triangle record by a 32-bit BYTE offset (pt_traverse.h tri_ptr): 89.4 M record slots
 static_assert(sizeof(BvhNode8) == 80, "node8 must be 5 x 16 bytes");
 
 #ifndef INCR_MAX_LEAF_TRIS

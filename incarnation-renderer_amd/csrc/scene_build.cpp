@@ -776,6 +776,7 @@ const char* check_bvh(const HostBvh& bvh) {
     if (bvh.numTriangles > n) return "more triangles than records";
     if (bvh.nodes8.size() > kMaxBvhNodes) return "more nodes than a traversal stack entry can address (2^23)";
     if (bvh.maxDepth > kMaxBvhDepth) return "tree deeper than the traversal stack (25 levels)";
+    if (n > kMaxTriRecords) return "more triangle records than a 32-bit byte offset can address (89.4 M)";
     std::vector<uint8_t> seen(n, 0), seenFlat(n, 0);
     size_t holes = 0;
     for (size_t i = 0; i < n; ++i) {

@@ -32,6 +32,7 @@ extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_bc_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
+extern "C" hipError_t incr_launch_material_chain(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint64_t words, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
 extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
@@ -533,7 +534,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         }
     }
     // Interleaved level-0 texels per material for the path tracer's chsMain (device_types.h MaterialTexels), from the row-major level 0
-    std::vector<MaterialTexels> mtex(desc->num_materials, MaterialTexels{nullptr, 0u, 0u, 0u, 0u});
+    std::vector<MaterialTexels> mtex(desc->num_materials, MaterialTexels{nullptr, 0u, 0u, 0u, 0u, nullptr});
     const bool fuseMaterials = !(getenv("INCR_MATERIAL_TEXELS") && atoi(getenv("INCR_MATERIAL_TEXELS")) == 0);      // A/B hook
     for (uint32_t mi = 0; mi < desc->num_materials && !rc && fuseMaterials; ++mi) {
         const int32_t bt = desc->materials[mi].baseColorTextureIndex, nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
@@ -553,9 +554,8 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "material texel interleave failed: %s", hipGetErrorString(e)); break; }
         sc->dTexels.push_back(d);
         sc->textureBytes += n * 8;
-        mtex[mi] = MaterialTexels{d, Bc.width, Bc.height, Bc.format, 0u};
+        mtex[mi] = MaterialTexels{d, Bc.width, Bc.height, Bc.format, 0u, nullptr};
     }
-    if (!rc) rc = upload_vec(&sc->dMaterialTexels, mtex.data(), mtex.size());
     // The chains above are row-major (what the generators write); the samplers read a TILED copy.  The row-major chains are freed
     // afterwards (incr_scene_texture_download de-tiles on demand): a texture is resident once, not twice.
     std::vector<void*> linear(desc->num_textures, nullptr);
@@ -579,6 +579,28 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         if (e != hipSuccess) { rc = fail(INCR_ERR_HIP, "texture tiling failed: %s", hipGetErrorString(e)); break; }
         T.texels = (const uint8_t*)d;
     }
+    // The same interleave for the whole TILED chain (MaterialTexels::chain): the raster passes' Sample of a material's three maps reads it
+    const bool fuseChains = !(getenv("INCR_MATERIAL_CHAINS") && atoi(getenv("INCR_MATERIAL_CHAINS")) == 0);      // A/B hook
+    for (uint32_t mi = 0; mi < desc->num_materials && !rc && fuseChains; ++mi) {
+        if (!mtex[mi].texels || mtex[mi].baseFormat != INCR_TEX_RGBA8_SRGB) continue;
+        const int32_t bt = desc->materials[mi].baseColorTextureIndex, nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
+        const DeviceTexture& Bc = texs[(size_t)bt]; const DeviceTexture& N = texs[(size_t)nt]; const DeviceTexture& M = texs[(size_t)mt];
+        if (Bc.pad[1] != N.pad[1] || Bc.pad[1] != M.pad[1] || !Bc.pad[1]) continue;
+        bool shared = false;
+        for (uint32_t mj = 0; mj < mi && !shared; ++mj)
+            if (mtex[mj].chain && mtex[mj].texels == mtex[mi].texels) { mtex[mi].chain = mtex[mj].chain; shared = true; }
+        if (shared) continue;
+        uint64_t words = 0;
+        for (uint32_t l = 0; l < Bc.pad[1]; ++l) words += texel_level_words(level_dim(Bc.width, l), level_dim(Bc.height, l));
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, words * 8);
+        if (e == hipSuccess) e = incr_launch_material_chain((const uint32_t*)Bc.texels, (const uint32_t*)N.texels, (const uint32_t*)M.texels, words, d, nullptr);
+        if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "material chain interleave failed: %s", hipGetErrorString(e)); break; }
+        sc->dTexels.push_back(d);
+        sc->textureBytes += words * 8;
+        mtex[mi].chain = d;
+    }
+    if (!rc) rc = upload_vec(&sc->dMaterialTexels, mtex.data(), mtex.size());
     if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
     if (!rc) for (void* lp : linear) {           // the tiled copies are complete: drop the row-major chains
         if (!lp) continue;

@@ -115,6 +115,9 @@ struct MaterialTexels {
     uint32_t width, height;
     uint32_t baseFormat;      // INCR_TEX_* of the base-colour texture (normal = RG_SNORM, metallic-roughness = BGRA8_SWIZZLE_RG by construction)
     uint32_t pad;
+    const void* chain;        // the same interleave for the WHOLE mip chain, in the textures' own tiled word order (texel_tile_index + the level offsets of the three
+                              // textures, which share one size and level count): entry i = {base word i, normal.rg | metal << 16 | roughness << 24}.  What the raster passes'
+                              // anisotropic Sample reads: four 8-byte loads per tap and level instead of twelve 4-byte ones out of three textures.  NULL where not built.
 };
 INCR_HD uint32_t material_tiles_x(uint32_t w) { return (w + 3u) >> 2; }
 INCR_HD uint64_t material_texel_count(uint32_t w, uint32_t h) { return (uint64_t)material_tiles_x(w) * ((h + 3u) >> 2) * 16u; }

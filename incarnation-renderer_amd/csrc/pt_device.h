@@ -349,6 +349,7 @@ DI f3 unpack_r11g11b10(uint32_t p) {
 }
 
 // ---------------------------------------------------------------- texture unit stand-in (bilinear, wrap, mip 0)
+static constexpr uint32_t kTexJointMR = 0x100u;      // internal: not an incr_texture_desc format
 DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t rgba) {
     const float inv255 = 1.f / 255.f;
     const uint32_t r = rgba & 0xffu, g = (rgba >> 8) & 0xffu, b = (rgba >> 16) & 0xffu, a = rgba >> 24;
@@ -356,6 +357,7 @@ DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t 
     case INCR_TEX_RGBA8_SRGB:       return {srgbLut[r], srgbLut[g], srgbLut[b], (float)a * inv255};
     case INCR_TEX_RG_SNORM:         return {2.f * ((float)r * inv255) - 1.f, 2.f * ((float)g * inv255) - 1.f, 0.f, 1.f};
     case INCR_TEX_BGRA8_SWIZZLE_RG: return {(float)b * inv255, (float)g * inv255, 0.f, 1.f};
+    case kTexJointMR:               return {(float)b * inv255, (float)a * inv255, 0.f, 1.f};      // second word of MaterialTexels::chain: metal in byte 2, roughness in byte 3 (the same bytes, the same operations)
     // decoded BC4 / BC5 blocks (texture_mips.hip bc_decode_kernel): the palette entry's exact numerator over 35 x 255, or 35 x 127 signed,
     // times the float nearest the reciprocal (8925 and 4445 times it are exactly 1; a division here is ten instructions at every one of
     // the samplers' decode sites, executed or not)
@@ -741,6 +743,40 @@ DI JointSamples SampleGradJointT(const DeviceTexture& tb, const DeviceTexture& t
     s.mr = {s.mr.x / n, s.mr.y / n, s.mr.z / n, s.mr.w / n};
     return s;
 }
+// The same Sample out of the material's INTERLEAVED chain (MaterialTexels::chain; sRGB base colour + SNORM normals + swizzled metallic-roughness of one size and level count):
+// a tap's four texels of the three maps are four 8-byte loads; decode, weights and summation order are SampleGradJointT's operation for operation.
+DI JointSamples SampleGradJointChain(const uint2* __restrict__ chain, const DeviceTexture& tb, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
+    const Footprint fp = texture_footprint(tb, ddx, ddy, maxAniso);
+    const LevelPair L = level_pair(tb, fp.lod);
+    JointSamples s; s.base = {0.f, 0.f, 0.f, 0.f}; s.normal = s.base; s.mr = s.base;
+    auto tap = [&](const BilinearTap& k, f4& cb, f4& cn, f4& cm) {
+        const uint2 c00 = chain[k.i00], c10 = chain[k.i10], c01 = chain[k.i01], c11 = chain[k.i11];
+        cb = bilinear_blend(k, lut, (uint32_t)INCR_TEX_RGBA8_SRGB, c00.x, c10.x, c01.x, c11.x);
+        cn = bilinear_blend(k, lut, (uint32_t)INCR_TEX_RG_SNORM, c00.y, c10.y, c01.y, c11.y);
+        cm = bilinear_blend(k, lut, kTexJointMR, c00.y, c10.y, c01.y, c11.y);
+    };
+    for (uint32_t i = 1u; i <= fp.taps; ++i) {
+        const float o = fp.taps == 1u ? 0.f : tap_offset(i, fp.taps);
+        f2 st = uv;
+        if (fp.taps != 1u) st = {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o};
+        const BilinearTap ka = bilinear_tap(L.W0, L.H0, L.off0, st);
+        f4 cb, cn, cm; tap(ka, cb, cn, cm);
+        if (L.two) {
+            const BilinearTap kb = bilinear_tap(L.W1, L.H1, L.off1, st);
+            f4 db, dn, dm; tap(kb, db, dn, dm);
+            cb = lerp_levels(cb, db, L.frac); cn = lerp_levels(cn, dn, L.frac); cm = lerp_levels(cm, dm, L.frac);
+        }
+        if (fp.taps == 1u) { s.base = cb; s.normal = cn; s.mr = cm; return s; }
+        s.base.x += cb.x; s.base.y += cb.y; s.base.z += cb.z; s.base.w += cb.w;
+        s.normal.x += cn.x; s.normal.y += cn.y; s.normal.z += cn.z; s.normal.w += cn.w;
+        s.mr.x += cm.x; s.mr.y += cm.y; s.mr.z += cm.z; s.mr.w += cm.w;
+    }
+    const float n = (float)fp.taps;
+    s.base = {s.base.x / n, s.base.y / n, s.base.z / n, s.base.w / n};
+    s.normal = {s.normal.x / n, s.normal.y / n, s.normal.z / n, s.normal.w / n};
+    s.mr = {s.mr.x / n, s.mr.y / n, s.mr.z / n, s.mr.w / n};
+    return s;
+}
 DI JointSamples SampleGradJoint(const DeviceTexture& tb, const DeviceTexture& tn, const DeviceTexture& tm, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
     if (tb.format == INCR_TEX_RGBA8_SRGB && tn.format == INCR_TEX_RG_SNORM && tm.format == INCR_TEX_BGRA8_SWIZZLE_RG)
         return SampleGradJointT<INCR_TEX_RGBA8_SRGB, INCR_TEX_RG_SNORM, INCR_TEX_BGRA8_SWIZZLE_RG>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
@@ -748,8 +784,16 @@ DI JointSamples SampleGradJoint(const DeviceTexture& tb, const DeviceTexture& tn
         return SampleGradJointT<INCR_TEX_RGBA8_SRGB, INCR_TEX_RG16S_OVER_4445, INCR_TEX_RG16_OVER_8925>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
     return SampleGradJointT<-1, -1, -1>(tb, tn, tm, lut, uv, ddx, ddy, maxAniso);
 }
-DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {   // raster: Sample
+DI MatProps EvaluateMaterialPropertiesGrad(const incr_material& mat, const DeviceTexture* __restrict__ textures, const float* __restrict__ lut, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso,
+                                           const void* chain = nullptr) {   // raster: Sample; chain = the material's MaterialTexels::chain where the scene built one
     const int ib = mat.baseColorTextureIndex, in = mat.normalTextureIndex, im = mat.metallicRoughnessTextureIndex;
+    if (chain) {          // implies the three maps, one size, one level count, the usual formats (incr_scene_create)
+        const DeviceTexture tb = textures[ib];
+        const JointSamples js = SampleGradJointChain((const uint2*)chain, tb, lut, uv, ddx, ddy, maxAniso);
+        return EvaluateMaterialPropertiesT(mat, uv, [&](int tex, f2 st) {
+            return tex == ib ? js.base : (tex == in ? js.normal : (tex == im ? js.mr : SampleGrad(textures, lut, tex, st, ddx, ddy, maxAniso)));
+        });
+    }
     if (ib != -1 && in != -1 && im != -1) {
         const DeviceTexture tb = textures[ib], tn = textures[in], tm = textures[im];
         if (tb.width == tn.width && tb.width == tm.width && tb.height == tn.height && tb.height == tm.height && tb.pad[1] == tn.pad[1] && tb.pad[1] == tm.pad[1]) {

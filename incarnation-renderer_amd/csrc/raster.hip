@@ -666,7 +666,8 @@ __global__ __launch_bounds__(256, 4) void gbuffer_kernel(const GBufferParams P) 
     const f3 B = normalize(cross(N, T) * tanW0);
     const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
     const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
-    const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, s_srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
+    const MatProps mi = EvaluateMaterialPropertiesGrad(P.S.materials[materialIndex], P.S.textures, s_srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy,
+                                                       P.S.materialTexels ? P.S.materialTexels[materialIndex].chain : nullptr);      // Sample(g_anisoSampler, uv), gbuffer-compute.hlsl:240
     if (mi.bHasNormalmap) {
         const float* __restrict__ L = P.S.meshLocalToWorld + (size_t)meshIndex * 16;
         const f3 l0 = {L[0], L[1], L[2]}, l1 = {L[4], L[5], L[6]}, l2 = {L[8], L[9], L[10]};
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(kBlock) void forward_shade_kernel(const ForwardPara
             const f2 UV = interp2(uv[0], uv[1], uv[2], lam);
             const incr_material mat = P.S.materials[d.materialIndex];
             const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], x, y, (float)P.W, (float)P.H);
-            const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy);
+            const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, UV, gr.ddx, gr.ddy, P.S.maxAnisotropy, P.S.materialTexels ? P.S.materialTexels[d.materialIndex].chain : nullptr);
             bool done = true;
             if (P.viewmode == 2) out = mk3(p.roughness);                             // ps_main :95-105 (`#if VIWEMODE == 1` never fires)
             else if (P.viewmode == 3) out = mk3(p.metallic);
@@ -1211,7 +1212,7 @@ DI void decal_fragment(const DecalParams& P, const SubTriRec& r, uint32_t px, ui
     const f3 lam = bary_eval(bs, pixel_ndc(px, py, (float)P.W, (float)P.H));
     const incr_material mat = P.S.materials[d.materialIndex];
     const UvGrad gr = quad_uv_gradient(bs, uv[0], uv[1], uv[2], px, py, (float)P.W, (float)P.H);
-    const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy, P.S.maxAnisotropy);
+    const MatProps p = EvaluateMaterialPropertiesGrad(mat, P.S.textures, P.S.srgbLut, interp2(uv[0], uv[1], uv[2], lam), gr.ddx, gr.ddy, P.S.maxAnisotropy, P.S.materialTexels ? P.S.materialTexels[d.materialIndex].chain : nullptr);
     const f3 T = normalize(interp3(tW[0], tW[1], tW[2], lam)), B = normalize(interp3(bW[0], bW[1], bW[2], lam));
     f3 N = normalize(interp3(nW[0], nW[1], nW[2], lam));
     if (p.bHasNormalmap) {

@@ -23,6 +23,7 @@ struct RasterScene {
     const float* __restrict__ meshLocalToWorld;   // 16 floats per mesh: mul(meshTransform, sceneRotation)
     const incr_material* __restrict__ materials;
     const DeviceTexture* __restrict__ textures;
+    const MaterialTexels* __restrict__ materialTexels;      // per material: the interleaved chain of its three main maps (device_types.h), chain == NULL where not built
     const float* __restrict__ srgbLut;
     uint32_t numMeshlets, numMeshes;
     uint32_t maxAnisotropy;                   // g_anisoSampler's MaxAnisotropy (incr_scene_desc::max_anisotropy; 16 as the reference's root signatures)

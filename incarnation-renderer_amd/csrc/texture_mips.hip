@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void material_texels_kernel(const uint32_t* __
     dst[material_texel_index(x, y, w)] = make_uint2(base[i], (n & 0xffffu) | (((m >> 16) & 0xffu) << 16) | (((m >> 8) & 0xffu) << 24));      // n.r, n.g, m.b (metal), m.g (roughness)
 }
 
+// the whole tiled chain of the three textures, interleaved word by word (MaterialTexels::chain)
+__global__ __launch_bounds__(256) void material_chain_kernel(const uint32_t* __restrict__ base, const uint32_t* __restrict__ normal, const uint32_t* __restrict__ mr,
+                                                             uint64_t words, uint2* __restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= words) return;
+    const uint32_t n = normal[i], m = mr[i];
+    dst[i] = make_uint2(base[i], (n & 0xffffu) | (((m >> 16) & 0xffu) << 16) | (((m >> 8) & 0xffu) << 24));
+}
+
 } // namespace incr
 
 namespace incr {
@@ -144,6 +153,11 @@ extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, ui
 }
 extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream) {
     hipLaunchKernelGGL(incr::material_texels_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, base, normal, mr, w, h, (uint2*)dst);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_material_chain(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint64_t words, void* dst, hipStream_t stream) {
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(incr::material_chain_kernel, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, base, normal, mr, words, (uint2*)dst);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {

@@ -237,3 +237,35 @@ def test_device_reciprocal_is_the_correctly_rounded_one(gpu_ctx):
     print("rcp_cr vs 1.f / x: %d of the patterns with x and 1 / x normal differ, %d of them by more than one ulp; %d differ outside that domain" % (out[0], out[1], out[2]))
     assert out[1] == 0
     assert out[0] <= 2 ** 32 * 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ interleaved material chains (raster)
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["sponza_small", "helmet"])
+def test_interleaved_material_chains_are_bit_identical(gpu_ctx, R, sio, A, request, scene_name):
+    """The raster passes' anisotropic Sample of a material's base-colour, normal and metallic-roughness maps out of the interleaved chain
+    (device_types.h MaterialTexels::chain: four 8-byte loads per tap and level) must give the bytes of the three-texture path: G-buffers,
+    lit colour and TAA history of three frames, with the scene built once with and once without the chains (INCR_MATERIAL_CHAINS=0)."""
+    packed = request.getfixturevalue(scene_name)
+    R.generate_meshlets(packed)
+    W, H = 384, 216
+    view = sio.FView().reset(packed, aspect=W / H)
+    view.position = (view.position + 0.35 * view.right).astype(np.float32); view.update_view_transform()          # off-axis: anisotropic footprints, several levels
+    out = []
+    for chains in ("1", "0"):
+        old = os.environ.get("INCR_MATERIAL_CHAINS")
+        os.environ["INCR_MATERIAL_CHAINS"] = chains
+        try:
+            sc = gpu_ctx.create_scene(packed)
+        finally:
+            if old is None: os.environ.pop("INCR_MATERIAL_CHAINS", None)
+            else: os.environ["INCR_MATERIAL_CHAINS"] = old
+        hr = R.HostRenderer(gpu_ctx, sc, W, H)
+        for _ in range(3): hr.render(view)
+        gpu_ctx.synchronize()
+        out.append({n: hr.download(w).copy() for n, w in (("basecolor", A.SURFACE_GBUFFER_BASECOLOR), ("normals", A.SURFACE_GBUFFER_NORMALS), ("mra", A.SURFACE_GBUFFER_MRA),
+                                                        ("hdr", A.SURFACE_HDR_RASTER), ("taa", A.SURFACE_TAA_ACCUMULATION), ("vis", A.SURFACE_VISIBILITY))})
+        hr.close(); sc.close()
+    assert (out[0]["vis"] != 0xFFFFF000).mean() > 0.2
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)

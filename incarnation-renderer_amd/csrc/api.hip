@@ -32,6 +32,7 @@ extern "C" hipError_t incr_launch_mip_box(const uint32_t* src, uint32_t sw, uint
 extern "C" hipError_t incr_launch_mip_tile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_bc_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint32_t format, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
+extern "C" hipError_t incr_launch_alpha_quads(const uint32_t* level, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_material_chain(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint64_t words, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream);
 extern "C" hipError_t incr_launch_mip_adopt_vmf(const uint32_t* vmfN, const uint32_t* vmfMR, uint32_t* dstN, uint32_t* dstMR, uint64_t first, uint64_t count, hipStream_t stream);
@@ -358,7 +359,7 @@ extern "C" {
 int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMaterialTexels, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
+    void* ptrs[] = {(void*)sc->dAlphaQuads, sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMaterialTexels, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
                     sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
@@ -601,6 +602,29 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         mtex[mi].chain = d;
     }
     if (!rc) rc = upload_vec(&sc->dMaterialTexels, mtex.data(), mtex.size());
+    // Alpha quads of the textures the visibility scan alpha-tests against (RGBA8 with an alpha that is not 255 everywhere)
+    std::vector<const uint32_t*> quads(desc->num_textures, nullptr);
+    const bool alphaQuads = !(getenv("INCR_ALPHA_QUADS") && atoi(getenv("INCR_ALPHA_QUADS")) == 0);      // A/B hook
+    for (uint32_t i = 0; i < desc->num_textures && !rc && alphaQuads; ++i) {
+        const DeviceTexture& T = texs[i];
+        if ((T.format != INCR_TEX_RGBA8_SRGB && T.format != INCR_TEX_RGBA8_UNORM) || T.pad[0] || !T.pad[1]) continue;
+        size_t words = 0;
+        for (uint32_t l = 0; l < T.pad[1]; ++l) words += texel_level_words(level_dim(T.width, l), level_dim(T.height, l));
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, words * 4);
+        if (e == hipSuccess) e = hipMemset(d, 0, words * 4);
+        const uint32_t* src = (const uint32_t*)T.texels; uint32_t* dst = (uint32_t*)d;
+        for (uint32_t l = 0; l < T.pad[1] && e == hipSuccess; ++l) {
+            const uint32_t w = level_dim(T.width, l), h = level_dim(T.height, l);
+            e = incr_launch_alpha_quads(src, w, h, dst, nullptr);
+            src += texel_level_words(w, h); dst += texel_level_words(w, h);
+        }
+        if (e != hipSuccess) { if (d) (void)hipFree(d); rc = fail(INCR_ERR_HIP, "alpha quad chain failed: %s", hipGetErrorString(e)); break; }
+        sc->dTexels.push_back(d);
+        sc->textureBytes += words * 4;
+        quads[i] = (const uint32_t*)d;
+    }
+    if (!rc) rc = upload_vec(&sc->dAlphaQuads, quads.data(), quads.size());
     if (!rc) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = fail(INCR_ERR_HIP, "mip generation failed: %s", hipGetErrorString(e)); }
     if (!rc) for (void* lp : linear) {           // the tiled copies are complete: drop the row-major chains
         if (!lp) continue;

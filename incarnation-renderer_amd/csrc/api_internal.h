@@ -70,6 +70,7 @@ struct incr_scene {
     incr::HostBvh bvh;
     // device mirrors
     incr::BvhNode8* dNodes = nullptr; incr::TriIsect* dTris = nullptr; incr::TriShade* dShade = nullptr;
+    const uint32_t** dAlphaQuads = nullptr;      // per texture: its alpha-quad chain (texture_mips.hip alpha_quads_kernel) or NULL (no alpha, or 255 everywhere)
     incr_material* dMaterials = nullptr; incr::DeviceTexture* dTextures = nullptr;
     float* dMeshLocalToWorld = nullptr;
     float* dResolvedLights = nullptr;

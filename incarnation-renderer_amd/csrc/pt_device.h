@@ -531,6 +531,22 @@ DI float trilinear_alpha_at(const DeviceTexture& t, const LevelPair& L, f2 uv) {
     const float b = bilinear_alpha(kb, b00, b10, b01, b11);
     return a + (b - a) * L.frac;
 }
+// The same tap out of the texture's ALPHA QUADS (texture_mips.hip alpha_quads_kernel; DeviceTexture::pad[2] = 1 and texels -> the quad chain): one word per level holds
+// the four alpha bytes of the footprint, so a tap is two loads, and only the footprint's first index is computed.  Same bytes, same operations.
+DI float quad_alpha(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xffu) * (1.f / 255.f); }
+DI float bilinear_alpha_quad(const BilinearTap& t, uint32_t q) {
+    const float wx0 = 1.f - t.fx, wy0 = 1.f - t.fy;
+    return (quad_alpha(q, 0) * wx0 + quad_alpha(q, 1) * t.fx) * wy0 + (quad_alpha(q, 2) * wx0 + quad_alpha(q, 3) * t.fx) * t.fy;
+}
+DI float trilinear_alpha_quads_at(const DeviceTexture& t, const LevelPair& L, f2 uv) {
+    const BilinearTap ka = bilinear_tap(L.W0, L.H0, L.off0, uv), kb = bilinear_tap(L.W1, L.H1, L.off1, uv);
+    const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+    const uint32_t qa = px[ka.i00], qb = px[kb.i00];
+    const float a = bilinear_alpha_quad(ka, qa);
+    if (!L.two) return a;
+    const float b = bilinear_alpha_quad(kb, qb);
+    return a + (b - a) * L.frac;
+}
 // clip(Sample(..).w - 0.5): true when the fragment survives.  Along an anisotropic line the decision is often known before the last
 // tap and the loop stops there -- without changing it: every tap's alpha is >= 0 (convex weights of non-negative texels, and
 // a + (b - a) frac >= 0 for frac < 1), so a partial sum >= n / 2 (exact in float for n <= 16) keeps fl(sum / n) >= 0.5 by the
@@ -540,12 +556,14 @@ DI bool AlphaTestGrad(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy, uint32_t ma
     if (!format_has_alpha(t.format)) return true;          // every texel decodes to alpha 1: any filter of ones stays above 0.5
     const Footprint fp = texture_footprint(t, ddx, ddy, maxAniso);
     const LevelPair L = level_pair(t, fp.lod);
-    if (fp.taps == 1u) return !(trilinear_alpha_at(t, L, uv) - 0.5f < 0.f);
+    const bool quads = t.pad[2] != 0u;          // wave-divergent at worst per triangle: the descriptor travels with it
+    auto tap = [&](f2 st) { return quads ? trilinear_alpha_quads_at(t, L, st) : trilinear_alpha_at(t, L, st); };
+    if (fp.taps == 1u) return !(tap(uv) - 0.5f < 0.f);
     const float n = (float)fp.taps;
     float sum = 0.f;
     for (uint32_t i = 1u; i <= fp.taps; ++i) {
         const float o = tap_offset(i, fp.taps);
-        sum += trilinear_alpha_at(t, L, {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o});
+        sum += tap({uv.x + fp.axis.x * o, uv.y + fp.axis.y * o});
         if (sum >= 0.5f * n) return true;
         if (sum + (float)(fp.taps - i) * 1.00001f < 0.49999f * n) return false;
     }

@@ -369,6 +369,7 @@ DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
     st->bs = bary_setup({a.p[0], a.p[1], a.p[2], a.p[3]}, {a.p[4], a.p[5], a.p[6], a.p[7]}, {a.p[8], a.p[9], a.p[10], a.p[11]});
     st->uv0 = {a.uv[0], a.uv[1]}; st->uv1 = {a.uv[2], a.uv[3]}; st->uv2 = {a.uv[4], a.uv[5]};
     st->tex = P.S.textures[st->alphaTex];
+    if (P.S.alphaQuads) { const uint32_t* q = P.S.alphaQuads[st->alphaTex]; if (q) { st->tex.texels = (const uint8_t*)q; st->tex.pad[2] = 1u; } }      // the alpha test reads the quad chain
 }
 DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriRec r = P.recs[idx];

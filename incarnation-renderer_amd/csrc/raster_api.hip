@@ -212,7 +212,7 @@ void fill_raster_scene(const incr_context* ctx, const incr_scene* sc, RasterScen
     memset(&S, 0, sizeof S);
     S.meshlets = sc->dMeshlets; S.packedTris = sc->dPackedTris; S.meshVisibility = sc->dMeshVisibility;
     S.mvPos = sc->dMvPos; S.mvUv = sc->dMvUv; S.mvNormal = sc->dMvNormal; S.mvTangent = sc->dMvTangent;
-    S.meshLocalToWorld = sc->dMeshLocalToWorld; S.materials = sc->dMaterials; S.textures = sc->dTextures; S.materialTexels = sc->dMaterialTexels; S.srgbLut = ctx->srgbLut;
+    S.meshLocalToWorld = sc->dMeshLocalToWorld; S.materials = sc->dMaterials; S.textures = sc->dTextures; S.materialTexels = sc->dMaterialTexels; S.alphaQuads = sc->dAlphaQuads; S.srgbLut = ctx->srgbLut;
     S.numMeshlets = (uint32_t)sc->host.meshlets.size(); S.numMeshes = (uint32_t)sc->host.meshTransforms.size();
     S.maxAnisotropy = sc->host.maxAnisotropy;
 }

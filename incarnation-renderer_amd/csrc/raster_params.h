@@ -23,6 +23,7 @@ struct RasterScene {
     const float* __restrict__ meshLocalToWorld;   // 16 floats per mesh: mul(meshTransform, sceneRotation)
     const incr_material* __restrict__ materials;
     const DeviceTexture* __restrict__ textures;
+    const uint32_t* const* __restrict__ alphaQuads;          // per texture: the alpha-quad chain the scan's alpha test reads (NULL: sample the texture)
     const MaterialTexels* __restrict__ materialTexels;      // per material: the interleaved chain of its three main maps (device_types.h), chain == NULL where not built
     const float* __restrict__ srgbLut;
     uint32_t numMeshlets, numMeshes;

@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void material_texels_kernel(const uint32_t* __
     dst[material_texel_index(x, y, w)] = make_uint2(base[i], (n & 0xffffu) | (((m >> 16) & 0xffu) << 16) | (((m >> 8) & 0xffu) << 24));      // n.r, n.g, m.b (metal), m.g (roughness)
 }
 
+// ALPHA QUADS of one level of a tiled RGBA8 chain: word (x, y) = the alpha bytes of the bilinear footprint whose top-left texel is (x, y) -- a(x, y), a(x + 1, y),
+// a(x, y + 1), a(x + 1, y + 1), with the sampler's wrap -- in the level's own tiled order.  The visibility scan's alpha test reads ONE word per tap and level where the
+// colour texture costs four loads (pt_device.h trilinear_alpha_quads_at).
+__global__ __launch_bounds__(256) void alpha_quads_kernel(const uint32_t* __restrict__ level, uint32_t w, uint32_t h, uint32_t* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const uint32_t x1 = x + 1u == w ? 0u : x + 1u, y1 = y + 1u == h ? 0u : y + 1u;
+    const uint32_t a00 = level[texel_tile_index(x, y, w)] >> 24, a10 = level[texel_tile_index(x1, y, w)] >> 24;
+    const uint32_t a01 = level[texel_tile_index(x, y1, w)] >> 24, a11 = level[texel_tile_index(x1, y1, w)] >> 24;
+    dst[texel_tile_index(x, y, w)] = a00 | (a10 << 8) | (a01 << 16) | (a11 << 24);
+}
 // the whole tiled chain of the three textures, interleaved word by word (MaterialTexels::chain)
 __global__ __launch_bounds__(256) void material_chain_kernel(const uint32_t* __restrict__ base, const uint32_t* __restrict__ normal, const uint32_t* __restrict__ mr,
                                                              uint64_t words, uint2* __restrict__ dst) {
@@ -153,6 +164,10 @@ extern "C" hipError_t incr_launch_mip_untile(const uint32_t* src, uint32_t w, ui
 }
 extern "C" hipError_t incr_launch_material_texels(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint32_t w, uint32_t h, void* dst, hipStream_t stream) {
     hipLaunchKernelGGL(incr::material_texels_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, base, normal, mr, w, h, (uint2*)dst);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_alpha_quads(const uint32_t* level, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(incr::alpha_quads_kernel, dim3((w + 31u) / 32u, (h + 7u) / 8u), dim3(256), 0, stream, level, w, h, dst);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_material_chain(const uint32_t* base, const uint32_t* normal, const uint32_t* mr, uint64_t words, void* dst, hipStream_t stream) {

@@ -241,11 +241,13 @@ def test_device_reciprocal_is_the_correctly_rounded_one(gpu_ctx):
 
 # ------------------------------------------------------------------------------------------------ interleaved material chains (raster)
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene_name", ["sponza_small", "helmet"])
-def test_interleaved_material_chains_are_bit_identical(gpu_ctx, R, sio, A, request, scene_name):
+@pytest.mark.parametrize("scene_name,hook", [("sponza_small", "INCR_MATERIAL_CHAINS"), ("helmet", "INCR_MATERIAL_CHAINS"), ("sponza_small", "INCR_ALPHA_QUADS")])
+def test_interleaved_material_chains_are_bit_identical(gpu_ctx, R, sio, A, request, scene_name, hook):
     """The raster passes' anisotropic Sample of a material's base-colour, normal and metallic-roughness maps out of the interleaved chain
     (device_types.h MaterialTexels::chain: four 8-byte loads per tap and level) must give the bytes of the three-texture path: G-buffers,
-    lit colour and TAA history of three frames, with the scene built once with and once without the chains (INCR_MATERIAL_CHAINS=0)."""
+    lit colour and TAA history of three frames, with the scene built once with and once without the chains (INCR_MATERIAL_CHAINS=0).
+    Likewise the visibility scan's alpha test out of the alpha quads (texture_mips.hip alpha_quads_kernel: one word per tap and level,
+    INCR_ALPHA_QUADS=0 samples the colour texture): ids and everything behind them."""
     packed = request.getfixturevalue(scene_name)
     R.generate_meshlets(packed)
     W, H = 384, 216
@@ -253,13 +255,13 @@ def test_interleaved_material_chains_are_bit_identical(gpu_ctx, R, sio, A, reque
     view.position = (view.position + 0.35 * view.right).astype(np.float32); view.update_view_transform()          # off-axis: anisotropic footprints, several levels
     out = []
     for chains in ("1", "0"):
-        old = os.environ.get("INCR_MATERIAL_CHAINS")
-        os.environ["INCR_MATERIAL_CHAINS"] = chains
+        old = os.environ.get(hook)
+        os.environ[hook] = chains
         try:
             sc = gpu_ctx.create_scene(packed)
         finally:
-            if old is None: os.environ.pop("INCR_MATERIAL_CHAINS", None)
-            else: os.environ["INCR_MATERIAL_CHAINS"] = old
+            if old is None: os.environ.pop(hook, None)
+            else: os.environ[hook] = old
         hr = R.HostRenderer(gpu_ctx, sc, W, H)
         for _ in range(3): hr.render(view)
         gpu_ctx.synchronize()

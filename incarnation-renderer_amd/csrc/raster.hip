@@ -441,7 +441,17 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
         }
         if (small) continue;
         const uint32_t tw = (bw + 7u) >> 3, th = (bh + 7u) >> 3;
-        const uint32_t rowsPerItem = max(1u, 64u / tw), nItems = (th + rowsPerItem - 1u) / rowsPerItem;
+        // tiles per band item: 64 for an opaque triangle, 32 for an alpha-tested one -- its fragments run the sampler's serial tap loop, a 64-tile item of foliage kept ONE
+        // wave busy for most of the launch while the others had finished (PMC: the average wave lived a quarter of the kernel's duration).  Measured, raster frame at
+        // 64 / 32 / 24 / 16 / 12 / 8 / 4 tiles: 2.68 / 2.54 / 2.54 / 2.56 / 2.60 / 2.64 / 2.70 ms; the opaque items at 32 or 16: no change (profiles/r04_ab_raster_waves.txt)
+#ifndef INCR_VIS_ALPHA_ITEM_TILES
+#define INCR_VIS_ALPHA_ITEM_TILES 32
+#endif
+#ifndef INCR_VIS_ITEM_TILES
+#define INCR_VIS_ITEM_TILES 64
+#endif
+        const uint32_t tileBudget = alphaTex >= 0 ? (uint32_t)INCR_VIS_ALPHA_ITEM_TILES : (uint32_t)INCR_VIS_ITEM_TILES;
+        const uint32_t rowsPerItem = max(1u, tileBudget / tw), nItems = (th + rowsPerItem - 1u) / rowsPerItem;
         const uint32_t base = atomicAdd(P.vqCounters + 1, nItems);
         if (base + nItems <= P.bigCap) {
             for (uint32_t i = 0; i < nItems; ++i) P.bigQueue[base + i] = make_uint2(idx, ((i * rowsPerItem) << 16) | min(rowsPerItem, th - i * rowsPerItem));

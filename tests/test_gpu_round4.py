@@ -248,8 +248,7 @@ def test_interleaved_material_chains_are_bit_identical(gpu_ctx, R, sio, A, reque
     lit colour and TAA history of three frames, with the scene built once with and once without the chains (INCR_MATERIAL_CHAINS=0).
     Likewise the visibility scan's alpha test out of the alpha quads (texture_mips.hip alpha_quads_kernel: one word per tap and level,
     INCR_ALPHA_QUADS=0 samples the colour texture): ids and everything behind them."""
-    packed = request.getfixturevalue(scene_name)
-    R.generate_meshlets(packed)
+    packed = request.getfixturevalue(scene_name)          # (the session fixtures carry their meshlets: regenerating them here would pull the arrays from under the session's oracle scenes)
     W, H = 384, 216
     view = sio.FView().reset(packed, aspect=W / H)
     view.position = (view.position + 0.35 * view.right).astype(np.float32); view.update_view_transform()          # off-axis: anisotropic footprints, several levels

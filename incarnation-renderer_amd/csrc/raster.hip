@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
     QueueWalk q;
     qw_init(q, nBig, 1u);
 #ifndef INCR_VIS_GRAB
-#define INCR_VIS_GRAB 4
+#define INCR_VIS_GRAB 2      // band items per atomic on the cursor: raster frame 2.56 / 2.52 / 2.82 ms at 4 / 2 / 1 with the 32-tile alpha items (4 was the choice with 64-tile items)
 #endif
     for (uint32_t i; qw_next(q, P.vqCounters + 4, nBig, 1u, (uint32_t)INCR_VIS_GRAB, &i);) {          // band items
         const uint2 item = P.bigQueue[i];

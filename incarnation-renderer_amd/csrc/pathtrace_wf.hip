@@ -63,30 +63,37 @@ static constexpr int kWfBlock = 256;
 // LDS stack entries per lane in the traversal kernels: a template parameter, the launcher picks the smallest of
 // 8 / 10 / 12 / 16 / 24 that holds the scene's tree (one entry per level below the root, pt_traverse.h): Sponza-stat and
 // Bistro-scale (10 levels with the SAH-optimal collapse) take 10.
-template <int N> using WfStack = LaneStackT<N, kWfBlock, false, true>;        // any-hit (shadow) traversal
-template <int N> using WfStackK = LaneStackT<N, kWfBlock, true, true>;         // closest-hit traversal: keyed, drops groups beyond the best hit
-// Hottest nodes kept in LDS per workgroup (80 B each), sized so that stack + copy still give the kernels' workgroups per CU
-// out of 160 KB: extend 7 / 6 / 6 / 4 / 3 workgroups, shadow 7 / 7 / 7 / 7 / 6 at N = 8 / 10 / 12 / 16 / 24.
-#ifndef INCR_EXTEND_TOP
-#define INCR_EXTEND_TOP 80
-#endif
-#ifndef INCR_SHADOW_TOP
-#define INCR_SHADOW_TOP 144
+#ifndef INCR_EXTEND_WAVES10
+#define INCR_EXTEND_WAVES10 7
 #endif
 #ifndef INCR_SHADOW_WAVES
 #define INCR_SHADOW_WAVES 7     // the overlapped step (pt_traverse.h trav_any_step2) keeps a node and a triangle in flight: 72 VGPRs; at 8 waves (64) it spills 28 B and loses (shadow 9.4 ms against 7.9)
 #endif
-#ifndef INCR_EXTEND_TOP10
-#define INCR_EXTEND_TOP10 24
+// WORKGROUPS OF THE PERSISTENT TRAVERSAL KERNELS (round 5: the workgroup's size is a parameter).  The LDS copy of the hottest nodes (NODE ORDER,
+// scene_build.cpp) serves any number of waves, so fewer, larger workgroups per CU could keep more nodes: 7 workgroups of 4 waves hold 151 nodes each for the
+// any-hit kernel (48 % of its node visits by tools/trav_sim) and 23 for the closest-hit kernel, whose stack carries keys (23 %); 4 workgroups of 7 waves hold
+// 275 / 51 (55 % / 30 %), 2 workgroups of 14 waves 560 / 110 (64 % / 41 %).  Measured, same box, ms per 4K frame with every kernel alone, any-hit /
+// closest-hit (profiles/r05_ab_trav_blocks.txt): 7 workgroups 7.33-7.41 / 7.43-7.49, 4 workgroups 7.44-7.52 / 7.78-7.82, 2 workgroups 8.44-8.55 / 8.71-8.81
+// (frame 16.5 / 17.3 / 20.1 ms): what the larger copy takes off the vector memory path is less than what the larger workgroups cost (their waves spread
+// unevenly over the four SIMDs and the CU's LDS is handed out in two or four pieces instead of seven).  Seven it stays.
+#ifndef INCR_TRAV_BLOCKS_PER_CU
+#define INCR_TRAV_BLOCKS_PER_CU 7
 #endif
-#ifndef INCR_SHADOW_TOP10
-#define INCR_SHADOW_TOP10 120
-#endif
-template <int N> struct TopNodes { static constexpr uint32_t kExtend = N <= 8 ? (uint32_t)INCR_EXTEND_TOP : (N <= 10 ? (uint32_t)INCR_EXTEND_TOP10 : (N <= 12 ? 24u : (N <= 16 ? 80u : 64u)));
-                                   static constexpr uint32_t kShadow = N <= 8 ? (uint32_t)INCR_SHADOW_TOP : (N <= 10 ? (uint32_t)INCR_SHADOW_TOP10 : (N <= 12 ? 96u : (N <= 16 ? 48u : 24u))); };
+template <int N, bool SHADOW> struct TravCfg {
+    static constexpr int kWaves = SHADOW ? (N <= 16 ? INCR_SHADOW_WAVES : 6) : (N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3))));      // waves per SIMD (VGPRs, LDS stack bytes)
+    static constexpr int kBlocksPerCU = (kWaves * 4) % INCR_TRAV_BLOCKS_PER_CU == 0 ? INCR_TRAV_BLOCKS_PER_CU : kWaves;
+    static constexpr int kBlock = kWaves * 256 / kBlocksPerCU;                  // threads per workgroup
+    static constexpr int kStackBytes = N * kBlock * 4 * (SHADOW ? 1 : 2);       // entries, and keys for the closest-hit kernel
+    static constexpr int kLdsBudget = 163840 / kBlocksPerCU - 1024;             // 160 KB per CU; 1 KB for allocation granularity
+    static constexpr uint32_t kTop = (uint32_t)((kLdsBudget - kStackBytes) / 80 < 8 ? 8 : (kLdsBudget - kStackBytes) / 80);      // hottest nodes kept in LDS (80 B each)
+    static_assert(kBlock % 64 == 0 && kBlock <= 1024, "traversal workgroup: whole waves, at most 16");
+    static_assert(kStackBytes + (int)kTop * 80 <= 163840 / kBlocksPerCU, "traversal workgroup: LDS");
+};
+template <int N, bool SHADOW> using TravStack = LaneStackT<N, TravCfg<N, SHADOW>::kBlock, !SHADOW, true>;      // any-hit: plain; closest-hit: keyed, drops groups beyond the best hit
+template <int BLOCK>
 DI uint32_t load_top_nodes(const PtParams& P, float4* s_top, uint32_t capacity) {
     const uint32_t count = min(capacity, P.numNodes);
-    for (uint32_t i = threadIdx.x; i < count * 5u; i += kWfBlock) s_top[i] = ((const float4*)P.nodes)[i];
+    for (uint32_t i = threadIdx.x; i < count * 5u; i += (uint32_t)BLOCK) s_top[i] = ((const float4*)P.nodes)[i];
     __syncthreads();
     return count;
 }
@@ -214,7 +221,7 @@ DI uint32_t light_cell(const PtParams& P, f3 p) {
 
 // Wave-level work distribution: hands the next items of the wave's chunk to idle lanes (consecutive indices in
 // lane order), taking a new chunk from the device-wide cursor when the current one is used up.
-template <uint32_t kChunkDefault> struct WaveChunk {
+template <uint32_t kChunkDefault, int BLOCK> struct WaveChunk {
     uint32_t next, end;     // wave-uniform
     bool exhausted;
 #if INCR_WF_CURSOR_STRIPES > 1
@@ -229,7 +236,7 @@ template <uint32_t kChunkDefault> struct WaveChunk {
     // fetch, was measured and dropped: shadow 10.6 -> 11.1 ms per frame -- loads and atomics return in order, so every step
     // issued after the ask waits for the contended atomic instead of only the one step at the chunk boundary.)
     DI void init_static(uint32_t total) {
-        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (kWfBlock / 64) + (threadIdx.x >> 6)) * kChunk);
+        const uint32_t b = __builtin_amdgcn_readfirstlane((blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * kChunk);
         exhausted = b >= total;
         next = exhausted ? 0u : b; end = exhausted ? 0u : min(b + kChunk, total);
     }
@@ -242,7 +249,7 @@ template <uint32_t kChunkDefault> struct WaveChunk {
             // STRIPED cursors: the part of the list behind the static round is cut into INCR_WF_CURSOR_STRIPES contiguous segments, each with a cursor of
             // its own (on its own cache line); a wave draws from its home segment (workgroup index modulo the stripe count) and moves on to the next
             // when that one is used up -- the grid's chunk requests no longer queue on one word
-            const uint32_t dynBase = min(gridDim.x * (kWfBlock / 64) * kChunk, total), dynTotal = total - dynBase;
+            const uint32_t dynBase = min(gridDim.x * (BLOCK / 64) * kChunk, total), dynTotal = total - dynBase;
             const uint32_t segLen = ((dynTotal + INCR_WF_CURSOR_STRIPES * kChunk - 1u) / (INCR_WF_CURSOR_STRIPES * kChunk)) * kChunk;
             for (;;) {
                 if (tried >= (uint32_t)INCR_WF_CURSOR_STRIPES || segLen == 0u) { exhausted = true; break; }
@@ -276,7 +283,10 @@ template <uint32_t kChunkDefault> struct WaveChunk {
 // samples in flight: the tile rows of sample s follow those of sample s - 1 (tilesY rows each).  false: no ray (outside the frame, or a
 // shard's padding row, whose pixel is cleared here).
 DI bool generate_lane(const PtParams& P, uint32_t i, uint32_t total, uint32_t tilesX, uint32_t tilesY, uint32_t tileBase, float4* rayO, float4* rayD) {
-    const uint32_t tile = (i >> 6) + tileBase, w = i & 63u;
+    const uint32_t lt = i >> 6, w = i & 63u;
+    // (LIST ORDER of bounce 0 in column strips of 8 / 16 / 32 tiles instead of full-width tile rows -- what the grid works on at any time is then a compact window of the
+    // image -- was measured in round 5 for the L2's sake: 4K frame 16.33-16.47 ms against 16.44-16.49, every kernel within its noise: profiles/r05_ab_tile_strip.txt.)
+    const uint32_t tile = lt + tileBase;
     const uint32_t tyv = tile / tilesX, smp = tyv / tilesY;
     const uint32_t px = (tile - tyv * tilesX) * 8u + (w & 7u), ly = (tyv - smp * tilesY) * 8u + (w >> 3);
     *rayO = make_float4(0.f, 0.f, 0.f, 0.f); *rayD = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -327,19 +337,18 @@ extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
 #endif
 
 // ------------------------------------------------------------------------------------------------ extend
-#ifndef INCR_EXTEND_WAVES10
-#define INCR_EXTEND_WAVES10 7      // 10-entry keyed stack: 70 VGPRs since the hit's shading index is its flattened id and 1 / d comes from v_rcp: 7 workgroups of 22.4 KB LDS per CU
-#endif
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3)))) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce, uint32_t chunkSize) {
-    __shared__ uint32_t s_stack[N * kWfBlock];
-    __shared__ float s_keys[N * kWfBlock];
-    __shared__ float4 s_top[TopNodes<N>::kExtend * 5];
+// (INCR_EXTEND_WAVES10 = 7, with TravCfg above: the 10-entry keyed stack takes 70 VGPRs since the hit's shading index is its flattened id and 1 / d comes from v_rcp)
+template <int N> __global__ __launch_bounds__((TravCfg<N, false>::kBlock), (TravCfg<N, false>::kWaves)) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce, uint32_t chunkSize) {
+    typedef TravCfg<N, false> Cfg;
+    __shared__ uint32_t s_stack[N * Cfg::kBlock];
+    __shared__ float s_keys[N * Cfg::kBlock];
+    __shared__ float4 s_top[Cfg::kTop * 5];
     const uint32_t total = B.counters[bounce];
     // a workgroup whose first wave has no static chunk has none at all (WaveChunk::init_static) and never takes one from the cursor: it leaves
     // before copying the top nodes -- a short list (a small frame, a late bounce) is then a short launch
-    if (blockIdx.x * (kWfBlock / 64) * chunkSize >= total) return;
-    WfStackK<N> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
-    st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kExtend));
+    if (blockIdx.x * (Cfg::kBlock / 64) * chunkSize >= total) return;
+    TravStack<N, false> st; st.bind(s_stack + threadIdx.x, s_keys + threadIdx.x); st.sp = 0;
+    st.bind_top(s_top, load_top_nodes<Cfg::kBlock>(P, s_top, Cfg::kTop));
     // the rays of this bounce: a flat queue in list order (origin + path id, direction), written by generate / shade -- a refill
     // is two coalesced loads, not a path id and two gathers behind it
     const float4* __restrict__ ext = (bounce & 1) ? B.extB : B.extA;
@@ -348,7 +357,7 @@ template <int N> __global__ __launch_bounds__(kWfBlock, N <= 8 ? INCR_EXTEND_WAV
 #else
     uint32_t* cursor = B.counters + kCursorBase + 2 * bounce;
 #endif
-    WaveChunk<kExtendChunk> chunk; chunk.kChunk = chunkSize; chunk.init_static(total);
+    WaveChunk<kExtendChunk, Cfg::kBlock> chunk; chunk.kChunk = chunkSize; chunk.init_static(total);
     bool active = false; uint32_t slot = 0;
     TravClosest2 T; trav_closest_begin(T, {0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f, 10000.0f); T.triBase1 = 0; T.triMask1 = 0;      // the interval every ray of this kernel has: tmin / tmax stay compile-time constants
     uint32_t rays = 0;
@@ -886,20 +895,21 @@ template <bool ENV> __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) voi
 // next refill, all of them with one instruction.
 // `launch` = the index of this launch within the frame (its cursor); it traces the rays of bounces loBounce .. hiBounce = the queue range between the
 // snapshots [kSnapBase + loBounce, kSnapBase + hiBounce + 1).
-template <int N> __global__ __launch_bounds__(kWfBlock, N <= 16 ? INCR_SHADOW_WAVES : 6) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int launch, int loBounce, int hiBounce) {
-    __shared__ uint32_t s_stack[N * kWfBlock];
-    __shared__ float4 s_top[TopNodes<N>::kShadow * 5];
+template <int N> __global__ __launch_bounds__((TravCfg<N, true>::kBlock), (TravCfg<N, true>::kWaves)) void wf_shadow_kernel(const PtParams P, const WfBuffers B, int launch, int loBounce, int hiBounce) {
+    typedef TravCfg<N, true> Cfg;
+    __shared__ uint32_t s_stack[N * Cfg::kBlock];
+    __shared__ float4 s_top[Cfg::kTop * 5];
     const uint32_t first = min(B.counters[kSnapBase + loBounce], B.rayCap);
     const uint32_t total = min(B.counters[kSnapBase + hiBounce + 1], B.rayCap) - first;
-    if (blockIdx.x * (kWfBlock / 64) * kShadowChunk >= total) return;          // no static chunk for any wave of this workgroup (see wf_extend_kernel)
-    WfStack<N> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
-    st.bind_top(s_top, load_top_nodes(P, s_top, TopNodes<N>::kShadow));
+    if (blockIdx.x * (Cfg::kBlock / 64) * kShadowChunk >= total) return;          // no static chunk for any wave of this workgroup (see wf_extend_kernel)
+    TravStack<N, true> st; st.bind(s_stack + threadIdx.x, nullptr); st.sp = 0;
+    st.bind_top(s_top, load_top_nodes<Cfg::kBlock>(P, s_top, Cfg::kTop));
 #if INCR_WF_CURSOR_STRIPES > 1
     uint32_t* cursor = B.counters + kStripeBase + (4 + launch) * INCR_WF_CURSOR_STRIPES * 32;
 #else
     uint32_t* cursor = B.counters + kCursorBase + 2 * launch + 1;
 #endif
-    WaveChunk<kShadowChunk> chunk; chunk.init_static(total);
+    WaveChunk<kShadowChunk, Cfg::kBlock> chunk; chunk.init_static(total);
     bool active = false, pending = false, occludedDone = false;
     uint32_t rayIndex = 0;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
@@ -1092,10 +1102,18 @@ __global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters
 #endif
 }
 template <int N> static void launch_extend(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int bounce, uint32_t chunk) {
-    hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, bounce, chunk);
+    hipLaunchKernelGGL(wf_extend_kernel<N>, dim3(blocks), dim3(TravCfg<N, false>::kBlock), 0, stream, p, b, bounce, chunk);
 }
 template <int N> static void launch_shadow(uint32_t blocks, hipStream_t stream, const PtParams& p, const WfBuffers& b, int launch, int lo, int hi) {
-    hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(kWfBlock), 0, stream, p, b, launch, lo, hi);
+    hipLaunchKernelGGL(wf_shadow_kernel<N>, dim3(blocks), dim3(TravCfg<N, true>::kBlock), 0, stream, p, b, launch, lo, hi);
+}
+// workgroups per CU and threads per workgroup of the traversal kernels for a stack of `sv` entries (TravCfg)
+template <bool SHADOW> static void trav_geometry(int sv, uint32_t* perCU, uint32_t* block) {
+    if (sv == 8) { *perCU = TravCfg<8, SHADOW>::kBlocksPerCU; *block = TravCfg<8, SHADOW>::kBlock; }
+    else if (sv == 10) { *perCU = TravCfg<10, SHADOW>::kBlocksPerCU; *block = TravCfg<10, SHADOW>::kBlock; }
+    else if (sv == 12) { *perCU = TravCfg<12, SHADOW>::kBlocksPerCU; *block = TravCfg<12, SHADOW>::kBlock; }
+    else if (sv == 16) { *perCU = TravCfg<16, SHADOW>::kBlocksPerCU; *block = TravCfg<16, SHADOW>::kBlock; }
+    else { *perCU = TravCfg<24, SHADOW>::kBlocksPerCU; *block = TravCfg<24, SHADOW>::kBlock; }
 }
 // behind wf_shade_kernel(bounce): the shadow-ray queue's length with the rays of bounces 0 .. bounce in it
 __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int bounce) {
@@ -1135,7 +1153,8 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     const int sv = stackEntries <= 8u ? 8 : (stackEntries <= 10u ? 10 : (stackEntries <= 12u ? 12 : (stackEntries <= 16u ? 16 : 24)));
     const uint32_t cus = (uint32_t)std::max(numCUs, 1);
     // persistent traversal grids: enough waves to fill every CU at the kernels' occupancy (LDS stack bytes per workgroup decide it)
-    const uint32_t extendPerCU = sv == 8 ? (uint32_t)INCR_EXTEND_WAVES : (sv == 10 ? (uint32_t)INCR_EXTEND_WAVES10 : (sv <= 12 ? 6u : (sv == 16 ? 4u : 3u))), shadowPerCU = sv <= 16 ? (uint32_t)INCR_SHADOW_WAVES : 6u;
+    uint32_t extendPerCU, extendBlock, shadowPerCU, shadowBlock;
+    trav_geometry<false>(sv, &extendPerCU, &extendBlock); trav_geometry<true>(sv, &shadowPerCU, &shadowBlock);
     const uint32_t blocksShadow = cus * shadowPerCU;        // the length of the ray queue is only known on the device
     uint32_t total[8], blocksAll[8], blocksExtend[8], extendChunk[8];
     for (int i = 0; i < numPipes; ++i) {
@@ -1146,7 +1165,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         // generate / shade / shadow_gen / accumulate: one workgroup per 256 list slots and the hardware dispatcher as the load balancer
         // (capped at 4 / 8 / 16 / 32 workgroups per CU with a grid-stride loop the 4K frame took 46.0 / 43.8 / 43.9 / 43.1 ms, uncapped 42.7)
         blocksAll[i] = std::max(1u, (total[i] + kWfBlock - 1) / kWfBlock);
-        blocksExtend[i] = std::max(1u, std::min(cus * extendPerCU, (total[i] + kWfBlock - 1) / kWfBlock));
+        blocksExtend[i] = std::max(1u, std::min(cus * extendPerCU, (total[i] + extendBlock - 1) / extendBlock));
     }
     if (numPipes > 1) {
         (void)hipEventRecord(fork, streams[0]);
@@ -1189,7 +1208,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
     // stage-major issue order: the pipelines' kernels of one stage sit next to each other in the queues
     for (int i = 0; i < numPipes; ++i) {
         if (!total[i]) continue;
-        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (kWfBlock / 64) * extendChunk[i], blocksShadow * (kWfBlock / 64) * kShadowChunk, skyConsts);
+        hipLaunchKernelGGL(wf_init_counters_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, blocksExtend[i] * (extendBlock / 64) * extendChunk[i], blocksShadow * (shadowBlock / 64) * kShadowChunk, skyConsts);
         if (events) { (void)hipEventRecord(events[i * kWfProfEvents], streams[i]); rec[i][0] = true; }
     }
     int groupLo[8] = {}, launches[8] = {};

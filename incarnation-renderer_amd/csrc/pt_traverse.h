@@ -436,6 +436,16 @@ template <class ST> DI bool trav_any_step2(const PtParams& P, ST& st, TravAny2& 
     if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const float4* __restrict__ tp = tri_ptr(P, ti); ta = tp[0]; tb = tp[1]; tc = tp[2]; }      // 32-bit sum: triBase is biased modulo 2^32
     Fetch5 f;                            // as above (20 v_mov)
     if (wantNode) f = fetch_step(P, st, T.cur, 0u, 0u);
+#ifdef INCR_DIAG_VMEM      // sensitivity diagnostic: every traversal fetch issued twice (the second hits the line the first brought in)
+    { incr_v4f da, db, dc, dd, de, dta, dtb, dtc;
+      if (wantTri) { const uint32_t ti = T.triBase + (uint32_t)__builtin_ctz(T.triMask); const volatile incr_v4f* tp = (const volatile incr_v4f*)tri_ptr(P, ti); dta = tp[0]; dtb = tp[1]; dtc = tp[2]; asm volatile("" :: "v"(dta.x), "v"(dtb.x), "v"(dtc.x)); }
+      if (wantNode && !(T.cur < st.topCount)) { const volatile incr_v4f* np = (const volatile incr_v4f*)node_ptr(P, T.cur); da = np[0]; db = np[1]; dc = np[2]; dd = np[3]; de = np[4]; asm volatile("" :: "v"(da.x), "v"(db.x), "v"(dc.x), "v"(dd.x), "v"(de.x)); } }
+#endif
+#ifdef INCR_DIAG_VALU      // sensitivity diagnostic: INCR_DIAG_VALU x 10 extra vector instructions per iteration
+    { float dv = T.rs.o.x;
+#pragma unroll
+      for (int q = 0; q < INCR_DIAG_VALU; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0\n v_max_f32 %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_max_f32 %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_max_f32 %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_max_f32 %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_max_f32 %0, %0, %0" : "+v"(dv)); }
+#endif
     if (wantTri) {
         T.triMask &= T.triMask - 1u;
         float det, U, V, Tn;

@@ -67,6 +67,7 @@ static uint32_t child_index(const BvhNode8& n, uint32_t k) { return n.childBase 
 struct Trace { std::vector<uint32_t> start; std::vector<uint8_t> tris; void begin() { start.push_back((uint32_t)tris.size()); } };
 static Trace* g_trace = nullptr;
 static std::vector<uint8_t> g_nodeDepth; static double g_visitsByDepth[2][32];
+static std::vector<double> g_visitsByIndex[2];          // round 5: how many node visits do the K lowest node indices (NODE ORDER: the LDS copy of the traversal kernels) take?
 struct Stats { double rays = 0, nodes = 0, tris = 0, pushes = 0, hits = 0; std::vector<uint32_t> depthHist = std::vector<uint32_t>(128, 0); };
 static void note(Stats& s, uint32_t nodes, uint32_t tris, uint32_t pushes, uint32_t maxDepth, bool hit) {
     s.rays++; s.nodes += nodes; s.tris += tris; s.pushes += pushes; s.hits += hit; s.depthHist[std::min(maxDepth, 127u)]++;
@@ -115,7 +116,7 @@ static Result closest(const HostBvh& B, const std::vector<uint8_t>& sortAxis, co
             if (!got) break;
         }
         have = false;
-        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[0][g_nodeDepth[cur]]++;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) { g_visitsByDepth[0][g_nodeDepth[cur]]++; g_visitsByIndex[0][cur]++; }
         NodeT N; node_test(n, r, invd, best, N);
         if (g_trace) g_trace->tris.push_back((uint8_t)__builtin_popcount(tri_mask(n, N.hit)));
         test_tris(n, tri_mask(n, N.hit));
@@ -228,7 +229,7 @@ static bool anyhit(const HostBvh& B, const std::vector<uint8_t>& sortAxis, const
             }
         }
         have = false;
-        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) g_visitsByDepth[1][g_nodeDepth[cur]]++;
+        const BvhNode8& n = B.nodes8[cur]; ++nodes; if (!g_nodeDepth.empty()) { g_visitsByDepth[1][g_nodeDepth[cur]]++; g_visitsByIndex[1][cur]++; }
         NodeT N; node_test(n, r, invd, r.tmax, N);
         uint32_t tm = tri_mask(n, N.hit);
         const uint32_t trisBefore = tris;
@@ -586,7 +587,7 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             std::vector<uint32_t> occTri(3 * 256, 0xffffffffu); double occStat[3][3] = {};
             Trace trP, trB, trS; const bool model = cfg == 2 && variant == 2;
             g_nodeDepth.clear(); memset(g_visitsByDepth, 0, sizeof g_visitsByDepth);
-            if (cfg == 2 && variant == 2) { g_nodeDepth.assign(B.nodes8.size(), 0); std::vector<std::pair<uint32_t,uint8_t>> q; q.push_back({0u, 1}); while (!q.empty()) { auto [ni, d] = q.back(); q.pop_back(); g_nodeDepth[ni] = d; for (int k = 0; k < 8; ++k) if ((B.nodes8[ni].imask >> k) & 1u) q.push_back({B.nodes8[ni].childBase + (uint32_t)k, (uint8_t)(d + 1)}); } }
+            if (cfg == 2 && variant == 2) { g_visitsByIndex[0].assign(B.nodes8.size(), 0.0); g_visitsByIndex[1].assign(B.nodes8.size(), 0.0); g_nodeDepth.assign(B.nodes8.size(), 0); std::vector<std::pair<uint32_t,uint8_t>> q; q.push_back({0u, 1}); while (!q.empty()) { auto [ni, d] = q.back(); q.pop_back(); g_nodeDepth[ni] = d; for (int k = 0; k < 8; ++k) if ((B.nodes8[ni].imask >> k) & 1u) q.push_back({B.nodes8[ni].childBase + (uint32_t)k, (uint8_t)(d + 1)}); } }
             double checksum = 0;
             for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
                 const float sx = ((x + 0.5f) / W * 2.f - 1.f) * tanHalfFovY * aspect, sy = (1.f - (y + 0.5f) / H * 2.f) * tanHalfFovY;
@@ -650,7 +651,9 @@ extern "C" int trav_sim(const incr_scene_desc* desc, const float* cam /* pos, ri
             printf(" variant %d (checksum %.6f)\n", variant, checksum);
             if (cfg == 2 && variant == 2) {
                 for (int w = 0; w < 2; ++w) { double tot = 0, acc = 0; for (int d = 0; d < 32; ++d) tot += g_visitsByDepth[w][d];
-                    printf("  %s node visits by depth (cumulative share):", w ? "any-hit" : "closest"); for (int d = 1; d < 12; ++d) { acc += g_visitsByDepth[w][d]; printf(" d%d %.3f", d, acc / tot); } printf("\n"); }
+                    printf("  %s node visits by depth (cumulative share):", w ? "any-hit" : "closest"); for (int d = 1; d < 12; ++d) { acc += g_visitsByDepth[w][d]; printf(" d%d %.3f", d, acc / tot); } printf("\n");
+                    printf("  %s node visits taken by the K lowest indices:", w ? "any-hit" : "closest"); double a2 = 0; size_t i2 = 0;
+                    for (size_t K : {8, 24, 64, 120, 200, 288, 400, 576, 800, 1100, 1536, 2048, 4096}) { for (; i2 < K && i2 < g_visitsByIndex[w].size(); ++i2) a2 += g_visitsByIndex[w][i2]; printf(" %zu: %.3f", K, a2 / tot); } printf("\n"); }
 
             }
             print_stats("closest primary", sp); print_stats("closest bounce", sb); print_stats("any-hit shadow", ss);

@@ -474,9 +474,16 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
         mat.metallicRoughnessTextureIndex = tex(pbr.get("metallicRoughnessTexture"), A.TEX_BGRA8_SWIZZLE_RG)
         mat.normalTextureIndex = tex(m.get("normalTexture"), A.TEX_RG_SNORM)
         ext = m.get("extensions", {})
-        mat.transmissionFactor = ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0)
-        mat.clearcoatFactor = ext.get("KHR_materials_clearcoat", {}).get("clearcoatFactor", 0.0)
-        mat.clearcoatRoughnessFactor = ext.get("KHR_materials_clearcoat", {}).get("clearcoatRoughnessFactor", 0.0)
+        # KHR_materials_transmission / KHR_materials_clearcoat (scene.cpp:939-1001): factors default to 0, the single-channel maps go to the
+        # BC4 slots (source format R8G8B8A8_UNORM), clearcoat roughness / normal to the BC5 slots of their base-material counterparts
+        tr = ext.get("KHR_materials_transmission", {}); cc = ext.get("KHR_materials_clearcoat", {})
+        mat.transmissionFactor = tr.get("transmissionFactor", 0.0)
+        mat.transmissionTextureIndex = tex(tr.get("transmissionTexture"), A.TEX_RGBA8_UNORM)
+        mat.clearcoatFactor = cc.get("clearcoatFactor", 0.0)
+        mat.clearcoatRoughnessFactor = cc.get("clearcoatRoughnessFactor", 0.0)
+        mat.clearcoatTextureIndex = tex(cc.get("clearcoatTexture"), A.TEX_RGBA8_UNORM)
+        mat.clearcoatRoughnessTextureIndex = tex(cc.get("clearcoatRoughnessTexture"), A.TEX_BGRA8_SWIZZLE_RG)
+        mat.clearcoatNormalTextureIndex = tex(cc.get("clearcoatNormalTexture"), A.TEX_RG_SNORM)
         mat.alphaMode = {"OPAQUE": A.ALPHA_OPAQUE, "MASK": A.ALPHA_MASKED, "BLEND": A.ALPHA_BLEND}[m.get("alphaMode", "OPAQUE")]
         mat.doubleSided = 1 if m.get("doubleSided", False) else 0
         s.materials.append(mat)

@@ -62,6 +62,20 @@ def helmet(sio):
 
 
 @pytest.fixture(scope="session")
+def suzanne(sio):
+    """content/models/suzanne of the reference checkout: one mesh, 16-bit indices, shipped tangents, a camera under a two-node chain."""
+    s = sio.load_gltf(os.path.join(ROOT, "assets/suzanne/Suzanne.gltf"), max_texture_size=512)
+    return mod("raster").generate_meshlets(s)
+
+
+@pytest.fixture(scope="session")
+def transmission_test(sio):
+    """content/models/transmission-test: 22 meshes under a node hierarchy, 32-bit indices, KHR_materials_transmission, MASK materials, JPEG + PNG images."""
+    s = sio.load_gltf(os.path.join(ROOT, "assets/transmission-test/TransmissionTest.gltf"))
+    return mod("raster").generate_meshlets(s)
+
+
+@pytest.fixture(scope="session")
 def helmet_oracle(ob, helmet):
     return ob.OracleScene(helmet)
 

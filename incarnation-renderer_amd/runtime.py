@@ -23,7 +23,7 @@ EXPORTS = [
     "incr_scene_get_info", "incr_scene_texture_info", "incr_scene_texture_download", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
     "incr_trace_rays", "incr_selftest_small_float", "incr_selftest_reciprocal", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines", "incr_set_pathtrace_overlap",
     # raster path
-    "incr_generate_tangents", "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
+    "incr_generate_tangents", "incr_decode_jpeg", "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
     "incr_sky_lighting", "incr_direct_lighting", "incr_clustered_lighting", "incr_taa_resolve", "incr_dynamic_sky",
     "incr_hbao", "incr_environmentmap", "incr_debug_visualization", "incr_forward_lighting", "incr_gbuffer_decals",
@@ -102,6 +102,7 @@ def load():
     L.incr_meshletize.restype = C.c_int
     L.incr_meshletize.argtypes = [vp, u32, vp, u32, u32, u32, u32, C.POINTER(vp)]
     L.incr_generate_tangents.restype = C.c_int; L.incr_generate_tangents.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.incr_decode_jpeg.restype = C.c_int; L.incr_decode_jpeg.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, C.c_size_t]
     L.incr_meshlet_set_counts.restype = u32; L.incr_meshlet_set_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.incr_meshlet_set_copy.restype = C.c_int; L.incr_meshlet_set_copy.argtypes = [vp, vp, vp, vp]
     L.incr_meshlet_set_free.restype = None; L.incr_meshlet_set_free.argtypes = [vp]

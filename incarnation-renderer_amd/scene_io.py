@@ -342,7 +342,20 @@ def _bounding_sphere(pos):
     return np.array([c[0], c[1], c[2], r], dtype=f32)
 
 
-def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False, use_content_cache=False, texture_cache_dir=None):
+def decode_jpeg(data):
+    """JPEG bytes -> RGBA8 array through incr_decode_jpeg: stb_image's published integer pipeline (what tinygltf::LoadImageData runs, scene.cpp:40, 98-117)."""
+    import ctypes as C
+    from . import runtime as _rt
+    L = _rt.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = C.c_int32(0), C.c_int32(0)
+    _rt.check(L.incr_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    _rt.check(L.incr_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), out.ctypes.data, out.size))
+    return out
+
+
+def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=False, use_content_cache=False, texture_cache_dir=None, jpeg_decoder="stb"):
     """glTF 2.0 loader -> PackedScene: .gltf (external or `data:` buffers and images) and binary .glb (embedded BIN chunk,
     bufferView images) -- the two containers tinygltf's LoadASCIIFromFile / LoadBinaryFromFile accept (scene.cpp:113-130)."""
     import base64
@@ -415,12 +428,15 @@ def load_gltf(path, load_images=True, max_texture_size=None, ignore_tangents=Fal
                 import hashlib
                 cdir = os.path.join(os.path.dirname(os.path.abspath(path)), ".content-cache")
                 stem = os.path.splitext(os.path.basename(im["uri"]))[0] if "uri" in im and not im["uri"].startswith("data:") else "image%d" % image_index
-                cached = os.path.join(cdir, "%s.%s.%s.npy" % (stem, hashlib.sha256(data).hexdigest()[:16], max_texture_size or "full"))
+                cached = os.path.join(cdir, "%s.%s.%s%s.npy" % (stem, hashlib.sha256(data).hexdigest()[:16], max_texture_size or "full", "" if jpeg_decoder == "stb" else "." + jpeg_decoder))
                 if os.path.exists(cached):
                     image_cache[image_index] = np.load(cached)
                     content_cache_stats["hits"] += 1
                     return image_cache[image_index]
-            img = Image.open(io.BytesIO(data)).convert("RGBA")    # "Source Images are always 4 channel 8bpp" (scene.cpp:1167)
+            if data[:2] == b"\xff\xd8" and jpeg_decoder == "stb":
+                img = Image.fromarray(decode_jpeg(data), "RGBA")      # stb_image's integer pipeline (csrc/jpeg_decode.cpp): the reference's texel bytes
+            else:
+                img = Image.open(io.BytesIO(data)).convert("RGBA")    # "Source Images are always 4 channel 8bpp" (scene.cpp:1167); PNG is lossless
             if max_texture_size and max(img.size) > max_texture_size:
                 img = img.resize((max_texture_size, max_texture_size), Image.BOX)
             image_cache[image_index] = np.asarray(img, dtype=np.uint8).copy()

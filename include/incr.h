@@ -256,6 +256,14 @@ int  incr_unshard(incr_context* ctx, void* dst_full, const void* src_gathered, u
  */
 int      incr_generate_tangents(const float* positions, const float* normals, const float* uvs, const uint32_t* indices,
                                 uint32_t vertex_count, uint32_t triangle_count, float* out_tangents);
+/*
+ * The image decode of the glTF load (src/scene.cpp:40, 98-117: tinygltf::LoadImageData = stb_image, four components requested): JPEG files through the
+ * integer pipeline stb_image publishes -- baseline and progressive Huffman, the 12-bit "islow" IDCT, the 3:1 chroma up-sampling filters, 20-bit fixed-point
+ * YCbCr -> RGB -- so that texel BYTES are the reference's (libjpeg-turbo rounds 1-2 codes differently).  Host function.  Call with rgba = NULL to get the
+ * size, then with width x height x 4 bytes.  One- and three-component 8-bit files; anything else (CMYK, arithmetic coding, 12 bit) is INCR_ERR_INVALID_ARGUMENT.
+ * PNG needs no counterpart: it is lossless.
+ */
+int      incr_decode_jpeg(const uint8_t* bytes, size_t size, int32_t* width, int32_t* height, uint8_t* rgba, size_t capacity);
 /* MeshUtils::Meshletize (src/mesh-utils.cpp:640-835) as called by FScene::GenerateMeshlets (src/scene.cpp:503-560):
  * HOST-side load-time utility.  positions: vertex_count records of `position_stride_bytes` (>= 12) starting with xyz.
  * The returned set holds FGpuMeshlet ranges + bounding spheres (accessor/mesh/material fields are -1 for the caller to

@@ -29,6 +29,10 @@ PKG = "incarnation-renderer_amd"
 # Algorithmic bytes (SURVEY.md 8d / DESIGN.md "Measurement"): per traversal query 32 + ceil(log2 T)*32 + 36 + 16,
 # per shaded hit 378, per pixel-sample 24.
 B_HIT, B_PX = 378, 24
+# cycles a SIMD-32 spends issuing one wave64 vector instruction: the hardware guide's rate, and the slot cost measured on the traversal loop's mix at 7 waves per SIMD
+# (profiles/r05_issue_rate.txt)
+VALU_CYCLES_SIMD32 = 2.0
+VALU_CYCLES_MEASURED_MIX = 1.18
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
@@ -412,7 +416,7 @@ def main():
     packed.max_anisotropy = args.max_anisotropy
     if args.block_compress:
         packed.compress_textures()
-    importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
+    packed = importlib.import_module(PKG + ".raster").generate_meshlets(packed)       # FScene::GenerateMeshlets at load time
     view = sio.FView().reset(packed, aspect=W / H)
     ctx = rt.Context(local_rank)
     ctx.set_pathtrace_pipelines(max(0, min(args.pipelines, 8)))
@@ -546,10 +550,8 @@ def main():
         # extend makes the camera rays itself and shade sets its vertices' shadow rays up: the "generate" and "shadow_gen" intervals of rounds 1-2 are empty);
         # the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
         # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
-        per_kernel = {"incr::wf_generate_kernel": (prof.generate_ms, max(prof.frames, 1), rows * W * 64.0 * args.steps),
-                      "incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
+        per_kernel = {"incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
                       "incr::wf_shade_kernel": (prof.shade_ms, max(prof.launches[1], 1), float(ls[4]) * B_HIT),
-                      "incr::wf_shadow_gen_kernel": (prof.shadow_gen_ms, max(prof.launches[2], 1), float(ls[2] + ls[3]) * 32.0 + float(ls[4]) * 52.0),
                       "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3]) * b_ray),
                       "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[4], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
         # With more than one pipeline in flight the event intervals of the streaming kernels (generate, shade, shadow_gen, accumulate)
@@ -620,14 +622,22 @@ def main():
                 if entry and tj.get("kernel_source_hash") == kernel_source_hash() and default_workload and tj.get("pipelines") == int(prof.pipelines) and bool(tj.get("bounce_overlap", False)) == bool(prof.overlap):
                     out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tj.get("source")
-                    # the traversal kernels are VALU-issue bound: instructions per launch x 4 cycles per wave64
-                    # instruction / 1024 SIMDs against the elapsed cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs)
+                    # Vector-ALU issue of the dominant kernel, priced twice (round 5; rounds 2-4 priced a wave64 instruction at 4 cycles per SIMD -- what ONE wave sustains -- and
+                    # reported a utilisation above 1): against the SIMD-32 rate of the hardware guide (2 cycles per wave64 instruction) and against the slot cost
+                    # measured with the loop's own instruction mix at the kernel's occupancy (tools/microbench/issue_rate.hip, profiles/r05_issue_rate.txt).  Neither may
+                    # exceed 1: a fraction above 1 means the model is wrong, and the run fails.
                     if entry.get("SQ_INSTS_VALU_per_launch") and entry.get("GRBM_GUI_ACTIVE_per_launch"):
-                        issue = entry["SQ_INSTS_VALU_per_launch"] * 4.0 / 1024.0
-                        elapsed = entry["GRBM_GUI_ACTIVE_per_launch"] / 8.0
-                        out["roofline"]["valu"] = {"insts_per_launch": int(entry["SQ_INSTS_VALU_per_launch"]), "issue_cycles_per_simd": int(issue),
-                                                   "elapsed_cycles": int(elapsed), "frac": round(issue / elapsed, 4),
+                        insts_per_simd = entry["SQ_INSTS_VALU_per_launch"] / 1024.0
+                        elapsed = entry["GRBM_GUI_ACTIVE_per_launch"] / 8.0          # GRBM_GUI_ACTIVE sums the 8 XCDs
+                        frac_simd32 = insts_per_simd * VALU_CYCLES_SIMD32 / elapsed
+                        frac_measured = insts_per_simd * VALU_CYCLES_MEASURED_MIX / elapsed
+                        out["roofline"]["valu"] = {"insts_per_launch": int(entry["SQ_INSTS_VALU_per_launch"]), "elapsed_cycles": int(elapsed),
+                                                   "cycles_per_inst_simd32": VALU_CYCLES_SIMD32, "frac_simd32": round(frac_simd32, 4),
+                                                   "cycles_per_inst_measured": VALU_CYCLES_MEASURED_MIX, "frac_measured": round(frac_measured, 4),
+                                                   "measured_with": "tools/microbench/issue_rate.hip: the traversal loop's mix (cvt_ubyte, fma, min / max, cndmask) at 7 waves per SIMD, every CU loaded",
                                                    "lane_utilisation": round(entry.get("SQ_THREAD_CYCLES_VALU_per_launch", 0.0) / max(entry.get("SQ_ACTIVE_INST_VALU_per_launch", 1.0), 1.0) / 64.0, 4)}
+                        if max(frac_simd32, frac_measured) > 1.0:
+                            raise RuntimeError("roofline.valu: a vector-issue fraction above 1 (%.3f / %.3f): the issue model does not describe this kernel" % (frac_simd32, frac_measured))
                 else:
                     out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources, another workload or another pipeline count: not attached"
             except Exception:

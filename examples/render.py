@@ -139,7 +139,7 @@ def main():
     packed.max_anisotropy = a.max_anisotropy
     if a.block_compress:
         packed.compress_textures()
-    R.generate_meshlets(packed)
+    packed = R.generate_meshlets(packed)
 
     class Cfg(A.FConfig):
         EnableHBAO = a.hbao

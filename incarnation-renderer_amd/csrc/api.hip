@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "test_hooks.h"
 
 using namespace incr;
 
@@ -112,19 +113,19 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     // block-reduced atomic per workgroup, spread over 64 L2 lines) and a one-wave kernel folds them into the caller's stats
     HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
     HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
-    const char* rc = getenv("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
+    const char* rc = test_hook_env("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
     ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 12u;          // one queue for the four bounces of a path (6 rays per path on the bench scene)
-    const char* se = getenv("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
+    const char* se = test_hook_env("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
     ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0; ctx->wfStage = nullptr; ctx->wfStageBytes = 0;
     // pipelines of a path-traced frame (pathtrace_wf.hip): independent bands of tile rows on concurrent streams
-    const char* pe = getenv("INCR_WF_PIPELINES");
+    const char* pe = test_hook_env("INCR_WF_PIPELINES");
     ctx->wfPipesWanted = pe ? std::min(std::max(atoi(pe), 1), kMaxPipes) : INCR_WF_PIPELINES_DEFAULT;
     ctx->wfPipes = 1; memset(ctx->wfTileRow, 0, sizeof ctx->wfTileRow);
     memset(ctx->wfStreams, 0, sizeof ctx->wfStreams); memset(ctx->wfJoin, 0, sizeof ctx->wfJoin);
     memset(ctx->wfSideStreams, 0, sizeof ctx->wfSideStreams); memset(ctx->wfBounceFork, 0, sizeof ctx->wfBounceFork); memset(ctx->wfBounceJoin, 0, sizeof ctx->wfBounceJoin);
-    { const char* ap = getenv("INCR_WF_ACC_PLACEMENT"); ctx->wfAccPlacement = ap ? std::min(std::max(atoi(ap), -1), 1) : -1; }
-    { const char* ov = getenv("INCR_WF_OVERLAP"); ctx->wfOverlap = ov ? atoi(ov) != 0 : true; }          // bounce overlap (pathtrace_wf.hip launcher), incr_set_pathtrace_overlap
+    { const char* ap = test_hook_env("INCR_WF_ACC_PLACEMENT"); ctx->wfAccPlacement = ap ? std::min(std::max(atoi(ap), -1), 1) : -1; }
+    { const char* ov = test_hook_env("INCR_WF_OVERLAP"); ctx->wfOverlap = ov ? atoi(ov) != 0 : true; }          // bounce overlap (pathtrace_wf.hip launcher), incr_set_pathtrace_overlap
     HIP_TRY(hipEventCreateWithFlags(&ctx->wfFork, hipEventDisableTiming));      // the pipelines' own streams are created on first use
     ctx->profiling = false; ctx->profFrames = 0;
     ctx->rasterBlock = nullptr; ctx->rasterBytes = 0; ctx->rasterCounters = nullptr;
@@ -378,7 +379,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     incr_scene* sc = new (std::nothrow) incr_scene();
     if (!sc) return fail(INCR_ERR_OUT_OF_MEMORY, "host allocation failed");
     sc->ctx = ctx;
-    struct Lap { const bool on = getenv("INCR_SCENE_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    struct Lap { const bool on = test_hook_env("INCR_SCENE_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                  void operator()(const char* what) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  incr_scene_create %-26s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } } lap;
     copy_scene_desc(*desc, sc->host);
     lap("copy of the desc");
@@ -536,7 +537,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     }
     // Interleaved level-0 texels per material for the path tracer's chsMain (device_types.h MaterialTexels), from the row-major level 0
     std::vector<MaterialTexels> mtex(desc->num_materials, MaterialTexels{nullptr, 0u, 0u, 0u, 0u, nullptr});
-    const bool fuseMaterials = !(getenv("INCR_MATERIAL_TEXELS") && atoi(getenv("INCR_MATERIAL_TEXELS")) == 0);      // A/B hook
+    const bool fuseMaterials = !(test_hook_env("INCR_MATERIAL_TEXELS") && atoi(test_hook_env("INCR_MATERIAL_TEXELS")) == 0);      // A/B hook
     for (uint32_t mi = 0; mi < desc->num_materials && !rc && fuseMaterials; ++mi) {
         const int32_t bt = desc->materials[mi].baseColorTextureIndex, nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
         if (bt < 0 || nt < 0 || mt < 0) continue;
@@ -581,7 +582,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
         T.texels = (const uint8_t*)d;
     }
     // The same interleave for the whole TILED chain (MaterialTexels::chain): the raster passes' Sample of a material's three maps reads it
-    const bool fuseChains = !(getenv("INCR_MATERIAL_CHAINS") && atoi(getenv("INCR_MATERIAL_CHAINS")) == 0);      // A/B hook
+    const bool fuseChains = !(test_hook_env("INCR_MATERIAL_CHAINS") && atoi(test_hook_env("INCR_MATERIAL_CHAINS")) == 0);      // A/B hook
     for (uint32_t mi = 0; mi < desc->num_materials && !rc && fuseChains; ++mi) {
         if (!mtex[mi].texels || mtex[mi].baseFormat != INCR_TEX_RGBA8_SRGB) continue;
         const int32_t bt = desc->materials[mi].baseColorTextureIndex, nt = desc->materials[mi].normalTextureIndex, mt = desc->materials[mi].metallicRoughnessTextureIndex;
@@ -604,7 +605,7 @@ int incr_scene_create(incr_context* ctx, const incr_scene_desc* desc, incr_scene
     if (!rc) rc = upload_vec(&sc->dMaterialTexels, mtex.data(), mtex.size());
     // Alpha quads of the textures the visibility scan alpha-tests against (RGBA8 with an alpha that is not 255 everywhere)
     std::vector<const uint32_t*> quads(desc->num_textures, nullptr);
-    const bool alphaQuads = !(getenv("INCR_ALPHA_QUADS") && atoi(getenv("INCR_ALPHA_QUADS")) == 0);      // A/B hook
+    const bool alphaQuads = !(test_hook_env("INCR_ALPHA_QUADS") && atoi(test_hook_env("INCR_ALPHA_QUADS")) == 0);      // A/B hook
     for (uint32_t i = 0; i < desc->num_textures && !rc && alphaQuads; ++i) {
         const DeviceTexture& T = texs[i];
         if ((T.format != INCR_TEX_RGBA8_SRGB && T.format != INCR_TEX_RGBA8_UNORM) || T.pad[0] || !T.pad[1]) continue;

@@ -25,8 +25,18 @@ __global__ __launch_bounds__(256) void downsample2d_kernel(const uint32_t* __res
     const f3 c = unpack_r11g11b10(src[(size_t)(2 * y + 1) * srcW + 2 * x]), d = unpack_r11g11b10(src[(size_t)(2 * y + 1) * srcW + 2 * x + 1]);
     dst[(size_t)y * dstW + x] = pack_r11g11b10(0.25f * (((a + b) + c) + d), rounding);
 }
-// content-pipeline/cubemapgen.hlsl:19-121, one level
-__global__ __launch_bounds__(256) void cubemapgen_kernel(const uint32_t* __restrict__ latlong, uint32_t llW, uint32_t llH, uint32_t* __restrict__ cube, uint32_t n, int rounding) {
+// DirectX::GenerateMipMaps(TEX_FILTER_LINEAR) on the RGBA32F lat-long of an HDRI (demo.cpp:318-320): a 2:1 level is the bilinear tap half way between four texels, weights
+// 1/2 per axis, rows first -- (a/2 + b/2)/2 + (c/2 + d/2)/2 (every halving exact, two roundings); alpha rides along
+__global__ __launch_bounds__(256) void downsample2d_f32_kernel(const float4* __restrict__ src, uint32_t srcW, float4* __restrict__ dst, uint32_t dstW, uint32_t dstH) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dstW || y >= dstH) return;
+    const float4 a = src[(size_t)(2 * y) * srcW + 2 * x], b = src[(size_t)(2 * y) * srcW + 2 * x + 1], c = src[(size_t)(2 * y + 1) * srcW + 2 * x], d = src[(size_t)(2 * y + 1) * srcW + 2 * x + 1];
+    dst[(size_t)y * dstW + x] = make_float4(0.5f * (0.5f * a.x + 0.5f * b.x) + 0.5f * (0.5f * c.x + 0.5f * d.x), 0.5f * (0.5f * a.y + 0.5f * b.y) + 0.5f * (0.5f * c.y + 0.5f * d.y),
+                                            0.5f * (0.5f * a.z + 0.5f * b.z) + 0.5f * (0.5f * c.z + 0.5f * d.z), 0.5f * (0.5f * a.w + 0.5f * b.w) + 0.5f * (0.5f * c.w + 0.5f * d.w));
+}
+// content-pipeline/cubemapgen.hlsl:19-121, one level; TEXEL = uint32_t (R11G11B10: the dynamic sky) or float4 (RGBA32F: an HDRI)
+template <class TEXEL>
+__global__ __launch_bounds__(256) void cubemapgen_kernel(const TEXEL* __restrict__ latlong, uint32_t llW, uint32_t llH, uint32_t* __restrict__ cube, uint32_t n, int rounding) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= n || y >= n) return;
     const float ftx[6] = {K_PI_OVER_2, -K_PI_OVER_2, 0.f, 0.f, 0.f, K_PI}, fty[6] = {0.f, 0.f, K_PI_OVER_2, -K_PI_OVER_2, 0.f, 0.f};
@@ -59,12 +69,12 @@ DI f3 GetEnvDir(uint32_t face, f2 uv) {                              // split-su
     default: return normalize(mk3(-vx, vy, -1.f));
     }
 }
-// split-sum-approx/prefilter.hlsl:43-95, one level, all six faces (blockIdx.z = face)
-__global__ __launch_bounds__(256) void prefilter_kernel(const CubeChain src, uint32_t level, uint32_t* __restrict__ dst, uint32_t sampleCount, float roughness, int rounding) {
-    const uint32_t mipSize = mip_dim(src.N, level);
+// split-sum-approx/prefilter.hlsl:43-95, one level, all six faces (blockIdx.z = face).  mipSize / cubemapSize are the shader's root constants: the OUTPUT level's size and
+// the output cube's size (renderer.cpp:504-526) -- the dynamic sky filters into a cube of the source's size, CacheHDRI into one of half the size (demo.cpp:357-369)
+__global__ __launch_bounds__(256) void prefilter_kernel(const CubeChain src, uint32_t mipSize, uint32_t cubemapSize, uint32_t* __restrict__ dst, uint32_t sampleCount, float roughness, int rounding) {
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15u), y = blockIdx.y * 16 + (threadIdx.x >> 4), face = blockIdx.z;
     if (x >= mipSize || y >= mipSize) return;
-    const float Resolution = (float)src.N;
+    const float Resolution = (float)cubemapSize;
     const f3 R = GetEnvDir(face, {(float)x / (float)mipSize, (float)y / (float)mipSize});
     const f3 N = R, V = R;
     const f3 up = fabsf(N.z) < 0.999f ? mk3(0.f, 0.f, 1.f) : mk3(1.f, 0.f, 0.f);       // TangentToWorld (common/math.hlsli:82-89)
@@ -90,7 +100,8 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const CubeChain src, uin
     dst[((size_t)face * mipSize + y) * mipSize + x] = pack_r11g11b10(color / totalWeight, rounding);
 }
 // spherical-harmonics/projection.hlsl:17-49 (blockIdx.z unused: one lane writes the nine coefficient slices)
-__global__ __launch_bounds__(256) void sh_project_kernel(const uint32_t* __restrict__ latlong, uint32_t W, uint32_t H, float4* __restrict__ out) {
+template <class TEXEL>
+__global__ __launch_bounds__(256) void sh_project_kernel(const TEXEL* __restrict__ latlong, uint32_t W, uint32_t H, float4* __restrict__ out) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float K[9] = {0.282095f, 0.488603f, 0.488603f, 0.488603f, 1.092548f, 1.092548f, 0.315392f, 1.092548f, 0.546274f};
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void sh_project_kernel(const uint32_t* __restr
     float b[9];
     b[0] = K[0]; b[1] = K[1] * dir.y; b[2] = K[2] * dir.z; b[3] = K[3] * dir.x;
     b[4] = (K[4] * dir.x) * dir.y; b[5] = (K[5] * dir.y) * dir.z; b[6] = K[6] * ((3.0f * dir.z) * dir.z - 1.0f); b[7] = (K[7] * dir.x) * dir.z; b[8] = K[8] * (dir.x * dir.x - dir.y * dir.y);
-    const f3 rad = unpack_r11g11b10(latlong[(size_t)y * W + x]);
+    const f3 rad = load_radiance(latlong, (size_t)y * W + x);          // (an RGBA32F HDRI carries alpha 1, as a Load of R11G11B10 returns: the fourth channel is the same)
     const float sint = sinf(K_PI * uv.y), dTheta = K_PI / (float)H, dPhi = 2.f * K_PI / (float)W;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -152,6 +163,17 @@ __global__ __launch_bounds__(256) void env_brdf_kernel(uint32_t* __restrict__ ou
 using namespace incr;
 static inline dim3 grid64x4(uint32_t W, uint32_t H) { return dim3((W + 63) / 64, (H + 3) / 4); }
 
+// ShEncode behind the projection (renderer.cpp:533-800): 2 x 2 sums level after level, then the export of the last two texels
+static void sh_reduce_and_export(float4* shScratch, uint32_t W, uint32_t H, uint32_t shMips, float4* sh9, hipStream_t stream) {
+    uint32_t sw = W, sh = H; size_t off = 0;
+    for (uint32_t m = 0; m + 1 < shMips; ++m) {
+        const uint32_t dw = std::max(W >> (m + 1), 1u), dh = std::max(H >> (m + 1), 1u);
+        const size_t next = off + (size_t)sw * sh * 9;
+        hipLaunchKernelGGL(sh_reduce_kernel, dim3((dw + 7) / 8, (dh + 7) / 8, 9), dim3(64), 0, stream, shScratch + off, sw, sh, shScratch + next, dw, dh);
+        off = next; sw = dw; sh = dh;
+    }
+    hipLaunchKernelGGL(sh_export_kernel, dim3(1), dim3(64), 0, stream, shScratch + off, sw, sh, sh9);
+}
 // FScene::UpdateDynamicSky: the whole chain on one stream.  `shScratch` holds the SH projection mip chain.
 extern "C" hipError_t incr_launch_update_dynamic_sky(const IblParams* p, hipStream_t stream) {
     const uint32_t N = p->cubemapRes, W = 2 * N, H = N, mips = p->mips;
@@ -163,26 +185,42 @@ extern "C" hipError_t incr_launch_update_dynamic_sky(const IblParams* p, hipStre
     }
     for (uint32_t m = 0; m < mips; ++m) {         // renderer.cpp:450-466
         const uint32_t n = std::max(N >> m, 1u);
-        hipLaunchKernelGGL(cubemapgen_kernel, grid64x4(n, n), dim3(256), 0, stream, p->latlong + p->latlongOffset[m], std::max(W >> m, 1u), std::max(H >> m, 1u),
+        hipLaunchKernelGGL(cubemapgen_kernel<uint32_t>, grid64x4(n, n), dim3(256), 0, stream, (const uint32_t*)(p->latlong + p->latlongOffset[m]), std::max(W >> m, 1u), std::max(H >> m, 1u),
                            p->srcCube + p->cubeOffset[m], n, p->rounding);
     }
     const CubeChain src = {N, mips, p->srcCube};
     for (uint32_t m = 0; m < mips; ++m) {         // renderer.cpp:504-526
         const uint32_t n = std::max(N >> m, 1u);
-        hipLaunchKernelGGL(prefilter_kernel, dim3((n + 15) / 16, (n + 15) / 16, 6), dim3(256), 0, stream, src, m, p->envmap + p->cubeOffset[m], p->sampleCount,
+        hipLaunchKernelGGL(prefilter_kernel, dim3((n + 15) / 16, (n + 15) / 16, 6), dim3(256), 0, stream, src, n, N, p->envmap + p->cubeOffset[m], p->sampleCount,
                            (float)m / (float)mips, p->rounding);
     }
     // ShEncode (renderer.cpp:533-800)
-    hipLaunchKernelGGL(sh_project_kernel, grid64x4(W, H), dim3(256), 0, stream, p->latlong, W, H, p->shScratch);
-    const uint32_t shMips = p->shMips;
-    uint32_t sw = W, sh = H; size_t off = 0;
-    for (uint32_t m = 0; m + 1 < shMips; ++m) {
-        const uint32_t dw = std::max(W >> (m + 1), 1u), dh = std::max(H >> (m + 1), 1u);
-        const size_t next = off + (size_t)sw * sh * 9;
-        hipLaunchKernelGGL(sh_reduce_kernel, dim3((dw + 7) / 8, (dh + 7) / 8, 9), dim3(64), 0, stream, p->shScratch + off, sw, sh, p->shScratch + next, dw, dh);
-        off = next; sw = dw; sh = dh;
+    hipLaunchKernelGGL(sh_project_kernel<uint32_t>, grid64x4(W, H), dim3(256), 0, stream, (const uint32_t*)p->latlong, W, H, p->shScratch);
+    sh_reduce_and_export(p->shScratch, W, H, p->shMips, p->sh9, stream);
+    return hipGetLastError();
+}
+// FTextureCache::CacheHDRI (src/demo.cpp:292-434) behind the file read: RGBA32F lat-long (W x H = 2N x N) -> `mips` = CalcMipCount(W, H, true) levels -> an N^2 source cube of as many
+// levels (level m from lat-long level m) -> the prefiltered cube of HALF the size with one level fewer, roughness m / (mips - 1) -> SH9 from level 0 of the lat-long.
+extern "C" hipError_t incr_launch_cache_hdri(const HdriParams* p, hipStream_t stream) {
+    const uint32_t N = p->cubemapRes, W = p->width, H = p->height, mips = p->mips;
+    for (uint32_t m = 1; m < mips; ++m) {
+        const uint32_t dw = std::max(W >> m, 1u), dh = std::max(H >> m, 1u);
+        hipLaunchKernelGGL(downsample2d_f32_kernel, grid64x4(dw, dh), dim3(256), 0, stream, p->latlong + p->latlongOffset[m - 1], std::max(W >> (m - 1), 1u), p->latlong + p->latlongOffset[m], dw, dh);
     }
-    hipLaunchKernelGGL(sh_export_kernel, dim3(1), dim3(64), 0, stream, p->shScratch + off, sw, sh, p->sh9);
+    for (uint32_t m = 0; m < mips; ++m) {         // renderer.cpp:450-466
+        const uint32_t n = std::max(N >> m, 1u);
+        hipLaunchKernelGGL(cubemapgen_kernel<float4>, grid64x4(n, n), dim3(256), 0, stream, (const float4*)(p->latlong + p->latlongOffset[m]), std::max(W >> m, 1u), std::max(H >> m, 1u),
+                           p->srcCube + p->cubeOffset[m], n, p->rounding);
+    }
+    const CubeChain src = {N, mips, p->srcCube};
+    const uint32_t envN = N >> 1, envMips = mips - 1;
+    for (uint32_t m = 0; m < envMips; ++m) {      // demo.cpp:357-369 -> renderer.cpp:504-526: cubemapRes = filteredEnvmapSize, numMips = filteredEnvmapMips
+        const uint32_t n = envN >> m;
+        hipLaunchKernelGGL(prefilter_kernel, dim3((n + 15) / 16, (n + 15) / 16, 6), dim3(256), 0, stream, src, n, envN, p->envmap + p->envOffset[m], p->sampleCount,
+                           (float)m / (float)envMips, p->rounding);
+    }
+    hipLaunchKernelGGL(sh_project_kernel<float4>, grid64x4(W, H), dim3(256), 0, stream, (const float4*)p->latlong, W, H, p->shScratch);      // demo.cpp:398: from the source image
+    sh_reduce_and_export(p->shScratch, W, H, p->shMips, p->sh9, stream);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_env_brdf(uint32_t* out, uint32_t W, uint32_t H, uint32_t numSamples, int rounding, hipStream_t stream) {

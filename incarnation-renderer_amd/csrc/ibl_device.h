@@ -28,6 +28,24 @@ DI f3 sample2d_bilinear_wrap(const uint32_t* __restrict__ img, uint32_t W, uint3
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
 }
 
+// the same tap on an R32G32B32A32_FLOAT level (the Radiance HDRI of FTextureCache::CacheHDRI: DirectX::LoadFromHDRFile decodes to RGBA32F)
+DI f3 sample2d_bilinear_wrap(const float4* __restrict__ img, uint32_t W, uint32_t H, f2 uv) {
+    float u = uv.x - floorf(uv.x), v = uv.y - floorf(uv.y);
+    if (!(u >= 0.f && u <= 1.f)) u = 0.f;
+    if (!(v >= 0.f && v <= 1.f)) v = 0.f;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    x0 = x0 < 0 ? x0 + (int)W : x0; y0 = y0 < 0 ? y0 + (int)H : y0;
+    const int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
+    const float4 a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1], c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
+    const f3 t00 = {a.x, a.y, a.z}, t10 = {b.x, b.y, b.z}, t01 = {c.x, c.y, c.z}, t11 = {d.x, d.y, d.z};
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
+}
+DI f3 load_radiance(const uint32_t* __restrict__ img, size_t i) { return unpack_r11g11b10(img[i]); }
+DI f3 load_radiance(const float4* __restrict__ img, size_t i) { const float4 t = img[i]; return {t.x, t.y, t.z}; }
+
 DI void cube_face_uv(f3 d, uint32_t* face, float* u, float* v) {
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     float sc, tc, ma;

@@ -21,4 +21,15 @@ struct IblParams {
     size_t latlongOffset[kMaxEnvMips], cubeOffset[kMaxEnvMips];
 };
 
+// FTextureCache::CacheHDRI (ibl.hip incr_launch_cache_hdri)
+struct HdriParams {
+    uint32_t width, height, cubemapRes, mips, shMips, sampleCount;      // lat-long W x H (RGBA32F), source cube N = H, CalcMipCount(W, H, true) levels
+    int32_t rounding;
+    float4* latlong;              // all levels packed; level 0 uploaded by the caller
+    uint32_t* srcCube;            // N^2 x 6, `mips` levels
+    uint32_t* envmap;             // (N / 2)^2 x 6, `mips - 1` levels: FLightProbe::m_envmapTextureIndex
+    float4* shScratch; float4* sh9;
+    size_t latlongOffset[kMaxEnvMips], cubeOffset[kMaxEnvMips], envOffset[kMaxEnvMips];
+};
+
 } // namespace incr

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "test_hooks.h"
 
 using namespace incr;
 
@@ -246,7 +247,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws, size_t prims = 0) {
     size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
     // test hook: a tiny band queue forces the overflow path (large triangles scanned whole by one wave)
-    if (const char* cap = pixels ? getenv("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
+    if (const char* cap = pixels ? test_hook_env("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
     const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
@@ -473,7 +474,7 @@ int incr_gbuffer_decals(incr_context* ctx, const incr_gbuffer_decals_desc* d, in
     P.recs = ws.recs; P.numSlots = (uint32_t)slots;
     P.listCap = 1024;
     // test hook: a small tile list forces flushes in the middle of the slot walk (the blend order must survive them)
-    if (const char* cap = getenv("INCR_DECAL_LIST_CAP")) { const unsigned long v = strtoul(cap, nullptr, 10); P.listCap = v < 256 ? 256u : (v > 1024 ? 1024u : (uint32_t)v); }
+    if (const char* cap = test_hook_env("INCR_DECAL_LIST_CAP")) { const unsigned long v = strtoul(cap, nullptr, 10); P.listCap = v < 256 ? 256u : (v > 1024 ? 1024u : (uint32_t)v); }
     HIP_TRY(incr_launch_decals(&P, ctx->props.multiProcessorCount, (hipStream_t)stream));
     return INCR_OK;
 }

@@ -2,6 +2,7 @@
 // See scene_build.h.  Compiled with -ffp-contract=off: the world-space vertex positions are part of the
 // parity contract (tests compare hit t/u/v bit for bit against the oracle's flattening).
 #include "scene_build.h"
+#include "test_hooks.h"
 
 #include <algorithm>
 #include <chrono>
@@ -388,7 +389,7 @@ static void reorder_best_first(WideTree& W) {
 // the binary one.
 static void build_wide_subtree(const Box* tb, const V3* cen, uint32_t first, uint32_t count, uint32_t depthBudget, WideTree& W) {
     uint32_t depthLimit = depthBudget;
-    if (const char* e = getenv("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
+    if (const char* e = test_hook_env("INCR_BVH_DEPTH_LIMIT")) depthLimit = std::min<uint32_t>(depthLimit, (uint32_t)std::max(atoi(e), 1));      // test hook: exercises the rebuilds on ordinary scenes
     box_reset(W.box);
     for (const uint32_t sahDepth : {48u, 12u, 0u}) {
         Builder b(tb, cen, first, count);
@@ -556,7 +557,7 @@ template <class F> void parallel_for(size_t count, size_t grain, F&& fn) {
     for (std::thread& t : th) t.join();
 }
 struct StageTimer {          // INCR_SCENE_TIMING=1: wall time of the stages of build_world_bvh on stderr (tools/scene_create_time.py)
-    const bool on = getenv("INCR_SCENE_TIMING") != nullptr;
+    const bool on = test_hook_env("INCR_SCENE_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char* what) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  build_world_bvh %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
 };

@@ -272,7 +272,9 @@ class DeferredLightingDesc(C.Structure):
 class SkyIblInfo(C.Structure):
     _fields_ = [("cubemap_res", C.c_uint32), ("num_mips", C.c_uint32), ("latlong_r11g11b10", C.c_void_p),
                 ("source_cube_r11g11b10", C.c_void_p), ("envmap_r11g11b10", C.c_void_p), ("sh9_rgba", C.c_void_p),
-                ("latlong_texels", C.c_uint64), ("cube_texels", C.c_uint64)]
+                ("latlong_texels", C.c_uint64), ("cube_texels", C.c_uint64),
+                ("latlong_rgba32f", C.c_void_p), ("latlong_width", C.c_uint32), ("latlong_height", C.c_uint32),
+                ("source_cube_res", C.c_uint32), ("source_cube_mips", C.c_uint32)]
 
 
 class RendererScene(C.Structure):

@@ -16,7 +16,8 @@ MAX_MESHLET_PRIMS = 126
 
 def generate_meshlets(scene, max_verts=MAX_MESHLET_VERTS, max_prims=MAX_MESHLET_PRIMS):
     """FScene::GenerateMeshlets + the meshlet packing of CreateGpuGeometryBuffers (scene.cpp:1488-1558, 503-560):
-    meshletize every primitive with the host utility of the HIP library and pack mesh -> primitive -> meshlet."""
+    meshletize every primitive with the host utility of the HIP library and pack mesh -> primitive -> meshlet.
+    Returns a copy of `scene` that carries the meshlets (the arrays of `scene` are shared, never replaced)."""
     lib = rt.load()
     meshlets, vert_lists, tri_lists = [], [], []
     vbase = tbase = 0
@@ -56,9 +57,13 @@ def generate_meshlets(scene, max_verts=MAX_MESHLET_VERTS, max_prims=MAX_MESHLET_
         C.memmove(C.byref(arr, i * C.sizeof(A.GpuMeshlet)), C.byref(m), C.sizeof(A.GpuMeshlet))
     vi = np.concatenate(vert_lists) if vert_lists else np.zeros(0, np.uint32)
     tri = np.concatenate(tri_lists) if tri_lists else np.zeros(0, np.uint32)
-    scene.meshlets = (arr, np.ascontiguousarray(vi, dtype=np.uint32), np.ascontiguousarray(tri, dtype=np.uint32))
-    scene.num_meshlets = len(meshlets)
-    return scene
+    # A NEW scene object: the caller's scene and everything built from it (a GPU scene, an oracle scene that borrows its arrays by pointer) stay as they were
+    import copy
+    out = copy.copy(scene)
+    out._keep, out._desc = [], None
+    out.meshlets = (arr, np.ascontiguousarray(vi, dtype=np.uint32), np.ascontiguousarray(tri, dtype=np.uint32))
+    out.num_meshlets = len(meshlets)
+    return out
 
 
 def pixel_jitter(frame_index, res_x, res_y):

@@ -33,7 +33,7 @@ EXPORTS = [
     "incr_renderer_reset_accumulation", "incr_renderer_last_error", "incr_renderer_surface",
     "incr_renderer_set_band", "incr_renderer_tonemap", "incr_visibility_get_stats", "incr_renderer_get_stats", "incr_renderer_get_frame_info", "incr_renderer_tick", "incr_renderer_set_profiling", "incr_renderer_get_pass_times",
     # sky / IBL precompute
-    "incr_update_dynamic_sky", "incr_sky_ibl_get_info", "incr_sky_ibl_destroy", "incr_generate_env_brdf",
+    "incr_update_dynamic_sky", "incr_cache_hdri", "incr_decode_hdr", "incr_sky_ibl_get_info", "incr_sky_ibl_destroy", "incr_generate_env_brdf",
     # texture ingest, GPU step
     "incr_compressed_mip_count", "incr_mip_chain_texels", "incr_prefilter_normal_roughness",
 ]
@@ -137,6 +137,8 @@ def load():
     L.incr_visibility_get_stats.restype = C.c_int; L.incr_visibility_get_stats.argtypes = [vp, C.POINTER(u32)]
     L.incr_update_dynamic_sky.restype = C.c_int; L.incr_update_dynamic_sky.argtypes = [vp, vp, u32, C.c_float, C.c_int32, vp, C.POINTER(vp)]
     L.incr_sky_ibl_get_info.restype = C.c_int; L.incr_sky_ibl_get_info.argtypes = [vp, C.POINTER(A.SkyIblInfo)]
+    L.incr_cache_hdri.restype = C.c_int; L.incr_cache_hdri.argtypes = [vp, vp, C.c_size_t, C.c_int32, vp, C.POINTER(C.c_void_p)]
+    L.incr_decode_hdr.restype = C.c_int; L.incr_decode_hdr.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, C.c_size_t]
     L.incr_sky_ibl_destroy.restype = C.c_int; L.incr_sky_ibl_destroy.argtypes = [vp, vp]
     L.incr_generate_env_brdf.restype = C.c_int; L.incr_generate_env_brdf.argtypes = [vp, u32, u32, C.c_int32, vp, vp]
     L.incr_compressed_mip_count.restype = u32; L.incr_compressed_mip_count.argtypes = [u32, u32]

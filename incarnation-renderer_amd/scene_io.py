@@ -324,6 +324,7 @@ class PackedScene:
             d.num_decal_primitives = len(dps)
             d.decal_primitives = C.cast(arr(A.GpuPrimitive, dps), C.POINTER(A.GpuPrimitive))
             d.decal_transforms = C.cast(arr(A.Matrix, [to_matrix(m) for _, m in self.decal_primitives]), C.POINTER(A.Matrix))
+        d._keep = keep          # whoever holds the descriptor holds the arrays its pointers name (a later to_desc() makes new ones)
         self._desc = d
         return d
 

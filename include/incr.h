@@ -596,10 +596,24 @@ typedef struct incr_sky_ibl_info {
     const uint32_t* source_cube_r11g11b10;      /* device: unfiltered cube, all levels */
     const uint32_t* envmap_r11g11b10;           /* device: prefiltered cube = FScene::m_dynamicSkyEnvmap, all levels */
     const float*    sh9_rgba;                   /* device: 9 x float4 = FScene::m_dynamicSkySH */
-    uint64_t latlong_texels, cube_texels;       /* texels over all levels */
+    uint64_t latlong_texels, cube_texels;       /* texels over all levels (of the lat-long, of the prefiltered cube) */
+    /* round 5 (appended: the fields above keep their offsets).  incr_cache_hdri: the lat-long is the decoded RGBA32F picture (latlong_r11g11b10 is NULL), the source
+     * cube is latlong_height^2 with CalcMipCount(w, h, true) levels and the prefiltered cube half its size with one level fewer; for the dynamic sky these repeat the above. */
+    const float*    latlong_rgba32f;            /* device: latlong_width x latlong_height x RGBA32F, all levels; NULL for the dynamic sky */
+    uint32_t latlong_width, latlong_height;
+    uint32_t source_cube_res, source_cube_mips;
 } incr_sky_ibl_info;
 int incr_update_dynamic_sky(incr_context* ctx, const incr_scene* scene, uint32_t envmap_resolution, float turbidity, int32_t storage_rounding,
                             incr_stream stream, incr_sky_ibl** inout_ibl);
+/*
+ * FTextureCache::CacheHDRI (src/demo.cpp:292-434), the light probe of EnvSkyMode::HDRI (FScene::ReloadEnvironment, src/scene.cpp:219-226): a Radiance .hdr lat-long
+ * picture (DirectX::LoadFromHDRFile -> RGBA32F) -> GenerateMipMaps(TEX_FILTER_LINEAR) down to 4 x 4 -> ConvertLatlong2Cubemap at size = picture height ->
+ * PrefilterCubemap at half that size with one level fewer (roughness = level / levels) -> ShEncode from the source picture.  `hdr_file` = the file's bytes (host);
+ * the products are those of incr_update_dynamic_sky: envmap_r11g11b10 = FLightProbe::m_envmapTextureIndex, sh9_rgba = m_shTextureIndex.  2:1 pictures with a
+ * power-of-two height.  incr_decode_hdr: the reader alone (host; rgba = NULL returns the size).
+ */
+int incr_cache_hdri(incr_context* ctx, const uint8_t* hdr_file, size_t size, int32_t storage_rounding, incr_stream stream, incr_sky_ibl** out_ibl);
+int incr_decode_hdr(const uint8_t* bytes, size_t size, int32_t* width, int32_t* height, float* rgba, size_t capacity_floats);
 int incr_sky_ibl_get_info(const incr_sky_ibl* ibl, incr_sky_ibl_info* out_info);
 int incr_sky_ibl_destroy(incr_context* ctx, incr_sky_ibl* ibl);
 /* Renderer::GenerateEnvBrdfTexture (src/renderer.cpp:169-245; split-sum-approx/brdf-integration.hlsl): R16G16_FLOAT LUT,

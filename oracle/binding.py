@@ -80,6 +80,8 @@ def lib():
         # sky / IBL precompute (oracle_ibl.h)
         L.orc_ibl_sizes.restype = C.c_uint64; L.orc_ibl_sizes.argtypes = [u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_update_dynamic_sky.argtypes = [fp, C.c_float, u32, u32, C.c_int, vp, vp, vp, vp]
+        L.orc_hdri_sizes.restype = C.c_uint64; L.orc_hdri_sizes.argtypes = [u32, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_cache_hdri.argtypes = [vp, u32, u32, u32, C.c_int, vp, vp, vp]
         L.orc_env_brdf.argtypes = [u32, u32, u32, vp, C.c_int]
         L.orc_cube_sample.argtypes = [vp, u32, u32, fp, C.c_float, fp]
         # texture ingest (oracle_content.cpp)
@@ -127,11 +129,13 @@ def _fa(vals):
 
 
 class OracleScene:
-    """Oracle-side scene: borrows the PackedScene's host arrays."""
+    """Oracle-side scene: borrows the PackedScene's host arrays by raw pointer, so it holds references to every one of them for as long as it lives (the
+    descriptor's own keep-alive list plus the scene's buffers, textures and meshlet arrays as they were when it was made)."""
 
     def __init__(self, packed_scene):
         self.packed = packed_scene
         self.desc = packed_scene.to_desc()
+        self._borrowed = (list(self.desc._keep), list(packed_scene.buffers), [t[0] for t in packed_scene.textures], packed_scene.meshlets)
         self.handle = lib().orc_scene_create(C.byref(self.desc))
 
     def close(self):
@@ -306,6 +310,18 @@ def update_dynamic_sky(sun_dir, turbidity=2.0, resolution=256, sample_count=1024
                sh9=np.zeros((9, 4), np.float32), mips=int(mips))
     lib().orc_update_dynamic_sky(_fa(sun_dir), turbidity, resolution, sample_count, rounding, out["latlong"].ctypes.data, out["source_cube"].ctypes.data,
                                  out["envmap"].ctypes.data, out["sh9"].ctypes.data)
+    return out
+
+
+def cache_hdri(rgba, sample_count=1024, rounding=0):
+    """FTextureCache::CacheHDRI behind the file read on the CPU: rgba = (H, W, 4) float32 lat-long picture (W = 2 H).
+    dict(latlong: all levels (texels, 4) f32; source_cube, envmap: packed u32 level chains; sh9: 9x4 f32; mips = source levels)."""
+    H, W = rgba.shape[:2]
+    ll, sc, en = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    mips = lib().orc_hdri_sizes(W, H, C.byref(ll), C.byref(sc), C.byref(en))
+    out = dict(latlong=np.zeros((ll.value, 4), np.float32), source_cube=np.zeros(sc.value, np.uint32), envmap=np.zeros(en.value, np.uint32), sh9=np.zeros((9, 4), np.float32), mips=int(mips))
+    out["latlong"][:W * H] = np.ascontiguousarray(rgba, np.float32).reshape(-1, 4)
+    lib().orc_cache_hdri(out["latlong"].ctypes.data, W, H, sample_count, rounding, out["source_cube"].ctypes.data, out["envmap"].ctypes.data, out["sh9"].ctypes.data)
     return out
 
 

@@ -16,7 +16,11 @@ static inline size_t mip_offset_2d(uint32_t W, uint32_t H, uint32_t level) { siz
 static inline size_t mip_offset_cube(uint32_t N, uint32_t level) { size_t o = 0; for (uint32_t k = 0; k < level; ++k) o += (size_t)6 * std::max(N >> k, 1u) * std::max(N >> k, 1u); return o; }
 static inline uint32_t mip_count(uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 1 && h >= 1) { ++n; w >>= 1; h >>= 1; } return n; }   // RenderUtils12::CalcMipCount
 
-static float3 sample2d_bilinear_wrap(const uint32_t* img, uint32_t W, uint32_t H, float2 uv) {
+struct float4f { float x, y, z, w; };          // an RGBA32F texel (the decoded Radiance picture of FTextureCache::CacheHDRI)
+static inline float3 load_radiance(const uint32_t* img, size_t i) { return unpack_r11g11b10(img[i]); }
+static inline float3 load_radiance(const float4f* img, size_t i) { return {img[i].x, img[i].y, img[i].z}; }
+template <class TEXEL>
+static float3 sample2d_bilinear_wrap(const TEXEL* img, uint32_t W, uint32_t H, float2 uv) {
     float u = uv.x - floorf(uv.x), v = uv.y - floorf(uv.y);
     if (!(u >= 0.f && u <= 1.f)) u = 0.f;
     if (!(v >= 0.f && v <= 1.f)) v = 0.f;
@@ -24,8 +28,8 @@ static float3 sample2d_bilinear_wrap(const uint32_t* img, uint32_t W, uint32_t H
     const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
     const int x0 = (((int)x0f % (int)W) + (int)W) % (int)W, y0 = (((int)y0f % (int)H) + (int)H) % (int)H;
     const int x1 = (x0 + 1) % (int)W, y1 = (y0 + 1) % (int)H;
-    const float3 t00 = unpack_r11g11b10(img[(size_t)y0 * W + x0]), t10 = unpack_r11g11b10(img[(size_t)y0 * W + x1]);
-    const float3 t01 = unpack_r11g11b10(img[(size_t)y1 * W + x0]), t11 = unpack_r11g11b10(img[(size_t)y1 * W + x1]);
+    const float3 t00 = load_radiance(img, (size_t)y0 * W + x0), t10 = load_radiance(img, (size_t)y0 * W + x1);
+    const float3 t01 = load_radiance(img, (size_t)y1 * W + x0), t11 = load_radiance(img, (size_t)y1 * W + x1);
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;
 }
@@ -138,8 +142,18 @@ static void downsample2d(const uint32_t* src, uint32_t srcW, uint32_t* dst, uint
         dst[(size_t)y * dstW + x] = pack_r11g11b10(0.25f * (((a + b) + c) + d), rounding);
     }
 }
+// DirectX::GenerateMipMaps(TEX_FILTER_LINEAR) of the RGBA32F lat-long (demo.cpp:318-320), pinned for exact 2:1 levels: the bilinear tap half way between four
+// texels, weights 1/2 per axis, rows first: (a/2 + b/2)/2 + (c/2 + d/2)/2
+static void downsample2d_f32(const float4f* src, uint32_t srcW, float4f* dst, uint32_t dstW, uint32_t dstH) {
+    for (uint32_t y = 0; y < dstH; ++y) for (uint32_t x = 0; x < dstW; ++x) {
+        const float4f a = src[(size_t)(2 * y) * srcW + 2 * x], b = src[(size_t)(2 * y) * srcW + 2 * x + 1], c = src[(size_t)(2 * y + 1) * srcW + 2 * x], d = src[(size_t)(2 * y + 1) * srcW + 2 * x + 1];
+        dst[(size_t)y * dstW + x] = {0.5f * (0.5f * a.x + 0.5f * b.x) + 0.5f * (0.5f * c.x + 0.5f * d.x), 0.5f * (0.5f * a.y + 0.5f * b.y) + 0.5f * (0.5f * c.y + 0.5f * d.y),
+                                     0.5f * (0.5f * a.z + 0.5f * b.z) + 0.5f * (0.5f * c.z + 0.5f * d.z), 0.5f * (0.5f * a.w + 0.5f * b.w) + 0.5f * (0.5f * c.w + 0.5f * d.w)};
+    }
+}
 // content-pipeline/cubemapgen.hlsl:19-121 for one level
-static void cubemapgen_level(const uint32_t* latlong, uint32_t llW, uint32_t llH, uint32_t* cube, uint32_t n, int rounding) {
+template <class TEXEL>
+static void cubemapgen_level(const TEXEL* latlong, uint32_t llW, uint32_t llH, uint32_t* cube, uint32_t n, int rounding) {
     const float faceTransform[6][2] = {{k_PiOver2, 0.f}, {-k_PiOver2, 0.f}, {0.f, k_PiOver2}, {0.f, -k_PiOver2}, {0.f, 0.f}, {k_Pi, 0.f}};
     const float an = sinf(k_PiOver4), ak = cosf(k_PiOver4);
     for (uint32_t y = 0; y < n; ++y) for (uint32_t x = 0; x < n; ++x) {
@@ -183,9 +197,9 @@ static inline float3 GetEnvDir(uint32_t face, float2 uv) {                  // s
     }
 }
 // split-sum-approx/prefilter.hlsl:43-95 for one level (all six faces)
-static void prefilter_level(const CubeChain& src, uint32_t level, uint32_t* dst, uint32_t sampleCount, float roughness, int rounding) {
-    const uint32_t mipSize = std::max(src.N >> level, 1u);
-    const float Resolution = (float)src.N;
+// mipSize / cubemapSize = the shader's root constants: the output level's size and the OUTPUT cube's size (renderer.cpp:504-526)
+static void prefilter_level(const CubeChain& src, uint32_t mipSize, uint32_t cubemapSize, uint32_t* dst, uint32_t sampleCount, float roughness, int rounding) {
+    const float Resolution = (float)cubemapSize;
     for (uint32_t face = 0; face < 6; ++face) for (uint32_t y = 0; y < mipSize; ++y) for (uint32_t x = 0; x < mipSize; ++x) {
         const float3 R = GetEnvDir(face, {(float)x / (float)mipSize, (float)y / (float)mipSize});
         const float3 N = R, V = R;
@@ -213,7 +227,8 @@ static void prefilter_level(const CubeChain& src, uint32_t level, uint32_t* dst,
     }
 }
 // spherical-harmonics/{projection,parallel-reduction,export}.hlsl + renderer.cpp:533-800 (srcMipOffset 0)
-static void sh_encode(const uint32_t* latlong, uint32_t W, uint32_t H, float out9x4[36]) {
+template <class TEXEL>
+static void sh_encode(const TEXEL* latlong, uint32_t W, uint32_t H, float out9x4[36]) {
     static const float K[9] = {0.282095f, 0.488603f, 0.488603f, 0.488603f, 1.092548f, 1.092548f, 0.315392f, 1.092548f, 0.546274f};
     std::vector<float4> cur((size_t)W * H * 9), next;
     const float dTheta = k_Pi / (float)H, dPhi = 2.f * k_Pi / (float)W;
@@ -223,7 +238,7 @@ static void sh_encode(const uint32_t* latlong, uint32_t W, uint32_t H, float out
         float b[9];
         b[0] = K[0]; b[1] = K[1] * dir.y; b[2] = K[2] * dir.z; b[3] = K[3] * dir.x;
         b[4] = (K[4] * dir.x) * dir.y; b[5] = (K[5] * dir.y) * dir.z; b[6] = K[6] * ((3.0f * dir.z) * dir.z - 1.0f); b[7] = (K[7] * dir.x) * dir.z; b[8] = K[8] * (dir.x * dir.x - dir.y * dir.y);
-        const float3 rad = unpack_r11g11b10(latlong[(size_t)y * W + x]);
+        const float3 rad = load_radiance(latlong, (size_t)y * W + x);
         const float sint = sinf(k_Pi * uv.y);
         for (int i = 0; i < 9; ++i) {
             const float w = b[i];
@@ -282,8 +297,19 @@ static void update_dynamic_sky(const float sunDir[3], float turbidity, uint32_t 
         cubemapgen_level(latlong + mip_offset_2d(W, H, m), std::max(W >> m, 1u), std::max(H >> m, 1u), srcCube + mip_offset_cube(cubemapRes, m), std::max(cubemapRes >> m, 1u), rounding);
     const CubeChain src = {cubemapRes, mips, srcCube};
     for (uint32_t m = 0; m < mips; ++m)           // renderer.cpp:504-526: roughness = mipIndex / numMips
-        prefilter_level(src, m, envmap + mip_offset_cube(cubemapRes, m), sampleCount, (float)m / (float)mips, rounding);
+        prefilter_level(src, std::max(cubemapRes >> m, 1u), cubemapRes, envmap + mip_offset_cube(cubemapRes, m), sampleCount, (float)m / (float)mips, rounding);
     sh_encode(latlong, W, H, sh9x4);
+}
+// FTextureCache::CacheHDRI (src/demo.cpp:292-434) behind the file read: `latlong` holds level 0 (W x H RGBA32F, W = 2 H) on entry and the whole chain on return
+static inline uint32_t mip_count_compressed(uint32_t w, uint32_t h) { uint32_t n = 0; while (w >= 4 && h >= 4) { ++n; w >>= 1; h >>= 1; } return n; }   // CalcMipCount(w, h, true)
+static void cache_hdri(float4f* latlong, uint32_t W, uint32_t H, uint32_t sampleCount, int rounding, uint32_t* srcCube, uint32_t* envmap, float sh9x4[36]) {
+    const uint32_t N = H, mips = mip_count_compressed(W, H), envN = N >> 1, envMips = mips - 1;
+    for (uint32_t m = 1; m < mips; ++m) downsample2d_f32(latlong + mip_offset_2d(W, H, m - 1), W >> (m - 1), latlong + mip_offset_2d(W, H, m), W >> m, H >> m);      // demo.cpp:318-320
+    for (uint32_t m = 0; m < mips; ++m) cubemapgen_level(latlong + mip_offset_2d(W, H, m), W >> m, H >> m, srcCube + mip_offset_cube(N, m), N >> m, rounding);      // :352
+    const CubeChain src = {N, mips, srcCube};
+    for (uint32_t m = 0; m < envMips; ++m)        // :357-369: PrefilterCubemap(src, uavs, filteredEnvmapSize, 0, filteredEnvmapMips)
+        prefilter_level(src, envN >> m, envN, envmap + mip_offset_cube(envN, m), sampleCount, (float)m / (float)envMips, rounding);
+    sh_encode(latlong, W, H, sh9x4);              // :398: from the source picture
 }
 
 extern "C" {
@@ -296,6 +322,17 @@ uint64_t orc_ibl_sizes(uint32_t cubemapRes, uint64_t* latlongTexels, uint64_t* c
 void orc_update_dynamic_sky(const float sunDir[3], float turbidity, uint32_t cubemapRes, uint32_t sampleCount, int rounding,
                             uint32_t* latlong, uint32_t* srcCube, uint32_t* envmap, float* sh9x4) {
     update_dynamic_sky(sunDir, turbidity, cubemapRes, sampleCount, rounding, latlong, srcCube, envmap, sh9x4);
+}
+// level counts and texel totals of incr_cache_hdri's products for a W x H picture: returns the source levels
+uint64_t orc_hdri_sizes(uint32_t W, uint32_t H, uint64_t* latlongTexels, uint64_t* srcCubeTexels, uint64_t* envTexels) {
+    const uint32_t mips = mip_count_compressed(W, H);
+    if (latlongTexels) *latlongTexels = mip_offset_2d(W, H, mips);
+    if (srcCubeTexels) *srcCubeTexels = mip_offset_cube(H, mips);
+    if (envTexels) *envTexels = mip_offset_cube(H >> 1, mips - 1);
+    return mips;
+}
+void orc_cache_hdri(float* latlongRgba, uint32_t W, uint32_t H, uint32_t sampleCount, int rounding, uint32_t* srcCube, uint32_t* envmap, float* sh9x4) {
+    cache_hdri((float4f*)latlongRgba, W, H, sampleCount, rounding, srcCube, envmap, sh9x4);
 }
 void orc_env_brdf(uint32_t W, uint32_t H, uint32_t numSamples, uint32_t* outRG16F, int rounding) { env_brdf(W, H, numSamples, outRG16F, rounding); }
 void orc_cube_sample(const uint32_t* cube, uint32_t N, uint32_t mips, const float dir[3], float level, float out[3]) {

@@ -108,7 +108,7 @@ def test_raster_options_and_edges(rt, R, ob, A, sio, gpu_ctx, sponza_small, synt
         osc.close(); gscene.close()
     # hidden meshes draw nothing: every surface keeps its clear value
     hidden = synth.sponza_stat(texture_size=8, tri_scale=1 / 64.0, with_lights=False)
-    R.generate_meshlets(hidden)
+    hidden = R.generate_meshlets(hidden)
     hidden.mesh_visibility = [0] * len(hidden.mesh_primitives)
     gscene = gpu_ctx.create_scene(hidden)
     try:
@@ -578,7 +578,7 @@ def test_rccl_collective_on_library_surface(rt, R, A, sio, gpu_ctx, helmet):
 def test_raster_4k_properties(rt, R, ob, A, sio, gpu_ctx, synth):
     """Full-size frame (BASELINE config 3 shape: Sponza statistics at 3840x2160): size-independent properties."""
     scene = synth.sponza_stat(texture_size=256)
-    R.generate_meshlets(scene)
+    scene = R.generate_meshlets(scene)
     W, H = 3840, 2160
     view = sio.FView().reset(scene, aspect=W / H)
     gscene = gpu_ctx.create_scene(scene)

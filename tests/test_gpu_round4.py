@@ -53,7 +53,7 @@ def test_raster_4k_bench_configuration_bands_vs_oracle(gpu_ctx, rt, R, sio, synt
     from test_gpu_raster import colour_close
     W, H = 3840, 2160
     scene = synth.sponza_stat(texture_size=1024)
-    R.generate_meshlets(scene)
+    scene = R.generate_meshlets(scene)
     assert sum(p["index_count"] // 3 for prims in scene.mesh_primitives for p in prims) == 262267 and len(scene.global_lights) == 65
     view = sio.FView().reset(scene, aspect=W / H)
     gscene = gpu_ctx.create_scene(scene)
@@ -158,7 +158,7 @@ def test_primitive_path_uses_all_12_bits_of_primitive_id(gpu_ctx, rt, R, sio, sy
         UseMeshlets = False
     scene = synth.bistro_scale(num_instances=3600, tris_per_mesh=64, num_materials=12, texture_size=8)
     assert sum(len(p) for p in scene.mesh_primitives) == 3601
-    R.generate_meshlets(scene)                       # sizes the draw lists (one entry per meshlet >= one per primitive)
+    scene = R.generate_meshlets(scene)               # sizes the draw lists (one entry per meshlet >= one per primitive)
     W, H = 384, 216
     view = sio.FView()                                  # above the street, looking down the grid: thousands of props on screen
     view.position = np.array([0, 45, -110], dtype=np.float32); view.look = np.array([0, -0.45, 1], dtype=np.float32); view.right = np.array([1, 0, 0], dtype=np.float32)

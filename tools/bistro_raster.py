@@ -5,7 +5,7 @@ PKG="incarnation-renderer_amd"
 A = importlib.import_module(PKG + ".ctypes_api"); sio = importlib.import_module(PKG + ".scene_io"); syn = importlib.import_module(PKG + ".synth")
 R = importlib.import_module(PKG + ".raster"); rt = importlib.import_module(PKG + ".runtime")
 t=time.time(); s = syn.bistro_scale(); print("gen %.1fs"%(time.time()-t))
-t=time.time(); R.generate_meshlets(s); print("meshlets %d %.1fs"%(s.num_meshlets, time.time()-t))
+t=time.time(); s = R.generate_meshlets(s); print("meshlets %d %.1fs"%(s.num_meshlets, time.time()-t))
 ctx = rt.Context(0); t=time.time(); gs = ctx.create_scene(s); print("create %.1fs"%(time.time()-t))
 W,H=3840,2160
 view = sio.FView().reset(s, aspect=W/H)

@@ -125,7 +125,7 @@ with open(os.path.join(G, "scalar_kats.json"), "w") as f:
 # 4. raster crop (item 9): helmet 64x64 frame without TAA -- visibility ids, depth, G-buffers, colour target
 class NoTaa(A.FConfig):
     EnableTAA = False
-R.generate_meshlets(s)
+s = R.generate_meshlets(s)
 osc = ob.OracleScene(s)                                # a new oracle scene: the first one was packed before the meshlets existed
 hs = ob.HostSurfaces(W, H, s.num_meshlets, 16 * 9 * 24, 64)
 hs.arr["sh9"][:, :3] = 0.25

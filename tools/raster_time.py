@@ -19,7 +19,7 @@ class Cfg(A.FConfig):
     UseMeshlets = not a.prims
 W, H = map(int, a.res.split("x"))
 t = time.time(); scene = synth.sponza_stat(texture_size=a.texture_size); print("scene %.1fs" % (time.time() - t))
-t = time.time(); R.generate_meshlets(scene); print("meshlets %d in %.1fs" % (scene.num_meshlets, time.time() - t))
+t = time.time(); scene = R.generate_meshlets(scene); print("meshlets %d in %.1fs" % (scene.num_meshlets, time.time() - t))
 ctx = rt.Context(0)
 t = time.time(); gs = ctx.create_scene(scene); print("upload %.1fs" % (time.time() - t))
 view = sio.FView().reset(scene, aspect=W / H)

@@ -597,6 +597,11 @@ def main():
                                         "achieved": round(frame_alg_bytes / (call_ms * 1e-3) / 1e9, 2)},
                          "kernel_ms_per_step": {k.split("::")[1]: round(v[0] / args.steps, 4) for k, v in per_kernel.items()}},
         }
+        # the shadow-ray queue: rays beyond its capacity are traced inline by the summation kernel (same image, slower) -- a silent cliff until round 5
+        out["config"]["shadow_queue"] = {"rays_asked_per_step": int(prof.shadow_rays_asked) // max(int(prof.frames), 1), "rays_inline_per_step": int(prof.shadow_rays_inline) // max(int(prof.frames), 1),
+                                         "overflowed_calls": int(prof.shadow_queue_overflows)}
+        if prof.shadow_queue_overflows:
+            print("bench.py: WARNING: the shadow-ray queue overflowed in %d call(s): %d rays per step were traced inline" % (prof.shadow_queue_overflows, int(prof.shadow_rays_inline) // max(int(prof.frames), 1)), file=sys.stderr)
         if alone is not None:
             pa, sa, na = alone
             alone_kernel = {"incr::wf_extend_kernel": (pa.extend_ms, max(pa.launches[0], 1), float(sa[0] + sa[1]) * b_ray),

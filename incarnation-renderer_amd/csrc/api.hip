@@ -24,7 +24,7 @@ using namespace incr;
 
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
-                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement);
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement, unsigned long long* overflowTally);
 extern "C" hipError_t incr_launch_bvh_update(uint32_t numTris, const incr::TriObject* src, const float* meshLocalToWorld, const incr::MeshInstanceInfo* meshInfo,
                                              incr::TriIsect* tris, incr::TriShade* shade, incr::BvhNode8* nodes, const uint32_t* dLevelNodes,
                                              const uint32_t* ranges, uint32_t numRanges, void* nodeBoxes, hipStream_t stream);
@@ -114,7 +114,10 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
     HIP_TRY(hipMemset(ctx->statStripes, 0, 64 * 128));
     const char* rc = test_hook_env("INCR_WF_RAYS_PER_PATH");      // test hook: a tiny queue forces the overflow (inline shadow) path
-    ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) : 12u;          // one queue for the four bounces of a path (6 rays per path on the bench scene)
+    ctx->raysPerPath = rc ? (uint32_t)std::max(0, atoi(rc)) + 0x80000000u : 0u;          // bit 31: forced; otherwise sized from the scene per call (wf_rays_per_path)
+    ctx->wfRaysPerPathAllocated = 0; ctx->wfOverflowTally = nullptr;
+    HIP_TRY(hipMalloc((void**)&ctx->wfOverflowTally, 8 * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->wfOverflowTally, 0, 8 * 4 * sizeof(unsigned long long)));
     const char* se = test_hook_env("INCR_WF_STACK_ENTRIES");      // test hook: run the 16- / 24-entry traversal kernels on a shallow tree
     ctx->forceStackEntries = se ? (uint32_t)std::max(0, atoi(se)) : 0u;
     memset(&ctx->wf, 0, sizeof ctx->wf); ctx->wfBlock = nullptr; ctx->wfBytes = 0; ctx->wfStage = nullptr; ctx->wfStageBytes = 0;
@@ -139,6 +142,7 @@ int incr_teardown(incr_context* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
     if (ctx->statStripes) (void)hipFree(ctx->statStripes);
+    if (ctx->wfOverflowTally) (void)hipFree(ctx->wfOverflowTally);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->wfStage) (void)hipFree(ctx->wfStage);
     for (int i = 1; i < kMaxPipes; ++i) { if (ctx->wfStreams[i]) (void)hipStreamDestroy(ctx->wfStreams[i]); if (ctx->wfJoin[i]) (void)hipEventDestroy(ctx->wfJoin[i]); }
@@ -308,7 +312,19 @@ static void upload_grid_params(const incr_scene* sc, PtParams& P) {
 // Path-state workspace of the wavefront path tracer: one allocation, carved into SoA arrays (16-byte aligned) per pipeline.
 // 656 B of path state (the vertex records of the four bounces side by side) + raysPerPath x 48 B of shadow-ray queue per pixel: 10.2 GB at 4K -- 3.5 % of the 288 GB.
 // A pipeline owns a band of 8-pixel tile rows (equal shares; a frame of fewer tile rows than pipelines uses fewer).
-static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, uint32_t numSamples, hipStream_t stream) {
+// Shadow-ray queue slots per path: the four vertices of a path each ask for at most one ray per light of their light-grid cell plus the sky sample.  The mean over the
+// OCCUPIED cells of the scene's grid, times four, plus four of slack, and never fewer than 12 (rounds 2-4 had a fixed 8 per bounce, then a fixed 12 per path: a light-dense
+// scene overflowed into the inline path of wf_accumulate_kernel without anyone noticing).  48 B per slot: Sponza-stat (65 lights, 1.3 per occupied cell) takes 14 = 5.6 GB at 4K.
+static uint32_t wf_rays_per_path(const incr_context* ctx, const incr_scene* sc) {
+    if (ctx->raysPerPath & 0x80000000u) return ctx->raysPerPath & 0x7fffffffu;
+    const std::vector<uint32_t>& off = sc->grid.cellOffsets;
+    uint64_t lights = 0, occupied = 0;
+    const size_t cells = off.size() >= 2 ? off.size() - 2 : 0;          // the last cell lists every light (the fallback for non-finite attenuation)
+    for (size_t c = 0; c < cells; ++c) { const uint32_t k = off[c + 1] - off[c]; if (k) { lights += k; ++occupied; } }
+    const double mean = occupied ? (double)lights / (double)occupied : 0.0;
+    return (uint32_t)std::min(std::max(std::ceil(4.0 * (mean + 1.0)) + 4.0, 12.0), 96.0);
+}
+static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows, uint32_t numSamples, uint32_t raysPerPath, hipStream_t stream) {
     const uint32_t tilesX = (W + 7u) / 8u, tilesY = (localRows + 7u) / 8u * numSamples;       // samples in flight: the tile rows of one sample after the other
     // wfPipesWanted == 0: by size -- two pipelines for a frame, four for a framebuffer shard (a 1/8 shard of 4K: 4.80 -> 4.64 ms with
     // four, the full frame 23.2 -> 24.1 ms: the shorter the ray lists, the more of a launch is its longest ray, tools/shard_emulation.py)
@@ -332,7 +348,7 @@ static int ensure_wf_workspace(incr_context* ctx, uint32_t W, uint32_t localRows
     for (int i = 0; i < pipes; ++i) {
         const uint64_t paths = std::max<uint64_t>((uint64_t)(ctx->wfTileRow[i + 1] - ctx->wfTileRow[i]) * tilesX * 64u, 1);
         n[i] = (paths + 255) & ~255ull;
-        rayCap[i] = std::min<uint64_t>(n[i] * ctx->raysPerPath, 0xfffffff0ull);
+        rayCap[i] = std::min<uint64_t>(n[i] * raysPerPath, 0xfffffff0ull);
         need += n[i] * (32 * 4 + 16 + 4 * 128) + 65536 + (rayCap[i] + 1) * 48;          // vertex records of the four bounces side by side (deferred accumulation)
     }
     if (ctx->wfBytes < need) {
@@ -889,7 +905,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     P.localPixels = P.localRows * P.W;
     P.divLocalPixels = make_fastdiv(std::max(P.localPixels, 1u));
     if ((uint64_t)P.localPixels * P.numSamples > 0x7fffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "num_samples %u x %u local pixels overflows the path index", P.numSamples, P.localPixels);
-    int rc = ensure_wf_workspace(ctx, P.W, P.localRows, P.numSamples, (hipStream_t)stream);
+    int rc = ensure_wf_workspace(ctx, P.W, P.localRows, P.numSamples, wf_rays_per_path(ctx, sc), (hipStream_t)stream);
     if (rc) return rc;
     if (P.numSamples > 1u) {        // the samples' parking surface (RGBA16F bits per sample and local pixel), library-owned, grown on demand
         const uint64_t needStage = (uint64_t)P.localPixels * P.numSamples * 8u;
@@ -912,7 +928,7 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
     const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
     ctx->wfStreams[0] = (hipStream_t)stream;
     HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev,
-                                     ctx->wfSideStreams, ctx->wfBounceFork, ctx->wfBounceJoin, ctx->wfOverlap ? 1 : 0, ctx->wfAccPlacement));
+                                     ctx->wfSideStreams, ctx->wfBounceFork, ctx->wfBounceJoin, ctx->wfOverlap ? 1 : 0, ctx->wfAccPlacement, ctx->profiling ? ctx->wfOverflowTally : nullptr));
     return INCR_OK;
 }
 
@@ -968,9 +984,18 @@ int incr_set_pathtrace_overlap(incr_context* ctx, int32_t enable) {
     return INCR_OK;
 }
 
+int incr_set_pathtrace_accumulate_placement(incr_context* ctx, int32_t placement) {
+    if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
+    if (placement < -1 || placement > 1) return fail(INCR_ERR_INVALID_ARGUMENT, "placement %d: -1 (by size), 0 (end of the main stream) or 1 (behind the any-hit launches)", placement);
+    ctx->wfAccPlacement = placement;
+    return INCR_OK;
+}
+
 int incr_profile_begin(incr_context* ctx) {
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     ctx->profiling = true; ctx->profFrames = 0; ctx->profPipes.clear();
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(ctx->wfOverflowTally, 0, 8 * 4 * sizeof(unsigned long long)));
     return INCR_OK;
 }
 
@@ -995,6 +1020,9 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     out->frames = (uint32_t)ctx->profFrames;
     out->pipelines = ctx->profPipes.empty() ? 0u : (uint32_t)(ctx->profPipes.back() & 0xff);
     out->overlap = ctx->profPipes.empty() ? 0u : (uint32_t)((ctx->profPipes.back() >> 8) & 1);
+    unsigned long long tally[32];
+    HIP_TRY(hipMemcpy(tally, ctx->wfOverflowTally, sizeof tally, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) { out->shadow_rays_asked += tally[4 * i]; out->shadow_rays_inline += tally[4 * i + 1]; out->shadow_queue_overflows += (uint32_t)tally[4 * i + 2]; }
     ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }

@@ -39,14 +39,17 @@ struct incr_context {
     float* srgbLut;           // 256 floats in HBM
     unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
     uint32_t forceStackEntries; // INCR_WF_STACK_ENTRIES (tests): lower bound for the traversal kernels' stack size
-    uint32_t raysPerPath;     // shadow-ray queue slots per path of the wavefront path tracer (8; INCR_WF_RAYS_PER_PATH)
+    uint32_t raysPerPath;     // INCR_WF_RAYS_PER_PATH (tests: a tiny queue forces the overflow path); 0 = sized from the scene (api.hip wf_rays_per_path)
+    uint32_t wfRaysPerPathAllocated;     // what the workspace was carved for
+    unsigned long long* wfOverflowTally; // device, 8 pipelines x 4 words: rays asked for, rays beyond the queue, calls that overflowed (profiled calls; wf_overflow_tally_kernel)
     incr::WfBuffers wf[8];    // path-state workspace of the wavefront path tracer, one set per pipeline (pathtrace_wf.hip), grown on demand
     uint32_t wfTileRow[9];    // tile rows [wfTileRow[i], wfTileRow[i + 1]) belong to pipeline i
     int wfPipes;              // pipelines of the current frame
     int wfPipesWanted;        // INCR_WF_PIPELINES / incr_set_pathtrace_pipelines; 0 = by size
     hipStream_t wfStreams[8]; // [0] is filled per call with the caller's stream; the others are library-owned
     hipEvent_t wfFork, wfJoin[8];
-    bool wfOverlap;           // bounce overlap: extend(b + 1) beside shadow(b) on the pipeline's side stream (INCR_WF_OVERLAP, incr_set_pathtrace_overlap)
+    bool wfOverlap;           // the any-hit launches (and, for small frames, the summation) on the pipeline's SIDE stream beside the main chain primary -> shade -> extend -> ... on the caller's
+                              // (deferred accumulation, pathtrace_wf.hip launcher; INCR_WF_OVERLAP, incr_set_pathtrace_overlap)
     hipStream_t wfSideStreams[8];                     // library-owned, created on first use
     hipEvent_t wfBounceFork[32], wfBounceJoin[32];    // [pipeline * 4 + bounce]
     int wfAccPlacement;                               // where wf_accumulate_kernel runs: -1 = by size; 0 the end of the main stream, 1 behind the any-hit launches on the side stream (INCR_WF_ACC_PLACEMENT)

@@ -152,6 +152,7 @@ static constexpr int kCursorBase = 16, kRayCountBase = 32, kSnapBase = 40;
 // (far more common) hit side -- as kernel arguments they are preloaded for the whole kernel and spill
 static constexpr int kSkyConstBase = 4096;
 struct WfSkyConsts { incr_perez_distribution perez; SkySun sunMiss; };
+static_assert(sizeof(WfSkyConsts) % 4 == 0 && sizeof(WfSkyConsts) / 4 <= 64, "wf_init_counters_kernel copies WfSkyConsts with its 64 threads, one word each");
 
 // Path state is indexed by LIST SLOT, not by pixel: the rays of a bounce are a flat list (generate / shade append to it), and
 // everything a kernel of that bounce touches -- the ray, the colour / attenuation travelling with it, the hit, the vertex record --
@@ -883,9 +884,10 @@ template <bool ENV> __global__ __launch_bounds__(kWfBlock, INCR_SHADE_WAVES) voi
 // one lane per RAY and the traversal kernel reads a flat, coalesced ray queue (32 B per ray: origin + path id, direction
 // + request slot); rays of one vertex are neighbours in the queue, so neighbouring lanes leave from the same point.
 //
-// Queue capacity is a soft limit (rayCap = 8 rays per path, four to five times what the light grid asks for on the
-// bench scenes): a workgroup whose rays do not fit flags its vertices kFlagInlineShadow and accumulate traces those
-// requests itself -- slower, same result, nothing is dropped.
+// Queue capacity is a soft limit: ONE queue holds the shadow rays of a path's four bounces, rayCap = paths x rays per path, where the rays per path come
+// from the scene (api.hip wf_rays_per_path: 4 vertices x (mean lights per occupied light-grid cell + the sky sample) + 4, at least 12: twice what the bench
+// scene's paths ask for).  A workgroup whose rays do not fit flags its vertices kFlagInlineShadow and accumulate traces those requests itself -- slower, same
+// result, nothing is dropped; wf_overflow_tally_kernel (below) counts such rays when a profile is being recorded, incr_pathtrace_profile reports them.
 
 // Pure any-hit traversal over the ray queue: idle lanes take the next rays of the wave's chunk; an occluded ray zeroes the
 // visibility word of its own record (a plain 4-byte store; unoccluded rays -- the majority of the light rays -- write nothing).
@@ -1115,6 +1117,10 @@ template <bool SHADOW> static void trav_geometry(int sv, uint32_t* perCU, uint32
     else if (sv == 16) { *perCU = TravCfg<16, SHADOW>::kBlocksPerCU; *block = TravCfg<16, SHADOW>::kBlock; }
     else { *perCU = TravCfg<24, SHADOW>::kBlocksPerCU; *block = TravCfg<24, SHADOW>::kBlock; }
 }
+// profiled calls only: the rays the frame asked for beyond the queue's capacity (they were traced inline by wf_accumulate_kernel), and one count per call that had any
+__global__ __launch_bounds__(64) void wf_overflow_tally_kernel(const uint32_t* counters, uint32_t rayCap, unsigned long long* tally) {
+    if (threadIdx.x == 0) { const uint32_t asked = counters[kRayCountBase]; tally[0] += asked; if (asked > rayCap) { tally[1] += asked - rayCap; tally[2] += 1ull; } }
+}
 // behind wf_shade_kernel(bounce): the shadow-ray queue's length with the rays of bounces 0 .. bounce in it
 __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int bounce) {
     if (threadIdx.x == 0) counters[kSnapBase + bounce + 1] = counters[kRayCountBase];
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int
 // `events` (optional, kWfProfEvents per pipeline): see pt_params.h.
 extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const incr::WfBuffers* pipes, int numPipes, const uint32_t* tileRow, hipStream_t* streams,
                                                hipEvent_t fork, hipEvent_t* joins, int numCUs, uint32_t stackEntries, hipEvent_t* events,
-                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement) {
+                                               hipStream_t* sideStreams, hipEvent_t* bounceFork, hipEvent_t* bounceJoin, int overlap, int accPlacement, unsigned long long* overflowTally) {
     using namespace incr;
     const uint32_t tilesX = (p->W + 7u) / 8u, tilesY = (p->localRows + 7u) / 8u;      // tileRow[] counts rows of all samples in flight: tilesY per sample
     if (numPipes < 1 || numPipes > 8) return hipErrorInvalidValue;
@@ -1267,6 +1273,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         }
     }
     if (events) for (int i = 0; i < numPipes; ++i) for (int k = 0; k < kWfProfEvents; ++k) if (!rec[i][k]) (void)hipEventRecord(events[i * kWfProfEvents + k], streams[i]);      // kernels that did not run: zero-length intervals
+    if (overflowTally) for (int i = 0; i < numPipes; ++i) if (total[i]) hipLaunchKernelGGL(wf_overflow_tally_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, pipes[i].rayCap, overflowTally + 4 * i);
     for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
     if (p->numSamples > 1u && p->localPixels) hipLaunchKernelGGL(wf_integrate_samples_kernel, dim3((p->localPixels + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, streams[0], *p);
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);

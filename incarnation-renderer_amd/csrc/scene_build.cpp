@@ -551,10 +551,21 @@ template <class F> void parallel_for(size_t count, size_t grain, F&& fn) {
     const size_t chunks = (count + grain - 1) / std::max<size_t>(grain, 1);
     const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64), chunks);
     std::atomic<size_t> next{0};
-    auto worker = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= chunks) break; fn(c * grain, std::min(count, (c + 1) * grain)); } };
-    if (nThreads <= 1) { worker(); return; }
-    std::vector<std::thread> th; for (size_t t = 0; t < nThreads; ++t) th.emplace_back(worker);
-    for (std::thread& t : th) t.join();
+    // An exception must not leave a worker thread (std::terminate), and a thread that failed to start must not leave running ones unjoined: a worker keeps the
+    // first exception of its chunks and stops the hand-out; the threads that did start are always joined; the exception is rethrown on the calling thread, where
+    // incr_scene_create turns it into an error code.
+    std::exception_ptr failure; std::mutex failureLock;
+    auto worker = [&]() {
+        try { for (;;) { const size_t c = next.fetch_add(1); if (c >= chunks) break; fn(c * grain, std::min(count, (c + 1) * grain)); } }
+        catch (...) { std::lock_guard<std::mutex> g(failureLock); if (!failure) failure = std::current_exception(); next.store(chunks); }
+    };
+    if (nThreads <= 1) { worker(); if (failure) std::rethrow_exception(failure); return; }
+    struct JoinAll { std::vector<std::thread> th; ~JoinAll() { for (std::thread& t : th) if (t.joinable()) t.join(); } } pool;
+    pool.th.reserve(nThreads);
+    try { for (size_t t = 0; t < nThreads; ++t) pool.th.emplace_back(worker); }
+    catch (...) { std::lock_guard<std::mutex> g(failureLock); if (!failure) failure = std::current_exception(); next.store(chunks); }
+    for (std::thread& t : pool.th) t.join();
+    if (failure) std::rethrow_exception(failure);
 }
 struct StageTimer {          // INCR_SCENE_TIMING=1: wall time of the stages of build_world_bvh on stderr (tools/scene_create_time.py)
     const bool on = test_hook_env("INCR_SCENE_TIMING") != nullptr;
@@ -653,18 +664,10 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     {
         std::vector<uint32_t> todo;
         for (uint32_t m = 0; m < (uint32_t)numMeshes; ++m) if (meshFirst[m + 1] > meshFirst[m]) todo.push_back(m);
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= todo.size()) break;
-                const uint32_t m = todo[i];
-                build_wide_subtree(tb, cen, meshFirst[m], meshFirst[m + 1] - meshFirst[m], kMaxBvhDepth - 8u, sub[m]);
-            }
-        };
-        const size_t nThreads = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64), todo.size());
-        if (nThreads <= 1) worker();
-        else { std::vector<std::thread> th; for (size_t t = 0; t < nThreads; ++t) th.emplace_back(worker); for (std::thread& t : th) t.join(); }
+        // the subtree builders allocate (Builder::order / nodes: ~1 GB over a Bistro-scale scene): through parallel_for, whose workers hand an exception back to this thread
+        parallel_for(todo.size(), 1, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; ++i) { const uint32_t m = todo[i]; build_wide_subtree(tb, cen, meshFirst[m], meshFirst[m + 1] - meshFirst[m], kMaxBvhDepth - 8u, sub[m]); }
+        });
     }
     timer.lap("subtrees (parallel)");
     // 3. one node array: the TOP REGION (top tree + a copy of every mesh root, rebuild_top_tree) in front, then the subtrees below
@@ -726,6 +729,9 @@ void build_world_bvh(const HostScene& s, HostBvh& out) {
     const size_t slots = leafOrder.size();                 // triangles + holes (device_types.h LEAF SLOTS)
     out.numTriangles = (uint32_t)n;
     out.tris.resize(slots); out.shade.resize(n); out.triObj.resize(slots);
+    // RecordVec leaves its elements uninitialised (a zero fill of ~200 MB was a serial stage): every byte that is uploaded must be written below.  The records have no
+    // padding -- the named fields are all there is -- and every slot writes all of them, holes included.
+    static_assert(sizeof(TriIsect) == 12 * 4 && sizeof(TriObject) == 12 * 4 && sizeof(TriShade) == (9 + 12 + 6 + 5) * 4, "records without padding: all fields are written per slot");
     parallel_for(slots, 32768, [&](size_t s0, size_t s1) {          // every slot writes its own records (shading records: one per flattened id)
     for (size_t i = s0; i < s1; ++i) {
         if (leafOrder[i] == kTriHole) {

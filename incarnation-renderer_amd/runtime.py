@@ -21,7 +21,7 @@ EXPORTS = [
     "incr_buffer_create", "incr_buffer_destroy", "incr_buffer_upload", "incr_buffer_download", "incr_buffer_clear",
     "incr_stream_synchronize", "incr_scene_create", "incr_scene_destroy", "incr_update_bvh", "incr_scene_set_sun_dir", "incr_scene_set_max_anisotropy",
     "incr_scene_get_info", "incr_scene_texture_info", "incr_scene_texture_download", "incr_shard_local_rows", "incr_pathtrace", "incr_tonemap", "incr_unshard",
-    "incr_trace_rays", "incr_selftest_small_float", "incr_selftest_reciprocal", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines", "incr_set_pathtrace_overlap",
+    "incr_trace_rays", "incr_selftest_small_float", "incr_selftest_reciprocal", "incr_scene_validate_host", "incr_profile_begin", "incr_profile_end", "incr_set_pathtrace_pipelines", "incr_set_pathtrace_overlap", "incr_set_pathtrace_accumulate_placement",
     # raster path
     "incr_generate_tangents", "incr_decode_jpeg", "incr_meshletize", "incr_meshlet_set_counts", "incr_meshlet_set_copy", "incr_meshlet_set_free",
     "incr_pixel_jitter", "incr_make_view_constants", "incr_batch_cull", "incr_light_cull", "incr_visibility", "incr_gbuffer",
@@ -95,6 +95,7 @@ def load():
     L.incr_profile_begin.restype = C.c_int; L.incr_profile_begin.argtypes = [vp]
     L.incr_set_pathtrace_pipelines.restype = C.c_int; L.incr_set_pathtrace_pipelines.argtypes = [vp, C.c_uint32]
     L.incr_set_pathtrace_overlap.restype = C.c_int; L.incr_set_pathtrace_overlap.argtypes = [vp, C.c_int32]
+    L.incr_set_pathtrace_accumulate_placement.restype = C.c_int; L.incr_set_pathtrace_accumulate_placement.argtypes = [vp, C.c_int32]
     L.incr_profile_end.restype = C.c_int; L.incr_profile_end.argtypes = [vp, C.POINTER(A.PathtraceProfile)]
     L.incr_scene_validate_host.restype = C.c_int
     L.incr_scene_validate_host.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(A.SceneInfo)]
@@ -195,6 +196,9 @@ class Context:
 
     def set_pathtrace_overlap(self, enable):
         check(self.lib.incr_set_pathtrace_overlap(self.handle, 1 if enable else 0))
+
+    def set_pathtrace_accumulate_placement(self, placement):
+        check(self.lib.incr_set_pathtrace_accumulate_placement(self.handle, int(placement)))
 
     def profile_begin(self):
         check(self.lib.incr_profile_begin(self.handle))

@@ -170,6 +170,10 @@ int  incr_set_pathtrace_pipelines(incr_context* ctx, uint32_t pipelines);
  * is what per-kernel timing wants.
  */
 int  incr_set_pathtrace_overlap(incr_context* ctx, int32_t enable);
+/* Where the four summation launches (wf_accumulate_kernel) of a call run when the any-hit launches are on the side stream: 0 = at the end of the main stream, 1 = each right
+ * behind the any-hit launch of its bounce on the side stream, -1 = by the number of paths (0 from 3 M paths up: a 4K frame; 1 below).  An issue order, not a result: every
+ * placement leaves the same bits.  Not in the reference. */
+int  incr_set_pathtrace_accumulate_placement(incr_context* ctx, int32_t placement);
 
 /*
  * Per-kernel timing of the path tracer (stands in for the reference's PIX/Tracy GPU zones, inc/profiling.h:10-12):
@@ -184,8 +188,11 @@ typedef struct incr_pathtrace_profile {
     uint32_t pipelines;              /* pipelines of the last recorded call */
     uint32_t overlap;                /* 1: the last recorded call ran its any-hit launches on the pipelines' side streams (incr_set_pathtrace_overlap, below): the
                                         launches of the two streams share the GPU while they are timed */
-    uint32_t reserved0;
-    double   extend_wait_ms;         /* reserved (0) */
+    uint32_t shadow_queue_overflows; /* (pipeline, call) pairs whose shadow-ray queue was too small: their excess rays were traced inline by the summation kernel --
+                                        same image, slower.  The queue is sized from the scene's light grid (4 x (mean lights per occupied cell + 1) + 4 rays per path,
+                                        at least 12); a count above 0 says a view is far denser than the scene's mean.  (round 4: reserved0) */
+    uint64_t shadow_rays_inline;     /* the rays beyond the queue, over all recorded calls (round 4: the reserved extend_wait_ms; same size and offset) */
+    uint64_t shadow_rays_asked;      /* shadow rays the recorded calls asked for (appended in round 5: the structure grew by 8 bytes) */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);
 int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);

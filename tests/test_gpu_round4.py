@@ -195,9 +195,10 @@ def test_primitive_path_uses_all_12_bits_of_primitive_id(gpu_ctx, rt, R, sio, sy
 # ------------------------------------------------------------------------------------------------ bounce overlap
 @pytest.mark.parametrize("scene_name,W,H,pipes", [("sponza_small", 320, 180, 1), ("sponza_small", 203, 117, 2), ("helmet", 256, 256, 4)])
 def test_bounce_overlap_is_bit_identical(gpu_ctx, rt, sio, A, request, scene_name, W, H, pipes):
-    """incr_set_pathtrace_overlap: wf_extend_kernel(b + 1) on the pipeline's side stream beside wf_shadow_kernel(b) + wf_accumulate_kernel(b).
-    Same kernels on the same inputs in another issue order: target, history, ray counts and the hit chains equal the sequential issue bit for
-    bit, over several samples (the side streams are reused across calls), with samples in flight and on a framebuffer shard."""
+    """incr_set_pathtrace_overlap: the any-hit launches on the pipeline's side stream beside the main chain primary -> shade -> extend -> ..., the four summation
+    launches at the end of the main stream or each behind the any-hit launch of its bounce (incr_set_pathtrace_accumulate_placement 0 / 1: a 4K frame takes 0 by
+    size, these small frames 1 -- both are forced here).  Same kernels on the same inputs in another issue order: target, history, ray counts and the hit chains
+    equal the sequential issue bit for bit, over several samples (the side streams are reused across calls), with samples in flight and on a framebuffer shard."""
     from parity_helpers import stats_tuple
     packed = request.getfixturevalue(scene_name)
     sc = gpu_ctx.create_scene(packed)
@@ -205,8 +206,8 @@ def test_bounce_overlap_is_bit_identical(gpu_ctx, rt, sio, A, request, scene_nam
     gpu_ctx.set_pathtrace_pipelines(pipes)
     try:
         res = []
-        for overlap in (False, True):
-            gpu_ctx.set_pathtrace_overlap(overlap)
+        for overlap, placement in ((False, -1), (True, 0), (True, 1)):
+            gpu_ctx.set_pathtrace_overlap(overlap); gpu_ctx.set_pathtrace_accumulate_placement(placement)
             out = []
             for shard in (None, A.Shard(8, 1, 3)):
                 pt = rt.PathTracer(gpu_ctx, sc, W, H, shard=shard)
@@ -216,12 +217,13 @@ def test_bounce_overlap_is_bit_identical(gpu_ctx, rt, sio, A, request, scene_nam
                 r = pt.read(); r["chain"] = pt.read_chain()
                 out.append(r); pt.close()
             res.append(out)
-        for a, b in zip(*res):
-            assert stats_tuple(a["stats"]) == stats_tuple(b["stats"]) and a["stats"].bounce_rays > 0
-            for k in ("target", "history", "chain"):
-                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert stats_tuple(a["stats"]) == stats_tuple(b["stats"]) and a["stats"].bounce_rays > 0
+                for k in ("target", "history", "chain"):
+                    np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     finally:
-        gpu_ctx.set_pathtrace_pipelines(0); gpu_ctx.set_pathtrace_overlap(True)
+        gpu_ctx.set_pathtrace_pipelines(0); gpu_ctx.set_pathtrace_overlap(True); gpu_ctx.set_pathtrace_accumulate_placement(-1)
         sc.close()
 
 

@@ -445,6 +445,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     sif = args.samples_in_flight if args.samples_in_flight > 0 else (8 if world > 1 else 1)
+    gather_events = []          # (start, end) around every all_gather + incr_unshard, on the render stream
 
     def step(sample_index, e0=None, e1=None, gather=True, num_samples=1):
         d = rt.make_pathtrace_desc(view, W, H, sample_index, shard, envmap=envmap, num_samples=num_samples)
@@ -459,8 +460,12 @@ def main():
         if e1 is not None:
             e1.record(stream)
         if collective and gather:   # the one exchange step of the path: gather disjoint framebuffer shards (final HDR of the accumulation)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(stream)
             dist.all_gather_into_tensor(gathered, history)
             ctx.unshard(full.data_ptr(), gathered.data_ptr(), W, H, shard.row_block_height, world, 4, stream.cuda_stream)
+            g1.record(stream)
+            gather_events.append((g0, g1))
 
     def barrier():
         if collective:
@@ -476,6 +481,7 @@ def main():
         step(sample, num_samples=S); sample += S; w += S
     barrier()
     stats.zero_()
+    gather_events.clear()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ctx.profile_begin()        # HIP events around every kernel of incr_pathtrace, recorded on the launch stream
     barrier()
@@ -647,6 +653,10 @@ def main():
                     out["roofline"]["traffic_note"] = "profiles/hbm_traffic_latest.json was measured on other kernel sources, another workload or another pipeline count: not attached"
             except Exception:
                 pass
+        if collective and gather_events:
+            gms = [a.elapsed_time(b) for a, b in gather_events]
+            out["config"]["gather"] = {"gathers": len(gms), "gather_ms": round(sum(gms) / len(gms), 4), "gather_ms_max": round(max(gms), 4), "bytes_gathered": int(world * rows * W * 4),
+                                       "what": "%s all_gather_into_tensor of the R11G11B10F history shards + incr_unshard into the %dx%d frame, HIP events on the render stream (rank 0)" % (args.backend, W, H)}
         if args.force_collectives:
             out["config"]["force_collectives"] = ("world size 1 over %s: init_process_group(device_id), all_gather_into_tensor of the history shard + incr_unshard, "
                                                   "the TAA band gather on the library-owned surface, all_reduce of time and ray counts, destroy_process_group" % args.backend)

@@ -12,9 +12,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--res", "640x360", "--texture-size", "64",
-           "--no-cpu-baseline", "--checksums", "--spp-per-gather", "4"] + list(extra)
+def _bench(*extra, res="640x360", steps=6, spg=4):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--res", res, "--texture-size", "64",
+           "--no-cpu-baseline", "--checksums", "--spp-per-gather", str(spg)] + list(extra)
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -39,6 +39,60 @@ def test_bench_force_collectives_runs_the_rccl_branch_bit_identically():
     assert coll["raster"]["taa_accumulation_crc32"] == plain["raster"]["taa_accumulation_crc32"]
     assert coll["config"]["rays_per_step"] == plain["config"]["rays_per_step"]
     assert coll["n_gpus"] == 1 and coll["value"] > 0
+
+
+def test_bench_force_collectives_at_4k_reports_the_gather():
+    """The exchange step at BASELINE config 4's size: one RCCL all_gather of the 33 MB R11G11B10F history + incr_unshard per gathered frame, timed with HIP events on
+    the render stream and reported as config.gather.gather_ms; the gathered 4K history equals the plain run's bit for bit."""
+    plain = _bench("--no-raster", res="3840x2160", steps=8, spg=8)
+    coll = _bench("--no-raster", "--force-collectives", res="3840x2160", steps=8, spg=8)
+    assert coll["config"]["history_crc32"] == plain["config"]["history_crc32"] and coll["config"]["rays_per_step"] == plain["config"]["rays_per_step"]
+    g = coll["config"]["gather"]
+    assert g["gathers"] == 1 and g["bytes_gathered"] == 3840 * 2160 * 4 and 0.0 < g["gather_ms"] < 5.0, g
+    assert "gather" not in plain["config"]
+    print("4K gather: %.3f ms for %.1f MB" % (g["gather_ms"], g["bytes_gathered"] / 1e6))
+
+
+def test_eight_shards_of_the_4k_frame(gpu_ctx, rt, sio, synth, A):
+    """tools/shard_emulation.py as a test: the 4K frame rendered as the 8 framebuffer shards of an 8-GPU run (incr_shard{8, r, 8}) -- every shard's history and target
+    rows are the full frame's rows bit for bit, and with 8 samples in flight a shard takes less than a sixth of the full frame's time per sample (the compute-only
+    projection of the north star's >= 6x at 8 GPUs; measured x7.8).  One GPU: the shards run one after the other."""
+    import ctypes as C
+    import time
+    W, H, S = 3840, 2160, 8
+    scene = synth.sponza_stat(texture_size=64)
+    view = sio.FView().reset(scene, aspect=W / H)
+    sc = gpu_ctx.create_scene(scene)
+    try:
+        def run(shard, samples, steps):
+            pt = rt.PathTracer(gpu_ctx, sc, W, H, shard=shard)
+            pt.render(view, 1, num_samples=samples, count_rays=False)          # sample 1 (.. S): what is compared, and the warm-up of the timed calls
+            first = pt.read()
+            gpu_ctx.synchronize()
+            t0 = time.perf_counter()
+            n = 1 + samples
+            for _ in range(steps):
+                pt.render(view, n, num_samples=samples, count_rays=False); n += samples
+            gpu_ctx.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / (steps * samples)
+            pt.close()
+            return first, ms
+        full1, _ = run(None, 1, 1)
+        fullS, full_ms = run(None, 1, 6)                     # the full frame at one sample per call: what one GPU does
+        worst = 0.0
+        for r in range(8):
+            rows = np.concatenate([np.arange(b * 8, min(b * 8 + 8, H)) for b in range(r, (H + 7) // 8, 8)])
+            one, _ = run(A.Shard(8, r, 8), 1, 1)
+            assert one["history"].shape[0] == 272 and len(rows) in (264, 272)          # every rank holds 34 blocks; the last one of ranks 6 and 7 is padding (cleared)
+            np.testing.assert_array_equal(one["history"][:len(rows)], full1["history"][rows], err_msg="shard %d history" % r)
+            np.testing.assert_array_equal(one["target"][:len(rows)], full1["target"][rows], err_msg="shard %d target" % r)
+            assert not one["target"][len(rows):].any()
+            _, ms = min((run(A.Shard(8, r, 8), S, 3) for _ in range(2)), key=lambda t: t[1])
+            worst = max(worst, ms)
+        print("full frame %.2f ms per sample, slowest 1/8 shard with %d samples in flight %.2f ms per sample: projected x%.2f" % (full_ms, S, worst, full_ms / worst))
+        assert full_ms / worst >= 6.0, (full_ms, worst)
+    finally:
+        sc.close()
 
 
 # ------------------------------------------------------------------------------------------------ raster ids at config 3's real size

@@ -17,9 +17,8 @@ DI f3 sample2d_bilinear_wrap(const uint32_t* __restrict__ img, uint32_t W, uint3
     float u = uv.x - floorf(uv.x), v = uv.y - floorf(uv.y);
     if (!(u >= 0.f && u <= 1.f)) u = 0.f;
     if (!(v >= 0.f && v <= 1.f)) v = 0.f;
-    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;                      // u, v in [0, 1] => floor in [-1, W - 1]: wrap without integer division
+    int x0, y0; float fx, fy;
+    linear_address(u * (float)W, &x0, &fx); linear_address(v * (float)H, &y0, &fy);                      // u, v in [0, 1] => floor in [-1, W - 1]: wrap without integer division
     x0 = x0 < 0 ? x0 + (int)W : x0; y0 = y0 < 0 ? y0 + (int)H : y0;
     const int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
     const f3 t00 = unpack_r11g11b10(img[(size_t)y0 * W + x0]), t10 = unpack_r11g11b10(img[(size_t)y0 * W + x1]);
@@ -33,9 +32,8 @@ DI f3 sample2d_bilinear_wrap(const float4* __restrict__ img, uint32_t W, uint32_
     float u = uv.x - floorf(uv.x), v = uv.y - floorf(uv.y);
     if (!(u >= 0.f && u <= 1.f)) u = 0.f;
     if (!(v >= 0.f && v <= 1.f)) v = 0.f;
-    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;
+    int x0, y0; float fx, fy;
+    linear_address(u * (float)W, &x0, &fx); linear_address(v * (float)H, &y0, &fy);
     x0 = x0 < 0 ? x0 + (int)W : x0; y0 = y0 < 0 ? y0 + (int)H : y0;
     const int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
     const float4 a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1], c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
@@ -101,9 +99,9 @@ DI f3 cube_sample_level(const CubeChain& c, f3 dir, uint32_t level) {
     if (!(v == v)) v = 0.f;
     const uint32_t n = mip_dim(c.N, level);
     const uint32_t* __restrict__ lvl = c.data + mip_offset_cube(c.N, level);
-    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;                  // u, v in [0, 1]: x, y in [-0.5, n - 0.5]
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;             // x0 in [-1, n - 1], x1 in [0, n]
+    int x0, y0; float fx, fy;                                                      // u, v in [0, 1]: x0 in [-1, n - 1], x1 in [0, n]
+    linear_address(u * (float)n, &x0, &fx); linear_address(v * (float)n, &y0, &fy);
+    const int x1 = x0 + 1, y1 = y0 + 1;
     f3 t00, t10, t01, t11;
     if (x0 >= 0 && y0 >= 0 && x1 < (int)n && y1 < (int)n) {                         // the footprint lies inside the face
         const uint32_t* __restrict__ img = lvl + (size_t)face * n * n;

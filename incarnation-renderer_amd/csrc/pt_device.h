@@ -366,7 +366,15 @@ DI f4 decode_texel(const float* __restrict__ srgbLut, uint32_t format, uint32_t 
     default:                        return {(float)r * inv255, (float)g * inv255, (float)b * inv255, (float)a * inv255};
     }
 }
-// Bilinear, wrap, texel centre + 0.5, float weights, on level `level` of a texture's mip chain (levels packed one after the
+// LINEAR SAMPLE ADDRESSING (round 5; D3D11.3 functional spec 7.18.8): the scaled texel coordinate is snapped to fixed point with 8 fractional bits (round to
+// nearest even), half a texel is subtracted THERE, the integer part names the left / upper texel and the 8 fractional bits are the weight: w = f / 256 and
+// 1 - w = (256 - f) / 256, both exact floats.  Rounds 1-4 used the float fraction x - floor(x): further from what a texture unit does, and a weight that the
+// oracle's CPU and the device had to agree on to the last ulp.  Every linear filter of the library goes through this: 2-D textures (wrap and clamp), the
+// lat-long sky, the cube maps, the LUTs.  linear_split: the same on a coordinate that was clamped in fixed point.
+DI void linear_split(int xi, int* i0, float* w) { *i0 = xi >> 8; *w = (float)(xi & 255) * 0.00390625f; }
+DI int linear_fixed(float scaled) { return __float2int_rn(scaled * 256.f) - 128; }
+DI void linear_address(float scaled, int* i0, float* w) { linear_split(linear_fixed(scaled), i0, w); }
+// Bilinear, wrap, texel centre + 0.5, 8-bit fixed-point weights (linear_address), on level `level` of a texture's mip chain (levels packed one after the
 // other behind level 0; level l is max(W >> l, 1) x max(H >> l, 1)).
 DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgbLut, uint32_t level, f2 uv) {
     int W = (int)t.width, H = (int)t.height;
@@ -375,12 +383,10 @@ DI f4 SampleBilinearLevel(const DeviceTexture& t, const float* __restrict__ srgb
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
-    float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
-    float x0f = floorf(x), y0f = floorf(y);
-    float fx = x - x0f, fy = y - y0f;
-    // wrap: fu, fv are in [0, 1], so floor(x) is in [-1, W - 1] -- two compares instead of four integer divisions by a run-time W
+    int x0, y0; float fx, fy;
+    linear_address(fu * (float)W, &x0, &fx); linear_address(fv * (float)H, &y0, &fy);
+    // wrap: fu, fv are in [0, 1], so the left texel is in [-1, W - 1] -- two compares instead of four integer divisions by a run-time W
     // (~40 VALU instructions each; this function runs 3-10 times per shaded hit / G-buffer pixel)
-    int x0 = (int)x0f, y0 = (int)y0f;
     x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
     const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     const uint32_t* __restrict__ px = (const uint32_t*)t.texels + off;
@@ -460,10 +466,8 @@ DI BilinearTap bilinear_tap(int W, int H, size_t off, f2 uv) {
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
-    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y);
-    BilinearTap t; t.fx = x - x0f; t.fy = y - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;
+    BilinearTap t; int x0, y0;
+    linear_address(fu * (float)W, &x0, &t.fx); linear_address(fv * (float)H, &y0, &t.fy);
     x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
     const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     const uint32_t o = (uint32_t)off;
@@ -615,10 +619,8 @@ DI Level0Tap level0_tap(const DeviceTexture& t, f2 uv) {
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
-    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y);
-    a.fx = x - x0f; a.fy = y - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;                      // wrap without integer division, as in SampleBilinearLevel
+    int x0, y0;                                            // wrap without integer division, as in SampleBilinearLevel
+    linear_address(fu * (float)W, &x0, &a.fx); linear_address(fv * (float)H, &y0, &a.fy);
     x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
     const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     a.px = (const uint32_t*)t.texels; a.format = t.format; a.W = W;
@@ -645,10 +647,9 @@ DI MatProps EvaluateMaterialPropertiesInterleaved(const incr_material& mat, cons
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
-    const float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y);
-    const float fx = x - x0f, fy = y - y0f, wx0 = 1.f - fx, wy0 = 1.f - fy;
-    int x0 = (int)x0f, y0 = (int)y0f;
+    int x0, y0; float fx, fy;
+    linear_address(fu * (float)W, &x0, &fx); linear_address(fv * (float)H, &y0, &fy);
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
     const int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     const uint2* __restrict__ px = (const uint2*)mt.texels;

@@ -734,10 +734,12 @@ DI f2 sample_rg16f_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, 
     float u = uv.x, v = uv.y;
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
-    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    x = fminf(fmaxf(x, 0.f), (float)(W - 1)); y = fminf(fmaxf(y, 0.f), (float)(H - 1));
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    // CLAMP: the fixed-point coordinate (pt_device.h linear_address) held inside [0, W - 1] texel centres; a NaN or out-of-range float saturates in the conversion
+    u = fminf(fmaxf(u, 0.f), 1.f); v = fminf(fmaxf(v, 0.f), 1.f);
+    int xi = linear_fixed(u * (float)W), yi = linear_fixed(v * (float)H), x0i, y0i; float fx, fy;
+    xi = min(max(xi, 0), (int)(W - 1) * 256); yi = min(max(yi, 0), (int)(H - 1) * 256);
+    linear_split(xi, &x0i, &fx); linear_split(yi, &y0i, &fy);
+    const uint32_t x0 = (uint32_t)x0i, y0 = (uint32_t)y0i, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
     const uint32_t a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1], c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
     const f2 t00 = {f16_bits_to_f32(a & 0xffffu), f16_bits_to_f32(a >> 16)}, t10 = {f16_bits_to_f32(b & 0xffffu), f16_bits_to_f32(b >> 16)};
     const f2 t01 = {f16_bits_to_f32(c & 0xffffu), f16_bits_to_f32(c >> 16)}, t11 = {f16_bits_to_f32(d & 0xffffu), f16_bits_to_f32(d >> 16)};
@@ -1466,11 +1468,12 @@ DI f3 sample_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, uint32
     float u = uv.x, v = uv.y;
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
-    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    x = fminf(fmaxf(x, -1.f), (float)W); y = fminf(fmaxf(y, -1.f), (float)H);
-    const float x0f = floorf(x), y0f = floorf(y);
-    const float fx = x - x0f, fy = y - y0f;
-    const int x0 = clampi((int)x0f, (int)W), x1 = clampi((int)x0f + 1, (int)W), y0 = clampi((int)y0f, (int)H), y1 = clampi((int)y0f + 1, (int)H);
+    // the coordinate clamped to one texel beyond the frame on either side, in fixed point (pt_device.h linear_address), the texel indices clamped to the frame
+    u = fminf(fmaxf(u, -2.f), 3.f); v = fminf(fmaxf(v, -2.f), 3.f);
+    int xi = linear_fixed(u * (float)W), yi = linear_fixed(v * (float)H), xf, yf; float fx, fy;
+    xi = min(max(xi, -256), (int)W * 256); yi = min(max(yi, -256), (int)H * 256);
+    linear_split(xi, &xf, &fx); linear_split(yi, &yf, &fy);
+    const int x0 = clampi(xf, (int)W), x1 = clampi(xf + 1, (int)W), y0 = clampi(yf, (int)H), y1 = clampi(yf + 1, (int)H);
     const f3 t00 = load_hdr(img, W, H, x0, y0), t10 = load_hdr(img, W, H, x1, y0), t01 = load_hdr(img, W, H, x0, y1), t11 = load_hdr(img, W, H, x1, y1);
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;

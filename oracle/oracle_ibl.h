@@ -24,9 +24,9 @@ static float3 sample2d_bilinear_wrap(const TEXEL* img, uint32_t W, uint32_t H, f
     float u = uv.x - floorf(uv.x), v = uv.y - floorf(uv.y);
     if (!(u >= 0.f && u <= 1.f)) u = 0.f;
     if (!(v >= 0.f && v <= 1.f)) v = 0.f;
-    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const int x0 = (((int)x0f % (int)W) + (int)W) % (int)W, y0 = (((int)y0f % (int)H) + (int)H) % (int)H;
+    int xl, yl; float fx, fy;
+    linear_address(u * (float)W, &xl, &fx); linear_address(v * (float)H, &yl, &fy);
+    const int x0 = ((xl % (int)W) + (int)W) % (int)W, y0 = ((yl % (int)H) + (int)H) % (int)H;
     const int x1 = (x0 + 1) % (int)W, y1 = (y0 + 1) % (int)H;
     const float3 t00 = load_radiance(img, (size_t)y0 * W + x0), t10 = load_radiance(img, (size_t)y0 * W + x1);
     const float3 t01 = load_radiance(img, (size_t)y1 * W + x0), t11 = load_radiance(img, (size_t)y1 * W + x1);
@@ -85,9 +85,9 @@ static float3 cube_sample_level(const CubeChain& c, float3 dir, uint32_t level) 
     if (!(v == v)) v = 0.f;
     const uint32_t n = std::max(c.N >> level, 1u);
     const uint32_t* lvl = c.data + mip_offset_cube(c.N, level);
-    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const int xs[2] = {(int)x0f, (int)x0f + 1}, ys[2] = {(int)y0f, (int)y0f + 1};
+    int xl, yl; float fx, fy;
+    linear_address(u * (float)n, &xl, &fx); linear_address(v * (float)n, &yl, &fy);
+    const int xs[2] = {xl, xl + 1}, ys[2] = {yl, yl + 1};
     float3 t[2][2]; bool missing[2][2]; bool anyMissing = false;
     for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
         const bool offX = xs[i] < 0 || xs[i] >= (int)n, offY = ys[j] < 0 || ys[j] >= (int)n;

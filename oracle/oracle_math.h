@@ -62,6 +62,12 @@ static inline float3 normalize(float3 v) { const float r = 1.f / sqrtf(dot(v, v)
 static inline float hmax(float a, float b) { return fmaxf(a, b); }
 static inline float hmin(float a, float b) { return fminf(a, b); }
 static inline float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+// LINEAR SAMPLE ADDRESSING (D3D11.3 functional spec 7.18.8; pinned in round 5): the scaled texel coordinate snapped to fixed point with 8
+// fractional bits (round to nearest even: lrintf under the default rounding mode), half a texel subtracted there; integer part = the left / upper texel, the
+// 8 fractional bits = the weight f / 256 (and 1 - w = (256 - f) / 256: both exact).  Every linear filter of the oracle goes through it.
+static inline void linear_split(int xi, int* i0, float* w) { *i0 = xi >> 8; *w = (float)(xi & 255) * 0.00390625f; }
+static inline int linear_fixed(float scaled) { return (int)lrintf(scaled * 256.f) - 128; }
+static inline void linear_address(float scaled, int* i0, float* w) { linear_split(linear_fixed(scaled), i0, w); }
 static inline float3 saturate(float3 v) { return {saturate(v.x), saturate(v.y), saturate(v.z)}; }
 // HLSL reflect(i, n) = i - 2 * n * dot(i, n)
 static inline float3 reflect(float3 i, float3 n) { float d = dot(i, n); return i - (2.f * n) * d; }

@@ -292,10 +292,9 @@ static float4 SampleBilinearLevel(const Scene& s, int texIndex, uint32_t level, 
     float fu = uv.x - floorf(uv.x), fv = uv.y - floorf(uv.y);
     if (!(fu >= 0.f && fu <= 1.f)) fu = 0.f;      // NaN / inf coordinates sample texel (0,0)
     if (!(fv >= 0.f && fv <= 1.f)) fv = 0.f;
-    float x = fu * (float)W - 0.5f, y = fv * (float)H - 0.5f;
-    float x0f = floorf(x), y0f = floorf(y);
-    float fx = x - x0f, fy = y - y0f;
-    int x0 = ((int)x0f + W) % W, y0 = ((int)y0f + H) % H;
+    int xl, yl; float fx, fy;
+    linear_address(fu * (float)W, &xl, &fx); linear_address(fv * (float)H, &yl, &fy);
+    int x0 = (xl + W) % W, y0 = (yl + H) % H;
     int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
     const uint32_t fmt = s.texFormat[(size_t)texIndex];
     float4 t00 = decode_texel_word(s, fmt, px[(size_t)y0 * W + x0]), t10 = decode_texel_word(s, fmt, px[(size_t)y0 * W + x1]);

@@ -718,10 +718,11 @@ static float2 sample_rg16f_bilinear_clamp(const uint32_t* img, uint32_t W, uint3
     float u = uv.x, v = uv.y;
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
-    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    x = fminf(fmaxf(x, 0.f), (float)(W - 1)); y = fminf(fmaxf(y, 0.f), (float)(H - 1));
-    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
-    const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f, x1 = std::min(x0 + 1, W - 1), y1 = std::min(y0 + 1, H - 1);
+    u = fminf(fmaxf(u, 0.f), 1.f); v = fminf(fmaxf(v, 0.f), 1.f);
+    int xi = linear_fixed(u * (float)W), yi = linear_fixed(v * (float)H), x0i, y0i; float fx, fy;          // CLAMP in fixed point: [0, W - 1] texel centres
+    xi = std::min(std::max(xi, 0), (int)(W - 1) * 256); yi = std::min(std::max(yi, 0), (int)(H - 1) * 256);
+    linear_split(xi, &x0i, &fx); linear_split(yi, &y0i, &fy);
+    const uint32_t x0 = (uint32_t)x0i, y0 = (uint32_t)y0i, x1 = std::min(x0 + 1, W - 1), y1 = std::min(y0 + 1, H - 1);
     auto ld = [&](uint32_t xx, uint32_t yy) -> float2 { const uint32_t t = img[(size_t)yy * W + xx]; return {f16_to_f32((uint16_t)(t & 0xffffu)), f16_to_f32((uint16_t)(t >> 16))}; };
     const float2 t00 = ld(x0, y0), t10 = ld(x1, y0), t01 = ld(x0, y1), t11 = ld(x1, y1);
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
@@ -996,12 +997,12 @@ static float3 sample_bilinear_clamp(const uint32_t* img, uint32_t W, uint32_t H,
     float u = uv.x, v = uv.y;
     if (!(u == u)) u = 0.f;
     if (!(v == v)) v = 0.f;
-    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    x = fminf(fmaxf(x, -1.f), (float)W); y = fminf(fmaxf(y, -1.f), (float)H);
-    const float x0f = floorf(x), y0f = floorf(y);
-    const float fx = x - x0f, fy = y - y0f;
+    u = fminf(fmaxf(u, -2.f), 3.f); v = fminf(fmaxf(v, -2.f), 3.f);
+    int xi = linear_fixed(u * (float)W), yi = linear_fixed(v * (float)H), xf, yf; float fx, fy;          // one texel beyond the frame on either side, in fixed point
+    xi = std::min(std::max(xi, -256), (int)W * 256); yi = std::min(std::max(yi, -256), (int)H * 256);
+    linear_split(xi, &xf, &fx); linear_split(yi, &yf, &fy);
     auto cl = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
-    const int x0 = cl((int)x0f, (int)W), x1 = cl((int)x0f + 1, (int)W), y0 = cl((int)y0f, (int)H), y1 = cl((int)y0f + 1, (int)H);
+    const int x0 = cl(xf, (int)W), x1 = cl(xf + 1, (int)W), y0 = cl(yf, (int)H), y1 = cl(yf + 1, (int)H);
     const float3 t00 = load_hdr(img, W, H, x0, y0), t10 = load_hdr(img, W, H, x1, y0), t01 = load_hdr(img, W, H, x0, y1), t11 = load_hdr(img, W, H, x1, y1);
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     return (t00 * wx0 + t10 * fx) * wy0 + (t01 * wx0 + t11 * fx) * fy;

@@ -556,6 +556,9 @@ DI float trilinear_alpha_quads_at(const DeviceTexture& t, const LevelPair& L, f2
 // a + (b - a) frac >= 0 for frac < 1), so a partial sum >= n / 2 (exact in float for n <= 16) keeps fl(sum / n) >= 0.5 by the
 // monotonicity of the rounded sum and division; and no tap exceeds 1 by more than a few ulp, so a partial sum that cannot reach
 // 0.49999 n even if every remaining tap read 1.00001 ends below 0.5.
+#ifndef INCR_ALPHA_TAP_BATCH
+#define INCR_ALPHA_TAP_BATCH 2
+#endif
 DI bool AlphaTestGrad(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy, uint32_t maxAniso) {
     if (!format_has_alpha(t.format)) return true;          // every texel decodes to alpha 1: any filter of ones stays above 0.5
     const Footprint fp = texture_footprint(t, ddx, ddy, maxAniso);
@@ -565,6 +568,36 @@ DI bool AlphaTestGrad(const DeviceTexture& t, f2 uv, f2 ddx, f2 ddy, uint32_t ma
     if (fp.taps == 1u) return !(tap(uv) - 0.5f < 0.f);
     const float n = (float)fp.taps;
     float sum = 0.f;
+#if INCR_ALPHA_TAP_BATCH > 1
+    if (quads) {
+        // FOUR TAPS PER ROUND TRIP (round 5).  The loop below is a chain of dependent memory round trips -- a tap's texels, then the decision whether the next tap is needed -- and
+        // the visibility scan is made of such chains: a band item of foliage is 32 tiles x up to 16 round trips of ~1 us on ONE wave while the rest of the grid has
+        // finished (PMC, round 4: the average wave lives a third of the launch).  Here the quad words of up to four taps are fetched together and then summed in the
+        // same order with the same two exits after every tap: the same decision, a quarter of the round trips.  (Taps beyond the line's count re-read the last
+        // one's address and are not summed.)
+        const uint32_t* __restrict__ px = (const uint32_t*)t.texels;
+        for (uint32_t i = 1u; i <= fp.taps; i += (uint32_t)INCR_ALPHA_TAP_BATCH) {
+            BilinearTap ka[INCR_ALPHA_TAP_BATCH], kb[INCR_ALPHA_TAP_BATCH]; uint32_t qa[INCR_ALPHA_TAP_BATCH], qb[INCR_ALPHA_TAP_BATCH];
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)INCR_ALPHA_TAP_BATCH; ++k) {
+                const float o = tap_offset(min(i + k, fp.taps), fp.taps);
+                const f2 st = {uv.x + fp.axis.x * o, uv.y + fp.axis.y * o};
+                ka[k] = bilinear_tap(L.W0, L.H0, L.off0, st); kb[k] = bilinear_tap(L.W1, L.H1, L.off1, st);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)INCR_ALPHA_TAP_BATCH; ++k) { qa[k] = px[ka[k].i00]; qb[k] = px[kb[k].i00]; }
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)INCR_ALPHA_TAP_BATCH; ++k) {
+                if (i + k > fp.taps) break;
+                const float a = bilinear_alpha_quad(ka[k], qa[k]);
+                sum += L.two ? a + (bilinear_alpha_quad(kb[k], qb[k]) - a) * L.frac : a;
+                if (sum >= 0.5f * n) return true;
+                if (sum + (float)(fp.taps - (i + k)) * 1.00001f < 0.49999f * n) return false;
+            }
+        }
+        return !(sum / n - 0.5f < 0.f);
+    }
+#endif
     for (uint32_t i = 1u; i <= fp.taps; ++i) {
         const float o = tap_offset(i, fp.taps);
         sum += tap({uv.x + fp.axis.x * o, uv.y + fp.axis.y * o});

@@ -225,6 +225,11 @@ DI const float4* node_ptr(const PtParams& P, uint32_t node) { return (const floa
 DI const float4* tri_ptr(const PtParams& P, uint32_t tri) { return (const float4*)((const char*)P.tris + (size_t)tri_byte_offset(tri)); }
 // (Same box, ms per 4K frame with every kernel alone, shadow / extend: 64-bit addresses 7.36 / 6.93; these 7.05 / 6.89; the offsets as inline shift-adds 7.25 / 6.89:
 //  profiles/r04_ab_lane_fill.txt.)
+// (Round 5, measured and removed: the LDS branch and the memory branch below write the same registers, so the compiler makes every ds_read of the LDS branch wait for ALL the
+//  memory loads of the other lanes -- s_waitcnt vmcnt(0) in front of it: a lane served from LDS pays the memory latency and then an LDS round trip.  Issuing the LDS reads FIRST, then
+//  the triangle loads, then the other lanes' node loads removes that wait, but the register allocation it produces puts the ds_read results where the refill's visibility store keeps
+//  its address, and the store's hazard becomes a vmcnt(0) in front of the step that also waits for the refill's queue loads -- the software pipelining of wf_shadow_kernel is gone:
+//  any-hit 7.77-7.86 ms per frame alone against 7.34-7.62, closest-hit unchanged, frame 16.70-16.76 against 16.52-16.58 ms: profiles/r05_ab_fetch_order.txt.)
 struct Fetch5 { float4 a, b, c, d, e; };
 template <class ST> DI Fetch5 fetch_step(const PtParams& P, const ST& st, uint32_t cur, uint32_t triBase, uint32_t triMask) {
     Fetch5 f;

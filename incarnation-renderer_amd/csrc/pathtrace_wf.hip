@@ -83,7 +83,7 @@ template <int N, bool SHADOW> struct TravCfg {
     static constexpr int kWaves = SHADOW ? (N <= 16 ? INCR_SHADOW_WAVES : 6) : (N <= 8 ? INCR_EXTEND_WAVES : (N <= 10 ? INCR_EXTEND_WAVES10 : (N <= 12 ? 6 : (N <= 16 ? 4 : 3))));      // waves per SIMD (VGPRs, LDS stack bytes)
     static constexpr int kBlocksPerCU = (kWaves * 4) % INCR_TRAV_BLOCKS_PER_CU == 0 ? INCR_TRAV_BLOCKS_PER_CU : kWaves;
     static constexpr int kBlock = kWaves * 256 / kBlocksPerCU;                  // threads per workgroup
-    static constexpr int kStackBytes = N * kBlock * 4 * (SHADOW ? 1 : 2);       // entries, and keys for the closest-hit kernel
+    static constexpr int kStackBytes = N * kBlock * (SHADOW ? 4 : 6);           // 32-bit entries; the closest-hit kernel's 16-bit keys beside them (pt_traverse.h LaneStackT)
     static constexpr int kLdsBudget = 163840 / kBlocksPerCU - 1024;             // 160 KB per CU; 1 KB for allocation granularity
     static constexpr uint32_t kTop = (uint32_t)((kLdsBudget - kStackBytes) / 80 < 8 ? 8 : (kLdsBudget - kStackBytes) / 80);      // hottest nodes kept in LDS (80 B each)
     static_assert(kBlock % 64 == 0 && kBlock <= 1024, "traversal workgroup: whole waves, at most 16");
@@ -342,7 +342,7 @@ extern "C" int incr_debug_lane_stats(unsigned long long* out16) {
 template <int N> __global__ __launch_bounds__((TravCfg<N, false>::kBlock), (TravCfg<N, false>::kWaves)) void wf_extend_kernel(const PtParams P, const WfBuffers B, int bounce, uint32_t chunkSize) {
     typedef TravCfg<N, false> Cfg;
     __shared__ uint32_t s_stack[N * Cfg::kBlock];
-    __shared__ float s_keys[N * Cfg::kBlock];
+    __shared__ uint16_t s_keys[N * Cfg::kBlock];
     __shared__ float4 s_top[Cfg::kTop * 5];
     const uint32_t total = B.counters[bounce];
     // a workgroup whose first wave has no static chunk has none at all (WaveChunk::init_static) and never takes one from the cursor: it leaves

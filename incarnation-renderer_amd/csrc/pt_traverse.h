@@ -39,18 +39,21 @@ struct LaneStackT {
     DI void bind_top(const float4* ldsNodes, uint32_t count) { topNodes = (LdsNodes)ldsNodes; topCount = count; }
     // explicit LDS address space: through a generic pointer the pushes/pops compile to flat_* instructions
     __attribute__((address_space(3))) uint32_t* lds;      // &stack[0][tid]
-    __attribute__((address_space(3))) float* ldsKey;      // &keys[0][tid]   (KEYED only)
-    DI void bind(uint32_t* stackBase, float* keyBase) {
+    // KEYED only: &keys[0][tid].  A key is kept as the UPPER 16 BITS of its float (round 5): entry distances are positive, so truncation rounds down and the key stays a
+    // lower bound -- a group is dropped a little later at worst, the hit found is the same -- and the closest-hit kernel's stack takes 6 bytes per entry instead of 8: the
+    // LDS it gives back holds 87 hot nodes per workgroup instead of 23 (pathtrace_wf.hip TravCfg).
+    __attribute__((address_space(3))) uint16_t* ldsKey;
+    DI void bind(uint32_t* stackBase, uint16_t* keyBase) {
         lds = (__attribute__((address_space(3))) uint32_t*)stackBase;
-        ldsKey = (__attribute__((address_space(3))) float*)keyBase;
+        ldsKey = (__attribute__((address_space(3))) uint16_t*)keyBase;
     }
     int sp;
     DI void reset() { sp = 0; }
     DI void push(uint32_t v, float key = 0.f) {
-        if (sp < NLDS) { lds[sp * STRIDE] = v; if constexpr (KEYED) ldsKey[sp * STRIDE] = key; ++sp; }      // sp == NLDS: unreachable for a checked tree
+        if (sp < NLDS) { lds[sp * STRIDE] = v; if constexpr (KEYED) ldsKey[sp * STRIDE] = (uint16_t)(__float_as_uint(key) >> 16); ++sp; }      // sp == NLDS: unreachable for a checked tree
     }
     DI uint32_t top() const { return lds[(sp - 1) * STRIDE]; }
-    DI float topKey() const { return ldsKey[(sp - 1) * STRIDE]; }
+    DI float topKey() const { return __uint_as_float((uint32_t)ldsKey[(sp - 1) * STRIDE] << 16); }
     DI void setTop(uint32_t v) { lds[(sp - 1) * STRIDE] = v; }
     DI void drop() { --sp; }
 };

@@ -21,6 +21,10 @@ for rep in $(seq ${REPS:-2}); do
     cp /tmp/ab/$(basename $v).so $C/libincr_hip.so
     r=$(cd $GRAFT_REPO_ROOT && timeout -k 10 200 python bench.py --no-cpu-baseline --no-raster --steps 16 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
     h=$(cd $GRAFT_REPO_ROOT && timeout -k 10 200 python bench.py --no-cpu-baseline --no-raster --scene helmet --res 1920x1080 --steps 64 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])")
-    echo "[$v] 4K: $r   helmet 1080p: $h ms"
+    a=$(cd $GRAFT_REPO_ROOT && timeout -k 10 200 python bench.py --no-cpu-baseline --no-raster --steps 8 --warmup 2 --pipelines 1 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']
+print('alone: shadow %.3f extend %.3f shade %.3f' % (k['wf_shadow_kernel'], k['wf_extend_kernel'], k['wf_shade_kernel']))")
+    echo "[$v] 4K: $r   helmet 1080p: $h ms   $a"
   done
 done

@@ -306,7 +306,11 @@ DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVer
 }
 DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, long long E01, long long E12, long long E20) {
     if (E01 + st.bias[0] < 0 || E12 + st.bias[1] < 0 || E20 + st.bias[2] < 0) return;
+#ifdef INCR_DIAG_F32_DEPTH       // diagnostic only (not bit-exact): the weights in single precision
+    const float l1 = (float)E20 * (float)st.area, l2 = (float)E01 * (float)st.area;
+#else
     const float l1 = (float)((double)E20 * st.area), l2 = (float)((double)E01 * st.area);
+#endif
     float depth = (st.z0 + l1 * st.dz1) + l2 * st.dz2;
     if (!(depth >= 0.f)) return;
     if (depth > 1.f) depth = 1.f;
@@ -314,7 +318,12 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
     // between the two draw lists, and the id keeps all of its 32 bits (EncodePrimitiveVisibility uses every one: 12 + 20)
     const unsigned long long v = ((unsigned long long)__float_as_uint(depth) << 34) | ((unsigned long long)st.list << 33) | ((unsigned long long)st.key + 1ull);
     unsigned long long* dst = P.packed + (size_t)py * P.W + px;
-    if (st.alphaTex >= 0) {                                        // ps_meshlet_main: clip(opacity - 0.5)
+#ifndef INCR_DIAG_NO_ALPHA       // diagnostic only: every triangle scanned as opaque
+    if (st.alphaTex >= 0)
+#else
+    if (false)
+#endif
+    {                                                              // ps_meshlet_main: clip(opacity - 0.5)
         // values only grow: a fragment that loses now loses for good -- worth a load before the texture sample (fetching the surface
         // word and the texels together was measured: +0.16 ms per frame, most alpha fragments lose here).  Opaque fragments skip
         // the check: the atomic is fire-and-forget, a load would put a memory round trip into every step.
@@ -325,7 +334,13 @@ DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, l
         const UvGrad g = quad_uv_gradient(st.bs, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
         if (!AlphaTestGrad(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy, P.S.maxAnisotropy)) return;
     }
+#if defined(INCR_DIAG_NO_ATOMIC)     // diagnostic only: the fragment's arithmetic without its atomic
+    if (v == 0x123456789abcull) *dst = v;
+#elif defined(INCR_DIAG_STORE)       // diagnostic only: a plain store in the atomic's place
+    *dst = v;
+#else
     atomicMax(dst, v);
+#endif
 }
 DI void raster_serial(const VisParams& P, const SubTri& st) {
     long long r0 = st.e[0], r1 = st.e[1], r2 = st.e[2];
@@ -352,6 +367,9 @@ DI void raster_coop(const VisParams& P, const SubTri& st, uint32_t lane) {
                 const long long hi = base[k] + (st.sx[k] > 0 ? 7 * st.sx[k] : 0) + (st.sy[k] > 0 ? 7 * st.sy[k] : 0) + st.bias[k];
                 reject = reject || hi < 0;
             }
+#if defined(INCR_DIAG_VIS_COUNT) && INCR_DIAG_VIS_COUNT >= 2       // (1.7 M same-address atomics: distorts the cycle counts of level 1)
+            if (lane == 0) atomicAdd(P.vqCounters + (reject ? 17 : 16), 1u);
+#endif
             if (reject) continue;
             const int32_t px = ox + lx, py = oy + ly;
             if (px <= st.px1 && py <= st.py1)
@@ -570,32 +588,97 @@ DI bool qw_next(QueueWalk& q, uint32_t* __restrict__ cursor, uint32_t n, uint32_
     *out = q.cur; q.cur += step;
     return true;
 }
+// The band queue's walk: static first entry like the others, then STRIPED cursors -- one cursor for the whole queue was the scan's largest single cost (72 K band items
+// on the 4K Sponza-stat frame: an atomic per item 1.05 ms for the pass, per two items 0.69, per eight 0.54 with the alpha test compiled out, ~11 ns per same-address
+// atomic; profiles/r05_ab_vis_cursor.txt), and large grabs leave the foliage's expensive items to a few waves.  A wave draws from its home segment (workgroup index
+// modulo the stripe count) and moves on to the next when that one is used up; a segment found empty is never asked again.
+struct BandWalk { uint32_t cur, end, stripe, tried, dynBase, segLen; bool done; };
+DI void bw_init(BandWalk& q, uint32_t n) {
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    q.cur = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    q.end = q.cur + 1u; q.done = q.cur >= n;
+    q.stripe = blockIdx.x % (uint32_t)INCR_VIS_STRIPES; q.tried = 0u;
+    q.dynBase = min(waves, n);
+    q.segLen = (n - q.dynBase + (uint32_t)INCR_VIS_STRIPES - 1u) / (uint32_t)INCR_VIS_STRIPES;
+}
+DI bool bw_next(BandWalk& q, uint32_t* __restrict__ counters, uint32_t n, uint32_t grab, uint32_t* out) {
+    if (q.done) return false;
+    if (q.cur >= q.end) {
+        for (;;) {
+            if (q.tried >= (uint32_t)INCR_VIS_STRIPES || q.segLen == 0u) { q.done = true; return false; }
+            uint32_t b = 0;
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counters + 64u + q.stripe * 32u, grab);
+            b = __builtin_amdgcn_readfirstlane(b);
+            const uint32_t segBegin = q.dynBase + q.stripe * q.segLen;
+            if (b < q.segLen && segBegin + b < n) { q.cur = segBegin + b; q.end = min(min(q.cur + grab, segBegin + q.segLen), n); break; }
+            ++q.tried; q.stripe = q.stripe + 1u == (uint32_t)INCR_VIS_STRIPES ? 0u : q.stripe + 1u;
+        }
+    }
+    *out = q.cur++;
+    return true;
+}
 __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
     QueueWalk q;
-    qw_init(q, nBig, 1u);
+    BandWalk bq;
+    bw_init(bq, nBig);
 #ifndef INCR_VIS_GRAB
-#define INCR_VIS_GRAB 2      // band items per atomic on the cursor: raster frame 2.56 / 2.52 / 2.82 ms at 4 / 2 / 1 with the 32-tile alpha items (4 was the choice with 64-tile items)
+#define INCR_VIS_GRAB 2      // band items per atomic on a segment's cursor
 #endif
-    for (uint32_t i; qw_next(q, P.vqCounters + 4, nBig, 1u, (uint32_t)INCR_VIS_GRAB, &i);) {          // band items
+#ifdef INCR_DIAG_VIS_COUNT
+    const long long diagT0 = clock64(), diagW0 = wall_clock64(); long long diagItemMax = 0, diagPrev = diagT0, diagSetup = 0, diagQueue = 0, diagCursor = 0, diagTop = diagT0; uint32_t diagItems = 0;
+#endif
+#ifdef INCR_DIAG_NO_BAND         // diagnostic only: the scan without its band items
+    bq.done = true;
+#endif
+    for (uint32_t i; bw_next(bq, P.vqCounters, nBig, (uint32_t)INCR_VIS_GRAB, &i);) {          // band items
+#ifdef INCR_DIAG_VIS_COUNT
+        { const long long now = clock64(); if (diagItems) diagItemMax = max(diagItemMax, now - diagPrev); diagPrev = now; ++diagItems; diagCursor += now - diagTop; }
+#endif
         const uint2 item = P.bigQueue[i];
+#ifdef INCR_DIAG_VIS_COUNT
+        { const uint32_t use = __builtin_amdgcn_readfirstlane(item.x); asm volatile("" :: "s"(use)); diagQueue += clock64() - diagPrev; }
+#endif
         const uint32_t rowStart = item.y >> 16, rowCount = item.y & 0xffffu;
         if (!rowCount) continue;
         SubTri st;
         if (!subtri_from_rec(P, item.x, &st)) continue;
+#ifdef INCR_DIAG_VIS_COUNT
+        { const long long now = clock64(); diagSetup += now - diagPrev; }       // cursor + queue entry + record (+ alpha block) since the item began
+#endif
         const int32_t skip = (int32_t)rowStart * 8;
 #pragma unroll
         for (int k = 0; k < 3; ++k) st.e[k] += (long long)skip * st.sy[k];
         st.py0 += skip; st.py1 = min(st.py1, st.py0 + (int32_t)rowCount * 8 - 1);
         raster_coop(P, st, lane);
+#ifdef INCR_DIAG_VIS_COUNT
+        diagTop = clock64();
+#endif
     }
+#ifdef INCR_DIAG_VIS_COUNT
+    if (lane == 0) {
+        const long long t = clock64() - diagT0;
+        atomicAdd((unsigned long long*)(P.vqCounters + 28), (unsigned long long)(wall_clock64() - diagW0));
+        atomicAdd((unsigned long long*)(P.vqCounters + 30), (unsigned long long)diagQueue);
+        atomicAdd((unsigned long long*)(P.vqCounters + 32), (unsigned long long)diagCursor);
+        atomicAdd((unsigned long long*)(P.vqCounters + 20), (unsigned long long)t);
+        atomicAdd((unsigned long long*)(P.vqCounters + 26), (unsigned long long)diagSetup);
+        atomicMax(P.vqCounters + 22, (uint32_t)(t >> 4));
+        atomicMax(P.vqCounters + 23, (uint32_t)(diagItemMax >> 4));
+        atomicMax(P.vqCounters + 24, diagItems);
+        atomicAdd(P.vqCounters + 18, diagItems ? 1u : 0u);
+    }
+#endif
     qw_init(q, nWhole, 1u);
     for (uint32_t i; qw_next(q, P.vqCounters + 5, nWhole, 1u, 1u, &i);) {        // whole large triangles (band-queue overflow)
         SubTri st;
         if (subtri_from_rec(P, P.wholeQueue[i], &st)) raster_coop(P, st, lane);
     }
     qw_init(q, nSmall, 64u);
+#ifdef INCR_DIAG_NO_SMALL        // diagnostic only: the scan without its small triangles
+    q.done = true;
+#endif
     for (uint32_t base; qw_next(q, P.vqCounters + 6, nSmall, 64u, 1u, &base);) { // small triangles: one per lane
         const uint32_t i = base + lane;
         SubTri st;
@@ -1544,7 +1627,7 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
     const size_t n = (size_t)p->W * (p->y1 - p->y0), first = (size_t)p->W * p->y0;     // only the scissor rows are cleared, drawn and resolved
     hipError_t e = hipMemsetAsync(p->packed + first, 0, n * 8, stream);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(p->vqCounters, 0, 64, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(p->vqCounters, 0, kVisCounterBytes, stream)) != hipSuccess) return e;
     if (maxJobs) {
         const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
         if (p->prims.draws) {            // primitive path: draw lists -> flags, then one wave per 64-triangle chunk

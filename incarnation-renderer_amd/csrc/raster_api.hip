@@ -248,7 +248,7 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
     // test hook: a tiny band queue forces the overflow path (large triangles scanned whole by one wave)
     if (const char* cap = pixels ? test_hook_env("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
-    const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = 256, szPacked = align256(pixels * 8);
+    const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = align256(kVisCounterBytes), szPacked = align256(pixels * 8);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
     const size_t szFlags = align256((prims + 1) * 4), szIds = align256(pixels * 4);
@@ -364,6 +364,15 @@ int incr_visibility_get_stats(incr_context* ctx, uint32_t out_counters[4]) {
     if (!ctx->rasterBlock || !ctx->rasterCounters) return fail(INCR_ERR_INVALID_ARGUMENT, "incr_visibility has not run yet");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_counters, ctx->rasterCounters, 16, hipMemcpyDeviceToHost));
+#ifdef INCR_DIAG_VIS_COUNT
+    uint32_t c[64];
+    HIP_TRY(hipMemcpy(c, ctx->rasterCounters, 256, hipMemcpyDeviceToHost));
+    unsigned long long sum, setup; memcpy(&sum, c + 20, 8); memcpy(&setup, c + 26, 8);
+    unsigned long long wall, queue, cursor; memcpy(&wall, c + 28, 8); memcpy(&queue, c + 30, 8); memcpy(&cursor, c + 32, 8);
+    fprintf(stderr, "vis diag: of the band phase cycles: cursor %llu, queue entry %llu, queue entry + record + set-up %llu; band phase in 100 MHz ticks: %llu\n", cursor, queue, setup, wall);
+    fprintf(stderr, "vis diag: tiles scanned %u rejected %u; waves with band items %u; band phase cycles: sum %llu, max %llu; longest item %llu cycles; most items by one wave %u\n",
+            c[16], c[17], c[18], sum, (unsigned long long)c[22] << 4, (unsigned long long)c[23] << 4, c[24]);
+#endif
     return INCR_OK;
 }
 

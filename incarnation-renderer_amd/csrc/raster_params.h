@@ -81,6 +81,12 @@ struct alignas(16) SubTriRec { int32_t X0, Y0, X1, Y1, X2, Y2; float z0, z1, z2;
 struct alignas(16) SubTriAlpha { float p[12]; float uv[6]; float pad[2]; };
 static_assert(sizeof(SubTriRec) == 48 && sizeof(SubTriAlpha) == 80, "visibility queue records");
 
+// Band-queue cursors: the part of the queue behind the scan grid's static round is cut into INCR_VIS_STRIPES contiguous segments, each with a cursor on a
+// cache line of its own (raster.hip band_next)
+#ifndef INCR_VIS_STRIPES
+#define INCR_VIS_STRIPES 16
+#endif
+static constexpr size_t kVisCounterBytes = 256 + (size_t)INCR_VIS_STRIPES * 128;
 struct VisParams {
     RasterScene S;
     float viewProj[16];
@@ -91,7 +97,7 @@ struct VisParams {
     // triangle queues (raster.hip "Work distribution")
     SubTriRec* __restrict__ recs; SubTriAlpha* __restrict__ alphas;
     uint2* __restrict__ bigQueue; uint32_t* __restrict__ smallQueue; uint32_t* __restrict__ wholeQueue;
-    uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors
+    uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors; [64 + 32 s] band cursor of stripe s (kVisCounterBytes)
     uint32_t recCap, bigCap;
     uint32_t y0, y1;                                 // scissor rows [y0, y1) (incr_view_constants::scissor_y0/y1)
     RasterPrims prims;                               // primitive path only

@@ -285,11 +285,12 @@ DI bool orient_subtri(ScreenVert& v0, ScreenVert& v1, ScreenVert& v2, bool cullB
     return true;
 }
 // Scan set-up of a clockwise screen triangle; false when its bounding box holds no pixel centre.
-DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, uint32_t W, uint32_t y0, uint32_t y1, SubTri* st) {
+// The scan rectangle is columns [x0, x1) x rows [y0, y1): the frame's width and scissor rows, or a screen bin.
+DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, SubTri* st) {
     const long long area = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (v1.Y - v0.Y);
     const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
     const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
-    st->px0 = max(0, (minX + 127) >> 8); st->px1 = min((int32_t)W - 1, (maxX - 128) >> 8);
+    st->px0 = max((int32_t)x0, (minX + 127) >> 8); st->px1 = min((int32_t)x1 - 1, (maxX - 128) >> 8);
     st->py0 = max((int32_t)y0, (minY + 127) >> 8); st->py1 = min((int32_t)y1 - 1, (maxY - 128) >> 8);      // scissor rows [y0, y1)
     if (st->px0 > st->px1 || st->py0 > st->py1) return false;
     const long long Sx = (long long)st->px0 * 256 + 128, Sy = (long long)st->py0 * 256 + 128;
@@ -302,6 +303,16 @@ DI bool setup_subtri(const ScreenVert& v0, const ScreenVert& v1, const ScreenVer
     st->bias[0] = top_left(dx01, dy01) ? 0 : -1; st->bias[1] = top_left(dx12, dy12) ? 0 : -1; st->bias[2] = top_left(dx20, dy20) ? 0 : -1;
     st->area = 1.0 / (double)area;           // reciprocal once per triangle: the per-fragment weights are products
     st->z0 = v0.z; st->dz1 = v1.z - v0.z; st->dz2 = v2.z - v0.z;
+    return true;
+}
+// Coverage + depth of one fragment -> the surface word it competes with (false: not covered / clipped)
+DI bool fragment_word(const SubTri& st, long long E01, long long E12, long long E20, unsigned long long* word) {
+    if (E01 + st.bias[0] < 0 || E12 + st.bias[1] < 0 || E20 + st.bias[2] < 0) return false;
+    const float l1 = (float)((double)E20 * st.area), l2 = (float)((double)E01 * st.area);
+    float depth = (st.z0 + l1 * st.dz1) + l2 * st.dz2;
+    if (!(depth >= 0.f)) return false;
+    if (depth > 1.f) depth = 1.f;
+    *word = ((unsigned long long)__float_as_uint(depth) << 34) | ((unsigned long long)st.list << 33) | ((unsigned long long)st.key + 1ull);
     return true;
 }
 DI void fragment(const VisParams& P, const SubTri& st, int32_t px, int32_t py, long long E01, long long E12, long long E20) {
@@ -376,6 +387,79 @@ DI void raster_coop(const VisParams& P, const SubTri& st, uint32_t lane) {
                 fragment(P, st, px, py, base[0] + lx * st.sx[0] + ly * st.sy[0], base[1] + lx * st.sx[1] + ly * st.sy[1], base[2] + lx * st.sx[2] + ly * st.sy[2]);
         }
 }
+// The alpha-tested large triangle by the whole wave, its fragments COMPACTED before they cost anything: the tile loop only computes coverage and the surface word
+// and appends the covered fragments to a queue of the wave in LDS (A); 64 of them at a time look at the stored word (one round trip per 64 fragments instead of
+// one per tile) and the survivors move to a second queue (B); 64 of those at a time run the sampler's tap loop and the atomic.  Scanned tile by tile, a foliage
+// triangle ran its taps with the lanes of one tile that were covered AND not yet hidden -- a third of the wave on the 4K Sponza-stat frame, whose alpha-tested
+// items were 0.52 of the scan's 0.63 ms.  The queues hold 128 entries (fewer than 64 left + at most 64 new); `st` is wave-uniform.
+struct FragQueues { uint32_t* pixA; unsigned long long* wordA; uint32_t* pixB; unsigned long long* wordB; };
+static constexpr uint32_t kFragQueue = 128;
+DI void alpha_look(const VisParams& P, const FragQueues& q, uint32_t lane, uint32_t first, uint32_t count, uint32_t& bn) {
+    uint32_t pix = 0; unsigned long long v = 0ull; bool live = false;
+    if (lane < count) {
+        pix = q.pixA[first + lane]; v = q.wordA[first + lane];
+        live = v > __atomic_load_n(P.packed + (size_t)(pix >> 16) * P.W + (pix & 0xffffu), __ATOMIC_RELAXED);      // values only grow: a fragment that loses now loses for good
+    }
+    const unsigned long long m = __ballot(live);
+#if defined(INCR_DIAG_VIS_COUNT) && INCR_DIAG_VIS_COUNT >= 2
+    if (lane == 0) { atomicAdd(P.vqCounters + 34, count); atomicAdd(P.vqCounters + 35, (uint32_t)__popcll(m)); atomicAdd(P.vqCounters + 37, 1u); }
+#endif
+    if (live) { const uint32_t at = bn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); q.pixB[at] = pix; q.wordB[at] = v; }
+    bn += (uint32_t)__popcll(m);
+}
+DI void alpha_sample(const VisParams& P, const SubTri& st, const FragQueues& q, uint32_t lane, uint32_t first, uint32_t count) {
+    if (lane >= count) return;
+    const uint32_t pix = q.pixB[first + lane], px = pix & 0xffffu, py = pix >> 16;
+    const unsigned long long v = q.wordB[first + lane];
+    const f3 lam = bary_eval(st.bs, pixel_ndc(px, py, (float)P.W, (float)P.H));
+    const UvGrad g = quad_uv_gradient(st.bs, st.uv0, st.uv1, st.uv2, px, py, (float)P.W, (float)P.H);
+    const bool pass = AlphaTestGrad(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy, P.S.maxAnisotropy);
+#if defined(INCR_DIAG_VIS_COUNT) && INCR_DIAG_VIS_COUNT >= 2
+    { const unsigned long long pm = __ballot(pass); if (lane == 0) { atomicAdd(P.vqCounters + 36, (uint32_t)__popcll(pm)); atomicAdd(P.vqCounters + 38, 1u); } }
+#endif
+    if (pass) atomicMax(P.packed + (size_t)py * P.W + px, v);
+}
+DI void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DI void raster_coop_alpha(const VisParams& P, const SubTri& st, uint32_t lane, const FragQueues& q) {
+    const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    uint32_t an = 0, bn = 0;                                       // wave-uniform fill of the two queues
+    auto drain = [&](bool all) {
+        while (an >= 64u || (all && an != 0u)) {
+            const uint32_t n = min(an, 64u);
+            an -= n;
+            wave_lds_fence();
+            alpha_look(P, q, lane, an, n, bn);
+            wave_lds_fence();
+            if (bn >= 64u) { bn -= 64u; alpha_sample(P, st, q, lane, bn, 64u); }
+        }
+        if (all && bn != 0u) { wave_lds_fence(); alpha_sample(P, st, q, lane, 0u, bn); bn = 0u; }
+    };
+    for (int32_t oy = st.py0; oy <= st.py1; oy += 8)
+        for (int32_t ox = st.px0; ox <= st.px1; ox += 8) {
+            const long long ix = ox - st.px0, iy = oy - st.py0;
+            bool reject = false;
+            long long base[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                base[k] = st.e[k] + ix * st.sx[k] + iy * st.sy[k];
+                const long long hi = base[k] + (st.sx[k] > 0 ? 7 * st.sx[k] : 0) + (st.sy[k] > 0 ? 7 * st.sy[k] : 0) + st.bias[k];
+                reject = reject || hi < 0;
+            }
+            if (reject) continue;
+            const int32_t px = ox + lx, py = oy + ly;
+            unsigned long long v = 0ull;
+            const bool covered = px <= st.px1 && py <= st.py1 &&
+                fragment_word(st, base[0] + lx * st.sx[0] + ly * st.sy[0], base[1] + lx * st.sx[1] + ly * st.sy[1], base[2] + lx * st.sx[2] + ly * st.sy[2], &v);
+            const unsigned long long m = __ballot(covered);
+            if (m == 0ull) continue;
+            if (covered) { const uint32_t at = an + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); q.pixA[at] = ((uint32_t)py << 16) | (uint32_t)px; q.wordA[at] = v; }
+            an += (uint32_t)__popcll(m);
+            drain(false);
+        }
+    drain(true);
+}
 // Work distribution (DESIGN.md "Visibility pass"): the set-up kernel turns every surviving screen triangle into a
 // 48-byte record and files it by bounding-box size; the scan kernel's persistent waves then pull
 //   * band items  -- <= 64 8x8 tiles of one large triangle, scanned by the whole wave (one tile per step),
@@ -392,12 +476,26 @@ DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
 DI bool subtri_from_rec(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriRec r = P.recs[idx];
     const ScreenVert v0 = {r.X0, r.Y0, r.z0}, v1 = {r.X1, r.Y1, r.z1}, v2 = {r.X2, r.Y2, r.z2};
-    if (!setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, st)) return false;
+    if (!setup_subtri(v0, v1, v2, 0u, P.W, P.y0, P.y1, st)) return false;
     st->key = r.key; st->list = r.pad; st->alphaTex = r.alphaTex;
     if (r.alphaTex >= 0) vq_load_alpha(P, idx, st);
     return true;
 }
 
+// Can a pixel centre of columns [rx0, rx1] x rows [ry0, ry1] lie inside the clockwise triangle?  false when one edge function (with its fill-rule bias) is negative at
+// the rectangle's corner where it is largest -- the scan's tile reject on a rectangle of any size.
+DI bool rect_may_touch(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, int32_t rx0, int32_t rx1, int32_t ry0, int32_t ry1) {
+    const long long Sx = (long long)rx0 * 256 + 128, Sy = (long long)ry0 * 256 + 128, w = (long long)(rx1 - rx0) * 256, h = (long long)(ry1 - ry0) * 256;
+    const ScreenVert* v[4] = {&v0, &v1, &v2, &v0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int32_t dx = v[k + 1]->X - v[k]->X, dy = v[k + 1]->Y - v[k]->Y;
+        const long long e = (long long)dx * (Sy - v[k]->Y) - (long long)dy * (Sx - v[k]->X);
+        const long long hi = e + (dy < 0 ? -(long long)dy * w : 0) + (dx > 0 ? (long long)dx * h : 0) + (top_left(dx, dy) ? 0 : -1);
+        if (hi < 0) return false;
+    }
+    return true;
+}
 // Primitive assembly for one triangle per lane: near-plane clip, viewport snap, facing / culling, 48-byte record, filing by
 // bounding-box size.  MUST be called by all 64 lanes (queue slots are allocated with ballots: one atomic per wave and
 // queue instead of one per triangle -- 930 K same-address atomics cost 9 ms on the Bistro-scale scene).
@@ -425,7 +523,7 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
         SubTri st;
         bool have = ok && (s == 0 || np == 4);
         if (have) have = orient_subtri(v0, v1, v2, cullBack);
-        if (have) have = setup_subtri(v0, v1, v2, P.W, P.y0, P.y1, &st);
+        if (have) have = setup_subtri(v0, v1, v2, 0u, P.W, P.y0, P.y1, &st);
         const unsigned long long hm = __ballot(have);
         if (hm == 0ull) continue;
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -437,13 +535,60 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
         have = have && idx < P.recCap;                           // cannot fail: recCap = 2 x scene triangles
         const uint32_t bw = have ? (uint32_t)(st.px1 - st.px0 + 1) : 0u, bh = have ? (uint32_t)(st.py1 - st.py0 + 1) : 0u;
         const bool small = have && bw * bh <= (uint32_t)(alphaTex >= 0 ? INCR_VIS_ALPHA_BOX : kBigBoxPixels);
-        const unsigned long long sm = __ballot(small);
+        // Every triangle is filed per SCREEN BIN (vis_bin_kernel scans a bin's triangles into an LDS copy of the bin: a fragment's 64-bit atomic -- 184 cycles of a CU per
+        // 8 x 8 tile on the device surface, 0.25 of the scan's 0.63 ms on the 4K Sponza-stat frame -- and the alpha-tested fragment's look at the stored word become LDS
+        // operations), in one of three lists per bin: opaque large, alpha-tested large, small.  The (triangle, bin) pairs of the wave's triangles are flattened over the
+        // lanes 64 at a time (a triangle at a time waits for every triangle's returning atomic in turn: set-up kernel 0.050 -> 0.128 ms; a lane per triangle waits for the
+        // widest one).  A bin is skipped when one edge has it outside; a triangle that finds a list full takes the device-surface queues below instead -- fragments
+        // scanned twice lose against themselves, the surface keeps the maximum.
+#ifndef INCR_VIS_BIN_KINDS
+#define INCR_VIS_BIN_KINDS 5     // bit per list: 1 opaque large, 2 alpha-tested large, 4 small
+#endif
+        const uint32_t kind = small ? (uint32_t)kBinSmall : (alphaTex >= 0 ? (uint32_t)kBinAlpha : (uint32_t)kBinOpaque);
+        bool binned = have && P.binCap != 0u && (((uint32_t)INCR_VIS_BIN_KINDS >> kind) & 1u) != 0u;
+        if (P.binCap != 0u && __ballot(binned) != 0ull) {
+            const uint32_t sh = P.binShift;
+            const uint32_t cx0 = binned ? (uint32_t)st.px0 >> sh : 0u, cy0 = binned ? ((uint32_t)st.py0 - P.y0) >> sh : 0u;
+            const uint32_t ncx = binned ? ((uint32_t)st.px1 >> sh) - cx0 + 1u : 0u, nb = binned ? ncx * ((((uint32_t)st.py1 - P.y0) >> sh) - cy0 + 1u) : 0u;
+            uint32_t incl = nb;                                   // inclusive prefix sum of the pair counts over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if ((int)lane >= off) incl += t; }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            bool full = false;                                    // per SOURCE lane: one of its lists was full
+            for (uint32_t p0 = 0; p0 < total; p0 += 64u) {
+                const uint32_t pair = p0 + lane;
+                uint32_t src = 0;                                 // first lane whose inclusive sum exceeds `pair`
+#pragma unroll
+                for (uint32_t half = 32u; half != 0u; half >>= 1) { const uint32_t t = (uint32_t)__shfl((int)incl, (int)(src + half - 1u), 64); if (t <= pair) src += half; }
+                src = min(src, 63u);
+                ScreenVert a, b, c;
+                a.X = __shfl(v0.X, (int)src, 64); a.Y = __shfl(v0.Y, (int)src, 64); b.X = __shfl(v1.X, (int)src, 64); b.Y = __shfl(v1.Y, (int)src, 64);
+                c.X = __shfl(v2.X, (int)src, 64); c.Y = __shfl(v2.Y, (int)src, 64);
+                const int32_t bx0p = __shfl(st.px0, (int)src, 64), bx1p = __shfl(st.px1, (int)src, 64), by0p = __shfl(st.py0, (int)src, 64), by1p = __shfl(st.py1, (int)src, 64);
+                const uint32_t sidx = (uint32_t)__shfl((int)idx, (int)src, 64), sncx = (uint32_t)__shfl((int)ncx, (int)src, 64), skind = (uint32_t)__shfl((int)kind, (int)src, 64);
+                const uint32_t j = pair - ((uint32_t)__shfl((int)incl, (int)src, 64) - (uint32_t)__shfl((int)nb, (int)src, 64));
+                bool mine = false;
+                if (pair < total) {
+                    const uint32_t cx = ((uint32_t)bx0p >> sh) + j % sncx, cy = (((uint32_t)by0p - P.y0) >> sh) + j / sncx;
+                    const int32_t rx0 = max(bx0p, (int32_t)(cx << sh)), rx1 = min(bx1p, (int32_t)(((cx + 1u) << sh) - 1u));
+                    const int32_t ry0 = max(by0p, (int32_t)(P.y0 + (cy << sh))), ry1 = min(by1p, (int32_t)(P.y0 + ((cy + 1u) << sh) - 1u));
+                    if (rect_may_touch(a, b, c, rx0, rx1, ry0, ry1)) {
+                        const uint32_t list = (cy * P.binsX + cx) * (uint32_t)kVisBinLists + skind, slot = atomicAdd(P.binCount + list, 1u);
+                        if (slot < P.binCap) P.binList[(size_t)list * P.binCap + slot] = sidx; else mine = true;
+                    }
+                }
+                for (unsigned long long m = __ballot(mine); m != 0ull; m &= m - 1ull)          // rare: tell the triangle's own lane
+                    if (lane == (uint32_t)__shfl((int)src, __ffsll((long long)m) - 1, 64)) full = true;
+            }
+            if (full) binned = false;
+        }
+        const unsigned long long sm = __ballot(small && !binned);
         if (sm != 0ull) {
             uint32_t sbase = 0;
             const int sleader = __ffsll((long long)sm) - 1;
             if ((int)lane == sleader) sbase = atomicAdd(P.vqCounters + 2, (uint32_t)__popcll(sm));
             sbase = (uint32_t)__shfl((int)sbase, sleader, 64);
-            if (small) P.smallQueue[sbase + (uint32_t)__popcll(sm & below)] = idx;
+            if (small && !binned) P.smallQueue[sbase + (uint32_t)__popcll(sm & below)] = idx;
         }
         if (!have) continue;
         SubTriRec r;
@@ -457,7 +602,7 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
             al.uv[0] = uvA.x; al.uv[1] = uvA.y; al.uv[2] = uvB.x; al.uv[3] = uvB.y; al.uv[4] = uvC.x; al.uv[5] = uvC.y; al.pad[0] = al.pad[1] = 0.f;
             P.alphas[idx] = al;
         }
-        if (small) continue;
+        if (small || binned) continue;
         const uint32_t tw = (bw + 7u) >> 3, th = (bh + 7u) >> 3;
         // tiles per band item: 64 for an opaque triangle, 32 for an alpha-tested one -- its fragments run the sampler's serial tap loop, a 64-tile item of foliage kept ONE
         // wave busy for most of the launch while the others had finished (PMC: the average wave lived a quarter of the kernel's duration).  Measured, raster frame at
@@ -588,6 +733,110 @@ DI bool qw_next(QueueWalk& q, uint32_t* __restrict__ cursor, uint32_t n, uint32_
     *out = q.cur; q.cur += step;
     return true;
 }
+// The visibility scan, bin by bin (first phase of vis_scan_kernel): a workgroup takes a screen bin (2^SHIFT pixels square, origin column 0 / row y0) and scans the
+// triangles filed for it into an LDS copy of the bin's surface words -- the same edge functions, depth and word as on the device surface, atomicMax on LDS --, then
+// merges the copy into the surface with one atomicMax per covered pixel.  Large triangles: a wave each, 8 x 8 tiles aligned to the bin.  Small
+// ones: a lane each.  The alpha-tested large triangles come last, behind a barrier: their fragments look at the stored word before they sample (ps_meshlet_main's
+// clip), and by then the bin's opaque geometry is in place.  The wave-level queues of vis_scan_kernel follow: the alpha-tested large triangles (not binned by default: foliage piles up in few bins) and whatever found its list full.  LDS holds the bin tile by tile (a tile = 512
+// contiguous bytes: the 64 atomics of a wave fall into different bank pairs).
+template <uint32_t SHIFT> struct BinTile {
+    static constexpr uint32_t kBin = 1u << SHIFT, kTilesX = kBin / 8u, kWords = kBin * kBin;
+    static DI uint32_t word_index(uint32_t x, uint32_t y) { return ((y >> 3) * kTilesX + (x >> 3)) * 64u + (y & 7u) * 8u + (x & 7u); }
+};
+// One fragment against the LDS copy (fragment() on the device surface)
+DI void fragment_lds(const VisParams& P, const SubTri& st, int32_t px, int32_t py, long long E01, long long E12, long long E20, unsigned long long* __restrict__ w) {
+    unsigned long long v;
+    if (!fragment_word(st, E01, E12, E20, &v)) return;
+    if (st.alphaTex >= 0) {
+        if (v <= *(volatile unsigned long long*)w) return;
+        const f3 lam = bary_eval(st.bs, pixel_ndc((uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H));
+        const UvGrad g = quad_uv_gradient(st.bs, st.uv0, st.uv1, st.uv2, (uint32_t)px, (uint32_t)py, (float)P.W, (float)P.H);
+        if (!AlphaTestGrad(st.tex, interp2(st.uv0, st.uv1, st.uv2, lam), g.ddx, g.ddy, P.S.maxAnisotropy)) return;
+    }
+    atomicMax(w, v);
+}
+// Record -> scan set-up inside the rectangle [X0, X1) x [Y0, Y1)
+DI bool subtri_in_rect(const VisParams& P, uint32_t idx, uint32_t X0, uint32_t X1, uint32_t Y0, uint32_t Y1, SubTri* st) {
+    const SubTriRec r = P.recs[idx];
+    const ScreenVert v0 = {r.X0, r.Y0, r.z0}, v1 = {r.X1, r.Y1, r.z1}, v2 = {r.X2, r.Y2, r.z2};
+    if (!setup_subtri(v0, v1, v2, X0, X1, Y0, Y1, st)) return false;
+    st->key = r.key; st->list = r.pad; st->alphaTex = r.alphaTex;
+    if (r.alphaTex >= 0) vq_load_alpha(P, idx, st);
+    return true;
+}
+template <uint32_t SHIFT>
+DI void scan_bin(const VisParams& P, uint32_t bin, unsigned long long* __restrict__ s_words, uint32_t* __restrict__ s_next) {
+    using T = BinTile<SHIFT>;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cx = bin % P.binsX, cy = bin / P.binsX;
+    const uint32_t X0 = cx << SHIFT, Y0 = P.y0 + (cy << SHIFT), X1 = min(X0 + T::kBin, P.W), Y1 = min(Y0 + T::kBin, P.y1);
+    for (uint32_t i = threadIdx.x; i < T::kWords; i += 256u) s_words[i] = 0ull;
+    if (threadIdx.x < (uint32_t)kVisBinLists) s_next[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t count[kVisBinLists];
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kVisBinLists; ++k) count[k] = min(P.binCount[bin * (uint32_t)kVisBinLists + k], P.binCap);
+    const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    // a large triangle by the whole wave
+    auto scan_large = [&](uint32_t list) {
+        const uint32_t* __restrict__ entries = P.binList + (size_t)(bin * (uint32_t)kVisBinLists + list) * P.binCap;
+        for (;;) {
+            uint32_t e = 0;
+            if (lane == 0) e = atomicAdd(&s_next[list], 1u);
+            e = __builtin_amdgcn_readfirstlane(e);
+            if (e >= count[list]) break;
+            SubTri st;
+            if (!subtri_in_rect(P, __builtin_amdgcn_readfirstlane(entries[e]), X0, X1, Y0, Y1, &st)) continue;
+            const int32_t tx0 = (st.px0 - (int32_t)X0) >> 3, tx1 = (st.px1 - (int32_t)X0) >> 3, ty0 = (st.py0 - (int32_t)Y0) >> 3, ty1 = (st.py1 - (int32_t)Y0) >> 3;
+            for (int32_t ty = ty0; ty <= ty1; ++ty)
+                for (int32_t tx = tx0; tx <= tx1; ++tx) {
+                    const long long ix = (int32_t)X0 + tx * 8 - st.px0, iy = (int32_t)Y0 + ty * 8 - st.py0;       // >= -7: the tile may begin left of / above the rectangle
+                    bool reject = false;
+                    long long base[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        base[k] = st.e[k] + ix * st.sx[k] + iy * st.sy[k];
+                        const long long hi = base[k] + (st.sx[k] > 0 ? 7 * st.sx[k] : 0) + (st.sy[k] > 0 ? 7 * st.sy[k] : 0) + st.bias[k];
+                        reject = reject || hi < 0;
+                    }
+                    if (reject) continue;
+                    const int32_t px = (int32_t)X0 + tx * 8 + lx, py = (int32_t)Y0 + ty * 8 + ly;
+                    if (px >= st.px0 && px <= st.px1 && py >= st.py0 && py <= st.py1)
+                        fragment_lds(P, st, px, py, base[0] + lx * st.sx[0] + ly * st.sy[0], base[1] + lx * st.sx[1] + ly * st.sy[1], base[2] + lx * st.sx[2] + ly * st.sy[2],
+                                     &s_words[((uint32_t)ty * T::kTilesX + (uint32_t)tx) * 64u + lane]);
+                }
+        }
+    };
+    scan_large(kBinOpaque);
+    for (;;) {                                                   // small triangles: one per lane, its part of the bin pixel by pixel
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(&s_next[kBinSmall], 64u);
+        e = __builtin_amdgcn_readfirstlane(e);
+        if (e >= count[kBinSmall]) break;
+        SubTri st;
+        if (e + lane < count[kBinSmall] && subtri_in_rect(P, P.binList[(size_t)(bin * (uint32_t)kVisBinLists + (uint32_t)kBinSmall) * P.binCap + e + lane], X0, X1, Y0, Y1, &st)) {
+            long long r0 = st.e[0], r1 = st.e[1], r2 = st.e[2];
+            for (int32_t py = st.py0; py <= st.py1; ++py) {
+                long long a = r0, b = r1, c = r2;
+                for (int32_t px = st.px0; px <= st.px1; ++px) {
+                    fragment_lds(P, st, px, py, a, b, c, &s_words[T::word_index((uint32_t)px - X0, (uint32_t)py - Y0)]);
+                    a += st.sx[0]; b += st.sx[1]; c += st.sx[2];
+                }
+                r0 += st.sy[0]; r1 += st.sy[1]; r2 += st.sy[2];
+            }
+        }
+    }
+    __syncthreads();
+    scan_large(kBinAlpha);
+    __syncthreads();
+    // into the device surface: other workgroups' alpha-tested and overflowed triangles write there at the same time
+    for (uint32_t i = threadIdx.x; i < T::kWords; i += 256u) {
+        const uint32_t x = i & (T::kBin - 1u), y = i >> SHIFT;
+        const unsigned long long w = s_words[T::word_index(x, y)];
+        if (w != 0ull && X0 + x < X1 && Y0 + y < Y1) atomicMax(P.packed + (size_t)(Y0 + y) * P.W + X0 + x, w);
+    }
+    __syncthreads();                                              // the LDS copy is reused (next bin, the fragment queues)
+}
 // The band queue's walk: static first entry like the others, then STRIPED cursors -- one cursor for the whole queue was the scan's largest single cost (72 K band items
 // on the 4K Sponza-stat frame: an atomic per item 1.05 ms for the pass, per two items 0.69, per eight 0.54 with the alpha test compiled out, ~11 ns per same-address
 // atomic; profiles/r05_ab_vis_cursor.txt), and large grabs leave the foliage's expensive items to a few waves.  A wave draws from its home segment (workgroup index
@@ -617,8 +866,18 @@ DI bool bw_next(BandWalk& q, uint32_t* __restrict__ counters, uint32_t n, uint32
     *out = q.cur++;
     return true;
 }
+template <uint32_t SHIFT>
 __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
+    // one LDS block: a bin's surface words while the workgroup scans bins, the four waves' fragment queues afterwards
+    constexpr uint32_t kQueueWords = 4u * 2u * kFragQueue, kLdsWords = BinTile<SHIFT>::kWords > kQueueWords + kQueueWords / 2u ? BinTile<SHIFT>::kWords : kQueueWords + kQueueWords / 2u;
+    __shared__ unsigned long long s_lds[kLdsWords];
+    __shared__ uint32_t s_next[kVisBinLists];
+    const uint32_t lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
+    if (P.binCap != 0u)
+        for (uint32_t bin = blockIdx.x; bin < P.binsX * P.binsY; bin += gridDim.x) scan_bin<SHIFT>(P, bin, s_lds, s_next);
+    unsigned long long* const fragWord = s_lds + waveInBlock * 2u * kFragQueue;
+    uint32_t* const fragPix = (uint32_t*)(s_lds + kQueueWords) + waveInBlock * 2u * kFragQueue;
+    const FragQueues fq = {fragPix, fragWord, fragPix + kFragQueue, fragWord + kFragQueue};
     const uint32_t nBig = min(P.vqCounters[1], P.bigCap), nSmall = P.vqCounters[2], nWhole = P.vqCounters[3];
     QueueWalk q;
     BandWalk bq;
@@ -651,7 +910,7 @@ __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) st.e[k] += (long long)skip * st.sy[k];
         st.py0 += skip; st.py1 = min(st.py1, st.py0 + (int32_t)rowCount * 8 - 1);
-        raster_coop(P, st, lane);
+        if (st.alphaTex >= 0) raster_coop_alpha(P, st, lane, fq); else raster_coop(P, st, lane);
 #ifdef INCR_DIAG_VIS_COUNT
         diagTop = clock64();
 #endif
@@ -673,7 +932,7 @@ __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
     qw_init(q, nWhole, 1u);
     for (uint32_t i; qw_next(q, P.vqCounters + 5, nWhole, 1u, 1u, &i);) {        // whole large triangles (band-queue overflow)
         SubTri st;
-        if (subtri_from_rec(P, P.wholeQueue[i], &st)) raster_coop(P, st, lane);
+        if (subtri_from_rec(P, P.wholeQueue[i], &st)) { if (st.alphaTex >= 0) raster_coop_alpha(P, st, lane, fq); else raster_coop(P, st, lane); }
     }
     qw_init(q, nSmall, 64u);
 #ifdef INCR_DIAG_NO_SMALL        // diagnostic only: the scan without its small triangles
@@ -1627,7 +1886,9 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
     const size_t n = (size_t)p->W * (p->y1 - p->y0), first = (size_t)p->W * p->y0;     // only the scissor rows are cleared, drawn and resolved
     hipError_t e = hipMemsetAsync(p->packed + first, 0, n * 8, stream);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(p->vqCounters, 0, kVisCounterBytes, stream)) != hipSuccess) return e;
+    const bool bins = maxJobs && p->binCap;
+    // the queue counters and, right behind them, the bins' triangle counts
+    if ((e = hipMemsetAsync(p->vqCounters, 0, bins ? (size_t)((const uint8_t*)(p->binCount + (size_t)p->binsX * p->binsY * kVisBinLists) - (const uint8_t*)p->vqCounters) : kVisCounterBytes, stream)) != hipSuccess) return e;
     if (maxJobs) {
         const uint32_t blocks = std::min<uint32_t>((maxJobs + kVisWaves - 1) / kVisWaves, (uint32_t)numCUs * 8u);
         if (p->prims.draws) {            // primitive path: draw lists -> flags, then one wave per 64-triangle chunk
@@ -1643,7 +1904,9 @@ extern "C" hipError_t incr_launch_visibility(const VisParams* p, uint32_t maxJob
             hipLaunchKernelGGL(vis_setup_kernel, dim3(blocks), dim3(kVisWaves * 64), 0, stream, *p);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(vis_scan_kernel, dim3((uint32_t)numCUs * 8u), dim3(256), 0, stream, *p);
+        // every workgroup resident (4 per CU: registers and LDS): the bins are the grid's first round, the wave-level queues what follows
+        if (p->binShift == 6u) hipLaunchKernelGGL(vis_scan_kernel<6u>, dim3((uint32_t)numCUs * 4u), dim3(256), 0, stream, *p);
+        else hipLaunchKernelGGL(vis_scan_kernel<5u>, dim3((uint32_t)numCUs * 4u), dim3(256), 0, stream, *p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(vis_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p->packed + first, vis + first, depth + first, n);

@@ -242,17 +242,30 @@ struct RasterWorkspace {
     uint32_t recCap, bigCap;
     uint32_t* primFlags;                   // primitive path: one word per primitive
     uint32_t* ids;                         // forward pass: its own visibility ids (the frame's vis buffer keeps the deferred ids)
+    uint32_t* binCount; uint32_t* binList; uint32_t binCap;      // screen bins (binCount sits right behind `counters`: one clear)
 };
+// Screen bins of a W-wide surface with `rows` scissor rows
+static inline uint32_t vis_bin_shift(uint32_t W, uint32_t H) {
+    uint32_t shift = (size_t)W * H >= ((size_t)1 << 22) ? 6u : 5u;
+    if (const char* v = test_hook_env("INCR_VIS_BIN_SHIFT")) shift = strtoul(v, nullptr, 10) == 6 ? 6u : 5u;
+    return shift;
+}
+static inline uint32_t vis_bins(uint32_t pixels, uint32_t shift) { return (pixels + (1u << shift) - 1u) >> shift; }
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws, size_t prims = 0) {
+int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, size_t tris, hipStream_t stream, RasterWorkspace* ws, size_t prims = 0, size_t bins = 0) {
     size_t recCap = pixels ? 2 * tris + 64 : 0, bigCap = pixels ? recCap + pixels / 16 + 64 : 0;
     // test hook: a tiny band queue forces the overflow path (large triangles scanned whole by one wave)
     if (const char* cap = pixels ? test_hook_env("INCR_VIS_BAND_QUEUE_CAP") : nullptr) bigCap = (size_t)strtoul(cap, nullptr, 10) + 1;
-    const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = align256(kVisCounterBytes), szPacked = align256(pixels * 8);
+    // test hook: a tiny bin capacity forces the bins' overflow path (the triangle takes the band queue), 0 turns the bins off
+    size_t binCap = bins ? kVisBinCapDefault : 0;
+    if (const char* cap = bins ? test_hook_env("INCR_VIS_BIN_CAP") : nullptr) binCap = (size_t)strtoul(cap, nullptr, 10);
+    if (!binCap) bins = 0;
+    const size_t szFrames = align256((meshes + 1) * sizeof(MeshFrame)), szCounters = align256(kVisCounterBytes) + align256(bins * kVisBinLists * 4), szPacked = align256(pixels * 8);
+    const size_t szBinList = align256(bins * kVisBinLists * binCap * 4);
     const size_t szRecs = align256(recCap * sizeof(SubTriRec)), szAlpha = align256(recCap * sizeof(SubTriAlpha));
     const size_t szSmall = align256(recCap * 4), szWhole = szSmall, szBig = align256(bigCap * 8);
     const size_t szFlags = align256((prims + 1) * 4), szIds = align256(pixels * 4);
-    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig + szFlags + szIds;
+    const size_t need = szFrames + szCounters + szPacked + szRecs + szAlpha + szSmall + szWhole + szBig + szFlags + szIds + szBinList;
     if (recCap > 0xffffffffull || bigCap > 0xffffffffull) return fail(INCR_ERR_INVALID_ARGUMENT, "scene too large for the visibility queues");
     if (ctx->rasterBytes < need || !ctx->rasterBlock) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -262,7 +275,7 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     }
     uint8_t* p = (uint8_t*)ctx->rasterBlock;
     ws->frames = (MeshFrame*)p; p += szFrames;
-    ws->counters = (uint32_t*)p; p += szCounters;
+    ws->counters = (uint32_t*)p; ws->binCount = (uint32_t*)(p + align256(kVisCounterBytes)); p += szCounters;
     ws->packed = (unsigned long long*)p; p += szPacked;
     ws->recs = (SubTriRec*)p; p += szRecs;
     ws->alphas = (SubTriAlpha*)p; p += szAlpha;
@@ -270,7 +283,8 @@ int ensure_raster_workspace(incr_context* ctx, size_t pixels, size_t meshes, siz
     ws->wholeQueue = (uint32_t*)p; p += szWhole;
     ws->bigQueue = (uint2*)p; p += szBig;
     ws->primFlags = (uint32_t*)p; p += szFlags;
-    ws->ids = (uint32_t*)p;
+    ws->ids = (uint32_t*)p; p += szIds;
+    ws->binList = (uint32_t*)p; ws->binCap = (uint32_t)binCap;
     ws->recCap = (uint32_t)recCap; ws->bigCap = (uint32_t)bigCap;
     return INCR_OK;
 }
@@ -370,6 +384,7 @@ int incr_visibility_get_stats(incr_context* ctx, uint32_t out_counters[4]) {
     unsigned long long sum, setup; memcpy(&sum, c + 20, 8); memcpy(&setup, c + 26, 8);
     unsigned long long wall, queue, cursor; memcpy(&wall, c + 28, 8); memcpy(&queue, c + 30, 8); memcpy(&cursor, c + 32, 8);
     fprintf(stderr, "vis diag: of the band phase cycles: cursor %llu, queue entry %llu, queue entry + record + set-up %llu; band phase in 100 MHz ticks: %llu\n", cursor, queue, setup, wall);
+    fprintf(stderr, "vis diag: alpha fragments covered %u (in %u batches), not hidden when looked at %u, passed the alpha test %u (%u sampler batches)\n", c[34], c[37], c[35], c[36], c[38]);
     fprintf(stderr, "vis diag: tiles scanned %u rejected %u; waves with band items %u; band phase cycles: sum %llu, max %llu; longest item %llu cycles; most items by one wave %u\n",
             c[16], c[17], c[18], sum, (unsigned long long)c[22] << 4, (unsigned long long)c[23] << 4, c[24]);
 #endif
@@ -393,10 +408,12 @@ int incr_visibility(incr_context* ctx, const incr_visibility_desc* d, incr_strea
     RasterWorkspace ws;
     size_t tris = sc->host.meshletPackedTriangles.size();
     if (d->use_primitives) { tris = 0; for (const incr_gpu_primitive& pr : sc->host.primitives) tris += pr.indexCount > 0 ? (size_t)pr.indexCount / 3 : 0; }
-    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size()))) return rc;
+    P.binShift = vis_bin_shift(P.W, P.H); P.binsX = vis_bins(P.W, P.binShift); P.binsY = vis_bins(P.y1 > P.y0 ? P.y1 - P.y0 : 0u, P.binShift);
+    if ((rc = ensure_raster_workspace(ctx, (size_t)P.W * P.H, P.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size(), (size_t)P.binsX * vis_bins(P.H, P.binShift)))) return rc;
     if (d->use_primitives && (rc = fill_raster_prims(sc, ws.primFlags, P.prims))) return rc;
     P.packed = ws.packed; P.recs = ws.recs; P.alphas = ws.alphas; P.bigQueue = ws.bigQueue; P.smallQueue = ws.smallQueue; P.wholeQueue = ws.wholeQueue;
     P.vqCounters = ws.counters; P.recCap = ws.recCap; P.bigCap = ws.bigCap;
+    P.binCount = ws.binCount; P.binList = ws.binList; P.binCap = ws.binCap;
     ctx->rasterCounters = ws.counters;
     HIP_TRY(incr_launch_visibility(&P, d->use_primitives ? P.prims.numChunks : P.S.numMeshlets, ctx->props.multiProcessorCount, d->vis_buffer, d->depth_buffer, (hipStream_t)stream));
     return INCR_OK;
@@ -508,10 +525,12 @@ int incr_forward_lighting(incr_context* ctx, const incr_forward_lighting_desc* d
     size_t tris = 0;
     for (const incr_gpu_primitive& pr : sc->host.primitives) tris += pr.indexCount > 0 ? (size_t)pr.indexCount / 3 : 0;
     RasterWorkspace ws;
-    if ((rc = ensure_raster_workspace(ctx, (size_t)V.W * V.H, V.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size()))) return rc;
+    V.binShift = vis_bin_shift(V.W, V.H); V.binsX = vis_bins(V.W, V.binShift); V.binsY = vis_bins(V.y1 > V.y0 ? V.y1 - V.y0 : 0u, V.binShift);
+    if ((rc = ensure_raster_workspace(ctx, (size_t)V.W * V.H, V.S.numMeshes, tris, (hipStream_t)stream, &ws, sc->host.primitives.size(), (size_t)V.binsX * vis_bins(V.H, V.binShift)))) return rc;
     if ((rc = fill_raster_prims(sc, ws.primFlags, V.prims))) return rc;
     V.packed = ws.packed; V.recs = ws.recs; V.alphas = ws.alphas; V.bigQueue = ws.bigQueue; V.smallQueue = ws.smallQueue; V.wholeQueue = ws.wholeQueue;
     V.vqCounters = ws.counters; V.recCap = ws.recCap; V.bigCap = ws.bigCap;
+    V.binCount = ws.binCount; V.binList = ws.binList; V.binCap = ws.binCap;
     ctx->rasterCounters = ws.counters;
     HIP_TRY(incr_launch_visibility(&V, V.prims.numChunks, ctx->props.multiProcessorCount, ws.ids, d->depth_buffer, (hipStream_t)stream));
     // 2. pixel shader

@@ -87,6 +87,10 @@ static_assert(sizeof(SubTriRec) == 48 && sizeof(SubTriAlpha) == 80, "visibility 
 #define INCR_VIS_STRIPES 16
 #endif
 static constexpr size_t kVisCounterBytes = 256 + (size_t)INCR_VIS_STRIPES * 128;
+// Screen bins (raster.hip vis_bin_kernel): one workgroup scans a bin's triangles into an LDS copy of the bin and stores it.  A bin is 2^binShift pixels square
+// (64 for frames of 4 M pixels and more, 32 below: enough workgroups to fill the chip); per bin three lists of triangle record indices.
+static constexpr uint32_t kVisBinCapDefault = 1024;
+enum VisBinList : uint32_t { kBinOpaque = 0, kBinAlpha = 1, kBinSmall = 2, kVisBinLists = 3 };
 struct VisParams {
     RasterScene S;
     float viewProj[16];
@@ -100,6 +104,9 @@ struct VisParams {
     uint32_t* __restrict__ vqCounters;               // [0] records [1] band items [2] small [3] whole [4..6] consumer cursors; [64 + 32 s] band cursor of stripe s (kVisCounterBytes)
     uint32_t recCap, bigCap;
     uint32_t y0, y1;                                 // scissor rows [y0, y1) (incr_view_constants::scissor_y0/y1)
+    // screen bins (origin: column 0, row y0): binCount[bin * 3 + list] triangles filed, the first binCap of them in binList[(bin * 3 + list) * binCap ..]; binCap == 0: no bins
+    uint32_t* __restrict__ binCount; uint32_t* __restrict__ binList;
+    uint32_t binsX, binsY, binCap, binShift;
     RasterPrims prims;                               // primitive path only
     int32_t forward;                                 // forward pass: every primitive of every visible mesh in scene order, cull mode from the material
 };

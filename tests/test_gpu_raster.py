@@ -535,6 +535,7 @@ def test_visibility_band_queue_overflow_path(rt, R, A, sio, gpu_ctx, sponza_smal
             out = hr.download(A.SURFACE_VISIBILITY), hr.download(A.SURFACE_DEPTH), list(st)
             hr.close()
             return out
+        monkeypatch.setenv("INCR_VIS_BIN_CAP", "0")                            # no screen bins: every large triangle takes the band queue
         vis0, depth0, st0 = frame()
         assert st0[0] > 0 and st0[1] > 0 and st0[2] > 0 and st0[3] == 0        # triangles, band items, small items, no overflow
         monkeypatch.setenv("INCR_VIS_BAND_QUEUE_CAP", "16")
@@ -543,6 +544,38 @@ def test_visibility_band_queue_overflow_path(rt, R, A, sio, gpu_ctx, sponza_smal
         assert st1[0] == st0[0] and st1[2] == st0[2] and st1[3] > 0            # same triangles, most large ones took the overflow path
         np.testing.assert_array_equal(vis1, vis0)
         np.testing.assert_array_equal(depth1, depth0)
+    finally:
+        gscene.close()
+
+
+@pytest.mark.parametrize("res", [(640, 360), (1000, 523)])
+def test_visibility_screen_bins(rt, R, A, sio, gpu_ctx, sponza_small, monkeypatch, res):
+    """Opaque large triangles are filed per screen bin and scanned into LDS by one workgroup per bin (vis_bin_kernel); a triangle that finds a
+    bin full takes the band queue instead.  With the bins off, on, and two entries small, ids and depths must agree bit for bit -- also at a
+    resolution that is no multiple of the bin or the tile size."""
+    W, H = res
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+    gscene = gpu_ctx.create_scene(sponza_small)
+    try:
+        def frame():
+            hr = R.HostRenderer(gpu_ctx, gscene, W, H)
+            hr.render(view); gpu_ctx.synchronize()
+            st = (C.c_uint32 * 4)()
+            rt.check(gpu_ctx.lib.incr_visibility_get_stats(gpu_ctx.handle, st))
+            out = hr.download(A.SURFACE_VISIBILITY), hr.download(A.SURFACE_DEPTH), list(st)
+            hr.close()
+            return out
+        vis_on, depth_on, st_on = frame()
+        monkeypatch.setenv("INCR_VIS_BIN_CAP", "0")
+        vis_off, depth_off, st_off = frame()
+        monkeypatch.setenv("INCR_VIS_BIN_CAP", "2")
+        vis_two, depth_two, st_two = frame()
+        monkeypatch.delenv("INCR_VIS_BIN_CAP")
+        assert st_on[0] == st_off[0] == st_two[0] and st_on[1] < st_two[1] <= st_off[1]      # same triangles; band items: alpha-tested only < + overflowed <= all
+        assert (vis_on != 0xFFFFF000).any()
+        for v, d in ((vis_off, depth_off), (vis_two, depth_two)):
+            np.testing.assert_array_equal(v, vis_on)
+            np.testing.assert_array_equal(d, depth_on)
     finally:
         gscene.close()
 

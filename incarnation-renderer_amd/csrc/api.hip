@@ -41,7 +41,7 @@ extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n
                                              int anyHit, uint32_t* ids, float* tuv, hipStream_t stream);
 extern "C" hipError_t incr_launch_codec_selftest(unsigned long long* out4, hipStream_t stream);
 extern "C" hipError_t incr_launch_rcp_selftest(unsigned long long* out2, hipStream_t stream);
-extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream);
+extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, const float* srgbSteps, hipStream_t stream);
 extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,
                                           uint32_t localRows, uint32_t texelBytes, hipStream_t stream);
 
@@ -109,6 +109,25 @@ int incr_initialize(int device_index, incr_context** out_ctx) {
     }
     HIP_TRY(hipMalloc((void**)&ctx->srgbLut, sizeof lut));
     HIP_TRY(hipMemcpy(ctx->srgbLut, lut, sizeof lut, hipMemcpyHostToDevice));
+    // FLOAT -> UNORM_SRGB render-target encode as the values where it steps (pt_device.h linear_to_srgb8): steps[k] = the smallest float in [0, 1] whose code is >= k,
+    // by bisection over the float patterns (non-negative floats order like their patterns; the encode is non-decreasing) with this host's powf
+    {
+        auto code = [](float c) {
+            const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.f / 2.4f) - 0.055f;
+            return (int)floorf(e * 255.f + 0.5f);
+        };
+        auto from_bits = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+        float steps[260];
+        steps[0] = 0.f;
+        for (int k = 1; k <= 255; ++k) {
+            uint32_t lo = 0u, hi = 0x3f800000u;                   // code(lo) < k <= code(hi): code(0) = 0, code(1) = 255
+            while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (code(from_bits(mid)) >= k) hi = mid; else lo = mid; }
+            steps[k] = from_bits(hi);
+        }
+        steps[256] = steps[257] = steps[258] = steps[259] = INFINITY;
+        HIP_TRY(hipMalloc((void**)&ctx->srgbSteps, sizeof steps));
+        HIP_TRY(hipMemcpy(ctx->srgbSteps, steps, sizeof steps, hipMemcpyHostToDevice));
+    }
     // 64 ray-count stripes, one 128-byte line each: the lane-per-pixel raster passes count their ray queries here (one
     // block-reduced atomic per workgroup, spread over 64 L2 lines) and a one-wave kernel folds them into the caller's stats
     HIP_TRY(hipMalloc((void**)&ctx->statStripes, 64 * 128));
@@ -141,6 +160,7 @@ int incr_teardown(incr_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->srgbLut) (void)hipFree(ctx->srgbLut);
+    if (ctx->srgbSteps) (void)hipFree(ctx->srgbSteps);
     if (ctx->statStripes) (void)hipFree(ctx->statStripes);
     if (ctx->wfOverflowTally) (void)hipFree(ctx->wfOverflowTally);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
@@ -1059,7 +1079,7 @@ int incr_tonemap(incr_context* ctx, const incr_tonemap_desc* d, incr_stream stre
     INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
     if (!d || !d->hdr_r11g11b10 || !d->ldr_rgba8) return fail(INCR_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(incr_launch_tonemap((const uint32_t*)d->hdr_r11g11b10, (uint32_t*)d->ldr_rgba8, (size_t)d->res_x * d->rows, (int)d->exposure, d->viewmode, (hipStream_t)stream));
+    HIP_TRY(incr_launch_tonemap((const uint32_t*)d->hdr_r11g11b10, (uint32_t*)d->ldr_rgba8, (size_t)d->res_x * d->rows, (int)d->exposure, d->viewmode, ctx->srgbSteps, (hipStream_t)stream));
     return INCR_OK;
 }
 

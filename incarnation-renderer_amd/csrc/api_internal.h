@@ -37,6 +37,7 @@ struct incr_context {
     int device;
     hipDeviceProp_t props;
     float* srgbLut;           // 256 floats in HBM
+    float* srgbSteps;         // the sRGB encode's 257 step positions (pt_device.h linear_to_srgb8)
     unsigned long long* statStripes;   // 64 x 128 B: striped ray counters of the lane-per-pixel raster passes (raster.hip count_rays)
     uint32_t forceStackEntries; // INCR_WF_STACK_ENTRIES (tests): lower bound for the traversal kernels' stack size
     uint32_t raysPerPath;     // INCR_WF_RAYS_PER_PATH (tests: a tiny queue forces the overflow path); 0 = sized from the scene (api.hip wf_rays_per_path)

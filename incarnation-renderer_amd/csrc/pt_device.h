@@ -208,11 +208,21 @@ DI f3 ACESFilm(f3 x) {
     return saturate((x * (a * x + b)) / (x * (c * x + d) + e));
 }
 // R8G8B8A8_UNORM_SRGB render-target encode + the tonemap of one R11G11B10F texel (postprocess/tonemap.hlsl:30-59)
-DI uint32_t linear_to_srgb8(float c) {
+// The encode is floor(e(c) * 255 + 0.5) with e(c) = 12.92 c below 0.0031308 and 1.055 c^(1/2.4) - 0.055 above, a non-decreasing step function of c: it is given by
+// the 255 values of c where it steps.  `steps[k]` is the smallest float whose code is >= k (steps[0] = 0, steps[256] = +inf), found at context creation by bisection
+// with the HOST's powf -- the one the reference's CPU restatement calls: the GPU result equals it bit for bit (the device library's powf differs from it by an ulp
+// here and there: round 1-4 tests allowed +-1 LSB), and the ~150 instructions of powf per channel -- half of the TAA resolve's instruction count -- become a
+// hardware log2 / exp2 estimate of the code plus two table compares.
+static constexpr uint32_t kSrgbSteps = 257;
+DI uint32_t linear_to_srgb8(const float* __restrict__ steps, float c) {
     if (!(c > 0.f)) c = 0.f;
     if (c > 1.f) c = 1.f;
-    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.f / 2.4f) - 0.055f;
-    return (uint32_t)floorf(e * 255.f + 0.5f);
+    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.f / 2.4f)) - 0.055f;     // estimate: within a fraction of a code
+    int k = (int)floorf(e * 255.f + 0.5f);
+    k = min(max(k, 0), 255);
+    if (c < steps[k]) --k;
+    else if (c >= steps[k + 1]) ++k;
+    return (uint32_t)k;
 }
 
 // ---------------------------------------------------------------- Preetham sky (preetham.hlsli:36-89)
@@ -869,11 +879,11 @@ DI float pinned_exp_neg(float x) {
     return __uint_as_float(__float_as_uint(p) + (uint32_t)((int)fi << 23));
 }
 
-DI uint32_t tonemap_texel(uint32_t hdrBits, float exposure, int viewmode) {
+DI uint32_t tonemap_texel(const float* __restrict__ srgbSteps, uint32_t hdrBits, float exposure, int viewmode) {
     const f3 h = unpack_r11g11b10(hdrBits);
     f3 l;
     if (viewmode != 0 && viewmode != 1) l = h; else l = ACESFilm(h * exposure);
-    return linear_to_srgb8(l.x) | (linear_to_srgb8(l.y) << 8) | (linear_to_srgb8(l.z) << 16) | 0xff000000u;
+    return linear_to_srgb8(srgbSteps, l.x) | (linear_to_srgb8(srgbSteps, l.y) << 8) | (linear_to_srgb8(srgbSteps, l.z) << 16) | 0xff000000u;
 }
 
 } // namespace incr

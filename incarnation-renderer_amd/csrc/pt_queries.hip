@@ -85,19 +85,25 @@ __global__ __launch_bounds__(256) void rcp_selftest_kernel(unsigned long long* _
 
 // TonemapPass: shaders/postprocess/tonemap.hlsl:30-59 with the R8G8B8A8_UNORM_SRGB render-target encode (tonemap_texel, pt_device.h).
 // Streaming: 16 B in, 16 B out per lane (four texels) -- with one texel per lane the pass ran at 0.59 TB/s.
-__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode, const float* __restrict__ srgbSteps) {
+    __shared__ float s_steps[kSrgbSteps];
+    for (uint32_t i = threadIdx.x; i < kSrgbSteps; i += blockDim.x) s_steps[i] = srgbSteps[i];
+    __syncthreads();
     const float e = Exposure(ev100);
     const size_t quads = n / 4;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
         const uint4 h = ((const uint4*)hdr)[q];
-        ((uint4*)ldr)[q] = make_uint4(tonemap_texel(h.x, e, viewmode), tonemap_texel(h.y, e, viewmode), tonemap_texel(h.z, e, viewmode), tonemap_texel(h.w, e, viewmode));
+        ((uint4*)ldr)[q] = make_uint4(tonemap_texel(s_steps, h.x, e, viewmode), tonemap_texel(s_steps, h.y, e, viewmode), tonemap_texel(s_steps, h.z, e, viewmode), tonemap_texel(s_steps, h.w, e, viewmode));
     }
-    for (size_t i = quads * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) ldr[i] = tonemap_texel(hdr[i], e, viewmode);
+    for (size_t i = quads * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) ldr[i] = tonemap_texel(s_steps, hdr[i], e, viewmode);
 }
 
-__global__ __launch_bounds__(256) void tonemap_scalar_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode) {
+__global__ __launch_bounds__(256) void tonemap_scalar_kernel(const uint32_t* __restrict__ hdr, uint32_t* __restrict__ ldr, size_t n, int ev100, int viewmode, const float* __restrict__ srgbSteps) {
+    __shared__ float s_steps[kSrgbSteps];
+    for (uint32_t i = threadIdx.x; i < kSrgbSteps; i += blockDim.x) s_steps[i] = srgbSteps[i];
+    __syncthreads();
     const float e = Exposure(ev100);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) ldr[i] = tonemap_texel(hdr[i], e, viewmode);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) ldr[i] = tonemap_texel(s_steps, hdr[i], e, viewmode);
 }
 
 // un-interleave gathered shards: src [numShards][localRows][W] -> dst [H][W]
@@ -124,14 +130,14 @@ extern "C" hipError_t incr_launch_trace_rays(const incr::PtParams* p, uint32_t n
     hipLaunchKernelGGL(incr::trace_rays_kernel, dim3((n + incr::kBlock - 1) / incr::kBlock), dim3(incr::kBlock), 0, stream, *p, n, origins, dirs, tmin, tmax, anyHit, ids, tuv);
     return hipGetLastError();
 }
-extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, hipStream_t stream) {
+extern "C" hipError_t incr_launch_tonemap(const uint32_t* hdr, uint32_t* ldr, size_t n, int ev100, int viewmode, const float* srgbSteps, hipStream_t stream) {
     if (!n) return hipSuccess;
     // surfaces come from hipMalloc (256-B aligned) or are row offsets of one: rows*res_x*4 B keeps uint4 alignment when res_x % 4 == 0;
     // anything else takes the scalar tail loop only
     const bool wide = (((uintptr_t)hdr | (uintptr_t)ldr) & 15u) == 0;
-    if (!wide) { const unsigned b1 = (unsigned)std::min<size_t>((n + 255) / 256, 8192); hipLaunchKernelGGL(incr::tonemap_scalar_kernel, dim3(b1), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode); return hipGetLastError(); }
+    if (!wide) { const unsigned b1 = (unsigned)std::min<size_t>((n + 255) / 256, 8192); hipLaunchKernelGGL(incr::tonemap_scalar_kernel, dim3(b1), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode, srgbSteps); return hipGetLastError(); }
     const unsigned blocks = (unsigned)std::min<size_t>((n / 4 + 255) / 256 + 1, 8192);
-    hipLaunchKernelGGL(incr::tonemap_kernel, dim3(blocks), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode);
+    hipLaunchKernelGGL(incr::tonemap_kernel, dim3(blocks), dim3(256), 0, stream, hdr, ldr, n, ev100, viewmode, srgbSteps);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_unshard(uint8_t* dst, const uint8_t* src, uint32_t W, uint32_t H, uint32_t h, uint32_t numShards,

@@ -883,7 +883,8 @@ __global__ __launch_bounds__(256, 4) void vis_scan_kernel(const VisParams P) {
     BandWalk bq;
     bw_init(bq, nBig);
 #ifndef INCR_VIS_GRAB
-#define INCR_VIS_GRAB 2      // band items per atomic on a segment's cursor
+#define INCR_VIS_GRAB 1      // band items per atomic on a segment's cursor: with the striped cursors the atomic is cheap and the items that are left (alpha-tested: their cost is their
+                             // surviving fragments, unknown beforehand) want the finest balance -- scan kernel 0.504 / 0.556 / 0.686 ms at 1 / 2 / 4
 #endif
 #ifdef INCR_DIAG_VIS_COUNT
     const long long diagT0 = clock64(), diagW0 = wall_clock64(); long long diagItemMax = 0, diagPrev = diagT0, diagSetup = 0, diagQueue = 0, diagCursor = 0, diagTop = diagT0; uint32_t diagItems = 0;
@@ -1823,6 +1824,11 @@ DI f3 sample_bilinear_clamp(const uint32_t* __restrict__ img, uint32_t W, uint32
 DI float lum_weight(f3 c) { return 1.f / (1.f + ((c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f)); }
 // taa-resolve.hlsl:34-117
 __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
+    __shared__ float s_steps[kSrgbSteps];
+    if (P.ldr) {                                                  // kernel-uniform
+        for (uint32_t i = threadIdx.x; i < kSrgbSteps; i += 256u) s_steps[i] = P.srgbSteps[i];
+        __syncthreads();
+    }
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.y1) return;
     const size_t i = (size_t)y * P.W + x;
@@ -1830,7 +1836,7 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
     if (P.historyIndex == 0) {
         const uint32_t o = pack_r11g11b10(cur, P.rounding);
         P.histOut[i] = o;
-        if (P.ldr) P.ldr[i] = tonemap_texel(o, Exposure(P.ev100), P.viewmode);
+        if (P.ldr) P.ldr[i] = tonemap_texel(s_steps, o, Exposure(P.ev100), P.viewmode);
         return;
     }
     const f2 uv = {((float)x + 0.5f) / (float)P.W, ((float)y + 0.5f) / (float)P.H};
@@ -1855,7 +1861,7 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(const TaaParams P) {
     const uint32_t o = pack_r11g11b10(out, P.rounding);
     P.histOut[i] = o;
     // TonemapPass fused into the resolve when the caller presents this surface: the tonemap reads exactly the stored texel
-    if (P.ldr) P.ldr[i] = tonemap_texel(o, Exposure(P.ev100), P.viewmode);
+    if (P.ldr) P.ldr[i] = tonemap_texel(s_steps, o, Exposure(P.ev100), P.viewmode);
 }
 
 } // namespace incr

@@ -727,7 +727,7 @@ int incr_taa_resolve(incr_context* ctx, const incr_taa_resolve_desc* d, incr_str
     scissor_rows(*d->view, &P.y0, &P.y1);
     P.hdr = d->hdr_scene_color; P.histIn = d->history_in; P.histOut = d->history_out; P.depth = d->depth_buffer;
     memcpy(P.invViewProj, d->view->taa_inv_view_proj.m, 64); memcpy(P.prevViewProj, d->view->prev_view_proj_transform.m, 64);
-    P.ldr = (uint32_t*)d->ldr_rgba8; P.ev100 = (int)d->exposure; P.viewmode = d->viewmode;
+    P.ldr = (uint32_t*)d->ldr_rgba8; P.ev100 = (int)d->exposure; P.viewmode = d->viewmode; P.srgbSteps = ctx->srgbSteps;
     HIP_TRY(incr_launch_taa_resolve(&P, (hipStream_t)stream));
     return INCR_OK;
 }

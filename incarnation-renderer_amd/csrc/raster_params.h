@@ -213,6 +213,7 @@ struct TaaParams {
     float invViewProj[16], prevViewProj[16];
     uint32_t y0, y1;
     uint32_t* __restrict__ ldr; int32_t ev100, viewmode;      // optional: tonemapped copy of the resolved texel (presenting path)
+    const float* __restrict__ srgbSteps;                      // pt_device.h linear_to_srgb8
 };
 
 } // namespace incr

@@ -397,9 +397,10 @@ int incr_scene_destroy(incr_context* ctx, incr_scene* sc) {
     if (!sc) return INCR_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     void* ptrs[] = {(void*)sc->dAlphaQuads, sc->dNodes, sc->dTris, sc->dShade, sc->dMaterials, sc->dTextures, sc->dMaterialTexels, sc->dMeshLocalToWorld, sc->dGlobalLights, sc->dLightIndices, sc->dLightTransforms,
-                    sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes};
+                    sc->dGridOffsets, sc->dGridLights, sc->dResolvedLights, sc->dTriObj, sc->dLevelNodes, sc->dMeshInfo, sc->dNodeBoxes, sc->sunCover};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : sc->dTexels) if (p) (void)hipFree(p);
+    if (sc->sunCoverBuilt) (void)hipEventDestroy(sc->sunCoverBuilt);
     for (int k = 0; k < 2; ++k) { if (sc->staging.done[k]) { (void)hipEventSynchronize(sc->staging.done[k]); (void)hipEventDestroy(sc->staging.done[k]); } if (sc->staging.host[k]) (void)hipHostFree(sc->staging.host[k]); }
     incr_raster_scene_free(sc);
     delete sc;
@@ -706,6 +707,7 @@ int incr_update_bvh(incr_context* ctx, incr_scene* sc, const incr_matrix* mesh_t
         for (size_t i = 0; i < nm; ++i) if (sc->host.meshVisibility[i] != mesh_visibility[i]) { sc->host.meshVisibility[i] = mesh_visibility[i]; dirty = true; }
     if (root_transform && memcmp(sc->host.rootTransform.m, root_transform->m, 64)) { sc->host.rootTransform = m44_from(*root_transform); dirty = true; }
     if (!dirty) return INCR_OK;          // the reference rebuilds its TLAS every frame; ours only when an input changed
+    ++sc->geometryEpoch;                 // what is derived from the world-space triangles (the sun cover map) is stale
     // The device work below is ordered on the caller's stream: small uploads (per-mesh matrices and instance ids, the rebuilt top
     // tree, the light grid), then the re-transform and refit kernels of bvh_update.hip.  The CALL itself does host work -- the top
     // tree and the light grid are rebuilt on the host, and taking a staging slot may wait for the slot's previous use

@@ -79,6 +79,11 @@ struct incr_scene {
     float* dMeshLocalToWorld = nullptr;
     float* dResolvedLights = nullptr;
     incr_light* dGlobalLights = nullptr; int32_t* dLightIndices = nullptr; float* dLightTransforms = nullptr;
+    // sun cover map of this scene (raster_params.h SunCover; 256-byte header + G x G words): built by the first lighting pass that has a sun, again after an
+    // incr_update_bvh that moved something (geometryEpoch) or for another light index.  A cache behind const scene pointers.
+    mutable void* sunCover = nullptr; mutable uint64_t sunCoverEpoch = 0; mutable uint32_t sunCoverIndex = 0;
+    mutable hipEvent_t sunCoverBuilt = nullptr; mutable hipStream_t sunCoverStream = nullptr;      // a pass on another stream waits for the build
+    uint64_t geometryEpoch = 1;
     std::vector<void*> dTexels;
     std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers of the TILED chains + mip counts)
     incr::MaterialTexels* dMaterialTexels = nullptr;   // per material: interleaved level-0 texels of its three main textures (device_types.h)

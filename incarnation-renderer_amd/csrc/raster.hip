@@ -1221,6 +1221,131 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
     return occluded;
 }
 
+// ---- sun cover map (raster_params.h SunCover) ----
+// heights as unsigned keys that order like the floats (atomicMax); 0 = below everything
+DI uint32_t height_key(float h) { const uint32_t b = __float_as_uint(h); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+// One thread: the frame of the map from the sun's direction (light_setup's, from the light table the lighting pass reads) and the root node's box.
+__global__ void sun_cover_header_kernel(const PtParams S, uint32_t sunIndex, SunCoverHeader* __restrict__ out) {
+    SunCoverHeader h = {};
+    incr_light light; const float* m; bool haveT;
+    load_global_light(S, sunIndex, light, m, haveT);
+    const LightSample ls = light_setup(light, m, haveT, {0.f, 0.f, 0.f}, {0.f, 1.f, 0.f});
+    const f3 L = ls.L;
+    const bool unit = fabsf(dot(L, L) - 1.f) < 1e-3f;             // also false for NaN
+    if (light.type == INCR_LIGHT_DIRECTIONAL && unit && S.numNodes != 0u) {
+        const f3 a = fabsf(L.x) < 0.577f ? mk3(1.f, 0.f, 0.f) : (fabsf(L.y) < 0.577f ? mk3(0.f, 1.f, 0.f) : mk3(0.f, 0.f, 1.f));
+        const f3 U = normalize(cross(a, L)), V = cross(L, U);
+        const BvhNode8 root = S.nodes[0];
+        const f3 lo = {root.ox, root.oy, root.oz};
+        const f3 hi = {root.ox + 256.f * __uint_as_float((uint32_t)root.ex << 23), root.oy + 256.f * __uint_as_float((uint32_t)root.ey << 23), root.oz + 256.f * __uint_as_float((uint32_t)root.ez << 23)};
+        float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, ext = 0.f;
+        for (int c = 0; c < 8; ++c) {
+            const f3 p = {c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z};
+            const float u = dot(p, U), v = dot(p, V);
+            umin = fminf(umin, u); umax = fmaxf(umax, u); vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            ext = fmaxf(ext, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+        }
+        const float side = fmaxf(umax - umin, vmax - vmin);
+        if (side > 0.f && side < 3.0e37f && ext < 3.0e37f) {
+            h.U[0] = U.x; h.U[1] = U.y; h.U[2] = U.z; h.V[0] = V.x; h.V[1] = V.y; h.V[2] = V.z; h.L[0] = L.x; h.L[1] = L.y; h.L[2] = L.z;
+            // eps: far above the rounding of a projection (|p| 2^-22) and of the traversal's triangle test, far below a cell
+            h.eps = fmaxf(ext, side) * (1.f / 16384.f);
+            h.u0 = umin - 2.f * h.eps; h.v0 = vmin - 2.f * h.eps;
+            h.invCell = (float)kSunCoverG / (side + 4.f * h.eps);
+            h.valid = 1u;
+        }
+    }
+#ifdef INCR_DIAG_SUN_COUNT
+    printf("sun cover header: valid %u type %u L %g %g %g u0 %g v0 %g invCell %g eps %g nodes %u root %g %g %g e %u %u %u\n", h.valid, (unsigned)light.type, L.x, L.y, L.z, h.u0, h.v0, h.invCell, h.eps,
+           S.numNodes, S.nodes[0].ox, S.nodes[0].oy, S.nodes[0].oz, (unsigned)S.nodes[0].ex, (unsigned)S.nodes[0].ey, (unsigned)S.nodes[0].ez);
+#endif
+    *out = h;
+}
+// One lane per triangle record, conservative rasterisation onto the map: every cell that the triangle's projection (grown by eps) can touch takes the greatest height of
+// the triangle's PLANE over the cell, capped by the triangle's highest vertex (+ eps) -- a sloped triangle must not lift its whole bounding box to its top vertex, or the
+// surface a shadow ray starts from would hide its own lit neighbourhood.  Triangles seen edge-on or nearly so (plane gradient beyond 1000) fall back to the vertex cap.
+// Footprints of more than 16 cells are spread over the wave.
+struct SunTri { float u[3], v[3]; float h0, gu, gv, hcap, orient; int32_t cu0, cu1, cv0, cv1; };
+DI void sun_cover_cell(const SunCoverHeader& H, const SunTri& t, int32_t cu, int32_t cv, uint32_t* __restrict__ grid) {
+    const float cell = 1.f / H.invCell;
+    const float x0 = H.u0 + (float)cu * cell - H.eps, x1 = H.u0 + (float)(cu + 1) * cell + H.eps, y0 = H.v0 + (float)cv * cell - H.eps, y1 = H.v0 + (float)(cv + 1) * cell + H.eps;
+    if (t.orient != 0.f) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                            // the cell's corner that lies deepest inside edge k must not be outside it
+            const int j = k == 2 ? 0 : k + 1;
+            const float A = -t.orient * (t.v[j] - t.v[k]), B = t.orient * (t.u[j] - t.u[k]);
+            const float e = A * ((A > 0.f ? x1 : x0) - t.u[k]) + B * ((B > 0.f ? y1 : y0) - t.v[k]);
+            if (e < -(fabsf(A) + fabsf(B)) * H.eps) return;
+        }
+    }
+    float h = t.hcap;
+    if (t.gu == t.gu) h = fminf(h, t.h0 + t.gu * ((t.gu > 0.f ? x1 : x0) - t.u[0]) + t.gv * ((t.gv > 0.f ? y1 : y0) - t.v[0]) + 2.f * H.eps);
+    atomicMax(grid + (size_t)cv * kSunCoverG + (uint32_t)cu, height_key(h));
+}
+__global__ __launch_bounds__(256) void sun_cover_raster_kernel(const TriIsect* __restrict__ tris, uint32_t numTris, const SunCoverHeader* __restrict__ header, uint32_t* __restrict__ grid) {
+    const SunCoverHeader H = *header;
+    if (!H.valid) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    bool have = false;
+    SunTri t = {};
+    if (i < numTris) {
+        const TriIsect r = tris[i];
+        if (r.flatId != kTriHole) {
+            const f3 p0 = {r.v0x, r.v0y, r.v0z}, p1 = {r.v0x + r.e1x, r.v0y + r.e1y, r.v0z + r.e1z}, p2 = {r.v0x + r.e2x, r.v0y + r.e2y, r.v0z + r.e2z};
+            const f3 U = {H.U[0], H.U[1], H.U[2]}, V = {H.V[0], H.V[1], H.V[2]}, L = {H.L[0], H.L[1], H.L[2]};
+            t.u[0] = dot(p0, U); t.u[1] = dot(p1, U); t.u[2] = dot(p2, U); t.v[0] = dot(p0, V); t.v[1] = dot(p1, V); t.v[2] = dot(p2, V);
+            const float h0 = dot(p0, L), h1 = dot(p1, L), h2 = dot(p2, L);
+            t.h0 = h0; t.hcap = fmaxf(h0, fmaxf(h1, h2)) + H.eps;
+            const float ulo = fminf(t.u[0], fminf(t.u[1], t.u[2])) - H.eps, uhi = fmaxf(t.u[0], fmaxf(t.u[1], t.u[2])) + H.eps;
+            const float vlo = fminf(t.v[0], fminf(t.v[1], t.v[2])) - H.eps, vhi = fmaxf(t.v[0], fmaxf(t.v[1], t.v[2])) + H.eps;
+            // the shadow query culls back faces (pt_traverse.h tri_hit: det = e1 . (d x e2) > 0 with d = L): a triangle that fails this for the sun's direction
+            // -- the courtyard's roof seen from below -- hides nothing.  The same expression; kept when within rounding of zero.
+            const f3 e1 = {r.e1x, r.e1y, r.e1z}, e2 = {r.e2x, r.e2y, r.e2z};
+            const float det = dot(e1, cross(L, e2));
+            const bool faces = !(det < -1e-5f * sqrtf(dot(e1, e1) * dot(e2, e2)));
+            if (faces && ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi && t.hcap == t.hcap) {          // (a record with NaNs no ray can hit)
+                const float G1 = (float)(kSunCoverG - 1u);
+                t.cu0 = (int32_t)fminf(fmaxf(floorf((ulo - H.u0) * H.invCell), 0.f), G1); t.cu1 = (int32_t)fminf(fmaxf(floorf((uhi - H.u0) * H.invCell), 0.f), G1);
+                t.cv0 = (int32_t)fminf(fmaxf(floorf((vlo - H.v0) * H.invCell), 0.f), G1); t.cv1 = (int32_t)fminf(fmaxf(floorf((vhi - H.v0) * H.invCell), 0.f), G1);
+                const float du1 = t.u[1] - t.u[0], dv1 = t.v[1] - t.v[0], du2 = t.u[2] - t.u[0], dv2 = t.v[2] - t.v[0];
+                const float area2 = du1 * dv2 - du2 * dv1;
+                // the projection's area against its edges' rounding: below that the triangle is a sliver on the map -- every cell of its box, the vertex cap
+                const bool flat = fabsf(area2) > 1e-4f * ((fabsf(du1) + fabsf(dv1)) * (fabsf(du2) + fabsf(dv2)));
+                t.orient = flat ? (area2 > 0.f ? 1.f : -1.f) : 0.f;
+                t.gu = t.gv = __uint_as_float(0x7fc00000u);
+                if (flat) {
+                    const float gu = ((h1 - h0) * dv2 - (h2 - h0) * dv1) / area2, gv = ((h2 - h0) * du1 - (h1 - h0) * du2) / area2;
+                    if (fabsf(gu) < 1000.f && fabsf(gv) < 1000.f) { t.gu = gu; t.gv = gv; }
+                }
+                have = true;
+            }
+        }
+    }
+    const uint32_t ncu = have ? (uint32_t)(t.cu1 - t.cu0 + 1) : 0u, cells = have ? ncu * (uint32_t)(t.cv1 - t.cv0 + 1) : 0u;
+    if (have && cells <= 16u)
+        for (int32_t cv = t.cv0; cv <= t.cv1; ++cv)
+            for (int32_t cu = t.cu0; cu <= t.cu1; ++cu) sun_cover_cell(H, t, cu, cv, grid);
+    for (unsigned long long big = __ballot(have && cells > 16u); big != 0ull; big &= big - 1ull) {
+        const int src = __ffsll((long long)big) - 1;
+        SunTri s;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s.u[k] = __shfl(t.u[k], src, 64); s.v[k] = __shfl(t.v[k], src, 64); }
+        s.h0 = __shfl(t.h0, src, 64); s.gu = __shfl(t.gu, src, 64); s.gv = __shfl(t.gv, src, 64); s.hcap = __shfl(t.hcap, src, 64); s.orient = __shfl(t.orient, src, 64);
+        s.cu0 = __shfl(t.cu0, src, 64); s.cv0 = __shfl(t.cv0, src, 64);
+        const uint32_t sn = (uint32_t)__shfl((int)ncu, src, 64), sc = (uint32_t)__shfl((int)cells, src, 64);
+        for (uint32_t j = lane; j < sc; j += 64u) sun_cover_cell(H, s, s.cu0 + (int32_t)(j % sn), s.cv0 + (int32_t)(j / sn), grid);
+    }
+}
+// true: nothing of the scene lies above `p` toward the sun beyond the query's tmin -- the shadow ray from p is unoccluded
+DI bool sun_cover_clear(const SunCover& C, f3 p, float tmin) {
+    const SunCoverHeader& H = *C.header;
+    if (!H.valid) return false;
+    const float u = ((p.x * H.U[0] + p.y * H.U[1]) + p.z * H.U[2] - H.u0) * H.invCell, v = ((p.x * H.V[0] + p.y * H.V[1]) + p.z * H.V[2] - H.v0) * H.invCell;
+    if (!(u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG)) return false;
+    const float h = (p.x * H.L[0] + p.y * H.L[1]) + p.z * H.L[2];
+    return C.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] < height_key(h + tmin - 2.f * H.eps);
+}
+
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115), in two halves around the shadow
 // query so that the query can be made by the whole wave at once
 struct DirectSetup { LightSample s; f3 worldPos, V; bool wantsRay; };
@@ -1262,8 +1387,23 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
     GBufferPixel g = {};
     DirectSetup ds = {};
     if (valid) { g = read_gbuffer(P.L, i); ds = direct_setup(P, g, x, y, i, rays); }
+#ifdef INCR_DIAG_SUN_COUNT       // diagnostic only: light_shadow_rays = rays + 65536 x rays the cover map answers (=2) / occluded rays (otherwise)
+    const bool diagWanted = ds.wantsRay;
+    if (P.cover.header && valid && (x % 640u) == 320u && (y % 540u) == 270u) {
+        const SunCoverHeader& H = *P.cover.header; const f3 p = ds.worldPos;
+        const float u = ((p.x * H.U[0] + p.y * H.U[1]) + p.z * H.U[2] - H.u0) * H.invCell, v = ((p.x * H.V[0] + p.y * H.V[1]) + p.z * H.V[2] - H.v0) * H.invCell;
+        const float h = (p.x * H.L[0] + p.y * H.L[1]) + p.z * H.L[2];
+        const uint32_t k = (u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG) ? P.cover.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] : 0u;
+        const float stored = __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+        printf("pixel %u %u: world %g %g %g wants %d  cell %g %g  height %g  map %g (key %08x)  N %g %g %g\n", x, y, p.x, p.y, p.z, (int)ds.wantsRay, u, v, h, stored, k, g.N.x, g.N.y, g.N.z);
+    }
+#endif
+    if (P.cover.header && ds.wantsRay && sun_cover_clear(P.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
     const bool occluded = trace_any_packet(P.S, s_stack + (threadIdx.x >> 6) * kPacketStack, ds.worldPos, ds.s.L, 0.1f, 1000.f, valid && ds.wantsRay);
     if (valid) add_color(P.L, i, direct_finish(ds, g, occluded));
+#ifdef INCR_DIAG_SUN_COUNT
+    if (INCR_DIAG_SUN_COUNT == 2 ? (valid && diagWanted && !ds.wantsRay) : (valid && ds.wantsRay && occluded)) rays += 65536u;
+#endif
     count_rays(P.S, rays);
 }
 
@@ -1706,7 +1846,12 @@ __global__ __launch_bounds__(kBlock) void deferred_lighting_kernel(const FusedLi
     if (P.haveDirect) {          // uniform: the shadow query is made by the whole wave (trace_any_packet)
         DirectSetup ds = {};
         if (valid) ds = direct_setup(P.direct, g, x, y, i, rays);
+        if (P.direct.cover.header && ds.wantsRay && sun_cover_clear(P.direct.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
+#ifdef INCR_DIAG_NO_SUN_WALK     // diagnostic only: the pass without the sun's shadow walk (everything lit)
+        const bool occluded = false;
+#else
         const bool occluded = trace_any_packet(P.direct.S, s_stack + (threadIdx.x >> 6) * kPacketStack, ds.worldPos, ds.s.L, 0.1f, 1000.f, valid && ds.wantsRay);
+#endif
         if (valid) c = pack_r11g11b10(unpack_r11g11b10(c) + direct_finish(ds, g, occluded), L.rounding);
     }
     if (valid) {
@@ -1926,6 +2071,13 @@ extern "C" hipError_t incr_launch_gbuffer(const GBufferParams* p, hipStream_t st
 extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t stream) {
     if (!p->L.W || p->L.y1 <= p->L.y0) return hipSuccess;
     hipLaunchKernelGGL(sky_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t incr_launch_sun_cover(const PtParams* S, uint32_t sunIndex, SunCoverHeader* header, uint32_t* grid, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(grid, 0, (size_t)kSunCoverG * kSunCoverG * 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sun_cover_header_kernel, dim3(1), dim3(1), 0, stream, *S, sunIndex, header);
+    if (S->numTris) hipLaunchKernelGGL(sun_cover_raster_kernel, dim3((S->numTris + 255u) / 256u), dim3(256), 0, stream, S->tris, S->numTris, header, grid);
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {

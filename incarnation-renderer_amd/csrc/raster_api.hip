@@ -28,6 +28,7 @@ extern "C" hipError_t incr_launch_decals(const DecalParams* p, int numCUs, hipSt
 extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
+extern "C" hipError_t incr_launch_sun_cover(const PtParams* S, uint32_t sunIndex, SunCoverHeader* header, uint32_t* grid, hipStream_t stream);
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------- scene data
@@ -586,6 +587,23 @@ static int fill_direct(incr_context* ctx, const incr_direct_lighting_desc* d, Di
     P.sunIndex = (uint32_t)d->directional_light_index;
     return INCR_OK;
 }
+// The sun cover map of the pass's scene (raster_params.h SunCover), (re)built on `stream` ahead of the lighting kernel when the scene's is stale.  Test hook INCR_SUN_COVER=0: no map.
+static int build_sun_cover(incr_context* ctx, const incr_scene* sc, DirectParams& P, hipStream_t stream) {
+    if (const char* v = test_hook_env("INCR_SUN_COVER")) if (v[0] == '0') return INCR_OK;
+    if (!P.S.numTris || !P.S.numNodes) return INCR_OK;
+    if (!sc->sunCover) {
+        HIP_TRY(hipMalloc((void**)&sc->sunCover, 256 + (size_t)kSunCoverG * kSunCoverG * 4)); sc->sunCoverEpoch = 0;
+        HIP_TRY(hipEventCreateWithFlags(&sc->sunCoverBuilt, hipEventDisableTiming));
+    }
+    SunCoverHeader* header = (SunCoverHeader*)sc->sunCover; uint32_t* grid = (uint32_t*)((uint8_t*)sc->sunCover + 256);
+    if (sc->sunCoverEpoch != sc->geometryEpoch || sc->sunCoverIndex != P.sunIndex) {
+        HIP_TRY(incr_launch_sun_cover(&P.S, P.sunIndex, header, grid, stream));
+        HIP_TRY(hipEventRecord(sc->sunCoverBuilt, stream));
+        sc->sunCoverEpoch = sc->geometryEpoch; sc->sunCoverIndex = P.sunIndex; sc->sunCoverStream = stream;
+    } else if (stream != sc->sunCoverStream) HIP_TRY(hipStreamWaitEvent(stream, sc->sunCoverBuilt, 0));
+    P.cover.header = header; P.cover.grid = grid;
+    return INCR_OK;
+}
 int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
     INCR_RANGE();
     if (!ctx) return fail(INCR_ERR_NOT_INITIALIZED, "context is NULL");
@@ -593,6 +611,7 @@ int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, 
     DirectParams P;
     int rc = fill_direct(ctx, d, P);
     if (rc) return rc;
+    if ((rc = build_sun_cover(ctx, d->in.scene, P, (hipStream_t)stream))) return rc;
     HIP_TRY(incr_launch_direct_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }
@@ -634,7 +653,7 @@ int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc*
     int rc = INCR_OK;
     P.haveSky = d->sky != nullptr; P.haveDirect = d->direct != nullptr; P.haveClustered = d->clustered != nullptr;
     if (d->sky && (rc = fill_sky(d->sky, P.sky))) return rc;
-    if (d->direct && (rc = fill_direct(ctx, d->direct, P.direct))) return rc;
+    if (d->direct && ((rc = fill_direct(ctx, d->direct, P.direct)) || (rc = build_sun_cover(ctx, d->direct->in.scene, P.direct, (hipStream_t)stream)))) return rc;
     if (d->clustered && (rc = fill_clustered(ctx, d->clustered, P.clustered))) return rc;
     const LightingParams* parts[3] = {d->sky ? &P.sky.L : nullptr, d->direct ? &P.direct.L : nullptr, d->clustered ? &P.clustered.L : nullptr};
     const LightingParams* first = nullptr;

@@ -547,6 +547,44 @@ def test_visibility_band_queue_overflow_path(rt, R, A, sio, gpu_ctx, sponza_smal
         gscene.close()
 
 
+def test_sun_cover_map_changes_nothing(rt, R, A, sio, gpu_ctx, sponza_small, monkeypatch):
+    """The sun's shadow rays skip the BVH walk where the sun cover map (the scene's greatest height toward the sun per cell of an orthographic grid)
+    proves nothing can be hit.  With the map and without it the lit frame and the ray counters must agree bit for bit -- also after a mesh has
+    moved (the map is rebuilt when incr_update_bvh changed something) and for a renderer on a second stream (which waits for the build)."""
+    import torch
+    W, H = 640, 360
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+
+    def frames(cover):
+        if cover: monkeypatch.delenv("INCR_SUN_COVER", raising=False)
+        else: monkeypatch.setenv("INCR_SUN_COVER", "0")
+        gscene = gpu_ctx.create_scene(sponza_small)
+        out = []
+        try:
+            hr = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9)
+            hr.render(view); gpu_ctx.synchronize()
+            out.append((hr.download(A.SURFACE_HDR_RASTER), hr.stats()[1].light_shadow_rays))
+            other = torch.cuda.Stream(device=0)
+            hr2 = R.HostRenderer(gpu_ctx, gscene, W, H, sh9_rgb=DEFAULT_SH9, stream=C.c_void_p(other.cuda_stream))
+            hr2.render(view); other.synchronize(); gpu_ctx.synchronize()
+            out.append((hr2.download(A.SURFACE_HDR_RASTER), hr2.stats()[1].light_shadow_rays))
+            hr2.close()
+            m = np.array(sponza_small.mesh_transforms[0], dtype=np.float32).reshape(4, 4).copy()
+            m[3, 1] += 0.75                                        # the whole mesh three quarters of a unit up: every height on the map changes
+            gscene.update_bvh(mesh_transforms=[m]); gpu_ctx.synchronize()
+            hr.render(view); gpu_ctx.synchronize()
+            out.append((hr.download(A.SURFACE_HDR_RASTER), hr.stats()[1].light_shadow_rays))
+            hr.close()
+        finally:
+            gscene.close()
+        return out
+    with_map, without = frames(True), frames(False)
+    assert with_map[0][1] > 0 and (with_map[0][0] != with_map[2][0]).any()          # the sun shines and the move changed the picture
+    for k, ((a, ra), (b, rb)) in enumerate(zip(with_map, without)):
+        np.testing.assert_array_equal(a, b, err_msg="frame %d" % k)
+        assert ra == rb, k
+
+
 @pytest.mark.parametrize("res", [(640, 360), (1000, 523)])
 def test_visibility_screen_bins(rt, R, A, sio, gpu_ctx, sponza_small, monkeypatch, res):
     """Opaque large triangles are filed per screen bin and scanned into LDS by one workgroup per bin (vis_bin_kernel); a triangle that finds a

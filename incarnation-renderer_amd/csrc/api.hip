@@ -947,6 +947,10 @@ int incr_pathtrace(incr_context* ctx, const incr_pathtrace_desc* d, incr_stream 
         ctx->profPipes.push_back(ctx->wfPipes | (ctx->wfOverlap ? 0x100 : 0));
         ctx->profFrames++;
     }
+    // the scene's sun cover map: a shadow ray toward the first directional light that provably hits nothing is answered at its set-up (pathtrace_wf.hip shadow_gen_block)
+    if (P.directLighting)
+        for (size_t li = 0; li < sc->host.globalLights.size(); ++li)
+            if (sc->host.globalLights[li].type == INCR_LIGHT_DIRECTIONAL) { if ((rc = incr_ensure_sun_cover(ctx, sc, (uint32_t)li, P, (hipStream_t)stream))) return rc; break; }
     const uint32_t stackEntries = std::max(sc->bvh.maxDepth > 1 ? sc->bvh.maxDepth - 1 : 1u, std::min(ctx->forceStackEntries, 24u));
     ctx->wfStreams[0] = (hipStream_t)stream;
     HIP_TRY(incr_launch_pathtrace_wf(&P, ctx->wf, ctx->wfPipes, ctx->wfTileRow, ctx->wfStreams, ctx->wfFork, ctx->wfJoin, ctx->props.multiProcessorCount, stackEntries, ev,

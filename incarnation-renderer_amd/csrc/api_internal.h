@@ -127,6 +127,7 @@ void incr_perez_from_turbidity(float t, incr_perez_distribution* p);
 void incr_sky_sun_terms(const float s[3], float t, const incr_perez_distribution& pc, incr::SkySun* out);
 // scene part of the traversal / shading kernel arguments (api.hip)
 void incr_fill_scene_params(const incr_context* ctx, const incr_scene* sc, incr::PtParams& P);
+extern "C" int incr_ensure_sun_cover(incr_context* ctx, const incr_scene* sc, uint32_t sunIndex, incr::PtParams& S, hipStream_t stream);      // raster_api.hip
 // raster_api.hip: bake + upload the per-meshlet-vertex attribute arrays; free them
 int  incr_raster_scene_upload(incr_scene* sc);
 void incr_raster_scene_free(incr_scene* sc);

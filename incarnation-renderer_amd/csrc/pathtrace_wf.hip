@@ -632,6 +632,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
         f3 L, contribution = {0.f, 0.f, 0.f};
+        bool answered = false;       // the sun cover map (pt_params.h SunCover) proves the ray unoccluded: its queue entry is a null ray, its record stays "visible"
         if (slot == kSkySlot) {
             // chsMain's sky sample (pathtracing.hlsl:239-244): GetSkyRadiance with lightVisibility = 1 (lighting/common.hlsli:145-202) over the
             // pdf, times the path attenuation -- evaluated HERE like the lights', so that accumulate only sums
@@ -655,11 +656,12 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const f3 N = {n4.x, n4.y, n4.z};
             const LightSample ls = light_setup(light, lm, true, origin, N);
             L = ls.L;
+            answered = P.cover.header && sun_cover_is_light(P.cover, light, L) && sun_cover_clear(P.cover, origin, 0.1f);
             const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
             const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
             contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
         }
-        B.rayQ[(size_t)(base + dest) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
+        B.rayQ[(size_t)(base + dest) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(answered ? 0xffffffffu : vp));
         B.rayQ[(size_t)(base + dest) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(base + r));      // .w: the ray's record
         B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
     }

@@ -1222,8 +1222,6 @@ DI bool trace_any_packet(const PtParams& P, uint32_t* __restrict__ stack, f3 o, 
 }
 
 // ---- sun cover map (raster_params.h SunCover) ----
-// heights as unsigned keys that order like the floats (atomicMax); 0 = below everything
-DI uint32_t height_key(float h) { const uint32_t b = __float_as_uint(h); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 // One thread: the frame of the map from the sun's direction (light_setup's, from the light table the lighting pass reads) and the root node's box.
 __global__ void sun_cover_header_kernel(const PtParams S, uint32_t sunIndex, SunCoverHeader* __restrict__ out) {
     SunCoverHeader h = {};
@@ -1336,16 +1334,6 @@ __global__ __launch_bounds__(256) void sun_cover_raster_kernel(const TriIsect* _
         for (uint32_t j = lane; j < sc; j += 64u) sun_cover_cell(H, s, s.cu0 + (int32_t)(j % sn), s.cv0 + (int32_t)(j / sn), grid);
     }
 }
-// true: nothing of the scene lies above `p` toward the sun beyond the query's tmin -- the shadow ray from p is unoccluded
-DI bool sun_cover_clear(const SunCover& C, f3 p, float tmin) {
-    const SunCoverHeader& H = *C.header;
-    if (!H.valid) return false;
-    const float u = ((p.x * H.U[0] + p.y * H.U[1]) + p.z * H.U[2] - H.u0) * H.invCell, v = ((p.x * H.V[0] + p.y * H.V[1]) + p.z * H.V[2] - H.v0) * H.invCell;
-    if (!(u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG)) return false;
-    const float h = (p.x * H.L[0] + p.y * H.L[1]) + p.z * H.L[2];
-    return C.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] < height_key(h + tmin - 2.f * H.eps);
-}
-
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115), in two halves around the shadow
 // query so that the query can be made by the whole wave at once
 struct DirectSetup { LightSample s; f3 worldPos, V; bool wantsRay; };
@@ -1389,16 +1377,16 @@ __global__ __launch_bounds__(kBlock) void direct_lighting_kernel(const DirectPar
     if (valid) { g = read_gbuffer(P.L, i); ds = direct_setup(P, g, x, y, i, rays); }
 #ifdef INCR_DIAG_SUN_COUNT       // diagnostic only: light_shadow_rays = rays + 65536 x rays the cover map answers (=2) / occluded rays (otherwise)
     const bool diagWanted = ds.wantsRay;
-    if (P.cover.header && valid && (x % 640u) == 320u && (y % 540u) == 270u) {
-        const SunCoverHeader& H = *P.cover.header; const f3 p = ds.worldPos;
+    if (P.S.cover.header && valid && (x % 640u) == 320u && (y % 540u) == 270u) {
+        const SunCoverHeader& H = *P.S.cover.header; const f3 p = ds.worldPos;
         const float u = ((p.x * H.U[0] + p.y * H.U[1]) + p.z * H.U[2] - H.u0) * H.invCell, v = ((p.x * H.V[0] + p.y * H.V[1]) + p.z * H.V[2] - H.v0) * H.invCell;
         const float h = (p.x * H.L[0] + p.y * H.L[1]) + p.z * H.L[2];
-        const uint32_t k = (u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG) ? P.cover.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] : 0u;
+        const uint32_t k = (u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG) ? P.S.cover.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] : 0u;
         const float stored = __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
         printf("pixel %u %u: world %g %g %g wants %d  cell %g %g  height %g  map %g (key %08x)  N %g %g %g\n", x, y, p.x, p.y, p.z, (int)ds.wantsRay, u, v, h, stored, k, g.N.x, g.N.y, g.N.z);
     }
 #endif
-    if (P.cover.header && ds.wantsRay && sun_cover_clear(P.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
+    if (P.S.cover.header && ds.wantsRay && sun_cover_clear(P.S.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
     const bool occluded = trace_any_packet(P.S, s_stack + (threadIdx.x >> 6) * kPacketStack, ds.worldPos, ds.s.L, 0.1f, 1000.f, valid && ds.wantsRay);
     if (valid) add_color(P.L, i, direct_finish(ds, g, occluded));
 #ifdef INCR_DIAG_SUN_COUNT
@@ -1846,7 +1834,7 @@ __global__ __launch_bounds__(kBlock) void deferred_lighting_kernel(const FusedLi
     if (P.haveDirect) {          // uniform: the shadow query is made by the whole wave (trace_any_packet)
         DirectSetup ds = {};
         if (valid) ds = direct_setup(P.direct, g, x, y, i, rays);
-        if (P.direct.cover.header && ds.wantsRay && sun_cover_clear(P.direct.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
+        if (P.direct.S.cover.header && ds.wantsRay && sun_cover_clear(P.direct.S.cover, ds.worldPos, 0.1f)) ds.wantsRay = false;     // provably unoccluded: `occluded` stays false
 #ifdef INCR_DIAG_NO_SUN_WALK     // diagnostic only: the pass without the sun's shadow walk (everything lit)
         const bool occluded = false;
 #else

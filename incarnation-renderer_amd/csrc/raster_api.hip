@@ -587,21 +587,23 @@ static int fill_direct(incr_context* ctx, const incr_direct_lighting_desc* d, Di
     P.sunIndex = (uint32_t)d->directional_light_index;
     return INCR_OK;
 }
-// The sun cover map of the pass's scene (raster_params.h SunCover), (re)built on `stream` ahead of the lighting kernel when the scene's is stale.  Test hook INCR_SUN_COVER=0: no map.
-static int build_sun_cover(incr_context* ctx, const incr_scene* sc, DirectParams& P, hipStream_t stream) {
+// The scene's sun cover map (pt_params.h SunCover) for global light `sunIndex`, (re)built on `stream` when stale, handed to the pass in S.cover.  Also called by
+// incr_pathtrace (api.hip).  Test hook INCR_SUN_COVER=0: no map.
+int incr_ensure_sun_cover(incr_context* ctx, const incr_scene* sc, uint32_t sunIndex, PtParams& S, hipStream_t stream) {
+    (void)ctx;
     if (const char* v = test_hook_env("INCR_SUN_COVER")) if (v[0] == '0') return INCR_OK;
-    if (!P.S.numTris || !P.S.numNodes) return INCR_OK;
+    if (!S.numTris || !S.numNodes) return INCR_OK;
     if (!sc->sunCover) {
         HIP_TRY(hipMalloc((void**)&sc->sunCover, 256 + (size_t)kSunCoverG * kSunCoverG * 4)); sc->sunCoverEpoch = 0;
         HIP_TRY(hipEventCreateWithFlags(&sc->sunCoverBuilt, hipEventDisableTiming));
     }
     SunCoverHeader* header = (SunCoverHeader*)sc->sunCover; uint32_t* grid = (uint32_t*)((uint8_t*)sc->sunCover + 256);
-    if (sc->sunCoverEpoch != sc->geometryEpoch || sc->sunCoverIndex != P.sunIndex) {
-        HIP_TRY(incr_launch_sun_cover(&P.S, P.sunIndex, header, grid, stream));
+    if (sc->sunCoverEpoch != sc->geometryEpoch || sc->sunCoverIndex != sunIndex) {
+        HIP_TRY(incr_launch_sun_cover(&S, sunIndex, header, grid, stream));
         HIP_TRY(hipEventRecord(sc->sunCoverBuilt, stream));
-        sc->sunCoverEpoch = sc->geometryEpoch; sc->sunCoverIndex = P.sunIndex; sc->sunCoverStream = stream;
+        sc->sunCoverEpoch = sc->geometryEpoch; sc->sunCoverIndex = sunIndex; sc->sunCoverStream = stream;
     } else if (stream != sc->sunCoverStream) HIP_TRY(hipStreamWaitEvent(stream, sc->sunCoverBuilt, 0));
-    P.cover.header = header; P.cover.grid = grid;
+    S.cover.header = header; S.cover.grid = grid;
     return INCR_OK;
 }
 int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, incr_stream stream) {
@@ -611,7 +613,7 @@ int incr_direct_lighting(incr_context* ctx, const incr_direct_lighting_desc* d, 
     DirectParams P;
     int rc = fill_direct(ctx, d, P);
     if (rc) return rc;
-    if ((rc = build_sun_cover(ctx, d->in.scene, P, (hipStream_t)stream))) return rc;
+    if ((rc = incr_ensure_sun_cover(ctx, d->in.scene, P.sunIndex, P.S, (hipStream_t)stream))) return rc;
     HIP_TRY(incr_launch_direct_lighting(&P, (hipStream_t)stream));
     return INCR_OK;
 }
@@ -653,7 +655,7 @@ int incr_deferred_lighting(incr_context* ctx, const incr_deferred_lighting_desc*
     int rc = INCR_OK;
     P.haveSky = d->sky != nullptr; P.haveDirect = d->direct != nullptr; P.haveClustered = d->clustered != nullptr;
     if (d->sky && (rc = fill_sky(d->sky, P.sky))) return rc;
-    if (d->direct && ((rc = fill_direct(ctx, d->direct, P.direct)) || (rc = build_sun_cover(ctx, d->direct->in.scene, P.direct, (hipStream_t)stream)))) return rc;
+    if (d->direct && ((rc = fill_direct(ctx, d->direct, P.direct)) || (rc = incr_ensure_sun_cover(ctx, d->direct->in.scene, P.direct.sunIndex, P.direct.S, (hipStream_t)stream)))) return rc;
     if (d->clustered && (rc = fill_clustered(ctx, d->clustered, P.clustered))) return rc;
     const LightingParams* parts[3] = {d->sky ? &P.sky.L : nullptr, d->direct ? &P.direct.L : nullptr, d->clustered ? &P.clustered.L : nullptr};
     const LightingParams* first = nullptr;

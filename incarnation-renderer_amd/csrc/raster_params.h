@@ -172,17 +172,7 @@ struct HbaoParams {
     PtParams S;
 };
 
-// Sun cover map (raster.hip sun_cover_*): the scene seen from the sun, an orthographic G x G grid over the BVH's bounds whose cell holds the greatest height (distance
-// along the direction TO the sun) of any triangle over that cell.  A shadow ray toward the sun that starts above its cell's entry cannot hit anything -- the
-// walk that would only prove that (94 % of the 4K Sponza-stat frame's sun rays are unoccluded, and an unoccluded ray visits every node along its whole length) is
-// skipped.  Everything is derived on the device from what the shadow query itself reads (light table, triangle records, root node).
-#ifndef INCR_SUN_COVER_G
-#define INCR_SUN_COVER_G 2048
-#endif
-static constexpr uint32_t kSunCoverG = INCR_SUN_COVER_G;
-struct SunCoverHeader { float U[3], V[3], L[3]; float u0, v0, invCell, eps; uint32_t valid, pad[3]; };
-struct SunCover { const SunCoverHeader* __restrict__ header; const uint32_t* __restrict__ grid; };      // header == NULL: no map
-struct DirectParams { LightingParams L; PtParams S; uint32_t sunIndex; SunCover cover; };
+struct DirectParams { LightingParams L; PtParams S; uint32_t sunIndex; };      // S.cover: the sun cover map of the scene, if it has one
 
 struct ClusteredParams {
     LightingParams L; PtParams S;

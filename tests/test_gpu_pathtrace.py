@@ -160,6 +160,28 @@ def test_sponza_small_lights_and_alpha_mask(gpu_ctx, rt, sio, sponza_small, spon
     pt.close()
 
 
+def test_sun_cover_map_answers_shadow_rays_identically(gpu_ctx, rt, sio, sponza_small, monkeypatch):
+    """Shadow rays toward the sun whose origin the sun cover map proves clear are queued as null rays (pathtrace_wf.hip shadow_gen_block).
+    Accumulation, targets and every ray counter must be what they are without the map."""
+    W, H = 320, 180
+    view = sio.FView().reset(sponza_small, aspect=W / H)
+
+    def run(cover):
+        if cover: monkeypatch.delenv("INCR_SUN_COVER", raising=False)
+        else: monkeypatch.setenv("INCR_SUN_COVER", "0")
+        gscene = gpu_ctx.create_scene(sponza_small)
+        pt = rt.PathTracer(gpu_ctx, gscene, W, H)
+        for s in range(1, 4):
+            pt.render(view, s)
+        g = pt.read()
+        pt.close(); gscene.close()
+        return g
+    a, b = run(True), run(False)
+    assert stats_tuple(a["stats"]) == stats_tuple(b["stats"]) and a["stats"].light_shadow_rays > W * H
+    np.testing.assert_array_equal(a["history"], b["history"])
+    np.testing.assert_array_equal(a["target"], b["target"])
+
+
 def test_shards_are_bit_identical_to_the_full_frame(gpu_ctx, rt, sio, A, helmet, helmet_gpu):
     """sampler keys use full-frame coordinates, so a shard equals the same rows of the full frame."""
     W, H, h, n = 200, 116, 8, 3                    # 116 rows = 14.5 blocks over 3 ranks: ragged block + padding rows

@@ -552,13 +552,15 @@ def main():
 
     if rank == 0:
         b_ray = bytes_per_ray(int(info.num_triangles))
+        answered = int(prof.shadow_rays_answered)          # over the profiled steps, like the ray statistics `ls`
         # Roofline of the DOMINANT kernel on this rank.  incr_pathtrace is 16 launches per pipeline (4 x extend / shade / shadow / accumulate; bounce 0's
         # extend makes the camera rays itself and shade sets its vertices' shadow rays up: the "generate" and "shadow_gen" intervals of rounds 1-2 are empty);
         # the per-kernel HIP-event sums say which one dominates.  Traversal kernels move
         # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
         per_kernel = {"incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
                       "incr::wf_shade_kernel": (prof.shade_ms, max(prof.launches[1], 1), float(ls[4]) * B_HIT),
-                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3]) * b_ray),
+                      # ... less the rays the sun cover map answered at their set-up: the any-hit kernel fetches their 32-byte (null) queue entries and nothing else
+                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3] - answered) * b_ray + float(answered) * 32.0),
                       "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[4], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
         # With more than one pipeline in flight the event intervals of the streaming kernels (generate, shade, shadow_gen, accumulate)
         # mostly measure how long their workgroups WAITED for the CUs the other band's persistent traversal kernel holds (2-4 x their
@@ -576,7 +578,7 @@ def main():
         alg_bytes_per_launch = dom_bytes / dom_launches if dom_ms > 0 else 0.0
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         l_rays = int(ls[0] + ls[1] + ls[2] + ls[3]); l_hits = int(ls[4])
-        frame_alg_bytes = (l_rays * b_ray + l_hits * B_HIT) / args.steps + rows * W * B_PX
+        frame_alg_bytes = ((l_rays - answered) * b_ray + answered * 32 + l_hits * B_HIT) / args.steps + rows * W * B_PX
         out = {
             "metric": "Mray/s", "value": round(rays / dt / 1e6, 3), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -605,6 +607,7 @@ def main():
         }
         # the shadow-ray queue: rays beyond its capacity are traced inline by the summation kernel (same image, slower) -- a silent cliff until round 5
         out["config"]["shadow_queue"] = {"rays_asked_per_step": int(prof.shadow_rays_asked) // max(int(prof.frames), 1), "rays_inline_per_step": int(prof.shadow_rays_inline) // max(int(prof.frames), 1),
+                                         "rays_answered_by_sun_cover_per_step": int(prof.shadow_rays_answered) // max(int(prof.frames), 1),
                                          "overflowed_calls": int(prof.shadow_queue_overflows)}
         if prof.shadow_queue_overflows:
             print("bench.py: WARNING: the shadow-ray queue overflowed in %d call(s): %d rays per step were traced inline" % (prof.shadow_queue_overflows, int(prof.shadow_rays_inline) // max(int(prof.frames), 1)), file=sys.stderr)
@@ -612,7 +615,7 @@ def main():
             pa, sa, na = alone
             alone_kernel = {"incr::wf_extend_kernel": (pa.extend_ms, max(pa.launches[0], 1), float(sa[0] + sa[1]) * b_ray),
                             "incr::wf_shade_kernel": (pa.shade_ms, max(pa.launches[1], 1), float(sa[4]) * B_HIT),
-                            "incr::wf_shadow_kernel": (pa.shadow_ms, max(pa.launches[3], 1), float(sa[2] + sa[3]) * b_ray),
+                            "incr::wf_shadow_kernel": (pa.shadow_ms, max(pa.launches[3], 1), float(sa[2] + sa[3] - int(pa.shadow_rays_answered)) * b_ray + float(pa.shadow_rays_answered) * 32.0),
                             "incr::wf_accumulate_kernel": (pa.accumulate_ms, max(pa.launches[4], 1), float(sa[4]) * 128.0 + rows * W * B_PX * na)}
             a_ms, a_launches, a_bytes = alone_kernel[dominant]
             if a_ms > 0:

@@ -1048,7 +1048,7 @@ int incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out) {
     out->overlap = ctx->profPipes.empty() ? 0u : (uint32_t)((ctx->profPipes.back() >> 8) & 1);
     unsigned long long tally[32];
     HIP_TRY(hipMemcpy(tally, ctx->wfOverflowTally, sizeof tally, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) { out->shadow_rays_asked += tally[4 * i]; out->shadow_rays_inline += tally[4 * i + 1]; out->shadow_queue_overflows += (uint32_t)tally[4 * i + 2]; }
+    for (int i = 0; i < 8; ++i) { out->shadow_rays_asked += tally[4 * i]; out->shadow_rays_inline += tally[4 * i + 1]; out->shadow_queue_overflows += (uint32_t)tally[4 * i + 2]; out->shadow_rays_answered += tally[4 * i + 3]; }
     ctx->profFrames = 0; ctx->profPipes.clear();
     return INCR_OK;
 }

@@ -147,6 +147,9 @@ static constexpr int kStripeBase = 128;
 // (round 4: ONE shadow-ray queue for the four bounces -- [32] counts its rays; [40 + b] = its length before the rays of bounce b, [40 + b + 1] after
 //  them, written by wf_snapshot_kernel behind wf_shade_kernel(b): a shadow launch traces the rays of one or several bounces as the range between two snapshots)
 static constexpr int kCursorBase = 16, kRayCountBase = 32, kSnapBase = 40;
+static constexpr int kQueueCountBase = 96;     // entries of the shadow-ray QUEUE (rayQ): the rays asked for (kRayCountBase: the RECORDS, rayC) less those the sun cover map answered;
+                                               // what the snapshots copy and the any-hit launches walk.  On a cache line of its own: both counters take an atomic per workgroup.
+static constexpr int kAnsweredBase = 33;      // shadow rays the sun cover map answered at their set-up (queued as null rays): incr_pathtrace_profile::shadow_rays_answered
 // The dynamic sky's launch constants (Perez coefficients + the miss shader's sun: 32 floats) live in the counters block as well, written by
 // wf_init_counters_kernel: wf_accumulate_kernel reads them with scalar loads inside its miss branch only, so that they hold no SGPRs on the
 // (far more common) hit side -- as kernel arguments they are preloaded for the whole kernel and spill
@@ -514,7 +517,9 @@ struct ShadowGenLds {
     uint4 mask[kWfBlock];
     float4 pos[kWfBlock], sky[kWfBlock] /* .w = incoming ray direction .y */, nrm[kWfBlock], col[kWfBlock], att[kWfBlock], skyRad[kWfBlock] /* .w = incoming ray direction .z */;
     float4 lights[kGenLdsLights * 5];          // the resolved light table (pt_shade.h), when the scene's lights fit
-    uint32_t base;
+    uint32_t base, baseQ;
+    unsigned long long ansBallot[kWfBlock / 64];      // per wave: which vertices have a ray the sun cover map answers
+    uint8_t ansSlot[kWfBlock];                        // ... and its request slot (0xff: none): the map is of ONE light, a vertex has at most one such ray
 };
 // What a lane brings for its list slot: the vertex wf_shade_kernel made (or nothing: a miss, a slot past the list's end).
 struct ShadowGenVertex {
@@ -536,6 +541,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
     uint32_t* const s_prefix = S.prefix; uint32_t* const s_waveTotal = S.waveTotal; uint4* const s_mask = S.mask;
     float4* const s_pos = S.pos; float4* const s_sky = S.sky; float4* const s_nrm = S.nrm; float4* const s_col = S.col; float4* const s_att = S.att;
     float4* const s_lights = S.lights; uint32_t& s_base = S.base; float4* const s_skyRad = S.skyRad;
+    uint8_t* const s_ansSlot = S.ansSlot; unsigned long long* const s_ansBallot = S.ansBallot; uint32_t& s_baseQ = S.baseQ;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool ldsLights = (uint32_t)P.lightCount <= kGenLdsLights;
     auto fetch_light = [&](uint32_t li, incr_light& light, float mm[16]) {
@@ -555,6 +561,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
         if (lane == 63u) s_waveTotal[wave] = incl;
         s_mask[tid] = req; s_pos[tid] = vpos; s_sky[tid] = make_float4(vsky.x, vsky.y, vsky.z, vyz.x); s_nrm[tid] = vnrm; s_col[tid] = vcol; s_att[tid] = vatt;
         s_skyRad[tid] = make_float4(V.skyRad.x, V.skyRad.y, V.skyRad.z, vyz.y);
+        s_ansSlot[tid] = 0xffu;
         __syncthreads();
         uint32_t waveBase = 0, totalCand = 0;
 #pragma unroll
@@ -571,9 +578,14 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const float4 v0 = s_pos[lo], n4 = s_nrm[lo];
             incr_light light; float lm[16];
             fetch_light(P.gridCellLights[__float_as_uint(v0.w) + k], light, lm);
-            if (light_setup(light, lm, true, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z}).needsShadow) {
+            const LightSample ls = light_setup(light, lm, true, {v0.x, v0.y, v0.z}, {n4.x, n4.y, n4.z});
+            if (ls.needsShadow) {
                 ++lightShadow;
-                if (k < kSkySlot) atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
+                if (k < kSkySlot) {
+                    atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
+                    // the sun cover map (pt_params.h SunCover) proves this ray unoccluded: it gets its record ("visible") and no queue entry
+                    if (P.cover.header && sun_cover_is_light(P.cover, light, ls.L) && sun_cover_clear(P.cover, {v0.x, v0.y, v0.z}, 0.1f)) s_ansSlot[lo] = (uint8_t)k;
+                }
             }
         }
         Counters cnt = {0, 0, 0, lightShadow, 0};
@@ -596,20 +608,33 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
     for (int w = 0; w < kWfBlock / 64; ++w) { const uint32_t c = s_waveTotal[w]; if ((uint32_t)w < wave) waveBase += c; total += c; }
     __syncthreads();
     s_prefix[tid] = waveBase + incl - n;
-    if (tid == 0) { s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase, total) : 0u; }
+    const uint32_t myAns = s_ansSlot[tid];                        // (phase 1's barrier is behind us)
+    const unsigned long long ansWave = __ballot(n != 0u && myAns != 0xffu);
+    if (lane == 0u) s_ansBallot[wave] = ansWave;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t answeredTotal = 0;
+#pragma unroll
+        for (int w = 0; w < kWfBlock / 64; ++w) answeredTotal += (uint32_t)__popcll(s_ansBallot[w]);
+        s_prefix[kWfBlock] = total; s_base = total ? atomicAdd(B.counters + kRayCountBase, total) : 0u;
+        // records that fit get their queue entries (fewer: the answered rays have none); records beyond the capacity are traced by accumulate and claim no queue space
+        const bool fits = !(s_base + total > B.rayCap || s_base + total < s_base);
+        s_baseQ = (fits && total > answeredTotal) ? atomicAdd(B.counters + kQueueCountBase, total - answeredTotal) : 0u;
+    }
     __syncthreads();
     if (total == 0u) return out;
-    const uint32_t base = s_base;
+    const uint32_t base = s_base, baseQ = s_baseQ;
     if (base + total > B.rayCap || base + total < base) {
-        // queue full: these vertices are traced by accumulate; the part of the claimed range that lies inside the queue
-        // is filled with null rays so that the traversal kernel never reads an unwritten record
-        if (n) out.flags |= kFlagInlineShadow;
-        for (uint32_t r = tid; r < total && base + r < B.rayCap; r += kWfBlock) {
-            B.rayQ[(size_t)(base + r) * 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-            B.rayQ[(size_t)(base + r) * 2 + 1] = make_float4(0.f, 0.f, 1.f, 0.f);
-        }
+        if (n) out.flags |= kFlagInlineShadow;                    // queue full: these vertices are traced by accumulate
         return out;
     }
+    // queue entries before vertex v's: its records' offset less the answered rays of the vertices before it
+    auto answered_before = [&](uint32_t v) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)(kWfBlock / 64); ++w) { const unsigned long long b = s_ansBallot[w]; c += w < (v >> 6) ? (uint32_t)__popcll(b) : (w == (v >> 6) ? (uint32_t)__popcll(b & ((1ull << (v & 63u)) - 1ull)) : 0u); }
+        return c;
+    };
     if (n) out.rayBase = base + s_prefix[tid];                                  // the vertex's RECORDS (rayC) are [rayBase, rayBase + popc(mask)), ascending slot
     // Which ray is record r?  Owner vertex = the last v with s_prefix[v] <= r, request slot = the (r - s_prefix[v])-th set bit of its mask.
     auto decode = [&](uint32_t r, uint32_t* owner, uint32_t* slotOut) {
@@ -625,6 +650,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
     };
     // The RECORD of a ray (rayC: its radiance and visibility, what accumulate sums in chsMain's loop order) and its QUEUE entry (rayQ: what the
     // traversal kernel walks) share the index base + r; the queue entry names the record in direction.w.
+    uint32_t answeredRays = 0;
     for (uint32_t r = tid; r < total; r += kWfBlock) {
         uint32_t lo, slot; const uint32_t dest = r;
         decode(r, &lo, &slot);
@@ -632,7 +658,8 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
         const float4 v0 = s_pos[lo];
         const f3 origin = {v0.x, v0.y, v0.z};
         f3 L, contribution = {0.f, 0.f, 0.f};
-        bool answered = false;       // the sun cover map (pt_params.h SunCover) proves the ray unoccluded: its queue entry is a null ray, its record stays "visible"
+        const uint32_t ansOfOwner = s_ansSlot[lo];
+        const bool answered = ansOfOwner == slot;       // the sun cover map proved the ray unoccluded (phase 1): a record, no queue entry
         if (slot == kSkySlot) {
             // chsMain's sky sample (pathtracing.hlsl:239-244): GetSkyRadiance with lightVisibility = 1 (lighting/common.hlsli:145-202) over the
             // pdf, times the path attenuation -- evaluated HERE like the lights', so that accumulate only sums
@@ -656,14 +683,27 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
             const f3 N = {n4.x, n4.y, n4.z};
             const LightSample ls = light_setup(light, lm, true, origin, N);
             L = ls.L;
-            answered = P.cover.header && sun_cover_is_light(P.cover, light, L) && sun_cover_clear(P.cover, origin, 0.1f);
             const f3 V = -mk3(a4.w, vyz2.x, vyz2.y);
             const f3 radianceOut = light_shade(ls, mk3(c4.x, c4.y, c4.z), c4.w, n4.w, N, V);
             contribution = mk3(a4.x, a4.y, a4.z) * radianceOut;
         }
-        B.rayQ[(size_t)(base + dest) * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(answered ? 0xffffffffu : vp));
-        B.rayQ[(size_t)(base + dest) * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(base + r));      // .w: the ray's record
+        if (!answered) {
+            const size_t q = (size_t)baseQ + dest - answered_before(lo) - ((ansOfOwner != 0xffu && slot > ansOfOwner) ? 1u : 0u);
+            B.rayQ[q * 2] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(vp));
+            B.rayQ[q * 2 + 1] = make_float4(L.x, L.y, L.z, __uint_as_float(base + r));      // .w: the ray's record
+        }
         B.rayC[base + r] = make_float4(contribution.x, contribution.y, contribution.z, 1.f);      // .w: 1 = unoccluded until the shadow kernel says otherwise
+        answeredRays += answered ? 1u : 0u;
+    }
+    if (P.cover.header) {                                         // kernel-uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) answeredRays += __shfl_down(answeredRays, off, 64);
+        // one word of the ray statistics' stripes (word 5 of 16; the first five are incr_ray_stats): an atomic per wave on ONE counter word was 355 K same-address
+        // atomics a frame, +2.7 ms on the shade kernel
+        if (lane == 0 && answeredRays) {
+            if (P.statStripes) atomicAdd(P.statStripes + (blockIdx.x & 63u) * 16u + 5u, (unsigned long long)answeredRays);
+            else atomicAdd(B.counters + kAnsweredBase, answeredRays);
+        }
     }
     return out;
 }
@@ -1101,6 +1141,7 @@ __global__ __launch_bounds__(64) void wf_init_counters_kernel(uint32_t* counters
     uint32_t v = 0u;
     if (i >= (uint32_t)kCursorBase && i < (uint32_t)kCursorBase + 8u) v = ((i - kCursorBase) & 1u) ? shadowStart : extendStart;   // behind the static first round
     counters[i] = v;
+    if (i == 0u) counters[kQueueCountBase] = 0u;
 #if INCR_WF_CURSOR_STRIPES > 1
     for (uint32_t k = i; k < 8u * INCR_WF_CURSOR_STRIPES; k += 64u) counters[kStripeBase + k * 32u] = 0u;
 #endif
@@ -1120,12 +1161,15 @@ template <bool SHADOW> static void trav_geometry(int sv, uint32_t* perCU, uint32
     else { *perCU = TravCfg<24, SHADOW>::kBlocksPerCU; *block = TravCfg<24, SHADOW>::kBlock; }
 }
 // profiled calls only: the rays the frame asked for beyond the queue's capacity (they were traced inline by wf_accumulate_kernel), and one count per call that had any
-__global__ __launch_bounds__(64) void wf_overflow_tally_kernel(const uint32_t* counters, uint32_t rayCap, unsigned long long* tally) {
-    if (threadIdx.x == 0) { const uint32_t asked = counters[kRayCountBase]; tally[0] += asked; if (asked > rayCap) { tally[1] += asked - rayCap; tally[2] += 1ull; } }
+__global__ __launch_bounds__(64) void wf_overflow_tally_kernel(const uint32_t* counters, uint32_t rayCap, unsigned long long* tally, unsigned long long* statStripes) {
+    unsigned long long answered = statStripes ? atomicExch(statStripes + threadIdx.x * 16u + 5u, 0ull) : 0ull;       // shared by the pipelines: whichever tallies first takes them
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) answered += __shfl_down(answered, off, 64);
+    if (threadIdx.x == 0) { const uint32_t asked = counters[kRayCountBase]; tally[0] += asked; if (asked > rayCap) { tally[1] += asked - rayCap; tally[2] += 1ull; } tally[3] += answered + counters[kAnsweredBase]; }
 }
 // behind wf_shade_kernel(bounce): the shadow-ray queue's length with the rays of bounces 0 .. bounce in it
 __global__ __launch_bounds__(64) void wf_snapshot_kernel(uint32_t* counters, int bounce) {
-    if (threadIdx.x == 0) counters[kSnapBase + bounce + 1] = counters[kRayCountBase];
+    if (threadIdx.x == 0) counters[kSnapBase + bounce + 1] = counters[kQueueCountBase];
 }
 } // namespace incr
 
@@ -1275,7 +1319,7 @@ extern "C" hipError_t incr_launch_pathtrace_wf(const incr::PtParams* p, const in
         }
     }
     if (events) for (int i = 0; i < numPipes; ++i) for (int k = 0; k < kWfProfEvents; ++k) if (!rec[i][k]) (void)hipEventRecord(events[i * kWfProfEvents + k], streams[i]);      // kernels that did not run: zero-length intervals
-    if (overflowTally) for (int i = 0; i < numPipes; ++i) if (total[i]) hipLaunchKernelGGL(wf_overflow_tally_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, pipes[i].rayCap, overflowTally + 4 * i);
+    if (overflowTally) for (int i = 0; i < numPipes; ++i) if (total[i]) hipLaunchKernelGGL(wf_overflow_tally_kernel, dim3(1), dim3(64), 0, streams[i], pipes[i].counters, pipes[i].rayCap, overflowTally + 4 * i, p->statStripes);
     for (int i = 1; i < numPipes; ++i) { (void)hipEventRecord(joins[i], streams[i]); (void)hipStreamWaitEvent(streams[0], joins[i], 0); }
     if (p->numSamples > 1u && p->localPixels) hipLaunchKernelGGL(wf_integrate_samples_kernel, dim3((p->localPixels + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, streams[0], *p);
     if (p->stats && p->statStripes) (void)incr_launch_fold_ray_stats(p->statStripes, p->stats, streams[0]);

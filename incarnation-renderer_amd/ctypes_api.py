@@ -140,7 +140,7 @@ class PathtraceDesc(C.Structure):
 class PathtraceProfile(C.Structure):
     _fields_ = [("generate_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_gen_ms", C.c_double),
                 ("shadow_ms", C.c_double), ("accumulate_ms", C.c_double), ("launches", C.c_uint32 * 5), ("frames", C.c_uint32), ("pipelines", C.c_uint32),
-                ("overlap", C.c_uint32), ("shadow_queue_overflows", C.c_uint32), ("shadow_rays_inline", C.c_uint64), ("shadow_rays_asked", C.c_uint64)]
+                ("overlap", C.c_uint32), ("shadow_queue_overflows", C.c_uint32), ("shadow_rays_inline", C.c_uint64), ("shadow_rays_asked", C.c_uint64), ("shadow_rays_answered", C.c_uint64)]
 
 
 class TonemapDesc(C.Structure):

@@ -193,6 +193,8 @@ typedef struct incr_pathtrace_profile {
                                         at least 12); a count above 0 says a view is far denser than the scene's mean.  (round 4: reserved0) */
     uint64_t shadow_rays_inline;     /* the rays beyond the queue, over all recorded calls (round 4: the reserved extend_wait_ms; same size and offset) */
     uint64_t shadow_rays_asked;      /* shadow rays the recorded calls asked for (appended in round 5: the structure grew by 8 bytes) */
+    uint64_t shadow_rays_answered;   /* ... of which the scene's sun cover map answered at their set-up: rays toward the directional light from origins with nothing
+                                        above them are queued as null rays, their records stay "unoccluded" (appended in round 5: another 8 bytes) */
 } incr_pathtrace_profile;
 int  incr_profile_begin(incr_context* ctx);
 int  incr_profile_end(incr_context* ctx, incr_pathtrace_profile* out_profile);

@@ -1280,46 +1280,51 @@ DI void sun_cover_cell(const SunCoverHeader& H, const SunTri& t, int32_t cu, int
     if (t.gu == t.gu) h = fminf(h, t.h0 + t.gu * ((t.gu > 0.f ? x1 : x0) - t.u[0]) + t.gv * ((t.gv > 0.f ? y1 : y0) - t.v[0]) + 2.f * H.eps);
     atomicMax(grid + (size_t)cv * kSunCoverG + (uint32_t)cu, height_key(h));
 }
-__global__ __launch_bounds__(256) void sun_cover_raster_kernel(const TriIsect* __restrict__ tris, uint32_t numTris, const SunCoverHeader* __restrict__ header, uint32_t* __restrict__ grid) {
+// Record -> what the rasterisation needs (false: a hole, a back face, a record with NaNs: nothing a shadow ray toward the sun can hit)
+DI bool sun_tri_setup(const SunCoverHeader& H, const TriIsect& r, SunTri& t) {
+    if (r.flatId == kTriHole) return false;
+    const f3 p0 = {r.v0x, r.v0y, r.v0z}, p1 = {r.v0x + r.e1x, r.v0y + r.e1y, r.v0z + r.e1z}, p2 = {r.v0x + r.e2x, r.v0y + r.e2y, r.v0z + r.e2z};
+    const f3 U = {H.U[0], H.U[1], H.U[2]}, V = {H.V[0], H.V[1], H.V[2]}, L = {H.L[0], H.L[1], H.L[2]};
+    t.u[0] = dot(p0, U); t.u[1] = dot(p1, U); t.u[2] = dot(p2, U); t.v[0] = dot(p0, V); t.v[1] = dot(p1, V); t.v[2] = dot(p2, V);
+    const float h0 = dot(p0, L), h1 = dot(p1, L), h2 = dot(p2, L);
+    t.h0 = h0; t.hcap = fmaxf(h0, fmaxf(h1, h2)) + H.eps;
+    const float ulo = fminf(t.u[0], fminf(t.u[1], t.u[2])) - H.eps, uhi = fmaxf(t.u[0], fmaxf(t.u[1], t.u[2])) + H.eps;
+    const float vlo = fminf(t.v[0], fminf(t.v[1], t.v[2])) - H.eps, vhi = fmaxf(t.v[0], fmaxf(t.v[1], t.v[2])) + H.eps;
+    // the shadow query culls back faces (pt_traverse.h tri_hit: det = e1 . (d x e2) > 0 with d = L): a triangle that fails this for the sun's direction
+    // -- the courtyard's roof seen from below -- hides nothing.  The same expression; kept when within rounding of zero.
+    const f3 e1 = {r.e1x, r.e1y, r.e1z}, e2 = {r.e2x, r.e2y, r.e2z};
+    const float det = dot(e1, cross(L, e2));
+    const bool faces = !(det < -1e-5f * sqrtf(dot(e1, e1) * dot(e2, e2)));
+    if (!(faces && ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi && t.hcap == t.hcap)) return false;          // (a record with NaNs no ray can hit)
+    const float G1 = (float)(kSunCoverG - 1u);
+    t.cu0 = (int32_t)fminf(fmaxf(floorf((ulo - H.u0) * H.invCell), 0.f), G1); t.cu1 = (int32_t)fminf(fmaxf(floorf((uhi - H.u0) * H.invCell), 0.f), G1);
+    t.cv0 = (int32_t)fminf(fmaxf(floorf((vlo - H.v0) * H.invCell), 0.f), G1); t.cv1 = (int32_t)fminf(fmaxf(floorf((vhi - H.v0) * H.invCell), 0.f), G1);
+    const float du1 = t.u[1] - t.u[0], dv1 = t.v[1] - t.v[0], du2 = t.u[2] - t.u[0], dv2 = t.v[2] - t.v[0];
+    const float area2 = du1 * dv2 - du2 * dv1;
+    // the projection's area against its edges' rounding: below that the triangle is a sliver on the map -- every cell of its box, the vertex cap
+    const bool solid = fabsf(area2) > 1e-4f * ((fabsf(du1) + fabsf(dv1)) * (fabsf(du2) + fabsf(dv2)));
+    t.orient = solid ? (area2 > 0.f ? 1.f : -1.f) : 0.f;
+    t.gu = t.gv = __uint_as_float(0x7fc00000u);
+    if (solid) {
+        const float gu = ((h1 - h0) * dv2 - (h2 - h0) * dv1) / area2, gv = ((h2 - h0) * du1 - (h1 - h0) * du2) / area2;
+        if (fabsf(gu) < 1000.f && fabsf(gv) < 1000.f) { t.gu = gu; t.gv = gv; }
+    }
+    return true;
+}
+// Footprints by size: <= 16 cells by the triangle's own lane; <= 1024 spread over its wave; larger ones go to a list that sun_cover_large_kernel works off with a
+// workgroup per 65 536 cells -- a ground plane of two triangles covers the whole map, and one wave would be at it for 50 ms.
+static constexpr uint32_t kSunLargeCells = 1024, kSunLargeChunk = 65536, kSunLargeCap = 65536;
+__global__ __launch_bounds__(256) void sun_cover_raster_kernel(const TriIsect* __restrict__ tris, uint32_t numTris, SunCoverHeader* __restrict__ header, uint32_t* __restrict__ grid, uint2* __restrict__ large) {
     const SunCoverHeader H = *header;
     if (!H.valid) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    bool have = false;
     SunTri t = {};
-    if (i < numTris) {
-        const TriIsect r = tris[i];
-        if (r.flatId != kTriHole) {
-            const f3 p0 = {r.v0x, r.v0y, r.v0z}, p1 = {r.v0x + r.e1x, r.v0y + r.e1y, r.v0z + r.e1z}, p2 = {r.v0x + r.e2x, r.v0y + r.e2y, r.v0z + r.e2z};
-            const f3 U = {H.U[0], H.U[1], H.U[2]}, V = {H.V[0], H.V[1], H.V[2]}, L = {H.L[0], H.L[1], H.L[2]};
-            t.u[0] = dot(p0, U); t.u[1] = dot(p1, U); t.u[2] = dot(p2, U); t.v[0] = dot(p0, V); t.v[1] = dot(p1, V); t.v[2] = dot(p2, V);
-            const float h0 = dot(p0, L), h1 = dot(p1, L), h2 = dot(p2, L);
-            t.h0 = h0; t.hcap = fmaxf(h0, fmaxf(h1, h2)) + H.eps;
-            const float ulo = fminf(t.u[0], fminf(t.u[1], t.u[2])) - H.eps, uhi = fmaxf(t.u[0], fmaxf(t.u[1], t.u[2])) + H.eps;
-            const float vlo = fminf(t.v[0], fminf(t.v[1], t.v[2])) - H.eps, vhi = fmaxf(t.v[0], fmaxf(t.v[1], t.v[2])) + H.eps;
-            // the shadow query culls back faces (pt_traverse.h tri_hit: det = e1 . (d x e2) > 0 with d = L): a triangle that fails this for the sun's direction
-            // -- the courtyard's roof seen from below -- hides nothing.  The same expression; kept when within rounding of zero.
-            const f3 e1 = {r.e1x, r.e1y, r.e1z}, e2 = {r.e2x, r.e2y, r.e2z};
-            const float det = dot(e1, cross(L, e2));
-            const bool faces = !(det < -1e-5f * sqrtf(dot(e1, e1) * dot(e2, e2)));
-            if (faces && ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi && t.hcap == t.hcap) {          // (a record with NaNs no ray can hit)
-                const float G1 = (float)(kSunCoverG - 1u);
-                t.cu0 = (int32_t)fminf(fmaxf(floorf((ulo - H.u0) * H.invCell), 0.f), G1); t.cu1 = (int32_t)fminf(fmaxf(floorf((uhi - H.u0) * H.invCell), 0.f), G1);
-                t.cv0 = (int32_t)fminf(fmaxf(floorf((vlo - H.v0) * H.invCell), 0.f), G1); t.cv1 = (int32_t)fminf(fmaxf(floorf((vhi - H.v0) * H.invCell), 0.f), G1);
-                const float du1 = t.u[1] - t.u[0], dv1 = t.v[1] - t.v[0], du2 = t.u[2] - t.u[0], dv2 = t.v[2] - t.v[0];
-                const float area2 = du1 * dv2 - du2 * dv1;
-                // the projection's area against its edges' rounding: below that the triangle is a sliver on the map -- every cell of its box, the vertex cap
-                const bool flat = fabsf(area2) > 1e-4f * ((fabsf(du1) + fabsf(dv1)) * (fabsf(du2) + fabsf(dv2)));
-                t.orient = flat ? (area2 > 0.f ? 1.f : -1.f) : 0.f;
-                t.gu = t.gv = __uint_as_float(0x7fc00000u);
-                if (flat) {
-                    const float gu = ((h1 - h0) * dv2 - (h2 - h0) * dv1) / area2, gv = ((h2 - h0) * du1 - (h1 - h0) * du2) / area2;
-                    if (fabsf(gu) < 1000.f && fabsf(gv) < 1000.f) { t.gu = gu; t.gv = gv; }
-                }
-                have = true;
-            }
-        }
-    }
+    bool have = i < numTris && sun_tri_setup(H, tris[i], t);
     const uint32_t ncu = have ? (uint32_t)(t.cu1 - t.cu0 + 1) : 0u, cells = have ? ncu * (uint32_t)(t.cv1 - t.cv0 + 1) : 0u;
+    if (have && cells > kSunLargeCells) {
+        const uint32_t chunks = (cells + kSunLargeChunk - 1u) / kSunLargeChunk, at = atomicAdd(&header->pad[0], chunks);
+        if (at + chunks <= kSunLargeCap) { for (uint32_t c = 0; c < chunks; ++c) large[at + c] = make_uint2(i, c); have = false; }       // (a full list: the wave does it after all)
+    }
     if (have && cells <= 16u)
         for (int32_t cv = t.cv0; cv <= t.cv1; ++cv)
             for (int32_t cu = t.cu0; cu <= t.cu1; ++cu) sun_cover_cell(H, t, cu, cv, grid);
@@ -1332,6 +1337,19 @@ __global__ __launch_bounds__(256) void sun_cover_raster_kernel(const TriIsect* _
         s.cu0 = __shfl(t.cu0, src, 64); s.cv0 = __shfl(t.cv0, src, 64);
         const uint32_t sn = (uint32_t)__shfl((int)ncu, src, 64), sc = (uint32_t)__shfl((int)cells, src, 64);
         for (uint32_t j = lane; j < sc; j += 64u) sun_cover_cell(H, s, s.cu0 + (int32_t)(j % sn), s.cv0 + (int32_t)(j / sn), grid);
+    }
+}
+__global__ __launch_bounds__(256) void sun_cover_large_kernel(const TriIsect* __restrict__ tris, const SunCoverHeader* __restrict__ header, uint32_t* __restrict__ grid, const uint2* __restrict__ large) {
+    const SunCoverHeader H = *header;
+    if (!H.valid) return;
+    const uint32_t n = min(H.pad[0], kSunLargeCap);
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint2 item = large[e];
+        SunTri t = {};
+        if (!sun_tri_setup(H, tris[item.x], t)) continue;          // (cannot fail: it was filed)
+        const uint32_t ncu = (uint32_t)(t.cu1 - t.cu0 + 1), cells = ncu * (uint32_t)(t.cv1 - t.cv0 + 1);
+        const uint32_t lo = item.y * kSunLargeChunk, hi = min(cells, lo + kSunLargeChunk);
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += 256u) sun_cover_cell(H, t, t.cu0 + (int32_t)(j % ncu), t.cv0 + (int32_t)(j / ncu), grid);
     }
 }
 // direct-lighting.hlsl:31-85: the sun with a ray-traced shadow (lighting/common.hlsli:102-115), in two halves around the shadow
@@ -2061,11 +2079,16 @@ extern "C" hipError_t incr_launch_sky_lighting(const SkyParams* p, hipStream_t s
     hipLaunchKernelGGL(sky_lighting_kernel, pixel_grid(p->L.W, p->L.y0, p->L.y1), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
+extern "C" size_t incr_sun_cover_bytes() { return 256 + (size_t)kSunCoverG * kSunCoverG * 4 + (size_t)kSunLargeCap * sizeof(uint2); }      // header, map, the list of large footprints
 extern "C" hipError_t incr_launch_sun_cover(const PtParams* S, uint32_t sunIndex, SunCoverHeader* header, uint32_t* grid, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(grid, 0, (size_t)kSunCoverG * kSunCoverG * 4, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sun_cover_header_kernel, dim3(1), dim3(1), 0, stream, *S, sunIndex, header);
-    if (S->numTris) hipLaunchKernelGGL(sun_cover_raster_kernel, dim3((S->numTris + 255u) / 256u), dim3(256), 0, stream, S->tris, S->numTris, header, grid);
+    if (S->numTris) {
+        uint2* large = (uint2*)(grid + (size_t)kSunCoverG * kSunCoverG);          // behind the map (incr_sun_cover_bytes)
+        hipLaunchKernelGGL(sun_cover_raster_kernel, dim3((S->numTris + 255u) / 256u), dim3(256), 0, stream, S->tris, S->numTris, header, grid, large);
+        hipLaunchKernelGGL(sun_cover_large_kernel, dim3(1024), dim3(256), 0, stream, S->tris, header, grid, large);
+    }
     return hipGetLastError();
 }
 extern "C" hipError_t incr_launch_direct_lighting(const DirectParams* p, hipStream_t stream) {

@@ -29,6 +29,7 @@ extern "C" hipError_t incr_launch_environmentmap(const EnvmapParams* p, hipStrea
 extern "C" hipError_t incr_launch_debug_viz(const DebugVizParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_taa_resolve(const TaaParams* p, hipStream_t stream);
 extern "C" hipError_t incr_launch_sun_cover(const PtParams* S, uint32_t sunIndex, SunCoverHeader* header, uint32_t* grid, hipStream_t stream);
+extern "C" size_t incr_sun_cover_bytes();
 extern "C" hipError_t incr_launch_dynamic_sky(const DynamicSkyParams* p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------- scene data
@@ -594,7 +595,7 @@ int incr_ensure_sun_cover(incr_context* ctx, const incr_scene* sc, uint32_t sunI
     if (const char* v = test_hook_env("INCR_SUN_COVER")) if (v[0] == '0') return INCR_OK;
     if (!S.numTris || !S.numNodes) return INCR_OK;
     if (!sc->sunCover) {
-        HIP_TRY(hipMalloc((void**)&sc->sunCover, 256 + (size_t)kSunCoverG * kSunCoverG * 4)); sc->sunCoverEpoch = 0;
+        HIP_TRY(hipMalloc((void**)&sc->sunCover, incr_sun_cover_bytes())); sc->sunCoverEpoch = 0;
         HIP_TRY(hipEventCreateWithFlags(&sc->sunCoverBuilt, hipEventDisableTiming));
     }
     SunCoverHeader* header = (SunCoverHeader*)sc->sunCover; uint32_t* grid = (uint32_t*)((uint8_t*)sc->sunCover + 256);

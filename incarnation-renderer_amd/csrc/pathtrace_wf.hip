@@ -520,6 +520,7 @@ struct ShadowGenLds {
     uint32_t base, baseQ;
     unsigned long long ansBallot[kWfBlock / 64];      // per wave: which vertices have a ray the sun cover map answers
     uint8_t ansSlot[kWfBlock];                        // ... and its request slot (0xff: none): the map is of ONE light, a vertex has at most one such ray
+    SunCoverHeader cover;                             // the map's header (copied with the light table): out of HBM it was a scalar load per candidate in a divergent loop
 };
 // What a lane brings for its list slot: the vertex wf_shade_kernel made (or nothing: a miss, a slot past the list's end).
 struct ShadowGenVertex {
@@ -529,6 +530,7 @@ struct ShadowGenVertex {
     float2 vyz /* incoming ray direction .yz */;
 };
 DI void shadow_gen_load_lights(const PtParams& P, ShadowGenLds& S) {          // visible after the next __syncthreads
+    if (P.cover.header && threadIdx.x < sizeof(SunCoverHeader) / 4u) ((uint32_t*)&S.cover)[threadIdx.x] = ((const uint32_t*)P.cover.header)[threadIdx.x];
     if ((uint32_t)P.lightCount <= kGenLdsLights) for (uint32_t k = threadIdx.x; k < (uint32_t)P.lightCount * 5u; k += kWfBlock) S.lights[k] = P.resolvedLights[k];
 }
 // The ray set-up of one workgroup's 256 list slots (every thread of the workgroup must call it: it synchronises).  `pid` = the lane's
@@ -584,7 +586,7 @@ DI ShadowGenResult shadow_gen_block(const PtParams& P, const WfBuffers& B, int b
                 if (k < kSkySlot) {
                     atomicOr(&((uint32_t*)&s_mask[lo])[k >> 5], 1u << (k & 31u));      // k >= 127: traced inside accumulate, counted here
                     // the sun cover map (pt_params.h SunCover) proves this ray unoccluded: it gets its record ("visible") and no queue entry
-                    if (P.cover.header && sun_cover_is_light(P.cover, light, ls.L) && sun_cover_clear(P.cover, {v0.x, v0.y, v0.z}, 0.1f)) s_ansSlot[lo] = (uint8_t)k;
+                    if (P.cover.header && sun_cover_is_light(S.cover, light, ls.L) && sun_cover_clear(S.cover, P.cover.grid, {v0.x, v0.y, v0.z}, 0.1f)) s_ansSlot[lo] = (uint8_t)k;
                 }
             }
         }

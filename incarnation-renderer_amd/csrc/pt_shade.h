@@ -65,18 +65,17 @@ DI LightSample light_setup(const incr_light& light, const float* __restrict__ m,
 // heights as unsigned keys that order like the floats (atomicMax); 0 = below everything
 DI uint32_t height_key(float h) { const uint32_t b = __float_as_uint(h); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 // true: nothing of the scene lies above `p` toward the sun beyond the query's tmin -- the shadow ray from p is unoccluded
-DI bool sun_cover_clear(const SunCover& C, f3 p, float tmin) {
-    const SunCoverHeader& H = *C.header;
+DI bool sun_cover_clear(const SunCoverHeader& H, const uint32_t* __restrict__ grid, f3 p, float tmin) {
     if (!H.valid) return false;
     const float u = ((p.x * H.U[0] + p.y * H.U[1]) + p.z * H.U[2] - H.u0) * H.invCell, v = ((p.x * H.V[0] + p.y * H.V[1]) + p.z * H.V[2] - H.v0) * H.invCell;
     if (!(u >= 0.f && v >= 0.f && u < (float)kSunCoverG && v < (float)kSunCoverG)) return false;
     const float h = (p.x * H.L[0] + p.y * H.L[1]) + p.z * H.L[2];
-    return C.grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] < height_key(h + tmin - 2.f * H.eps);
+    return grid[(size_t)(uint32_t)v * kSunCoverG + (uint32_t)u] < height_key(h + tmin - 2.f * H.eps);
 }
+DI bool sun_cover_clear(const SunCover& C, f3 p, float tmin) { return sun_cover_clear(*C.header, C.grid, p, tmin); }
 
 // the map's light?  Its direction, bit for bit as light_setup gives it for a directional light
-DI bool sun_cover_is_light(const SunCover& C, const incr_light& light, f3 L) {
-    const SunCoverHeader& H = *C.header;
+DI bool sun_cover_is_light(const SunCoverHeader& H, const incr_light& light, f3 L) {
     return light.type == INCR_LIGHT_DIRECTIONAL && L.x == H.L[0] && L.y == H.L[1] && L.z == H.L[2];
 }
 

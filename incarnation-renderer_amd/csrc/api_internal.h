@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "../../include/incr.h"
@@ -83,6 +84,7 @@ struct incr_scene {
     // incr_update_bvh that moved something (geometryEpoch) or for another light index.  A cache behind const scene pointers.
     mutable void* sunCover = nullptr; mutable uint64_t sunCoverEpoch = 0; mutable uint32_t sunCoverIndex = 0;
     mutable hipEvent_t sunCoverBuilt = nullptr; mutable hipStream_t sunCoverStream = nullptr;      // a pass on another stream waits for the build
+    mutable std::mutex sunCoverLock;                                                                   // host threads submitting passes of one scene at the same time
     uint64_t geometryEpoch = 1;
     std::vector<void*> dTexels;
     std::vector<incr::DeviceTexture> hostTextures;     // host copy of the descriptor table (device pointers of the TILED chains + mip counts)

@@ -594,6 +594,7 @@ int incr_ensure_sun_cover(incr_context* ctx, const incr_scene* sc, uint32_t sunI
     (void)ctx;
     if (const char* v = test_hook_env("INCR_SUN_COVER")) if (v[0] == '0') return INCR_OK;
     if (!S.numTris || !S.numNodes) return INCR_OK;
+    std::lock_guard<std::mutex> guard(sc->sunCoverLock);
     if (!sc->sunCover) {
         HIP_TRY(hipMalloc((void**)&sc->sunCover, incr_sun_cover_bytes())); sc->sunCoverEpoch = 0;
         HIP_TRY(hipEventCreateWithFlags(&sc->sunCoverBuilt, hipEventDisableTiming));

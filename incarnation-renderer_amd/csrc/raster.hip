@@ -1471,7 +1471,10 @@ DI float hbao_horizon(const PtParams& S, uint32_t* __restrict__ stack, float sta
     }
     return hi;
 }
-__global__ __launch_bounds__(kBlock) void hbao_kernel(const HbaoParams P) {            // cs_main, hbao.hlsl:109-175
+#ifndef INCR_HBAO_MIN_BLOCKS
+#define INCR_HBAO_MIN_BLOCKS 8          // 64 VGPRs (36 B of scratch) instead of 72: the pass 14.25 -> 13.64 ms
+#endif
+__global__ __launch_bounds__(kBlock, INCR_HBAO_MIN_BLOCKS) void hbao_kernel(const HbaoParams P) {            // cs_main, hbao.hlsl:109-175
     __shared__ uint32_t s_stack[(kBlock / 64) * kPacketStack];
     uint32_t* stack = s_stack + (threadIdx.x >> 6) * kPacketStack;
     uint32_t x, y; tile_pixel(P.y0, &x, &y);
@@ -1835,7 +1838,10 @@ __global__ __launch_bounds__(256) void clustered_lighting_kernel(const Clustered
 // dispatches, sky-lighting.inl, direct-lighting.inl, clustered-lighting.inl) moves 24 B per pixel per pass.  The colour is
 // re-quantised to R11G11B10F between the parts exactly where the chain stores it, so the result is bit-identical to running
 // the three kernels one after the other (tests/test_gpu_raster.py::test_fused_deferred_lighting_equals_the_chain).
-__global__ __launch_bounds__(kBlock) void deferred_lighting_kernel(const FusedLightingParams P) {
+#ifndef INCR_LIGHTING_MIN_BLOCKS
+#define INCR_LIGHTING_MIN_BLOCKS 8      // 64 VGPRs (28 B of scratch) for 8 waves per SIMD instead of 78 for 6: fused lighting 0.667-0.694 -> 0.638-0.649 ms (tools/ab_occupancy.sh)
+#endif
+__global__ __launch_bounds__(kBlock, INCR_LIGHTING_MIN_BLOCKS) void deferred_lighting_kernel(const FusedLightingParams P) {
     __shared__ uint32_t s_stack[(kBlock / 64) * kPacketStack];
     const LightingParams& L = P.haveSky ? P.sky.L : (P.haveDirect ? P.direct.L : P.clustered.L);
     uint32_t x, y; tile_pixel(L.y0, &x, &y);

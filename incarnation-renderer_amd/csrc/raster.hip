@@ -965,7 +965,10 @@ __global__ __launch_bounds__(256) void vis_resolve_kernel(const unsigned long lo
 
 // ---------------------------------------------------------------------------------------------- G-buffer
 // gbuffer-compute.hlsl:157-253 (USING_MESHLETS); 16x16 thread groups there, 64x4 pixel blocks here (one wave = one row run)
-__global__ __launch_bounds__(256, 4) void gbuffer_kernel(const GBufferParams P) {
+#ifndef INCR_GBUFFER_MIN_BLOCKS
+#define INCR_GBUFFER_MIN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, INCR_GBUFFER_MIN_BLOCKS) void gbuffer_kernel(const GBufferParams P) {
     // the sRGB decode table in LDS: a trilinear tap of a base-colour map looks 24 values up, as many instructions on the vector memory
     // pipeline (which bounds this kernel) as its texel loads
     __shared__ float s_srgbLut[256];

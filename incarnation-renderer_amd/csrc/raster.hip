@@ -535,7 +535,7 @@ DI void emit_triangle(const VisParams& P, uint32_t lane, bool valid, const float
         have = have && idx < P.recCap;                           // cannot fail: recCap = 2 x scene triangles
         const uint32_t bw = have ? (uint32_t)(st.px1 - st.px0 + 1) : 0u, bh = have ? (uint32_t)(st.py1 - st.py0 + 1) : 0u;
         const bool small = have && bw * bh <= (uint32_t)(alphaTex >= 0 ? INCR_VIS_ALPHA_BOX : kBigBoxPixels);
-        // Every triangle is filed per SCREEN BIN (vis_bin_kernel scans a bin's triangles into an LDS copy of the bin: a fragment's 64-bit atomic -- 184 cycles of a CU per
+        // Every triangle is filed per SCREEN BIN (scan_bin, the first phase of vis_scan_kernel, scans a bin's triangles into an LDS copy of the bin: a fragment's 64-bit atomic -- 184 cycles of a CU per
         // 8 x 8 tile on the device surface, 0.25 of the scan's 0.63 ms on the 4K Sponza-stat frame -- and the alpha-tested fragment's look at the stored word become LDS
         // operations), in one of three lists per bin: opaque large, alpha-tested large, small.  The (triangle, bin) pairs of the wave's triangles are flattened over the
         // lanes 64 at a time (a triangle at a time waits for every triangle's returning atomic in turn: set-up kernel 0.050 -> 0.128 ms; a lane per triangle waits for the

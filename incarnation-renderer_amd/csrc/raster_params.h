@@ -87,7 +87,7 @@ static_assert(sizeof(SubTriRec) == 48 && sizeof(SubTriAlpha) == 80, "visibility 
 #define INCR_VIS_STRIPES 16
 #endif
 static constexpr size_t kVisCounterBytes = 256 + (size_t)INCR_VIS_STRIPES * 128;
-// Screen bins (raster.hip vis_bin_kernel): one workgroup scans a bin's triangles into an LDS copy of the bin and stores it.  A bin is 2^binShift pixels square
+// Screen bins (raster.hip scan_bin, the first phase of vis_scan_kernel): a workgroup scans a bin's triangles into an LDS copy of the bin and merges it into the surface.  A bin is 2^binShift pixels square
 // (64 for frames of 4 M pixels and more, 32 below: enough workgroups to fill the chip); per bin three lists of triangle record indices.
 static constexpr uint32_t kVisBinCapDefault = 1024;
 enum VisBinList : uint32_t { kBinOpaque = 0, kBinAlpha = 1, kBinSmall = 2, kVisBinLists = 3 };

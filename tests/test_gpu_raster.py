@@ -587,7 +587,7 @@ def test_sun_cover_map_changes_nothing(rt, R, A, sio, gpu_ctx, sponza_small, mon
 
 @pytest.mark.parametrize("res", [(640, 360), (1000, 523)])
 def test_visibility_screen_bins(rt, R, A, sio, gpu_ctx, sponza_small, monkeypatch, res):
-    """Opaque large triangles are filed per screen bin and scanned into LDS by one workgroup per bin (vis_bin_kernel); a triangle that finds a
+    """Opaque large triangles are filed per screen bin and scanned into LDS by one workgroup per bin (scan_bin, the first phase of vis_scan_kernel); a triangle that finds a
     bin full takes the band queue instead.  With the bins off, on, and two entries small, ids and depths must agree bit for bit -- also at a
     resolution that is no multiple of the bin or the tile size."""
     W, H = res

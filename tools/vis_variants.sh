@@ -9,7 +9,7 @@ for flags in "$@"; do
   f=$(find /tmp/visvar -name "*kernel_stats.csv" | head -1)
   echo "[$flags] $(python3 - $f <<'PY'
 import csv, sys
-want = ("vis_setup_kernel", "vis_bin_kernel", "vis_scan_kernel", "vis_resolve_kernel", "gbuffer_kernel", "deferred_lighting_kernel")
+want = ("vis_setup_kernel", "vis_scan_kernel", "vis_resolve_kernel", "gbuffer_kernel", "deferred_lighting_kernel")
 print("  ".join("%s %.4f ms" % (w, float(r["AverageNs"]) / 1e6) for w in want for r in csv.DictReader(open(sys.argv[1])) if "incr::" + w in r["Name"]))
 PY
 )"

@@ -600,11 +600,16 @@ int incr_ensure_sun_cover(incr_context* ctx, const incr_scene* sc, uint32_t sunI
         HIP_TRY(hipEventCreateWithFlags(&sc->sunCoverBuilt, hipEventDisableTiming));
     }
     SunCoverHeader* header = (SunCoverHeader*)sc->sunCover; uint32_t* grid = (uint32_t*)((uint8_t*)sc->sunCover + 256);
+    // a stream that is being captured (the C++ renderer replays its frame as a HIP graph) neither waits for an event recorded outside the capture nor records one that
+    // streams outside would wait for: the graph is launched on the stream the earlier frames -- and with them the build -- were issued on
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capture);
+    const bool capturing = capture != hipStreamCaptureStatusNone;
     if (sc->sunCoverEpoch != sc->geometryEpoch || sc->sunCoverIndex != sunIndex) {
         HIP_TRY(incr_launch_sun_cover(&S, sunIndex, header, grid, stream));
-        HIP_TRY(hipEventRecord(sc->sunCoverBuilt, stream));
-        sc->sunCoverEpoch = sc->geometryEpoch; sc->sunCoverIndex = sunIndex; sc->sunCoverStream = stream;
-    } else if (stream != sc->sunCoverStream) HIP_TRY(hipStreamWaitEvent(stream, sc->sunCoverBuilt, 0));
+        if (!capturing) { HIP_TRY(hipEventRecord(sc->sunCoverBuilt, stream)); sc->sunCoverStream = stream; }
+        sc->sunCoverEpoch = sc->geometryEpoch; sc->sunCoverIndex = sunIndex;
+    } else if (!capturing && sc->sunCoverStream && stream != sc->sunCoverStream) HIP_TRY(hipStreamWaitEvent(stream, sc->sunCoverBuilt, 0));
     S.cover.header = header; S.cover.grid = grid;
     return INCR_OK;
 }

@@ -37,7 +37,7 @@ def test_config2_helmet_1080p_parity(gpu_ctx, rt, sio, helmet, helmet_oracle):
 
 
 # ------------------------------------------------------------------------------------------------ config 5
-def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob):
+def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob, monkeypatch):
     """BASELINE config 5 on one GPU: Bistro-scale (1,025 instances, 2.9 M triangles, u32 indices, mirrored RH->LH transforms)
     at 3840x2160: full-size properties, a 64x64 crop of (id, t, u, v) bit-exact vs the oracle, 16 spp accumulation and a
     TAA raster frame pair."""
@@ -103,6 +103,13 @@ def test_config5_bistro_scale_4k(gpu_ctx, rt, R, sio, synth, A, ob):
     assert f0["counts"][0] + f0["counts"][1] > 1000                               # meshlets survived culling
     assert abs(int(f0["counts"][0]) - int(f1["counts"][0])) < 100                    # same view, sub-pixel jitter only
     assert np.isfinite(ob.unpack_r11g11b10(f1["taa1"])).all()
+    # the same first frame without the visibility scan's screen bins (round 5): 2.9 M mostly small triangles fill many a bin's list, the rest take the queues --
+    # ids and depths must not care
+    monkeypatch.setenv("INCR_VIS_BIN_CAP", "0")
+    (_, g0), = gpu_frame(rt, R, gpu_ctx, sc, view, W, H, Cfg, frames=1)
+    monkeypatch.delenv("INCR_VIS_BIN_CAP")
+    np.testing.assert_array_equal(g0["vis"], f0["vis"])
+    np.testing.assert_array_equal(g0["depth"].view(np.uint32), f0["depth"].view(np.uint32))
     # 128x72 raster parity of the same scene vs the oracle (ids, depth bit-exact)
     Wr, Hr = 128, 72
     vr = sio.FView().reset(s, aspect=Wr / Hr)

@@ -460,12 +460,13 @@ DI void raster_coop_alpha(const VisParams& P, const SubTri& st, uint32_t lane, c
         }
     drain(true);
 }
-// Work distribution (DESIGN.md "Visibility pass"): the set-up kernel turns every surviving screen triangle into a
-// 48-byte record and files it by bounding-box size; the scan kernel's persistent waves then pull
-//   * band items  -- <= 64 8x8 tiles of one large triangle, scanned by the whole wave (one tile per step),
-//   * whole items -- large triangles that did not fit the band queue (same scan, all bands by one wave),
-//   * small items -- 64 small triangles per wave, one per lane, scanned serially.
-// The result does not depend on the order: depth test and id write are one atomicMax on depth | order key.
+// Work distribution (DESIGN.md 5.2 `vis_scan_kernel`): the set-up kernel turns every surviving screen triangle into a 48-byte record and files it
+//   * per SCREEN BIN (round 5): opaque large triangles and small ones -- the scan kernel's workgroups first take bins and scan a bin's lists into an LDS copy of it (scan_bin);
+//   * as band items  -- <= 32 8x8 tiles of an alpha-tested large triangle (or of any large triangle that found a bin list full), scanned by the whole wave, fragments compacted
+//     before they sample (raster_coop_alpha);
+//   * as whole items -- large triangles that did not fit the band queue (same scan, all bands by one wave);
+//   * as small items -- small triangles that found a bin list full: 64 per wave, one per lane, scanned serially.
+// The result does not depend on the order or on which path a triangle took: depth test and id write are one atomicMax on depth | order key, in LDS or on the surface.
 DI void vq_load_alpha(const VisParams& P, uint32_t idx, SubTri* st) {
     const SubTriAlpha a = P.alphas[idx];
     st->bs = bary_setup({a.p[0], a.p[1], a.p[2], a.p[3]}, {a.p[4], a.p[5], a.p[6], a.p[7]}, {a.p[8], a.p[9], a.p[10], a.p[11]});

@@ -559,8 +559,8 @@ def main():
         # bytes_per_ray per query, the shading kernels bytes_per_hit per shaded hit, shadow_gen 32 B per queued ray + the request mask.
         per_kernel = {"incr::wf_extend_kernel": (prof.extend_ms, max(prof.launches[0], 1), float(ls[0] + ls[1]) * b_ray),
                       "incr::wf_shade_kernel": (prof.shade_ms, max(prof.launches[1], 1), float(ls[4]) * B_HIT),
-                      # ... less the rays the sun cover map answered at their set-up: the any-hit kernel fetches their 32-byte (null) queue entries and nothing else
-                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3] - answered) * b_ray + float(answered) * 32.0),
+                      # ... less the rays the sun cover map answered at their set-up: they have no queue entry, the any-hit kernel never sees them
+                      "incr::wf_shadow_kernel": (prof.shadow_ms, max(prof.launches[3], 1), float(ls[2] + ls[3] - answered) * b_ray),
                       "incr::wf_accumulate_kernel": (prof.accumulate_ms, max(prof.launches[4], 1), float(ls[4]) * 128.0 + rows * W * B_PX * args.steps)}
         # With more than one pipeline in flight the event intervals of the streaming kernels (generate, shade, shadow_gen, accumulate)
         # mostly measure how long their workgroups WAITED for the CUs the other band's persistent traversal kernel holds (2-4 x their
@@ -578,6 +578,7 @@ def main():
         alg_bytes_per_launch = dom_bytes / dom_launches if dom_ms > 0 else 0.0
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         l_rays = int(ls[0] + ls[1] + ls[2] + ls[3]); l_hits = int(ls[4])
+        # an answered ray moves its 16-byte record twice (written by the set-up, read by the summation) and nothing else
         frame_alg_bytes = ((l_rays - answered) * b_ray + answered * 32 + l_hits * B_HIT) / args.steps + rows * W * B_PX
         out = {
             "metric": "Mray/s", "value": round(rays / dt / 1e6, 3), "unit": "Mray/s",
@@ -615,7 +616,7 @@ def main():
             pa, sa, na = alone
             alone_kernel = {"incr::wf_extend_kernel": (pa.extend_ms, max(pa.launches[0], 1), float(sa[0] + sa[1]) * b_ray),
                             "incr::wf_shade_kernel": (pa.shade_ms, max(pa.launches[1], 1), float(sa[4]) * B_HIT),
-                            "incr::wf_shadow_kernel": (pa.shadow_ms, max(pa.launches[3], 1), float(sa[2] + sa[3] - int(pa.shadow_rays_answered)) * b_ray + float(pa.shadow_rays_answered) * 32.0),
+                            "incr::wf_shadow_kernel": (pa.shadow_ms, max(pa.launches[3], 1), float(sa[2] + sa[3] - int(pa.shadow_rays_answered)) * b_ray),
                             "incr::wf_accumulate_kernel": (pa.accumulate_ms, max(pa.launches[4], 1), float(sa[4]) * 128.0 + rows * W * B_PX * na)}
             a_ms, a_launches, a_bytes = alone_kernel[dominant]
             if a_ms > 0:
